@@ -1,0 +1,46 @@
+"""Shared test helpers (config handling, golden loading). Tests may import oracle/."""
+import copy
+import os
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASR_YAML = os.path.join(ROOT, "tailored-avsr_amd", "configs", "asr_branchformer_transformer_ctc_english.yaml")
+
+TOKENS_EN = (["<blank>", "<unk>", "'"] + [str(d) for d in range(10)] + ["<space>"]
+             + [chr(c) for c in range(ord("A"), ord("Z") + 1)] + ["<sos/eos>"])
+
+
+def golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+
+
+def asr_conf(num_blocks=12, dropout=0.0, dec_blocks=6, **enc_over):
+    """Same edits as oracle/gen_golden.py:asr_conf, on the repo's own YAML."""
+    conf = yaml.safe_load(open(ASR_YAML))
+    conf["input_size"] = 80
+    conf["specaug"] = None
+    conf["encoder_conf"]["num_blocks"] = num_blocks
+    conf["decoder_conf"]["num_blocks"] = dec_blocks
+    for k in ("dropout_rate", "positional_dropout_rate", "attention_dropout_rate"):
+        conf["encoder_conf"][k] = dropout
+    for k in ("dropout_rate", "positional_dropout_rate", "self_attention_dropout_rate", "src_attention_dropout_rate"):
+        conf["decoder_conf"][k] = dropout
+    conf["ctc_conf"]["dropout_rate"] = dropout
+    conf["encoder_conf"].update(enc_over)
+    return copy.deepcopy(conf)
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().to(torch.float64).flatten()
+    b = torch.as_tensor(b).detach().to(torch.float64).flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def max_rel(a, b):
+    """max |a-b| / max|b| : the '1e-4 rel' activation criterion of BASELINE.json north_star."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
