@@ -1,0 +1,71 @@
+// Internal helpers shared by the gfx950 kernels of libtavsr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tavsr.h"
+
+namespace tavsr {
+
+void set_error(const char* fmt, ...);
+
+#define TAVSR_REQUIRE(cond, code, ...)   \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::tavsr::set_error(__VA_ARGS__);   \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+// Launch-status check: never synchronises (graph-capture safe).
+#define TAVSR_LAUNCH_CHECK()                                                   \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      ::tavsr::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,        \
+                         hipGetErrorString(e__));                              \
+      return (int)e__;                                                         \
+    }                                                                          \
+  } while (0)
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float act_fwd(int act, float z) {
+  switch (act) {
+    case TAVSR_ACT_RELU: return z > 0.f ? z : 0.f;
+    case TAVSR_ACT_SWISH: return z / (1.f + expf(-z));
+    case TAVSR_ACT_GELU: return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+    default: return z;
+  }
+}
+// derivative of the activation at pre-activation z
+__device__ __forceinline__ float act_bwd(int act, float z) {
+  switch (act) {
+    case TAVSR_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case TAVSR_ACT_SWISH: {
+      float s = 1.f / (1.f + expf(-z));
+      return s * (1.f + z * (1.f - s));
+    }
+    case TAVSR_ACT_GELU: {
+      float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+      float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+      return cdf + z * pdf;
+    }
+    default: return 1.f;
+  }
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace tavsr

@@ -1,0 +1,235 @@
+// LayerNorm forward/backward and column reductions (HBM-bound: one wave per row, 16-B loads,
+// shuffle reductions, deterministic two-stage parameter-gradient sums - no atomics).
+#include "common.h"
+
+namespace tavsr {
+
+constexpr int LN_MAXV = 4;  // float4 chunks per lane: D <= 4*64*4 = 1024
+
+// ---- forward: y = (x-mean)*rstd*gamma + beta ; one wave per row -------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ y, int64_t ldy,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c = (i * 64 + lane) * 4;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D) v[i] = *reinterpret_cast<const float4*>(xr + c);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
+      q += (a * a + b * b) + (cc * cc + dd * dd);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  float* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      float4 b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mu) * rs * g.x + b.x;
+      o.y = (v[i].y - mu) * rs * g.y + b.y;
+      o.z = (v[i].z - mu) * rs * g.z + b.z;
+      o.w = (v[i].w - mu) * rs * g.w + b.w;
+      *reinterpret_cast<float4*>(yr + c) = o;
+    }
+  }
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+// dx = dx_add + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  per-block partial sums of
+// dgamma = sum dy*xhat and dbeta = sum dy go to part[blk][2][D], summed by sum_partials_kernel.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ dx_add, int64_t ldadd,
+                                                            float* __restrict__ dx, int64_t lddx,
+                                                            float* __restrict__ part, int M, int D) {
+  __shared__ float red[4][2][LN_MAXV * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
+    const float* xr = x + (int64_t)row * ldx;
+    const float* dr = dy + (int64_t)row * lddy;
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[LN_MAXV], gd[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      xh[i] = gd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < D) {
+        float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        float4 dv = *reinterpret_cast<const float4*>(dr + c);
+        float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+        ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+        gd[i] = make_float4(dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w);
+        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+        s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    float* or_ = dx + (int64_t)row * lddx;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        float4 o;
+        o.x = rs * (gd[i].x - s1 - xh[i].x * s2);
+        o.y = rs * (gd[i].y - s1 - xh[i].y * s2);
+        o.z = rs * (gd[i].z - s1 - xh[i].z * s2);
+        o.w = rs * (gd[i].w - s1 - xh[i].w * s2);
+        if (dx_add) {
+          float4 a = *reinterpret_cast<const float4*>(dx_add + (int64_t)row * ldadd + c);
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        *reinterpret_cast<float4*>(or_ + c) = o;
+      }
+    }
+  }
+  // cross-wave reduce of the column partials, fixed order (deterministic)
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c = (i * 64 + lane) * 4;
+    *reinterpret_cast<float4*>(&red[w][0][c]) = ag[i];
+    *reinterpret_cast<float4*>(&red[w][1][c]) = ab[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    int which = c / D, col = c % D;
+    float s = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+    part[((int64_t)blockIdx.x * 2 + which) * D + col] = s;
+  }
+}
+
+// out[c] (+)= sum_p part[p*stride + c]
+__global__ void sum_partials_kernel(const float* __restrict__ part, int nparts, int64_t stride, float* __restrict__ out,
+                                    int n, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * stride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---- column sums of a [M,N] matrix (bias gradients, pos_bias_u/v gradients) -------------------
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
+                                                          int rows_per_chunk, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(M, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + ry; r < r1; r += 4) s += x[(int64_t)r * ldx + col];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+
+static inline int ln_blocks(int M) { return min(cdiv(M, 4 * 8), 512); }
+static inline int colsum_chunks(int M) { return min(cdiv(M, 64), 256); }
+
+}  // namespace tavsr
+
+using namespace tavsr;
+
+extern "C" int tavsr_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                   float* y, int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D,
+                                   tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && gamma && beta && y, TAVSR_EINVAL, "layernorm_fwd: null pointer");
+  TAVSR_REQUIRE(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, TAVSR_EUNSUPPORTED,
+                "layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, LN_MAXV * 256);
+  TAVSR_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
+                    ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0),
+                TAVSR_EALIGN, "layernorm_fwd: rows must be 16-byte aligned");
+  if (M <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                     eps, y, ldy, mean, rstd, M, D);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int64_t tavsr_layernorm_bwd_ws(int32_t M, int32_t D) { return (int64_t)ln_blocks(M) * 2 * D; }
+
+extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                   const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd,
+                                   float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                                   float* ws, int32_t M, int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, TAVSR_EINVAL,
+                "layernorm_bwd: null pointer");
+  TAVSR_REQUIRE(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, TAVSR_EUNSUPPORTED, "layernorm_bwd: unsupported D=%d", D);
+  TAVSR_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldadd % 4 == 0 && ((uintptr_t)x % 16 == 0) &&
+                    ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) && ((uintptr_t)dx_add % 16 == 0),
+                TAVSR_EALIGN, "layernorm_bwd: rows must be 16-byte aligned");
+  if (M <= 0) return TAVSR_OK;
+  const int nb = ln_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
+                     ldadd, dx, lddx, ws, M, D);
+  TAVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, ws, nb, (int64_t)2 * D, dgamma, D,
+                     accumulate);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, ws + D, nb, (int64_t)2 * D, dbeta, D,
+                     accumulate);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int64_t tavsr_colsum_ws(int32_t M, int32_t N) { return (int64_t)colsum_chunks(M) * N; }
+
+extern "C" int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+                            float* ws, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && out && ws, TAVSR_EINVAL, "colsum: null pointer");
+  if (N <= 0) return TAVSR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = M > 0 ? colsum_chunks(M) : 1;
+  const int rpc = M > 0 ? cdiv(M, chunks) : 1;
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, s, x, ldx, M, N, rpc, ws);
+  TAVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, chunks, (int64_t)N, out, N,
+                     accumulate);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// Generic "sum nparts slabs of n floats" (used by the host for per-block parameter-gradient partials).
+extern "C" int tavsr_sum_partials(const float* part, int32_t nparts, int64_t stride, float* out, int32_t n,
+                                  int32_t accumulate, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(part && out, TAVSR_EINVAL, "sum_partials: null pointer");
+  if (n <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts, stride,
+                     out, n, accumulate);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}

@@ -1,0 +1,77 @@
+"""ctypes binding of libtavsr_hip.so (C ABI declared in include/tavsr.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+``TavsrError`` is raised.  Device pointers are passed as raw addresses (``tensor.data_ptr()``) and
+every call is enqueued on torch's current HIP stream, so the calls compose with torch's caching
+allocator, stream semantics and HIP-graph capture.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtavsr_hip.so")
+
+ACT = {None: 0, "none": 0, "relu": 1, "swish": 2, "gelu": 3}
+
+
+class TavsrError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32),
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("nb1", C.c_int32), ("nb2", C.c_int32),
+        ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
+        ("sC1", C.c_int64), ("sC2", C.c_int64),
+        ("bias", C.c_void_p),
+        ("act", C.c_int32), ("alpha", C.c_float),
+        ("Z", C.c_void_p),
+        ("R", C.c_void_p), ("ldr", C.c_int64), ("sR1", C.c_int64), ("sR2", C.c_int64),
+        ("DZ", C.c_void_p), ("dact", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; fail loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TavsrError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.tavsr_last_error_string.restype = C.c_char_p
+        _lib.tavsr_version.restype = C.c_int
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().tavsr_last_error_string().decode()
+        raise TavsrError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise TavsrError("tavsr ops run on the MI355X only: got a CPU tensor (no CPU fallback exists)")

@@ -1,0 +1,119 @@
+"""GPU: fp32 MFMA GEMM through the C ABI vs a torch fp32/fp64 reference of the same contraction."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(A, B, a_k, b_k, M, N, K, bias=None, act=None, alpha=1.0, R=None, want_z=False, DZ=None, dact=None,
+          batch=None):
+    from tavsr import _lib as L
+    d = L.GemmDesc()
+    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = M, N, K, int(a_k), int(b_k)
+    nb = 1 if batch is None else batch
+    Cout = torch.empty((nb, M, N), device="cuda")
+    Z = torch.empty_like(Cout) if want_z else None
+    d.A, d.lda = A.data_ptr(), A.stride(-2)
+    d.B, d.ldb = B.data_ptr(), B.stride(-2)
+    d.C, d.ldc = Cout.data_ptr(), N
+    d.nb1, d.nb2 = nb, 1
+    d.sA1 = A.stride(0) if batch else 0
+    d.sB1 = B.stride(0) if batch else 0
+    d.sC1 = M * N
+    d.bias = None if bias is None else bias.data_ptr()
+    d.act, d.alpha = L.ACT[act], alpha
+    d.Z = None if Z is None else Z.data_ptr()
+    if R is not None:
+        d.R, d.ldr, d.sR1 = R.data_ptr(), N, M * N
+    if DZ is not None:
+        d.DZ, d.dact = DZ.data_ptr(), L.ACT[dact]
+    L.check(L.lib().tavsr_gemm(C.byref(d), L.stream()), "tavsr_gemm")
+    return Cout, Z
+
+
+def _ref_act(z, act):
+    if act == "relu":
+        return torch.relu(z)
+    if act == "swish":
+        return z * torch.sigmoid(z)
+    if act == "gelu":
+        return torch.nn.functional.gelu(z)
+    return z
+
+
+@pytest.mark.parametrize("M,N,K", [(3168, 256, 2048), (3168, 2048, 256), (99, 41, 256), (197, 256, 256),
+                                    (64, 64, 32), (1, 1, 1), (130, 70, 41), (3168, 768, 256)])
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
+def test_gemm_layouts(M, N, K, mode):
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda")
+    b = torch.randn(K, N, device="cuda")
+    ref = (a.double() @ b.double())
+    A = a.t().contiguous() if mode == "TN" else a            # [K,M] kmajor
+    B = b if mode in ("NN", "TN") else b.t().contiguous()    # NT: W[N,K]
+    out, _ = _gemm(A, B, mode == "TN", mode != "NT", M, N, K)
+    err = (out[0].double() - ref).abs().max() / ref.abs().max()
+    assert err < 2e-6, (mode, float(err))
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C write (cdna guide 3)."""
+    n = 96
+    A = torch.eye(n, device="cuda")
+    B = torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n)  # B[k][n]
+    out, _ = _gemm(A, B, False, True, n, n, n)
+    assert torch.equal(out[0], B)
+
+
+@pytest.mark.parametrize("act", [None, "relu", "swish", "gelu"])
+def test_gemm_epilogue(act):
+    torch.manual_seed(0)
+    M, N, K = 300, 200, 128
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") / 8
+    bias, R = torch.randn(N, device="cuda"), torch.randn(1, M, N, device="cuda")
+    out, z = _gemm(a, w, False, False, M, N, K, bias=bias, act=act, alpha=0.5, R=R, want_z=True)
+    zr = a.double() @ w.double().t() + bias.double()
+    ref = R[0].double() + 0.5 * _ref_act(zr, act)
+    assert (z[0].double() - zr).abs().max() < 1e-4
+    assert (out[0].double() - ref).abs().max() < 1e-4
+    # backward-style epilogue: acc * act'(z)
+    zs = torch.randn(1, M, N, device="cuda")
+    out2, _ = _gemm(a, w, False, False, M, N, K, DZ=zs, dact=act)
+    zz = zs[0].double().requires_grad_(True)
+    _ref_act(zz, act).sum().backward()
+    ref2 = (a.double() @ w.double().t()) * zz.grad
+    assert (out2[0].double() - ref2).abs().max() < 1e-4
+
+
+def test_gemm_batched_strided():
+    """heads addressed in place inside a [B*T, 3*D] QKV buffer (no transposes)."""
+    from tavsr import _lib as L
+    torch.manual_seed(1)
+    Bn, H, T, dk = 3, 4, 37, 64
+    D = H * dk
+    qkv = torch.randn(Bn, T, 3 * D, device="cuda")
+    out = torch.empty(H, Bn, T, T, device="cuda")
+    d = L.GemmDesc()
+    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = T, T, dk, 0, 0
+    d.A, d.lda = qkv.data_ptr(), 3 * D
+    d.B, d.ldb = qkv.data_ptr() + 4 * D, 3 * D
+    d.C, d.ldc = out.data_ptr(), T
+    d.nb1, d.nb2 = Bn, H
+    d.sA1, d.sA2, d.sB1, d.sB2 = T * 3 * D, dk, T * 3 * D, dk
+    d.sC1, d.sC2 = T * T, Bn * T * T
+    d.alpha = 1.0
+    L.check(L.lib().tavsr_gemm(C.byref(d), L.stream()), "tavsr_gemm")
+    q = qkv[..., :D].reshape(Bn, T, H, dk).permute(2, 0, 1, 3).double()
+    k = qkv[..., D:2 * D].reshape(Bn, T, H, dk).permute(2, 0, 1, 3).double()
+    ref = q @ k.transpose(-1, -2)
+    assert (out.double() - ref).abs().max() / ref.abs().max() < 2e-6
+
+
+def test_gemm_rejects_bad_descriptor():
+    from tavsr import _lib as L
+    d = L.GemmDesc()
+    d.M, d.N, d.K = 4, 4, 4
+    assert L.lib().tavsr_gemm(C.byref(d), L.stream()) == -1
+    assert b"null operand" in L.lib().tavsr_last_error_string()
