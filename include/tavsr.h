@@ -67,6 +67,154 @@ typedef struct tavsr_gemm_desc {
 
 int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm (espnet LayerNorm = torch.nn.LayerNorm(eps=1e-12); the five norms of
+ * encoder_layer.py:102-109, csgu.norm, encoder.py:313 after_norm, decoder norms).  D % 4 == 0,
+ * D <= 1024, rows 16-byte aligned.  mean/rstd [M] are saved for backward (may be NULL in fwd).
+ * bwd: dx = dx_add + LN'(dy) (dx_add may be NULL; lets the caller fold a residual-branch gradient
+ * in), dgamma/dbeta are overwritten or accumulated; ws >= tavsr_layernorm_bwd_ws(M, D) floats.
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                        float* y, int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D,
+                        tavsr_stream_t stream);
+int64_t tavsr_layernorm_bwd_ws(int32_t M, int32_t D);
+int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                        const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd,
+                        float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                        float* ws, int32_t M, int32_t D, tavsr_stream_t stream);
+
+/* Column sums out[n] (+)= scale * sum_m x[m*ldx + n]: bias gradients of every Linear, pos_bias_u/v
+ * gradients.  ws >= tavsr_colsum_ws(M, N) floats.  Deterministic (two-stage, no atomics). */
+int64_t tavsr_colsum_ws(int32_t M, int32_t N);
+int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, float scale, float* out,
+                 int32_t accumulate, float* ws, tavsr_stream_t stream);
+/* out[i] (+)= sum_{p < nparts} part[p*stride + i], i < n */
+int tavsr_sum_partials(const float* part, int32_t nparts, int64_t stride, float* out, int32_t n,
+                       int32_t accumulate, tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention glue (espnet attention.py: RelPositionMultiHeadedAttention.forward / rel_shift /
+ * MultiHeadedAttention.forward_attention; called at encoder_layer.py:208 and by the decoder).
+ * Score tensors are [H, B, T1, T2] fp32; the QK^T, (q+v)P^T, PV products are tavsr_gemm calls.
+ *   add_head_bias: qu = q + pos_bias_u, qv = q + pos_bias_v   (q rows strided by ldq, D = H*d_k)
+ *   softmax_fwd  : attn = softmax_j((ac + rel_shift(bd)) * scale) over keys j < klens[b]
+ *                  (and j <= i when causal), exactly 0 on masked keys; bd may be NULL
+ *                  (plain attention); bd is the UNSHIFTED [H,B,T,2T-1] product, W = 2T-1:
+ *                  rel_shift(bd)[i,j] = bd[i, T-1-i+j]
+ *   softmax_bwd  : ds = attn*(dattn - <attn,dattn>)*scale and (optional) its un-shifted copy
+ *                  ds_skew[i, T-1-i+j] = ds[i,j], 0 elsewhere, that feeds the positional GEMMs
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_add_head_bias(const float* q, int64_t ldq, const float* u, const float* v, float* qu, float* qv,
+                        int64_t M, int32_t D, tavsr_stream_t stream);
+int tavsr_softmax_fwd(const float* ac, const float* bd, const int64_t* klens, float* attn, int32_t H,
+                      int32_t B, int32_t T1, int32_t T2, int32_t W, float scale, int32_t causal,
+                      tavsr_stream_t stream);
+int tavsr_softmax_bwd(const float* attn, const float* dattn, float* ds, float* ds_skew, int32_t H,
+                      int32_t B, int32_t T1, int32_t T2, int32_t W, float scale, tavsr_stream_t stream);
+
+/* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
+int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);
+int tavsr_axpby2d(const float* x, int64_t ldx, const float* y, int64_t ldy, float a, float b, float* out,
+                  int64_t ldo, int64_t M, int32_t N, tavsr_stream_t stream);
+int tavsr_act_bwd(const float* dh, const float* z, float* dz, int64_t n, int32_t act, tavsr_stream_t stream);
+/* out = x * (c * s[0]), s a DEVICE scalar (an upstream loss gradient): keeps backward free of host syncs */
+int tavsr_scale_dev(const float* x, const float* s, float c, float* out, int64_t n, tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * cgMLP spatial gating unit (espnet2 cgmlp.py ConvolutionalSpatialGatingUnit, reached from
+ * encoder_layer.py:220): out = r * (bias + depthwise_conv1d_K(gn)) along time, "same" padding,
+ * per utterance; gn = LayerNorm(gate half) is a tavsr_layernorm_fwd call on the strided half.
+ *   gn, out, conv: [B*T, C];  r: gate-free half, row stride ldr;  w: [C, K] (torch [C,1,K]).
+ * bwd: dr (row stride lddr), dgn, dw, dbias; ws >= tavsr_dwconv_gate_bwd_ws floats.
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_dwconv_gate_fwd(const float* gn, const float* r, int64_t ldr, const float* w, const float* bias,
+                          float* out, float* conv, int32_t B, int32_t T, int32_t C, int32_t K,
+                          tavsr_stream_t stream);
+int64_t tavsr_dwconv_gate_bwd_ws(int32_t B, int32_t T, int32_t C, int32_t K);
+int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv,
+                          const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,
+                          int32_t accumulate, float* ws, int32_t B, int32_t T, int32_t C, int32_t K,
+                          tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * learned_ave branch merge (encoder_layer.py:232-293) and the same pooling used by
+ * AdaptiveAudioVisualFusion (adaptive_audiovisual_fusion.py:137-191).
+ *   params (HOST array of 8 device pointers): pooling_proj{1,2}.weight[D], pooling_proj{1,2}.bias[1],
+ *   weight_proj{1,2}.weight[D], weight_proj{1,2}.bias[1].
+ *   pool_fwd: score [2,B,T], pooled [2,B,D], w [B,2] = (weight_global, weight_local)
+ *   combine : out = w[b,0]*x1 + w[b,1]*x2
+ *   bwd     : dx1, dx2 and the 8 parameter gradients (dparams: HOST array of device pointers,
+ *             order weight{pool1,pool2,w1,w2} then bias{pool1,pool2,w1,w2});
+ *             ws >= tavsr_merge_bwd_ws(B, D) floats.
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int64_t* lens, const float* const* params,
+                         float* score, float* pooled, float* w, int32_t B, int32_t T, int32_t D,
+                         tavsr_stream_t stream);
+int tavsr_merge_combine(const float* x1, const float* x2, const float* w, float* out, int32_t B, int32_t T,
+                        int32_t D, tavsr_stream_t stream);
+int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D);
+int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens,
+                    const float* const* params, const float* score, const float* pooled, const float* w,
+                    float* dx1, float* dx2, float* const* dparams, int32_t accumulate, float* ws, int32_t B,
+                    int32_t T, int32_t D, tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv2dSubsampling (espnet subsampling.py; encoder.py:149-155,364) in channels-last form, and
+ * UtteranceMVN (espnet_model.py:388).
+ *   conv1_fwd : y[B,To,Fo,C] = relu(conv3x3 stride 2 (x[B,T,F], w[C,1,3,3]) + bias)
+ *   conv1_bwd : dw[C,9], db[C] from dz (relu' already applied); ws >= tavsr_conv1_bwd_ws floats
+ *   im2col    : col[(b,to,fo)][(kh*3+kw)*C + c] = y[b,2to+kh,2fo+kw,c]   -> conv2 is a tavsr_gemm
+ *   col2im    : dz = relu'(y) * scatter-free gather of dcol (gradient w.r.t. conv1's output)
+ *   transpose_inner: out[n][c][r] (+)= in[n][r][c]  (weight re-indexing torch order <-> NHWC order)
+ *   utterance_mvn  : per-utterance mean removal over valid frames, padded frames -> 0
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_conv1_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t T,
+                    int32_t F, int32_t C, tavsr_stream_t stream);
+int64_t tavsr_conv1_bwd_ws(int32_t B, int32_t T, int32_t F, int32_t C);
+int tavsr_conv1_bwd(const float* dz, const float* x, float* dw, float* db, int32_t accumulate, float* ws,
+                    int32_t B, int32_t T, int32_t F, int32_t C, tavsr_stream_t stream);
+int tavsr_im2col3x3s2(const float* y, float* col, int32_t B, int32_t Ti, int32_t Fi, int32_t C,
+                      tavsr_stream_t stream);
+int tavsr_col2im3x3s2_relu(const float* dcol, const float* yrelu, float* dz, int32_t B, int32_t Ti,
+                           int32_t Fi, int32_t C, tavsr_stream_t stream);
+int tavsr_transpose_inner(const float* in, float* out, int64_t nb, int32_t R, int32_t Cc, int32_t accumulate,
+                          tavsr_stream_t stream);
+int tavsr_utterance_mvn(const float* x, const int64_t* lens, float* y, int32_t B, int32_t T, int32_t F,
+                        tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CTC (src/ctc/ctc.py).  logits[b][t][v] at b*ld_b + t*ld_t + v.
+ *   ctc_loss  : per-utterance negative log-likelihood of torch.nn.CTCLoss(reduction="none",
+ *               zero_infinity) on log_softmax(logits) (ctc.py:58-69) AND d loss[b] / d logits
+ *               (the caller scales by its upstream gradient).  targets int64 [B, ld_tgt] padded,
+ *               ws >= tavsr_ctc_loss_ws(B, T, Lmax) floats.
+ *   ctc_greedy: ids = argmax_v (ctc.py:180-188, lowest index on ties); hyp/hyp_len (optional) =
+ *               collapse-repeats-then-drop-blank of ids[:hlens[b]] (maskctc_model.py:289-291),
+ *               hyp padded with -1.  Integer outputs: bit-exact contract.
+ * ------------------------------------------------------------------------------------------- */
+int64_t tavsr_ctc_loss_ws(int32_t B, int32_t T, int32_t Lmax);
+int tavsr_ctc_loss(const float* logits, int64_t ld_t, int64_t ld_b, const int64_t* hlens,
+                   const int64_t* targets, int64_t ld_tgt, const int64_t* tlens, int32_t blank,
+                   int32_t zero_infinity, float* loss, float* grad, float* ws, int32_t B, int32_t T,
+                   int32_t V, int32_t Lmax, tavsr_stream_t stream);
+int tavsr_ctc_greedy(const float* logits, int64_t ld_t, int64_t ld_b, const int64_t* hlens, int32_t blank,
+                     int64_t* ids, int64_t* hyp, int64_t* hyp_len, int32_t B, int32_t T, int32_t V,
+                     tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention-decoder loss side (espnet LabelSmoothingLoss + th_accuracy, espnet_model.py:553-569)
+ * and decoder input embedding (Embedding + PositionalEncoding, espnet transformer_decoder.py).
+ *   lsm_loss: row_loss[r] = KL(smoothed one-hot || softmax(logits[r])) (0 for ignored rows),
+ *             grad = d row_loss / d logits, correct[r] in {1, 0, -1 = ignored}.
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_lsm_loss(const float* logits, int64_t ld, const int64_t* target, int32_t ignore, float smoothing,
+                   float* row_loss, float* grad, int32_t* correct, int64_t rows, int32_t V,
+                   tavsr_stream_t stream);
+int tavsr_embed_pe(const int64_t* ids, const float* table, const float* pe, float scale, float* out, int64_t N,
+                   int32_t L, int32_t D, tavsr_stream_t stream);
+int tavsr_embed_bwd(const int64_t* ids, const float* dout, float scale, float* dtable, int64_t N, int32_t V,
+                    int32_t D, int32_t accumulate, tavsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

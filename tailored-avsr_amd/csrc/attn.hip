@@ -5,6 +5,7 @@
 // K = B*T1 GEMM per head.  One wave per score row; rows are re-read from L2 instead of held in
 // registers so any T2 works.
 #include <float.h>
+#include <algorithm>
 
 #include "common.h"
 
@@ -110,6 +111,20 @@ __global__ void axpby_kernel(const float* __restrict__ x, const float* __restric
   }
 }
 
+__global__ void axpby_scalar_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b,
+                                    float* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+// out = x * (c * s[0]) with s a device scalar (upstream loss gradient): no host round trip
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float c,
+                                 float* __restrict__ out, int64_t n) {
+  const float f = c * s[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = x[i] * f;
+}
+
 // strided 2-D variant: out[m*ldo + c] = a*x[m*ldx + c] + b*y[m*ldy + c], c < N (N % 4 == 0)
 __global__ void axpby2d_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy,
                                float a, float b, float* __restrict__ out, int64_t ldo, int64_t total4, int N4) {
@@ -188,9 +203,11 @@ extern "C" int tavsr_softmax_bwd(const float* attn, const float* dattn, float* d
 extern "C" int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n,
                            tavsr_stream_t stream) {
   TAVSR_REQUIRE(x && out, TAVSR_EINVAL, "axpby: null pointer");
-  TAVSR_REQUIRE(al16(x) && al16(y) && al16(out), TAVSR_EALIGN, "axpby: 16-byte alignment required");
   if (n <= 0) return TAVSR_OK;
-  hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, x, y, a, b, out, n);
+  if (al16(x) && al16(y) && al16(out))
+    hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, x, y, a, b, out, n);
+  else
+    hipLaunchKernelGGL(axpby_scalar_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, a, b, out, n);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
@@ -214,6 +231,15 @@ extern "C" int tavsr_act_bwd(const float* dh, const float* z, float* dz, int64_t
   TAVSR_REQUIRE(al16(dh) && al16(z) && al16(dz), TAVSR_EALIGN, "act_bwd: 16-byte alignment required");
   if (n <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, dh, z, dz, n, act);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_scale_dev(const float* x, const float* s, float c, float* out, int64_t n, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && s && out, TAVSR_EINVAL, "scale_dev: null pointer");
+  if (n <= 0) return TAVSR_OK;
+  int blocks = (int)std::min<int64_t>(cdiv(n, 256), 2048);
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, s, c, out, n);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

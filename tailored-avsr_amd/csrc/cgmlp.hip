@@ -1,0 +1,403 @@
+// cgMLP spatial gating unit and branch-merge kernels.
+//   ConvolutionalSpatialGatingUnit (espnet2/asr/layers/cgmlp.py, called at
+//   src/encoder/branchformer/encoder_layer.py:220): x_r * (depthwise_conv_k(LN(x_g)) + bias)
+//   learned_ave merge (encoder_layer.py:232-293): attention pooling + softmax over the two branches.
+// HBM-bound, time-major tiles staged through LDS with the conv halo; parameter gradients go through
+// per-block partial slabs + tavsr_sum_partials (deterministic, no atomics).
+#include <float.h>
+
+#include "common.h"
+
+namespace tavsr {
+
+constexpr int CG_CH = 64;    // channels per block (lanes -> consecutive channels: coalesced, LDS conflict free)
+constexpr int CG_TT = 128;   // time steps per block
+constexpr int CG_KMAX = 63;  // max depthwise kernel size
+
+// out[b,t,c] = r[b,t,c] * (bias[c] + sum_k w[c,k] * gn[b,t+k-pad,c]) ; conv (pre-gate) optionally saved
+__global__ __launch_bounds__(256) void dwconv_gate_fwd_kernel(const float* __restrict__ gn, const float* __restrict__ r,
+                                                              int64_t ldr, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              float* __restrict__ conv, int B, int T, int C, int K) {
+  extern __shared__ float sm[];
+  const int pad = (K - 1) / 2;
+  float* s_x = sm;                             // [(CG_TT + K - 1)][CG_CH]
+  float* s_w = sm + (CG_TT + K - 1) * CG_CH;   // [K][CG_CH]
+  const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * CG_CH, t0 = blockIdx.y * CG_TT, b = blockIdx.z;
+  const int c = c0 + cx;
+  const int rows = CG_TT + K - 1;
+  for (int i = ty; i < rows; i += 4) {
+    int t = t0 + i - pad;
+    float v = 0.f;
+    if (t >= 0 && t < T && c < C) v = gn[((int64_t)b * T + t) * C + c];
+    s_x[i * CG_CH + cx] = v;
+  }
+  for (int k = ty; k < K; k += 4) s_w[k * CG_CH + cx] = c < C ? w[(int64_t)c * K + k] : 0.f;
+  __syncthreads();
+  if (c >= C) return;
+  const float bv = bias[c];
+  for (int tt = ty; tt < CG_TT; tt += 4) {
+    int t = t0 + tt;
+    if (t >= T) break;
+    float acc = bv;
+    for (int k = 0; k < K; ++k) acc += s_w[k * CG_CH + cx] * s_x[(tt + k) * CG_CH + cx];
+    int64_t m = (int64_t)b * T + t;
+    if (conv) conv[m * C + c] = acc;
+    out[m * C + c] = r[m * ldr + c] * acc;
+  }
+}
+
+// du -> dr = du*conv ; dconv = du*r ; dgn[t] = sum_k w[c,k]*dconv[t-k+pad] ;
+// partial dw[c,k] = sum_t dconv[t]*gn[t+k-pad], partial dbias[c] = sum_t dconv[t]  (per block slab)
+__global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(const float* __restrict__ du, const float* __restrict__ gn,
+                                                              const float* __restrict__ r, int64_t ldr,
+                                                              const float* __restrict__ conv,
+                                                              const float* __restrict__ w, float* __restrict__ dr,
+                                                              int64_t lddr, float* __restrict__ dgn,
+                                                              float* __restrict__ part, int B, int T, int C, int K) {
+  extern __shared__ float sm[];
+  const int pad = (K - 1) / 2;
+  const int rows = CG_TT + K - 1;
+  float* s_d = sm;                         // dconv with halo [rows][CG_CH]
+  float* s_g = s_d + rows * CG_CH;         // gn with halo    [rows][CG_CH]
+  float* s_w = s_g + rows * CG_CH;         // [K][CG_CH]
+  float* s_red = s_w + K * CG_CH;          // [4][CG_CH]
+  const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * CG_CH, t0 = blockIdx.y * CG_TT, b = blockIdx.z;
+  const int c = c0 + cx;
+  for (int i = ty; i < rows; i += 4) {
+    int t = t0 + i - pad;
+    float dv = 0.f, gv = 0.f;
+    if (t >= 0 && t < T && c < C) {
+      int64_t m = (int64_t)b * T + t;
+      dv = du[m * C + c] * r[m * ldr + c];
+      gv = gn[m * C + c];
+    }
+    s_d[i * CG_CH + cx] = dv;
+    s_g[i * CG_CH + cx] = gv;
+  }
+  for (int k = ty; k < K; k += 4) s_w[k * CG_CH + cx] = c < C ? w[(int64_t)c * K + k] : 0.f;
+  __syncthreads();
+  // data gradients for the block's own time steps (centre rows pad .. pad+CG_TT)
+  if (c < C) {
+    for (int tt = ty; tt < CG_TT; tt += 4) {
+      int t = t0 + tt;
+      if (t >= T) break;
+      int64_t m = (int64_t)b * T + t;
+      dr[m * lddr + c] = du[m * C + c] * conv[m * C + c];
+      float acc = 0.f;
+      // dgn[t] = sum_k w[k] * dconv[t - k + pad]  -> LDS row (tt + pad) - k + pad
+      for (int k = 0; k < K; ++k) acc += s_w[k * CG_CH + cx] * s_d[(tt + 2 * pad - k) * CG_CH + cx];
+      dgn[m * C + c] = acc;
+    }
+  }
+  // weight-gradient partials over this block's time steps: dw[k] = sum_t dconv[t] * gn[t + k - pad]
+  const int nblk = gridDim.y * gridDim.z;
+  const int blk = blockIdx.z * gridDim.y + blockIdx.y;
+  float* pw = part + (int64_t)blk * C * (K + 1);
+  for (int k = 0; k <= K; ++k) {
+    float acc = 0.f;
+    for (int tt = ty; tt < CG_TT; tt += 4) {
+      float dv = s_d[(tt + pad) * CG_CH + cx];
+      acc += (k < K) ? dv * s_g[(tt + k) * CG_CH + cx] : dv;
+    }
+    s_red[ty * CG_CH + cx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+      float s = (s_red[cx] + s_red[CG_CH + cx]) + (s_red[2 * CG_CH + cx] + s_red[3 * CG_CH + cx]);
+      pw[(int64_t)c * (K + 1) + k] = s;   // [C][K+1]: k == K holds the bias partial
+    }
+    __syncthreads();
+  }
+  (void)nblk;
+}
+
+// split [C][K+1] summed slab into dw[C][K] and dbias[C]
+__global__ void dwconv_split_kernel(const float* __restrict__ sum, float* __restrict__ dw, float* __restrict__ db, int C,
+                                    int K, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * (K + 1)) return;
+  int c = i / (K + 1), k = i % (K + 1);
+  float v = sum[i];
+  if (k < K) dw[c * K + k] = accumulate ? dw[c * K + k] + v : v;
+  else db[c] = accumulate ? db[c] + v : v;
+}
+
+// ------------------------------- learned_ave merge ---------------------------------------------
+// One block per utterance b.  For branch k in {1,2}:
+//   score_k[t] = softmax_t( (x_k[t,:] . wp_k + bp_k) / sqrt(D) ) over t < len, 0 beyond
+//   pooled_k   = sum_t score_k[t] x_k[t,:] ;  weight_k = pooled_k . ww_k + bw_k
+//   (w1, w2) = softmax(weight_1, weight_2)
+struct MergeParams {
+  const float* wp[2]; const float* bp[2]; const float* ww[2]; const float* bw[2];
+};
+
+__global__ __launch_bounds__(256) void merge_pool_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                             const int64_t* __restrict__ lens, MergeParams p,
+                                                             float* __restrict__ score, float* __restrict__ pooled,
+                                                             float* __restrict__ wout, int B, int T, int D) {
+  extern __shared__ float sm[];
+  float* s_sc = sm;        // [T]
+  float* s_red = sm + T;   // [8]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int len = lens ? (int)min((int64_t)T, lens[b]) : T;
+  const float inv_sqrt_d = 1.f / sqrtf((float)D);
+  float weight[2];
+  for (int k = 0; k < 2; ++k) {
+    const float* x = (k == 0 ? x1 : x2) + (int64_t)b * T * D;
+    for (int t = wv; t < T; t += 4) {
+      float acc = 0.f;
+      if (t < len)
+        for (int c = lane; c < D; c += 64) acc += x[(int64_t)t * D + c] * p.wp[k][c];
+      acc = wave_sum(acc);
+      if (lane == 0) s_sc[t] = (acc + p.bp[k][0]) * inv_sqrt_d;
+    }
+    __syncthreads();
+    float mx = -FLT_MAX;
+    for (int t = threadIdx.x; t < len; t += 256) mx = fmaxf(mx, s_sc[t]);
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < len; t += 256) sum += expf(s_sc[t] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[4 + wv] = sum;
+    __syncthreads();
+    sum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    const float inv = len > 0 ? 1.f / sum : 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      float v = t < len ? expf(s_sc[t] - mx) * inv : 0.f;
+      s_sc[t] = v;
+      score[((int64_t)k * B + b) * T + t] = v;
+    }
+    __syncthreads();
+    float wacc = 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) {
+      float acc = 0.f;
+      for (int t = 0; t < len; ++t) acc += s_sc[t] * x[(int64_t)t * D + c];
+      pooled[((int64_t)k * B + b) * D + c] = acc;
+      wacc += acc * p.ww[k][c];
+    }
+    wacc = wave_sum(wacc);
+    __syncthreads();
+    if (lane == 0) s_red[wv] = wacc;
+    __syncthreads();
+    weight[k] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]) + p.bw[k][0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float m = fmaxf(weight[0], weight[1]);
+    float e0 = expf(weight[0] - m), e1 = expf(weight[1] - m);
+    wout[b * 2 + 0] = e0 / (e0 + e1);
+    wout[b * 2 + 1] = e1 / (e0 + e1);
+  }
+}
+
+// out[b,t,:] = w[b,0]*x1[b,t,:] + w[b,1]*x2[b,t,:]
+__global__ void merge_combine_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                     const float* __restrict__ w, float* __restrict__ out, int64_t total4, int TD4) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  int b = (int)(i / TD4);
+  float w1 = w[b * 2], w2 = w[b * 2 + 1];
+  float4 a = reinterpret_cast<const float4*>(x1)[i], c = reinterpret_cast<const float4*>(x2)[i];
+  reinterpret_cast<float4*>(out)[i] = make_float4(w1 * a.x + w2 * c.x, w1 * a.y + w2 * c.y, w1 * a.z + w2 * c.z,
+                                                  w1 * a.w + w2 * c.w);
+}
+
+__device__ __forceinline__ float block_sum256(float v, float* s_red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// Backward of pool + combine for one utterance per block.
+// part[b] = { dwp1[D], dwp2[D], dww1[D], dww2[D], dbp1, dbp2, dbw1, dbw2 }  (4*D + 4 floats)
+__global__ __launch_bounds__(256) void merge_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ x1,
+                                                        const float* __restrict__ x2, const int64_t* __restrict__ lens,
+                                                        MergeParams p, const float* __restrict__ score,
+                                                        const float* __restrict__ pooled, const float* __restrict__ w,
+                                                        float* __restrict__ dx1, float* __restrict__ dx2,
+                                                        float* __restrict__ part, int B, int T, int D) {
+  extern __shared__ float sm[];
+  float* s_ds = sm;            // [T]  d(score) then ds_pre
+  float* s_dp = sm + T;        // [D]  dpooled
+  float* s_red = s_dp + D;     // [4]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int len = lens ? (int)min((int64_t)T, lens[b]) : T;
+  const int64_t base = (int64_t)b * T * D;
+  const float inv_sqrt_d = 1.f / sqrtf((float)D);
+  const float w1 = w[b * 2], w2 = w[b * 2 + 1];
+  // dL/dw_k = <dm, x_k>
+  float a1 = 0.f, a2 = 0.f;
+  for (int64_t i = threadIdx.x; i < (int64_t)T * D; i += 256) {
+    float g = dm[base + i];
+    a1 += g * x1[base + i];
+    a2 += g * x2[base + i];
+  }
+  a1 = block_sum256(a1, s_red);
+  a2 = block_sum256(a2, s_red);
+  const float dotw = w1 * a1 + w2 * a2;
+  const float dweight[2] = {w1 * (a1 - dotw), w2 * (a2 - dotw)};
+  float* pb = part + (int64_t)b * (4 * D + 4);
+  for (int k = 0; k < 2; ++k) {
+    const float* x = (k == 0 ? x1 : x2) + base;
+    float* dx = (k == 0 ? dx1 : dx2) + base;
+    const float* sc = score + ((int64_t)k * B + b) * T;
+    const float* po = pooled + ((int64_t)k * B + b) * D;
+    const float wk = k == 0 ? w1 : w2;
+    for (int c = threadIdx.x; c < D; c += 256) {
+      s_dp[c] = dweight[k] * p.ww[k][c];
+      pb[(2 + k) * D + c] = dweight[k] * po[c];  // dww_k
+    }
+    __syncthreads();
+    // dscore[t] = <dpooled, x[t,:]>
+    for (int t = wv; t < T; t += 4) {
+      float acc = 0.f;
+      if (t < len)
+        for (int c = lane; c < D; c += 64) acc += s_dp[c] * x[(int64_t)t * D + c];
+      acc = wave_sum(acc);
+      if (lane == 0) s_ds[t] = acc;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int t = threadIdx.x; t < len; t += 256) dot += sc[t] * s_ds[t];
+    dot = block_sum256(dot, s_red);
+    float sb = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      float v = t < len ? sc[t] * (s_ds[t] - dot) * inv_sqrt_d : 0.f;
+      s_ds[t] = v;  // ds_pre
+      sb += v;
+    }
+    sb = block_sum256(sb, s_red);  // also orders the s_ds writes before the reads below
+    if (threadIdx.x == 0) {
+      pb[4 * D + k] = sb;               // dbp_k
+      pb[4 * D + 2 + k] = dweight[k];   // dbw_k
+    }
+    // dx_k and dwp_k
+    for (int c = threadIdx.x; c < D; c += 256) {
+      const float wpc = p.wp[k][c], dpc = s_dp[c];
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) {
+        int64_t o = (int64_t)t * D + c;
+        float xv = x[o];
+        float s = t < len ? sc[t] : 0.f;
+        dx[o] = wk * dm[base + o] + s * dpc + s_ds[t] * wpc;
+        acc += s_ds[t] * xv;
+      }
+      pb[k * D + c] = acc;  // dwp_k
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace tavsr
+
+using namespace tavsr;
+
+extern "C" int tavsr_dwconv_gate_fwd(const float* gn, const float* r, int64_t ldr, const float* w, const float* bias,
+                                     float* out, float* conv, int32_t B, int32_t T, int32_t C, int32_t K,
+                                     tavsr_stream_t stream) {
+  TAVSR_REQUIRE(gn && r && w && bias && out, TAVSR_EINVAL, "dwconv_gate_fwd: null pointer");
+  TAVSR_REQUIRE(K >= 1 && K <= CG_KMAX && (K & 1), TAVSR_EUNSUPPORTED, "dwconv_gate_fwd: odd K <= %d required", CG_KMAX);
+  if (B <= 0 || T <= 0 || C <= 0) return TAVSR_OK;
+  size_t lds = ((CG_TT + K - 1) * CG_CH + K * CG_CH) * sizeof(float);
+  hipLaunchKernelGGL(dwconv_gate_fwd_kernel, dim3(cdiv(C, CG_CH), cdiv(T, CG_TT), B), dim3(256), lds,
+                     (hipStream_t)stream, gn, r, ldr, w, bias, out, conv, B, T, C, K);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int64_t tavsr_dwconv_gate_bwd_ws(int32_t B, int32_t T, int32_t C, int32_t K) {
+  return ((int64_t)B * cdiv(T, CG_TT) + 1) * C * (K + 1);
+}
+
+extern "C" int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv,
+                                     const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,
+                                     int32_t accumulate, float* ws, int32_t B, int32_t T, int32_t C, int32_t K,
+                                     tavsr_stream_t stream) {
+  TAVSR_REQUIRE(du && gn && r && conv && w && dr && dgn && dw && dbias && ws, TAVSR_EINVAL,
+                "dwconv_gate_bwd: null pointer");
+  TAVSR_REQUIRE(K >= 1 && K <= CG_KMAX && (K & 1), TAVSR_EUNSUPPORTED, "dwconv_gate_bwd: odd K <= %d required", CG_KMAX);
+  if (B <= 0 || T <= 0 || C <= 0) return TAVSR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int ty = cdiv(T, CG_TT);
+  size_t lds = (2 * (CG_TT + K - 1) * CG_CH + K * CG_CH + 4 * CG_CH) * sizeof(float);
+  hipLaunchKernelGGL(dwconv_gate_bwd_kernel, dim3(cdiv(C, CG_CH), ty, B), dim3(256), lds, s, du, gn, r, ldr, conv, w, dr,
+                     lddr, dgn, ws, B, T, C, K);
+  TAVSR_LAUNCH_CHECK();
+  const int nblk = B * ty, n = C * (K + 1);
+  float* sum = ws + (int64_t)nblk * n;
+  int rc = tavsr_sum_partials(ws, nblk, n, sum, n, 0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dwconv_split_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, sum, dw, dbias, C, K, accumulate);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+static MergeParams mk(const float* const* prm) {
+  MergeParams p;
+  for (int k = 0; k < 2; ++k) {
+    p.wp[k] = prm[k]; p.bp[k] = prm[2 + k]; p.ww[k] = prm[4 + k]; p.bw[k] = prm[6 + k];
+  }
+  return p;
+}
+
+// params = { pooling_proj1.weight, pooling_proj2.weight, pooling_proj1.bias, pooling_proj2.bias,
+//            weight_proj1.weight, weight_proj2.weight, weight_proj1.bias, weight_proj2.bias } (device pointers,
+//            the array itself is HOST memory)
+extern "C" int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int64_t* lens, const float* const* params,
+                                    float* score, float* pooled, float* w, int32_t B, int32_t T, int32_t D,
+                                    tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x1 && x2 && params && score && pooled && w, TAVSR_EINVAL, "merge_pool_fwd: null pointer");
+  for (int i = 0; i < 8; ++i) TAVSR_REQUIRE(params[i], TAVSR_EINVAL, "merge_pool_fwd: null parameter %d", i);
+  if (B <= 0) return TAVSR_OK;
+  size_t lds = (T + 8) * sizeof(float);
+  TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_pool_fwd: T=%d too long", T);
+  hipLaunchKernelGGL(merge_pool_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x1, x2, lens, mk(params),
+                     score, pooled, w, B, T, D);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_merge_combine(const float* x1, const float* x2, const float* w, float* out, int32_t B, int32_t T,
+                                   int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x1 && x2 && w && out, TAVSR_EINVAL, "merge_combine: null pointer");
+  TAVSR_REQUIRE(((int64_t)T * D) % 4 == 0, TAVSR_EALIGN, "merge_combine: T*D must be a multiple of 4");
+  int64_t total4 = (int64_t)B * T * D / 4;
+  if (total4 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(merge_combine_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x1, x2, w, out,
+                     total4, (int)((int64_t)T * D / 4));
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D) { return (int64_t)(B + 1) * (4 * D + 4); }
+
+// dparams = { d pooling_proj1.weight[D], d pooling_proj2.weight[D], d weight_proj1.weight[D], d weight_proj2.weight[D],
+//             d pooling_proj1.bias[1], d pooling_proj2.bias[1], d weight_proj1.bias[1], d weight_proj2.bias[1] }
+extern "C" int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens,
+                               const float* const* params, const float* score, const float* pooled, const float* w,
+                               float* dx1, float* dx2, float* const* dparams, int32_t accumulate, float* ws, int32_t B,
+                               int32_t T, int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dm && x1 && x2 && params && score && pooled && w && dx1 && dx2 && dparams && ws, TAVSR_EINVAL,
+                "merge_bwd: null pointer");
+  if (B <= 0) return TAVSR_OK;
+  size_t lds = (T + D + 4) * sizeof(float);
+  TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_bwd: T=%d too long", T);
+  hipLaunchKernelGGL(merge_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dm, x1, x2, lens, mk(params), score,
+                     pooled, w, dx1, dx2, ws, B, T, D);
+  TAVSR_LAUNCH_CHECK();
+  const int n = 4 * D + 4;
+  float* sum = ws + (int64_t)B * n;
+  int rc = tavsr_sum_partials(ws, B, n, sum, n, 0, stream);
+  if (rc) return rc;
+  // scatter the summed slab to the eight parameter gradients
+  for (int i = 0; i < 4 && !rc; ++i) rc = tavsr_sum_partials(sum + (int64_t)i * D, 1, 0, dparams[i], D, accumulate, stream);
+  for (int i = 0; i < 4 && !rc; ++i) rc = tavsr_sum_partials(sum + 4 * D + i, 1, 0, dparams[4 + i], 1, accumulate, stream);
+  return rc;
+}

@@ -1,0 +1,313 @@
+// CTC head: loss + gradient (torch.nn.CTCLoss(reduction="none", zero_infinity) as called by
+// src/ctc/ctc.py:58-69,143-156) and greedy decode (argmax at ctc.py:180-188 + the collapse at
+// src/models/maskctc_model.py:289-291).  One workgroup per utterance; the alpha lattice lives in a
+// caller-provided workspace, the beta recursion is fused with the gradient.  Log-space fp32.
+#include <float.h>
+#include <math.h>
+
+#include "common.h"
+
+namespace tavsr {
+
+__device__ __forceinline__ float log_add(float a, float b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  float m = fmaxf(a, b);
+  return m + log1pf(expf(-fabsf(a - b)));
+}
+__device__ __forceinline__ float log_add3(float a, float b, float c) {
+  float m = fmaxf(fmaxf(a, b), c);
+  if (m == -INFINITY) return -INFINITY;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// label of lattice state s (2L+1 states): blank at even s, target[(s-1)/2] at odd s
+__device__ __forceinline__ int lat_label(const int64_t* tgt, int s, int blank) { return (s & 1) ? (int)tgt[s >> 1] : blank; }
+
+__global__ __launch_bounds__(256) void ctc_loss_kernel(const float* __restrict__ logits, int64_t ld_t, int64_t ld_b,
+                                                       const int64_t* __restrict__ hlens,
+                                                       const int64_t* __restrict__ targets, int64_t ld_tgt,
+                                                       const int64_t* __restrict__ tlens, int blank, int zero_infinity,
+                                                       float* __restrict__ loss, float* __restrict__ grad,
+                                                       float* __restrict__ ws, int T, int V, int Smax) {
+  extern __shared__ float sm[];
+  float* s_prev = sm;                 // [Smax]
+  float* s_cur = sm + Smax;           // [Smax]
+  float* s_ab = sm + 2 * Smax;        // [Smax]   alpha+beta at the current frame
+  float* s_lz = sm + 3 * Smax;        // [T]      log-partition of every frame
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int Tb = (int)min((int64_t)T, hlens[b]);
+  const int L = (int)tlens[b];
+  const int S = 2 * L + 1;
+  const int64_t* tgt = targets + (int64_t)b * ld_tgt;
+  const float* lg = logits + (int64_t)b * ld_b;
+  float* gr = grad + (int64_t)b * ld_b;
+  float* alpha = ws + (int64_t)b * T * Smax;
+
+  // log-softmax partition per frame
+  for (int t = wv; t < Tb; t += 4) {
+    const float* row = lg + (int64_t)t * ld_t;
+    float mx = -FLT_MAX;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, row[v]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int v = lane; v < V; v += 64) se += expf(row[v] - mx);
+    se = wave_sum(se);
+    if (lane == 0) s_lz[t] = mx + logf(se);
+  }
+  __syncthreads();
+
+  // ---- alpha
+  for (int s = tid; s < S; s += 256) {
+    float a = -INFINITY;
+    if (Tb > 0 && s < 2) a = lg[lat_label(tgt, s, blank)] - s_lz[0];
+    s_prev[s] = a;
+    if (Tb > 0) alpha[s] = a;
+  }
+  __syncthreads();
+  for (int t = 1; t < Tb; ++t) {
+    const float* row = lg + (int64_t)t * ld_t;
+    for (int s = tid; s < S; s += 256) {
+      int lab = lat_label(tgt, s, blank);
+      float a0 = s_prev[s];
+      float a1 = s >= 1 ? s_prev[s - 1] : -INFINITY;
+      float a2 = (s >= 2 && (s & 1) && lab != lat_label(tgt, s - 2, blank)) ? s_prev[s - 2] : -INFINITY;
+      float a = log_add3(a0, a1, a2);
+      if (a != -INFINITY) a += row[lab] - s_lz[t];
+      s_cur[s] = a;
+      alpha[(int64_t)t * Smax + s] = a;
+    }
+    __syncthreads();
+    float* tmp = s_prev; s_prev = s_cur; s_cur = tmp;
+  }
+  float ll = -INFINITY;
+  if (Tb > 0) ll = log_add(s_prev[S - 1], S >= 2 ? s_prev[S - 2] : -INFINITY);
+  const float nll = -ll;
+  const bool inf = !(nll < INFINITY);
+  if (tid == 0) loss[b] = (inf && zero_infinity) ? 0.f : nll;
+  __syncthreads();
+
+  // ---- beta fused with the gradient.  grad[t][v] = softmax[t][v] - exp(lse_{s:lab(s)=v}(alpha+beta) + nll - lp[t][v])
+  for (int s = tid; s < S; s += 256) {
+    float bt = -INFINITY;
+    if (Tb > 0 && s >= S - 2) bt = lg[(int64_t)(Tb - 1) * ld_t + lat_label(tgt, s, blank)] - s_lz[Tb - 1];
+    s_prev[s] = bt;
+  }
+  __syncthreads();
+  for (int t = Tb - 1; t >= 0; --t) {
+    const float* row = lg + (int64_t)t * ld_t;
+    float* grow = gr + (int64_t)t * ld_t;
+    if (t < Tb - 1) {
+      for (int s = tid; s < S; s += 256) {
+        int lab = lat_label(tgt, s, blank);
+        float b0 = s_prev[s];
+        float b1 = s + 1 < S ? s_prev[s + 1] : -INFINITY;
+        float b2 = (s + 2 < S && (s & 1) && lab != lat_label(tgt, s + 2, blank)) ? s_prev[s + 2] : -INFINITY;
+        float bt = log_add3(b0, b1, b2);
+        if (bt != -INFINITY) bt += row[lab] - s_lz[t];
+        s_cur[s] = bt;
+      }
+      __syncthreads();
+      float* tmp = s_prev; s_prev = s_cur; s_cur = tmp;
+    }
+    for (int s = tid; s < S; s += 256) s_ab[s] = alpha[(int64_t)t * Smax + s] + s_prev[s];
+    __syncthreads();
+    for (int v = tid; v < V; v += 256) {
+      float lp = row[v] - s_lz[t];
+      float lse = -INFINITY;
+      if (v == blank) {
+        for (int s = 0; s < S; s += 2) lse = log_add(lse, s_ab[s]);
+      } else {
+        for (int s = 1; s < S; s += 2)
+          if ((int)tgt[s >> 1] == v) lse = log_add(lse, s_ab[s]);
+      }
+      float g = expf(lp);
+      if (lse != -INFINITY) g -= expf(lse + nll - lp);
+      grow[v] = (inf && zero_infinity) ? 0.f : g;
+    }
+    __syncthreads();
+  }
+  // frames beyond the utterance get no gradient
+  for (int64_t i = (int64_t)Tb * ld_t + tid; i < (int64_t)T * ld_t; i += 256) {
+    if ((int)(i % ld_t) < V) gr[i] = 0.f;
+  }
+}
+
+// ids[b,t] = argmax_v logits[b,t,v] (lowest index wins ties, like torch.argmax); hyp[b,:n] = collapse
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logits, int64_t ld_t, int64_t ld_b,
+                                                         const int64_t* __restrict__ hlens, int blank,
+                                                         int64_t* __restrict__ ids, int64_t* __restrict__ hyp,
+                                                         int64_t* __restrict__ hyp_len, int T, int V) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* lg = logits + (int64_t)b * ld_b;
+  for (int t = wv; t < T; t += 4) {
+    const float* row = lg + (int64_t)t * ld_t;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = lane; v < V; v += 64) {
+      float x = row[v];
+      // NaN compares as the maximum in torch.argmax
+      bool better = (x > best) || (x != x && best == best) || (x == best && v < bi);
+      if (bi == 0x7fffffff || better) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ob = __shfl_xor(best, o, 64);
+      int oi = __shfl_xor(bi, o, 64);
+      bool take = (oi != 0x7fffffff) && ((bi == 0x7fffffff) || (ob > best) || (ob != ob && best == best) ||
+                                         (ob == best && oi < bi));
+      if (take) { best = ob; bi = oi; }
+    }
+    if (lane == 0) ids[(int64_t)b * T + t] = bi;
+  }
+  __syncthreads();
+  if (hyp && tid == 0) {
+    const int Tb = hlens ? (int)min((int64_t)T, hlens[b]) : T;
+    int n = 0;
+    int64_t prev = -1;
+    for (int t = 0; t < Tb; ++t) {
+      int64_t c = ids[(int64_t)b * T + t];
+      if (c != prev && c != blank) hyp[(int64_t)b * T + n++] = c;
+      prev = c;
+    }
+    for (int t = n; t < T; ++t) hyp[(int64_t)b * T + t] = -1;
+    hyp_len[b] = n;
+  }
+}
+
+// Label-smoothing KL loss (espnet LabelSmoothingLoss, espnet_model.py:175-180,563) fused with its
+// gradient and the th_accuracy counters.  One wave per (b, l) row.
+__global__ __launch_bounds__(256) void lsm_loss_kernel(const float* __restrict__ logits, int64_t ld,
+                                                       const int64_t* __restrict__ target, int ignore, float smoothing,
+                                                       float* __restrict__ row_loss, float* __restrict__ grad,
+                                                       int32_t* __restrict__ correct, int64_t rows, int V) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* x = logits + r * ld;
+  float* g = grad + r * ld;
+  const int64_t tg = target[r];
+  const bool ign = tg == ignore;
+  float mx = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = lane; v < V; v += 64) {
+    float xv = x[v];
+    if (bi == 0x7fffffff || xv > mx) { mx = xv; bi = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float om = __shfl_xor(mx, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || om > mx || (om == mx && oi < bi))) { mx = om; bi = oi; }
+  }
+  float se = 0.f;
+  for (int v = lane; v < V; v += 64) se += expf(x[v] - mx);
+  se = wave_sum(se);
+  const float lz = mx + logf(se);
+  const float conf = 1.f - smoothing, low = smoothing / (float)(V - 1);
+  float l = 0.f;
+  for (int v = lane; v < V; v += 64) {
+    float lp = x[v] - lz;
+    float td = (v == (int)tg) ? conf : low;
+    if (!ign && td > 0.f) l += td * (logf(td) - lp);
+    g[v] = ign ? 0.f : (expf(lp) - td);
+  }
+  l = wave_sum(l);
+  if (lane == 0) {
+    row_loss[r] = l;
+    if (correct) correct[r] = ign ? -1 : (bi == (int)tg ? 1 : 0);
+  }
+}
+
+// out[n,:] = table[ids[n],:] * scale + pe[n % L, :]      (decoder embed: Embedding + PositionalEncoding)
+__global__ void embed_pe_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                const float* __restrict__ pe, float scale, float* __restrict__ out, int64_t total4,
+                                int D4, int L) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  int64_t n = i / D4;
+  int c4 = (int)(i % D4);
+  float4 e = reinterpret_cast<const float4*>(table)[ids[n] * D4 + c4];
+  float4 p = reinterpret_cast<const float4*>(pe)[(n % L) * D4 + c4];
+  reinterpret_cast<float4*>(out)[i] = make_float4(e.x * scale + p.x, e.y * scale + p.y, e.z * scale + p.z, e.w * scale + p.w);
+}
+
+// dtable[v,:] = scale * sum_{n: ids[n]==v} dout[n,:]   (one block per vocabulary row: deterministic)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                        float scale, float* __restrict__ dtable, int64_t N, int D,
+                                                        int accumulate) {
+  const int v = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float acc = 0.f;
+    for (int64_t n = 0; n < N; ++n)
+      if (ids[n] == v) acc += dout[n * D + c];
+    acc *= scale;
+    dtable[(int64_t)v * D + c] = accumulate ? dtable[(int64_t)v * D + c] + acc : acc;
+  }
+}
+
+}  // namespace tavsr
+
+using namespace tavsr;
+
+extern "C" int64_t tavsr_ctc_loss_ws(int32_t B, int32_t T, int32_t Lmax) { return (int64_t)B * T * (2 * Lmax + 1); }
+
+extern "C" int tavsr_ctc_loss(const float* logits, int64_t ld_t, int64_t ld_b, const int64_t* hlens,
+                              const int64_t* targets, int64_t ld_tgt, const int64_t* tlens, int32_t blank,
+                              int32_t zero_infinity, float* loss, float* grad, float* ws, int32_t B, int32_t T,
+                              int32_t V, int32_t Lmax, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(logits && hlens && targets && tlens && loss && grad && ws, TAVSR_EINVAL, "ctc_loss: null pointer");
+  if (B <= 0) return TAVSR_OK;
+  const int Smax = 2 * Lmax + 1;
+  size_t lds = (3 * (size_t)Smax + T) * sizeof(float);
+  TAVSR_REQUIRE(lds <= 64000, TAVSR_EUNSUPPORTED, "ctc_loss: T=%d / Lmax=%d exceed the LDS lattice budget", T, Lmax);
+  hipLaunchKernelGGL(ctc_loss_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, logits, ld_t, ld_b, hlens, targets,
+                     ld_tgt, tlens, blank, zero_infinity, loss, grad, ws, T, V, Smax);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_ctc_greedy(const float* logits, int64_t ld_t, int64_t ld_b, const int64_t* hlens, int32_t blank,
+                                int64_t* ids, int64_t* hyp, int64_t* hyp_len, int32_t B, int32_t T, int32_t V,
+                                tavsr_stream_t stream) {
+  TAVSR_REQUIRE(logits && ids, TAVSR_EINVAL, "ctc_greedy: null pointer");
+  TAVSR_REQUIRE(!hyp || hyp_len, TAVSR_EINVAL, "ctc_greedy: hyp needs hyp_len");
+  if (B <= 0 || T <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld_t, ld_b, hlens, blank, ids,
+                     hyp, hyp_len, T, V);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_lsm_loss(const float* logits, int64_t ld, const int64_t* target, int32_t ignore, float smoothing,
+                              float* row_loss, float* grad, int32_t* correct, int64_t rows, int32_t V,
+                              tavsr_stream_t stream) {
+  TAVSR_REQUIRE(logits && target && row_loss && grad, TAVSR_EINVAL, "lsm_loss: null pointer");
+  if (rows <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(lsm_loss_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ignore,
+                     smoothing, row_loss, grad, correct, rows, V);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_embed_pe(const int64_t* ids, const float* table, const float* pe, float scale, float* out,
+                              int64_t N, int32_t L, int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(ids && table && pe && out, TAVSR_EINVAL, "embed_pe: null pointer");
+  TAVSR_REQUIRE(D % 4 == 0 && L > 0, TAVSR_EINVAL, "embed_pe: D %% 4 == 0 required");
+  int64_t total4 = N * (D / 4);
+  if (total4 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(embed_pe_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, ids, table, pe, scale,
+                     out, total4, D / 4, L);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_embed_bwd(const int64_t* ids, const float* dout, float scale, float* dtable, int64_t N, int32_t V,
+                               int32_t D, int32_t accumulate, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(ids && dout && dtable, TAVSR_EINVAL, "embed_bwd: null pointer");
+  if (V <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dout, scale, dtable, N, D,
+                     accumulate);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}

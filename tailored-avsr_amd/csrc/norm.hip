@@ -133,11 +133,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // out[c] (+)= sum_p part[p*stride + c]
 __global__ void sum_partials_kernel(const float* __restrict__ part, int nparts, int64_t stride, float* __restrict__ out,
-                                    int n, int accumulate) {
+                                    int n, int accumulate, float scale = 1.f) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   float s = 0.f;
   for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * stride + c];
+  s *= scale;
   out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -199,17 +200,17 @@ extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x
                      ldadd, dx, lddx, ws, M, D);
   TAVSR_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, ws, nb, (int64_t)2 * D, dgamma, D,
-                     accumulate);
+                     accumulate, 1.f);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, ws + D, nb, (int64_t)2 * D, dbeta, D,
-                     accumulate);
+                     accumulate, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
 
 extern "C" int64_t tavsr_colsum_ws(int32_t M, int32_t N) { return (int64_t)colsum_chunks(M) * N; }
 
-extern "C" int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
-                            float* ws, tavsr_stream_t stream) {
+extern "C" int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, float scale, float* out,
+                            int32_t accumulate, float* ws, tavsr_stream_t stream) {
   TAVSR_REQUIRE(x && out && ws, TAVSR_EINVAL, "colsum: null pointer");
   if (N <= 0) return TAVSR_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -218,7 +219,7 @@ extern "C" int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, f
   hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, s, x, ldx, M, N, rpc, ws);
   TAVSR_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, chunks, (int64_t)N, out, N,
-                     accumulate);
+                     accumulate, scale);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
@@ -229,7 +230,7 @@ extern "C" int tavsr_sum_partials(const float* part, int32_t nparts, int64_t str
   TAVSR_REQUIRE(part && out, TAVSR_EINVAL, "sum_partials: null pointer");
   if (n <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts, stride,
-                     out, n, accumulate);
+                     out, n, accumulate, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

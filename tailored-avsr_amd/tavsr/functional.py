@@ -1,0 +1,624 @@
+"""Hand-written forward/backward of the hot-path blocks as ``torch.autograd.Function``s.
+
+Each Function is one node of the autograd graph (a whole Branchformer layer, the whole
+Conv2dSubsampling, a decoder layer, ...) whose forward and backward are sequences of C-ABI calls
+(``tavsr.ops``).  Gradient accumulation at fan-out points, residual adds, activations and their
+derivatives are all fused into those kernels (GEMM epilogues, ``dx_add`` of the LayerNorm
+backward), so no torch arithmetic kernel runs on the hot path.  The Python here only orders calls
+and owns buffers; it is written so that each Function body can move behind a single C entry point
+(`tavsr_bf_layer_fwd/bwd`) without changing callers.
+
+Reference semantics followed are cited per Function.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+EPS_ESPNET = 1e-12  # espnet LayerNorm eps
+
+
+# ------------------------------------------------------------------------------------------------
+# building blocks shared by the Functions (plain python, explicit saved state)
+# ------------------------------------------------------------------------------------------------
+class _FFN:
+    """y = x + scale * W2 act(W1 LN(x) + b1) + b2   (encoder_layer.py:192-194,312-314; decoder FFN)."""
+
+    @staticmethod
+    def fwd(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, eps=EPS_ESPNET):
+        n, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, eps)
+        h, z = ops.linear(n, w1, b1, act=act, save_z=True)
+        y = ops.linear(h, w2, b2, alpha=scale, res=x)
+        return y, (x, mean, rstd, n, z, h)
+
+    @staticmethod
+    def bwd(dy, saved, ln_w, w1, w2, act, scale):
+        """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2)."""
+        x, mean, rstd, n, z, h = saved
+        gw2 = ops.linear_dw(dy, h, alpha=scale)
+        gb2 = ops.colsum(dy, scale=scale)
+        dz = ops.linear_dx(dy, w2, alpha=scale, DZ=z, dact=act)
+        gw1 = ops.linear_dw(dz, n)
+        gb1 = ops.colsum(dz)
+        dn = ops.linear_dx(dz, w1)
+        dx, gln_w, gln_b = ops.layernorm_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
+        return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2)
+
+
+class _SelfAttnCore:
+    """Scores/softmax/context of one attention call on head-strided buffers.
+
+    q rows live in ``qbuf`` (row stride ldq, element offset q_off), k/v likewise; outputs go to
+    ``ctx`` [B*T1, D].  rel-pos (espnet RelPositionMultiHeadedAttention) when ``p`` is given."""
+
+    @staticmethod
+    def fwd(qu, ldq, q_off, kbuf, ldk, k_off, vbuf, ldv, v_off, B, T1, T2, H, dk, klens, causal, qv=None, p=None):
+        D = H * dk
+        dev = qu
+        ac = ops.empty(H, B, T1, T2, like=dev)
+        # ac[h,b] = Qu[b,:,h] K[b,:,h]^T
+        ops.gemm(T1, T2, dk, qu, ldq, kbuf, ldk, ac, T2, a_off=q_off, b_off=k_off, nb1=B, nb2=H,
+                 sA=(T1 * ldq, dk), sB=(T2 * ldk, dk), sC=(T1 * T2, B * T1 * T2))
+        bd = None
+        if p is not None:
+            W = 2 * T1 - 1
+            bd = ops.empty(H, B, T1, W, like=dev)
+            ops.gemm(T1, W, dk, qv, D, p, D, bd, W, nb1=B, nb2=H, sA=(T1 * D, dk), sB=(0, dk),
+                     sC=(T1 * W, B * T1 * W))
+        attn = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal)
+        ctx = ops.empty(B * T1, D, like=dev)
+        # ctx[b,:,h] = attn[h,b] V[b,:,h]
+        ops.gemm(T1, dk, T2, attn, T2, vbuf, ldv, ctx, D, b_off=v_off, b_kmajor=True, nb1=B, nb2=H,
+                 sA=(T1 * T2, B * T1 * T2), sB=(T2 * ldv, dk), sC=(T1 * D, dk))
+        return ctx, attn
+
+    @staticmethod
+    def bwd(dctx, attn, qu, ldq, q_off, kbuf, ldk, k_off, vbuf, ldv, v_off, dq, lddq, dq_off, dk_buf, lddk, dk_off,
+            dv_buf, lddv, dv_off, B, T1, T2, H, dk, qv=None, p=None):
+        """Writes dQ(u) into dq, dK into dk_buf, dV into dv_buf (head-strided); returns (dqv, dp) for rel-pos."""
+        D = H * dk
+        dattn = torch.empty_like(attn)
+        # dattn[h,b] = dctx[b,:,h] V[b,:,h]^T
+        ops.gemm(T1, T2, dk, dctx, D, vbuf, ldv, dattn, T2, b_off=v_off, nb1=B, nb2=H, sA=(T1 * D, dk),
+                 sB=(T2 * ldv, dk), sC=(T1 * T2, B * T1 * T2))
+        # dV[b,:,h] = attn[h,b]^T dctx[b,:,h]
+        ops.gemm(T2, dk, T1, attn, T2, dctx, D, dv_buf, lddv, c_off=dv_off, a_kmajor=True, b_kmajor=True, nb1=B, nb2=H,
+                 sA=(T1 * T2, B * T1 * T2), sB=(T1 * D, dk), sC=(T2 * lddv, dk))
+        ds, sk = ops.softmax_bwd(attn, dattn, 1.0 / math.sqrt(dk), skew=p is not None)
+        # dQu[b,:,h] = ds[h,b] K[b,:,h]
+        ops.gemm(T1, dk, T2, ds, T2, kbuf, ldk, dq, lddq, b_off=k_off, c_off=dq_off, b_kmajor=True, nb1=B, nb2=H,
+                 sA=(T1 * T2, B * T1 * T2), sB=(T2 * ldk, dk), sC=(T1 * lddq, dk))
+        # dK[b,:,h] = ds[h,b]^T Qu[b,:,h]
+        ops.gemm(T2, dk, T1, ds, T2, qu, ldq, dk_buf, lddk, b_off=q_off, c_off=dk_off, a_kmajor=True, b_kmajor=True,
+                 nb1=B, nb2=H, sA=(T1 * T2, B * T1 * T2), sB=(T1 * ldq, dk), sC=(T2 * lddk, dk))
+        if p is None:
+            return None, None
+        W = 2 * T1 - 1
+        dqv = ops.empty(B * T1, D, like=dctx)
+        # dQv[b,:,h] = ds_skew[h,b] P[:,h]
+        ops.gemm(T1, dk, W, sk, W, p, D, dqv, D, b_kmajor=True, nb1=B, nb2=H, sA=(T1 * W, B * T1 * W), sB=(0, dk),
+                 sC=(T1 * D, dk))
+        # dP[:,h] = sum_b ds_skew[h,b]^T Qv[b,:,h]  == one K = B*T1 GEMM per head
+        dp = ops.empty(W, D, like=dctx)
+        ops.gemm(W, dk, B * T1, sk, W, qv, D, dp, D, a_kmajor=True, b_kmajor=True, nb1=H, sA=(B * T1 * W, 0),
+                 sB=(dk, 0), sC=(dk, 0))
+        return dqv, dp
+
+
+# ------------------------------------------------------------------------------------------------
+# Branchformer encoder layer
+# ------------------------------------------------------------------------------------------------
+# parameter order of BranchformerLayerFn (None entries allowed for absent branches)
+BF_PARAM_NAMES = (
+    "norm_ff_macaron.weight", "norm_ff_macaron.bias",
+    "feed_forward_macaron.w_1.weight", "feed_forward_macaron.w_1.bias",
+    "feed_forward_macaron.w_2.weight", "feed_forward_macaron.w_2.bias",
+    "norm_mha.weight", "norm_mha.bias",
+    "attn.linear_q.weight", "attn.linear_q.bias", "attn.linear_k.weight", "attn.linear_k.bias",
+    "attn.linear_v.weight", "attn.linear_v.bias", "attn.linear_out.weight", "attn.linear_out.bias",
+    "attn.linear_pos.weight", "attn.pos_bias_u", "attn.pos_bias_v",
+    "norm_mlp.weight", "norm_mlp.bias",
+    "cgmlp.channel_proj1.0.weight", "cgmlp.channel_proj1.0.bias",
+    "cgmlp.csgu.norm.weight", "cgmlp.csgu.norm.bias", "cgmlp.csgu.conv.weight", "cgmlp.csgu.conv.bias",
+    "cgmlp.channel_proj2.weight", "cgmlp.channel_proj2.bias",
+    "pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias", "pooling_proj2.bias",
+    "weight_proj1.weight", "weight_proj2.weight", "weight_proj1.bias", "weight_proj2.bias",
+    "merge_proj.weight", "merge_proj.bias",
+    "norm_ff.weight", "norm_ff.bias",
+    "feed_forward.w_1.weight", "feed_forward.w_1.bias", "feed_forward.w_2.weight", "feed_forward.w_2.bias",
+    "norm_final.weight", "norm_final.bias",
+)
+_I = {n: i for i, n in enumerate(BF_PARAM_NAMES)}
+
+
+class BranchformerLayerFn(torch.autograd.Function):
+    """``MyBranchformerEncoderLayer.forward`` (src/encoder/branchformer/encoder_layer.py:153-321) with
+    dropout / stochastic depth disabled (rate 0 or eval); ``coeff`` is the stochastic-depth scale."""
+
+    @staticmethod
+    def forward(ctx, x, pos_emb, lens, cfg, *P):
+        B, T, D = x.shape
+        M = B * T
+        H = cfg["heads"]
+        dk = D // H
+        act = cfg["ffn_act"]
+        merge = cfg["merge"]  # learned_ave | fixed_ave | concat | attn_only | mlp_only (+ identity flag)
+        has_attn, has_mlp = cfg["has_attn"], cfg["has_mlp"]
+        coeff = cfg.get("coeff", 1.0)
+        p = lambda n: P[_I[n]]
+        x2d = x.reshape(M, D)
+        sv = {}
+
+        x1, sv["ffm"] = _FFN.fwd(x2d, p("norm_ff_macaron.weight"), p("norm_ff_macaron.bias"),
+                                 p("feed_forward_macaron.w_1.weight"), p("feed_forward_macaron.w_1.bias"),
+                                 p("feed_forward_macaron.w_2.weight"), p("feed_forward_macaron.w_2.bias"), act, 0.5)
+        two = has_attn and has_mlp
+        cat = ops.empty(M, 2 * D, like=x) if merge == "concat" else None
+        xa = xm = None
+        if has_attn:
+            n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mha.weight"), p("norm_mha.bias"), EPS_ESPNET)
+            qkv = ops.empty(M, 3 * D, like=x)
+            ops.linear(n, p("attn.linear_q.weight"), p("attn.linear_q.bias"), out=qkv, out_off=0, ldc=3 * D)
+            ops.linear(n, p("attn.linear_k.weight"), p("attn.linear_k.bias"), out=qkv, out_off=D, ldc=3 * D)
+            ops.linear(n, p("attn.linear_v.weight"), p("attn.linear_v.bias"), out=qkv, out_off=2 * D, ldc=3 * D)
+            pe2d = pos_emb.reshape(-1, D)
+            pp = ops.linear(pe2d, p("attn.linear_pos.weight"))
+            qu, qv = ops.add_head_bias(qkv[:, :D], p("attn.pos_bias_u").reshape(-1), p("attn.pos_bias_v").reshape(-1))
+            cx, attn = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
+                                         qv=qv, p=pp)
+            if merge == "concat":
+                ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), out=cat, out_off=0, ldc=2 * D)
+                xa = cat[:, :D]
+            else:
+                xa = ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"))
+            sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn)
+        if has_mlp:
+            n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mlp.weight"), p("norm_mlp.bias"), EPS_ESPNET)
+            g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu",
+                              save_z=True)
+            Cn = g.shape[1] // 2
+            gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p("cgmlp.csgu.norm.weight"), p("cgmlp.csgu.norm.bias"),
+                                                 EPS_ESPNET)
+            cw = p("cgmlp.csgu.conv.weight")
+            u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p("cgmlp.csgu.conv.bias"), B, T)
+            if merge == "concat":
+                ops.linear(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"), out=cat, out_off=D,
+                           ldc=2 * D)
+                xm = cat[:, D:]
+            else:
+                xm = ops.linear(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"))
+            sv["mlp"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv)
+        wts = None
+        if two and merge == "learned_ave":
+            mp = [p(k) for k in ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias",
+                                 "pooling_proj2.bias", "weight_proj1.weight", "weight_proj2.weight",
+                                 "weight_proj1.bias", "weight_proj2.bias")]
+            score, pooled, wts = ops.merge_pool_fwd(xa, xm, lens, mp, B, T)
+            m = ops.merge_combine(xa, xm, wts, B, T)
+            sv["merge"] = (score, pooled, wts, m)
+        elif two and merge == "fixed_ave":
+            cw_ = cfg["cgmlp_weight"]
+            m = ops.axpby(xa, xm, 1.0 - cw_, cw_)
+            sv["merge"] = (m,)
+        elif two and merge == "concat":
+            m = cat
+            sv["merge"] = (m,)
+        else:
+            m = xa if has_attn else xm
+            sv["merge"] = (m,)
+        if cfg["merge_identity"]:
+            x2 = ops.axpby(x1, m, 1.0, coeff)
+        else:
+            x2 = ops.linear(m, p("merge_proj.weight"), p("merge_proj.bias"), alpha=coeff, res=x1)
+        x3, sv["ff"] = _FFN.fwd(x2, p("norm_ff.weight"), p("norm_ff.bias"), p("feed_forward.w_1.weight"),
+                                p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
+                                act, 0.5)
+        y, fmean, frstd = ops.layernorm_fwd(x3, p("norm_final.weight"), p("norm_final.bias"), EPS_ESPNET)
+        sv["final"] = (x3, fmean, frstd)
+        sv["x1"], sv["xa"], sv["xm"] = x1, xa, xm
+        ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = sv, cfg, P, lens, pos_emb
+        ctx.shape = (B, T, D)
+        cfg["_last_w"] = wts   # (weight_global, weight_local) for the introspection attributes
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sv, cfg, P = ctx.sv, ctx.cfg, ctx.P
+        B, T, D = ctx.shape
+        M = B * T
+        H = cfg["heads"]
+        dk = D // H
+        act, merge = cfg["ffn_act"], cfg["merge"]
+        has_attn, has_mlp = cfg["has_attn"], cfg["has_mlp"]
+        coeff = cfg.get("coeff", 1.0)
+        two = has_attn and has_mlp
+        p = lambda n: P[_I[n]]
+        G: List[Optional[torch.Tensor]] = [None] * len(BF_PARAM_NAMES)
+
+        def put(name, g, like=None):
+            G[_I[name]] = g if like is None else g.view_as(like)
+
+        dy2 = dy.contiguous().view(M, D)
+        x3, fmean, frstd = sv["final"]
+        dx3, g1, g2 = ops.layernorm_bwd(dy2, x3, fmean, frstd, p("norm_final.weight"))
+        put("norm_final.weight", g1); put("norm_final.bias", g2)
+        dx2, gs = _FFN.bwd(dx3, sv["ff"], p("norm_ff.weight"), p("feed_forward.w_1.weight"),
+                           p("feed_forward.w_2.weight"), act, 0.5)
+        for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
+                          "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
+            put(n_, g)
+        # merge projection: x2 = x1 + coeff * (m Wm^T + bm)
+        m = sv["merge"][-1]
+        if cfg["merge_identity"]:
+            dm = ops.axpby(dx2, None, coeff, 0.0) if coeff != 1.0 else dx2
+        else:
+            put("merge_proj.weight", ops.linear_dw(dx2, m, alpha=coeff))
+            put("merge_proj.bias", ops.colsum(dx2, scale=coeff))
+            dm = ops.linear_dx(dx2, p("merge_proj.weight"), alpha=coeff)
+        xa, xm = sv["xa"], sv["xm"]
+        if two and merge == "learned_ave":
+            score, pooled, wts, _ = sv["merge"]
+            mp = [p(k) for k in ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias",
+                                 "pooling_proj2.bias", "weight_proj1.weight", "weight_proj2.weight",
+                                 "weight_proj1.bias", "weight_proj2.bias")]
+            dxa, dxm, mg = ops.merge_bwd(dm, xa, xm, ctx.lens, mp, score, pooled, wts, B, T)
+            for k, g in zip(("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias", "pooling_proj2.bias",
+                             "weight_proj1.weight", "weight_proj2.weight", "weight_proj1.bias", "weight_proj2.bias"), mg):
+                put(k, g, like=p(k))
+        elif two and merge == "fixed_ave":
+            cw_ = cfg["cgmlp_weight"]
+            dxa = ops.axpby(dm, None, 1.0 - cw_, 0.0)
+            dxm = ops.axpby(dm, None, cw_, 0.0)
+        elif two and merge == "concat":
+            dxa, dxm = dm[:, :D], dm[:, D:]
+        else:
+            dxa = dm if has_attn else None
+            dxm = dm if has_mlp else None
+
+        x1 = sv["x1"]
+        dx1 = dx2  # residual path; branch gradients are folded in through dx_add
+        if has_mlp:
+            mean, rstd, n, g, z, gn, gmean, grstd, u, conv = sv["mlp"]
+            Cn = g.shape[1] // 2
+            put("cgmlp.channel_proj2.weight", ops.linear_dw(dxm, u))
+            put("cgmlp.channel_proj2.bias", ops.colsum(dxm))
+            du = ops.linear_dx(dxm, p("cgmlp.channel_proj2.weight"))
+            dg = torch.empty_like(g)
+            cw = p("cgmlp.csgu.conv.weight")
+            dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
+            put("cgmlp.csgu.conv.weight", gcw, like=cw); put("cgmlp.csgu.conv.bias", gcb)
+            _, g1, g2 = ops.layernorm_bwd(dgn, g[:, Cn:], gmean, grstd, p("cgmlp.csgu.norm.weight"), dx=dg[:, Cn:])
+            put("cgmlp.csgu.norm.weight", g1); put("cgmlp.csgu.norm.bias", g2)
+            ops.act_bwd_(dg, z, "gelu")
+            put("cgmlp.channel_proj1.0.weight", ops.linear_dw(dg, n))
+            put("cgmlp.channel_proj1.0.bias", ops.colsum(dg))
+            dn = ops.linear_dx(dg, p("cgmlp.channel_proj1.0.weight"))
+            dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1)
+            put("norm_mlp.weight", g1); put("norm_mlp.bias", g2)
+        if has_attn:
+            mean, rstd, n, qkv, pp, qu, qv, cx, attn = sv["attn"]
+            put("attn.linear_out.weight", ops.linear_dw(dxa, cx))
+            put("attn.linear_out.bias", ops.colsum(dxa))
+            dcx = ops.linear_dx(dxa, p("attn.linear_out.weight"))
+            dqkv = torch.empty_like(qkv)
+            dqu = ops.empty(M, D, like=dy2)
+            dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
+                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp)
+            put("attn.pos_bias_u", ops.colsum(dqu), like=p("attn.pos_bias_u"))
+            put("attn.pos_bias_v", ops.colsum(dqv), like=p("attn.pos_bias_v"))
+            ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
+            pe2d = ctx.pos_emb.reshape(-1, D)
+            put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))
+            gw = ops.linear_dw(dqkv, n)  # [3D, D]
+            gb = ops.colsum(dqkv)
+            put("attn.linear_q.weight", gw[:D]); put("attn.linear_k.weight", gw[D:2 * D]); put("attn.linear_v.weight", gw[2 * D:])
+            put("attn.linear_q.bias", gb[:D]); put("attn.linear_k.bias", gb[D:2 * D]); put("attn.linear_v.bias", gb[2 * D:])
+            dn = ops.linear_dx(dqkv[:, :D], p("attn.linear_q.weight"))
+            ops.linear_dx(dqkv[:, D:2 * D], p("attn.linear_k.weight"), res=dn, out=dn)
+            ops.linear_dx(dqkv[:, 2 * D:], p("attn.linear_v.weight"), res=dn, out=dn)
+            dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mha.weight"), dx_add=dx1)
+            put("norm_mha.weight", g1); put("norm_mha.bias", g2)
+        dx, gs = _FFN.bwd(dx1, sv["ffm"], p("norm_ff_macaron.weight"), p("feed_forward_macaron.w_1.weight"),
+                          p("feed_forward_macaron.w_2.weight"), act, 0.5)
+        for n_, g in zip(("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight",
+                          "feed_forward_macaron.w_1.bias", "feed_forward_macaron.w_2.weight",
+                          "feed_forward_macaron.w_2.bias"), gs):
+            put(n_, g)
+        for i, prm in enumerate(P):
+            if prm is None:
+                G[i] = None
+        ctx.sv = None
+        return (dx.view(B, T, D), None, None, None, *G)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm / Linear as stand-alone nodes (after_norm, ctc_lo, decoder output layer)
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2, w, b, eps)
+        ctx.save_for_backward(x2, mean, rstd, w)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, w = ctx.saved_tensors
+        dx, gw, gb = ops.layernorm_bwd(dy.contiguous().view(x2.shape), x2, mean, rstd, w)
+        return dx.view(dy.shape), gw, gb, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = alpha * (x W^T + b)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, alpha):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y = ops.linear(x2, w, b, alpha=alpha)
+        ctx.save_for_backward(x2, w)
+        ctx.alpha, ctx.has_b = alpha, b is not None
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.contiguous().view(x2.shape[0], w.shape[0])
+        dx = ops.linear_dx(dy2, w, alpha=ctx.alpha) if ctx.needs_input_grad[0] else None
+        gw = ops.linear_dw(dy2, x2, alpha=ctx.alpha)
+        gb = ops.colsum(dy2, scale=ctx.alpha) if ctx.has_b else None
+        return (None if dx is None else dx.view(*dy.shape[:-1], w.shape[1])), gw, gb, None
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv2dSubsampling (espnet subsampling.py; encoder.py:149-155,364): conv-relu-conv-relu-linear, x sqrt(d)
+# ------------------------------------------------------------------------------------------------
+class Conv2dSubsamplingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, wo, bo, xscale):
+        B, T, F = x.shape
+        Cn = w1.shape[0]
+        y1 = ops.conv1_fwd(x.contiguous(), w1.reshape(Cn, 9), b1)              # [B,T1,F1,C] NHWC, relu
+        col, T2, F2 = ops.im2col3x3s2(y1)                                      # [B*T2*F2, 9C]
+        # torch (co, ci, kh, kw) -> (co, kh, kw, ci) to match the channels-last im2col
+        w2r = ops.transpose_inner(w2, Cn, Cn, 9).view(Cn, 9 * Cn)
+        y2 = ops.linear(col, w2r, b2, act="relu")                              # [B*T2*F2, C] == (b,t,f,c)
+        # out Linear consumes (c*F2 + f); re-index its weight to (f*C + c) instead of transposing activations
+        wor = ops.transpose_inner(wo, wo.shape[0], Cn, F2).view(wo.shape[0], F2 * Cn)
+        out = ops.linear(y2.view(B * T2, F2 * Cn), wor, bo, alpha=xscale)
+        ctx.save_for_backward(x, y1, col, y2, w2r, wor)
+        ctx.dims = (B, T, F, Cn, T2, F2, xscale, w1.shape, w2.shape, wo.shape)
+        return out.view(B, T2, -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y1, col, y2, w2r, wor = ctx.saved_tensors
+        B, T, F, Cn, T2, F2, xscale, w1s, w2s, wos = ctx.dims
+        do = dout.contiguous().view(B * T2, -1)
+        y2f = y2.view(B * T2, F2 * Cn)
+        gwor = ops.linear_dw(do, y2f, alpha=xscale)                             # [odim, F2*C]
+        gbo = ops.colsum(do, scale=xscale)
+        gwo = ops.transpose_inner(gwor, wos[0], F2, Cn).view(wos)
+        # dz2 = (do @ wor) * xscale * relu'(y2)
+        dz2 = ops.linear_dx(do, wor, alpha=xscale, DZ=y2f, dact="relu").view(B * T2 * F2, Cn)
+        gw2r = ops.linear_dw(dz2, col)                                          # [C, 9C]
+        gb2 = ops.colsum(dz2)
+        gw2 = ops.transpose_inner(gw2r, Cn, 9, Cn).view(w2s)
+        dcol = ops.linear_dx(dz2, w2r)                                          # [B*T2*F2, 9C]
+        dz1 = ops.col2im3x3s2_relu(dcol, y1)
+        gw1, gb1 = ops.conv1_bwd(dz1, x.contiguous(), Cn)
+        return None, gw1.view(w1s), gb1, gw2, gb2, gwo, gbo, None
+
+
+# ------------------------------------------------------------------------------------------------
+# CTC loss (src/ctc/ctc.py:133-158): Linear -> log_softmax -> CTCLoss(none, zero_infinity) -> sum/B
+# ------------------------------------------------------------------------------------------------
+class CTCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hs, w, b, hlens, ys, ylens, reduce, zero_infinity):
+        B, T, D = hs.shape
+        x2 = hs.reshape(B * T, D)
+        logits = ops.linear(x2, w, b).view(B, T, -1)
+        nll, g = ops.ctc_loss(logits, hlens, ys, ylens, 0, zero_infinity)
+        ctx.save_for_backward(x2, w, g)
+        ctx.reduce, ctx.B = reduce, B
+        if reduce:
+            return ops.colsum(nll.view(B, 1), scale=1.0 / B).view(())   # loss.sum() / B  (ctc.py:64-66)
+        return ops.axpby(nll, None, 1.0 / B, 0.0)
+
+    @staticmethod
+    def backward(ctx, dl):
+        x2, w, g = ctx.saved_tensors
+        B = ctx.B
+        V = w.shape[0]
+        g2 = g.view(-1, V)
+        if not ctx.reduce:
+            raise NotImplementedError("reduce=False backward is not on the shipped path")
+        gs = ops.scale_dev(g2, dl.contiguous(), 1.0 / B)   # dlogits = g * dl / B, dl stays on the device
+        dx = ops.linear_dx(gs, w)
+        gw = ops.linear_dw(gs, x2)
+        gb = ops.colsum(gs)
+        return dx.view(B, -1, x2.shape[1]), gw, gb, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# Transformer decoder, teacher forced (espnet2 TransformerDecoder.forward + DecoderLayer.forward,
+# called at src/models/espnet_model.py:557-560).  The whole stack is ONE autograd node so the six
+# per-layer gradients w.r.t. the encoder memory are accumulated in GEMM epilogues.
+# ------------------------------------------------------------------------------------------------
+DEC_LAYER_PARAM_NAMES = (
+    "norm1.weight", "norm1.bias",
+    "self_attn.linear_q.weight", "self_attn.linear_q.bias", "self_attn.linear_k.weight", "self_attn.linear_k.bias",
+    "self_attn.linear_v.weight", "self_attn.linear_v.bias", "self_attn.linear_out.weight", "self_attn.linear_out.bias",
+    "norm2.weight", "norm2.bias",
+    "src_attn.linear_q.weight", "src_attn.linear_q.bias", "src_attn.linear_k.weight", "src_attn.linear_k.bias",
+    "src_attn.linear_v.weight", "src_attn.linear_v.bias", "src_attn.linear_out.weight", "src_attn.linear_out.bias",
+    "norm3.weight", "norm3.bias",
+    "feed_forward.w_1.weight", "feed_forward.w_1.bias", "feed_forward.w_2.weight", "feed_forward.w_2.bias",
+)
+_NL = len(DEC_LAYER_PARAM_NAMES)
+_DI = {n: i for i, n in enumerate(DEC_LAYER_PARAM_NAMES)}
+
+
+class TransformerDecoderFn(torch.autograd.Function):
+    """P = [embed.0.weight, (26 per layer) x num_blocks, after_norm.weight, after_norm.bias,
+    output_layer.weight, output_layer.bias];  returns logits [B, L, V]."""
+
+    @staticmethod
+    def forward(ctx, memory, hlens, ys_in, ys_lens, pe, cfg, *P):
+        B, T, D = memory.shape
+        L = ys_in.shape[1]
+        H = cfg["heads"]
+        dk = D // H
+        nb = cfg["num_blocks"]
+        M = B * L
+        mem2 = memory.reshape(B * T, D)
+        emb_w = P[0]
+        x = ops.embed_pe(ys_in.contiguous(), emb_w, pe, math.sqrt(D)).view(M, D)
+        saved = []
+        for li in range(nb):
+            p = lambda n, li=li: P[1 + li * _NL + _DI[n]]
+            s = {}
+            # --- masked self attention
+            n1, m1, r1 = ops.layernorm_fwd(x, p("norm1.weight"), p("norm1.bias"), EPS_ESPNET)
+            qkv = ops.empty(M, 3 * D, like=x)
+            ops.linear(n1, p("self_attn.linear_q.weight"), p("self_attn.linear_q.bias"), out=qkv, out_off=0, ldc=3 * D)
+            ops.linear(n1, p("self_attn.linear_k.weight"), p("self_attn.linear_k.bias"), out=qkv, out_off=D, ldc=3 * D)
+            ops.linear(n1, p("self_attn.linear_v.weight"), p("self_attn.linear_v.bias"), out=qkv, out_off=2 * D, ldc=3 * D)
+            cx, attn = _SelfAttnCore.fwd(qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, L, L, H, dk, ys_lens, True)
+            x1 = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"), res=x)
+            s["self"] = (x, m1, r1, n1, qkv, cx, attn)
+            # --- source attention over the encoder memory
+            n2, m2, r2 = ops.layernorm_fwd(x1, p("norm2.weight"), p("norm2.bias"), EPS_ESPNET)
+            q2 = ops.linear(n2, p("src_attn.linear_q.weight"), p("src_attn.linear_q.bias"))
+            kv = ops.empty(B * T, 2 * D, like=x)
+            ops.linear(mem2, p("src_attn.linear_k.weight"), p("src_attn.linear_k.bias"), out=kv, out_off=0, ldc=2 * D)
+            ops.linear(mem2, p("src_attn.linear_v.weight"), p("src_attn.linear_v.bias"), out=kv, out_off=D, ldc=2 * D)
+            cx2, attn2 = _SelfAttnCore.fwd(q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, B, L, T, H, dk, hlens, False)
+            x2 = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"), res=x1)
+            s["src"] = (x1, m2, r2, n2, q2, kv, cx2, attn2)
+            # --- position-wise FFN (ReLU, scale 1)
+            x, s["ff"] = _FFN.fwd(x2, p("norm3.weight"), p("norm3.bias"), p("feed_forward.w_1.weight"),
+                                  p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
+                                  "relu", 1.0)
+            saved.append(s)
+        an_w, an_b, out_w, out_b = P[1 + nb * _NL: 1 + nb * _NL + 4]
+        xn, mf, rf = ops.layernorm_fwd(x, an_w, an_b, EPS_ESPNET)
+        logits = ops.linear(xn, out_w, out_b)
+        ctx.saved, ctx.final = saved, (x, mf, rf, xn)
+        ctx.P, ctx.cfg, ctx.dims = P, cfg, (B, T, L, D, H, dk, nb)
+        ctx.mem2, ctx.ys_in = mem2, ys_in
+        return logits.view(B, L, -1)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        P = ctx.P
+        B, T, L, D, H, dk, nb = ctx.dims
+        M = B * L
+        G: List[Optional[torch.Tensor]] = [None] * len(P)
+        an_i = 1 + nb * _NL
+        an_w, an_b, out_w, out_b = P[an_i: an_i + 4]
+        x, mf, rf, xn = ctx.final
+        dl = dlogits.contiguous().view(M, -1)
+        G[an_i + 2] = ops.linear_dw(dl, xn)
+        G[an_i + 3] = ops.colsum(dl)
+        dxn = ops.linear_dx(dl, out_w)
+        dx, G[an_i], G[an_i + 1] = ops.layernorm_bwd(dxn, x, mf, rf, an_w)
+        dmem = None
+        mem2 = ctx.mem2
+        for li in reversed(range(nb)):
+            base = 1 + li * _NL
+            p = lambda n, base=base: P[base + _DI[n]]
+
+            def put(n, g, base=base):
+                G[base + _DI[n]] = g
+
+            s = ctx.saved[li]
+            dx2, gs = _FFN.bwd(dx, s["ff"], p("norm3.weight"), p("feed_forward.w_1.weight"), p("feed_forward.w_2.weight"),
+                               "relu", 1.0)
+            for n_, g in zip(("norm3.weight", "norm3.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
+                              "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
+                put(n_, g)
+            # --- source attention
+            x1, m2, r2, n2, q2, kv, cx2, attn2 = s["src"]
+            put("src_attn.linear_out.weight", ops.linear_dw(dx2, cx2))
+            put("src_attn.linear_out.bias", ops.colsum(dx2))
+            dcx2 = ops.linear_dx(dx2, p("src_attn.linear_out.weight"))
+            dq2 = ops.empty(M, D, like=dl)
+            dkv = torch.empty_like(kv)
+            _SelfAttnCore.bwd(dcx2, attn2, q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, dq2, D, 0, dkv, 2 * D, 0, dkv, 2 * D, D,
+                              B, L, T, H, dk)
+            put("src_attn.linear_q.weight", ops.linear_dw(dq2, n2)); put("src_attn.linear_q.bias", ops.colsum(dq2))
+            gkv_w = ops.linear_dw(dkv, mem2)   # [2D, D]
+            gkv_b = ops.colsum(dkv)
+            put("src_attn.linear_k.weight", gkv_w[:D]); put("src_attn.linear_v.weight", gkv_w[D:])
+            put("src_attn.linear_k.bias", gkv_b[:D]); put("src_attn.linear_v.bias", gkv_b[D:])
+            if dmem is None:
+                dmem = ops.linear_dx(dkv[:, :D], p("src_attn.linear_k.weight"))
+            else:
+                ops.linear_dx(dkv[:, :D], p("src_attn.linear_k.weight"), res=dmem, out=dmem)
+            ops.linear_dx(dkv[:, D:], p("src_attn.linear_v.weight"), res=dmem, out=dmem)
+            dn2 = ops.linear_dx(dq2, p("src_attn.linear_q.weight"))
+            dx1, g1, g2 = ops.layernorm_bwd(dn2, x1, m2, r2, p("norm2.weight"), dx_add=dx2)
+            put("norm2.weight", g1); put("norm2.bias", g2)
+            # --- self attention
+            x0, m1, r1, n1, qkv, cx, attn = s["self"]
+            put("self_attn.linear_out.weight", ops.linear_dw(dx1, cx))
+            put("self_attn.linear_out.bias", ops.colsum(dx1))
+            dcx = ops.linear_dx(dx1, p("self_attn.linear_out.weight"))
+            dqkv = torch.empty_like(qkv)
+            _SelfAttnCore.bwd(dcx, attn, qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqkv, 3 * D, 0, dqkv, 3 * D, D,
+                              dqkv, 3 * D, 2 * D, B, L, L, H, dk)
+            gw = ops.linear_dw(dqkv, n1)
+            gb = ops.colsum(dqkv)
+            put("self_attn.linear_q.weight", gw[:D]); put("self_attn.linear_k.weight", gw[D:2 * D]); put("self_attn.linear_v.weight", gw[2 * D:])
+            put("self_attn.linear_q.bias", gb[:D]); put("self_attn.linear_k.bias", gb[D:2 * D]); put("self_attn.linear_v.bias", gb[2 * D:])
+            dn1 = ops.linear_dx(dqkv[:, :D], p("self_attn.linear_q.weight"))
+            ops.linear_dx(dqkv[:, D:2 * D], p("self_attn.linear_k.weight"), res=dn1, out=dn1)
+            ops.linear_dx(dqkv[:, 2 * D:], p("self_attn.linear_v.weight"), res=dn1, out=dn1)
+            dx, g1, g2 = ops.layernorm_bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1)
+            put("norm1.weight", g1); put("norm1.bias", g2)
+        G[0] = ops.embed_bwd(ctx.ys_in.contiguous(), dx, math.sqrt(D), P[0].shape[0])
+        ctx.saved = None
+        return (dmem.view(B, T, D), None, None, None, None, None, *G)
+
+
+class LabelSmoothingLossFn(torch.autograd.Function):
+    """espnet LabelSmoothingLoss (KL, sum / batch) on decoder logits; also yields the th_accuracy counters."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore, smoothing, normalize_length):
+        B, L, V = logits.shape
+        row, g, correct = ops.lsm_loss(logits.reshape(B * L, V), target.reshape(-1).contiguous(), ignore, smoothing)
+        if normalize_length:
+            raise NotImplementedError("length_normalized_loss=true is not used by the shipped configs")
+        ctx.save_for_backward(g)
+        ctx.B = B
+        ctx.mark_non_differentiable(correct)
+        return ops.colsum(row.view(-1, 1), scale=1.0 / B).view(()), correct
+
+    @staticmethod
+    def backward(ctx, dl, _dc):
+        (g,) = ctx.saved_tensors
+        return ops.scale_dev(g, dl.contiguous(), 1.0 / ctx.B).view(ctx.B, -1, g.shape[-1]), None, None, None, None
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """loss = a*l1 + b*l2 on 0-dim device tensors (espnet_model.py:330)."""
+
+    @staticmethod
+    def forward(ctx, l1, l2, a, b):
+        ctx.ab = (a, b)
+        return ops.axpby(l1.reshape(1).contiguous(), l2.reshape(1).contiguous(), a, b).view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        a, b = ctx.ab
+        d = dl.reshape(1).contiguous()
+        return ops.axpby(d, None, a, 0.0).view(()), ops.axpby(d, None, b, 0.0).view(()), None, None

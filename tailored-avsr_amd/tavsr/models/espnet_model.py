@@ -1,0 +1,198 @@
+"""``ESPnetASRModel`` - drop-in for src/models/espnet_model.py:38-593 (hybrid CTC/attention branch).
+
+``forward(speech, speech_lengths, text, text_lengths) -> (loss, stats, weight)`` with the reference's
+stats keys; ``encode`` as used by inference.  Host code here is orchestration only (tiny integer
+tensor manipulation such as add_sos_eos); every floating-point op runs in libtavsr_hip.so.
+"""
+from __future__ import annotations
+
+from itertools import groupby
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+
+from .. import functional as F_
+from .. import ops
+from ..ctc.ctc import CTC
+
+
+def add_sos_eos(ys_pad, ys_lens, sos, eos, ignore_id):
+    """espnet add_sos_eos on padded int64 batches without a per-utterance Python loop."""
+    B, L = ys_pad.shape
+    idx = torch.arange(L + 1, device=ys_pad.device)[None, :]
+    lens = ys_lens[:, None]
+    body = torch.nn.functional.pad(ys_pad, (1, 0), value=sos)
+    ys_in = torch.where(idx <= lens, body, torch.full_like(body, eos))
+    ys_in[:, 0] = sos
+    tail = torch.nn.functional.pad(ys_pad, (0, 1), value=ignore_id)
+    ys_out = torch.where(idx < lens, tail, torch.full_like(tail, ignore_id))
+    ys_out = torch.where(idx == lens, torch.full_like(tail, eos), ys_out)
+    return ys_in, ys_out
+
+
+def _levenshtein(a, b) -> int:
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, cb in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
+        prev = cur
+    return prev[-1]
+
+
+class ErrorCalculator:
+    """CER/WER of espnet.nets.e2e_asr_common.ErrorCalculator on id sequences (host side, eval only)."""
+
+    def __init__(self, char_list, sym_space, sym_blank, report_cer=False, report_wer=False):
+        self.char_list, self.space, self.blank = char_list, sym_space, sym_blank
+        self.report_cer, self.report_wer = report_cer, report_wer
+        self.idx_blank = char_list.index(sym_blank)
+        self.idx_space = char_list.index(sym_space) if sym_space in char_list else None
+
+    def cer_ctc(self, ys_hat, ys_pad):
+        errs, n = 0, 0
+        for y, ref in zip(ys_hat.tolist(), ys_pad.tolist()):
+            keep = lambda i: i != -1 and i != self.idx_blank and i != self.idx_space
+            hyp = [self.char_list[i] for i, _ in groupby(y) if keep(i)]
+            tru = [self.char_list[i] for i in ref if keep(i)]
+            if tru:
+                errs += _levenshtein(hyp, tru)
+                n += len(tru)
+        return errs / n if n else None
+
+    def __call__(self, ys_hat, ys_pad, is_ctc=False):
+        if is_ctc:
+            return self.cer_ctc(ys_hat, ys_pad)
+        hyps, refs = [], []
+        for y, ref in zip(ys_hat.tolist(), ys_pad.tolist()):
+            ymax = ref.index(-1) if -1 in ref else len(ref)
+            h = "".join(self.char_list[i] for i in y[:ymax]).replace(self.space, " ").replace(self.blank, "")
+            r = "".join(self.char_list[i] for i in ref if i != -1).replace(self.space, " ")
+            hyps.append(h)
+            refs.append(r)
+        cer = wer = None
+        if self.report_cer:
+            d = sum(_levenshtein(list(h.replace(" ", "")), list(r.replace(" ", ""))) for h, r in zip(hyps, refs))
+            cer = d / sum(len(r.replace(" ", "")) for r in refs)
+        if self.report_wer:
+            d = sum(_levenshtein(h.split(), r.split()) for h, r in zip(hyps, refs))
+            wer = d / sum(len(r.split()) for r in refs)
+        return cer, wer
+
+
+class UtteranceMVN(torch.nn.Module):
+    """espnet2 UtteranceMVN(norm_means=True, norm_vars=False) on the HIP path."""
+
+    def __init__(self, norm_means: bool = True, norm_vars: bool = False, eps: float = 1.0e-20):
+        super().__init__()
+        if not norm_means or norm_vars:
+            raise ValueError("HIP path covers norm_means=true, norm_vars=false (all shipped configs)")
+
+    def forward(self, x, ilens):
+        return ops.utterance_mvn(x.contiguous(), ilens.to(torch.int64)), ilens
+
+
+class ESPnetASRModel(torch.nn.Module):
+    def __init__(self, vocab_size: int, token_list: Union[Tuple[str, ...], List[str]], frontend, specaug, normalize,
+                 preencoder, encoder, postencoder, decoder, ctc: CTC, joint_network=None, aux_ctc: dict = None,
+                 ctc_weight: float = 0.5, interctc_weight: float = 0.0, ignore_id: int = -1, lsm_weight: float = 0.0,
+                 length_normalized_loss: bool = False, report_cer: bool = True, report_wer: bool = True,
+                 sym_space: str = "<space>", sym_blank: str = "<blank>", transducer_multi_blank_durations: List = [],
+                 transducer_multi_blank_sigma: float = 0.05, sym_sos: str = "<sos/eos>", sym_eos: str = "<sos/eos>",
+                 extract_feats_in_collect_stats: bool = True, lang_token_id: int = -1):
+        assert 0.0 <= ctc_weight <= 1.0, ctc_weight
+        assert 0.0 <= interctc_weight < 1.0, interctc_weight
+        super().__init__()
+        if joint_network is not None or preencoder is not None or postencoder is not None:
+            raise ValueError("transducer / pre- / post-encoder branches are out of the hot path (no shipped config)")
+        self.blank_id = token_list.index(sym_blank) if sym_blank in token_list else 0
+        self.sos = token_list.index(sym_sos) if sym_sos in token_list else vocab_size - 1
+        self.eos = token_list.index(sym_eos) if sym_eos in token_list else vocab_size - 1
+        self.vocab_size, self.ignore_id = vocab_size, ignore_id
+        self.ctc_weight, self.interctc_weight = ctc_weight, interctc_weight
+        self.token_list = list(token_list)
+        self.frontend, self.specaug, self.normalize, self.encoder = frontend, specaug, normalize, encoder
+        if not hasattr(self.encoder, "interctc_use_conditioning"):
+            self.encoder.interctc_use_conditioning = False
+        self.decoder = decoder if ctc_weight < 1.0 else None
+        self.lsm_weight, self.length_normalized_loss = lsm_weight, length_normalized_loss
+        self.error_calculator = (ErrorCalculator(self.token_list, sym_space, sym_blank, report_cer, report_wer)
+                                 if (report_cer or report_wer) else None)
+        self.ctc = ctc if ctc_weight != 0.0 else None
+
+    # ---------------------------------------------------------------- espnet_model.py:369-430
+    def encode(self, speech: torch.Tensor, speech_lengths: torch.Tensor):
+        speech = speech[:, : int(speech.size(1))]
+        if self.frontend is not None:
+            feats, feats_lengths = self.frontend(speech, speech_lengths)
+        else:
+            feats, feats_lengths = speech, speech_lengths
+        if self.specaug is not None and self.training:
+            feats, feats_lengths = self.specaug(feats, feats_lengths)
+        if self.normalize is not None:
+            feats, feats_lengths = self.normalize(feats, feats_lengths)
+        encoder_out, encoder_out_lens, _ = self.encoder(feats, feats_lengths)
+        return encoder_out, encoder_out_lens
+
+    # ---------------------------------------------------------------- espnet_model.py:206-356
+    def forward(self, speech, speech_lengths, text, text_lengths, **kwargs):
+        assert text_lengths.dim() == 1, text_lengths.shape
+        assert speech.shape[0] == speech_lengths.shape[0] == text.shape[0] == text_lengths.shape[0], (
+            speech.shape, speech_lengths.shape, text.shape, text_lengths.shape)
+        batch_size = speech.shape[0]
+        text = text.to(torch.int64)
+        text[text == -1] = self.ignore_id
+        encoder_out, encoder_out_lens = self.encode(speech, speech_lengths)
+        intermediate_outs = None
+        if isinstance(encoder_out, tuple):
+            encoder_out, intermediate_outs = encoder_out
+        stats: Dict[str, Optional[torch.Tensor]] = dict()
+        loss_ctc = loss_att = None
+        if self.ctc_weight != 0.0:
+            loss_ctc = self.ctc(encoder_out, encoder_out_lens, text, text_lengths)
+            cer_ctc = None
+            if not self.training and self.error_calculator is not None:
+                ys_hat = self.ctc.argmax(encoder_out).data
+                cer_ctc = self.error_calculator(ys_hat.cpu(), text.cpu(), is_ctc=True)
+            stats["loss_ctc"], stats["cer_ctc"] = loss_ctc.detach(), cer_ctc
+        if self.interctc_weight != 0.0 and intermediate_outs is not None:
+            raise NotImplementedError("interctc_weight > 0 is not used by the shipped ASR/AVSR recipes")
+        acc_att = cer_att = wer_att = None
+        if self.ctc_weight != 1.0:
+            ys_in, ys_out = add_sos_eos(text, text_lengths, self.sos, self.eos, self.ignore_id)
+            decoder_out, _ = self.decoder(encoder_out, encoder_out_lens, ys_in, text_lengths + 1)
+            loss_att, correct = F_.LabelSmoothingLossFn.apply(decoder_out, ys_out, self.ignore_id, self.lsm_weight,
+                                                             self.length_normalized_loss)
+            acc_att = _Accuracy(correct)
+            if not self.training and self.error_calculator is not None:
+                ids, _, _ = ops.ctc_greedy(decoder_out.detach().contiguous(), None, -1, collapse=False)  # argmax(-1)
+                cer_att, wer_att = self.error_calculator(ids.cpu(), text.cpu())
+        if self.ctc_weight == 0.0:
+            loss = loss_att
+        elif self.ctc_weight == 1.0:
+            loss = loss_ctc
+        else:
+            loss = F_.WeightedSumFn.apply(loss_ctc, loss_att, self.ctc_weight, 1 - self.ctc_weight)
+        stats["loss_att"] = loss_att.detach() if loss_att is not None else None
+        stats["acc"], stats["cer"], stats["wer"] = acc_att, cer_att, wer_att
+        stats["loss"] = loss.detach()
+        weight = torch.tensor([batch_size], dtype=torch.long, device=loss.device)
+        return loss.view(1), stats, weight
+
+    @torch.no_grad()
+    def ctc_greedy(self, speech, speech_lengths):
+        """-> (ids (B,T), hyp (B,T) padded -1, hyp_len (B)): argmax + collapse, integer exact."""
+        enc, olens = self.encode(speech, speech_lengths)
+        return self.ctc.greedy(enc, olens, self.blank_id)
+
+
+class _Accuracy:
+    """Lazy th_accuracy: the reference returns a Python float (a device->host sync, nets_utils.th_accuracy);
+    the counters stay on the device until somebody asks."""
+
+    def __init__(self, correct):
+        self.correct = correct
+
+    def __float__(self):
+        c = self.correct
+        return float((c == 1).sum()) / float((c >= 0).sum())

@@ -1,0 +1,359 @@
+"""Tensor-level wrappers over the C ABI (include/tavsr.h).  No autograd, no torch arithmetic:
+torch is used only to allocate buffers on the caching allocator and to name the current stream.
+Every function raises ``TavsrError`` on a CPU tensor or a failed call - there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT, GemmDesc, check, lib, ptr, require_cuda, stream
+
+f32 = torch.float32
+
+
+def empty(*shape, like: Optional[torch.Tensor] = None, dtype=f32, device=None):
+    dev = like.device if like is not None else (device if device is not None else "cuda")
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+def _addr(t: torch.Tensor, off: int = 0) -> int:
+    return t.data_ptr() + 4 * off
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
+         nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
+         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None):
+    """Raw descriptor call; offsets are in elements into the given tensors."""
+    require_cuda(A, B, Cc, bias, Z, R, DZ)
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.A, d.lda = _addr(A, a_off), lda
+    d.B, d.ldb = _addr(B, b_off), ldb
+    d.C, d.ldc = _addr(Cc, c_off), ldc
+    d.nb1, d.nb2 = nb1, nb2
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    d.bias = None if bias is None else bias.data_ptr()
+    d.act, d.alpha = ACT[act], alpha
+    d.Z = None if Z is None else _addr(Z, c_off)
+    if R is not None:
+        d.R, d.ldr = _addr(R, r_off), ldr
+        d.sR1, d.sR2 = sR
+    if DZ is not None:
+        d.DZ, d.dact = _addr(DZ, c_off), ACT[dact]
+    check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
+
+
+def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None):
+    """y = res + alpha*act(x @ w.T + b); x [M,K] (row stride x.stride(0)), w [N,K] torch layout."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = empty(M, N, like=x)
+        ldc = N
+    z = empty(M, N, like=x) if save_z else None
+    assert not save_z or (out_off == 0 and ldc == N)
+    gemm(M, N, K, x, x.stride(0), w, w.stride(0), out, ldc, c_off=out_off, bias=b, act=act, alpha=alpha, Z=z,
+         R=res, ldr=0 if res is None else res.stride(0))
+    return (out, z) if save_z else out
+
+
+def linear_dx(dy, w, *, alpha=1.0, DZ=None, dact=None, res=None, out=None):
+    """dx = res + alpha * (dy @ w) * act'(DZ);  dy [M,N], w [N,K] -> [M,K]."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = empty(M, K, like=dy)
+    gemm(M, K, N, dy, dy.stride(0), w, w.stride(0), out, out.stride(0), b_kmajor=True, alpha=alpha, DZ=DZ, dact=dact,
+         R=res, ldr=0 if res is None else res.stride(0))
+    return out
+
+
+def linear_dw(dy, x, *, alpha=1.0, out=None):
+    """dW = alpha * dy.T @ x;  dy [M,N], x [M,K] -> [N,K] (torch weight layout)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if out is None:
+        out = empty(N, K, like=dy)
+    gemm(N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), a_kmajor=True, b_kmajor=True, alpha=alpha)
+    return out
+
+
+def colsum(x, *, scale=1.0, out=None, accumulate=False):
+    M, N = x.shape
+    require_cuda(x)
+    if out is None:
+        out = empty(N, like=x)
+    ws = empty(lib_i64("tavsr_colsum_ws", M, N), like=x)
+    check(lib().tavsr_colsum(ptr(x), C.c_int64(x.stride(0)), M, N, C.c_float(scale), ptr(out), int(accumulate), ptr(ws),
+                             stream()), "tavsr_colsum")
+    return out
+
+
+def lib_i64(name, *args) -> int:
+    fn = getattr(lib(), name)
+    fn.restype = C.c_int64
+    return int(fn(*args))
+
+
+# ---------------------------------------------------------------------------------------------- norms
+def layernorm_fwd(x, gamma, beta, eps, *, save=True):
+    M, D = x.shape
+    require_cuda(x, gamma, beta)
+    y = empty(M, D, like=x)
+    mean = empty(M, like=x) if save else None
+    rstd = empty(M, like=x) if save else None
+    check(lib().tavsr_layernorm_fwd(ptr(x), C.c_int64(x.stride(0)), ptr(gamma), ptr(beta), C.c_float(eps), ptr(y),
+                                    C.c_int64(D), ptr(mean), ptr(rstd), M, D, stream()), "tavsr_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, dx_add=None, dx=None):
+    """returns dx (= dx_add + LN'(dy)), dgamma, dbeta."""
+    M, D = x.shape
+    require_cuda(dy, x, mean, rstd, gamma, dx_add)
+    if dx is None:
+        dx = empty(M, D, like=x)
+    dg, db = empty(D, like=x), empty(D, like=x)
+    ws = empty(lib_i64("tavsr_layernorm_bwd_ws", M, D), like=x)
+    check(lib().tavsr_layernorm_bwd(ptr(dy), C.c_int64(dy.stride(0)), ptr(x), C.c_int64(x.stride(0)), ptr(mean),
+                                    ptr(rstd), ptr(gamma), ptr(dx_add),
+                                    C.c_int64(0 if dx_add is None else dx_add.stride(0)), ptr(dx),
+                                    C.c_int64(dx.stride(0)), ptr(dg), ptr(db), 0, ptr(ws), M, D, stream()),
+          "tavsr_layernorm_bwd")
+    return dx, dg, db
+
+
+# ---------------------------------------------------------------------------------------------- attention glue
+def add_head_bias(q, u, v):
+    M, D = q.shape
+    qu, qv = empty(M, D, like=q), empty(M, D, like=q)
+    require_cuda(q, u, v)
+    check(lib().tavsr_add_head_bias(ptr(q), C.c_int64(q.stride(0)), ptr(u), ptr(v), ptr(qu), ptr(qv), C.c_int64(M), D,
+                                    stream()), "tavsr_add_head_bias")
+    return qu, qv
+
+
+def softmax_fwd(ac, bd, klens, scale, causal=False):
+    H, B, T1, T2 = ac.shape
+    attn = torch.empty_like(ac)
+    W = 0 if bd is None else bd.shape[-1]
+    require_cuda(ac, bd, klens)
+    check(lib().tavsr_softmax_fwd(ptr(ac), ptr(bd), ptr(klens), ptr(attn), H, B, T1, T2, W, C.c_float(scale),
+                                  int(causal), stream()), "tavsr_softmax_fwd")
+    return attn
+
+
+def softmax_bwd(attn, dattn, scale, skew=False):
+    H, B, T1, T2 = attn.shape
+    ds = torch.empty_like(attn)
+    W = 2 * T1 - 1 if skew else 0
+    sk = empty(H, B, T1, W, like=attn) if skew else None
+    check(lib().tavsr_softmax_bwd(ptr(attn), ptr(dattn), ptr(ds), ptr(sk), H, B, T1, T2, W, C.c_float(scale), stream()),
+          "tavsr_softmax_bwd")
+    return ds, sk
+
+
+def axpby(x, y=None, a=1.0, b=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    assert x.is_contiguous() and (y is None or y.is_contiguous()) and out.is_contiguous()
+    require_cuda(x, y, out)
+    check(lib().tavsr_axpby(ptr(x), ptr(y), C.c_float(a), C.c_float(b), ptr(out), C.c_int64(x.numel()), stream()),
+          "tavsr_axpby")
+    return out
+
+
+def scale_dev(x, s, c=1.0):
+    """x * (c * s) with ``s`` a 0-dim / 1-element device tensor."""
+    require_cuda(x, s)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    check(lib().tavsr_scale_dev(ptr(x), ptr(s), C.c_float(c), ptr(out), C.c_int64(x.numel()), stream()), "tavsr_scale_dev")
+    return out
+
+
+def axpby2d(x, y, a, b, out):
+    M, N = x.shape
+    require_cuda(x, y, out)
+    check(lib().tavsr_axpby2d(ptr(x), C.c_int64(x.stride(0)), ptr(y), C.c_int64(0 if y is None else y.stride(0)),
+                              C.c_float(a), C.c_float(b), ptr(out), C.c_int64(out.stride(0)), C.c_int64(M), N, stream()),
+          "tavsr_axpby2d")
+    return out
+
+
+def act_bwd_(dh, z, act):
+    """in place: dh *= act'(z)."""
+    assert dh.is_contiguous() and z.is_contiguous()
+    check(lib().tavsr_act_bwd(ptr(dh), ptr(z), ptr(dh), C.c_int64(dh.numel()), ACT[act], stream()), "tavsr_act_bwd")
+    return dh
+
+
+# ---------------------------------------------------------------------------------------------- cgMLP / merge
+def dwconv_gate_fwd(gn, r, w, bias, B, T):
+    M, Cn = gn.shape
+    K = w.shape[-1]
+    out, conv = empty(M, Cn, like=gn), empty(M, Cn, like=gn)
+    require_cuda(gn, r, w, bias)
+    check(lib().tavsr_dwconv_gate_fwd(ptr(gn), ptr(r), C.c_int64(r.stride(0)), ptr(w), ptr(bias), ptr(out), ptr(conv),
+                                      B, T, Cn, K, stream()), "tavsr_dwconv_gate_fwd")
+    return out, conv
+
+
+def dwconv_gate_bwd(du, gn, r, conv, w, dr, B, T):
+    M, Cn = gn.shape
+    K = w.shape[-1]
+    dgn = empty(M, Cn, like=gn)
+    dw, db = torch.empty_like(w), empty(Cn, like=gn)
+    ws = empty(lib_i64("tavsr_dwconv_gate_bwd_ws", B, T, Cn, K), like=gn)
+    check(lib().tavsr_dwconv_gate_bwd(ptr(du), ptr(gn), ptr(r), C.c_int64(r.stride(0)), ptr(conv), ptr(w), ptr(dr),
+                                      C.c_int64(dr.stride(0)), ptr(dgn), ptr(dw), ptr(db), 0, ptr(ws), B, T, Cn, K,
+                                      stream()), "tavsr_dwconv_gate_bwd")
+    return dgn, dw, db
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    require_cuda(*ts)
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def merge_pool_fwd(x1, x2, lens, params, B, T):
+    D = x1.shape[-1]
+    score, pooled, w = empty(2, B, T, like=x1), empty(2, B, D, like=x1), empty(B, 2, like=x1)
+    check(lib().tavsr_merge_pool_fwd(ptr(x1), ptr(x2), ptr(lens), _ptr_array(params), ptr(score), ptr(pooled), ptr(w),
+                                     B, T, D, stream()), "tavsr_merge_pool_fwd")
+    return score, pooled, w
+
+
+def merge_combine(x1, x2, w, B, T):
+    D = x1.shape[-1]
+    out = torch.empty_like(x1)
+    check(lib().tavsr_merge_combine(ptr(x1), ptr(x2), ptr(w), ptr(out), B, T, D, stream()), "tavsr_merge_combine")
+    return out
+
+
+def merge_bwd(dm, x1, x2, lens, params, score, pooled, w, B, T):
+    D = x1.shape[-1]
+    dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+    # gradient order: weight{pool1,pool2,w1,w2} then bias{pool1,pool2,w1,w2}
+    order = [0, 1, 4, 5, 2, 3, 6, 7]
+    dparams = [torch.empty_like(params[i]) for i in order]
+    ws = empty(lib_i64("tavsr_merge_bwd_ws", B, D), like=x1)
+    check(lib().tavsr_merge_bwd(ptr(dm), ptr(x1), ptr(x2), ptr(lens), _ptr_array(params), ptr(score), ptr(pooled),
+                                ptr(w), ptr(dx1), ptr(dx2), _ptr_array(dparams), 0, ptr(ws), B, T, D, stream()),
+          "tavsr_merge_bwd")
+    grads = [None] * 8
+    for g, i in zip(dparams, order):
+        grads[i] = g
+    return dx1, dx2, grads
+
+
+# ---------------------------------------------------------------------------------------------- subsampling
+def conv1_fwd(x, w, bias):
+    B, T, F = x.shape
+    Cn = w.shape[0]
+    To, Fo = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    y = empty(B, To, Fo, Cn, like=x)
+    require_cuda(x, w, bias)
+    check(lib().tavsr_conv1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, T, F, Cn, stream()), "tavsr_conv1_fwd")
+    return y
+
+
+def conv1_bwd(dz, x, Cn):
+    B, T, F = x.shape
+    dw, db = empty(Cn, 9, like=x), empty(Cn, like=x)
+    ws = empty(lib_i64("tavsr_conv1_bwd_ws", B, T, F, Cn), like=x)
+    check(lib().tavsr_conv1_bwd(ptr(dz), ptr(x), ptr(dw), ptr(db), 0, ptr(ws), B, T, F, Cn, stream()), "tavsr_conv1_bwd")
+    return dw, db
+
+
+def im2col3x3s2(y):
+    B, Ti, Fi, Cn = y.shape
+    To, Fo = (Ti - 3) // 2 + 1, (Fi - 3) // 2 + 1
+    col = empty(B * To * Fo, 9 * Cn, like=y)
+    check(lib().tavsr_im2col3x3s2(ptr(y), ptr(col), B, Ti, Fi, Cn, stream()), "tavsr_im2col3x3s2")
+    return col, To, Fo
+
+
+def col2im3x3s2_relu(dcol, yrelu):
+    B, Ti, Fi, Cn = yrelu.shape
+    dz = torch.empty_like(yrelu)
+    check(lib().tavsr_col2im3x3s2_relu(ptr(dcol), ptr(yrelu), ptr(dz), B, Ti, Fi, Cn, stream()), "tavsr_col2im3x3s2_relu")
+    return dz
+
+
+def transpose_inner(x, nb, R, Cc, out=None):
+    """out[n][c][r] = x[n][r][c] for a contiguous [nb, R, Cc] view of x."""
+    require_cuda(x)
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().tavsr_transpose_inner(ptr(x), ptr(out), C.c_int64(nb), R, Cc, 0, stream()), "tavsr_transpose_inner")
+    return out
+
+
+def utterance_mvn(x, lens):
+    B, T, F = x.shape
+    require_cuda(x, lens)
+    y = torch.empty_like(x)
+    check(lib().tavsr_utterance_mvn(ptr(x), ptr(lens), ptr(y), B, T, F, stream()), "tavsr_utterance_mvn")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------- CTC / losses
+def ctc_loss(logits, hlens, targets, tlens, blank=0, zero_infinity=True):
+    """logits [B,T,V] contiguous -> (nll [B], dnll/dlogits [B,T,V])."""
+    B, T, V = logits.shape
+    Lmax = targets.shape[1]
+    require_cuda(logits, hlens, targets, tlens)
+    loss, grad = empty(B, like=logits), torch.empty_like(logits)
+    ws = empty(lib_i64("tavsr_ctc_loss_ws", B, T, Lmax), like=logits)
+    check(lib().tavsr_ctc_loss(ptr(logits), C.c_int64(V), C.c_int64(T * V), ptr(hlens), ptr(targets),
+                               C.c_int64(targets.stride(0)), ptr(tlens), blank, int(zero_infinity), ptr(loss), ptr(grad),
+                               ptr(ws), B, T, V, Lmax, stream()), "tavsr_ctc_loss")
+    return loss, grad
+
+
+def ctc_greedy(logits, hlens=None, blank=0, collapse=True):
+    B, T, V = logits.shape
+    require_cuda(logits, hlens)
+    ids = torch.empty((B, T), dtype=torch.int64, device=logits.device)
+    hyp = torch.empty((B, T), dtype=torch.int64, device=logits.device) if collapse else None
+    hl = torch.empty((B,), dtype=torch.int64, device=logits.device) if collapse else None
+    check(lib().tavsr_ctc_greedy(ptr(logits), C.c_int64(V), C.c_int64(T * V), ptr(hlens), blank, ptr(ids), ptr(hyp),
+                                 ptr(hl), B, T, V, stream()), "tavsr_ctc_greedy")
+    return ids, hyp, hl
+
+
+def lsm_loss(logits2d, target, ignore, smoothing):
+    rows, V = logits2d.shape
+    require_cuda(logits2d, target)
+    row_loss, grad = empty(rows, like=logits2d), torch.empty_like(logits2d)
+    correct = torch.empty((rows,), dtype=torch.int32, device=logits2d.device)
+    check(lib().tavsr_lsm_loss(ptr(logits2d), C.c_int64(V), ptr(target), ignore, C.c_float(smoothing), ptr(row_loss),
+                               ptr(grad), ptr(correct), C.c_int64(rows), V, stream()), "tavsr_lsm_loss")
+    return row_loss, grad, correct
+
+
+def embed_pe(ids, table, pe, scale):
+    B, Lq = ids.shape
+    D = table.shape[1]
+    require_cuda(ids, table, pe)
+    out = empty(B, Lq, D, like=table)
+    check(lib().tavsr_embed_pe(ptr(ids), ptr(table), ptr(pe), C.c_float(scale), ptr(out), C.c_int64(B * Lq), Lq, D,
+                               stream()), "tavsr_embed_pe")
+    return out
+
+
+def embed_bwd(ids, dout, scale, V):
+    D = dout.shape[-1]
+    dt = empty(V, D, like=dout)
+    check(lib().tavsr_embed_bwd(ptr(ids), ptr(dout), C.c_float(scale), ptr(dt), C.c_int64(ids.numel()), V, D, 0,
+                                stream()), "tavsr_embed_bwd")
+    return dt

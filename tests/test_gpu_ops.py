@@ -1,0 +1,252 @@
+"""GPU: each HIP op through the C ABI vs a plain torch fp32/fp64 restatement of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=2e-5):
+    a, b = a.double().cpu(), b.double().cpu()
+    err = (a - b).abs().max() / b.abs().max().clamp_min(1e-30)
+    assert err < tol, float(err)
+
+
+@pytest.mark.parametrize("M,D", [(3168, 256), (7, 1024), (130, 64)])
+def test_layernorm_fwd_bwd(M, D):
+    from tavsr import ops
+    torch.manual_seed(0)
+    xs = torch.randn(M, 2 * D, device="cuda")
+    x = xs[:, D:]  # strided rows
+    w, b = torch.randn(D, device="cuda"), torch.randn(D, device="cuda")
+    y, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-12)
+    xr = x.double().clone().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), wr, br, 1e-12)
+    _close(y, yr)
+    dy = torch.randn(M, D, device="cuda")
+    add = torch.randn(M, D, device="cuda")
+    yr.backward(dy.double())
+    dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, w, dx_add=add)
+    _close(dx, xr.grad + add.double(), 1e-4)
+    _close(dg, wr.grad, 1e-4)
+    _close(db, br.grad, 1e-4)
+
+
+def test_colsum_and_scale():
+    from tavsr import ops
+    x = torch.randn(3168, 41, device="cuda")
+    _close(ops.colsum(x, scale=0.5), 0.5 * x.double().sum(0), 1e-5)
+    s = torch.tensor(0.37, device="cuda")
+    _close(ops.scale_dev(x, s, 2.0), x.double() * 0.74, 1e-6)
+    _close(ops.axpby(x[:, :1].contiguous().view(-1)[1:2], None, 3.0, 0.0), 3.0 * x[1:2, 0], 1e-6)
+
+
+@pytest.mark.parametrize("T,lens", [(23, [23, 17, 9]), (99, [99, 50, 1]), (130, [130, 64, 65])])
+def test_relpos_softmax_fwd_bwd(T, lens):
+    from tavsr import ops
+    torch.manual_seed(1)
+    H, B, W = 4, len(lens), 2 * T - 1
+    ac = torch.randn(H, B, T, T, device="cuda")
+    bd = torch.randn(H, B, T, W, device="cuda")
+    kl = torch.tensor(lens, device="cuda")
+    attn = ops.softmax_fwd(ac, bd, kl, 0.125)
+    acr, bdr = ac.double().requires_grad_(True), bd.double().requires_grad_(True)
+    idx = (T - 1 - torch.arange(T)[:, None] + torch.arange(T)[None, :]).cuda()
+    shifted = torch.gather(bdr, 3, idx.expand(H, B, T, T))
+    sc = (acr + shifted) * 0.125
+    dead = (torch.arange(T).cuda()[None, :] >= kl[:, None])[None, :, None, :]
+    ref = torch.softmax(sc.masked_fill(dead, torch.finfo(torch.float32).min), -1).masked_fill(dead, 0.0)
+    _close(attn, ref, 1e-5)
+    da = torch.randn_like(attn)
+    ref.backward(da.double())
+    ds, sk = ops.softmax_bwd(attn, da, 0.125, skew=True)
+    _close(ds, acr.grad, 1e-4)
+    _close(sk, bdr.grad, 1e-4)
+
+
+def test_plain_causal_softmax():
+    from tavsr import ops
+    torch.manual_seed(2)
+    H, B, L, T = 4, 3, 13, 29
+    sc = torch.randn(H, B, L, L, device="cuda")
+    kl = torch.tensor([13, 8, 2], device="cuda")
+    attn = ops.softmax_fwd(sc, None, kl, 0.5, causal=True)
+    mask = (torch.arange(L).cuda()[None, None, :] < kl[:, None, None]) & torch.tril(torch.ones(L, L, device="cuda")).bool()[None]
+    dead = ~mask[None]
+    ref = torch.softmax((sc.double() * 0.5).masked_fill(dead, -1e300), -1).masked_fill(dead, 0.0)
+    _close(attn, ref, 1e-5)
+    sc2 = torch.randn(H, B, L, T, device="cuda")
+    kl2 = torch.tensor([29, 11, 20], device="cuda")
+    a2 = ops.softmax_fwd(sc2, None, kl2, 0.5)
+    dead2 = (torch.arange(T).cuda()[None, :] >= kl2[:, None])[None, :, None, :]
+    _close(a2, torch.softmax((sc2.double() * 0.5).masked_fill(dead2, -1e300), -1).masked_fill(dead2, 0.0), 1e-5)
+
+
+@pytest.mark.parametrize("B,T", [(3, 23), (2, 99), (1, 300)])
+def test_dwconv_gate(B, T):
+    from tavsr import ops
+    torch.manual_seed(3)
+    Cn, K = 1024, 31
+    g = torch.randn(B * T, 2 * Cn, device="cuda")
+    gn = torch.randn(B * T, Cn, device="cuda")
+    w, bias = torch.randn(Cn, 1, K, device="cuda") / 5, torch.randn(Cn, device="cuda")
+    out, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], w.view(Cn, K), bias, B, T)
+    gnr, wr, br = gn.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    rr = g[:, :Cn].double().clone().requires_grad_(True)
+    cr = F.conv1d(gnr.view(B, T, Cn).transpose(1, 2), wr, br, 1, 15, 1, Cn).transpose(1, 2).reshape(B * T, Cn)
+    ref = rr * cr
+    _close(out, ref, 1e-5)
+    _close(conv, cr, 1e-5)
+    du = torch.randn_like(out)
+    ref.backward(du.double())
+    dg = torch.empty_like(g)
+    dgn, dw, db = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, w.view(Cn, K), dg[:, :Cn], B, T)
+    _close(dg[:, :Cn], rr.grad, 1e-4)
+    _close(dgn, gnr.grad, 1e-4)
+    _close(dw.view(Cn, 1, K), wr.grad, 1e-4)
+    _close(db, br.grad, 1e-4)
+
+
+def test_merge_learned_ave():
+    from tavsr import ops
+    torch.manual_seed(4)
+    B, T, D = 3, 23, 256
+    lens = torch.tensor([23, 17, 9], device="cuda")
+    x1, x2 = torch.randn(B, T, D, device="cuda"), torch.randn(B, T, D, device="cuda")
+    prm = [torch.randn(1, D, device="cuda") / 4, torch.randn(1, D, device="cuda") / 4, torch.randn(1, device="cuda"),
+           torch.randn(1, device="cuda"), torch.randn(1, D, device="cuda") / 4, torch.randn(1, D, device="cuda") / 4,
+           torch.randn(1, device="cuda"), torch.randn(1, device="cuda")]
+    score, pooled, w = ops.merge_pool_fwd(x1.view(-1, D), x2.view(-1, D), lens, prm, B, T)
+    m = ops.merge_combine(x1.view(-1, D), x2.view(-1, D), w, B, T)
+    P = [p.double().requires_grad_(True) for p in prm]
+    X = [x1.double().requires_grad_(True), x2.double().requires_grad_(True)]
+    mask = (torch.arange(T).cuda()[None, :] < lens[:, None])[:, None, :]
+    ws = []
+    for k in range(2):
+        s = (X[k] @ P[k].t() + P[2 + k]).transpose(1, 2) / D ** 0.5
+        s = torch.softmax(s.masked_fill(~mask, -1e300), -1).masked_fill(~mask, 0.0)
+        pl = torch.matmul(s, X[k]).squeeze(1)
+        ws.append(pl @ P[4 + k].t() + P[6 + k])
+    mw = torch.softmax(torch.cat(ws, -1), -1)
+    ref = mw[:, 0, None, None] * X[0] + mw[:, 1, None, None] * X[1]
+    _close(w, mw, 1e-5)
+    _close(m.view(B, T, D), ref, 1e-5)
+    dm = torch.randn(B * T, D, device="cuda")
+    ref.backward(dm.view(B, T, D).double())
+    dx1, dx2, grads = ops.merge_bwd(dm, x1.view(-1, D), x2.view(-1, D), lens, prm, score, pooled, w, B, T)
+    _close(dx1.view(B, T, D), X[0].grad, 1e-4)
+    _close(dx2.view(B, T, D), X[1].grad, 1e-4)
+    for i in (0, 1, 4, 5, 6, 7):
+        _close(grads[i].view(-1), P[i].grad.view(-1), 2e-4)
+    for i in (2, 3):  # d/d(pooling bias) is analytically 0 (softmax shift invariance)
+        assert grads[i].abs().max() < 1e-5
+
+
+def test_conv2d_subsampling_pieces():
+    from tavsr import ops
+    torch.manual_seed(5)
+    B, T, Fq, Cn = 2, 40, 80, 256
+    x = torch.randn(B, T, Fq, device="cuda")
+    w1, b1 = torch.randn(Cn, 1, 3, 3, device="cuda") / 3, torch.randn(Cn, device="cuda")
+    y1 = ops.conv1_fwd(x, w1.view(Cn, 9), b1)
+    r1 = F.relu(F.conv2d(x.double().unsqueeze(1), w1.double(), b1.double(), 2))  # B,C,T1,F1
+    _close(y1, r1.permute(0, 2, 3, 1), 1e-5)
+    col, T2, F2 = ops.im2col3x3s2(y1)
+    w2 = torch.randn(Cn, Cn, 3, 3, device="cuda") / 48
+    w2r = ops.transpose_inner(w2, Cn, Cn, 9).view(Cn, 9 * Cn)
+    y2 = ops.linear(col, w2r, None)
+    r2 = F.conv2d(r1, w2.double(), None, 2)
+    _close(y2.view(B, T2, F2, Cn), r2.permute(0, 2, 3, 1), 1e-5)
+    # col2im(+relu') == conv2 data gradient masked by relu'
+    dcol = torch.randn_like(col)
+    dz = ops.col2im3x3s2_relu(dcol, y1)
+    y1r = y1.double().clone().requires_grad_(True)
+    colr = F.unfold(y1r.permute(0, 3, 1, 2), 3, stride=2)  # B, C*9, L  (c-major, then kh,kw)
+    colr = colr.view(B, Cn, 9, -1).permute(0, 3, 2, 1).reshape(B * T2 * F2, 9 * Cn)
+    (colr * dcol.double()).sum().backward()
+    _close(dz, y1r.grad * (y1 > 0), 1e-5)
+    # conv1 weight gradient
+    dz1 = torch.randn_like(y1)
+    dw, db = ops.conv1_bwd(dz1, x, Cn)
+    w1r, b1r = w1.double().requires_grad_(True), b1.double().requires_grad_(True)
+    (F.conv2d(x.double().unsqueeze(1), w1r, b1r, 2).permute(0, 2, 3, 1) * dz1.double()).sum().backward()
+    _close(dw.view(Cn, 1, 3, 3), w1r.grad, 1e-4)
+    _close(db, b1r.grad, 1e-4)
+
+
+def test_utterance_mvn():
+    from tavsr import ops
+    x = torch.randn(3, 50, 80, device="cuda")
+    lens = torch.tensor([50, 31, 7], device="cuda")
+    y = ops.utterance_mvn(x, lens)
+    for b, l in enumerate(lens.tolist()):
+        _close(y[b, :l], x[b, :l].double() - x[b, :l].double().mean(0, keepdim=True), 1e-5)
+        assert (y[b, l:] == 0).all()
+
+
+def test_ctc_loss_vs_torch():
+    from tavsr import ops
+    torch.manual_seed(6)
+    B, T, V, L = 5, 37, 41, 12
+    logits = torch.randn(B, T, V, device="cuda") * 2
+    hl = torch.tensor([37, 30, 37, 5, 20], device="cuda")
+    tl = torch.tensor([12, 7, 0, 9, 3], device="cuda")
+    ys = torch.randint(1, V, (B, L), device="cuda")
+    ys[1, 3] = ys[1, 2]
+    nll, g = ops.ctc_loss(logits, hl, ys, tl)
+    lr = logits.double().cpu().requires_grad_(True)
+    ref = F.ctc_loss(lr.log_softmax(2).transpose(0, 1), ys.cpu(), hl.cpu(), tl.cpu(), blank=0, reduction="none",
+                     zero_infinity=True)
+    ref.sum().backward()
+    _close(nll, ref, 1e-5)
+    _close(g, lr.grad, 1e-4)
+    assert float(nll[3]) == 0.0 and float(g[3].abs().max()) == 0.0  # infeasible -> zero_infinity
+
+
+def test_ctc_greedy_bit_exact():
+    from tavsr import ops
+    from itertools import groupby
+    torch.manual_seed(7)
+    B, T, V = 6, 99, 41
+    logits = torch.randn(B, T, V, device="cuda")
+    logits[:, ::3] = logits[:, 1::3][:, : logits[:, ::3].size(1)]  # repeated frames -> repeats to collapse
+    logits[0, 5, 7] = logits[0, 5, 3] = 50.0                        # exact tie -> lowest index
+    hl = torch.tensor([99, 80, 1, 50, 99, 3], device="cuda")
+    ids, hyp, n = ops.ctc_greedy(logits, hl, 0)
+    ref = logits.cpu().argmax(-1)
+    assert torch.equal(ids.cpu(), ref)
+    for b in range(B):
+        want = [k for k, _ in groupby(ref[b, : int(hl[b])].tolist()) if k != 0]
+        assert hyp[b, : int(n[b])].tolist() == want
+        assert (hyp[b, int(n[b]):] == -1).all()
+
+
+def test_lsm_loss_and_embed():
+    from tavsr import ops
+    torch.manual_seed(8)
+    N, V, D, L = 40, 41, 256, 8
+    x = torch.randn(N, V, device="cuda")
+    tg = torch.randint(0, V, (N,), device="cuda")
+    tg[::5] = -1
+    row, g, correct = ops.lsm_loss(x, tg, -1, 0.1)
+    xr = x.double().requires_grad_(True)
+    td = torch.full((N, V), 0.1 / (V - 1), dtype=torch.float64, device="cuda")
+    ign = tg == -1
+    td.scatter_(1, tg.masked_fill(ign, 0).unsqueeze(1), 0.9)
+    kl = F.kl_div(torch.log_softmax(xr, 1), td, reduction="none").masked_fill(ign.unsqueeze(1), 0).sum(1)
+    kl.sum().backward()
+    _close(row, kl, 1e-5)
+    _close(g, xr.grad, 1e-5)
+    want = torch.where(ign, torch.full_like(tg, -1), (x.argmax(1) == tg).long())
+    assert torch.equal(correct.long(), want)
+    ids = torch.randint(0, V, (N // L, L), device="cuda")
+    table, pe = torch.randn(V, D, device="cuda"), torch.randn(L, D, device="cuda")
+    out = ops.embed_pe(ids, table, pe, 16.0)
+    _close(out, table[ids].double() * 16 + pe.double()[None], 1e-6)
+    do = torch.randn(N, D, device="cuda")
+    dt = ops.embed_bwd(ids, do, 16.0, V)
+    ref = torch.zeros(V, D, dtype=torch.float64, device="cuda").index_add_(0, ids.view(-1), do.double() * 16)
+    _close(dt, ref, 1e-5)
