@@ -1,0 +1,219 @@
+"""Headline benchmark (BASELINE.json): utterances/s, forward+backward, 12-layer Branchformer ASR model
+(Conv2dSubsampling + 12 x MyBranchformerEncoderLayer + CTC + 6-layer Transformer decoder,
+configs/ASR/branchformer_transformer+ctc_english.yaml), batch 32 x 4 s clips (400 mel frames x 80)
+per GPU, fp32, synthetic data, random-init weights.  Weak scaling: every rank steps its own batch of 32;
+ranks exchange gradients once per step (RCCL all-reduce, tavsr.dp).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - the dominant kernel (fp32 MFMA GEMM instantiation with the largest total time): algorithmic
+                 FLOPs / HIP-event launch durations, measured in a separate instrumented replay of the same step;
+  cpu_baseline - the oracle (CPU restatement, eager torch fp32) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "tailored-avsr_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+# Algorithmic work, forward, per utterance (BASELINE.md section 2 / SURVEY Appendix C); fwd+bwd = 3x.
+GFLOP_PER_UTT_FWD = 11.35
+B_PER_GPU, T_IN, N_MEL, L_TXT = 32, 400, 80, 40
+
+
+def make_conf():
+    conf = yaml.safe_load(open(os.path.join(PKG, "configs", "asr_branchformer_transformer_ctc_english.yaml")))
+    conf.update(input_size=N_MEL, specaug=None)
+    # Dropout kernels are not on the HIP path yet (DESIGN.md "not yet"): rates are set to 0 for BOTH the GPU run
+    # and the CPU baseline so the two time the same arithmetic.
+    for k in ("dropout_rate", "positional_dropout_rate", "attention_dropout_rate"):
+        conf["encoder_conf"][k] = 0.0
+    for k in ("dropout_rate", "positional_dropout_rate", "self_attention_dropout_rate", "src_attention_dropout_rate"):
+        conf["decoder_conf"][k] = 0.0
+    conf["ctc_conf"]["dropout_rate"] = 0.0
+    return conf
+
+
+def make_batch(batch, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    speech = torch.randn(batch, T_IN, N_MEL, generator=g)
+    slens = torch.full((batch,), T_IN, dtype=torch.int64)
+    text = torch.randint(1, 40, (batch, L_TXT), generator=g)
+    tlens = torch.full((batch,), L_TXT, dtype=torch.int64)
+    return [t.to(device) for t in (speech, slens, text, tlens)]
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle's fwd+bwd of the same model/workload on the host cores (bounded sample)."""
+    from oracle.model import build_asr_oracle
+    from tavsr.utils.tokens import CHAR_ENGLISH
+
+    torch.manual_seed(0)
+    model = build_asr_oracle(copy.deepcopy(make_conf()), CHAR_ENGLISH).train()
+    cores = torch.get_num_threads()
+    bs = 8
+    batch = make_batch(bs, 1234, "cpu")
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss, _, _ = model(*batch)
+        loss.backward()
+
+    step()  # warm-up (allocator, oneDNN primitives)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 10:
+            break
+    return {"value": round(bs * n / el, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of batch {bs} x 4 s (same model/config, dropout 0), eager torch fp32, "
+                      f"{cores} threads, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from tavsr import dp, ops
+    from tavsr.tasks.asr import ASRTask
+
+    rank, local, world = dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(0)
+    model = ASRTask.build_model(argparse.Namespace(**copy.deepcopy(make_conf()))).to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    buckets = dp.GradBuckets(params)
+    buckets.broadcast_parameters(0)
+    batch = make_batch(B_PER_GPU, 1234 + rank, dev)
+
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        loss, _, _ = model(*batch)
+        loss.backward()
+        return loss
+
+    graph = None
+    static_loss = None
+    if not args.no_graph:
+        # Capture the whole forward+backward (≈2.5k kernel launches) into one hipGraph: the step is
+        # launch-bound in eager mode.  Gradients land in graph-owned buffers that are stable across replays.
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        for p in params:
+            p.grad = None
+        with torch.cuda.graph(graph):
+            static_loss = model(*batch)[0]
+            static_loss.backward()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd()
+        buckets.allreduce_mean()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+
+    utts = B_PER_GPU * world * args.steps
+    value = utts / elapsed
+    out = {
+        "metric": "utterances/sec fwd+bwd, 12L Branchformer ASR (Conv2dSubsampling+CTC+6L decoder), 4 s clips, batch 32/GPU",
+        "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: audio-only 12-layer Branchformer d=256 + Conv2dSubsampling + CTC + "
+                               "6L Transformer decoder, batch 32 x 400 mel frames x 80 per GPU, text length 40, fwd+bwd",
+                   "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "dropout": 0.0,
+                   "launch": "eager" if graph is None else "hipGraph replay (whole fwd+bwd)"},
+        "model_tflops_per_s": round(value * 3 * GFLOP_PER_UTT_FWD / 1e3, 2),
+        "frac_of_fp32_mfma_peak_whole_step": round(value * 3 * GFLOP_PER_UTT_FWD / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # Instrumented eager replay of the same step: HIP events around every tavsr_gemm launch on the launch stream.
+        prof = ops.GemmProfile()
+        ops.PROFILE = prof
+        nprof = 3
+        for _ in range(nprof):
+            fwd_bwd()
+        ops.PROFILE = None
+        summ = prof.summary()
+        key = max(summ, key=lambda k: summ[k]["seconds"])
+        d = summ[key]
+        achieved = d["flops"] / d["seconds"] / 1e12
+        gemm_s = sum(v["seconds"] for v in summ.values()) / nprof
+        out["roofline"] = {
+            "bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": d["calls"] // nprof,
+            "avg_launch_us": round(1e6 * d["seconds"] / d["calls"], 2),
+            "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 4),
+            "all_gemm_ms_per_step": round(1e3 * gemm_s, 3),
+            "all_gemm_tflops": round(sum(v["flops"] for v in summ.values()) / nprof / gemm_s / 1e12, 2),
+            "by_kernel": {k: {"calls_per_step": v["calls"] // nprof, "ms_per_step": round(1e3 * v["seconds"] / nprof, 3),
+                              "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)} for k, v in summ.items()},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -140,8 +140,7 @@ class ESPnetASRModel(torch.nn.Module):
         assert speech.shape[0] == speech_lengths.shape[0] == text.shape[0] == text_lengths.shape[0], (
             speech.shape, speech_lengths.shape, text.shape, text_lengths.shape)
         batch_size = speech.shape[0]
-        text = text.to(torch.int64)
-        text[text == -1] = self.ignore_id
+        text = text.to(torch.int64).masked_fill(text == -1, self.ignore_id)
         encoder_out, encoder_out_lens = self.encode(speech, speech_lengths)
         intermediate_outs = None
         if isinstance(encoder_out, tuple):
@@ -176,7 +175,7 @@ class ESPnetASRModel(torch.nn.Module):
         stats["loss_att"] = loss_att.detach() if loss_att is not None else None
         stats["acc"], stats["cer"], stats["wer"] = acc_att, cer_att, wer_att
         stats["loss"] = loss.detach()
-        weight = torch.tensor([batch_size], dtype=torch.long, device=loss.device)
+        weight = torch.full((1,), batch_size, dtype=torch.long, device=loss.device)
         return loss.view(1), stats, weight
 
     @torch.no_grad()

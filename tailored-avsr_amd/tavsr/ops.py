@@ -24,6 +24,34 @@ def _addr(t: torch.Tensor, off: int = 0) -> int:
     return t.data_ptr() + 4 * off
 
 
+class GemmProfile:
+    """Optional per-launch timing of tavsr_gemm with HIP events on the launch stream (bench.py's roofline
+    leg).  Off on the product path (``PROFILE is None``): zero overhead."""
+
+    def __init__(self):
+        self.records = []  # (key, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        return {k: dict(calls=v[0], flops=v[1], seconds=v[2]) for k, v in agg.items()}
+
+
+PROFILE: Optional[GemmProfile] = None
+
+
+def _gemm_kernel_key(d) -> str:
+    """Mirror of the tile choice in csrc/gemm.hip: names the template instantiation a launch runs."""
+    big = -(-d.M // 128) * -(-d.N // 128) * max(1, d.nb1) * max(1, d.nb2) >= 1024
+    tile = "128x128x16" if big else "64x64x32"
+    return f"gemm_kernel<{tile},{'T' if d.a_kmajor else 'N'}{'N' if d.b_kmajor else 'T'}>"
+
+
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
@@ -48,7 +76,14 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.sR1, d.sR2 = sR
     if DZ is not None:
         d.DZ, d.dact = _addr(DZ, c_off), ACT[dact]
+    if PROFILE is None:
+        check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
+    e1.record()
+    PROFILE.records.append((_gemm_kernel_key(d), 2.0 * M * N * K * max(1, nb1) * max(1, nb2), e0, e1))
 
 
 def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None):
