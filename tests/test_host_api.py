@@ -1,0 +1,108 @@
+"""CPU: host-side mirror of the reference API (no GPU, no compute calls): config surface, registry,
+state_dict keys, error behaviour, and that the C-ABI library loads and exports every declared symbol."""
+import argparse
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import ROOT, TOKENS_EN, asr_conf, golden
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tavsr.h")).read()
+    names = set(re.findall(r"\b(tavsr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 30
+    lib = ctypes.CDLL(os.path.join(ROOT, "tailored-avsr_amd", "tavsr", "lib", "libtavsr_hip.so"))
+    for n in sorted(names):
+        assert hasattr(lib, n), n
+    assert lib.tavsr_version() >= 1
+
+
+def test_state_dict_keys_match_reference():
+    from tavsr.tasks.asr import ASRTask
+    from tavsr.utils.tokens import CHAR_ENGLISH
+    assert CHAR_ENGLISH == TOKENS_EN and len(CHAR_ENGLISH) == 41
+    g = golden("asr_model_3L")
+    m = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=3, dec_blocks=2)))
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    full = ASRTask.build_model(argparse.Namespace(**asr_conf()))
+    assert abs(sum(p.numel() for p in full.parameters()) / 1e6 - 51.2) < 0.1  # README table: 51.2 M
+
+
+def test_layer_variants_keys():
+    from tavsr.encoder.branchformer.encoder import MyBranchformerEncoder
+    for tag, kw in {"learned": dict(merge_method="learned_ave"), "fixed": dict(merge_method="fixed_ave", cgmlp_weight=0.3),
+                    "fixed_attn_only": dict(merge_method="fixed_ave", cgmlp_weight=0.0),
+                    "fixed_mlp_only": dict(merge_method="fixed_ave", cgmlp_weight=1.0),
+                    "concat": dict(merge_method="concat")}.items():
+        enc = MyBranchformerEncoder(input_size=256, num_blocks=1, input_layer=None, ffn_activation_type="swish", **kw)
+        assert sorted(enc.encoders[0].state_dict().keys()) == list(golden(f"bf_layer_{tag}")["keys"]), tag
+
+
+def test_no_cpu_fallback_and_error_behaviour():
+    from tavsr._lib import TavsrError
+    from tavsr.encoder.branchformer.encoder import MyBranchformerEncoder
+    from tavsr.layers import TooShortUttError
+    enc = MyBranchformerEncoder(input_size=80, num_blocks=1, input_layer="conv2d", dropout_rate=0.0,
+                                positional_dropout_rate=0.0, attention_dropout_rate=0.0).eval()
+    with pytest.raises(TavsrError):
+        enc(torch.randn(1, 40, 80), torch.tensor([40]))
+    with pytest.raises(TooShortUttError):          # encoder.py:356-363
+        enc(torch.randn(1, 6, 80), torch.tensor([6]))
+    with pytest.raises(ValueError):                # encoder.py:203
+        MyBranchformerEncoder(input_layer="bogus")
+    with pytest.raises(ValueError):                # encoder_layer.py:148
+        MyBranchformerEncoder(input_layer=None, merge_method="bogus")
+    layer = MyBranchformerEncoder(input_layer=None, num_blocks=1).encoders[0]
+    with pytest.raises(NotImplementedError):       # encoder_layer.py:168-169
+        layer((torch.zeros(1, 4, 256), torch.zeros(1, 7, 256)), None, cache=torch.zeros(1))
+
+
+def test_yaml_overrides_grammar(tmp_path):
+    from tavsr.utils.config import load_config, override_yaml
+    from helpers import ASR_YAML
+    cfg = load_config(ASR_YAML, ["encoder_conf:dropout_rate:0.0", "encoder_conf:num_blocks:6", "input_size:80"]
+                      if False else ["encoder_conf:dropout_rate:0.0", "encoder_conf:num_blocks:6"])
+    assert cfg.encoder_conf["dropout_rate"] == 0.0 and cfg.encoder_conf["num_blocks"] == 6
+    d = override_yaml({"a": {"flag": True, "n": 3}, "s": "x"}, ["a:flag:false", "a:n:5", "s:y"])
+    assert d == {"a": {"flag": False, "n": 5}, "s": "y"}
+
+
+def test_add_sos_eos_matches_espnet_semantics():
+    from oracle.leaves import add_sos_eos as ref
+    from tavsr.models.espnet_model import add_sos_eos
+    ys = torch.tensor([[3, 4, 5, -1], [7, 8, 9, 10], [1, -1, -1, -1]])
+    lens = torch.tensor([3, 4, 1])
+    a, b = add_sos_eos(ys, lens, 40, 40, -1)
+    c, d = ref(ys, 40, 40, -1)
+    assert torch.equal(a, c) and torch.equal(b, d)
+
+
+def test_c_oracle_ctc_greedy_matches_python_oracle():
+    import numpy as np
+    from oracle.leaves import ctc_greedy_collapse
+    so = os.path.join(ROOT, "oracle", "_build", "liboracle_ctc.so")
+    if not os.path.exists(so):
+        import subprocess
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "oracle", "ctc_greedy.c")])
+    lib = ctypes.CDLL(so)
+    lib.oracle_ctc_greedy.restype = ctypes.c_int64
+    g = golden("cfg1_wav_greedy")
+    rng = np.random.default_rng(0)
+    logits = rng.standard_normal((49, 41)).astype(np.float32)
+    logits[5, 7] = logits[5, 3] = 9.0
+    ids = np.zeros(49, dtype=np.int64)
+    hyp = np.zeros(49, dtype=np.int64)
+    n = lib.oracle_ctc_greedy(logits.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(49), ctypes.c_int64(41),
+                              ctypes.c_int64(0), ids.ctypes.data_as(ctypes.c_void_p), hyp.ctypes.data_as(ctypes.c_void_p))
+    t = torch.from_numpy(logits)
+    assert ids.tolist() == t.argmax(-1).tolist()
+    assert hyp[:n].tolist() == ctc_greedy_collapse(t.argmax(-1))
+    # and on the reference's own config-1 ids
+    ref_ids = torch.from_numpy(g["ids"][0])
+    assert ctc_greedy_collapse(ref_ids) == g["hyp"].tolist()
