@@ -63,9 +63,14 @@ typedef struct tavsr_gemm_desc {
   float* Z;
   const float* R; int64_t ldr; int64_t sR1, sR2;
   const float* DZ; int32_t dact;
+  float* ws; int64_t ws_floats;   /* optional split-K workspace (>= tavsr_gemm_ws(desc) floats), may be NULL */
 } tavsr_gemm_desc;
 
 int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);
+/* floats of workspace with which tavsr_gemm will split K over workgroups (0: not needed).  Few-tile, long-K
+ * problems (weight gradients, K = B*T) are split so the whole chip works; the slabs are summed in a fixed
+ * order (deterministic) by a second kernel that also applies the epilogue. */
+int64_t tavsr_gemm_ws(const tavsr_gemm_desc* desc);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (espnet LayerNorm = torch.nn.LayerNorm(eps=1e-12); the five norms of
@@ -95,7 +100,8 @@ int tavsr_sum_partials(const float* part, int32_t nparts, int64_t stride, float*
 /* ---------------------------------------------------------------------------------------------
  * Attention glue (espnet attention.py: RelPositionMultiHeadedAttention.forward / rel_shift /
  * MultiHeadedAttention.forward_attention; called at encoder_layer.py:208 and by the decoder).
- * Score tensors are [H, B, T1, T2] fp32; the QK^T, (q+v)P^T, PV products are tavsr_gemm calls.
+ * Score tensors are [H, B, T1, ld_s] fp32 with ld_s >= T2 (rows padded to a multiple of 4 floats so the
+ * GEMMs around them use 16-byte loads; likewise ld_w >= W); the QK^T, (q+v)P^T, PV products are tavsr_gemm calls.
  *   add_head_bias: qu = q + pos_bias_u, qv = q + pos_bias_v   (q rows strided by ldq, D = H*d_k)
  *   softmax_fwd  : attn = softmax_j((ac + rel_shift(bd)) * scale) over keys j < klens[b]
  *                  (and j <= i when causal), exactly 0 on masked keys; bd may be NULL
@@ -107,10 +113,11 @@ int tavsr_sum_partials(const float* part, int32_t nparts, int64_t stride, float*
 int tavsr_add_head_bias(const float* q, int64_t ldq, const float* u, const float* v, float* qu, float* qv,
                         int64_t M, int32_t D, tavsr_stream_t stream);
 int tavsr_softmax_fwd(const float* ac, const float* bd, const int64_t* klens, float* attn, int32_t H,
-                      int32_t B, int32_t T1, int32_t T2, int32_t W, float scale, int32_t causal,
-                      tavsr_stream_t stream);
+                      int32_t B, int32_t T1, int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w, float scale,
+                      int32_t causal, tavsr_stream_t stream);
 int tavsr_softmax_bwd(const float* attn, const float* dattn, float* ds, float* ds_skew, int32_t H,
-                      int32_t B, int32_t T1, int32_t T2, int32_t W, float scale, tavsr_stream_t stream);
+                      int32_t B, int32_t T1, int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w, float scale,
+                      tavsr_stream_t stream);
 
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);

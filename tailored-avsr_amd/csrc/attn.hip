@@ -31,8 +31,8 @@ __global__ void add_head_bias_kernel(const float* __restrict__ q, int64_t ldq, c
 // masked_fill(min) -> softmax -> masked_fill(0) because exp(min - max) == 0 in fp32.
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ ac, const float* __restrict__ bd,
                                                           const int64_t* __restrict__ klens, float* __restrict__ attn,
-                                                          int H, int B, int T1, int T2, int W, float scale,
-                                                          int causal) {
+                                                          int H, int B, int T1, int T2, int W, int64_t ld_s,
+                                                          int64_t ld_w, float scale, int causal) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (int64_t)H * B * T1) return;
@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
   const int b = (int)((row / T1) % B);
   int nk = klens ? (int)min((int64_t)T2, klens[b]) : T2;
   if (causal) nk = min(nk, i + 1);
-  const float* a = ac + row * T2;
-  const float* p = bd ? bd + row * W + (T1 - 1 - i) : nullptr;
-  float* o = attn + row * T2;
+  const float* a = ac + row * ld_s;
+  const float* p = bd ? bd + row * ld_w + (T1 - 1 - i) : nullptr;
+  float* o = attn + row * ld_s;
   float mx = -FLT_MAX;
   for (int j = lane; j < nk; j += 64) {
     float s = (a[j] + (p ? p[j] : 0.f)) * scale;
@@ -71,18 +71,18 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ attn,
                                                           const float* __restrict__ dattn, float* __restrict__ ds,
                                                           float* __restrict__ ds_skew, int64_t rows, int T1, int T2,
-                                                          int W, float scale) {
+                                                          int W, int64_t ld_s, int64_t ld_w, float scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int i = (int)(row % T1);
-  const float* a = attn + row * T2;
-  const float* g = dattn + row * T2;
+  const float* a = attn + row * ld_s;
+  const float* g = dattn + row * ld_s;
   float dot = 0.f;
   for (int j = lane; j < T2; j += 64) dot += a[j] * g[j];
   dot = wave_sum(dot);
-  float* o = ds + row * T2;
-  float* sk = ds_skew ? ds_skew + row * W : nullptr;
+  float* o = ds + row * ld_s;
+  float* sk = ds_skew ? ds_skew + row * ld_w : nullptr;
   const int off = T1 - 1 - i;
   if (sk)
     for (int c = lane; c < W; c += 64)
@@ -175,27 +175,30 @@ extern "C" int tavsr_add_head_bias(const float* q, int64_t ldq, const float* u, 
 }
 
 extern "C" int tavsr_softmax_fwd(const float* ac, const float* bd, const int64_t* klens, float* attn, int32_t H,
-                                 int32_t B, int32_t T1, int32_t T2, int32_t W, float scale, int32_t causal,
-                                 tavsr_stream_t stream) {
+                                 int32_t B, int32_t T1, int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w,
+                                 float scale, int32_t causal, tavsr_stream_t stream) {
   TAVSR_REQUIRE(ac && attn, TAVSR_EINVAL, "softmax_fwd: null pointer");
+  TAVSR_REQUIRE(ld_s >= T2 && (!bd || ld_w >= W), TAVSR_EINVAL, "softmax_fwd: leading dimension too small");
   TAVSR_REQUIRE(!bd || (T1 == T2 && W == 2 * T1 - 1), TAVSR_EINVAL,
                 "softmax_fwd: rel-pos term needs T1 == T2 and W == 2*T1-1 (got %d, %d, %d)", T1, T2, W);
   int64_t rows = (int64_t)H * B * T1;
   if (rows <= 0 || T2 <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, ac, bd, klens, attn, H,
-                     B, T1, T2, W, scale, causal);
+                     B, T1, T2, W, ld_s, ld_w, scale, causal);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
 
 extern "C" int tavsr_softmax_bwd(const float* attn, const float* dattn, float* ds, float* ds_skew, int32_t H,
-                                 int32_t B, int32_t T1, int32_t T2, int32_t W, float scale, tavsr_stream_t stream) {
+                                 int32_t B, int32_t T1, int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w,
+                                 float scale, tavsr_stream_t stream) {
   TAVSR_REQUIRE(attn && dattn && ds, TAVSR_EINVAL, "softmax_bwd: null pointer");
+  TAVSR_REQUIRE(ld_s >= T2 && (!ds_skew || ld_w >= W), TAVSR_EINVAL, "softmax_bwd: leading dimension too small");
   TAVSR_REQUIRE(!ds_skew || (T1 == T2 && W == 2 * T1 - 1), TAVSR_EINVAL, "softmax_bwd: bad skew geometry");
   int64_t rows = (int64_t)H * B * T1;
   if (rows <= 0 || T2 <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, attn, dattn, ds,
-                     ds_skew, rows, T1, T2, W, scale);
+                     ds_skew, rows, T1, T2, W, ld_s, ld_w, scale);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

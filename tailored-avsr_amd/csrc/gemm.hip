@@ -13,6 +13,8 @@
 // K-step's global loads are issued before the MFMAs of the current one.  LDS images:
 //   k-contiguous operand  : [row][BK+1]  (odd stride: the per-lane column read is conflict free)
 //   row-contiguous operand: [k][rows+4]  (16-B aligned rows: ds_write_b128, row read conflict free)
+#include <algorithm>
+
 #include "common.h"
 
 namespace tavsr {
@@ -21,7 +23,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
   tavsr_gemm_desc d;
+  float* ws;      // split-K slabs [nsplit][nb1*nb2][M][N]
+  int kchunk;     // K elements per split (multiple of BK)
+  int nsplit;
 };
+
+// Fixed-order sum of the split-K slabs + the fused epilogue (same math as the in-kernel one).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs args) {
+  const tavsr_gemm_desc& d = args.d;
+  const int64_t mn = (int64_t)d.M * d.N;
+  const int nbatch = d.nb1 * d.nb2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= mn) return;
+  const int z = blockIdx.y, z1 = z / d.nb2, z2 = z % d.nb2;
+  const int m = (int)(i / d.N), n = (int)(i % d.N);
+  float v = 0.f;
+  for (int s = 0; s < args.nsplit; ++s) v += args.ws[((int64_t)s * nbatch + z) * mn + i];
+  if (d.bias) v += d.bias[n];
+  const int64_t o = z1 * d.sC1 + z2 * d.sC2 + (int64_t)m * d.ldc + n;
+  if (d.Z) d.Z[o] = v;
+  v = act_fwd(d.act, v);
+  if (d.DZ) v *= act_bwd(d.dact, d.DZ[o]);
+  v *= d.alpha;
+  if (d.R) v += d.R[z1 * d.sR1 + z2 * d.sR2 + (int64_t)m * d.ldr + n];
+  d.C[o] = v;
+}
 
 template <int ROWS, int BK, bool KMAJOR>
 struct Tile {
@@ -56,8 +82,8 @@ struct Loader {
       if (KMAJOR) {
         if (gk < K) {
           const float* p = g + (int64_t)gk * ld + gr;
-          if (VEC) {
-            if (gr < nrows) val = *reinterpret_cast<const float4*>(p);
+          if (VEC && gr + 3 < nrows) {
+            val = *reinterpret_cast<const float4*>(p);
           } else {
             if (gr + 0 < nrows) val.x = p[0];
             if (gr + 1 < nrows) val.y = p[1];
@@ -68,8 +94,8 @@ struct Loader {
       } else {
         if (gr < nrows) {
           const float* p = g + (int64_t)gr * ld + gk;
-          if (VEC) {
-            if (gk < K) val = *reinterpret_cast<const float4*>(p);
+          if (VEC && gk + 3 < K) {
+            val = *reinterpret_cast<const float4*>(p);
           } else {
             if (gk + 0 < K) val.x = p[0];
             if (gk + 1 < K) val.y = p[1];
@@ -100,7 +126,7 @@ struct Loader {
   }
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool AK, bool BKM, bool VEC>
+template <int BM, int BN, int BK, int WM, int WN, bool AK, bool BKM, bool VEC, bool SPLITK>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) {
   const tavsr_gemm_desc& d = args.d;
   constexpr int NT = WM * WN * 64;
@@ -135,9 +161,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[LA::NV], rb[LB::NV];
-  const int nk = (d.K + BK - 1) / BK;
-  LA::load(A, d.lda, m0, 0, d.M, d.K, tid, ra);
-  LB::load(B, d.ldb, n0, 0, d.N, d.K, tid, rb);
+  // split-K: slice z covers k in [kbeg, kend); each slice writes a raw fp32 slab to the workspace
+  const int kbeg = SPLITK ? blockIdx.z * args.kchunk : 0;
+  const int kend = SPLITK ? min(d.K, kbeg + args.kchunk) : d.K;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  LA::load(A, d.lda, m0, kbeg, d.M, kend, tid, ra);
+  LB::load(B, d.ldb, n0, kbeg, d.N, kend, tid, rb);
   LA::store(smem, tid, ra);
   LB::store(smem + TA::SIZE, tid, rb);
   __syncthreads();
@@ -146,8 +175,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      LA::load(A, d.lda, m0, (kt + 1) * BK, d.M, d.K, tid, ra);
-      LB::load(B, d.ldb, n0, (kt + 1) * BK, d.N, d.K, tid, rb);
+      LA::load(A, d.lda, m0, kbeg + (kt + 1) * BK, d.M, kend, tid, ra);
+      LB::load(B, d.ldb, n0, kbeg + (kt + 1) * BK, d.N, kend, tid, rb);
     }
     const float* a_s = smem + cur * STAGE;
     const float* b_s = a_s + TA::SIZE;
@@ -172,6 +201,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) 
   }
 
   // ---- epilogue: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (SPLITK) {
+    float* slab = args.ws + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (int64_t)d.M * d.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + lr;
+      if (n >= d.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < d.M) slab[(int64_t)m * d.N + n] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
   float* C = d.C + coff;
   float* Z = d.Z ? d.Z + coff : nullptr;
   const float* R = d.R ? d.R + z1 * d.sR1 + z2 * d.sR2 : nullptr;
@@ -202,16 +249,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) 
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
-static int launch_cfg(const tavsr_gemm_desc& d, bool vec, hipStream_t s) {
-  GemmArgs a{d};
-  dim3 grid(cdiv(d.M, BM) * cdiv(d.N, BN), d.nb1 * d.nb2, 1);
+static int launch_cfg(const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
+  GemmArgs a{d, d.ws, kchunk, nsplit};
+  dim3 grid(cdiv(d.M, BM) * cdiv(d.N, BN), d.nb1 * d.nb2, nsplit);
   dim3 block(WM * WN * 64);
-#define TAVSR_GEMM_LAUNCH(AK, BKM)                                                           \
-  do {                                                                                       \
-    if (vec)                                                                                 \
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, true>), grid, block, 0, s, a); \
-    else                                                                                     \
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, false>), grid, block, 0, s, a); \
+#define TAVSR_GEMM_LAUNCH(AK, BKM)                                                                        \
+  do {                                                                                                    \
+    if (nsplit > 1) {                                                                                     \
+      if (vec)                                                                                            \
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, true, true>), grid, block, 0, s, a);  \
+      else                                                                                                \
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, false, true>), grid, block, 0, s, a); \
+    } else {                                                                                              \
+      if (vec)                                                                                            \
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, true, false>), grid, block, 0, s, a); \
+      else                                                                                                \
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, false, false>), grid, block, 0, s, a);\
+    }                                                                                                     \
   } while (0)
   if (!d.a_kmajor && !d.b_kmajor) TAVSR_GEMM_LAUNCH(false, false);
   else if (!d.a_kmajor && d.b_kmajor) TAVSR_GEMM_LAUNCH(false, true);
@@ -219,7 +273,30 @@ static int launch_cfg(const tavsr_gemm_desc& d, bool vec, hipStream_t s) {
   else TAVSR_GEMM_LAUNCH(true, false);
 #undef TAVSR_GEMM_LAUNCH
   TAVSR_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    dim3 g2(cdiv((int64_t)d.M * d.N, 256), d.nb1 * d.nb2, 1);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, g2, dim3(256), 0, s, a);
+    TAVSR_LAUNCH_CHECK();
+  }
   return TAVSR_OK;
+}
+
+// Split-K plan: fill the 256 CUs (>= 2 waves per SIMD) when the output has too few tiles but K is long
+// (weight gradients: K = B*T rows).  Returns nsplit (1 = none) and the K chunk per slice.
+static void plan_splitk(const tavsr_gemm_desc& d, int BM, int BN, int BK, int* nsplit, int* kchunk) {
+  *nsplit = 1;
+  *kchunk = d.K;
+  const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN) * d.nb1 * d.nb2;
+  if (tiles >= 384 || d.K < 8 * BK) return;
+  long want = std::min<long>({(long)cdiv(768, tiles), (long)d.K / (4 * BK), 64L});
+  if (want < 2) return;
+  int kc = cdiv(cdiv(d.K, want), BK) * BK;
+  *kchunk = kc;
+  *nsplit = cdiv(d.K, kc);
+}
+
+static bool use_big_tile(const tavsr_gemm_desc& d) {
+  return (long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.nb1 * d.nb2 >= 768;
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -240,10 +317,26 @@ extern "C" int tavsr_gemm(const tavsr_gemm_desc* dp, tavsr_stream_t stream) {
   // vector (16-B) operand loads need aligned bases, leading dims and batch strides
   bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.sA1 % 4 == 0 &&
              d.sA2 % 4 == 0 && d.sB1 % 4 == 0 && d.sB2 % 4 == 0;
-  // the contiguous direction must be a multiple of 4 so a float4 is wholly inside or outside
-  vec = vec && (d.a_kmajor ? d.M % 4 == 0 : d.K % 4 == 0) && (d.b_kmajor ? d.N % 4 == 0 : d.K % 4 == 0);
+  // (a float4 that straddles the end of the contiguous direction falls back to predicated scalar loads)
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.nb1 * d.nb2;
-  if (tiles128 >= 1024) return launch_cfg<128, 128, 16, 2, 2>(d, vec, s);
-  return launch_cfg<64, 64, 32, 2, 2>(d, vec, s);
+  if (use_big_tile(d)) return launch_cfg<128, 128, 16, 2, 2>(d, vec, 1, d.K, s);
+  int nsplit, kchunk;
+  plan_splitk(d, 64, 64, 32, &nsplit, &kchunk);
+  if (nsplit > 1) {
+    const int64_t need = (int64_t)nsplit * d.nb1 * d.nb2 * d.M * d.N;
+    if (d.ws == nullptr || d.ws_floats < need) nsplit = 1, kchunk = d.K;  // caller gave no workspace: plain path
+  }
+  return launch_cfg<64, 64, 32, 2, 2>(d, vec, nsplit, kchunk, s);
+}
+
+extern "C" int64_t tavsr_gemm_ws(const tavsr_gemm_desc* dp) {
+  using namespace tavsr;
+  if (!dp) return 0;
+  tavsr_gemm_desc d = *dp;
+  if (d.nb1 <= 0) d.nb1 = 1;
+  if (d.nb2 <= 0) d.nb2 = 1;
+  if (d.M <= 0 || d.N <= 0 || use_big_tile(d)) return 0;
+  int nsplit, kchunk;
+  plan_splitk(d, 64, 64, 32, &nsplit, &kchunk);
+  return nsplit > 1 ? (int64_t)nsplit * d.nb1 * d.nb2 * d.M * d.N : 0;
 }

@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("Z", C.c_void_p),
         ("R", C.c_void_p), ("ldr", C.c_int64), ("sR1", C.c_int64), ("sR2", C.c_int64),
         ("DZ", C.c_void_p), ("dact", C.c_int32),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 
@@ -54,6 +55,7 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.tavsr_last_error_string.restype = C.c_char_p
         _lib.tavsr_version.restype = C.c_int
+        _lib.tavsr_gemm_ws.restype = C.c_int64
     return _lib
 
 

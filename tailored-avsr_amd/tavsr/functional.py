@@ -59,21 +59,24 @@ class _SelfAttnCore:
     def fwd(qu, ldq, q_off, kbuf, ldk, k_off, vbuf, ldv, v_off, B, T1, T2, H, dk, klens, causal, qv=None, p=None):
         D = H * dk
         dev = qu
-        ac = ops.empty(H, B, T1, T2, like=dev)
+        S = ops.pad4(T2)   # padded score-row stride: 16-byte loads in the GEMMs that read the scores
+        ac = ops.empty(H, B, T1, S, like=dev)
         # ac[h,b] = Qu[b,:,h] K[b,:,h]^T
-        ops.gemm(T1, T2, dk, qu, ldq, kbuf, ldk, ac, T2, a_off=q_off, b_off=k_off, nb1=B, nb2=H,
-                 sA=(T1 * ldq, dk), sB=(T2 * ldk, dk), sC=(T1 * T2, B * T1 * T2))
+        ops.gemm(T1, T2, dk, qu, ldq, kbuf, ldk, ac, S, a_off=q_off, b_off=k_off, nb1=B, nb2=H,
+                 sA=(T1 * ldq, dk), sB=(T2 * ldk, dk), sC=(T1 * S, B * T1 * S))
         bd = None
+        W = 0
         if p is not None:
             W = 2 * T1 - 1
-            bd = ops.empty(H, B, T1, W, like=dev)
-            ops.gemm(T1, W, dk, qv, D, p, D, bd, W, nb1=B, nb2=H, sA=(T1 * D, dk), sB=(0, dk),
-                     sC=(T1 * W, B * T1 * W))
-        attn = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal)
+            Wp = ops.pad4(W)
+            bd = ops.empty(H, B, T1, Wp, like=dev)
+            ops.gemm(T1, W, dk, qv, D, p, D, bd, Wp, nb1=B, nb2=H, sA=(T1 * D, dk), sB=(0, dk),
+                     sC=(T1 * Wp, B * T1 * Wp))
+        attn = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal, T2=T2, W=W)
         ctx = ops.empty(B * T1, D, like=dev)
         # ctx[b,:,h] = attn[h,b] V[b,:,h]
-        ops.gemm(T1, dk, T2, attn, T2, vbuf, ldv, ctx, D, b_off=v_off, b_kmajor=True, nb1=B, nb2=H,
-                 sA=(T1 * T2, B * T1 * T2), sB=(T2 * ldv, dk), sC=(T1 * D, dk))
+        ops.gemm(T1, dk, T2, attn, S, vbuf, ldv, ctx, D, b_off=v_off, b_kmajor=True, nb1=B, nb2=H,
+                 sA=(T1 * S, B * T1 * S), sB=(T2 * ldv, dk), sC=(T1 * D, dk))
         return ctx, attn
 
     @staticmethod
@@ -81,30 +84,33 @@ class _SelfAttnCore:
             dv_buf, lddv, dv_off, B, T1, T2, H, dk, qv=None, p=None):
         """Writes dQ(u) into dq, dK into dk_buf, dV into dv_buf (head-strided); returns (dqv, dp) for rel-pos."""
         D = H * dk
+        S = attn.shape[-1]
+        sS = (T1 * S, B * T1 * S)
         dattn = torch.empty_like(attn)
         # dattn[h,b] = dctx[b,:,h] V[b,:,h]^T
-        ops.gemm(T1, T2, dk, dctx, D, vbuf, ldv, dattn, T2, b_off=v_off, nb1=B, nb2=H, sA=(T1 * D, dk),
-                 sB=(T2 * ldv, dk), sC=(T1 * T2, B * T1 * T2))
+        ops.gemm(T1, T2, dk, dctx, D, vbuf, ldv, dattn, S, b_off=v_off, nb1=B, nb2=H, sA=(T1 * D, dk),
+                 sB=(T2 * ldv, dk), sC=sS)
         # dV[b,:,h] = attn[h,b]^T dctx[b,:,h]
-        ops.gemm(T2, dk, T1, attn, T2, dctx, D, dv_buf, lddv, c_off=dv_off, a_kmajor=True, b_kmajor=True, nb1=B, nb2=H,
-                 sA=(T1 * T2, B * T1 * T2), sB=(T1 * D, dk), sC=(T2 * lddv, dk))
-        ds, sk = ops.softmax_bwd(attn, dattn, 1.0 / math.sqrt(dk), skew=p is not None)
+        ops.gemm(T2, dk, T1, attn, S, dctx, D, dv_buf, lddv, c_off=dv_off, a_kmajor=True, b_kmajor=True, nb1=B, nb2=H,
+                 sA=sS, sB=(T1 * D, dk), sC=(T2 * lddv, dk))
+        ds, sk = ops.softmax_bwd(attn, dattn, 1.0 / math.sqrt(dk), skew=p is not None, T2=T2)
         # dQu[b,:,h] = ds[h,b] K[b,:,h]
-        ops.gemm(T1, dk, T2, ds, T2, kbuf, ldk, dq, lddq, b_off=k_off, c_off=dq_off, b_kmajor=True, nb1=B, nb2=H,
-                 sA=(T1 * T2, B * T1 * T2), sB=(T2 * ldk, dk), sC=(T1 * lddq, dk))
+        ops.gemm(T1, dk, T2, ds, S, kbuf, ldk, dq, lddq, b_off=k_off, c_off=dq_off, b_kmajor=True, nb1=B, nb2=H,
+                 sA=sS, sB=(T2 * ldk, dk), sC=(T1 * lddq, dk))
         # dK[b,:,h] = ds[h,b]^T Qu[b,:,h]
-        ops.gemm(T2, dk, T1, ds, T2, qu, ldq, dk_buf, lddk, b_off=q_off, c_off=dk_off, a_kmajor=True, b_kmajor=True,
-                 nb1=B, nb2=H, sA=(T1 * T2, B * T1 * T2), sB=(T1 * ldq, dk), sC=(T2 * lddk, dk))
+        ops.gemm(T2, dk, T1, ds, S, qu, ldq, dk_buf, lddk, b_off=q_off, c_off=dk_off, a_kmajor=True, b_kmajor=True,
+                 nb1=B, nb2=H, sA=sS, sB=(T1 * ldq, dk), sC=(T2 * lddk, dk))
         if p is None:
             return None, None
         W = 2 * T1 - 1
+        Wp = sk.shape[-1]
         dqv = ops.empty(B * T1, D, like=dctx)
         # dQv[b,:,h] = ds_skew[h,b] P[:,h]
-        ops.gemm(T1, dk, W, sk, W, p, D, dqv, D, b_kmajor=True, nb1=B, nb2=H, sA=(T1 * W, B * T1 * W), sB=(0, dk),
+        ops.gemm(T1, dk, W, sk, Wp, p, D, dqv, D, b_kmajor=True, nb1=B, nb2=H, sA=(T1 * Wp, B * T1 * Wp), sB=(0, dk),
                  sC=(T1 * D, dk))
         # dP[:,h] = sum_b ds_skew[h,b]^T Qv[b,:,h]  == one K = B*T1 GEMM per head
         dp = ops.empty(W, D, like=dctx)
-        ops.gemm(W, dk, B * T1, sk, W, qv, D, dp, D, a_kmajor=True, b_kmajor=True, nb1=H, sA=(B * T1 * W, 0),
+        ops.gemm(W, dk, B * T1, sk, Wp, qv, D, dp, D, a_kmajor=True, b_kmajor=True, nb1=H, sA=(B * T1 * Wp, 0),
                  sB=(dk, 0), sC=(dk, 0))
         return dqv, dp
 

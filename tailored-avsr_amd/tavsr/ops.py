@@ -28,8 +28,9 @@ class GemmProfile:
     """Optional per-launch timing of tavsr_gemm with HIP events on the launch stream (bench.py's roofline
     leg).  Off on the product path (``PROFILE is None``): zero overhead."""
 
-    def __init__(self):
+    def __init__(self, by_shape: bool = False):
         self.records = []  # (key, flops, start_event, end_event)
+        self.by_shape = by_shape
 
     def summary(self):
         torch.cuda.synchronize()
@@ -76,6 +77,10 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.sR1, d.sR2 = sR
     if DZ is not None:
         d.DZ, d.dact = _addr(DZ, c_off), ACT[dact]
+    need = lib().tavsr_gemm_ws(C.byref(d))
+    if need > 0:
+        ws = torch.empty(need, dtype=f32, device=Cc.device)
+        d.ws, d.ws_floats = ws.data_ptr(), need
     if PROFILE is None:
         check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
         return
@@ -83,7 +88,10 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
     e0.record()
     check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
     e1.record()
-    PROFILE.records.append((_gemm_kernel_key(d), 2.0 * M * N * K * max(1, nb1) * max(1, nb2), e0, e1))
+    key = _gemm_kernel_key(d)
+    if PROFILE.by_shape:
+        key += f" M={M} N={N} K={K} nb={max(1, nb1) * max(1, nb2)}"
+    PROFILE.records.append((key, 2.0 * M * N * K * max(1, nb1) * max(1, nb2), e0, e1))
 
 
 def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None):
@@ -176,23 +184,34 @@ def add_head_bias(q, u, v):
     return qu, qv
 
 
-def softmax_fwd(ac, bd, klens, scale, causal=False):
-    H, B, T1, T2 = ac.shape
+def pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def softmax_fwd(ac, bd, klens, scale, causal=False, T2=None, W=0):
+    """ac [H,B,T1,ld_s] (ld_s >= T2, padded rows), bd [H,B,T1,ld_w] or None -> attn like ac."""
+    H, B, T1, ld_s = ac.shape
+    T2 = ld_s if T2 is None else T2
     attn = torch.empty_like(ac)
-    W = 0 if bd is None else bd.shape[-1]
+    ld_w = 0
+    if bd is not None:
+        ld_w = bd.shape[-1]
+        W = W or ld_w
     require_cuda(ac, bd, klens)
-    check(lib().tavsr_softmax_fwd(ptr(ac), ptr(bd), ptr(klens), ptr(attn), H, B, T1, T2, W, C.c_float(scale),
-                                  int(causal), stream()), "tavsr_softmax_fwd")
+    check(lib().tavsr_softmax_fwd(ptr(ac), ptr(bd), ptr(klens), ptr(attn), H, B, T1, T2, W, C.c_int64(ld_s),
+                                  C.c_int64(ld_w), C.c_float(scale), int(causal), stream()), "tavsr_softmax_fwd")
     return attn
 
 
-def softmax_bwd(attn, dattn, scale, skew=False):
-    H, B, T1, T2 = attn.shape
+def softmax_bwd(attn, dattn, scale, skew=False, T2=None):
+    H, B, T1, ld_s = attn.shape
+    T2 = ld_s if T2 is None else T2
     ds = torch.empty_like(attn)
     W = 2 * T1 - 1 if skew else 0
-    sk = empty(H, B, T1, W, like=attn) if skew else None
-    check(lib().tavsr_softmax_bwd(ptr(attn), ptr(dattn), ptr(ds), ptr(sk), H, B, T1, T2, W, C.c_float(scale), stream()),
-          "tavsr_softmax_bwd")
+    ld_w = pad4(W)
+    sk = empty(H, B, T1, ld_w, like=attn) if skew else None
+    check(lib().tavsr_softmax_bwd(ptr(attn), ptr(dattn), ptr(ds), ptr(sk), H, B, T1, T2, W, C.c_int64(ld_s),
+                                  C.c_int64(ld_w), C.c_float(scale), stream()), "tavsr_softmax_bwd")
     return ds, sk
 
 

@@ -117,3 +117,37 @@ def test_gemm_rejects_bad_descriptor():
     d.M, d.N, d.K = 4, 4, 4
     assert L.lib().tavsr_gemm(C.byref(d), L.stream()) == -1
     assert b"null operand" in L.lib().tavsr_last_error_string()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 3168), (2048, 256, 3168), (197, 64, 3168), (41, 256, 1312), (3168, 256, 2048)])
+def test_gemm_splitk_paths(M, N, K):
+    """few-tile / long-K problems go through the split-K slabs + fused reduce epilogue (ops.gemm gives the workspace)."""
+    from tavsr import ops
+    torch.manual_seed(3)
+    dy, x = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda")
+    got = ops.linear_dw(dy, x, alpha=0.5)
+    ref = 0.5 * dy.double().t() @ x.double()
+    assert (got.double() - ref).abs().max() / ref.abs().max() < 2e-6
+    a, w, b, r = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") / 30, torch.randn(N, device="cuda"), torch.randn(M, N, device="cuda")
+    y, z = ops.linear(a, w, b, act="swish", alpha=0.5, res=r, save_z=True)
+    zr = a.double() @ w.double().t() + b.double()
+    assert (z.double() - zr).abs().max() < 1e-4
+    assert (y.double() - (r.double() + 0.5 * zr * torch.sigmoid(zr))).abs().max() < 1e-4
+
+
+def test_gemm_unaligned_tail_vector_path():
+    """K (or M) not a multiple of 4 with 16-byte aligned rows: vector loads + predicated tail."""
+    from tavsr import ops
+    torch.manual_seed(4)
+    T, W, dk = 99, 197, 64
+    sk = torch.randn(T, 200, device="cuda")          # padded rows, W valid columns
+    p = torch.randn(W, dk, device="cuda")
+    out = ops.empty(T, dk, like=sk)
+    ops.gemm(T, dk, W, sk, 200, p, dk, out, dk, b_kmajor=True)
+    ref = sk[:, :W].double() @ p.double()
+    assert (out.double() - ref).abs().max() / ref.abs().max() < 2e-6
+    out2 = ops.empty(W, dk, like=sk)                  # TN with M = W = 197 (row direction tail)
+    q = torch.randn(T, dk, device="cuda")
+    ops.gemm(W, dk, T, sk, 200, q, dk, out2, dk, a_kmajor=True, b_kmajor=True)
+    ref2 = sk[:, :W].double().t() @ q.double()
+    assert (out2.double() - ref2).abs().max() / ref2.abs().max() < 2e-6
