@@ -64,13 +64,18 @@ typedef struct tavsr_gemm_desc {
   const float* R; int64_t ldr; int64_t sR1, sR2;
   const float* DZ; int32_t dact;
   float* ws; int64_t ws_floats;   /* optional split-K workspace (>= tavsr_gemm_ws(desc) floats), may be NULL */
+  float* a_rowsum;                /* optional [M]: alpha * sum_k A(m,k) (nb1*nb2 == 1).  With a_kmajor (weight
+                                     gradient dW = dY^T X) this is the bias gradient sum_rows dY - fused, so no
+                                     separate column-sum pass over dY is needed */
 } tavsr_gemm_desc;
 
 int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);
 /* floats of workspace with which tavsr_gemm will split K over workgroups (0: not needed).  Few-tile, long-K
- * problems (weight gradients, K = B*T) are split so the whole chip works; the slabs are summed in a fixed
- * order (deterministic) by a second kernel that also applies the epilogue. */
+ * problems (weight gradients, K = B*T) are split so the whole chip works; each slice stores an fp32 slab and a
+ * second kernel sums the slabs in slice order (deterministic) and applies the epilogue. */
 int64_t tavsr_gemm_ws(const tavsr_gemm_desc* desc);
+/* tuning/bench entry: force tile configuration cfg (see kCfgs in csrc/gemm.hip; BK = 32) and a K split (<= 1: none; needs ws/sync large enough) instead of the planner's choice. */
+int tavsr_gemm_tune(const tavsr_gemm_desc* desc, int32_t cfg, int32_t nsplit, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (espnet LayerNorm = torch.nn.LayerNorm(eps=1e-12); the five norms of

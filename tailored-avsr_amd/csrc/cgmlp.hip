@@ -49,7 +49,13 @@ __global__ __launch_bounds__(256) void dwconv_gate_fwd_kernel(const float* __res
 }
 
 // du -> dr = du*conv ; dconv = du*r ; dgn[t] = sum_k w[c,k]*dconv[t-k+pad] ;
-// partial dw[c,k] = sum_t dconv[t]*gn[t+k-pad], partial dbias[c] = sum_t dconv[t]  (per block slab)
+// dw[c,k] = sum_{b,t} dconv[t]*gn[t+k-pad], dbias[c] = sum_{b,t} dconv[t].
+// One block per (64 channels, utterance): it walks the utterance in time tiles of CG_TB steps (dconv and gn tiles
+// with their conv halo in LDS, lanes = consecutive channels: coalesced and bank-conflict free) and keeps the
+// weight-gradient sums in registers - thread (channel c, wave y) owns taps k = y, y+4, ... (tap K is the bias) - so
+// there is no cross-thread reduction and one partial slab [C][K+1] per utterance, summed by sum_partials_kernel.
+constexpr int CG_TB = 64;                      // time steps per tile in the backward kernel
+constexpr int CG_TAPS = (CG_KMAX + 1 + 3) / 4;  // taps per thread
 __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(const float* __restrict__ du, const float* __restrict__ gn,
                                                               const float* __restrict__ r, int64_t ldr,
                                                               const float* __restrict__ conv,
@@ -58,59 +64,69 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(const float* __res
                                                               float* __restrict__ part, int B, int T, int C, int K) {
   extern __shared__ float sm[];
   const int pad = (K - 1) / 2;
-  const int rows = CG_TT + K - 1;
+  const int rows = CG_TB + K - 1;
   float* s_d = sm;                         // dconv with halo [rows][CG_CH]
   float* s_g = s_d + rows * CG_CH;         // gn with halo    [rows][CG_CH]
   float* s_w = s_g + rows * CG_CH;         // [K][CG_CH]
-  float* s_red = s_w + K * CG_CH;          // [4][CG_CH]
   const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c0 = blockIdx.x * CG_CH, t0 = blockIdx.y * CG_TT, b = blockIdx.z;
+  const int c0 = blockIdx.x * CG_CH, b = blockIdx.y;
   const int c = c0 + cx;
-  for (int i = ty; i < rows; i += 4) {
-    int t = t0 + i - pad;
-    float dv = 0.f, gv = 0.f;
-    if (t >= 0 && t < T && c < C) {
-      int64_t m = (int64_t)b * T + t;
-      dv = du[m * C + c] * r[m * ldr + c];
-      gv = gn[m * C + c];
-    }
-    s_d[i * CG_CH + cx] = dv;
-    s_g[i * CG_CH + cx] = gv;
-  }
-  for (int k = ty; k < K; k += 4) s_w[k * CG_CH + cx] = c < C ? w[(int64_t)c * K + k] : 0.f;
-  __syncthreads();
-  // data gradients for the block's own time steps (centre rows pad .. pad+CG_TT)
-  if (c < C) {
-    for (int tt = ty; tt < CG_TT; tt += 4) {
-      int t = t0 + tt;
-      if (t >= T) break;
-      int64_t m = (int64_t)b * T + t;
-      dr[m * lddr + c] = du[m * C + c] * conv[m * C + c];
-      float acc = 0.f;
-      // dgn[t] = sum_k w[k] * dconv[t - k + pad]  -> LDS row (tt + pad) - k + pad
-      for (int k = 0; k < K; ++k) acc += s_w[k * CG_CH + cx] * s_d[(tt + 2 * pad - k) * CG_CH + cx];
-      dgn[m * C + c] = acc;
-    }
-  }
-  // weight-gradient partials over this block's time steps: dw[k] = sum_t dconv[t] * gn[t + k - pad]
-  const int nblk = gridDim.y * gridDim.z;
-  const int blk = blockIdx.z * gridDim.y + blockIdx.y;
-  float* pw = part + (int64_t)blk * C * (K + 1);
-  for (int k = 0; k <= K; ++k) {
-    float acc = 0.f;
-    for (int tt = ty; tt < CG_TT; tt += 4) {
-      float dv = s_d[(tt + pad) * CG_CH + cx];
-      acc += (k < K) ? dv * s_g[(tt + k) * CG_CH + cx] : dv;
-    }
-    s_red[ty * CG_CH + cx] = acc;
-    __syncthreads();
-    if (ty == 0 && c < C) {
-      float s = (s_red[cx] + s_red[CG_CH + cx]) + (s_red[2 * CG_CH + cx] + s_red[3 * CG_CH + cx]);
-      pw[(int64_t)c * (K + 1) + k] = s;   // [C][K+1]: k == K holds the bias partial
+  const bool cok = c < C;
+  for (int k = ty; k < K; k += 4) s_w[k * CG_CH + cx] = cok ? w[(int64_t)c * K + k] : 0.f;
+  float acc[CG_TAPS];
+#pragma unroll
+  for (int j = 0; j < CG_TAPS; ++j) acc[j] = 0.f;
+  const int ntap = (K + 1 - ty + 3) / 4;   // taps ty, ty+4, ... <= K
+  for (int t0 = 0; t0 < T; t0 += CG_TB) {
+    __syncthreads();   // previous tile fully consumed (and s_w visible)
+    for (int i = ty; i < rows; i += 4) {
+      const int t = t0 + i - pad;
+      float dv = 0.f, gv = 0.f;
+      if (t >= 0 && t < T && cok) {
+        const int64_t m = (int64_t)b * T + t;
+        dv = du[m * C + c] * r[m * ldr + c];
+        gv = gn[m * C + c];
+      }
+      s_d[i * CG_CH + cx] = dv;
+      s_g[i * CG_CH + cx] = gv;
     }
     __syncthreads();
+    const int nt = min(CG_TB, T - t0);
+    if (cok) {
+      // data gradients: rows tt = ty, ty+4, ...
+      for (int tt = ty; tt < nt; tt += 4) {
+        const int64_t m = (int64_t)b * T + t0 + tt;
+        dr[m * lddr + c] = du[m * C + c] * conv[m * C + c];
+        float a0 = 0.f, a1 = 0.f;
+        int k = 0;
+        // dgn[t] = sum_k w[k] * dconv[t - k + pad]  -> LDS row (tt + pad) - k + pad
+        for (; k + 1 < K; k += 2) {
+          a0 += s_w[k * CG_CH + cx] * s_d[(tt + 2 * pad - k) * CG_CH + cx];
+          a1 += s_w[(k + 1) * CG_CH + cx] * s_d[(tt + 2 * pad - k - 1) * CG_CH + cx];
+        }
+        if (k < K) a0 += s_w[k * CG_CH + cx] * s_d[(tt + 2 * pad - k) * CG_CH + cx];
+        dgn[m * C + c] = a0 + a1;
+      }
+      // weight gradient: acc[j] += dconv[t] * gn[t + k - pad], k = ty + 4j (k == K: bias)
+      for (int tt = 0; tt < nt; ++tt) {
+        const float dv = s_d[(tt + pad) * CG_CH + cx];
+        const float* g = s_g + (tt + ty) * CG_CH + cx;
+#pragma unroll
+        for (int j = 0; j < CG_TAPS; ++j) {
+          if (j < ntap) {
+            const int k = ty + 4 * j;
+            acc[j] += dv * (k < K ? g[4 * j * CG_CH] : 1.f);
+          }
+        }
+      }
+    }
   }
-  (void)nblk;
+  if (cok) {
+    float* pw = part + ((int64_t)b * C + c) * (K + 1);
+#pragma unroll
+    for (int j = 0; j < CG_TAPS; ++j)
+      if (j < ntap) pw[ty + 4 * j] = acc[j];   // [C][K+1]: k == K holds the bias partial
+  }
 }
 
 // split [C][K+1] summed slab into dw[C][K] and dbias[C]
@@ -125,7 +141,8 @@ __global__ void dwconv_split_kernel(const float* __restrict__ sum, float* __rest
 }
 
 // ------------------------------- learned_ave merge ---------------------------------------------
-// One block per utterance b.  For branch k in {1,2}:
+// One 512-thread block per utterance b: waves 0-3 work on branch 1, waves 4-7 on branch 2, in lock step.
+// For branch k in {1,2}:
 //   score_k[t] = softmax_t( (x_k[t,:] . wp_k + bp_k) / sqrt(D) ) over t < len, 0 beyond
 //   pooled_k   = sum_t score_k[t] x_k[t,:] ;  weight_k = pooled_k . ww_k + bw_k
 //   (w1, w2) = softmax(weight_1, weight_2)
@@ -133,63 +150,101 @@ struct MergeParams {
   const float* wp[2]; const float* bp[2]; const float* ww[2]; const float* bw[2];
 };
 
-__global__ __launch_bounds__(256) void merge_pool_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+// sum over the 256 threads of one half of the block (s_red: 4 floats of that half)
+__device__ __forceinline__ float half_sum(float v, float* s_red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[(threadIdx.x >> 6) & 3] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__device__ __forceinline__ float half_max(float v, float* s_red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[(threadIdx.x >> 6) & 3] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+}
+
+// dot[t] = <x[t,:], v> for the rows of one utterance (x rows are D floats, D % 4 == 0): one wave per row,
+// eight rows (eight 16-byte loads per lane) in flight per wave
+__device__ __forceinline__ void row_dots(const float* __restrict__ x, const float* __restrict__ v, int len, int T, int D,
+                                         int wv, int lane, float bias, float scale, float* __restrict__ out) {
+  const int D4 = D >> 2;
+  for (int tb = wv * 8; tb < T; tb += 32) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int c4 = lane; c4 < D4; c4 += 64) {
+      const float4 wv4 = reinterpret_cast<const float4*>(v)[c4];
+      float4 xv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = tb + i;
+        xv[i] = t < len ? reinterpret_cast<const float4*>(x + (int64_t)t * D)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += (xv[i].x * wv4.x + xv[i].y * wv4.y) + (xv[i].z * wv4.z + xv[i].w * wv4.w);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float r = wave_sum(acc[i]);
+      if (lane == 0 && tb + i < T) out[tb + i] = (r + bias) * scale;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void merge_pool_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                              const int64_t* __restrict__ lens, MergeParams p,
                                                              float* __restrict__ score, float* __restrict__ pooled,
                                                              float* __restrict__ wout, int B, int T, int D) {
   extern __shared__ float sm[];
-  float* s_sc = sm;        // [T]
-  float* s_red = sm + T;   // [8]
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = threadIdx.x >> 8;            // branch of this half
+  const int ht = threadIdx.x & 255;          // thread within the half
+  float* s_sc = sm + k * T;                  // [2][T]
+  float* s_red = sm + 2 * T + k * 4;         // [2][4]
+  float* s_w = sm + 2 * T + 8;               // [2] branch logits
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = ht >> 6;
   const int len = lens ? (int)min((int64_t)T, lens[b]) : T;
   const float inv_sqrt_d = 1.f / sqrtf((float)D);
-  float weight[2];
-  for (int k = 0; k < 2; ++k) {
-    const float* x = (k == 0 ? x1 : x2) + (int64_t)b * T * D;
-    for (int t = wv; t < T; t += 4) {
-      float acc = 0.f;
-      if (t < len)
-        for (int c = lane; c < D; c += 64) acc += x[(int64_t)t * D + c] * p.wp[k][c];
-      acc = wave_sum(acc);
-      if (lane == 0) s_sc[t] = (acc + p.bp[k][0]) * inv_sqrt_d;
-    }
-    __syncthreads();
-    float mx = -FLT_MAX;
-    for (int t = threadIdx.x; t < len; t += 256) mx = fmaxf(mx, s_sc[t]);
-    mx = wave_max(mx);
-    if (lane == 0) s_red[wv] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    float sum = 0.f;
-    for (int t = threadIdx.x; t < len; t += 256) sum += expf(s_sc[t] - mx);
-    sum = wave_sum(sum);
-    if (lane == 0) s_red[4 + wv] = sum;
-    __syncthreads();
-    sum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-    const float inv = len > 0 ? 1.f / sum : 0.f;
-    for (int t = threadIdx.x; t < T; t += 256) {
-      float v = t < len ? expf(s_sc[t] - mx) * inv : 0.f;
-      s_sc[t] = v;
-      score[((int64_t)k * B + b) * T + t] = v;
-    }
-    __syncthreads();
-    float wacc = 0.f;
-    for (int c = threadIdx.x; c < D; c += 256) {
-      float acc = 0.f;
-      for (int t = 0; t < len; ++t) acc += s_sc[t] * x[(int64_t)t * D + c];
-      pooled[((int64_t)k * B + b) * D + c] = acc;
-      wacc += acc * p.ww[k][c];
-    }
-    wacc = wave_sum(wacc);
-    __syncthreads();
-    if (lane == 0) s_red[wv] = wacc;
-    __syncthreads();
-    weight[k] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]) + p.bw[k][0];
-    __syncthreads();
+  const float* x = (k == 0 ? x1 : x2) + (int64_t)b * T * D;
+  row_dots(x, p.wp[k], len, T, D, wv, lane, p.bp[k][0], inv_sqrt_d, s_sc);
+  __syncthreads();
+  float mx = -FLT_MAX;
+  for (int t = ht; t < len; t += 256) mx = fmaxf(mx, s_sc[t]);
+  mx = half_max(mx, s_red);
+  float sum = 0.f;
+  for (int t = ht; t < len; t += 256) sum += expf(s_sc[t] - mx);
+  sum = half_sum(sum, s_red);
+  const float inv = len > 0 ? 1.f / sum : 0.f;
+  __syncthreads();
+  for (int t = ht; t < T; t += 256) {
+    float v = t < len ? expf(s_sc[t] - mx) * inv : 0.f;
+    s_sc[t] = v;
+    score[((int64_t)k * B + b) * T + t] = v;
   }
+  __syncthreads();
+  float wacc = 0.f;
+  for (int c = ht; c < D; c += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int t = 0;
+    for (; t + 3 < len; t += 4) {
+      a0 += s_sc[t] * x[(int64_t)t * D + c];
+      a1 += s_sc[t + 1] * x[(int64_t)(t + 1) * D + c];
+      a2 += s_sc[t + 2] * x[(int64_t)(t + 2) * D + c];
+      a3 += s_sc[t + 3] * x[(int64_t)(t + 3) * D + c];
+    }
+    for (; t < len; ++t) a0 += s_sc[t] * x[(int64_t)t * D + c];
+    const float acc = (a0 + a1) + (a2 + a3);
+    pooled[((int64_t)k * B + b) * D + c] = acc;
+    wacc += acc * p.ww[k][c];
+  }
+  wacc = half_sum(wacc, s_red);
+  if (ht == 0) s_w[k] = wacc + p.bw[k][0];
+  __syncthreads();
   if (threadIdx.x == 0) {
-    float m = fmaxf(weight[0], weight[1]);
-    float e0 = expf(weight[0] - m), e1 = expf(weight[1] - m);
+    float m = fmaxf(s_w[0], s_w[1]);
+    float e0 = expf(s_w[0] - m), e1 = expf(s_w[1] - m);
     wout[b * 2 + 0] = e0 / (e0 + e1);
     wout[b * 2 + 1] = e1 / (e0 + e1);
   }
@@ -207,92 +262,114 @@ __global__ void merge_combine_kernel(const float* __restrict__ x1, const float* 
                                                   w1 * a.w + w2 * c.w);
 }
 
-__device__ __forceinline__ float block_sum256(float v, float* s_red) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-}
-
-// Backward of pool + combine for one utterance per block.
+// Backward of pool + combine: one 512-thread block per utterance, one branch per half (as the forward).
 // part[b] = { dwp1[D], dwp2[D], dww1[D], dww2[D], dbp1, dbp2, dbw1, dbw2 }  (4*D + 4 floats)
-__global__ __launch_bounds__(256) void merge_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ x1,
+__global__ __launch_bounds__(512) void merge_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ x1,
                                                         const float* __restrict__ x2, const int64_t* __restrict__ lens,
                                                         MergeParams p, const float* __restrict__ score,
                                                         const float* __restrict__ pooled, const float* __restrict__ w,
                                                         float* __restrict__ dx1, float* __restrict__ dx2,
                                                         float* __restrict__ part, int B, int T, int D) {
   extern __shared__ float sm[];
-  float* s_ds = sm;            // [T]  d(score) then ds_pre
-  float* s_dp = sm + T;        // [D]  dpooled
-  float* s_red = s_dp + D;     // [4]
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = threadIdx.x >> 8, ht = threadIdx.x & 255;
+  float* s_ds = sm + k * T;                 // [2][T]  d(score) then ds_pre
+  float* s_dp = sm + 2 * T + k * D;         // [2][D]  dpooled
+  float* s_red = sm + 2 * T + 2 * D + k * 4;   // [2][4]
+  float* s_a = sm + 2 * T + 2 * D + 8;      // [2][8] per-wave partials of <dm,x1>, <dm,x2>
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = ht >> 6, wv8 = threadIdx.x >> 6;
   const int len = lens ? (int)min((int64_t)T, lens[b]) : T;
   const int64_t base = (int64_t)b * T * D;
   const float inv_sqrt_d = 1.f / sqrtf((float)D);
   const float w1 = w[b * 2], w2 = w[b * 2 + 1];
-  // dL/dw_k = <dm, x_k>
+  // dL/dw_k = <dm, x_k>: all 512 threads stream the utterance once (16-byte loads)
   float a1 = 0.f, a2 = 0.f;
-  for (int64_t i = threadIdx.x; i < (int64_t)T * D; i += 256) {
-    float g = dm[base + i];
-    a1 += g * x1[base + i];
-    a2 += g * x2[base + i];
+  {
+    const float4* g4 = reinterpret_cast<const float4*>(dm + base);
+    const float4* p1 = reinterpret_cast<const float4*>(x1 + base);
+    const float4* p2 = reinterpret_cast<const float4*>(x2 + base);
+    const int64_t n4 = (int64_t)T * D / 4;
+    for (int64_t i = threadIdx.x; i < n4; i += 512) {
+      const float4 g = g4[i], u = p1[i], v = p2[i];
+      a1 += (g.x * u.x + g.y * u.y) + (g.z * u.z + g.w * u.w);
+      a2 += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
+    }
   }
-  a1 = block_sum256(a1, s_red);
-  a2 = block_sum256(a2, s_red);
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (lane == 0) { s_a[wv8] = a1; s_a[8 + wv8] = a2; }
+  __syncthreads();
+  a1 = a2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a1 += s_a[i]; a2 += s_a[8 + i]; }
   const float dotw = w1 * a1 + w2 * a2;
-  const float dweight[2] = {w1 * (a1 - dotw), w2 * (a2 - dotw)};
+  const float dweight = k == 0 ? w1 * (a1 - dotw) : w2 * (a2 - dotw);
   float* pb = part + (int64_t)b * (4 * D + 4);
-  for (int k = 0; k < 2; ++k) {
-    const float* x = (k == 0 ? x1 : x2) + base;
-    float* dx = (k == 0 ? dx1 : dx2) + base;
-    const float* sc = score + ((int64_t)k * B + b) * T;
-    const float* po = pooled + ((int64_t)k * B + b) * D;
-    const float wk = k == 0 ? w1 : w2;
-    for (int c = threadIdx.x; c < D; c += 256) {
-      s_dp[c] = dweight[k] * p.ww[k][c];
-      pb[(2 + k) * D + c] = dweight[k] * po[c];  // dww_k
-    }
-    __syncthreads();
-    // dscore[t] = <dpooled, x[t,:]>
-    for (int t = wv; t < T; t += 4) {
-      float acc = 0.f;
-      if (t < len)
-        for (int c = lane; c < D; c += 64) acc += s_dp[c] * x[(int64_t)t * D + c];
-      acc = wave_sum(acc);
-      if (lane == 0) s_ds[t] = acc;
-    }
-    __syncthreads();
-    float dot = 0.f;
-    for (int t = threadIdx.x; t < len; t += 256) dot += sc[t] * s_ds[t];
-    dot = block_sum256(dot, s_red);
-    float sb = 0.f;
-    for (int t = threadIdx.x; t < T; t += 256) {
-      float v = t < len ? sc[t] * (s_ds[t] - dot) * inv_sqrt_d : 0.f;
-      s_ds[t] = v;  // ds_pre
-      sb += v;
-    }
-    sb = block_sum256(sb, s_red);  // also orders the s_ds writes before the reads below
-    if (threadIdx.x == 0) {
-      pb[4 * D + k] = sb;               // dbp_k
-      pb[4 * D + 2 + k] = dweight[k];   // dbw_k
-    }
-    // dx_k and dwp_k
-    for (int c = threadIdx.x; c < D; c += 256) {
-      const float wpc = p.wp[k][c], dpc = s_dp[c];
-      float acc = 0.f;
-      for (int t = 0; t < T; ++t) {
-        int64_t o = (int64_t)t * D + c;
-        float xv = x[o];
-        float s = t < len ? sc[t] : 0.f;
-        dx[o] = wk * dm[base + o] + s * dpc + s_ds[t] * wpc;
-        acc += s_ds[t] * xv;
-      }
-      pb[k * D + c] = acc;  // dwp_k
-    }
-    __syncthreads();
+  const float* x = (k == 0 ? x1 : x2) + base;
+  float* dx = (k == 0 ? dx1 : dx2) + base;
+  const float* sc = score + ((int64_t)k * B + b) * T;
+  const float* po = pooled + ((int64_t)k * B + b) * D;
+  const float wk = k == 0 ? w1 : w2;
+  for (int c = ht; c < D; c += 256) {
+    s_dp[c] = dweight * p.ww[k][c];
+    pb[(2 + k) * D + c] = dweight * po[c];  // dww_k
   }
+  __syncthreads();
+  // dscore[t] = <dpooled, x[t,:]>
+  row_dots(x, s_dp, len, T, D, wv, lane, 0.f, 1.f, s_ds);
+  __syncthreads();
+  float dot = 0.f;
+  for (int t = ht; t < len; t += 256) dot += sc[t] * s_ds[t];
+  dot = half_sum(dot, s_red);
+  float sb = 0.f;
+  __syncthreads();
+  for (int t = ht; t < T; t += 256) {
+    float v = t < len ? sc[t] * (s_ds[t] - dot) * inv_sqrt_d : 0.f;
+    s_ds[t] = v;  // ds_pre
+    sb += v;
+  }
+  sb = half_sum(sb, s_red);  // also orders the s_ds writes before the reads below
+  if (ht == 0) {
+    pb[4 * D + k] = sb;            // dbp_k
+    pb[4 * D + 2 + k] = dweight;   // dbw_k
+  }
+  // dx_k and dwp_k: thread = channel, four time steps per iteration in flight
+  for (int c = ht; c < D; c += 256) {
+    const float wpc = p.wp[k][c], dpc = s_dp[c];
+    float acc = 0.f;
+    int t = 0;
+    for (; t + 3 < T; t += 4) {
+      float xv[4], gv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t o = (int64_t)(t + i) * D + c;
+        xv[i] = x[o];
+        gv[i] = dm[base + o];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float s = t + i < len ? sc[t + i] : 0.f;
+        dx[(int64_t)(t + i) * D + c] = wk * gv[i] + s * dpc + s_ds[t + i] * wpc;
+        acc += s_ds[t + i] * xv[i];
+      }
+    }
+    for (; t < T; ++t) {
+      const int64_t o = (int64_t)t * D + c;
+      const float s = t < len ? sc[t] : 0.f;
+      dx[o] = wk * dm[base + o] + s * dpc + s_ds[t] * wpc;
+      acc += s_ds[t] * x[o];
+    }
+    pb[k * D + c] = acc;  // dwp_k
+  }
+}
+
+// scatter the summed merge-gradient slab {dwp1, dwp2, dww1, dww2 [D each], dbp1, dbp2, dbw1, dbw2} to the eight
+// parameter gradients (one launch instead of eight)
+struct MergeGradPtrs { float* g[8]; };
+__global__ void merge_scatter_kernel(const float* __restrict__ sum, MergeGradPtrs o, int D, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * D + 4) return;
+  float* dst = i < 4 * D ? o.g[i / D] + (i % D) : o.g[4 + (i - 4 * D)];
+  *dst = accumulate ? *dst + sum[i] : sum[i];
 }
 
 }  // namespace tavsr
@@ -313,7 +390,8 @@ extern "C" int tavsr_dwconv_gate_fwd(const float* gn, const float* r, int64_t ld
 }
 
 extern "C" int64_t tavsr_dwconv_gate_bwd_ws(int32_t B, int32_t T, int32_t C, int32_t K) {
-  return ((int64_t)B * cdiv(T, CG_TT) + 1) * C * (K + 1);
+  (void)T;
+  return ((int64_t)B + 1) * C * (K + 1);
 }
 
 extern "C" int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv,
@@ -325,12 +403,11 @@ extern "C" int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const flo
   TAVSR_REQUIRE(K >= 1 && K <= CG_KMAX && (K & 1), TAVSR_EUNSUPPORTED, "dwconv_gate_bwd: odd K <= %d required", CG_KMAX);
   if (B <= 0 || T <= 0 || C <= 0) return TAVSR_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int ty = cdiv(T, CG_TT);
-  size_t lds = (2 * (CG_TT + K - 1) * CG_CH + K * CG_CH + 4 * CG_CH) * sizeof(float);
-  hipLaunchKernelGGL(dwconv_gate_bwd_kernel, dim3(cdiv(C, CG_CH), ty, B), dim3(256), lds, s, du, gn, r, ldr, conv, w, dr,
+  size_t lds = (2 * (CG_TB + K - 1) * CG_CH + K * CG_CH) * sizeof(float);
+  hipLaunchKernelGGL(dwconv_gate_bwd_kernel, dim3(cdiv(C, CG_CH), B), dim3(256), lds, s, du, gn, r, ldr, conv, w, dr,
                      lddr, dgn, ws, B, T, C, K);
   TAVSR_LAUNCH_CHECK();
-  const int nblk = B * ty, n = C * (K + 1);
+  const int nblk = B, n = C * (K + 1);
   float* sum = ws + (int64_t)nblk * n;
   int rc = tavsr_sum_partials(ws, nblk, n, sum, n, 0, stream);
   if (rc) return rc;
@@ -356,9 +433,11 @@ extern "C" int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int6
   TAVSR_REQUIRE(x1 && x2 && params && score && pooled && w, TAVSR_EINVAL, "merge_pool_fwd: null pointer");
   for (int i = 0; i < 8; ++i) TAVSR_REQUIRE(params[i], TAVSR_EINVAL, "merge_pool_fwd: null parameter %d", i);
   if (B <= 0) return TAVSR_OK;
-  size_t lds = (T + 8) * sizeof(float);
+  TAVSR_REQUIRE(D % 4 == 0 && ((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0), TAVSR_EALIGN,
+                "merge_pool_fwd: D %% 4 == 0 and 16-byte aligned rows required");
+  size_t lds = (2 * T + 16) * sizeof(float);
   TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_pool_fwd: T=%d too long", T);
-  hipLaunchKernelGGL(merge_pool_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x1, x2, lens, mk(params),
+  hipLaunchKernelGGL(merge_pool_fwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, x1, x2, lens, mk(params),
                      score, pooled, w, B, T, D);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
@@ -387,17 +466,23 @@ extern "C" int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2
   TAVSR_REQUIRE(dm && x1 && x2 && params && score && pooled && w && dx1 && dx2 && dparams && ws, TAVSR_EINVAL,
                 "merge_bwd: null pointer");
   if (B <= 0) return TAVSR_OK;
-  size_t lds = (T + D + 4) * sizeof(float);
+  TAVSR_REQUIRE(D % 4 == 0 && ((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0) && ((uintptr_t)dm % 16 == 0),
+                TAVSR_EALIGN, "merge_bwd: D %% 4 == 0 and 16-byte aligned rows required");
+  size_t lds = (2 * T + 2 * D + 32) * sizeof(float);
   TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_bwd: T=%d too long", T);
-  hipLaunchKernelGGL(merge_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dm, x1, x2, lens, mk(params), score,
+  hipLaunchKernelGGL(merge_bwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, dm, x1, x2, lens, mk(params), score,
                      pooled, w, dx1, dx2, ws, B, T, D);
   TAVSR_LAUNCH_CHECK();
   const int n = 4 * D + 4;
   float* sum = ws + (int64_t)B * n;
   int rc = tavsr_sum_partials(ws, B, n, sum, n, 0, stream);
   if (rc) return rc;
-  // scatter the summed slab to the eight parameter gradients
-  for (int i = 0; i < 4 && !rc; ++i) rc = tavsr_sum_partials(sum + (int64_t)i * D, 1, 0, dparams[i], D, accumulate, stream);
-  for (int i = 0; i < 4 && !rc; ++i) rc = tavsr_sum_partials(sum + 4 * D + i, 1, 0, dparams[4 + i], 1, accumulate, stream);
-  return rc;
+  MergeGradPtrs o;
+  for (int i = 0; i < 8; ++i) {
+    TAVSR_REQUIRE(dparams[i], TAVSR_EINVAL, "merge_bwd: null gradient pointer %d", i);
+    o.g[i] = dparams[i];
+  }
+  hipLaunchKernelGGL(merge_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, sum, o, D, accumulate);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
 }

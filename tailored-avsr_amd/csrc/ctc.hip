@@ -133,6 +133,99 @@ __global__ __launch_bounds__(256) void ctc_loss_kernel(const float* __restrict__
   }
 }
 
+// Fast path of the same computation when the whole lattice fits in LDS (T*(V + 2*Smax) floats <= ~150 KB; the
+// shipped configs: T = 99, V = 41, Smax = 81 -> 80 KB): log-probabilities, alpha and beta live in LDS, the alpha
+// step of frame t and the beta step of frame Tb-1-t share one barrier (the two recursions are independent), the
+// state posteriors gamma[t][s] = alpha*beta / (P * y) are formed state-parallel, and the gradient of every (t, v)
+// is a deterministic in-order scan over the states of its parity - no atomics, no global round trips per frame.
+__global__ __launch_bounds__(256) void ctc_loss_lds_kernel(const float* __restrict__ logits, int64_t ld_t, int64_t ld_b,
+                                                           const int64_t* __restrict__ hlens,
+                                                           const int64_t* __restrict__ targets, int64_t ld_tgt,
+                                                           const int64_t* __restrict__ tlens, int blank,
+                                                           int zero_infinity, float* __restrict__ loss,
+                                                           float* __restrict__ grad, int T, int V, int Smax) {
+  extern __shared__ float sm[];
+  float* s_lp = sm;                         // [T][V] log-softmax
+  float* s_al = s_lp + (size_t)T * V;       // [T][Smax] alpha, later gamma
+  float* s_be = s_al + (size_t)T * Smax;    // [T][Smax] beta
+  int* s_lab = reinterpret_cast<int*>(s_be + (size_t)T * Smax);   // [Smax]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int Tb = (int)min((int64_t)T, hlens[b]);
+  const int L = (int)tlens[b];
+  const int S = 2 * L + 1;
+  const int64_t* tgt = targets + (int64_t)b * ld_tgt;
+  const float* lg = logits + (int64_t)b * ld_b;
+  float* gr = grad + (int64_t)b * ld_b;
+
+  for (int s = tid; s < S; s += 256) s_lab[s] = lat_label(tgt, s, blank);
+  for (int t = wv; t < Tb; t += 4) {
+    const float* row = lg + (int64_t)t * ld_t;
+    float mx = -FLT_MAX;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, row[v]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int v = lane; v < V; v += 64) se += expf(row[v] - mx);
+    se = wave_sum(se);
+    const float lz = mx + logf(se);
+    for (int v = lane; v < V; v += 64) s_lp[t * V + v] = row[v] - lz;
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += 256) {
+    float a = -INFINITY, bt = -INFINITY;
+    if (Tb > 0) {
+      if (s < 2) a = s_lp[s_lab[s]];
+      if (s >= S - 2) bt = s_lp[(Tb - 1) * V + s_lab[s]];
+      s_al[s] = a;
+      s_be[(Tb - 1) * Smax + s] = bt;
+    }
+  }
+  __syncthreads();
+  for (int i = 1; i < Tb; ++i) {
+    const int ta = i, tb = Tb - 1 - i;
+    for (int s = tid; s < S; s += 256) {
+      const int lab = s_lab[s];
+      const float* ap = s_al + (ta - 1) * Smax;
+      float a = log_add3(ap[s], s >= 1 ? ap[s - 1] : -INFINITY,
+                         (s >= 2 && (s & 1) && lab != s_lab[s - 2]) ? ap[s - 2] : -INFINITY);
+      if (a != -INFINITY) a += s_lp[ta * V + lab];
+      s_al[ta * Smax + s] = a;
+      const float* bp = s_be + (tb + 1) * Smax;
+      float bt = log_add3(bp[s], s + 1 < S ? bp[s + 1] : -INFINITY,
+                          (s + 2 < S && (s & 1) && lab != s_lab[s + 2]) ? bp[s + 2] : -INFINITY);
+      if (bt != -INFINITY) bt += s_lp[tb * V + lab];
+      s_be[tb * Smax + s] = bt;
+    }
+    __syncthreads();
+  }
+  float ll = -INFINITY;
+  if (Tb > 0) ll = log_add(s_al[(Tb - 1) * Smax + S - 1], S >= 2 ? s_al[(Tb - 1) * Smax + S - 2] : -INFINITY);
+  const float nll = -ll;
+  const bool inf = !(nll < INFINITY);
+  if (tid == 0) loss[b] = (inf && zero_infinity) ? 0.f : nll;
+  // gamma[t][s] = exp(alpha + beta + nll - lp[t][lab(s)])  (a posterior: in [0, 1])
+  for (int i = tid; i < Tb * S; i += 256) {
+    const int t = i / S, s = i % S;
+    const float ab = s_al[t * Smax + s] + s_be[t * Smax + s];
+    s_al[t * Smax + s] = (ab == -INFINITY || inf) ? 0.f : expf(ab + nll - s_lp[t * V + s_lab[s]]);
+  }
+  __syncthreads();
+  for (int i = tid; i < Tb * V; i += 256) {
+    const int t = i / V, v = i % V;
+    const float* gm = s_al + t * Smax;
+    float occ = 0.f;
+    if (v == blank) {
+      for (int s = 0; s < S; s += 2) occ += gm[s];
+    } else {
+      for (int s = 1; s < S; s += 2) occ += (s_lab[s] == v) ? gm[s] : 0.f;
+    }
+    gr[(int64_t)t * ld_t + v] = (inf && zero_infinity) ? 0.f : expf(s_lp[i]) - occ;
+  }
+  // frames beyond the utterance get no gradient
+  for (int64_t i = (int64_t)Tb * ld_t + tid; i < (int64_t)T * ld_t; i += 256) {
+    if ((int)(i % ld_t) < V) gr[i] = 0.f;
+  }
+}
+
 // ids[b,t] = argmax_v logits[b,t,v] (lowest index wins ties, like torch.argmax); hyp[b,:n] = collapse
 __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logits, int64_t ld_t, int64_t ld_b,
                                                          const int64_t* __restrict__ hlens, int blank,
@@ -259,6 +352,20 @@ extern "C" int tavsr_ctc_loss(const float* logits, int64_t ld_t, int64_t ld_b, c
   TAVSR_REQUIRE(logits && hlens && targets && tlens && loss && grad && ws, TAVSR_EINVAL, "ctc_loss: null pointer");
   if (B <= 0) return TAVSR_OK;
   const int Smax = 2 * Lmax + 1;
+  const size_t lds_fast = ((size_t)T * (V + 2 * (size_t)Smax) + Smax) * sizeof(float);
+  if (lds_fast <= 150 * 1024) {
+    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per process
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_loss_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      TAVSR_REQUIRE(e == hipSuccess, (int)e, "ctc_loss: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(ctc_loss_lds_kernel, dim3(B), dim3(256), lds_fast, (hipStream_t)stream, logits, ld_t, ld_b, hlens,
+                       targets, ld_tgt, tlens, blank, zero_infinity, loss, grad, T, V, Smax);
+    TAVSR_LAUNCH_CHECK();
+    return TAVSR_OK;
+  }
   size_t lds = (3 * (size_t)Smax + T) * sizeof(float);
   TAVSR_REQUIRE(lds <= 64000, TAVSR_EUNSUPPORTED, "ctc_loss: T=%d / Lmax=%d exceed the LDS lattice budget", T, Lmax);
   hipLaunchKernelGGL(ctc_loss_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, logits, ld_t, ld_b, hlens, targets,

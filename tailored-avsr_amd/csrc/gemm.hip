@@ -1,4 +1,4 @@
-// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32, exact f32 == k-ordered fmaf chain).
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain per output).
 //
 // One kernel family serves every contraction on the hot path:
 //   NT  C[M,N] = A[M,K] * W[N,K]^T          torch Linear forward (espnet Linear leaves)
@@ -6,14 +6,28 @@
 //   TN  C[M,N] = A[K,M]^T * B[K,N]          weight gradients, dK/dV
 // with two batch dimensions given by element strides (attention heads are addressed in place inside
 // the [B*T, 3*256] QKV buffer: no transposes are ever materialised) and a fused epilogue
-// (bias, ReLU/Swish/GELU, pre-activation store, residual + alpha, multiply by act'(z) for backward).
+// (bias, ReLU/Swish/GELU, pre-activation store, residual + alpha, multiply by act'(z) for backward,
+// row sums of op(A) = bias gradients of the weight-gradient GEMMs).
 //
-// Tiling: BM x BN block, WM x WN wavefronts (64 lanes), each wave owns TM x TN MFMA tiles of 32x32.
-// Operands are staged global -> registers -> LDS (double buffered, one barrier per K-step); the next
-// K-step's global loads are issued before the MFMAs of the current one.  LDS images:
-//   k-contiguous operand  : [row][BK+1]  (odd stride: the per-lane column read is conflict free)
-//   row-contiguous operand: [k][rows+4]  (16-B aligned rows: ds_write_b128, row read conflict free)
+// Tiling: BM x BN x BK block tile, WM x WN wavefronts (64 lanes), each wave owns TM x TN MFMA tiles
+// of 32x32.  LDS images (double buffered):
+//   k-contiguous operand  : [row][BK+4]   filled by ds_write_b128, fragments read by ds_read_b128:
+//                           lane (r = lane&31, h = lane>>5) gets k = 8g+4h .. 8g+4h+3 of row r, i.e. the
+//                           operands of FOUR consecutive MFMAs in one LDS instruction (conflict free:
+//                           144-byte row stride puts the 16 lanes of a b128 group on 16 distinct slots)
+//   row-contiguous operand: [k][rows+4]   filled by ds_write_b128, fragments read by ds_read_b32 at the
+//                           same k = 8g+4h+j (the MFMA sums over k in any order as long as A and B agree)
+// Pipeline per K-step (register staging, one barrier): tile t+1, fetched from global memory during the
+// previous step, is written to the other LDS buffer at the TOP of step t, the global loads of tile t+2
+// are issued right behind it, and only then the MFMAs of tile t run - so the loads have a whole step to
+// land and the LDS writes overlap the first MFMAs.
+//
+// Few-tile / long-K problems are split over K (gridDim.z slices): every slice stores its raw fp32
+// accumulators to a slab and a second, fully parallel kernel sums the slabs in slice order (deterministic)
+// and runs the epilogue.  (An in-kernel "last arriver reduces" variant was measured and lost: the reduction
+// of a 64x64 tile over 24 slices by ONE workgroup serialises ~400 KB of reads - profiles/r01_gemm_sweep_v2.txt.)
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -23,56 +37,103 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
   tavsr_gemm_desc d;
-  float* ws;      // split-K slabs [nsplit][nb1*nb2][M][N]
   int kchunk;     // K elements per split (multiple of BK)
   int nsplit;
+  int tiles_m, tiles_n;
 };
 
-// Fixed-order sum of the split-K slabs + the fused epilogue (same math as the in-kernel one).
+// Fixed-order sum of the split-K slabs + the fused epilogue (same math as the in-kernel one); one thread per
+// 4 consecutive columns when N % 4 == 0 (16-byte slab reads), else per element.
+template <int V>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs args) {
   const tavsr_gemm_desc& d = args.d;
   const int64_t mn = (int64_t)d.M * d.N;
   const int nbatch = d.nb1 * d.nb2;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= mn) return;
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
   const int z = blockIdx.y, z1 = z / d.nb2, z2 = z % d.nb2;
+  if (d.a_rowsum && z == 0 && i < d.M) {   // bias gradient: sum of the slices' row sums
+    const float* rs = d.ws + (int64_t)args.nsplit * nbatch * mn;
+    for (int q = 0; q < V && i + q < d.M; ++q) {
+      float v = 0.f;
+      for (int s = 0; s < args.nsplit; ++s) v += rs[(int64_t)s * d.M + i + q];
+      d.a_rowsum[i + q] = d.alpha * v;
+    }
+  }
+  if (i >= mn) return;
   const int m = (int)(i / d.N), n = (int)(i % d.N);
-  float v = 0.f;
-  for (int s = 0; s < args.nsplit; ++s) v += args.ws[((int64_t)s * nbatch + z) * mn + i];
-  if (d.bias) v += d.bias[n];
+  float v[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) v[q] = 0.f;
+  const float* p = d.ws + (int64_t)z * mn + i;
+#pragma unroll 4
+  for (int s = 0; s < args.nsplit; ++s) {
+    if (V == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * nbatch * mn);
+      v[0] += t.x; v[1 % V] += t.y; v[2 % V] += t.z; v[3 % V] += t.w;
+    } else {
+      v[0] += p[(int64_t)s * nbatch * mn];
+    }
+  }
   const int64_t o = z1 * d.sC1 + z2 * d.sC2 + (int64_t)m * d.ldc + n;
-  if (d.Z) d.Z[o] = v;
-  v = act_fwd(d.act, v);
-  if (d.DZ) v *= act_bwd(d.dact, d.DZ[o]);
-  v *= d.alpha;
-  if (d.R) v += d.R[z1 * d.sR1 + z2 * d.sR2 + (int64_t)m * d.ldr + n];
-  d.C[o] = v;
+  const int64_t ro = z1 * d.sR1 + z2 * d.sR2 + (int64_t)m * d.ldr + n;
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    float x = v[q];
+    if (d.bias) x += d.bias[n + q];
+    if (d.Z) d.Z[o + q] = x;
+    x = act_fwd(d.act, x);
+    if (d.DZ) x *= act_bwd(d.dact, d.DZ[o + q]);
+    x *= d.alpha;
+    if (d.R) x += d.R[ro + q];
+    d.C[o + q] = x;
+  }
 }
 
 template <int ROWS, int BK, bool KMAJOR>
 struct Tile {
-  static constexpr int LD = KMAJOR ? (ROWS + 4) : (BK + 1);
-  static constexpr int SIZE = KMAJOR ? BK * (ROWS + 4) : ROWS * (BK + 1);
-  __device__ static __forceinline__ int idx(int row, int k) { return KMAJOR ? k * LD + row : row * LD + k; }
+  static constexpr int LD = KMAJOR ? (ROWS + 4) : (BK + 4);
+  static constexpr int SIZE = KMAJOR ? BK * LD : ROWS * LD;
 };
 
-// Load one ROWS x BK operand tile into registers (NV float4 per thread).
+// Global -> register -> LDS staging of one ROWS x BK operand tile (NV float4 per thread).
 template <int ROWS, int BK, bool KMAJOR, bool VEC, int NT>
 struct Loader {
   static constexpr int NV = ROWS * BK / 4 / NT;
   static_assert(ROWS * BK % (4 * NT) == 0, "tile must divide over the block");
+  static constexpr int VPL = KMAJOR ? ROWS / 4 : BK / 4;   // float4 per contiguous line
+  using T = Tile<ROWS, BK, KMAJOR>;
+
   // vector v covers 4 consecutive elements along the contiguous direction
   __device__ static __forceinline__ void coords(int v, int& row, int& k) {
     if (KMAJOR) {
-      k = v / (ROWS / 4);
-      row = (v % (ROWS / 4)) * 4;
+      k = v / VPL;
+      row = (v % VPL) * 4;
     } else {
-      row = v / (BK / 4);
-      k = (v % (BK / 4)) * 4;
+      row = v / VPL;
+      k = (v % VPL) * 4;
     }
   }
-  __device__ static __forceinline__ void load(const float* __restrict__ g, int64_t ld, int row0, int k0,
-                                              int nrows, int K, int tid, float4 (&r)[NV]) {
+  // element offsets of this thread's vectors relative to (row0, k = 0); rows are clamped for the
+  // k-contiguous layout (the epilogue never stores rows >= nrows, so what they hold is irrelevant)
+  __device__ static __forceinline__ void offsets(int64_t ld, int row0, int nrows, int tid, int64_t (&off)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int row, k;
+      coords(tid + i * NT, row, k);
+      if (KMAJOR)
+        off[i] = (int64_t)k * ld + row0 + row;
+      else
+        off[i] = (int64_t)min(row0 + row, nrows - 1) * ld + k;
+    }
+  }
+  __device__ static __forceinline__ void load_fast(const float* __restrict__ g, const int64_t (&off)[NV],
+                                                   float4 (&r)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const float4*>(g + off[i]);
+  }
+  // fully predicated (edge tiles, K tails, unaligned operands): zero fill outside [nrows) x [K)
+  __device__ static __forceinline__ void load_safe(const float* __restrict__ g, int64_t ld, int row0, int k0,
+                                                   int nrows, int K, int tid, float4 (&r)[NV]) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int row, k;
@@ -108,44 +169,60 @@ struct Loader {
     }
   }
   __device__ static __forceinline__ void store(float* __restrict__ s, int tid, const float4 (&r)[NV]) {
-    using T = Tile<ROWS, BK, KMAJOR>;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int row, k;
       coords(tid + i * NT, row, k);
-      if (KMAJOR) {
-        *reinterpret_cast<float4*>(s + T::idx(row, k)) = r[i];
-      } else {
-        float* p = s + T::idx(row, k);
-        p[0] = r[i].x;
-        p[1] = r[i].y;
-        p[2] = r[i].z;
-        p[3] = r[i].w;
-      }
+      *reinterpret_cast<float4*>(s + (KMAJOR ? k * T::LD + row : row * T::LD + k)) = r[i];
     }
   }
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool AK, bool BKM, bool VEC, bool SPLITK>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) {
+// Fragments of one 32-row sub-tile for k-group g (8 k values): f[j] is the operand of MFMA j, k = 8g+4h+j.
+template <int ROWS, int BK, bool KMAJOR>
+__device__ __forceinline__ void read_frag(const float* __restrict__ s, int row, int g, int lk, float (&f)[4]) {
+  using T = Tile<ROWS, BK, KMAJOR>;
+  if (KMAJOR) {
+    const float* p = s + (g * 8 + 4 * lk) * T::LD + row;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = p[j * T::LD];
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(s + row * T::LD + g * 8 + 4 * lk);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+}
+
+// MINW: waves per SIMD the register allocation must leave room for (blocks per CU x waves per block / 4):
+// 4 blocks/CU for the 64x64 tile (its K-step is short: latency is hidden by co-resident blocks), 2 for the
+// larger tiles (LDS admits two of them per CU).
+template <int BM, int BN, int BK, int WM, int WN, int PF, int MINW, bool AK, bool BKM, bool VEC, int ABL = 0>
+__global__ __launch_bounds__(WM* WN * 64, MINW)
+void gemm_kernel(const GemmArgs args) {
   const tavsr_gemm_desc& d = args.d;
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NG = BK / 8;
   using TA = Tile<BM, BK, AK>;
   using TB = Tile<BN, BK, BKM>;
   using LA = Loader<BM, BK, AK, VEC, NT>;
   using LB = Loader<BN, BK, BKM, VEC, NT>;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (TA::SIZE + TB::SIZE)];
   constexpr int STAGE = TA::SIZE + TB::SIZE;  // stage s: A at smem + s*STAGE, B right after it
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lk = lane >> 5;
 
-  // tile index: x-fastest over N so consecutive blocks share the A panel
-  const int tiles_n = (d.N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM;
-  const int n0 = (blockIdx.x % tiles_n) * BN;
+  // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (its L2), give them neighbouring tiles.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // n fastest: neighbouring tiles share the A panel
+  const int m0 = (bid / args.tiles_n) * BM;
+  const int n0 = (bid % args.tiles_n) * BN;
   const int z1 = blockIdx.y / d.nb2, z2 = blockIdx.y % d.nb2;
 
   const float* A = d.A + z1 * d.sA1 + z2 * d.sA2;
@@ -159,50 +236,125 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float asum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+  const bool want_rowsum = d.a_rowsum != nullptr && n0 == 0 && wn == 0;
 
-  float4 ra[LA::NV], rb[LB::NV];
-  // split-K: slice z covers k in [kbeg, kend); each slice writes a raw fp32 slab to the workspace
-  const int kbeg = SPLITK ? blockIdx.z * args.kchunk : 0;
-  const int kend = SPLITK ? min(d.K, kbeg + args.kchunk) : d.K;
+  // split-K: slice z covers k in [kbeg, kend)
+  const int kbeg = blockIdx.z * args.kchunk;
+  const int kend = min(d.K, kbeg + args.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
-  LA::load(A, d.lda, m0, kbeg, d.M, kend, tid, ra);
-  LB::load(B, d.ldb, n0, kbeg, d.N, kend, tid, rb);
-  LA::store(smem, tid, ra);
-  LB::store(smem + TA::SIZE, tid, rb);
-  __syncthreads();
 
-  const int lr = lane & 31, lk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      LA::load(A, d.lda, m0, kbeg + (kt + 1) * BK, d.M, kend, tid, ra);
-      LB::load(B, d.ldb, n0, kbeg + (kt + 1) * BK, d.N, kend, tid, rb);
+  // a tile may use the unpredicated loads when it lies inside the operand (k-contiguous rows are clamped)
+  const bool fastA = VEC && (AK ? (m0 + BM <= d.M) : true);
+  const bool fastB = VEC && (BKM ? (n0 + BN <= d.N) : true);
+  const int64_t kstepA = AK ? (int64_t)BK * d.lda : BK;
+  const int64_t kstepB = BKM ? (int64_t)BK * d.ldb : BK;
+  int64_t offA[LA::NV], offB[LB::NV];
+  LA::offsets(d.lda, m0, d.M, tid, offA);
+  LB::offsets(d.ldb, n0, d.N, tid, offB);
+  const float* Ak = A + (AK ? (int64_t)kbeg * d.lda : kbeg);
+  const float* Bk = B + (BKM ? (int64_t)kbeg * d.ldb : kbeg);
+
+  // register ring: tile j is staged in set j % PF, PF K-steps before its MFMAs.
+  float4 ra[PF][LA::NV], rb[PF][LB::NV];
+  // A block whose tiles lie inside both operands and whose K range is whole K-steps runs a branch-free
+  // steady-state loop (FAST): any branch inside the K loop splits it into basic blocks, and hipcc then
+  // drains vmcnt/lgkmcnt at every join - the loads turn synchronous (measured: 2x on the whole kernel).
+  const bool fast = fastA && fastB && (kend - kbeg) % BK == 0;
+  auto load_tile = [&](int kt, float4 (&qa)[LA::NV], float4 (&qb)[LB::NV], auto fast_tag) {
+    if constexpr (decltype(fast_tag)::value) {
+      LA::load_fast(Ak + kt * kstepA, offA, qa);
+      LB::load_fast(Bk + kt * kstepB, offB, qb);
+    } else {
+      const int k0 = kbeg + kt * BK;
+      LA::load_safe(A, d.lda, m0, k0, d.M, kend, tid, qa);
+      LB::load_safe(B, d.ldb, n0, k0, d.N, kend, tid, qb);
     }
+  };
+  const int arow = wm * TM * 32 + lr, brow = wn * TN * 32 + lr;
+  // one K-step on LDS buffer (kt & 1); STORE: write ring set `rs` (tile kt+1) to the other buffer first,
+  // LOAD: refill that set with tile kt+1+PF
+  auto kstep = [&](int kt, float4 (&qa)[LA::NV], float4 (&qb)[LB::NV], bool do_store, bool do_load, auto fast_tag) {
+    const int cur = kt & 1;
     const float* a_s = smem + cur * STAGE;
     const float* b_s = a_s + TA::SIZE;
+    float af[2][TM][4], bf[2][TN][4];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i) read_frag<BM, BK, AK>(a_s, arow + i * 32, 0, lk, af[0][i]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = a_s[TA::idx(wm * TM * 32 + i * 32 + lr, kk + lk)];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = b_s[TB::idx(wn * TN * 32 + j * 32 + lr, kk + lk)];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < TN; ++j) read_frag<BN, BK, BKM>(b_s, brow + j * 32, 0, lk, bf[0][j]);
+    if (do_store) {   // tile kt+1 -> the other buffer (its readers finished at the previous barrier)
+      if (!(ABL & 2)) {
+        LA::store(smem + (cur ^ 1) * STAGE, tid, qa);
+        LB::store(smem + (cur ^ 1) * STAGE + TA::SIZE, tid, qb);
+      }
+      if (do_load && !(ABL & 1)) load_tile(kt + 1 + PF, qa, qb, fast_tag);
     }
-    if (kt + 1 < nk) {
-      LA::store(smem + (cur ^ 1) * STAGE, tid, ra);
-      LB::store(smem + (cur ^ 1) * STAGE + TA::SIZE, tid, rb);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int c = g & 1;
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_frag<BM, BK, AK>(a_s, arow + i * 32, g + 1, lk, af[c ^ 1][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_frag<BN, BK, BKM>(b_s, brow + j * 32, g + 1, lk, bf[c ^ 1][j]);
+      }
+      if (ABL & 8) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i][kk], bf[c][j][kk], acc[i][j], 0, 0, 0);
+      // row sums of op(A) ride along unconditionally (TM adds per 16*TM*TN MFMA cycles; no branch in the loop)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asum[i] += (af[c][i][0] + af[c][i][1]) + (af[c][i][2] + af[c][i][3]);
+    }
+    if (!(ABL & 4)) __syncthreads();
+  };
+  auto run_loop = [&](auto fast_tag) {
+    if (nk > 0) {
+      load_tile(0, ra[0], rb[0], fast_tag);
+      LA::store(smem, tid, ra[0]);
+      LB::store(smem + TA::SIZE, tid, rb[0]);
+#pragma unroll
+      for (int j = 1; j <= PF; ++j)
+        if (j < nk) load_tile(j, ra[j % PF], rb[j % PF], fast_tag);
     }
     __syncthreads();
+    int kt0 = 0;
+    // steady state: every step stores and refills, no conditions
+    for (; kt0 + 2 * PF < nk; kt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) kstep(kt0 + u, ra[(u + 1) % PF], rb[(u + 1) % PF], true, true, fast_tag);
+    }
+    // drain: the last (at most 2*PF) steps
+    for (; kt0 < nk; kt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int kt = kt0 + u;
+        if (kt < nk) kstep(kt, ra[(u + 1) % PF], rb[(u + 1) % PF], kt + 1 < nk, kt + 1 + PF < nk, fast_tag);
+      }
+    }
+  };
+  if (fast) run_loop(std::true_type{});
+  else run_loop(std::false_type{});
+
+  if (want_rowsum) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asum[i] += __shfl_xor(asum[i], 32, 64);
   }
 
-  // ---- epilogue: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-  if (SPLITK) {
-    float* slab = args.ws + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (int64_t)d.M * d.N;
+  // ---- split-K: every slice stores its raw accumulators (and row sums) to its slab; splitk_epilogue_kernel
+  //      sums the slabs in slice order (deterministic) and applies the epilogue
+  if (args.nsplit > 1) {
+    const int64_t mn = (int64_t)d.M * d.N;
+    const int nbatch = gridDim.y;
+    float* slab = d.ws + ((int64_t)blockIdx.z * nbatch + blockIdx.y) * mn;
+    float* rsum0 = d.ws + (int64_t)args.nsplit * nbatch * mn;       // [nsplit][M] (only when nbatch == 1)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * TN * 32 + j * 32 + lr;
@@ -217,7 +369,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) 
         }
       }
     }
+    if (want_rowsum && lk == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * TM * 32 + i * 32 + lr;
+        if (m < d.M) rsum0[(int64_t)blockIdx.z * d.M + m] = asum[i];
+      }
+    }
     return;
+  }
+
+  // ---- epilogue: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (want_rowsum && lk == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * TM * 32 + i * 32 + lr;
+      if (m < d.M) d.a_rowsum[m] = d.alpha * asum[i];
+    }
   }
   float* C = d.C + coff;
   float* Z = d.Z ? d.Z + coff : nullptr;
@@ -248,24 +416,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs args) 
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+// ---------------------------------------------------------------------------------------------- host side
+struct Cfg {
+  int bm, bn, bk, wm, wn, pf;
+};
+// tile configurations (index = cfg id of tavsr_gemm_tune)
+static const Cfg kCfgs[] = {
+    {128, 128, 32, 2, 2, 1},   // 0: wave tile 64x64, 1 wave/SIMD per block, 72 KB LDS
+    {128, 128, 32, 2, 2, 2},   // 1: same, two K-steps of prefetch
+    {128, 64, 32, 2, 2, 2},    // 2: wave tile 64x32
+    {64, 128, 32, 2, 2, 2},    // 3: wave tile 32x64
+    {64, 64, 32, 2, 2, 2},     // 4: wave tile 32x32
+    {64, 64, 32, 2, 2, 4},     // 5: wave tile 32x32, four K-steps of prefetch
+    {128, 128, 32, 2, 4, 2},   // 6: 8 waves, wave tile 64x32 (2 waves/SIMD inside one block)
+    {128, 64, 32, 2, 2, 3},    // 7: wave tile 64x32, three K-steps of prefetch
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kFallbackCfg = 4;   // the only configuration instantiated for unaligned (scalar-load) operands
+
+template <int BM, int BN, int BK, int WM, int WN, int PF, int MINW, int ABL = 0>
 static int launch_cfg(const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
-  GemmArgs a{d, d.ws, kchunk, nsplit};
-  dim3 grid(cdiv(d.M, BM) * cdiv(d.N, BN), d.nb1 * d.nb2, nsplit);
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, BM), cdiv(d.N, BN)};
+  dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
   dim3 block(WM * WN * 64);
-#define TAVSR_GEMM_LAUNCH(AK, BKM)                                                                        \
-  do {                                                                                                    \
-    if (nsplit > 1) {                                                                                     \
-      if (vec)                                                                                            \
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, true, true>), grid, block, 0, s, a);  \
-      else                                                                                                \
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, false, true>), grid, block, 0, s, a); \
-    } else {                                                                                              \
-      if (vec)                                                                                            \
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, true, false>), grid, block, 0, s, a); \
-      else                                                                                                \
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, AK, BKM, false, false>), grid, block, 0, s, a);\
-    }                                                                                                     \
+#define TAVSR_GEMM_LAUNCH(AK, BKM)                                                                   \
+  do {                                                                                               \
+    if (vec)                                                                                         \
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, PF, MINW, AK, BKM, true, ABL>), grid, block, 0, s, a); \
+    else if constexpr (BM == 64 && BN == 64 && PF == 2 && ABL == 0)                                              \
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, PF, MINW, AK, BKM, false>), grid, block, 0, s, a);\
   } while (0)
   if (!d.a_kmajor && !d.b_kmajor) TAVSR_GEMM_LAUNCH(false, false);
   else if (!d.a_kmajor && d.b_kmajor) TAVSR_GEMM_LAUNCH(false, true);
@@ -274,37 +453,74 @@ static int launch_cfg(const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk
 #undef TAVSR_GEMM_LAUNCH
   TAVSR_LAUNCH_CHECK();
   if (nsplit > 1) {
-    dim3 g2(cdiv((int64_t)d.M * d.N, 256), d.nb1 * d.nb2, 1);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, g2, dim3(256), 0, s, a);
+    const int64_t mn = (int64_t)d.M * d.N;
+    if (d.N % 4 == 0)
+      hipLaunchKernelGGL(splitk_epilogue_kernel<4>, dim3(cdiv(mn / 4, 256), d.nb1 * d.nb2), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(splitk_epilogue_kernel<1>, dim3(cdiv(mn, 256), d.nb1 * d.nb2), dim3(256), 0, s, a);
     TAVSR_LAUNCH_CHECK();
   }
   return TAVSR_OK;
 }
 
-// Split-K plan: fill the 256 CUs (>= 2 waves per SIMD) when the output has too few tiles but K is long
-// (weight gradients: K = B*T rows).  Returns nsplit (1 = none) and the K chunk per slice.
-static void plan_splitk(const tavsr_gemm_desc& d, int BM, int BN, int BK, int* nsplit, int* kchunk) {
-  *nsplit = 1;
-  *kchunk = d.K;
-  const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN) * d.nb1 * d.nb2;
-  if (tiles >= 384 || d.K < 8 * BK) return;
-  long want = std::min<long>({(long)cdiv(768, tiles), (long)d.K / (4 * BK), 64L});
-  if (want < 2) return;
-  int kc = cdiv(cdiv(d.K, want), BK) * BK;
-  *kchunk = kc;
-  *nsplit = cdiv(d.K, kc);
+static int launch(int cfg, const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
+  if (!vec) cfg = kFallbackCfg;
+#ifdef TAVSR_GEMM_ABLATE   // timing-only variants (wrong results): which part of the K-step costs what
+  switch (cfg) {
+    case 101: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 1>(d, vec, nsplit, kchunk, s);   // no global loads
+    case 103: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 3>(d, vec, nsplit, kchunk, s);   // + no LDS writes
+    case 107: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 7>(d, vec, nsplit, kchunk, s);   // + no barrier
+    case 102: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 2>(d, vec, nsplit, kchunk, s);   // loads but no LDS writes
+    case 108: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 8>(d, vec, nsplit, kchunk, s);   // full, reads pinned before MFMAs
+    case 115: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 15>(d, vec, nsplit, kchunk, s);  // pure loop, pinned
+    case 118: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 8>(d, vec, nsplit, kchunk, s);
+    case 125: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 15>(d, vec, nsplit, kchunk, s);
+    case 111: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 1>(d, vec, nsplit, kchunk, s);
+    case 113: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 3>(d, vec, nsplit, kchunk, s);
+    case 117: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 7>(d, vec, nsplit, kchunk, s);
+    default: break;
+  }
+#endif
+  switch (cfg) {
+    case 0: return launch_cfg<128, 128, 32, 2, 2, 1, 2>(d, vec, nsplit, kchunk, s);
+    case 1: return launch_cfg<128, 128, 32, 2, 2, 2, 2>(d, vec, nsplit, kchunk, s);
+    case 2: return launch_cfg<128, 64, 32, 2, 2, 2, 2>(d, vec, nsplit, kchunk, s);
+    case 3: return launch_cfg<64, 128, 32, 2, 2, 2, 2>(d, vec, nsplit, kchunk, s);
+    case 4: return launch_cfg<64, 64, 32, 2, 2, 2, 4>(d, vec, nsplit, kchunk, s);
+    case 5: return launch_cfg<64, 64, 32, 2, 2, 4, 3>(d, vec, nsplit, kchunk, s);
+    case 6: return launch_cfg<128, 128, 32, 2, 4, 2, 2>(d, vec, nsplit, kchunk, s);
+    default: return launch_cfg<128, 64, 32, 2, 2, 3, 2>(d, vec, nsplit, kchunk, s);
+  }
 }
 
-static bool use_big_tile(const tavsr_gemm_desc& d) {
-  return (long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.nb1 * d.nb2 >= 768;
+struct Plan {
+  int cfg, nsplit, kchunk;
+};
+
+// Planner (fitted to profiles/r01_gemm_sweep_v2.txt, MI355X): the 64x64 tile (4 blocks/CU) wins every hot-path
+// shape below ~1000 tiles of 128x128; above that the 8-wave 128x128 tile does.  Few-tile, long-K problems (weight
+// gradients: K = B*T) are split over K so that >= ~768 blocks exist.
+static Plan plan(const tavsr_gemm_desc& d, bool allow_split) {
+  const long nbatch = (long)d.nb1 * d.nb2;
+  if ((long)cdiv(d.M, 128) * cdiv(d.N, 128) * nbatch >= 900) return Plan{6, 1, d.K};
+  Plan p{kFallbackCfg, 1, d.K};
+  const long tiles = (long)cdiv(d.M, 64) * cdiv(d.N, 64) * nbatch;
+  if (!allow_split || tiles >= 384 || d.K < 8 * 32) return p;
+  const long want = std::min<long>({(long)cdiv(768, tiles), (long)d.K / (4 * 32), 64L});
+  if (want < 2) return p;
+  p.kchunk = cdiv(cdiv(d.K, want), 32) * 32;
+  p.nsplit = cdiv(d.K, p.kchunk);
+  return p;
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-}  // namespace tavsr
+static int64_t ws_floats_for(const tavsr_gemm_desc& d, int nsplit) {
+  if (nsplit <= 1) return 0;
+  return (int64_t)nsplit * d.nb1 * d.nb2 * d.M * d.N + (d.a_rowsum ? (int64_t)nsplit * d.M : 0);
+}
 
-extern "C" int tavsr_gemm(const tavsr_gemm_desc* dp, tavsr_stream_t stream) {
-  using namespace tavsr;
+static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStream_t s) {
   TAVSR_REQUIRE(dp != nullptr, TAVSR_EINVAL, "tavsr_gemm: null descriptor");
   tavsr_gemm_desc d = *dp;
   TAVSR_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, TAVSR_EINVAL, "tavsr_gemm: negative dims");
@@ -313,30 +529,50 @@ extern "C" int tavsr_gemm(const tavsr_gemm_desc* dp, tavsr_stream_t stream) {
   if (d.M == 0 || d.N == 0) return TAVSR_OK;
   TAVSR_REQUIRE(d.A && d.B && d.C, TAVSR_EINVAL, "tavsr_gemm: null operand");
   TAVSR_REQUIRE((long)d.nb1 * d.nb2 <= 65535, TAVSR_EINVAL, "tavsr_gemm: batch too large");
+  TAVSR_REQUIRE(d.a_rowsum == nullptr || d.nb1 * d.nb2 == 1, TAVSR_EUNSUPPORTED,
+                "tavsr_gemm: a_rowsum needs an unbatched problem");
   if (d.R == nullptr) { d.ldr = 0; d.sR1 = d.sR2 = 0; }
   // vector (16-B) operand loads need aligned bases, leading dims and batch strides
-  bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.sA1 % 4 == 0 &&
-             d.sA2 % 4 == 0 && d.sB1 % 4 == 0 && d.sB2 % 4 == 0;
-  // (a float4 that straddles the end of the contiguous direction falls back to predicated scalar loads)
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (use_big_tile(d)) return launch_cfg<128, 128, 16, 2, 2>(d, vec, 1, d.K, s);
-  int nsplit, kchunk;
-  plan_splitk(d, 64, 64, 32, &nsplit, &kchunk);
-  if (nsplit > 1) {
-    const int64_t need = (int64_t)nsplit * d.nb1 * d.nb2 * d.M * d.N;
-    if (d.ws == nullptr || d.ws_floats < need) nsplit = 1, kchunk = d.K;  // caller gave no workspace: plain path
+  const bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.sA1 % 4 == 0 &&
+                   d.sA2 % 4 == 0 && d.sB1 % 4 == 0 && d.sB2 % 4 == 0;
+  const bool can_split = d.ws != nullptr;
+  Plan p = plan(d, can_split);
+  if (force_cfg >= 0) {
+    TAVSR_REQUIRE(force_cfg < kNumCfgs || force_cfg >= 100, TAVSR_EINVAL, "tavsr_gemm_tune: cfg %d out of range", force_cfg);
+    p.cfg = force_cfg;
+    const int bk = 32;
+    int ns = std::max(1, force_split);
+    p.kchunk = cdiv(cdiv(d.K, ns), bk) * bk;
+    p.nsplit = std::max(1, cdiv(d.K, p.kchunk));
   }
-  return launch_cfg<64, 64, 32, 2, 2>(d, vec, nsplit, kchunk, s);
+  if (p.nsplit > 1) {
+    if (!can_split || d.ws_floats < ws_floats_for(d, p.nsplit)) {
+      TAVSR_REQUIRE(force_cfg < 0, TAVSR_EINVAL, "tavsr_gemm_tune: workspace too small for the forced split");
+      p = plan(d, false);
+    }
+  }
+  return launch(p.cfg, d, vec, p.nsplit, p.kchunk, s);
 }
 
+}  // namespace tavsr
+
+extern "C" int tavsr_gemm(const tavsr_gemm_desc* dp, tavsr_stream_t stream) {
+  return tavsr::run(dp, -1, 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tavsr_gemm_tune(const tavsr_gemm_desc* dp, int32_t cfg, int32_t nsplit, tavsr_stream_t stream) {
+  return tavsr::run(dp, cfg, nsplit, static_cast<hipStream_t>(stream));
+}
+
+// Workspace the planner would like for this problem: floats of split-K slabs (0: no split) and, through
+// *sync_ints, the number of zero-initialised int32 tile counters.
 extern "C" int64_t tavsr_gemm_ws(const tavsr_gemm_desc* dp) {
   using namespace tavsr;
   if (!dp) return 0;
   tavsr_gemm_desc d = *dp;
   if (d.nb1 <= 0) d.nb1 = 1;
   if (d.nb2 <= 0) d.nb2 = 1;
-  if (d.M <= 0 || d.N <= 0 || use_big_tile(d)) return 0;
-  int nsplit, kchunk;
-  plan_splitk(d, 64, 64, 32, &nsplit, &kchunk);
-  return nsplit > 1 ? (int64_t)nsplit * d.nb1 * d.nb2 * d.M * d.N : 0;
+  if (d.M <= 0 || d.N <= 0) return 0;
+  Plan p = plan(d, true);
+  return ws_floats_for(d, p.nsplit);
 }

@@ -131,15 +131,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
-// out[c] (+)= sum_p part[p*stride + c]
-__global__ void sum_partials_kernel(const float* __restrict__ part, int nparts, int64_t stride, float* __restrict__ out,
-                                    int n, int accumulate, float scale = 1.f) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * stride + c];
-  s *= scale;
-  out[c] = accumulate ? out[c] + s : s;
+// out[c] (+)= scale * sum_p part[p*stride + c].  One block per 64 columns; the 4 waves take the partials
+// p = w, w+4, ... (four independent load streams per lane), then a fixed-order cross-wave sum: deterministic.
+// Columns c >= n1 go to out2[c - n1] (LayerNorm: dgamma and dbeta from one [blk][2][D] slab in one launch).
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int nparts, int64_t stride,
+                                                          float* __restrict__ out, float* __restrict__ out2, int n1,
+                                                          int n, int accumulate, float scale) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < n) {
+    const float* p = part + c;
+    int q = w;
+    for (; q + 12 < nparts; q += 16) {
+      s0 += p[(int64_t)q * stride];
+      s1 += p[(int64_t)(q + 4) * stride];
+      s2 += p[(int64_t)(q + 8) * stride];
+      s3 += p[(int64_t)(q + 12) * stride];
+    }
+    for (; q < nparts; q += 4) s0 += p[(int64_t)q * stride];
+  }
+  red[w][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && c < n) {
+    const float s = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) * scale;
+    float* o = c < n1 ? out + c : out2 + (c - n1);
+    *o = accumulate ? *o + s : s;
+  }
 }
 
 // ---- column sums of a [M,N] matrix (bias gradients, pos_bias_u/v gradients) -------------------
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
 }
 
 static inline int ln_blocks(int M) { return min(cdiv(M, 4 * 8), 512); }
-static inline int colsum_chunks(int M) { return min(cdiv(M, 64), 256); }
+static inline int colsum_chunks(int M) { return min(cdiv(M, 64), 64); }
 
 }  // namespace tavsr
 
@@ -199,10 +218,8 @@ extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
                      ldadd, dx, lddx, ws, M, D);
   TAVSR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, ws, nb, (int64_t)2 * D, dgamma, D,
-                     accumulate, 1.f);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, ws + D, nb, (int64_t)2 * D, dbeta, D,
-                     accumulate, 1.f);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, s, ws, nb, (int64_t)2 * D, dgamma, dbeta,
+                     D, 2 * D, accumulate, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
@@ -218,7 +235,7 @@ extern "C" int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, f
   const int rpc = M > 0 ? cdiv(M, chunks) : 1;
   hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, s, x, ldx, M, N, rpc, ws);
   TAVSR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, chunks, (int64_t)N, out, N,
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, ws, chunks, (int64_t)N, out, out, N, N,
                      accumulate, scale);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
@@ -229,8 +246,8 @@ extern "C" int tavsr_sum_partials(const float* part, int32_t nparts, int64_t str
                                   int32_t accumulate, tavsr_stream_t stream) {
   TAVSR_REQUIRE(part && out, TAVSR_EINVAL, "sum_partials: null pointer");
   if (n <= 0) return TAVSR_OK;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts, stride,
-                     out, n, accumulate, 1.f);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, part, nparts, stride,
+                     out, out, n, n, accumulate, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

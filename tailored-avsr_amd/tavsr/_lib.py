@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("R", C.c_void_p), ("ldr", C.c_int64), ("sR1", C.c_int64), ("sR2", C.c_int64),
         ("DZ", C.c_void_p), ("dact", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+        ("a_rowsum", C.c_void_p),
     ]
 
 

@@ -39,11 +39,9 @@ class _FFN:
     def bwd(dy, saved, ln_w, w1, w2, act, scale):
         """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2)."""
         x, mean, rstd, n, z, h = saved
-        gw2 = ops.linear_dw(dy, h, alpha=scale)
-        gb2 = ops.colsum(dy, scale=scale)
+        gw2, gb2 = ops.linear_dw(dy, h, alpha=scale, bias_grad=True)
         dz = ops.linear_dx(dy, w2, alpha=scale, DZ=z, dact=act)
-        gw1 = ops.linear_dw(dz, n)
-        gb1 = ops.colsum(dz)
+        gw1, gb1 = ops.linear_dw(dz, n, bias_grad=True)
         dn = ops.linear_dx(dz, w1)
         dx, gln_w, gln_b = ops.layernorm_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
         return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2)
@@ -262,8 +260,8 @@ class BranchformerLayerFn(torch.autograd.Function):
         if cfg["merge_identity"]:
             dm = ops.axpby(dx2, None, coeff, 0.0) if coeff != 1.0 else dx2
         else:
-            put("merge_proj.weight", ops.linear_dw(dx2, m, alpha=coeff))
-            put("merge_proj.bias", ops.colsum(dx2, scale=coeff))
+            gw_, gb_ = ops.linear_dw(dx2, m, alpha=coeff, bias_grad=True)
+            put("merge_proj.weight", gw_); put("merge_proj.bias", gb_)
             dm = ops.linear_dx(dx2, p("merge_proj.weight"), alpha=coeff)
         xa, xm = sv["xa"], sv["xm"]
         if two and merge == "learned_ave":
@@ -290,8 +288,8 @@ class BranchformerLayerFn(torch.autograd.Function):
         if has_mlp:
             mean, rstd, n, g, z, gn, gmean, grstd, u, conv = sv["mlp"]
             Cn = g.shape[1] // 2
-            put("cgmlp.channel_proj2.weight", ops.linear_dw(dxm, u))
-            put("cgmlp.channel_proj2.bias", ops.colsum(dxm))
+            gw_, gb_ = ops.linear_dw(dxm, u, bias_grad=True)
+            put("cgmlp.channel_proj2.weight", gw_); put("cgmlp.channel_proj2.bias", gb_)
             du = ops.linear_dx(dxm, p("cgmlp.channel_proj2.weight"))
             dg = torch.empty_like(g)
             cw = p("cgmlp.csgu.conv.weight")
@@ -300,15 +298,15 @@ class BranchformerLayerFn(torch.autograd.Function):
             _, g1, g2 = ops.layernorm_bwd(dgn, g[:, Cn:], gmean, grstd, p("cgmlp.csgu.norm.weight"), dx=dg[:, Cn:])
             put("cgmlp.csgu.norm.weight", g1); put("cgmlp.csgu.norm.bias", g2)
             ops.act_bwd_(dg, z, "gelu")
-            put("cgmlp.channel_proj1.0.weight", ops.linear_dw(dg, n))
-            put("cgmlp.channel_proj1.0.bias", ops.colsum(dg))
+            gw_, gb_ = ops.linear_dw(dg, n, bias_grad=True)
+            put("cgmlp.channel_proj1.0.weight", gw_); put("cgmlp.channel_proj1.0.bias", gb_)
             dn = ops.linear_dx(dg, p("cgmlp.channel_proj1.0.weight"))
             dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1)
             put("norm_mlp.weight", g1); put("norm_mlp.bias", g2)
         if has_attn:
             mean, rstd, n, qkv, pp, qu, qv, cx, attn = sv["attn"]
-            put("attn.linear_out.weight", ops.linear_dw(dxa, cx))
-            put("attn.linear_out.bias", ops.colsum(dxa))
+            gw_, gb_ = ops.linear_dw(dxa, cx, bias_grad=True)
+            put("attn.linear_out.weight", gw_); put("attn.linear_out.bias", gb_)
             dcx = ops.linear_dx(dxa, p("attn.linear_out.weight"))
             dqkv = torch.empty_like(qkv)
             dqu = ops.empty(M, D, like=dy2)
@@ -319,8 +317,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
             pe2d = ctx.pos_emb.reshape(-1, D)
             put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))
-            gw = ops.linear_dw(dqkv, n)  # [3D, D]
-            gb = ops.colsum(dqkv)
+            gw, gb = ops.linear_dw(dqkv, n, bias_grad=True)  # [3D, D], [3D]
             put("attn.linear_q.weight", gw[:D]); put("attn.linear_k.weight", gw[D:2 * D]); put("attn.linear_v.weight", gw[2 * D:])
             put("attn.linear_q.bias", gb[:D]); put("attn.linear_k.bias", gb[D:2 * D]); put("attn.linear_v.bias", gb[2 * D:])
             dn = ops.linear_dx(dqkv[:, :D], p("attn.linear_q.weight"))
@@ -377,8 +374,10 @@ class LinearFn(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         dy2 = dy.contiguous().view(x2.shape[0], w.shape[0])
         dx = ops.linear_dx(dy2, w, alpha=ctx.alpha) if ctx.needs_input_grad[0] else None
-        gw = ops.linear_dw(dy2, x2, alpha=ctx.alpha)
-        gb = ops.colsum(dy2, scale=ctx.alpha) if ctx.has_b else None
+        if ctx.has_b:
+            gw, gb = ops.linear_dw(dy2, x2, alpha=ctx.alpha, bias_grad=True)
+        else:
+            gw, gb = ops.linear_dw(dy2, x2, alpha=ctx.alpha), None
         return (None if dx is None else dx.view(*dy.shape[:-1], w.shape[1])), gw, gb, None
 
 
@@ -408,13 +407,11 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         B, T, F, Cn, T2, F2, xscale, w1s, w2s, wos = ctx.dims
         do = dout.contiguous().view(B * T2, -1)
         y2f = y2.view(B * T2, F2 * Cn)
-        gwor = ops.linear_dw(do, y2f, alpha=xscale)                             # [odim, F2*C]
-        gbo = ops.colsum(do, scale=xscale)
+        gwor, gbo = ops.linear_dw(do, y2f, alpha=xscale, bias_grad=True)        # [odim, F2*C], [odim]
         gwo = ops.transpose_inner(gwor, wos[0], F2, Cn).view(wos)
         # dz2 = (do @ wor) * xscale * relu'(y2)
         dz2 = ops.linear_dx(do, wor, alpha=xscale, DZ=y2f, dact="relu").view(B * T2 * F2, Cn)
-        gw2r = ops.linear_dw(dz2, col)                                          # [C, 9C]
-        gb2 = ops.colsum(dz2)
+        gw2r, gb2 = ops.linear_dw(dz2, col, bias_grad=True)                     # [C, 9C], [C]
         gw2 = ops.transpose_inner(gw2r, Cn, 9, Cn).view(w2s)
         dcol = ops.linear_dx(dz2, w2r)                                          # [B*T2*F2, 9C]
         dz1 = ops.col2im3x3s2_relu(dcol, y1)
@@ -448,8 +445,7 @@ class CTCLossFn(torch.autograd.Function):
             raise NotImplementedError("reduce=False backward is not on the shipped path")
         gs = ops.scale_dev(g2, dl.contiguous(), 1.0 / B)   # dlogits = g * dl / B, dl stays on the device
         dx = ops.linear_dx(gs, w)
-        gw = ops.linear_dw(gs, x2)
-        gb = ops.colsum(gs)
+        gw, gb = ops.linear_dw(gs, x2, bias_grad=True)
         return dx.view(B, -1, x2.shape[1]), gw, gb, None, None, None, None, None
 
 
@@ -532,8 +528,7 @@ class TransformerDecoderFn(torch.autograd.Function):
         an_w, an_b, out_w, out_b = P[an_i: an_i + 4]
         x, mf, rf, xn = ctx.final
         dl = dlogits.contiguous().view(M, -1)
-        G[an_i + 2] = ops.linear_dw(dl, xn)
-        G[an_i + 3] = ops.colsum(dl)
+        G[an_i + 2], G[an_i + 3] = ops.linear_dw(dl, xn, bias_grad=True)
         dxn = ops.linear_dx(dl, out_w)
         dx, G[an_i], G[an_i + 1] = ops.layernorm_bwd(dxn, x, mf, rf, an_w)
         dmem = None
@@ -553,16 +548,16 @@ class TransformerDecoderFn(torch.autograd.Function):
                 put(n_, g)
             # --- source attention
             x1, m2, r2, n2, q2, kv, cx2, attn2 = s["src"]
-            put("src_attn.linear_out.weight", ops.linear_dw(dx2, cx2))
-            put("src_attn.linear_out.bias", ops.colsum(dx2))
+            gw_, gb_ = ops.linear_dw(dx2, cx2, bias_grad=True)
+            put("src_attn.linear_out.weight", gw_); put("src_attn.linear_out.bias", gb_)
             dcx2 = ops.linear_dx(dx2, p("src_attn.linear_out.weight"))
             dq2 = ops.empty(M, D, like=dl)
             dkv = torch.empty_like(kv)
             _SelfAttnCore.bwd(dcx2, attn2, q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, dq2, D, 0, dkv, 2 * D, 0, dkv, 2 * D, D,
                               B, L, T, H, dk)
-            put("src_attn.linear_q.weight", ops.linear_dw(dq2, n2)); put("src_attn.linear_q.bias", ops.colsum(dq2))
-            gkv_w = ops.linear_dw(dkv, mem2)   # [2D, D]
-            gkv_b = ops.colsum(dkv)
+            gw_, gb_ = ops.linear_dw(dq2, n2, bias_grad=True)
+            put("src_attn.linear_q.weight", gw_); put("src_attn.linear_q.bias", gb_)
+            gkv_w, gkv_b = ops.linear_dw(dkv, mem2, bias_grad=True)   # [2D, D], [2D]
             put("src_attn.linear_k.weight", gkv_w[:D]); put("src_attn.linear_v.weight", gkv_w[D:])
             put("src_attn.linear_k.bias", gkv_b[:D]); put("src_attn.linear_v.bias", gkv_b[D:])
             if dmem is None:
@@ -575,14 +570,13 @@ class TransformerDecoderFn(torch.autograd.Function):
             put("norm2.weight", g1); put("norm2.bias", g2)
             # --- self attention
             x0, m1, r1, n1, qkv, cx, attn = s["self"]
-            put("self_attn.linear_out.weight", ops.linear_dw(dx1, cx))
-            put("self_attn.linear_out.bias", ops.colsum(dx1))
+            gw_, gb_ = ops.linear_dw(dx1, cx, bias_grad=True)
+            put("self_attn.linear_out.weight", gw_); put("self_attn.linear_out.bias", gb_)
             dcx = ops.linear_dx(dx1, p("self_attn.linear_out.weight"))
             dqkv = torch.empty_like(qkv)
             _SelfAttnCore.bwd(dcx, attn, qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqkv, 3 * D, 0, dqkv, 3 * D, D,
                               dqkv, 3 * D, 2 * D, B, L, L, H, dk)
-            gw = ops.linear_dw(dqkv, n1)
-            gb = ops.colsum(dqkv)
+            gw, gb = ops.linear_dw(dqkv, n1, bias_grad=True)
             put("self_attn.linear_q.weight", gw[:D]); put("self_attn.linear_k.weight", gw[D:2 * D]); put("self_attn.linear_v.weight", gw[2 * D:])
             put("self_attn.linear_q.bias", gb[:D]); put("self_attn.linear_k.bias", gb[D:2 * D]); put("self_attn.linear_v.bias", gb[2 * D:])
             dn1 = ops.linear_dx(dqkv[:, :D], p("self_attn.linear_q.weight"))

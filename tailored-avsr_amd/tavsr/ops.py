@@ -47,18 +47,39 @@ PROFILE: Optional[GemmProfile] = None
 
 
 def _gemm_kernel_key(d) -> str:
-    """Mirror of the tile choice in csrc/gemm.hip: names the template instantiation a launch runs."""
-    big = -(-d.M // 128) * -(-d.N // 128) * max(1, d.nb1) * max(1, d.nb2) >= 1024
-    tile = "128x128x16" if big else "64x64x32"
-    return f"gemm_kernel<{tile},{'T' if d.a_kmajor else 'N'}{'N' if d.b_kmajor else 'T'}>"
+    """Names the kernel family a launch runs (layout); the tile is the planner's choice (csrc/gemm.hip)."""
+    return f"gemm_kernel<{'T' if d.a_kmajor else 'N'}{'N' if d.b_kmajor else 'T'}>"
+
+
+_SYNC = {}
+SYNC_INTS = 1 << 16
+
+
+def sync_counters(device) -> torch.Tensor:
+    """Zero-initialised int32 tile counters shared by all split-K GEMMs / last-block reductions issued on
+    one stream (every kernel leaves them zero).  Created outside any graph capture (first eager call)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream if not torch.cuda.is_current_stream_capturing() else "cap")
+    t = _SYNC.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            # inside a capture: reuse any buffer made by the eager warm-up on this device
+            for (dev, _), v in _SYNC.items():
+                if dev == key[0]:
+                    return v
+            raise L.TavsrError("run one eager step before capturing a graph (split-K counters are allocated lazily)")
+        t = torch.zeros(SYNC_INTS, dtype=torch.int32, device=device)
+        _SYNC[key] = t
+    return t
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
-         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None):
-    """Raw descriptor call; offsets are in elements into the given tensors."""
-    require_cuda(A, B, Cc, bias, Z, R, DZ)
+         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, force=None):
+    """Raw descriptor call; offsets are in elements into the given tensors.  ``force=(cfg, nsplit)`` bypasses
+    the planner (tuning / tests)."""
+    require_cuda(A, B, Cc, bias, Z, R, DZ, a_rowsum)
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
@@ -77,16 +98,28 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.sR1, d.sR2 = sR
     if DZ is not None:
         d.DZ, d.dact = _addr(DZ, c_off), ACT[dact]
-    need = lib().tavsr_gemm_ws(C.byref(d))
+    if a_rowsum is not None:
+        d.a_rowsum = a_rowsum.data_ptr()
+    if force is not None and force[1] > 1:
+        need = force[1] * max(1, nb1) * max(1, nb2) * M * N + force[1] * M
+    else:
+        need = lib().tavsr_gemm_ws(C.byref(d))
     if need > 0:
         ws = torch.empty(need, dtype=f32, device=Cc.device)
         d.ws, d.ws_floats = ws.data_ptr(), need
+
+    def call():
+        if force is None:
+            check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
+        else:
+            check(lib().tavsr_gemm_tune(C.byref(d), int(force[0]), int(force[1]), stream()), "tavsr_gemm_tune")
+
     if PROFILE is None:
-        check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
+        call()
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
+    call()
     e1.record()
     key = _gemm_kernel_key(d)
     if PROFILE.by_shape:
@@ -119,14 +152,17 @@ def linear_dx(dy, w, *, alpha=1.0, DZ=None, dact=None, res=None, out=None):
     return out
 
 
-def linear_dw(dy, x, *, alpha=1.0, out=None):
-    """dW = alpha * dy.T @ x;  dy [M,N], x [M,K] -> [N,K] (torch weight layout)."""
+def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False):
+    """dW = alpha * dy.T @ x;  dy [M,N], x [M,K] -> [N,K] (torch weight layout).  With ``bias_grad`` also returns
+    db = alpha * dy.sum(0), computed by the same launch from the A fragments (tavsr_gemm a_rowsum)."""
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
         out = empty(N, K, like=dy)
-    gemm(N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), a_kmajor=True, b_kmajor=True, alpha=alpha)
-    return out
+    gb = empty(N, like=dy) if bias_grad else None
+    gemm(N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), a_kmajor=True, b_kmajor=True, alpha=alpha,
+         a_rowsum=gb)
+    return (out, gb) if bias_grad else out
 
 
 def colsum(x, *, scale=1.0, out=None, accumulate=False):

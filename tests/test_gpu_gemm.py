@@ -151,3 +151,35 @@ def test_gemm_unaligned_tail_vector_path():
     ops.gemm(W, dk, T, sk, 200, q, dk, out2, dk, a_kmajor=True, b_kmajor=True)
     ref2 = sk[:, :W].double().t() @ q.double()
     assert (out2.double() - ref2).abs().max() / ref2.abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 3168), (2048, 256, 3168), (768, 256, 3168), (41, 256, 1312), (256, 4864, 3168),
+                                    (256, 2304, 6016)])
+def test_gemm_fused_bias_grad(M, N, K):
+    """dW = alpha dY^T X and db = alpha dY.sum(0) from ONE launch (a_rowsum), split-K and plain paths."""
+    from tavsr import ops
+    torch.manual_seed(5)
+    dy, x = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda")
+    gw, gb = ops.linear_dw(dy, x, alpha=0.5, bias_grad=True)
+    ref_w = 0.5 * dy.double().t() @ x.double()
+    ref_b = 0.5 * dy.double().sum(0)
+    assert (gw.double() - ref_w).abs().max() / ref_w.abs().max() < 2e-6
+    assert (gb.double() - ref_b).abs().max() / ref_b.abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("cfg", range(8))
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
+def test_gemm_every_tile_config(cfg, mode):
+    """each tile configuration of the planner's table, forced, incl. ragged edges and a forced K split"""
+    from tavsr import ops
+    torch.manual_seed(cfg)
+    M, N, K = 300, 200, 416
+    a, b = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda")
+    A = a.t().contiguous() if mode == "TN" else a
+    B = b if mode != "NT" else b.t().contiguous()
+    ref = a.double() @ b.double()
+    for ns in (1, 3):
+        out = torch.zeros(M, N, device="cuda")
+        ops.gemm(M, N, K, A, A.stride(0), B, B.stride(0), out, N, a_kmajor=mode == "TN", b_kmajor=mode != "NT",
+                 force=(cfg, ns))
+        assert (out.double() - ref).abs().max() / ref.abs().max() < 2e-6, (cfg, mode, ns)
