@@ -192,10 +192,90 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int row, 
   }
 }
 
+// Common tail of both kernels: lane pairs complete the row sums, then either the split-K slab store or the fused
+// epilogue.  Accumulator layout: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int TM, int TN>
+__device__ __forceinline__ void finish_tile(const GemmArgs& args, f32x16 (&acc)[TM][TN], float (&asum)[TM],
+                                            bool want_rowsum, int m0, int n0, int wm, int wn, int lr, int lk, int z1,
+                                            int z2, int64_t coff) {
+  const tavsr_gemm_desc& d = args.d;
+  if (want_rowsum) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asum[i] += __shfl_xor(asum[i], 32, 64);
+  }
+
+  // ---- split-K: every slice stores its raw accumulators (and row sums) to its slab; splitk_epilogue_kernel
+  //      sums the slabs in slice order (deterministic) and applies the epilogue
+  if (args.nsplit > 1) {
+    const int64_t mn = (int64_t)d.M * d.N;
+    const int nbatch = gridDim.y;
+    float* slab = d.ws + ((int64_t)blockIdx.z * nbatch + blockIdx.y) * mn;
+    float* rsum0 = d.ws + (int64_t)args.nsplit * nbatch * mn;       // [nsplit][M] (only when nbatch == 1)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + lr;
+      if (n >= d.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < d.M) slab[(int64_t)m * d.N + n] = acc[i][j][r];
+        }
+      }
+    }
+    if (want_rowsum && lk == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * TM * 32 + i * 32 + lr;
+        if (m < d.M) rsum0[(int64_t)blockIdx.z * d.M + m] = asum[i];
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (want_rowsum && lk == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * TM * 32 + i * 32 + lr;
+      if (m < d.M) d.a_rowsum[m] = d.alpha * asum[i];
+    }
+  }
+  float* C = d.C + coff;
+  float* Z = d.Z ? d.Z + coff : nullptr;
+  const float* R = d.R ? d.R + z1 * d.sR1 + z2 * d.sR2 : nullptr;
+  const float* DZ = d.DZ ? d.DZ + coff : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + lr;
+    if (n >= d.N) continue;
+    const float bv = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lk;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m >= d.M) continue;
+        float v = acc[i][j][r] + bv;
+        const int64_t o = (int64_t)m * d.ldc + n;
+        if (Z) Z[o] = v;
+        v = act_fwd(d.act, v);
+        if (DZ) v *= act_bwd(d.dact, DZ[o]);
+        v *= d.alpha;
+        if (R) v += R[(int64_t)m * d.ldr + n];
+        C[o] = v;
+      }
+    }
+  }
+}
+
 // MINW: waves per SIMD the register allocation must leave room for (blocks per CU x waves per block / 4):
 // 4 blocks/CU for the 64x64 tile (its K-step is short: latency is hidden by co-resident blocks), 2 for the
 // larger tiles (LDS admits two of them per CU).
-template <int BM, int BN, int BK, int WM, int WN, int PF, int MINW, bool AK, bool BKM, bool VEC, int ABL = 0>
+template <int BM, int BN, int BK, int WM, int WN, int PF, int MINW, bool AK, bool BKM, bool VEC>
 __global__ __launch_bounds__(WM* WN * 64, MINW)
 void gemm_kernel(const GemmArgs args) {
   const tavsr_gemm_desc& d = args.d;
@@ -286,11 +366,9 @@ void gemm_kernel(const GemmArgs args) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) read_frag<BN, BK, BKM>(b_s, brow + j * 32, 0, lk, bf[0][j]);
     if (do_store) {   // tile kt+1 -> the other buffer (its readers finished at the previous barrier)
-      if (!(ABL & 2)) {
-        LA::store(smem + (cur ^ 1) * STAGE, tid, qa);
-        LB::store(smem + (cur ^ 1) * STAGE + TA::SIZE, tid, qb);
-      }
-      if (do_load && !(ABL & 1)) load_tile(kt + 1 + PF, qa, qb, fast_tag);
+      LA::store(smem + (cur ^ 1) * STAGE, tid, qa);
+      LB::store(smem + (cur ^ 1) * STAGE + TA::SIZE, tid, qb);
+      if (do_load) load_tile(kt + 1 + PF, qa, qb, fast_tag);
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -301,7 +379,6 @@ void gemm_kernel(const GemmArgs args) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) read_frag<BN, BK, BKM>(b_s, brow + j * 32, g + 1, lk, bf[c ^ 1][j]);
       }
-      if (ABL & 8) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -313,7 +390,7 @@ void gemm_kernel(const GemmArgs args) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) asum[i] += (af[c][i][0] + af[c][i][1]) + (af[c][i][2] + af[c][i][3]);
     }
-    if (!(ABL & 4)) __syncthreads();
+    __syncthreads();
   };
   auto run_loop = [&](auto fast_tag) {
     if (nk > 0) {
@@ -343,116 +420,210 @@ void gemm_kernel(const GemmArgs args) {
   if (fast) run_loop(std::true_type{});
   else run_loop(std::false_type{});
 
-  if (want_rowsum) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) asum[i] += __shfl_xor(asum[i], 32, 64);
-  }
+  finish_tile<TM, TN>(args, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
+}
 
-  // ---- split-K: every slice stores its raw accumulators (and row sums) to its slab; splitk_epilogue_kernel
-  //      sums the slabs in slice order (deterministic) and applies the epilogue
-  if (args.nsplit > 1) {
-    const int64_t mn = (int64_t)d.M * d.N;
-    const int nbatch = gridDim.y;
-    float* slab = d.ws + ((int64_t)blockIdx.z * nbatch + blockIdx.y) * mn;
-    float* rsum0 = d.ws + (int64_t)args.nsplit * nbatch * mn;       // [nsplit][M] (only when nbatch == 1)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * TN * 32 + j * 32 + lr;
-      if (n >= d.N) continue;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lk;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < d.M) slab[(int64_t)m * d.N + n] = acc[i][j][r];
-        }
-      }
-    }
-    if (want_rowsum && lk == 0) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * TM * 32 + i * 32 + lr;
-        if (m < d.M) rsum0[(int64_t)blockIdx.z * d.M + m] = asum[i];
-      }
-    }
-    return;
-  }
+// ---------------------------------------------------------------------------------------------- LDS-DMA kernel
+// Fast path for tiles whose operands can be fetched with unpredicated 16-byte loads (aligned, K a multiple of 32,
+// row-contiguous operands with rows % 4 == 0).  Operand tiles go global -> LDS directly (global_load_lds_dwordx4:
+// no staging registers, so the compiler cannot turn the prefetch into a synchronous load by copying its result
+// registers - which is what it did to the register ring of gemm_kernel, profiles/r01_gemm_notes.md) through a ring
+// of S LDS stages; a counted s_waitcnt vmcnt leaves S-2 tiles in flight across the ONE barrier per K-step.
+// LDS images (a wave-instruction writes 1 KB linearly: no padding possible, conflicts are avoided by swizzling):
+//   k-contiguous operand  : [row][32 floats]; 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7)
+//                           (the SOURCE address is permuted, the LDS write stays linear; ds_read_b128 applies the
+//                           same XOR: the 16 lanes of a b128 group hit 16 distinct 16-byte slots)
+//   row-contiguous operand: [k][ROWS floats], read by ds_read_b32 over 32 consecutive rows
+typedef __attribute__((address_space(3))) float lds_float;
+typedef const __attribute__((address_space(1))) float glb_float;
 
-  // ---- epilogue: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-  if (want_rowsum && lk == 0) {
+template <int ROWS, bool KMAJOR, int NT>
+struct GLoader {
+  static constexpr int NR = ROWS * 8 / NT;   // LDS-DMA instructions per thread per tile
+  static_assert(ROWS * 8 % NT == 0, "tile must divide over the block");
+  __device__ static __forceinline__ void offsets(int64_t ld, int row0, int nrows, int tid, int64_t (&off)[NR]) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * TM * 32 + i * 32 + lr;
-      if (m < d.M) d.a_rowsum[m] = d.alpha * asum[i];
-    }
-  }
-  float* C = d.C + coff;
-  float* Z = d.Z ? d.Z + coff : nullptr;
-  const float* R = d.R ? d.R + z1 * d.sR1 + z2 * d.sR2 : nullptr;
-  const float* DZ = d.DZ ? d.DZ + coff : nullptr;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * TN * 32 + j * 32 + lr;
-    if (n >= d.N) continue;
-    const float bv = d.bias ? d.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lk;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m >= d.M) continue;
-        float v = acc[i][j][r] + bv;
-        const int64_t o = (int64_t)m * d.ldc + n;
-        if (Z) Z[o] = v;
-        v = act_fwd(d.act, v);
-        if (DZ) v *= act_bwd(d.dact, DZ[o]);
-        v *= d.alpha;
-        if (R) v += R[(int64_t)m * d.ldr + n];
-        C[o] = v;
+    for (int i = 0; i < NR; ++i) {
+      const int q = i * NT + tid;
+      if (KMAJOR) {
+        const int k = q / (ROWS / 4);
+        int r = row0 + (q % (ROWS / 4)) * 4;
+        if (r + 3 >= nrows) r = row0;            // rows past the edge are never stored: any valid address will do
+        off[i] = (int64_t)k * ld + r;
+      } else {
+        const int row = q >> 3, cp = q & 7;
+        const int cl = cp ^ ((row >> 1) & 7);
+        off[i] = (int64_t)min(row0 + row, nrows - 1) * ld + cl * 4;
       }
     }
   }
+  __device__ static __forceinline__ void issue(const float* __restrict__ g, const int64_t (&off)[NR],
+                                               float* __restrict__ stage, int wave) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      __builtin_amdgcn_global_load_lds((glb_float*)(g + off[i]), (lds_float*)(stage + (i * NT + wave * 64) * 4), 16, 0, 0);
+  }
+};
+
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void read_frag_g(const float* __restrict__ s, int row, int g, int lk, float (&f)[4]) {
+  if (KMAJOR) {
+    const float* p = s + (g * 8 + 4 * lk) * ROWS + row;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = p[j * ROWS];
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(s + row * 32 + (((2 * g + lk) ^ ((row >> 1) & 7)) << 2));
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM>
+__global__ __launch_bounds__(WM* WN * 64, MINW)
+void gemm_glds_kernel(const GemmArgs args) {
+  const tavsr_gemm_desc& d = args.d;
+  constexpr int BK = 32, NG = BK / 8;
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  using LA = GLoader<BM, AK, NT>;
+  using LB = GLoader<BN, BKM, NT>;
+  constexpr int ASZ = BM * BK, STAGE = (BM + BN) * BK;
+  constexpr int G = LA::NR + LB::NR;          // LDS-DMA instructions per wave per tile
+  static_assert((S - 2) * G <= 63, "vmcnt field");
+  __shared__ __attribute__((aligned(1024))) float smem[S * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lk = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int m0 = (bid / args.tiles_n) * BM;
+  const int n0 = (bid % args.tiles_n) * BN;
+  const int z1 = blockIdx.y / d.nb2, z2 = blockIdx.y % d.nb2;
+  const float* A = d.A + z1 * d.sA1 + z2 * d.sA2;
+  const float* B = d.B + z1 * d.sB1 + z2 * d.sB2;
+  const int64_t coff = z1 * d.sC1 + z2 * d.sC2;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float asum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+  const bool want_rowsum = d.a_rowsum != nullptr && n0 == 0 && wn == 0;
+
+  const int kbeg = blockIdx.z * args.kchunk;
+  const int kend = min(d.K, kbeg + args.kchunk);
+  const int nk = (kend - kbeg) / BK;          // whole K-steps only (host guarantees it)
+  const int64_t kstepA = AK ? (int64_t)BK * d.lda : BK;
+  const int64_t kstepB = BKM ? (int64_t)BK * d.ldb : BK;
+  int64_t offA[LA::NR], offB[LB::NR];
+  LA::offsets(d.lda, m0, d.M, tid, offA);
+  LB::offsets(d.ldb, n0, d.N, tid, offB);
+  const float* Ak = A + (AK ? (int64_t)kbeg * d.lda : kbeg);
+  const float* Bk = B + (BKM ? (int64_t)kbeg * d.ldb : kbeg);
+  auto issue = [&](int kt, int st) {
+    LA::issue(Ak + kt * kstepA, offA, smem + st * STAGE, wave);
+    LB::issue(Bk + kt * kstepB, offB, smem + st * STAGE + ASZ, wave);
+  };
+  const int arow = wm * TM * 32 + lr, brow = wn * TN * 32 + lr;
+  auto compute = [&](int st) {
+    const float* a_s = smem + st * STAGE;
+    const float* b_s = a_s + ASZ;
+    float af[2][TM][4], bf[2][TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) read_frag_g<BM, AK>(a_s, arow + i * 32, 0, lk, af[0][i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) read_frag_g<BN, BKM>(b_s, brow + j * 32, 0, lk, bf[0][j]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int c = g & 1;
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_frag_g<BM, AK>(a_s, arow + i * 32, g + 1, lk, af[c ^ 1][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_frag_g<BN, BKM>(b_s, brow + j * 32, g + 1, lk, bf[c ^ 1][j]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i][kk], bf[c][j][kk], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asum[i] += (af[c][i][0] + af[c][i][1]) + (af[c][i][2] + af[c][i][3]);
+    }
+  };
+
+  // prologue: tiles 0 .. S-2 in flight
+#pragma unroll
+  for (int j = 0; j < S - 1; ++j)
+    if (j < nk) issue(j, j);
+  int st = 0;             // stage of tile kt
+  int kt = 0;
+  // steady state: tile kt landed when at most (S-2) tiles issued after it are still in flight
+  for (; kt + S - 1 < nk; ++kt) {
+    wait_vmcnt<(S - 2) * G>();
+    __builtin_amdgcn_s_barrier();      // every wave's part of tile kt is in LDS; everyone left stage (kt-1) % S
+    const int sn = st == 0 ? S - 1 : st - 1;
+    issue(kt + S - 1, sn);
+    compute(st);
+    st = st + 1 == S ? 0 : st + 1;
+  }
+  // drain: nothing left to issue
+  for (; kt < nk; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    compute(st);
+    st = st + 1 == S ? 0 : st + 1;
+  }
+  finish_tile<TM, TN>(args, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
 struct Cfg {
-  int bm, bn, bk, wm, wn, pf;
+  int bm, bn, wm, wn, stages;
 };
-// tile configurations (index = cfg id of tavsr_gemm_tune)
+// LDS-DMA tile configurations (index = cfg id of tavsr_gemm_tune); id kFallbackCfg = the register-staged,
+// fully predicated 64x64 kernel that serves unaligned operands, K tails and ragged row-contiguous operands.
 static const Cfg kCfgs[] = {
-    {128, 128, 32, 2, 2, 1},   // 0: wave tile 64x64, 1 wave/SIMD per block, 72 KB LDS
-    {128, 128, 32, 2, 2, 2},   // 1: same, two K-steps of prefetch
-    {128, 64, 32, 2, 2, 2},    // 2: wave tile 64x32
-    {64, 128, 32, 2, 2, 2},    // 3: wave tile 32x64
-    {64, 64, 32, 2, 2, 2},     // 4: wave tile 32x32
-    {64, 64, 32, 2, 2, 4},     // 5: wave tile 32x32, four K-steps of prefetch
-    {128, 128, 32, 2, 4, 2},   // 6: 8 waves, wave tile 64x32 (2 waves/SIMD inside one block)
-    {128, 64, 32, 2, 2, 3},    // 7: wave tile 64x32, three K-steps of prefetch
+    {128, 128, 2, 2, 3},   // 0: wave tile 64x64, 96 KB LDS, one block per CU
+    {128, 128, 2, 4, 3},   // 1: 8 waves, wave tile 64x32 (two waves per SIMD inside the block)
+    {128, 64, 2, 2, 3},    // 2: wave tile 64x32, 72 KB, two blocks per CU
+    {64, 128, 2, 2, 3},    // 3: wave tile 32x64
+    {64, 64, 2, 2, 3},     // 4: wave tile 32x32, 48 KB, three blocks per CU
+    {64, 64, 2, 2, 4},     // 5: wave tile 32x32, four stages (three tiles in flight), two blocks per CU
+    {128, 64, 2, 2, 4},    // 6: wave tile 64x32, four stages, one block per CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-constexpr int kFallbackCfg = 4;   // the only configuration instantiated for unaligned (scalar-load) operands
+constexpr int kFallbackCfg = 9;
 
-template <int BM, int BN, int BK, int WM, int WN, int PF, int MINW, int ABL = 0>
-static int launch_cfg(const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
-  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, BM), cdiv(d.N, BN)};
-  dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
-  dim3 block(WM * WN * 64);
-#define TAVSR_GEMM_LAUNCH(AK, BKM)                                                                   \
-  do {                                                                                               \
-    if (vec)                                                                                         \
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, PF, MINW, AK, BKM, true, ABL>), grid, block, 0, s, a); \
-    else if constexpr (BM == 64 && BN == 64 && PF == 2 && ABL == 0)                                              \
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, PF, MINW, AK, BKM, false>), grid, block, 0, s, a);\
-  } while (0)
-  if (!d.a_kmajor && !d.b_kmajor) TAVSR_GEMM_LAUNCH(false, false);
-  else if (!d.a_kmajor && d.b_kmajor) TAVSR_GEMM_LAUNCH(false, true);
-  else if (d.a_kmajor && d.b_kmajor) TAVSR_GEMM_LAUNCH(true, true);
-  else TAVSR_GEMM_LAUNCH(true, false);
-#undef TAVSR_GEMM_LAUNCH
-  TAVSR_LAUNCH_CHECK();
-  if (nsplit > 1) {
+template <typename F>
+static int launch_layout(const tavsr_gemm_desc& d, F&& f) {
+  if (!d.a_kmajor && !d.b_kmajor) return f(std::false_type{}, std::false_type{});
+  if (!d.a_kmajor && d.b_kmajor) return f(std::false_type{}, std::true_type{});
+  if (d.a_kmajor && d.b_kmajor) return f(std::true_type{}, std::true_type{});
+  return f(std::true_type{}, std::false_type{});
+}
+
+static int launch_epilogue(const GemmArgs& a, hipStream_t s) {
+  const tavsr_gemm_desc& d = a.d;
+  if (a.nsplit > 1) {
     const int64_t mn = (int64_t)d.M * d.N;
     if (d.N % 4 == 0)
       hipLaunchKernelGGL(splitk_epilogue_kernel<4>, dim3(cdiv(mn / 4, 256), d.nb1 * d.nb2), dim3(256), 0, s, a);
@@ -463,33 +634,45 @@ static int launch_cfg(const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk
   return TAVSR_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int S, int MINW>
+static int launch_glds(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStream_t s) {
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, BM), cdiv(d.N, BN)};
+  dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
+  int rc = launch_layout(d, [&](auto ak, auto bk) {
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, S, MINW, decltype(ak)::value, decltype(bk)::value>), grid,
+                       dim3(WM * WN * 64), 0, s, a);
+    TAVSR_LAUNCH_CHECK();
+    return (int)TAVSR_OK;
+  });
+  return rc ? rc : launch_epilogue(a, s);
+}
+
+static int launch_fallback(const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64)};
+  dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
+  int rc = launch_layout(d, [&](auto ak, auto bk) {
+    if (vec)
+      hipLaunchKernelGGL((gemm_kernel<64, 64, 32, 2, 2, 2, 4, decltype(ak)::value, decltype(bk)::value, true>), grid,
+                         dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_kernel<64, 64, 32, 2, 2, 2, 4, decltype(ak)::value, decltype(bk)::value, false>), grid,
+                         dim3(256), 0, s, a);
+    TAVSR_LAUNCH_CHECK();
+    return (int)TAVSR_OK;
+  });
+  return rc ? rc : launch_epilogue(a, s);
+}
+
 static int launch(int cfg, const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
-  if (!vec) cfg = kFallbackCfg;
-#ifdef TAVSR_GEMM_ABLATE   // timing-only variants (wrong results): which part of the K-step costs what
   switch (cfg) {
-    case 101: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 1>(d, vec, nsplit, kchunk, s);   // no global loads
-    case 103: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 3>(d, vec, nsplit, kchunk, s);   // + no LDS writes
-    case 107: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 7>(d, vec, nsplit, kchunk, s);   // + no barrier
-    case 102: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 2>(d, vec, nsplit, kchunk, s);   // loads but no LDS writes
-    case 108: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 8>(d, vec, nsplit, kchunk, s);   // full, reads pinned before MFMAs
-    case 115: return launch_cfg<64, 64, 32, 2, 2, 2, 4, 15>(d, vec, nsplit, kchunk, s);  // pure loop, pinned
-    case 118: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 8>(d, vec, nsplit, kchunk, s);
-    case 125: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 15>(d, vec, nsplit, kchunk, s);
-    case 111: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 1>(d, vec, nsplit, kchunk, s);
-    case 113: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 3>(d, vec, nsplit, kchunk, s);
-    case 117: return launch_cfg<128, 128, 32, 2, 2, 1, 2, 7>(d, vec, nsplit, kchunk, s);
-    default: break;
-  }
-#endif
-  switch (cfg) {
-    case 0: return launch_cfg<128, 128, 32, 2, 2, 1, 2>(d, vec, nsplit, kchunk, s);
-    case 1: return launch_cfg<128, 128, 32, 2, 2, 2, 2>(d, vec, nsplit, kchunk, s);
-    case 2: return launch_cfg<128, 64, 32, 2, 2, 2, 2>(d, vec, nsplit, kchunk, s);
-    case 3: return launch_cfg<64, 128, 32, 2, 2, 2, 2>(d, vec, nsplit, kchunk, s);
-    case 4: return launch_cfg<64, 64, 32, 2, 2, 2, 4>(d, vec, nsplit, kchunk, s);
-    case 5: return launch_cfg<64, 64, 32, 2, 2, 4, 3>(d, vec, nsplit, kchunk, s);
-    case 6: return launch_cfg<128, 128, 32, 2, 4, 2, 2>(d, vec, nsplit, kchunk, s);
-    default: return launch_cfg<128, 64, 32, 2, 2, 3, 2>(d, vec, nsplit, kchunk, s);
+    case 0: return launch_glds<128, 128, 2, 2, 3, 1>(d, nsplit, kchunk, s);
+    case 1: return launch_glds<128, 128, 2, 4, 3, 2>(d, nsplit, kchunk, s);
+    case 2: return launch_glds<128, 64, 2, 2, 3, 2>(d, nsplit, kchunk, s);
+    case 3: return launch_glds<64, 128, 2, 2, 3, 2>(d, nsplit, kchunk, s);
+    case 4: return launch_glds<64, 64, 2, 2, 3, 3>(d, nsplit, kchunk, s);
+    case 5: return launch_glds<64, 64, 2, 2, 4, 2>(d, nsplit, kchunk, s);
+    case 6: return launch_glds<128, 64, 2, 2, 4, 1>(d, nsplit, kchunk, s);
+    default: return launch_fallback(d, vec, nsplit, kchunk, s);
   }
 }
 
@@ -497,19 +680,28 @@ struct Plan {
   int cfg, nsplit, kchunk;
 };
 
-// Planner (fitted to profiles/r01_gemm_sweep_v2.txt, MI355X): the 64x64 tile (4 blocks/CU) wins every hot-path
-// shape below ~1000 tiles of 128x128; above that the 8-wave 128x128 tile does.  Few-tile, long-K problems (weight
-// gradients: K = B*T) are split over K so that >= ~768 blocks exist.
-static Plan plan(const tavsr_gemm_desc& d, bool allow_split) {
+// Can the LDS-DMA kernel take this problem?  (unpredicated 16-byte loads: aligned operands, whole K-steps per
+// K slice, row-contiguous operands with a row count that is a multiple of 4)
+static bool glds_ok(const tavsr_gemm_desc& d, bool vec) {
+  return vec && d.K % 32 == 0 && d.K >= 32 && (!d.a_kmajor || d.M % 4 == 0) && (!d.b_kmajor || d.N % 4 == 0);
+}
+
+// Planner (fitted to profiles/r01_gemm_sweep_v3.txt, MI355X).  The 64x64 tile with three LDS stages wins or
+// ties every hot-path shape (three blocks per CU hide each other's barrier and LDS latency; larger tiles lose more
+// to tile quantisation at M = 3168 than they gain).  Few-tile, long-K problems (weight gradients: K = B*T; the
+// N = 256 projections with K >= 2048) are split over K so that ~450 blocks exist; more slices than that cost
+// more in slab traffic than they gain in occupancy.
+static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
   const long nbatch = (long)d.nb1 * d.nb2;
-  if ((long)cdiv(d.M, 128) * cdiv(d.N, 128) * nbatch >= 900) return Plan{6, 1, d.K};
-  Plan p{kFallbackCfg, 1, d.K};
+  Plan p{fast ? 4 : kFallbackCfg, 1, d.K};
   const long tiles = (long)cdiv(d.M, 64) * cdiv(d.N, 64) * nbatch;
-  if (!allow_split || tiles >= 384 || d.K < 8 * 32) return p;
-  const long want = std::min<long>({(long)cdiv(768, tiles), (long)d.K / (4 * 32), 64L});
+  if (!allow_split || tiles >= 384 || d.K < 512) return p;
+  if (d.K <= 1024 && tiles >= 150) return p;
+  long want = std::min<long>((448 + tiles / 2) / tiles, d.K / 256);
   if (want < 2) return p;
   p.kchunk = cdiv(cdiv(d.K, want), 32) * 32;
   p.nsplit = cdiv(d.K, p.kchunk);
+  if (p.nsplit < 2) p = Plan{p.cfg, 1, d.K};
   return p;
 }
 
@@ -536,10 +728,12 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
   const bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.sA1 % 4 == 0 &&
                    d.sA2 % 4 == 0 && d.sB1 % 4 == 0 && d.sB2 % 4 == 0;
   const bool can_split = d.ws != nullptr;
-  Plan p = plan(d, can_split);
+  const bool fast = glds_ok(d, vec);
+  Plan p = plan(d, can_split, fast);
   if (force_cfg >= 0) {
-    TAVSR_REQUIRE(force_cfg < kNumCfgs || force_cfg >= 100, TAVSR_EINVAL, "tavsr_gemm_tune: cfg %d out of range", force_cfg);
-    p.cfg = force_cfg;
+    TAVSR_REQUIRE(force_cfg < kNumCfgs || force_cfg == kFallbackCfg, TAVSR_EINVAL, "tavsr_gemm_tune: cfg %d out of range",
+                  force_cfg);
+    p.cfg = fast ? force_cfg : kFallbackCfg;
     const int bk = 32;
     int ns = std::max(1, force_split);
     p.kchunk = cdiv(cdiv(d.K, ns), bk) * bk;
@@ -548,7 +742,7 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
   if (p.nsplit > 1) {
     if (!can_split || d.ws_floats < ws_floats_for(d, p.nsplit)) {
       TAVSR_REQUIRE(force_cfg < 0, TAVSR_EINVAL, "tavsr_gemm_tune: workspace too small for the forced split");
-      p = plan(d, false);
+      p = plan(d, false, fast);
     }
   }
   return launch(p.cfg, d, vec, p.nsplit, p.kchunk, s);
@@ -573,6 +767,8 @@ extern "C" int64_t tavsr_gemm_ws(const tavsr_gemm_desc* dp) {
   if (d.nb1 <= 0) d.nb1 = 1;
   if (d.nb2 <= 0) d.nb2 = 1;
   if (d.M <= 0 || d.N <= 0) return 0;
-  Plan p = plan(d, true);
+  const bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.sA1 % 4 == 0 &&
+                   d.sA2 % 4 == 0 && d.sB1 % 4 == 0 && d.sB2 % 4 == 0;
+  Plan p = plan(d, true, glds_ok(d, vec));
   return ws_floats_for(d, p.nsplit);
 }

@@ -335,6 +335,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             if prm is None:
                 G[i] = None
         ctx.sv = None
+        ops.join_side()
         return (dx.view(B, T, D), None, None, None, *G)
 
 
@@ -378,6 +379,7 @@ class LinearFn(torch.autograd.Function):
             gw, gb = ops.linear_dw(dy2, x2, alpha=ctx.alpha, bias_grad=True)
         else:
             gw, gb = ops.linear_dw(dy2, x2, alpha=ctx.alpha), None
+        ops.join_side()
         return (None if dx is None else dx.view(*dy.shape[:-1], w.shape[1])), gw, gb, None
 
 
@@ -408,14 +410,15 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         do = dout.contiguous().view(B * T2, -1)
         y2f = y2.view(B * T2, F2 * Cn)
         gwor, gbo = ops.linear_dw(do, y2f, alpha=xscale, bias_grad=True)        # [odim, F2*C], [odim]
-        gwo = ops.transpose_inner(gwor, wos[0], F2, Cn).view(wos)
         # dz2 = (do @ wor) * xscale * relu'(y2)
         dz2 = ops.linear_dx(do, wor, alpha=xscale, DZ=y2f, dact="relu").view(B * T2 * F2, Cn)
         gw2r, gb2 = ops.linear_dw(dz2, col, bias_grad=True)                     # [C, 9C], [C]
-        gw2 = ops.transpose_inner(gw2r, Cn, 9, Cn).view(w2s)
         dcol = ops.linear_dx(dz2, w2r)                                          # [B*T2*F2, 9C]
         dz1 = ops.col2im3x3s2_relu(dcol, y1)
         gw1, gb1 = ops.conv1_bwd(dz1, x.contiguous(), Cn)
+        ops.join_side()   # the weight gradients ran on the side stream: re-index them to torch order after the join
+        gwo = ops.transpose_inner(gwor, wos[0], F2, Cn).view(wos)
+        gw2 = ops.transpose_inner(gw2r, Cn, 9, Cn).view(w2s)
         return None, gw1.view(w1s), gb1, gw2, gb2, gwo, gbo, None
 
 
@@ -446,6 +449,7 @@ class CTCLossFn(torch.autograd.Function):
         gs = ops.scale_dev(g2, dl.contiguous(), 1.0 / B)   # dlogits = g * dl / B, dl stays on the device
         dx = ops.linear_dx(gs, w)
         gw, gb = ops.linear_dw(gs, x2, bias_grad=True)
+        ops.join_side()
         return dx.view(B, -1, x2.shape[1]), gw, gb, None, None, None, None, None
 
 
@@ -586,6 +590,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             put("norm1.weight", g1); put("norm1.bias", g2)
         G[0] = ops.embed_bwd(ctx.ys_in.contiguous(), dx, math.sqrt(D), P[0].shape[0])
         ctx.saved = None
+        ops.join_side()
         return (dmem.view(B, T, D), None, None, None, None, None, *G)
 
 

@@ -5,6 +5,7 @@ Every function raises ``TavsrError`` on a CPU tensor or a failed call - there is
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -152,16 +153,56 @@ def linear_dx(dy, w, *, alpha=1.0, DZ=None, dact=None, res=None, out=None):
     return out
 
 
+# Weight-gradient GEMMs have few output tiles and a long K (= B*T rows): alone they fill a fraction of the 256 CUs.
+# They are leaves of the backward graph, so they are issued on a side stream and run beside the data-gradient chain
+# of the main stream (inside a captured hipGraph this is simply a parallel branch).  Every backward Function calls
+# ``join_side()`` before it returns, which orders the side stream before anything that consumes or frees its operands.
+WGRAD_SIDE_STREAM = os.environ.get("TAVSR_WGRAD_STREAM", "0") == "1"   # measured: no gain under hipGraph replay
+_SIDE = {}
+
+
+def side_stream() -> torch.cuda.Stream:
+    dev = torch.cuda.current_device()
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+class _SideScope:
+    def __enter__(self):
+        self.main = torch.cuda.current_stream()
+        self.side = side_stream()
+        self.on = WGRAD_SIDE_STREAM and self.main != self.side
+        if self.on:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_side():
+    """main stream waits for every weight-gradient launch issued so far on the side stream."""
+    if WGRAD_SIDE_STREAM and torch.cuda.current_device() in _SIDE:
+        torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
+
+
 def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False):
     """dW = alpha * dy.T @ x;  dy [M,N], x [M,K] -> [N,K] (torch weight layout).  With ``bias_grad`` also returns
     db = alpha * dy.sum(0), computed by the same launch from the A fragments (tavsr_gemm a_rowsum)."""
     M, N = dy.shape
     K = x.shape[1]
-    if out is None:
-        out = empty(N, K, like=dy)
-    gb = empty(N, like=dy) if bias_grad else None
-    gemm(N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), a_kmajor=True, b_kmajor=True, alpha=alpha,
-         a_rowsum=gb)
+    with _SideScope():
+        if out is None:
+            out = empty(N, K, like=dy)
+        gb = empty(N, like=dy) if bias_grad else None
+        gemm(N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), a_kmajor=True, b_kmajor=True, alpha=alpha,
+             a_rowsum=gb)
     return (out, gb) if bias_grad else out
 
 
