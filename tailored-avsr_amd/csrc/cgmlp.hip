@@ -27,11 +27,16 @@ __global__ __launch_bounds__(256) void dwconv_gate_fwd_kernel(const float* __res
   const int c0 = blockIdx.x * CG_CH, t0 = blockIdx.y * CG_TT, b = blockIdx.z;
   const int c = c0 + cx;
   const int rows = CG_TT + K - 1;
-  for (int i = ty; i < rows; i += 4) {
-    int t = t0 + i - pad;
-    float v = 0.f;
-    if (t >= 0 && t < T && c < C) v = gn[((int64_t)b * T + t) * C + c];
-    s_x[i * CG_CH + cx] = v;
+  for (int ib = ty * 4; ib < rows; ib += 16) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ib + q, t = t0 + i - pad;
+      v[q] = (i < rows && t >= 0 && t < T && c < C) ? gn[((int64_t)b * T + t) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ib + q < rows) s_x[(ib + q) * CG_CH + cx] = v[q];
   }
   for (int k = ty; k < K; k += 4) s_w[k * CG_CH + cx] = c < C ? w[(int64_t)c * K + k] : 0.f;
   __syncthreads();
@@ -40,11 +45,18 @@ __global__ __launch_bounds__(256) void dwconv_gate_fwd_kernel(const float* __res
   for (int tt = ty; tt < CG_TT; tt += 4) {
     int t = t0 + tt;
     if (t >= T) break;
-    float acc = bv;
-    for (int k = 0; k < K; ++k) acc += s_w[k * CG_CH + cx] * s_x[(tt + k) * CG_CH + cx];
     int64_t m = (int64_t)b * T + t;
+    const float rv = r[m * ldr + c];      // issued before the tap loop: its latency hides under the FMAs
+    float a0 = bv, a1 = 0.f;
+    int k = 0;
+    for (; k + 1 < K; k += 2) {
+      a0 += s_w[k * CG_CH + cx] * s_x[(tt + k) * CG_CH + cx];
+      a1 += s_w[(k + 1) * CG_CH + cx] * s_x[(tt + k + 1) * CG_CH + cx];
+    }
+    if (k < K) a0 += s_w[k * CG_CH + cx] * s_x[(tt + k) * CG_CH + cx];
+    const float acc = a0 + a1;
     if (conv) conv[m * C + c] = acc;
-    out[m * C + c] = r[m * ldr + c] * acc;
+    out[m * C + c] = rv * acc;
   }
 }
 
@@ -79,16 +91,31 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(const float* __res
   const int ntap = (K + 1 - ty + 3) / 4;   // taps ty, ty+4, ... <= K
   for (int t0 = 0; t0 < T; t0 += CG_TB) {
     __syncthreads();   // previous tile fully consumed (and s_w visible)
-    for (int i = ty; i < rows; i += 4) {
-      const int t = t0 + i - pad;
-      float dv = 0.f, gv = 0.f;
-      if (t >= 0 && t < T && cok) {
-        const int64_t m = (int64_t)b * T + t;
-        dv = du[m * C + c] * r[m * ldr + c];
-        gv = gn[m * C + c];
+    // tile load, four rows per wave in flight (du, r, gn and - for the tile's own rows - conv: dr = du*conv is
+    // written here so that the compute loops below touch LDS only)
+    for (int ib = ty * 4; ib < rows; ib += 16) {
+      float duv[4], rv[4], gv[4], cv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ib + q, t = t0 + i - pad;
+        duv[q] = rv[q] = gv[q] = cv[q] = 0.f;
+        if (i < rows && t >= 0 && t < T && cok) {
+          const int64_t m = (int64_t)b * T + t;
+          duv[q] = du[m * C + c];
+          rv[q] = r[m * ldr + c];
+          gv[q] = gn[m * C + c];
+          if (i >= pad && i < pad + CG_TB) cv[q] = conv[m * C + c];
+        }
       }
-      s_d[i * CG_CH + cx] = dv;
-      s_g[i * CG_CH + cx] = gv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ib + q, t = t0 + i - pad;
+        if (i < rows) {
+          s_d[i * CG_CH + cx] = duv[q] * rv[q];
+          s_g[i * CG_CH + cx] = gv[q];
+          if (i >= pad && i < pad + CG_TB && t < T && cok) dr[((int64_t)b * T + t) * lddr + c] = duv[q] * cv[q];
+        }
+      }
     }
     __syncthreads();
     const int nt = min(CG_TB, T - t0);
@@ -96,7 +123,6 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(const float* __res
       // data gradients: rows tt = ty, ty+4, ...
       for (int tt = ty; tt < nt; tt += 4) {
         const int64_t m = (int64_t)b * T + t0 + tt;
-        dr[m * lddr + c] = du[m * C + c] * conv[m * C + c];
         float a0 = 0.f, a1 = 0.f;
         int k = 0;
         // dgn[t] = sum_k w[k] * dconv[t - k + pad]  -> LDS row (tt + pad) - k + pad

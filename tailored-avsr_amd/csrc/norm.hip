@@ -61,6 +61,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // ---- backward ---------------------------------------------------------------------------------
 // dx = dx_add + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  per-block partial sums of
 // dgamma = sum dy*xhat and dbeta = sum dy go to part[blk][2][D], summed by sum_partials_kernel.
+// One wave per row, LN_RPW rows per wave with the loads of both rows issued together (the kernel is pure
+// latency otherwise: 3168 rows x 1 KB); NV = D / 256 float4 chunks per lane.
+constexpr int LN_RPW = 2;
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ mean,
@@ -69,56 +73,71 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dx_add, int64_t ldadd,
                                                             float* __restrict__ dx, int64_t lddx,
                                                             float* __restrict__ part, int M, int D) {
-  __shared__ float red[4][2][LN_MAXV * 256];
+  __shared__ float red[4][2][NV * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float4 ag[LN_MAXV], ab[LN_MAXV];
+  float4 ag[NV], ab[NV], g[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
-    const float* xr = x + (int64_t)row * ldx;
-    const float* dr = dy + (int64_t)row * lddy;
-    const float mu = mean[row], rs = rstd[row];
-    float4 xh[LN_MAXV], gd[LN_MAXV];
-    float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < NV; ++i) {
+    ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = (i * 64 + lane) * 4;
+    g[i] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row0 = (blockIdx.x * 4 + w) * LN_RPW; row0 < M; row0 += gridDim.x * 4 * LN_RPW) {
+    float4 xv[LN_RPW][NV], dv[LN_RPW][NV], av[LN_RPW][NV];
+    float mu[LN_RPW], rs[LN_RPW];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c = (i * 64 + lane) * 4;
-      xh[i] = gd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < D) {
-        float4 xv = *reinterpret_cast<const float4*>(xr + c);
-        float4 dv = *reinterpret_cast<const float4*>(dr + c);
-        float4 g = *reinterpret_cast<const float4*>(gamma + c);
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-        ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
-        ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
-        gd[i] = make_float4(dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w);
+    for (int q = 0; q < LN_RPW; ++q) {
+      const int row = min(row0 + q, M - 1);
+      mu[q] = mean[row];
+      rs[q] = rstd[row];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        xv[q][i] = dv[q][i] = av[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < D) {
+          xv[q][i] = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + c);
+          dv[q][i] = *reinterpret_cast<const float4*>(dy + (int64_t)row * lddy + c);
+          if (dx_add) av[q][i] = *reinterpret_cast<const float4*>(dx_add + (int64_t)row * ldadd + c);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < LN_RPW; ++q) {
+      if (row0 + q >= M) break;
+      float4 xh[NV], gd[NV];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 X = xv[q][i], Dv = dv[q][i];
+        xh[i] = make_float4((X.x - mu[q]) * rs[q], (X.y - mu[q]) * rs[q], (X.z - mu[q]) * rs[q], (X.w - mu[q]) * rs[q]);
+        const int c = (i * 64 + lane) * 4;
+        if (c >= D) xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ag[i].x += Dv.x * xh[i].x; ag[i].y += Dv.y * xh[i].y; ag[i].z += Dv.z * xh[i].z; ag[i].w += Dv.w * xh[i].w;
+        ab[i].x += Dv.x; ab[i].y += Dv.y; ab[i].z += Dv.z; ab[i].w += Dv.w;
+        gd[i] = make_float4(Dv.x * g[i].x, Dv.y * g[i].y, Dv.z * g[i].z, Dv.w * g[i].w);
         s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
         s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
       }
-    }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
-    float* or_ = dx + (int64_t)row * lddx;
+      s1 = wave_sum(s1) / (float)D;
+      s2 = wave_sum(s2) / (float)D;
+      float* or_ = dx + (int64_t)(row0 + q) * lddx;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int c = (i * 64 + lane) * 4;
-      if (c < D) {
-        float4 o;
-        o.x = rs * (gd[i].x - s1 - xh[i].x * s2);
-        o.y = rs * (gd[i].y - s1 - xh[i].y * s2);
-        o.z = rs * (gd[i].z - s1 - xh[i].z * s2);
-        o.w = rs * (gd[i].w - s1 - xh[i].w * s2);
-        if (dx_add) {
-          float4 a = *reinterpret_cast<const float4*>(dx_add + (int64_t)row * ldadd + c);
-          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+          float4 o;
+          o.x = rs[q] * (gd[i].x - s1 - xh[i].x * s2) + av[q][i].x;
+          o.y = rs[q] * (gd[i].y - s1 - xh[i].y * s2) + av[q][i].y;
+          o.z = rs[q] * (gd[i].z - s1 - xh[i].z * s2) + av[q][i].z;
+          o.w = rs[q] * (gd[i].w - s1 - xh[i].w * s2) + av[q][i].w;
+          *reinterpret_cast<float4*>(or_ + c) = o;
         }
-        *reinterpret_cast<float4*>(or_ + c) = o;
       }
     }
   }
   // cross-wave reduce of the column partials, fixed order (deterministic)
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     int c = (i * 64 + lane) * 4;
     *reinterpret_cast<float4*>(&red[w][0][c]) = ag[i];
     *reinterpret_cast<float4*>(&red[w][1][c]) = ab[i];
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   if (ry == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
-static inline int ln_blocks(int M) { return min(cdiv(M, 4 * 8), 512); }
+static inline int ln_blocks(int M) { return min(cdiv(M, 4 * LN_RPW * 2), 512); }   // ~2 row pairs per wave
 static inline int colsum_chunks(int M) { return min(cdiv(M, 64), 64); }
 
 }  // namespace tavsr
@@ -215,8 +234,15 @@ extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x
   if (M <= 0) return TAVSR_OK;
   const int nb = ln_blocks(M);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                     ldadd, dx, lddx, ws, M, D);
+  if (D <= 256)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
+                       ldadd, dx, lddx, ws, M, D);
+  else if (D <= 512)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
+                       ldadd, dx, lddx, ws, M, D);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
+                       ldadd, dx, lddx, ws, M, D);
   TAVSR_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, s, ws, nb, (int64_t)2 * D, dgamma, dbeta,
                      D, 2 * D, accumulate, 1.f);
