@@ -209,15 +209,215 @@ def gen_cfg1_wav():
           ids=_np(ids), hyp=np.array(hyp, dtype=np.int64), top2_gap=_np(top2[..., 0] - top2[..., 1]))
 
 
+AVSR_YAML = "/root/reference/configs/AVSR/tailored_transformer+ctc_english.yaml"
+AVSR_CONV_YAML = "/root/reference/configs/AVSR/conventional_transformer+ctc_english.yaml"
+
+
+def _zero_dropout(d):
+    """every *dropout_rate key of a (nested) conf dict -> 0.0"""
+    for k, v in d.items():
+        if isinstance(v, dict):
+            _zero_dropout(v)
+        elif k.endswith("dropout_rate"):
+            d[k] = 0.0
+
+
+def avsr_conf(yaml_path=AVSR_YAML, num_blocks=12, dec_blocks=6, visual_input_size=None, **enc_over):
+    conf = yaml.safe_load(open(yaml_path))
+    conf["acoustic_input_size"] = 80
+    conf["visual_input_size"] = visual_input_size
+    conf["specaug"] = None
+    _zero_dropout(conf)
+    if conf["encoder"] == "tailored":
+        conf["encoder_conf"]["num_blocks"] = num_blocks
+        conf["encoder_conf"]["acoustic_use_attn"] = conf["encoder_conf"]["acoustic_use_attn"][:num_blocks]
+        conf["encoder_conf"]["visual_use_attn"] = conf["encoder_conf"]["visual_use_attn"][:num_blocks]
+    else:
+        conf["encoder_conf"]["acoustic_encoder_conf"]["num_blocks"] = num_blocks
+        conf["encoder_conf"]["visual_encoder_conf"]["num_blocks"] = num_blocks
+    conf["decoder_conf"]["num_blocks"] = dec_blocks
+    conf["encoder_conf"].update(enc_over)
+    return conf
+
+
+def gen_visual_frontend():
+    """Conv3dResNet18.forward (conv3d_resnet18.py:77-97), train mode (batch statistics) with gradients, and eval
+    mode (running statistics).  Only name-level stand-ins are involved (AbsFrontend, Swish): direct vectors."""
+    from src.frontend.conv3d_resnet18.conv3d_resnet18 import Conv3dResNet18
+
+    m = Conv3dResNet18(activation_type="swish")
+    fill_parameters_(m, seed=61)
+    B, T = 2, 5
+    x = synth((B, T, 88, 88), seed=62)
+    lens = torch.tensor([5, 4])
+    m.train()
+    y, _ = m(x, lens)
+    r = synth((B, T, 512), seed=63)
+    (y * r).sum().backward()
+    params = dict(m.named_parameters())
+    pick = ["frontend3D.0.weight", "frontend3D.1.weight", "frontend3D.1.bias", "trunk.layer1.0.conv1.weight",
+            "trunk.layer1.1.bn2.weight", "trunk.layer2.0.downsample.0.weight", "trunk.layer2.0.downsample.1.bias",
+            "trunk.layer3.1.conv2.weight", "trunk.layer4.0.conv1.weight", "trunk.layer4.1.bn2.bias"]
+    grads = {"g_" + n: compact(params[n].grad) for n in pick}
+    bufs = dict(m.named_buffers())
+    stats = {"rm_stem": _np(bufs["frontend3D.1.running_mean"]), "rv_stem": _np(bufs["frontend3D.1.running_var"]),
+             "rm_l4": _np(bufs["trunk.layer4.1.bn2.running_mean"]), "rv_l4": _np(bufs["trunk.layer4.1.bn2.running_var"]),
+             "nbt": _np(bufs["frontend3D.1.num_batches_tracked"])}
+    m.eval()
+    with torch.no_grad():
+        ye, _ = m(x, lens)
+    _save("av_frontend", B=B, T=T, y_train=_np(y), y_eval=_np(ye), keys=np.array(sorted(m.state_dict().keys())),
+          n_params=sum(p.numel() for p in m.parameters()), **grads, **stats)
+
+
+def gen_tailored():
+    """TailoredEncoderLayer / TailoredEncoder forward+backward (tailored/encoder_layer.py:118-274, encoder.py:221-332)
+    and AdaptiveAudioVisualFusion (adaptive_audiovisual_fusion.py:113-211)."""
+    from espnet.nets.pytorch_backend.transformer.embedding import RelPositionalEncoding
+    from src.audiovisual_fusion.adaptive_audiovisual_fusion import AdaptiveAudioVisualFusion
+    from src.encoder.audiovisual.tailored.encoder import TailoredEncoder
+
+    B, T, D = 3, 21, 256
+    alens, vlens = torch.tensor([21, 15, 8]), torch.tensor([21, 16, 8])
+    am = (torch.arange(T)[None, :] < alens[:, None])[:, None, :]
+    vm = (torch.arange(T)[None, :] < vlens[:, None])[:, None, :]
+    pe = RelPositionalEncoding(D, 0.0)
+    for tag, (ua, uv) in {"aa": ([True], [True]), "ac": ([True], [False]), "ca": ([False], [True]),
+                          "cc": ([False], [False])}.items():
+        enc = TailoredEncoder("rel_pos", "latest", num_blocks=1, dropout_rate=0.0, positional_dropout_rate=0.0,
+                              attention_dropout_rate=0.0, acoustic_use_attn=ua, visual_use_attn=uv).train()
+        layer = enc.encoders[0]
+        fill_parameters_(layer, seed=71)
+        a = synth((B, T, D), seed=72).requires_grad_(True)
+        v = synth((B, T, D), seed=73).requires_grad_(True)
+        (xa, pos), _ = pe(a), None
+        xa, pos = pe(a)
+        xv, _ = pe(v)
+        (ya, _), _, (yv, _), _ = layer((xa, pos), am, (xv, pos), vm)
+        ra, rv = synth((B, T, D), seed=74), synth((B, T, D), seed=75)
+        ((ya * ra).sum() + (yv * rv).sum()).backward()
+        params = dict(layer.named_parameters())
+        grads = {"g_" + n: compact(p.grad) for n, p in params.items()
+                 if n.endswith(("feed_forward_macaron.w_1.weight", "feed_forward.w_2.bias", "norm_final.weight",
+                                "norm_ff_macaron.bias", "pos_bias_u", "linear_pos.weight", "csgu.conv.weight",
+                                "acoustic_norm_mha.weight", "visual_norm_cgmlp.bias", "visual_norm_mha.bias",
+                                "acoustic_norm_cgmlp.weight", "channel_proj2.weight", "linear_out.bias"))}
+        _save(f"av_tailored_layer_{tag}", B=B, T=T, D=D, alens=_np(alens), vlens=_np(vlens), ya=_np(ya), yv=_np(yv),
+              grad_a=_np(a.grad), grad_v=_np(v.grad), keys=np.array(sorted(layer.state_dict().keys())), **grads)
+
+    conf = avsr_conf(num_blocks=4)["encoder_conf"]
+    enc = TailoredEncoder("rel_pos", "latest", **conf).train()
+    fusion = AdaptiveAudioVisualFusion(input_size=256, **avsr_conf()["audiovisual_fusion_conf"]).train()
+    fill_parameters_(enc, seed=81)
+    fill_parameters_(fusion, seed=82)
+    a = synth((B, T, D), seed=83).requires_grad_(True)
+    v = synth((B, T, D), seed=84).requires_grad_(True)
+    xa, pos = pe(a)
+    xv, _ = pe(v)
+    ya, oam, yv, ovm, _ = enc((xa, pos), am, (xv, pos), vm)
+    yf, olens = fusion(ya, oam, yv, ovm)
+    r = synth((B, T, D), seed=85)
+    (yf * r).sum().backward()
+    pe_, pf = dict(enc.named_parameters()), dict(fusion.named_parameters())
+    grads = {"g_enc." + n: compact(pe_[n].grad) for n in
+             ["modality_encoding.weight", "encoders.0.feed_forward.w_1.weight", "encoders.3.norm_final.bias",
+              "after_norm.weight", "encoders.1.acoustic_attn.linear_q.weight", "encoders.0.acoustic_cgmlp.csgu.conv.bias"]}
+    grads.update({"g_fus." + n: compact(p.grad) for n, p in pf.items()})
+    _save("av_tailored_encoder_4L_fusion", B=B, T=T, D=D, alens=_np(alens), vlens=_np(vlens), ya=_np(ya), yv=_np(yv),
+          yf=_np(yf), olens=_np(olens), grad_a=_np(a.grad), grad_v=_np(v.grad),
+          acoustic_weight=_np(fusion.acoustic_weight), visual_weight=_np(fusion.visual_weight),
+          enc_keys=np.array(sorted(enc.state_dict().keys())), fus_keys=np.array(sorted(fusion.state_dict().keys())), **grads)
+
+
+def gen_av_embed():
+    """DefaultEmbeddingLayerForAVSR (src/embedding_for_avsr/default.py:111-162), both input layers."""
+    from src.embedding_for_avsr.default import DefaultEmbeddingLayerForAVSR
+
+    B = 3
+    for tag, kw, shape, lens in (("audio", dict(input_size=80, input_layer="conv2d"), (B, 120, 80), [120, 100, 57]),
+                                 ("video", dict(input_size=512, input_layer="linear"), (B, 30, 512), [30, 25, 14])):
+        m = DefaultEmbeddingLayerForAVSR(output_size=256, dropout_rate=0.0, positional_dropout_rate=0.0, **kw).train()
+        fill_parameters_(m, seed=91)
+        x = synth(shape, seed=92).requires_grad_(True)
+        il = torch.tensor(lens)
+        y, masks = m.apply_embed_layer(x, il)
+        (ys, pos) = m.apply_pos_enc(y)
+        r = synth(tuple(ys.shape), seed=93)
+        (ys * r).sum().backward()
+        grads = {"g_" + n: compact(p.grad) for n, p in m.named_parameters()}
+        _save(f"av_embed_{tag}", lens=_np(il), y=_np(y), ys=_np(ys), pos=_np(pos), masks=_np(masks), grad_x=compact(x.grad),
+              keys=np.array(sorted(m.state_dict().keys())), **grads)
+
+
+def _gen_avsr_model(name, yaml_path, nb, seed):
+    from src.tasks.avsr import AVSRTask
+
+    conf = avsr_conf(yaml_path, num_blocks=nb, dec_blocks=1)
+    conf["token_list"] = TOKENS
+    model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf)))
+    fill_parameters_(model, seed=seed)
+    B, Ta, Tv, Lmax = 2, 40, 9, 6
+    audio = synth((B, Ta, 80), seed=seed + 1)
+    video = synth((B, Tv, 88, 88), seed=seed + 2)
+    alens, vlens = torch.tensor([40, 32]), torch.tensor([9, 8])
+    tlens = torch.tensor([6, 4])
+    text = synth((B, Lmax), seed=seed + 3, kind="int", lo=1, hi=39)
+    for i, l in enumerate(tlens):
+        text[i, l:] = -1
+    model.train()
+    loss_t, stats_t, _ = model(audio.clone(), alens, video.clone(), vlens, text.clone(), tlens)
+    loss_t.backward()
+    params = dict(model.named_parameters())
+    gnorm = {n: float(p.grad.norm()) for n, p in params.items() if p.grad is not None}
+    pick = [n for n in ("visual_frontend.frontend3D.0.weight", "visual_frontend.trunk.layer4.1.bn2.weight",
+                        "acoustic_embed.embed.conv.0.weight", "visual_embed.embed.0.weight", "visual_embed.embed.1.weight",
+                        "encoder.modality_encoding.weight", "audiovisual_fusion.audiovisual_layer.w_1.weight",
+                        "audiovisual_fusion.acoustic_pooling_proj.weight", "ctc.ctc_lo.weight", "decoder.embed.0.weight")
+            if n in params]
+    grads = {"g_" + n: compact(params[n].grad) for n in pick}
+    model.eval()
+    with torch.no_grad():
+        loss_e, stats_e, _ = model(audio.clone(), alens, video.clone(), vlens, text.clone(), tlens)
+        enc, olens = model.encode(audio.clone(), alens, video.clone(), vlens)
+        ids = model.ctc.argmax(enc)
+        top2 = model.ctc.ctc_lo(enc).topk(2, dim=-1).values
+    _save(name, B=B, Ta=Ta, Tv=Tv, alens=_np(alens), vlens=_np(vlens), tlens=_np(tlens), text=_np(text),
+          loss_train=_np(loss_t), loss_ctc_train=_np(stats_t["loss_ctc"]), loss_att_train=_np(stats_t["loss_att"]),
+          loss_eval=_np(loss_e), loss_ctc=_np(stats_e["loss_ctc"]), loss_att=_np(stats_e["loss_att"]),
+          acc=_np(stats_e["acc"]), cer_ctc=_np(stats_e["cer_ctc"]), enc=_np(enc), olens=_np(olens), ctc_ids=_np(ids),
+          top2_gap=_np(top2[..., 0] - top2[..., 1]),
+          gnorm_keys=np.array(list(gnorm.keys())), gnorm_vals=np.array(list(gnorm.values()), dtype=np.float64),
+          n_params=sum(p.numel() for p in model.parameters()), keys=np.array(sorted(model.state_dict().keys())), **grads)
+
+
+def gen_avsr_models():
+    """ESPnetAVSRModel.forward/encode (avsr_espnet_model.py:211-488) built by AVSRTask.build_model
+    (src/tasks/avsr.py:506-718): tailored (2 blocks) and conventional (1 block) recipes, raw 88x88 lip frames in."""
+    _gen_avsr_model("av_model_tailored_2L", AVSR_YAML, 2, 101)
+    _gen_avsr_model("av_model_conventional_1L", AVSR_CONV_YAML, 1, 111)
+
+
 def main():
+    import sys
+
     _shim.install()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--av-only" in sys.argv:
+        gen_visual_frontend()
+        gen_av_embed()
+        gen_tailored()
+        gen_avsr_models()
+        return
     gen_ctc_direct()
     gen_layers()
     gen_encoders()
     gen_asr_model()
     gen_cfg1_wav()
+    gen_visual_frontend()
+    gen_av_embed()
+    gen_tailored()
+    gen_avsr_models()
 
 
 if __name__ == "__main__":

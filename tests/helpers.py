@@ -54,3 +54,34 @@ def grad_ok(a, b, tol):
     if float(b.abs().max()) < 1e-6:
         return float(a.abs().max()) < 1e-5
     return float((a - b).norm() / b.norm()) < tol
+
+
+AVSR_YAML = os.path.join(ROOT, "tailored-avsr_amd", "configs", "avsr_tailored_transformer_ctc_english.yaml")
+AVSR_CONV_YAML = os.path.join(ROOT, "tailored-avsr_amd", "configs", "avsr_conventional_transformer_ctc_english.yaml")
+
+
+def _zero_dropout(d):
+    for k, v in d.items():
+        if isinstance(v, dict):
+            _zero_dropout(v)
+        elif k.endswith("dropout_rate"):
+            d[k] = 0.0
+
+
+def avsr_conf(yaml_path=AVSR_YAML, num_blocks=12, dec_blocks=6, visual_input_size=None, **enc_over):
+    """Same edits as oracle/gen_golden.py:avsr_conf, on the repo's own YAML."""
+    conf = yaml.safe_load(open(yaml_path))
+    conf["acoustic_input_size"] = 80
+    conf["visual_input_size"] = visual_input_size
+    conf["specaug"] = None
+    _zero_dropout(conf)
+    if conf["encoder"] == "tailored":
+        conf["encoder_conf"]["num_blocks"] = num_blocks
+        conf["encoder_conf"]["acoustic_use_attn"] = conf["encoder_conf"]["acoustic_use_attn"][:num_blocks]
+        conf["encoder_conf"]["visual_use_attn"] = conf["encoder_conf"]["visual_use_attn"][:num_blocks]
+    else:
+        conf["encoder_conf"]["acoustic_encoder_conf"]["num_blocks"] = num_blocks
+        conf["encoder_conf"]["visual_encoder_conf"]["num_blocks"] = num_blocks
+    conf["decoder_conf"]["num_blocks"] = dec_blocks
+    conf["encoder_conf"].update(enc_over)
+    return copy.deepcopy(conf)
