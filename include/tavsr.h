@@ -155,17 +155,20 @@ int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int6
  *   weight_proj{1,2}.weight[D], weight_proj{1,2}.bias[1].
  *   pool_fwd: score [2,B,T], pooled [2,B,D], w [B,2] = (weight_global, weight_local)
  *   combine : out = w[b,0]*x1 + w[b,1]*x2
+ *   lens2   : optional valid lengths of the second stream (NULL: lens serves both) - the AV fusion pools the
+ *             audio and the video stream under their own masks (adaptive_audiovisual_fusion.py:146-179)
  *   bwd     : dx1, dx2 and the 8 parameter gradients (dparams: HOST array of device pointers,
  *             order weight{pool1,pool2,w1,w2} then bias{pool1,pool2,w1,w2});
  *             ws >= tavsr_merge_bwd_ws(B, D) floats.
  * ------------------------------------------------------------------------------------------- */
-int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int64_t* lens, const float* const* params,
+int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
+                         const float* const* params,
                          float* score, float* pooled, float* w, int32_t B, int32_t T, int32_t D,
                          tavsr_stream_t stream);
 int tavsr_merge_combine(const float* x1, const float* x2, const float* w, float* out, int32_t B, int32_t T,
                         int32_t D, tavsr_stream_t stream);
 int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D);
-int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens,
+int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
                     const float* const* params, const float* score, const float* pooled, const float* w,
                     float* dx1, float* dx2, float* const* dparams, int32_t accumulate, float* ws, int32_t B,
                     int32_t T, int32_t D, tavsr_stream_t stream);
@@ -226,6 +229,45 @@ int tavsr_embed_pe(const int64_t* ids, const float* table, const float* pe, floa
                    int32_t L, int32_t D, tavsr_stream_t stream);
 int tavsr_embed_bwd(const int64_t* ids, const float* dout, float scale, float* dtable, int64_t N, int32_t V,
                     int32_t D, int32_t accumulate, tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Visual frontend (src/frontend/conv3d_resnet18/conv3d_resnet18.py:42-97, modules/resnet.py:25-178), channels-last:
+ * every activation is a [N*H*W, C] matrix (N = B*T frames), each convolution = im2col + tavsr_gemm.
+ *   im2col2d / col2im2d : KHxKW patches, stride, zero padding (conv3x3 of BasicBlock resnet.py:8-22, 1x1 shortcut
+ *                         conv :25-41); col rows (n,ho,wo), columns (kh*KW+kw)*C + c; col2im is the gather-form adjoint
+ *   im2col_stem         : Conv3d(1->64, k (5,7,7), s (1,2,2), p (2,3,3)) patches of x[B,T,H,W], 245 taps padded to 256
+ *   bn_stats            : training-mode BatchNorm statistics over the M rows (two-pass, deterministic): mean, biased
+ *                         var, rstd; running_mean/var/num_batches_tracked updated like torch.nn.BatchNorm (may be NULL)
+ *   bn_apply_fwd        : y = act((x - mean) * rstd * gamma + beta (+ res)), act in {none, swish}
+ *   bn_bwd              : dz = dy * act'(z) (z recomputed; dz is also d/d res), dgamma, dbeta, dx; ws >= tavsr_bn_ws floats
+ *   rsqrt_eps           : out = 1 / sqrt(v + eps)  (eval-mode BatchNorm: rstd from running_var)
+ *   maxpool3x3s2        : per-frame 3x3 / stride 2 / pad 1 max pooling (the stem's MaxPool3d (1,3,3)); idx = winning tap
+ *   avgpool             : mean over the P pixels of a frame (AdaptiveAvgPool2d(1), resnet.py:176)
+ *   fill                : p[i] = value (alignment padding rows, avsr_espnet_model.py:531-538)
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_im2col2d(const float* x, float* col, int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
+                   int32_t stride, int32_t pad, tavsr_stream_t stream);
+int tavsr_col2im2d(const float* dcol, float* dx, int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
+                   int32_t stride, int32_t pad, tavsr_stream_t stream);
+int tavsr_im2col_stem(const float* x, float* col, int32_t B, int32_t T, int32_t H, int32_t W, tavsr_stream_t stream);
+int64_t tavsr_bn_ws(int64_t M, int32_t C);
+int tavsr_bn_stats(const float* x, int64_t M, int32_t C, float eps, float momentum, float* mean, float* var, float* rstd,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* ws, tavsr_stream_t stream);
+int tavsr_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* res, float* y, int64_t M, int32_t C, int32_t act, tavsr_stream_t stream);
+int tavsr_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 const float* res, float* dz, float* dx, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t act,
+                 float* ws, tavsr_stream_t stream);
+int tavsr_rsqrt_eps(const float* v, float eps, float* out, int64_t n, tavsr_stream_t stream);
+int tavsr_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int64_t N, int32_t H, int32_t W, int32_t C,
+                           tavsr_stream_t stream);
+int tavsr_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t N, int32_t H, int32_t W, int32_t C,
+                           tavsr_stream_t stream);
+int tavsr_avgpool_fwd(const float* x, float* y, int64_t N, int32_t P, int32_t C, tavsr_stream_t stream);
+int tavsr_avgpool_bwd(const float* dy, float* dx, int64_t N, int32_t P, int32_t C, tavsr_stream_t stream);
+int tavsr_fill(float* p, float value, int64_t n, tavsr_stream_t stream);
+/* dst[m*ldd + n] = src[m*lds + n], m < M, n < N (no alignment requirement) */
+int tavsr_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int64_t N, tavsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -14,5 +14,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace tavsr
 
-extern "C" int tavsr_version(void) { return 2; }
+extern "C" int tavsr_version(void) { return 3; }
 extern "C" const char* tavsr_last_error_string(void) { return tavsr::g_err; }

@@ -221,7 +221,8 @@ __device__ __forceinline__ void row_dots(const float* __restrict__ x, const floa
 }
 
 __global__ __launch_bounds__(512) void merge_pool_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                                             const int64_t* __restrict__ lens, MergeParams p,
+                                                             const int64_t* __restrict__ lens,
+                                                             const int64_t* __restrict__ lens2, MergeParams p,
                                                              float* __restrict__ score, float* __restrict__ pooled,
                                                              float* __restrict__ wout, int B, int T, int D) {
   extern __shared__ float sm[];
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(512) void merge_pool_fwd_kernel(const float* __rest
   float* s_red = sm + 2 * T + k * 4;         // [2][4]
   float* s_w = sm + 2 * T + 8;               // [2] branch logits
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = ht >> 6;
-  const int len = lens ? (int)min((int64_t)T, lens[b]) : T;
+  const int64_t* lk = (k == 1 && lens2) ? lens2 : lens;     // per-branch valid length (AV fusion: audio / video masks)
+  const int len = lk ? (int)min((int64_t)T, lk[b]) : T;
   const float inv_sqrt_d = 1.f / sqrtf((float)D);
   const float* x = (k == 0 ? x1 : x2) + (int64_t)b * T * D;
   row_dots(x, p.wp[k], len, T, D, wv, lane, p.bp[k][0], inv_sqrt_d, s_sc);
@@ -292,7 +294,8 @@ __global__ void merge_combine_kernel(const float* __restrict__ x1, const float* 
 // part[b] = { dwp1[D], dwp2[D], dww1[D], dww2[D], dbp1, dbp2, dbw1, dbw2 }  (4*D + 4 floats)
 __global__ __launch_bounds__(512) void merge_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ x1,
                                                         const float* __restrict__ x2, const int64_t* __restrict__ lens,
-                                                        MergeParams p, const float* __restrict__ score,
+                                                        const int64_t* __restrict__ lens2, MergeParams p,
+                                                        const float* __restrict__ score,
                                                         const float* __restrict__ pooled, const float* __restrict__ w,
                                                         float* __restrict__ dx1, float* __restrict__ dx2,
                                                         float* __restrict__ part, int B, int T, int D) {
@@ -303,7 +306,8 @@ __global__ __launch_bounds__(512) void merge_bwd_kernel(const float* __restrict_
   float* s_red = sm + 2 * T + 2 * D + k * 4;   // [2][4]
   float* s_a = sm + 2 * T + 2 * D + 8;      // [2][8] per-wave partials of <dm,x1>, <dm,x2>
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = ht >> 6, wv8 = threadIdx.x >> 6;
-  const int len = lens ? (int)min((int64_t)T, lens[b]) : T;
+  const int64_t* lk = (k == 1 && lens2) ? lens2 : lens;
+  const int len = lk ? (int)min((int64_t)T, lk[b]) : T;
   const int64_t base = (int64_t)b * T * D;
   const float inv_sqrt_d = 1.f / sqrtf((float)D);
   const float w1 = w[b * 2], w2 = w[b * 2 + 1];
@@ -453,7 +457,8 @@ static MergeParams mk(const float* const* prm) {
 // params = { pooling_proj1.weight, pooling_proj2.weight, pooling_proj1.bias, pooling_proj2.bias,
 //            weight_proj1.weight, weight_proj2.weight, weight_proj1.bias, weight_proj2.bias } (device pointers,
 //            the array itself is HOST memory)
-extern "C" int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int64_t* lens, const float* const* params,
+extern "C" int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
+                                    const float* const* params,
                                     float* score, float* pooled, float* w, int32_t B, int32_t T, int32_t D,
                                     tavsr_stream_t stream) {
   TAVSR_REQUIRE(x1 && x2 && params && score && pooled && w, TAVSR_EINVAL, "merge_pool_fwd: null pointer");
@@ -463,7 +468,7 @@ extern "C" int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int6
                 "merge_pool_fwd: D %% 4 == 0 and 16-byte aligned rows required");
   size_t lds = (2 * T + 16) * sizeof(float);
   TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_pool_fwd: T=%d too long", T);
-  hipLaunchKernelGGL(merge_pool_fwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, x1, x2, lens, mk(params),
+  hipLaunchKernelGGL(merge_pool_fwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, x1, x2, lens, lens2, mk(params),
                      score, pooled, w, B, T, D);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
@@ -486,7 +491,7 @@ extern "C" int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D) { return (int64_t)(B
 // dparams = { d pooling_proj1.weight[D], d pooling_proj2.weight[D], d weight_proj1.weight[D], d weight_proj2.weight[D],
 //             d pooling_proj1.bias[1], d pooling_proj2.bias[1], d weight_proj1.bias[1], d weight_proj2.bias[1] }
 extern "C" int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens,
-                               const float* const* params, const float* score, const float* pooled, const float* w,
+                               const int64_t* lens2, const float* const* params, const float* score, const float* pooled, const float* w,
                                float* dx1, float* dx2, float* const* dparams, int32_t accumulate, float* ws, int32_t B,
                                int32_t T, int32_t D, tavsr_stream_t stream) {
   TAVSR_REQUIRE(dm && x1 && x2 && params && score && pooled && w && dx1 && dx2 && dparams && ws, TAVSR_EINVAL,
@@ -496,7 +501,7 @@ extern "C" int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2
                 TAVSR_EALIGN, "merge_bwd: D %% 4 == 0 and 16-byte aligned rows required");
   size_t lds = (2 * T + 2 * D + 32) * sizeof(float);
   TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_bwd: T=%d too long", T);
-  hipLaunchKernelGGL(merge_bwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, dm, x1, x2, lens, mk(params), score,
+  hipLaunchKernelGGL(merge_bwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, dm, x1, x2, lens, lens2, mk(params), score,
                      pooled, w, dx1, dx2, ws, B, T, D);
   TAVSR_LAUNCH_CHECK();
   const int n = 4 * D + 4;

@@ -1,0 +1,471 @@
+// Visual frontend pieces: Conv3d(1->64, k 5x7x7, s 1x2x2) + BatchNorm3d + Swish + MaxPool(1,3,3) and the
+// ResNet-18 trunk (BasicBlock: conv3x3-BN-Swish-conv3x3-BN-(+1x1 conv/BN shortcut)-add-Swish, global average pool)
+// of src/frontend/conv3d_resnet18/conv3d_resnet18.py:42-97 and modules/resnet.py:25-178.
+//
+// Layout: every activation is channels-last, one row per output pixel: [N*H*W, C] with N = B*T frames, so each
+// convolution is an im2col gather (here) + one tavsr_gemm whose output IS the next layer's activation matrix, and
+// BatchNorm statistics are column reductions of that matrix.  All kernels here are HBM-bound streaming kernels
+// (16-byte accesses along C); reductions are two-stage with a fixed order (deterministic, no atomics).
+#include <float.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace tavsr {
+
+// col[(n,ho,wo)][(kh*KW+kw)*C + c] = x[n, ho*s-p+kh, wo*s-p+kw, c]  (0 outside)      C % 4 == 0
+__global__ void im2col2d_kernel(const float* __restrict__ x, float* __restrict__ col, int H, int W, int Ho, int Wo,
+                                int C4, int KH, int KW, int stride, int pad, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = (int)(i % C4);
+  int64_t r = i / C4;
+  const int k = (int)(r % (KH * KW));
+  const int64_t m = r / (KH * KW);
+  const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho);
+  const int64_t n = m / ((int64_t)Wo * Ho);
+  const int h = ho * stride - pad + k / KW, w = wo * stride - pad + k % KW;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (h >= 0 && h < H && w >= 0 && w < W) v = reinterpret_cast<const float4*>(x)[((n * H + h) * W + w) * C4 + c4];
+  reinterpret_cast<float4*>(col)[i] = v;
+}
+
+// dx[n,h,w,c] = sum over the (kh,kw) whose output position (h+p-kh)/s, (w+p-kw)/s exists of dcol[...]   (gather form)
+__global__ void col2im2d_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int H, int W, int Ho, int Wo,
+                                int C4, int KH, int KW, int stride, int pad, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = (int)(i % C4);
+  int64_t r = i / C4;
+  const int w = (int)(r % W), h = (int)((r / W) % H);
+  const int64_t n = r / ((int64_t)W * H);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int kh = 0; kh < KH; ++kh) {
+    const int hn = h + pad - kh;
+    if (hn < 0 || hn % stride) continue;
+    const int ho = hn / stride;
+    if (ho >= Ho) continue;
+    for (int kw = 0; kw < KW; ++kw) {
+      const int wn = w + pad - kw;
+      if (wn < 0 || wn % stride) continue;
+      const int wo = wn / stride;
+      if (wo >= Wo) continue;
+      const float4 v = reinterpret_cast<const float4*>(dcol)[(((n * Ho + ho) * Wo + wo) * (KH * KW) + kh * KW + kw) * C4 + c4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  reinterpret_cast<float4*>(dx)[i] = acc;
+}
+
+// Stem im2col: x [B,T,H,W] (one channel) -> col [(b,t,ho,wo)][KP] with k = (kt*7 + kh)*7 + kw < 245 and zeros up to
+// KP = 256; kernel (5,7,7), stride (1,2,2), padding (2,3,3) (conv3d_resnet18.py:48-56).  One thread per 4 taps.
+__global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restrict__ col, int T, int H, int W, int Ho,
+                                   int Wo, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int k4 = (int)(i & 63);
+  const int64_t m = i >> 6;
+  const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho);
+  const int t = (int)((m / ((int64_t)Wo * Ho)) % T);
+  const int64_t b = m / ((int64_t)Wo * Ho * T);
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k4 * 4 + j;
+    v[j] = 0.f;
+    if (k < 245) {
+      const int kw = k % 7, kh = (k / 7) % 7, kt = k / 49;
+      const int tt = t - 2 + kt, h = ho * 2 - 3 + kh, w = wo * 2 - 3 + kw;
+      if (tt >= 0 && tt < T && h >= 0 && h < H && w >= 0 && w < W) v[j] = x[((b * T + tt) * H + h) * W + w];
+    }
+  }
+  reinterpret_cast<float4*>(col)[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---- BatchNorm (training mode: batch statistics over the M rows of [M, C]) ----------------------------------
+// stage 1: per-block partial column sums of (x - shift)^p, p = 1 (shift = 0) or 2 (shift = mean): part[blk][C]
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                         int64_t M, int C, int64_t rows_per_block, int square,
+                                                         float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float sh = shift ? shift[c] : 0.f;
+    int64_t r = r0 + ry;
+    for (; r + 4 < r1; r += 8) {
+      float a = x[r * C + c] - sh, b = x[(r + 4) * C + c] - sh;
+      s0 += square ? a * a : a;
+      s1 += square ? b * b : b;
+    }
+    for (; r < r1; r += 4) {
+      float a = x[r * C + c] - sh;
+      s0 += square ? a * a : a;
+    }
+  }
+  red[ry][cx] = s0 + s1;
+  __syncthreads();
+  if (ry == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+
+// stage 2 (one thread per channel, partials summed in double in a fixed order):
+//   mode 0: mean[c] = sum / M
+//   mode 1: var[c] = sum / M (biased), rstd[c] = 1/sqrt(var + eps); running stats updated like torch BatchNorm
+//           (momentum m, unbiased variance), num_batches_tracked += 1 by thread 0
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, int64_t M, int mode, float eps,
+                                   float momentum, float* __restrict__ mean, float* __restrict__ var,
+                                   float* __restrict__ rstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += (double)part[(int64_t)p * C + c];
+  if (mode == 0) {
+    mean[c] = (float)(s / (double)M);
+  } else {
+    const float v = (float)(s / (double)M);
+    var[c] = v;
+    rstd[c] = 1.f / sqrtf(v + eps);
+    if (running_mean) {
+      const float unb = M > 1 ? (float)(s / (double)(M - 1)) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+    if (nbt && c == 0) nbt[0] += 1;
+  }
+}
+
+// y = act( (x - mean) * rstd * gamma + beta (+ res) ),  act = swish or identity;  float4 over C
+__global__ void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ res,
+                                    float* __restrict__ y, int C4, int act, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = (int)(i % C4);
+  const float4 xv = reinterpret_cast<const float4*>(x)[i];
+  const float4 mu = reinterpret_cast<const float4*>(mean)[c4], rs = reinterpret_cast<const float4*>(rstd)[c4];
+  const float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
+  float4 z = make_float4((xv.x - mu.x) * rs.x * g.x + b.x, (xv.y - mu.y) * rs.y * g.y + b.y,
+                         (xv.z - mu.z) * rs.z * g.z + b.z, (xv.w - mu.w) * rs.w * g.w + b.w);
+  if (res) {
+    const float4 r = reinterpret_cast<const float4*>(res)[i];
+    z.x += r.x; z.y += r.y; z.z += r.z; z.w += r.w;
+  }
+  reinterpret_cast<float4*>(y)[i] = make_float4(act_fwd(act, z.x), act_fwd(act, z.y), act_fwd(act, z.z), act_fwd(act, z.w));
+}
+
+// backward, pass 1: dz = dy * act'(z) with z recomputed from x (and res); writes dz (also the gradient of `res`) and
+// per-block partial column sums of dz and dz * xhat: part[blk][2][C]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ res, float* __restrict__ dz,
+                                                            int64_t M, int C, int64_t rows_per_block, int act,
+                                                            float* __restrict__ part) {
+  __shared__ float red[4][2][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float sb = 0.f, sg = 0.f;
+  if (c < C) {
+    const float mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
+    for (int64_t r = r0 + ry; r < r1; r += 4) {
+      const float xh = (x[r * C + c] - mu) * rs;
+      float z = xh * g + b;
+      if (res) z += res[r * C + c];
+      const float d = dy[r * C + c] * act_bwd(act, z);
+      dz[r * C + c] = d;
+      sb += d;
+      sg += d * xh;
+    }
+  }
+  red[ry][0][cx] = sb;
+  red[ry][1][cx] = sg;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    part[((int64_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][cx] + red[1][0][cx]) + (red[2][0][cx] + red[3][0][cx]);
+    part[((int64_t)blockIdx.y * 2 + 1) * C + c] = (red[0][1][cx] + red[1][1][cx]) + (red[2][1][cx] + red[3][1][cx]);
+  }
+}
+
+// backward, pass 2: dx = gamma * rstd * (dz - dbeta/M - xhat * dgamma/M)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, float* __restrict__ dx, int C4, float invM,
+                                    int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = (int)(i % C4);
+  const float4 d = reinterpret_cast<const float4*>(dz)[i], xv = reinterpret_cast<const float4*>(x)[i];
+  const float4 mu = reinterpret_cast<const float4*>(mean)[c4], rs = reinterpret_cast<const float4*>(rstd)[c4];
+  const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+  const float4 dg = reinterpret_cast<const float4*>(dgamma)[c4], db = reinterpret_cast<const float4*>(dbeta)[c4];
+  float4 o;
+  o.x = g.x * rs.x * (d.x - db.x * invM - (xv.x - mu.x) * rs.x * dg.x * invM);
+  o.y = g.y * rs.y * (d.y - db.y * invM - (xv.y - mu.y) * rs.y * dg.y * invM);
+  o.z = g.z * rs.z * (d.z - db.z * invM - (xv.z - mu.z) * rs.z * dg.z * invM);
+  o.w = g.w * rs.w * (d.w - db.w * invM - (xv.w - mu.w) * rs.w * dg.w * invM);
+  reinterpret_cast<float4*>(dx)[i] = o;
+}
+
+// ---- pooling ------------------------------------------------------------------------------------------------
+// MaxPool 3x3 stride 2 pad 1 per frame, NHWC (the (1,3,3)/(1,2,2) MaxPool3d of the stem); idx = winning tap 0..8
+__global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+                                        int H, int W, int Ho, int Wo, int C, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  int64_t r = i / C;
+  const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
+  const int64_t n = r / ((int64_t)Wo * Ho);
+  float best = -FLT_MAX;
+  int bi = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int h = ho * 2 - 1 + k / 3, w = wo * 2 - 1 + k % 3;
+    if (h < 0 || h >= H || w < 0 || w >= W) continue;
+    const float v = x[((n * H + h) * W + w) * C + c];
+    if (v > best || v != v) { best = v; bi = k; }     // first maximum wins (torch scan order); NaN propagates
+  }
+  y[i] = best;
+  idx[i] = (uint8_t)bi;
+}
+
+// dx[n,h,w,c] = sum of dy over the (at most 4) windows that selected this pixel (gather form, deterministic)
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                        float* __restrict__ dx, int H, int W, int Ho, int Wo, int C, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  int64_t r = i / C;
+  const int w = (int)(r % W), h = (int)((r / W) % H);
+  const int64_t n = r / ((int64_t)W * H);
+  float acc = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hn = h + 1 - kh;
+    if (hn < 0 || (hn & 1)) continue;
+    const int ho = hn >> 1;
+    if (ho >= Ho) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wn = w + 1 - kw;
+      if (wn < 0 || (wn & 1)) continue;
+      const int wo = wn >> 1;
+      if (wo >= Wo) continue;
+      const int64_t o = ((n * Ho + ho) * Wo + wo) * C + c;
+      if (idx[o] == kh * 3 + kw) acc += dy[o];
+    }
+  }
+  dx[i] = acc;
+}
+
+// global average pool over the P pixels of each frame: y[n,c] = mean_p x[n,p,c]; bwd: dx[n,p,c] = dy[n,c] / P
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int C, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t n = i / C;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += x[(n * P + p) * C + c];
+  y[i] = s / (float)P;
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int P, int C, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t n = i / ((int64_t)C * P);
+  dx[i] = dy[n * C + c] / (float)P;
+}
+
+__global__ void rsqrt_eps_kernel(const float* __restrict__ v, float eps, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.f / sqrtf(v[i] + eps);
+}
+
+// dst[m*ldd + n] = src[m*lds + n]: strided 2-D copy without alignment requirements (stem weight 245 <-> 256 columns,
+// alignment padding of [B, T*D] rows)
+__global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd, int64_t N,
+                              int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t m = i / N, n = i % N;
+  dst[m * ldd + n] = src[m * lds + n];
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+static inline int bn_chunks(int64_t M) { return (int)std::min<int64_t>(std::max<int64_t>(1, M / 256), 1024); }
+
+}  // namespace tavsr
+
+using namespace tavsr;
+
+static inline dim3 grid1d(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+extern "C" int tavsr_im2col2d(const float* x, float* col, int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
+                              int32_t stride, int32_t pad, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && col, TAVSR_EINVAL, "im2col2d: null pointer");
+  TAVSR_REQUIRE(C % 4 == 0 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, TAVSR_EUNSUPPORTED, "im2col2d: C %% 4 == 0 required");
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const int64_t total4 = N * Ho * Wo * KH * KW * (C / 4);
+  if (total4 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(im2col2d_kernel, grid1d(total4), dim3(256), 0, (hipStream_t)stream, x, col, H, W, Ho, Wo, C / 4, KH, KW,
+                     stride, pad, total4);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_col2im2d(const float* dcol, float* dx, int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
+                              int32_t stride, int32_t pad, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dcol && dx, TAVSR_EINVAL, "col2im2d: null pointer");
+  TAVSR_REQUIRE(C % 4 == 0 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, TAVSR_EUNSUPPORTED, "col2im2d: C %% 4 == 0 required");
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const int64_t total4 = N * H * W * (C / 4);
+  if (total4 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(col2im2d_kernel, grid1d(total4), dim3(256), 0, (hipStream_t)stream, dcol, dx, H, W, Ho, Wo, C / 4, KH, KW,
+                     stride, pad, total4);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_im2col_stem(const float* x, float* col, int32_t B, int32_t T, int32_t H, int32_t W, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && col, TAVSR_EINVAL, "im2col_stem: null pointer");
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int64_t total4 = (int64_t)B * T * Ho * Wo * 64;
+  if (total4 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(im2col_stem_kernel, grid1d(total4), dim3(256), 0, (hipStream_t)stream, x, col, T, H, W, Ho, Wo, total4);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int64_t tavsr_bn_ws(int64_t M, int32_t C) { return (int64_t)bn_chunks(M) * 2 * C; }
+
+extern "C" int tavsr_bn_stats(const float* x, int64_t M, int32_t C, float eps, float momentum, float* mean, float* var,
+                              float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* ws,
+                              tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && mean && var && rstd && ws, TAVSR_EINVAL, "bn_stats: null pointer");
+  TAVSR_REQUIRE(M > 0 && C > 0, TAVSR_EINVAL, "bn_stats: empty input");
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = bn_chunks(M);
+  const int64_t rpb = (M + chunks - 1) / chunks;
+  const dim3 g(cdiv(C, 64), chunks);
+  hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, s, x, (const float*)nullptr, M, C, rpb, 0, ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, chunks, C, M, 0, eps, momentum, mean, var,
+                     rstd, (float*)nullptr, (float*)nullptr, (int64_t*)nullptr);
+  hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, s, x, mean, M, C, rpb, 1, ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, chunks, C, M, 1, eps, momentum, mean, var,
+                     rstd, running_mean, running_var, num_batches_tracked);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* res, float* y, int64_t M, int32_t C, int32_t act, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && mean && rstd && gamma && beta && y, TAVSR_EINVAL, "bn_apply_fwd: null pointer");
+  TAVSR_REQUIRE(C % 4 == 0, TAVSR_EUNSUPPORTED, "bn_apply_fwd: C %% 4 == 0 required");
+  const int64_t total4 = M * (C / 4);
+  if (total4 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, grid1d(total4), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, res, y,
+                     C / 4, act, total4);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// dz (the gradient w.r.t. the pre-activation = the gradient of `res`), dx, dgamma, dbeta from dy; ws >= tavsr_bn_ws floats
+extern "C" int tavsr_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, const float* res, float* dz, float* dx, float* dgamma, float* dbeta, int64_t M,
+                            int32_t C, int32_t act, float* ws, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dy && x && mean && rstd && gamma && beta && dz && dx && dgamma && dbeta && ws, TAVSR_EINVAL, "bn_bwd: null pointer");
+  TAVSR_REQUIRE(C % 4 == 0, TAVSR_EUNSUPPORTED, "bn_bwd: C %% 4 == 0 required");
+  if (M <= 0) return TAVSR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = bn_chunks(M);
+  const int64_t rpb = (M + chunks - 1) / chunks;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), chunks), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta, res, dz, M,
+                     C, rpb, act, ws);
+  TAVSR_LAUNCH_CHECK();
+  int rc = tavsr_sum_partials(ws, chunks, (int64_t)2 * C, dbeta, C, 0, stream);
+  if (rc) return rc;
+  rc = tavsr_sum_partials(ws + C, chunks, (int64_t)2 * C, dgamma, C, 0, stream);
+  if (rc) return rc;
+  const int64_t total4 = M * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1d(total4), dim3(256), 0, s, dz, x, mean, rstd, gamma, dgamma, dbeta, dx, C / 4,
+                     1.f / (float)M, total4);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int64_t N, int32_t H, int32_t W, int32_t C,
+                                      tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && y && idx, TAVSR_EINVAL, "maxpool_fwd: null pointer");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = N * Ho * Wo * C;
+  if (total <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo, C, total);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t N, int32_t H, int32_t W, int32_t C,
+                                      tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dy && idx && dx, TAVSR_EINVAL, "maxpool_bwd: null pointer");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = N * H * W * C;
+  if (total <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, H, W, Ho, Wo, C, total);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_avgpool_fwd(const float* x, float* y, int64_t N, int32_t P, int32_t C, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && y, TAVSR_EINVAL, "avgpool_fwd: null pointer");
+  const int64_t total = N * C;
+  if (total <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(avgpool_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, P, C, total);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_avgpool_bwd(const float* dy, float* dx, int64_t N, int32_t P, int32_t C, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dy && dx, TAVSR_EINVAL, "avgpool_bwd: null pointer");
+  const int64_t total = N * P * C;
+  if (total <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, dy, dx, P, C, total);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_rsqrt_eps(const float* v, float eps, float* out, int64_t n, tavsr_stream_t stream) {
+  TAVSR_REQUIRE((v && out) || n <= 0, TAVSR_EINVAL, "rsqrt_eps: null pointer");
+  if (n <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(rsqrt_eps_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, v, eps, out, n);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int64_t N, tavsr_stream_t stream) {
+  TAVSR_REQUIRE((src && dst) || M * N <= 0, TAVSR_EINVAL, "copy2d: null pointer");
+  if (M * N <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(copy2d_kernel, grid1d(M * N), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, N, M * N);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_fill(float* p, float value, int64_t n, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(p || n <= 0, TAVSR_EINVAL, "fill: null pointer");
+  if (n <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(fill_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, p, value, n);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}

@@ -1,0 +1,412 @@
+"""Hand-written forward/backward of the audio-visual blocks as
+``torch.autograd.Function``s over the C ABI, in the same style as ``tavsr.functional``.
+
+Reference semantics followed are cited per Function.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .functional import EPS_ESPNET, _FFN, _SelfAttnCore
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch.nn.BatchNorm defaults (conv3d_resnet18.py:57, resnet.py:39,68,84)
+
+
+# ------------------------------------------------------------------------------------------------
+# visual frontend: Conv3d stem + ResNet-18 trunk  (src/frontend/conv3d_resnet18/conv3d_resnet18.py:77-97,
+# modules/resnet.py:89-106,167-178).  Activations are [N*H*W, C] matrices (N = B*T frames), convolutions are
+# im2col + tavsr_gemm, BatchNorm uses batch statistics in training (running buffers updated in place) and the
+# running statistics in eval.  im2col matrices and BN/Swish outputs are recomputed in backward instead of kept.
+# ------------------------------------------------------------------------------------------------
+def frontend_param_names() -> List[str]:
+    """differentiable parameters of Conv3dResNet18 in the order VisualFrontendFn takes them."""
+    names = ["frontend3D.0.weight", "frontend3D.1.weight", "frontend3D.1.bias"]
+    inpl = 64
+    for li, planes in enumerate((64, 128, 256, 512), start=1):
+        for bi in range(2):
+            p = f"trunk.layer{li}.{bi}."
+            names += [p + "conv1.weight", p + "bn1.weight", p + "bn1.bias", p + "conv2.weight", p + "bn2.weight", p + "bn2.bias"]
+            if bi == 0 and (li > 1 or inpl != planes):
+                names += [p + "downsample.0.weight", p + "downsample.1.weight", p + "downsample.1.bias"]
+        inpl = planes
+    return names
+
+
+def _w2d(w):
+    """torch conv weight (co, ci, kh, kw) -> GEMM weight [co, (kh*kw)*ci] matching the channels-last im2col."""
+    co, ci, kh, kw = w.shape
+    return ops.transpose_inner(w.contiguous(), co, ci, kh * kw).view(co, kh * kw * ci)
+
+
+def _w2d_grad(g, shape):
+    co, ci, kh, kw = shape
+    return ops.transpose_inner(g, co, kh * kw, ci).view(shape)
+
+
+class _BN:
+    """(mean, rstd) for a [M,C] matrix: batch statistics (+ running update) in training, running statistics in eval."""
+
+    @staticmethod
+    def stats(z, prefix, bufs, training):
+        rm, rv, nbt = bufs[prefix + "running_mean"], bufs[prefix + "running_var"], bufs[prefix + "num_batches_tracked"]
+        if training:
+            return ops.bn_stats(z, BN_EPS, BN_MOMENTUM, rm, rv, nbt)
+        return rm, ops.rsqrt_eps(rv, BN_EPS)
+
+
+def _bn_eval_bwd(dy, z, mean, rstd, gamma, beta, res, act):
+    """eval-mode BatchNorm backward (constant statistics): dz as in training, dx = dz * gamma * rstd."""
+    # not used by training; kept minimal: training-mode formula with the batch terms dropped is not exposed by the
+    # C ABI, and eval-mode backward is not on any reference path (validation runs under no_grad).
+    raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference's path (validation is no_grad)")
+
+
+class VisualFrontendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg, *P):
+        names = cfg["names"]
+        p = dict(zip(names, P))
+        bufs, training = cfg["buffers"], cfg["training"]
+        B, T, H, W = x.shape
+        N = B * T
+        x = x.contiguous()
+        saved = {}
+        # ---- stem: Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BN3d -> Swish -> MaxPool(1,3,3)/(1,2,2)
+        col0, H0, W0 = ops.im2col_stem(x)
+        w0 = ops.fill_(ops.empty(64, 256, like=x), 0.0)
+        ops.copy2d(p["frontend3D.0.weight"].reshape(64, 245), w0[:, :245])
+        z0 = ops.linear(col0, w0)
+        del col0
+        m0, r0 = _BN.stats(z0, "frontend3D.1.", bufs, training)
+        y0 = ops.bn_apply_fwd(z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
+        cur, idx0, Hc, Wc = ops.maxpool3x3s2_fwd(y0, N, H0, W0, 64)
+        del y0
+        saved["stem"] = (x, z0, m0, r0, idx0, H0, W0, w0)
+        # ---- trunk
+        blocks = []
+        cin = 64
+        for li, planes in enumerate((64, 128, 256, 512), start=1):
+            for bi in range(2):
+                pre = f"trunk.layer{li}.{bi}."
+                stride = 2 if (li > 1 and bi == 0) else 1
+                has_ds = (pre + "downsample.0.weight") in p
+                Xin, Hin, Win = cur, Hc, Wc
+                col1, Ho, Wo = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
+                w1 = _w2d(p[pre + "conv1.weight"])
+                z1 = ops.linear(col1, w1)
+                del col1
+                m1, r1 = _BN.stats(z1, pre + "bn1.", bufs, training)
+                y1 = ops.bn_apply_fwd(z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
+                col2, _, _ = ops.im2col2d(y1, N, Ho, Wo, planes, 3, 3, 1, 1)
+                del y1
+                w2 = _w2d(p[pre + "conv2.weight"])
+                z2 = ops.linear(col2, w2)
+                del col2
+                m2, r2 = _BN.stats(z2, pre + "bn2.", bufs, training)
+                ds = None
+                if has_ds:
+                    cold, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 1, 1, stride, 0)
+                    wd = _w2d(p[pre + "downsample.0.weight"])
+                    zd = ops.linear(cold, wd)
+                    del cold
+                    md, rd = _BN.stats(zd, pre + "downsample.1.", bufs, training)
+                    res = ops.bn_apply_fwd(zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None)
+                    ds = (zd, md, rd, wd)
+                else:
+                    res = Xin
+                cur = ops.bn_apply_fwd(z2, m2, r2, p[pre + "bn2.weight"], p[pre + "bn2.bias"], res, "swish")
+                blocks.append((pre, stride, cin, planes, Hin, Win, Ho, Wo, Xin, z1, m1, r1, w1, z2, m2, r2, w2, res, ds))
+                cin, Hc, Wc = planes, Ho, Wo
+        feat = ops.avgpool_fwd(cur, N, Hc * Wc, cin)
+        ctx.saved, ctx.blocks, ctx.p, ctx.names = saved, blocks, p, names
+        ctx.dims = (B, T, N, Hc, Wc, cin)
+        ctx.training = training
+        return feat.view(B, T, cin)
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        if not ctx.training:
+            _bn_eval_bwd(None, None, None, None, None, None, None, None)
+        p = ctx.p
+        B, T, N, Hc, Wc, cl = ctx.dims
+        G = {}
+        d = ops.avgpool_bwd(dfeat.contiguous().view(N, cl), N, Hc * Wc, cl)
+        for (pre, stride, cin, planes, Hin, Win, Ho, Wo, Xin, z1, m1, r1, w1, z2, m2, r2, w2, res, ds) in reversed(ctx.blocks):
+            # out = swish(bn2(z2) + res)
+            dres, dz2, G[pre + "bn2.weight"], G[pre + "bn2.bias"] = ops.bn_bwd(
+                d, z2, m2, r2, p[pre + "bn2.weight"], p[pre + "bn2.bias"], res, "swish")
+            y1 = ops.bn_apply_fwd(z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
+            col2, _, _ = ops.im2col2d(y1, N, Ho, Wo, planes, 3, 3, 1, 1)
+            del y1
+            G[pre + "conv2.weight"] = _w2d_grad(ops.linear_dw(dz2, col2), p[pre + "conv2.weight"].shape)
+            del col2
+            dcol2 = ops.linear_dx(dz2, w2)
+            dy1 = ops.col2im2d(dcol2, N, Ho, Wo, planes, 3, 3, 1, 1)
+            del dcol2
+            _, dz1, G[pre + "bn1.weight"], G[pre + "bn1.bias"] = ops.bn_bwd(
+                dy1, z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
+            col1, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
+            G[pre + "conv1.weight"] = _w2d_grad(ops.linear_dw(dz1, col1), p[pre + "conv1.weight"].shape)
+            del col1
+            dcol1 = ops.linear_dx(dz1, w1)
+            dX = ops.col2im2d(dcol1, N, Hin, Win, cin, 3, 3, stride, 1)
+            del dcol1
+            if ds is not None:
+                zd, md, rd, wd = ds
+                _, dzd, G[pre + "downsample.1.weight"], G[pre + "downsample.1.bias"] = ops.bn_bwd(
+                    dres, zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None)
+                cold, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 1, 1, stride, 0)
+                G[pre + "downsample.0.weight"] = _w2d_grad(ops.linear_dw(dzd, cold), p[pre + "downsample.0.weight"].shape)
+                del cold
+                dcold = ops.linear_dx(dzd, wd)
+                dXd = ops.col2im2d(dcold, N, Hin, Win, cin, 1, 1, stride, 0)
+                d = ops.axpby(dX, dXd, 1.0, 1.0)
+            else:
+                d = ops.axpby(dX, dres, 1.0, 1.0)
+        # ---- stem
+        x, z0, m0, r0, idx0, H0, W0, w0 = ctx.saved["stem"]
+        dy0 = ops.maxpool3x3s2_bwd(d, idx0, N, H0, W0, 64)
+        _, dz0, G["frontend3D.1.weight"], G["frontend3D.1.bias"] = ops.bn_bwd(
+            dy0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
+        col0, _, _ = ops.im2col_stem(x)
+        gw0 = ops.linear_dw(dz0, col0)            # [64, 256], columns >= 245 are padding
+        del col0
+        g0 = ops.empty(64, 245, like=gw0)
+        ops.copy2d(gw0[:, :245], g0)
+        G["frontend3D.0.weight"] = g0.view(p["frontend3D.0.weight"].shape)
+        ops.join_side()
+        ctx.saved = ctx.blocks = None
+        return (None, None, *[G[n] for n in ctx.names])
+
+
+# ------------------------------------------------------------------------------------------------
+# small differentiable glue used by the AV embedding / alignment / modality encoding
+# ------------------------------------------------------------------------------------------------
+class ScaleFn(torch.autograd.Function):
+    """y = s * x  (RelPositionalEncoding's xscale, applied after the AV alignment: default.py:157-162)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return ops.axpby(x.contiguous(), None, s, 0.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.axpby(dy.contiguous(), None, ctx.s, 0.0), None
+
+
+class PadTimeFn(torch.autograd.Function):
+    """x [B,T,D] -> [B,T+p,D] with the p new frames filled with ``value`` (audiovisual_alignment pads the shorter
+    stream's FEATURES with ignore_id = -1.0: avsr_espnet_model.py:531-538)."""
+
+    @staticmethod
+    def forward(ctx, x, p, value):
+        B, T, D = x.shape
+        x = x.contiguous()
+        out = ops.fill_(ops.empty(B, T + p, D, like=x), float(value))
+        ops.copy2d(x.view(B, T * D), out.view(B, (T + p) * D)[:, : T * D])
+        ctx.dims = (B, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, D = ctx.dims
+        dy = dy.contiguous()
+        dx = ops.empty(B, T * D, like=dy)
+        ops.copy2d(dy.view(B, -1)[:, : T * D], dx)
+        return dx.view(B, T, D), None, None
+
+
+class AddRowFn(torch.autograd.Function):
+    """x [B,T,D] + row [D]  (modality encoding, tailored/encoder.py:251-263); d row = column sum of dy."""
+
+    @staticmethod
+    def forward(ctx, x, row):
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1])
+        y, _ = ops.add_head_bias(x2, row.contiguous(), row.contiguous())
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        d2 = dy.contiguous().view(-1, dy.shape[-1])
+        return dy, ops.colsum(d2)
+
+
+# ------------------------------------------------------------------------------------------------
+# one modality stream of a TailoredEncoderLayer (src/encoder/audiovisual/tailored/encoder_layer.py:171-216 audio,
+# :218-264 video): macaron FFN -> (rel-pos MHSA | cgMLP) with its own LayerNorm and residual -> FFN -> norm_final.
+# The FFNs and the three shared norms get gradients from both streams' nodes; autograd sums them.
+# ------------------------------------------------------------------------------------------------
+TS_SHARED = ("norm_ff_macaron.weight", "norm_ff_macaron.bias",
+             "feed_forward_macaron.w_1.weight", "feed_forward_macaron.w_1.bias",
+             "feed_forward_macaron.w_2.weight", "feed_forward_macaron.w_2.bias",
+             "norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
+             "feed_forward.w_2.weight", "feed_forward.w_2.bias", "norm_final.weight", "norm_final.bias")
+TS_ATTN = ("norm_mha.weight", "norm_mha.bias", "attn.linear_q.weight", "attn.linear_q.bias", "attn.linear_k.weight",
+           "attn.linear_k.bias", "attn.linear_v.weight", "attn.linear_v.bias", "attn.linear_out.weight",
+           "attn.linear_out.bias", "attn.linear_pos.weight", "attn.pos_bias_u", "attn.pos_bias_v")
+TS_MLP = ("norm_cgmlp.weight", "norm_cgmlp.bias", "cgmlp.channel_proj1.0.weight", "cgmlp.channel_proj1.0.bias",
+          "cgmlp.csgu.norm.weight", "cgmlp.csgu.norm.bias", "cgmlp.csgu.conv.weight", "cgmlp.csgu.conv.bias",
+          "cgmlp.channel_proj2.weight", "cgmlp.channel_proj2.bias")
+
+
+def tailored_stream_param_names(use_attn: bool):
+    return TS_SHARED + (TS_ATTN if use_attn else TS_MLP)
+
+
+class TailoredStreamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos_emb, lens, cfg, *P):
+        names = tailored_stream_param_names(cfg["use_attn"])
+        p = dict(zip(names, P))
+        B, T, D = x.shape
+        M = B * T
+        H = cfg["heads"]
+        dk = D // H
+        act, coeff = cfg["ffn_act"], cfg.get("coeff", 1.0)
+        x2d = x.contiguous().view(M, D)
+        sv = {}
+        x1, sv["ffm"] = _FFN.fwd(x2d, p["norm_ff_macaron.weight"], p["norm_ff_macaron.bias"],
+                                 p["feed_forward_macaron.w_1.weight"], p["feed_forward_macaron.w_1.bias"],
+                                 p["feed_forward_macaron.w_2.weight"], p["feed_forward_macaron.w_2.bias"], act, 0.5)
+        if cfg["use_attn"]:
+            n, mean, rstd = ops.layernorm_fwd(x1, p["norm_mha.weight"], p["norm_mha.bias"], EPS_ESPNET)
+            qkv = ops.empty(M, 3 * D, like=x2d)
+            ops.linear(n, p["attn.linear_q.weight"], p["attn.linear_q.bias"], out=qkv, out_off=0, ldc=3 * D)
+            ops.linear(n, p["attn.linear_k.weight"], p["attn.linear_k.bias"], out=qkv, out_off=D, ldc=3 * D)
+            ops.linear(n, p["attn.linear_v.weight"], p["attn.linear_v.bias"], out=qkv, out_off=2 * D, ldc=3 * D)
+            pp = ops.linear(pos_emb.reshape(-1, D), p["attn.linear_pos.weight"])
+            qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
+            cx, attn = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False, qv=qv, p=pp)
+            x2 = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], alpha=coeff, res=x1)
+            sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn)
+        else:
+            n, mean, rstd = ops.layernorm_fwd(x1, p["norm_cgmlp.weight"], p["norm_cgmlp.bias"], EPS_ESPNET)
+            g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
+            Cn = g.shape[1] // 2
+            gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET)
+            cw = p["cgmlp.csgu.conv.weight"]
+            u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T)
+            x2 = ops.linear(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], alpha=coeff, res=x1)
+            sv["br"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv)
+        x3, sv["ff"] = _FFN.fwd(x2, p["norm_ff.weight"], p["norm_ff.bias"], p["feed_forward.w_1.weight"],
+                                p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"], p["feed_forward.w_2.bias"], act, 0.5)
+        y, fmean, frstd = ops.layernorm_fwd(x3, p["norm_final.weight"], p["norm_final.bias"], EPS_ESPNET)
+        sv["final"] = (x3, fmean, frstd)
+        sv["x1"] = x1
+        ctx.sv, ctx.cfg, ctx.p, ctx.names, ctx.pos_emb, ctx.shape = sv, cfg, p, names, pos_emb, (B, T, D)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sv, cfg, p = ctx.sv, ctx.cfg, ctx.p
+        B, T, D = ctx.shape
+        M = B * T
+        H = cfg["heads"]
+        dk = D // H
+        act, coeff = cfg["ffn_act"], cfg.get("coeff", 1.0)
+        G = {}
+        x3, fmean, frstd = sv["final"]
+        dx3, G["norm_final.weight"], G["norm_final.bias"] = ops.layernorm_bwd(dy.contiguous().view(M, D), x3, fmean, frstd,
+                                                                             p["norm_final.weight"])
+        dx2, gs = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act, 0.5)
+        for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
+                          "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
+            G[n_] = g
+        x1 = sv["x1"]
+        if cfg["use_attn"]:
+            mean, rstd, n, qkv, pp, qu, qv, cx, attn = sv["br"]
+            G["attn.linear_out.weight"], G["attn.linear_out.bias"] = ops.linear_dw(dx2, cx, alpha=coeff, bias_grad=True)
+            dcx = ops.linear_dx(dx2, p["attn.linear_out.weight"], alpha=coeff)
+            dqkv = torch.empty_like(qkv)
+            dqu = ops.empty(M, D, like=dx2)
+            dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
+                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp)
+            G["attn.pos_bias_u"] = ops.colsum(dqu).view_as(p["attn.pos_bias_u"])
+            G["attn.pos_bias_v"] = ops.colsum(dqv).view_as(p["attn.pos_bias_v"])
+            ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
+            G["attn.linear_pos.weight"] = ops.linear_dw(dp, ctx.pos_emb.reshape(-1, D))
+            gw, gb = ops.linear_dw(dqkv, n, bias_grad=True)
+            G["attn.linear_q.weight"], G["attn.linear_k.weight"], G["attn.linear_v.weight"] = gw[:D], gw[D:2 * D], gw[2 * D:]
+            G["attn.linear_q.bias"], G["attn.linear_k.bias"], G["attn.linear_v.bias"] = gb[:D], gb[D:2 * D], gb[2 * D:]
+            dn = ops.linear_dx(dqkv[:, :D], p["attn.linear_q.weight"])
+            ops.linear_dx(dqkv[:, D:2 * D], p["attn.linear_k.weight"], res=dn, out=dn)
+            ops.linear_dx(dqkv[:, 2 * D:], p["attn.linear_v.weight"], res=dn, out=dn)
+            dx1, G["norm_mha.weight"], G["norm_mha.bias"] = ops.layernorm_bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2)
+        else:
+            mean, rstd, n, g, z, gn, gmean, grstd, u, conv = sv["br"]
+            Cn = g.shape[1] // 2
+            G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = ops.linear_dw(dx2, u, alpha=coeff, bias_grad=True)
+            du = ops.linear_dx(dx2, p["cgmlp.channel_proj2.weight"], alpha=coeff)
+            dg = torch.empty_like(g)
+            cw = p["cgmlp.csgu.conv.weight"]
+            dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
+            G["cgmlp.csgu.conv.weight"], G["cgmlp.csgu.conv.bias"] = gcw.view_as(cw), gcb
+            _, G["cgmlp.csgu.norm.weight"], G["cgmlp.csgu.norm.bias"] = ops.layernorm_bwd(
+                dgn, g[:, Cn:], gmean, grstd, p["cgmlp.csgu.norm.weight"], dx=dg[:, Cn:])
+            ops.act_bwd_(dg, z, "gelu")
+            G["cgmlp.channel_proj1.0.weight"], G["cgmlp.channel_proj1.0.bias"] = ops.linear_dw(dg, n, bias_grad=True)
+            dn = ops.linear_dx(dg, p["cgmlp.channel_proj1.0.weight"])
+            dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"] = ops.layernorm_bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2)
+        dx, gs = _FFN.bwd(dx1, sv["ffm"], p["norm_ff_macaron.weight"], p["feed_forward_macaron.w_1.weight"],
+                          p["feed_forward_macaron.w_2.weight"], act, 0.5)
+        for n_, g in zip(("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight",
+                          "feed_forward_macaron.w_1.bias", "feed_forward_macaron.w_2.weight", "feed_forward_macaron.w_2.bias"), gs):
+            G[n_] = g
+        ctx.sv = None
+        ops.join_side()
+        return (dx.view(B, T, D), None, None, None, *[G[n] for n in ctx.names])
+
+
+# ------------------------------------------------------------------------------------------------
+# AdaptiveAudioVisualFusion, merge_method="learned_ave" (src/audiovisual_fusion/adaptive_audiovisual_fusion.py:137-205):
+# attention pooling of each stream under its own mask -> softmax over {audio, video} -> weighted sum ->
+# PositionwiseFeedForward (no residual) -> LayerNorm
+# ------------------------------------------------------------------------------------------------
+FUSION_PARAM_NAMES = ("acoustic_pooling_proj.weight", "visual_pooling_proj.weight", "acoustic_pooling_proj.bias",
+                      "visual_pooling_proj.bias", "acoustic_weight_proj.weight", "visual_weight_proj.weight",
+                      "acoustic_weight_proj.bias", "visual_weight_proj.bias",
+                      "audiovisual_layer.w_1.weight", "audiovisual_layer.w_1.bias", "audiovisual_layer.w_2.weight",
+                      "audiovisual_layer.w_2.bias", "norm_final.weight", "norm_final.bias")
+
+
+class FusionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, audio, video, alens, vlens, cfg, *P):
+        B, T, D = audio.shape
+        a2, v2 = audio.contiguous().view(B * T, D), video.contiguous().view(B * T, D)
+        mp = list(P[:8])
+        w1, b1, w2, b2, lw, lb = P[8:14]
+        score, pooled, wts = ops.merge_pool_fwd(a2, v2, alens, mp, B, T, lens2=vlens)
+        m = ops.merge_combine(a2, v2, wts, B, T)
+        h, z = ops.linear(m, w1, b1, act=cfg["act"], save_z=True)
+        y2 = ops.linear(h, w2, b2)
+        out, mean, rstd = ops.layernorm_fwd(y2, lw, lb, EPS_ESPNET)
+        ctx.sv = (a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd)
+        ctx.P, ctx.cfg, ctx.lens, ctx.dims = P, cfg, (alens, vlens), (B, T, D)
+        cfg["_last_w"] = wts
+        return out.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd = ctx.sv
+        P, cfg = ctx.P, ctx.cfg
+        B, T, D = ctx.dims
+        alens, vlens = ctx.lens
+        mp = list(P[:8])
+        w1, b1, w2, b2, lw, lb = P[8:14]
+        dy2, glw, glb = ops.layernorm_bwd(dy.contiguous().view(B * T, -1), y2, mean, rstd, lw)
+        gw2, gb2 = ops.linear_dw(dy2, h, bias_grad=True)
+        dz = ops.linear_dx(dy2, w2, DZ=z, dact=cfg["act"])
+        gw1, gb1 = ops.linear_dw(dz, m, bias_grad=True)
+        dm = ops.linear_dx(dz, w1)
+        da, dv, mg = ops.merge_bwd(dm, a2, v2, alens, mp, score, pooled, wts, B, T, lens2=vlens)
+        mg = [g.view_as(q) for g, q in zip(mg, mp)]
+        ops.join_side()
+        ctx.sv = None
+        return (da.view(B, T, D), dv.view(B, T, D), None, None, None, *mg, gw1, gb1, gw2, gb2, glw, glb)

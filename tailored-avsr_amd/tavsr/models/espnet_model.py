@@ -53,8 +53,10 @@ class ErrorCalculator:
         errs, n = 0, 0
         for y, ref in zip(ys_hat.tolist(), ys_pad.tolist()):
             keep = lambda i: i != -1 and i != self.idx_blank and i != self.idx_space
-            hyp = [self.char_list[i] for i, _ in groupby(y) if keep(i)]
-            tru = [self.char_list[i] for i in ref if keep(i)]
+            # the reference joins the token strings and measures the edit distance over CHARACTERS of the joined
+            # text, so a multi-character token such as "<unk>" counts as five symbols (espnet ErrorCalculator.calculate_cer_ctc)
+            hyp = "".join(self.char_list[i] for i, _ in groupby(y) if keep(i))
+            tru = "".join(self.char_list[i] for i in ref if keep(i))
             if tru:
                 errs += _levenshtein(hyp, tru)
                 n += len(tru)
@@ -142,6 +144,10 @@ class ESPnetASRModel(torch.nn.Module):
         batch_size = speech.shape[0]
         text = text.to(torch.int64).masked_fill(text == -1, self.ignore_id)
         encoder_out, encoder_out_lens = self.encode(speech, speech_lengths)
+        return self._hybrid_loss(encoder_out, encoder_out_lens, text, text_lengths, batch_size)
+
+    # CTC + attention losses and the stats dict: espnet_model.py:258-356 == avsr_espnet_model.py:253-367
+    def _hybrid_loss(self, encoder_out, encoder_out_lens, text, text_lengths, batch_size):
         intermediate_outs = None
         if isinstance(encoder_out, tuple):
             encoder_out, intermediate_outs = encoder_out

@@ -355,10 +355,11 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
     return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
 
-def merge_pool_fwd(x1, x2, lens, params, B, T):
+def merge_pool_fwd(x1, x2, lens, params, B, T, lens2=None):
     D = x1.shape[-1]
     score, pooled, w = empty(2, B, T, like=x1), empty(2, B, D, like=x1), empty(B, 2, like=x1)
-    check(lib().tavsr_merge_pool_fwd(ptr(x1), ptr(x2), ptr(lens), _ptr_array(params), ptr(score), ptr(pooled), ptr(w),
+    require_cuda(x1, x2, lens, lens2)
+    check(lib().tavsr_merge_pool_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(score), ptr(pooled), ptr(w),
                                      B, T, D, stream()), "tavsr_merge_pool_fwd")
     return score, pooled, w
 
@@ -370,14 +371,14 @@ def merge_combine(x1, x2, w, B, T):
     return out
 
 
-def merge_bwd(dm, x1, x2, lens, params, score, pooled, w, B, T):
+def merge_bwd(dm, x1, x2, lens, params, score, pooled, w, B, T, lens2=None):
     D = x1.shape[-1]
     dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
     # gradient order: weight{pool1,pool2,w1,w2} then bias{pool1,pool2,w1,w2}
     order = [0, 1, 4, 5, 2, 3, 6, 7]
     dparams = [torch.empty_like(params[i]) for i in order]
     ws = empty(lib_i64("tavsr_merge_bwd_ws", B, D), like=x1)
-    check(lib().tavsr_merge_bwd(ptr(dm), ptr(x1), ptr(x2), ptr(lens), _ptr_array(params), ptr(score), ptr(pooled),
+    check(lib().tavsr_merge_bwd(ptr(dm), ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(score), ptr(pooled),
                                 ptr(w), ptr(dx1), ptr(dx2), _ptr_array(dparams), 0, ptr(ws), B, T, D, stream()),
           "tavsr_merge_bwd")
     grads = [None] * 8
@@ -488,3 +489,113 @@ def embed_bwd(ids, dout, scale, V):
     check(lib().tavsr_embed_bwd(ptr(ids), ptr(dout), C.c_float(scale), ptr(dt), C.c_int64(ids.numel()), V, D, 0,
                                 stream()), "tavsr_embed_bwd")
     return dt
+
+
+# ---------------------------------------------------------------------------------------------- visual frontend
+def conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def im2col2d(x, N, H, W, Cn, KH, KW, stride, pad):
+    """x [N*H*W, C] channels-last -> col [N*Ho*Wo, KH*KW*C]."""
+    require_cuda(x)
+    Ho, Wo = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
+    col = empty(N * Ho * Wo, KH * KW * Cn, like=x)
+    check(lib().tavsr_im2col2d(ptr(x), ptr(col), C.c_int64(N), H, W, Cn, KH, KW, stride, pad, stream()), "tavsr_im2col2d")
+    return col, Ho, Wo
+
+
+def col2im2d(dcol, N, H, W, Cn, KH, KW, stride, pad):
+    require_cuda(dcol)
+    dx = empty(N * H * W, Cn, like=dcol)
+    check(lib().tavsr_col2im2d(ptr(dcol), ptr(dx), C.c_int64(N), H, W, Cn, KH, KW, stride, pad, stream()), "tavsr_col2im2d")
+    return dx
+
+
+def im2col_stem(x):
+    """x [B,T,H,W] -> col [B*T*Ho*Wo, 256] (245 taps of the (5,7,7) kernel + zero padding)."""
+    B, T, H, W = x.shape
+    require_cuda(x)
+    Ho, Wo = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+    col = empty(B * T * Ho * Wo, 256, like=x)
+    check(lib().tavsr_im2col_stem(ptr(x), ptr(col), B, T, H, W, stream()), "tavsr_im2col_stem")
+    return col, Ho, Wo
+
+
+def bn_stats(x, eps, momentum, running_mean=None, running_var=None, nbt=None):
+    M, Cn = x.shape
+    require_cuda(x, running_mean, running_var, nbt)
+    mean, var, rstd = empty(Cn, like=x), empty(Cn, like=x), empty(Cn, like=x)
+    ws = empty(lib_i64("tavsr_bn_ws", C.c_int64(M), Cn), like=x)
+    check(lib().tavsr_bn_stats(ptr(x), C.c_int64(M), Cn, C.c_float(eps), C.c_float(momentum), ptr(mean), ptr(var), ptr(rstd),
+                               ptr(running_mean), ptr(running_var), ptr(nbt), ptr(ws), stream()), "tavsr_bn_stats")
+    return mean, rstd
+
+
+def rsqrt_eps(v, eps):
+    out = torch.empty_like(v)
+    check(lib().tavsr_rsqrt_eps(ptr(v), C.c_float(eps), ptr(out), C.c_int64(v.numel()), stream()), "tavsr_rsqrt_eps")
+    return out
+
+
+def bn_apply_fwd(x, mean, rstd, gamma, beta, res=None, act=None):
+    M, Cn = x.shape
+    require_cuda(x, mean, rstd, gamma, beta, res)
+    y = torch.empty_like(x)
+    check(lib().tavsr_bn_apply_fwd(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), ptr(y), C.c_int64(M), Cn,
+                                   ACT[act], stream()), "tavsr_bn_apply_fwd")
+    return y
+
+
+def bn_bwd(dy, x, mean, rstd, gamma, beta, res=None, act=None):
+    """returns dz (gradient w.r.t. the pre-activation, = gradient of ``res``), dx, dgamma, dbeta."""
+    M, Cn = x.shape
+    require_cuda(dy, x, mean, rstd, gamma, beta, res)
+    dz, dx = torch.empty_like(x), torch.empty_like(x)
+    dg, db = empty(Cn, like=x), empty(Cn, like=x)
+    ws = empty(lib_i64("tavsr_bn_ws", C.c_int64(M), Cn), like=x)
+    check(lib().tavsr_bn_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), ptr(dz), ptr(dx), ptr(dg),
+                             ptr(db), C.c_int64(M), Cn, ACT[act], ptr(ws), stream()), "tavsr_bn_bwd")
+    return dz, dx, dg, db
+
+
+def maxpool3x3s2_fwd(x, N, H, W, Cn):
+    Ho, Wo = conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1)
+    y = empty(N * Ho * Wo, Cn, like=x)
+    idx = torch.empty((N * Ho * Wo, Cn), dtype=torch.uint8, device=x.device)
+    check(lib().tavsr_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(idx), C.c_int64(N), H, W, Cn, stream()), "tavsr_maxpool3x3s2_fwd")
+    return y, idx, Ho, Wo
+
+
+def maxpool3x3s2_bwd(dy, idx, N, H, W, Cn):
+    dx = empty(N * H * W, Cn, like=dy)
+    check(lib().tavsr_maxpool3x3s2_bwd(ptr(dy), ptr(idx), ptr(dx), C.c_int64(N), H, W, Cn, stream()), "tavsr_maxpool3x3s2_bwd")
+    return dx
+
+
+def avgpool_fwd(x, N, P, Cn):
+    y = empty(N, Cn, like=x)
+    check(lib().tavsr_avgpool_fwd(ptr(x), ptr(y), C.c_int64(N), P, Cn, stream()), "tavsr_avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, N, P, Cn):
+    dx = empty(N * P, Cn, like=dy)
+    check(lib().tavsr_avgpool_bwd(ptr(dy), ptr(dx), C.c_int64(N), P, Cn, stream()), "tavsr_avgpool_bwd")
+    return dx
+
+
+def fill_(t, value):
+    require_cuda(t)
+    assert t.is_contiguous()
+    check(lib().tavsr_fill(ptr(t), C.c_float(value), C.c_int64(t.numel()), stream()), "tavsr_fill")
+    return t
+
+
+def copy2d(src, dst):
+    """dst[m, :N] = src[m, :N] for 2-D (row-strided) views of equal shape; no alignment requirement."""
+    require_cuda(src, dst)
+    assert src.shape == dst.shape and src.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+    check(lib().tavsr_copy2d(ptr(src), C.c_int64(src.stride(0)), ptr(dst), C.c_int64(dst.stride(0)), C.c_int64(src.shape[0]),
+                             C.c_int64(src.shape[1]), stream()), "tavsr_copy2d")
+    return dst

@@ -1,0 +1,315 @@
+"""GPU parity of the audio-visual path: vision kernels vs torch references,
+the HIP modules vs the golden vectors generated from the REFERENCE's own modules, and the AV model at a realistic
+size vs the pinned oracle.  Same bars as test_gpu_parity.py (activations 1e-4 max-rel, ids bit-exact where binding,
+gradients 1e-3 relative L2)."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import AVSR_CONV_YAML, AVSR_YAML, TOKENS_EN, avsr_conf, golden, grad_ok, max_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = 1e-4
+GRAD_TOL = 1e-3
+
+
+def _fill(module, seed):
+    from oracle.model import fill_parameters_
+    fill_parameters_(module, seed=seed)
+    return module.cuda()
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("H,W,C,K,s,p", [(22, 22, 64, 3, 1, 1), (22, 22, 64, 3, 2, 1), (11, 11, 128, 1, 2, 0), (6, 5, 32, 3, 2, 1)])
+def test_im2col_col2im_vs_conv2d(H, W, C, K, s, p):
+    from tavsr import ops
+    torch.manual_seed(0)
+    N, Co = 5, 48
+    x = torch.randn(N, C, H, W, device="cuda", dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, C, K, K, device="cuda", dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(x, w, stride=s, padding=p)
+    r = torch.randn_like(ref)
+    (ref * r).sum().backward()
+    x2 = x.detach().float().permute(0, 2, 3, 1).contiguous().view(-1, C)
+    col, Ho, Wo = ops.im2col2d(x2, N, H, W, C, K, K, s, p)
+    w2 = w.float().permute(0, 2, 3, 1).contiguous().view(Co, -1)
+    y = ops.linear(col, w2).view(N, Ho, Wo, Co).permute(0, 3, 1, 2)
+    assert max_rel(y.cpu(), ref.detach().cpu()) < 1e-5
+    dy = r.float().permute(0, 2, 3, 1).contiguous().view(-1, Co)
+    dcol = ops.linear_dx(dy, w2)
+    dx = ops.col2im2d(dcol, N, H, W, C, K, K, s, p).view(N, H, W, C).permute(0, 3, 1, 2)
+    assert max_rel(dx.cpu(), x.grad.cpu()) < 1e-5
+
+
+def test_stem_im2col_vs_conv3d():
+    from tavsr import ops
+    torch.manual_seed(1)
+    B, T, H, W = 2, 6, 20, 18
+    x = torch.randn(B, T, H, W, device="cuda")
+    w = torch.randn(64, 1, 5, 7, 7, device="cuda") / 15
+    ref = torch.nn.functional.conv3d(x.double().unsqueeze(1), w.double(), stride=(1, 2, 2), padding=(2, 3, 3))
+    col, Ho, Wo = ops.im2col_stem(x)
+    w2 = torch.zeros(64, 256, device="cuda")
+    w2[:, :245] = w.view(64, 245)
+    y = ops.linear(col, w2).view(B, T, Ho, Wo, 64).permute(0, 4, 1, 2, 3)
+    assert max_rel(y.cpu(), ref.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("act,with_res", [("swish", False), ("swish", True), (None, False)])
+def test_batchnorm_train_vs_torch(act, with_res):
+    from tavsr import ops
+    torch.manual_seed(2)
+    M, C = 3001, 64
+    x = (torch.randn(M, C, device="cuda") * 2 + 0.7)
+    res = torch.randn(M, C, device="cuda") if with_res else None
+    bn = torch.nn.BatchNorm1d(C).cuda().double().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    rm, rv = bn.running_mean.clone().float(), bn.running_var.clone().float()
+    nbt = bn.num_batches_tracked.clone()
+    xd = x.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True) if with_res else None
+    z = bn(xd) + (rd if with_res else 0)
+    yref = z * torch.sigmoid(z) if act == "swish" else z
+    r = torch.randn(M, C, device="cuda", dtype=torch.float64)
+    (yref * r).sum().backward()
+    g, b = bn.weight.detach().float(), bn.bias.detach().float()
+    mean, rstd = ops.bn_stats(x, 1e-5, 0.1, rm, rv, nbt)
+    y = ops.bn_apply_fwd(x, mean, rstd, g, b, res, act)
+    assert max_rel(y.cpu(), yref.detach().cpu()) < 1e-5
+    assert rel_err(rm.cpu(), bn.running_mean.cpu()) < 1e-6 and rel_err(rv.cpu(), bn.running_var.cpu()) < 1e-5
+    assert int(nbt) == int(bn.num_batches_tracked)
+    dz, dx, dg, db = ops.bn_bwd(r.float(), x, mean, rstd, g, b, res, act)
+    assert rel_err(dx.cpu(), xd.grad.cpu()) < 1e-4
+    assert rel_err(dg.cpu(), bn.weight.grad.cpu()) < 1e-4 and rel_err(db.cpu(), bn.bias.grad.cpu()) < 1e-4
+    if with_res:
+        assert rel_err(dz.cpu(), rd.grad.cpu()) < 1e-4
+
+
+def test_pools_vs_torch():
+    from tavsr import ops
+    torch.manual_seed(3)
+    N, H, W, C = 7, 44, 44, 64
+    x = torch.randn(N, C, H, W, device="cuda", requires_grad=True)
+    ref = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+    r = torch.randn_like(ref)
+    (ref * r).sum().backward()
+    x2 = x.detach().permute(0, 2, 3, 1).contiguous().view(-1, C)
+    y, idx, Ho, Wo = ops.maxpool3x3s2_fwd(x2, N, H, W, C)
+    assert torch.equal(y.view(N, Ho, Wo, C).permute(0, 3, 1, 2), ref.detach())
+    dx = ops.maxpool3x3s2_bwd(r.permute(0, 2, 3, 1).contiguous().view(-1, C), idx, N, H, W, C)
+    assert max_rel(dx.view(N, H, W, C).permute(0, 3, 1, 2).cpu(), x.grad.cpu()) < 1e-6
+    f = torch.randn(N, 9, 512, device="cuda")
+    assert max_rel(ops.avgpool_fwd(f.view(-1, 512), N, 9, 512).cpu(), f.mean(1).cpu()) < 1e-6
+    d = torch.randn(N, 512, device="cuda")
+    assert max_rel(ops.avgpool_bwd(d, N, 9, 512).view(N, 9, 512).cpu(), (d / 9)[:, None, :].expand(N, 9, 512).cpu()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ modules vs reference goldens
+def test_visual_frontend_vs_reference_golden():
+    from oracle.model import compact, synth
+    from tavsr.frontend.conv3d_resnet18 import Conv3dResNet18
+    g = golden("av_frontend")
+    m = Conv3dResNet18()
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    m = _fill(m, 61).train()
+    B, T = int(g["B"]), int(g["T"])
+    x = synth((B, T, 88, 88), seed=62).cuda()
+    y, _ = m(x, torch.tensor([5, 4]).cuda())
+    (y * synth((B, T, 512), seed=63).cuda()).sum().backward()
+    assert max_rel(y.detach().cpu(), g["y_train"]) < ACT_TOL
+    params, bufs = dict(m.named_parameters()), dict(m.named_buffers())
+    for k in g.files:
+        if k.startswith("g_"):
+            assert grad_ok(compact(params[k[2:]].grad.cpu()), g[k], GRAD_TOL), k
+    assert rel_err(bufs["frontend3D.1.running_mean"].cpu(), g["rm_stem"]) < 1e-5
+    assert rel_err(bufs["frontend3D.1.running_var"].cpu(), g["rv_stem"]) < 1e-5
+    assert rel_err(bufs["trunk.layer4.1.bn2.running_var"].cpu(), g["rv_l4"]) < 1e-4
+    assert int(bufs["frontend3D.1.num_batches_tracked"]) == int(g["nbt"])
+    m.eval()
+    with torch.no_grad():
+        ye, _ = m(x, torch.tensor([5, 4]).cuda())
+    assert max_rel(ye.cpu(), g["y_eval"]) < ACT_TOL
+
+
+@pytest.mark.parametrize("tag,kw,shape", [("audio", dict(input_size=80, input_layer="conv2d"), (3, 120, 80)),
+                                          ("video", dict(input_size=512, input_layer="linear"), (3, 30, 512))])
+def test_av_embedding_vs_reference_golden(tag, kw, shape):
+    from oracle.model import compact, synth
+    from tavsr.embedding_for_avsr.default import DefaultEmbeddingLayerForAVSR
+    g = golden(f"av_embed_{tag}")
+    m = DefaultEmbeddingLayerForAVSR(output_size=256, dropout_rate=0.0, positional_dropout_rate=0.0, **kw)
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    m = _fill(m, 91).train()
+    x = synth(shape, seed=92).cuda().requires_grad_(tag == "video")
+    y, masks = m.apply_embed_layer(x, torch.from_numpy(g["lens"]).cuda())
+    ys, pos = m.apply_pos_enc(y)
+    (ys * synth(tuple(ys.shape), seed=93).cuda()).sum().backward()
+    assert max_rel(y.detach().cpu(), g["y"]) < ACT_TOL and max_rel(ys.detach().cpu(), g["ys"]) < ACT_TOL
+    assert max_rel(pos.cpu(), g["pos"]) < 1e-6
+    assert np.array_equal(masks.cpu().numpy(), g["masks"])
+    if tag == "video":
+        assert rel_err(compact(x.grad.cpu()), g["grad_x"]) < GRAD_TOL
+    for n, p in m.named_parameters():
+        assert grad_ok(compact(p.grad.cpu()), g["g_" + n], GRAD_TOL), n
+
+
+def _masks(g, T):
+    alens, vlens = torch.from_numpy(g["alens"]).cuda(), torch.from_numpy(g["vlens"]).cuda()
+    ar = torch.arange(T, device="cuda")[None, :]
+    return (ar < alens[:, None])[:, None, :], (ar < vlens[:, None])[:, None, :]
+
+
+@pytest.mark.parametrize("tag,ua,uv", [("aa", [True], [True]), ("ac", [True], [False]), ("ca", [False], [True]),
+                                       ("cc", [False], [False])])
+def test_tailored_layer_vs_reference_golden(tag, ua, uv):
+    from oracle.model import compact, synth
+    from tavsr.encoder.audiovisual.tailored.encoder import TailoredEncoder
+    from tavsr.layers import RelPositionalEncoding
+    g = golden(f"av_tailored_layer_{tag}")
+    B, T, D = int(g["B"]), int(g["T"]), int(g["D"])
+    enc = TailoredEncoder("rel_pos", "latest", num_blocks=1, dropout_rate=0.0, positional_dropout_rate=0.0,
+                          attention_dropout_rate=0.0, acoustic_use_attn=ua, visual_use_attn=uv)
+    layer = enc.encoders[0]
+    assert sorted(layer.state_dict().keys()) == list(g["keys"])
+    layer = _fill(layer, 71).train()
+    am, vm = _masks(g, T)
+    a = synth((B, T, D), seed=72).cuda()
+    v = synth((B, T, D), seed=73).cuda()
+    pe = RelPositionalEncoding(D, 0.0)
+    xa, pos = pe(a)
+    xv, _ = pe(v)
+    xa.requires_grad_(True)
+    xv.requires_grad_(True)
+    (ya, _), _, (yv, _), _ = layer((xa, pos), am, (xv, pos), vm)
+    ((ya * synth((B, T, D), seed=74).cuda()).sum() + (yv * synth((B, T, D), seed=75).cuda()).sum()).backward()
+    assert max_rel(ya.detach().cpu(), g["ya"]) < ACT_TOL and max_rel(yv.detach().cpu(), g["yv"]) < ACT_TOL
+    assert rel_err(xa.grad.cpu() * 16.0, g["grad_a"]) < GRAD_TOL and rel_err(xv.grad.cpu() * 16.0, g["grad_v"]) < GRAD_TOL
+    for n, p in layer.named_parameters():
+        if "g_" + n in g.files:
+            assert grad_ok(compact(p.grad.cpu()), g["g_" + n], GRAD_TOL), n
+
+
+def test_tailored_encoder_and_fusion_vs_reference_golden():
+    from oracle.model import compact, synth
+    from tavsr.audiovisual_fusion.adaptive_audiovisual_fusion import AdaptiveAudioVisualFusion
+    from tavsr.encoder.audiovisual.tailored.encoder import TailoredEncoder
+    from tavsr.layers import RelPositionalEncoding
+    g = golden("av_tailored_encoder_4L_fusion")
+    B, T, D = int(g["B"]), int(g["T"]), int(g["D"])
+    enc = TailoredEncoder("rel_pos", "latest", **avsr_conf(num_blocks=4)["encoder_conf"])
+    fusion = AdaptiveAudioVisualFusion(input_size=256, **avsr_conf()["audiovisual_fusion_conf"])
+    assert sorted(enc.state_dict().keys()) == list(g["enc_keys"])
+    assert sorted(fusion.state_dict().keys()) == list(g["fus_keys"])
+    enc, fusion = _fill(enc, 81).train(), _fill(fusion, 82).train()
+    am, vm = _masks(g, T)
+    pe = RelPositionalEncoding(D, 0.0)
+    xa, pos = pe(synth((B, T, D), seed=83).cuda())
+    xv, _ = pe(synth((B, T, D), seed=84).cuda())
+    xa.requires_grad_(True)
+    xv.requires_grad_(True)
+    ya, oam, yv, ovm, _ = enc((xa, pos), am, (xv, pos), vm)
+    yf, olens = fusion(ya, oam, yv, ovm)
+    (yf * synth((B, T, D), seed=85).cuda()).sum().backward()
+    assert max_rel(ya.detach().cpu(), g["ya"]) < ACT_TOL and max_rel(yv.detach().cpu(), g["yv"]) < ACT_TOL
+    assert max_rel(yf.detach().cpu(), g["yf"]) < ACT_TOL
+    assert np.array_equal(olens.cpu().numpy(), g["olens"])
+    assert rel_err(fusion.acoustic_weight.cpu(), g["acoustic_weight"]) < 1e-4
+    assert rel_err(fusion.visual_weight.cpu(), g["visual_weight"]) < 1e-4
+    assert rel_err(xa.grad.cpu() * 16.0, g["grad_a"]) < GRAD_TOL and rel_err(xv.grad.cpu() * 16.0, g["grad_v"]) < GRAD_TOL
+    pe_, pf = dict(enc.named_parameters()), dict(fusion.named_parameters())
+    for k in g.files:
+        if k.startswith("g_enc."):
+            assert grad_ok(compact(pe_[k[6:]].grad.cpu()), g[k], GRAD_TOL), k
+        if k.startswith("g_fus."):
+            assert grad_ok(compact(pf[k[6:]].grad.cpu()), g[k], GRAD_TOL), k
+
+
+@pytest.mark.parametrize("name,yaml_path,nb,seed", [("av_model_tailored_2L", AVSR_YAML, 2, 101),
+                                                    ("av_model_conventional_1L", AVSR_CONV_YAML, 1, 111)])
+def test_avsr_model_vs_reference_golden(name, yaml_path, nb, seed):
+    from oracle.model import compact, synth
+    from tavsr.tasks.avsr import AVSRTask
+    g = golden(name)
+    model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(yaml_path, num_blocks=nb, dec_blocks=1)))
+    assert sorted(model.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
+    model = _fill(model, seed)
+    B, Ta, Tv = int(g["B"]), int(g["Ta"]), int(g["Tv"])
+    audio, video = synth((B, Ta, 80), seed=seed + 1).cuda(), synth((B, Tv, 88, 88), seed=seed + 2).cuda()
+    alens, vlens, tlens, text = (torch.from_numpy(g[k]).cuda() for k in ("alens", "vlens", "tlens", "text"))
+    model.train()
+    loss_t, stats_t, _ = model(audio.clone(), alens, video.clone(), vlens, text.clone(), tlens)
+    loss_t.backward()
+    assert rel_err(loss_t.detach().cpu(), g["loss_train"]) < 1e-4
+    assert rel_err(stats_t["loss_ctc"].cpu(), g["loss_ctc_train"]) < 1e-4
+    params = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith("g_"):
+            assert grad_ok(compact(params[k[2:]].grad.cpu()), g[k], 2e-3), k
+    for n, v in zip(g["gnorm_keys"], g["gnorm_vals"]):
+        got = float(params[str(n)].grad.norm())
+        assert abs(got - v) <= 2e-3 * max(v, 1e-6) + 1e-6, (n, got, v)
+    model.eval()
+    with torch.no_grad():
+        loss, stats, _ = model(audio.clone(), alens, video.clone(), vlens, text.clone(), tlens)
+        enc, olens = model.encode(audio.clone(), alens, video.clone(), vlens)
+        ids, hyp, hl = model.ctc.greedy(enc, olens)
+    assert rel_err(loss.cpu(), g["loss_eval"]) < 1e-4
+    assert abs(float(stats["acc"]) - float(g["acc"][0])) < 1e-6
+    assert max_rel(enc.cpu(), g["enc"]) < ACT_TOL
+    assert np.array_equal(olens.cpu().numpy(), g["olens"])
+    binding = torch.from_numpy(g["top2_gap"] > 1e-4)
+    if bool(binding.all()):   # the CTC character error rate is an integer function of the ids: equal when every frame binds
+        assert abs(float(stats["cer_ctc"]) - float(g["cer_ctc"][0])) < 1e-6
+    assert torch.equal(ids.cpu()[binding], torch.from_numpy(g["ctc_ids"])[binding])
+
+
+def test_av_realistic_size_vs_oracle_cfg3():
+    """BASELINE configs[2] (tailored AV-Branchformer 12L, 4 s clips: 400 mel frames + 100 lip frames 88x88) at batch 4:
+    HIP vs the pinned oracle run on the host - loss, encoder output, greedy ids, every parameter gradient."""
+    from oracle.av import build_avsr_oracle
+    from oracle.model import fill_parameters_, synth
+    from tavsr.tasks.avsr import AVSRTask
+    conf = avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)
+    oracle = build_avsr_oracle(conf, TOKENS_EN)
+    fill_parameters_(oracle, seed=4321)
+    model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)))
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    oracle.train()
+    B = 4
+    audio, video = synth((B, 400, 80), seed=4321), synth((B, 100, 88, 88), seed=4322)
+    alens, vlens = torch.tensor([400, 400, 360, 300]), torch.tensor([100, 100, 90, 75])
+    text = synth((B, 40), seed=4323, kind="int", lo=1, hi=40)
+    tlens = torch.tensor([40, 33, 25, 12])
+    for i, l in enumerate(tlens):
+        text[i, l:] = -1
+    lo, so, _ = oracle(audio, alens, video, vlens, text, tlens)
+    lo.backward()
+    lg, sg, _ = model(audio.cuda(), alens.cuda(), video.cuda(), vlens.cuda(), text.cuda(), tlens.cuda())
+    lg.backward()
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 1e-4
+    po = dict(oracle.named_parameters())
+    for n, p in model.named_parameters():
+        assert grad_ok(p.grad.cpu(), po[n].grad, 5e-3), n
+    bo, bg = dict(oracle.named_buffers()), dict(model.named_buffers())
+    for n in bo:
+        assert rel_err(bg[n].float().cpu(), bo[n].float()) < 1e-4, n
+    model.eval()
+    oracle.eval()
+    with torch.no_grad():
+        eo, oo = oracle.encode(audio, alens, video, vlens)
+        eg, og = model.encode(audio.cuda(), alens.cuda(), video.cuda(), vlens.cuda())
+    assert max_rel(eg.cpu(), eo) < ACT_TOL
+    assert torch.equal(og.cpu(), oo)
+    logits = oracle.ctc.ctc_lo(eo)
+    top2 = logits.topk(2, -1).values
+    binding = (top2[..., 0] - top2[..., 1]) > 1e-4
+    ids, hyp, hl = model.ctc.greedy(eg, og)
+    assert torch.equal(ids.cpu()[binding], logits.argmax(-1)[binding])
