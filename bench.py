@@ -33,20 +33,29 @@ import yaml  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 # Algorithmic work, forward, per utterance (BASELINE.md section 2 / SURVEY Appendix C); fwd+bwd = 3x.
-GFLOP_PER_UTT_FWD = 11.35
-B_PER_GPU, T_IN, N_MEL, L_TXT = 32, 400, 80, 40
+GFLOP_PER_UTT_FWD = {"asr": 11.35, "avsr": 79.14}
+B_PER_GPU, T_IN, N_MEL, L_TXT, T_VID, HW = 32, 400, 80, 40, 100, 88
+WORKLOAD = "asr"   # set by --workload: "asr" = BASELINE configs[1] (the headline), "avsr" = configs[2]/[3]
+
+
+def _zero_dropout(d):
+    for k, v in d.items():
+        if isinstance(v, dict):
+            _zero_dropout(v)
+        elif k.endswith("dropout_rate"):
+            d[k] = 0.0
 
 
 def make_conf():
-    conf = yaml.safe_load(open(os.path.join(PKG, "configs", "asr_branchformer_transformer_ctc_english.yaml")))
-    conf.update(input_size=N_MEL, specaug=None)
     # Dropout kernels are not on the HIP path yet (DESIGN.md "not yet"): rates are set to 0 for BOTH the GPU run
     # and the CPU baseline so the two time the same arithmetic.
-    for k in ("dropout_rate", "positional_dropout_rate", "attention_dropout_rate"):
-        conf["encoder_conf"][k] = 0.0
-    for k in ("dropout_rate", "positional_dropout_rate", "self_attention_dropout_rate", "src_attention_dropout_rate"):
-        conf["decoder_conf"][k] = 0.0
-    conf["ctc_conf"]["dropout_rate"] = 0.0
+    if WORKLOAD == "avsr":
+        conf = yaml.safe_load(open(os.path.join(PKG, "configs", "avsr_tailored_transformer_ctc_english.yaml")))
+        conf.update(acoustic_input_size=N_MEL, visual_input_size=None, specaug=None)
+    else:
+        conf = yaml.safe_load(open(os.path.join(PKG, "configs", "asr_branchformer_transformer_ctc_english.yaml")))
+        conf.update(input_size=N_MEL, specaug=None)
+    _zero_dropout(conf)
     return conf
 
 
@@ -56,18 +65,33 @@ def make_batch(batch, seed, device):
     slens = torch.full((batch,), T_IN, dtype=torch.int64)
     text = torch.randint(1, 40, (batch, L_TXT), generator=g)
     tlens = torch.full((batch,), L_TXT, dtype=torch.int64)
+    if WORKLOAD == "avsr":
+        video = torch.randn(batch, T_VID, HW, HW, generator=g)
+        vlens = torch.full((batch,), T_VID, dtype=torch.int64)
+        return [t.to(device) for t in (speech, slens, video, vlens, text, tlens)]
     return [t.to(device) for t in (speech, slens, text, tlens)]
+
+
+def build_product_model():
+    import copy as _copy
+    if WORKLOAD == "avsr":
+        from tavsr.tasks.avsr import AVSRTask
+        return AVSRTask.build_model(argparse.Namespace(**_copy.deepcopy(make_conf())))
+    from tavsr.tasks.asr import ASRTask
+    return ASRTask.build_model(argparse.Namespace(**_copy.deepcopy(make_conf())))
 
 
 def cpu_baseline(budget_s=20.0):
     """The oracle's fwd+bwd of the same model/workload on the host cores (bounded sample)."""
+    from oracle.av import build_avsr_oracle
     from oracle.model import build_asr_oracle
     from tavsr.utils.tokens import CHAR_ENGLISH
 
     torch.manual_seed(0)
-    model = build_asr_oracle(copy.deepcopy(make_conf()), CHAR_ENGLISH).train()
+    build = build_avsr_oracle if WORKLOAD == "avsr" else build_asr_oracle
+    model = build(copy.deepcopy(make_conf()), CHAR_ENGLISH).train()
     cores = torch.get_num_threads()
-    bs = 8
+    bs = 4 if WORKLOAD == "avsr" else 8
     batch = make_batch(bs, 1234, "cpu")
 
     def step():
@@ -98,10 +122,13 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--workload", choices=("asr", "avsr"), default="asr",
+                    help="asr: BASELINE configs[1] (headline); avsr: configs[2] tailored AV-Branchformer incl. the visual frontend")
     args = ap.parse_args()
+    global WORKLOAD
+    WORKLOAD = args.workload
 
     from tavsr import dp, ops
-    from tavsr.tasks.asr import ASRTask
 
     rank, local, world = dp.init_from_env()
     if world != args.gpus:
@@ -110,7 +137,7 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(0)
-    model = ASRTask.build_model(argparse.Namespace(**copy.deepcopy(make_conf()))).to(dev).train()
+    model = build_product_model().to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     buckets = dp.GradBuckets(params)
     buckets.broadcast_parameters(0)
@@ -170,16 +197,21 @@ def main():
     utts = B_PER_GPU * world * args.steps
     value = utts / elapsed
     out = {
-        "metric": "utterances/sec fwd+bwd, 12L Branchformer ASR (Conv2dSubsampling+CTC+6L decoder), 4 s clips, batch 32/GPU",
+        "metric": ("utterances/sec fwd+bwd, 12L tailored AV-Branchformer (Conv3d+ResNet-18 lip frontend, fusion, CTC+6L decoder), "
+                   "4 s clips, batch 32/GPU") if WORKLOAD == "avsr" else
+                  "utterances/sec fwd+bwd, 12L Branchformer ASR (Conv2dSubsampling+CTC+6L decoder), 4 s clips, batch 32/GPU",
         "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: audio-only 12-layer Branchformer d=256 + Conv2dSubsampling + CTC + "
-                               "6L Transformer decoder, batch 32 x 400 mel frames x 80 per GPU, text length 40, fwd+bwd",
+        "config": {"workload": ("BASELINE configs[2]: tailored AV-Branchformer 12L (400 mel frames x 80 + 100 lip frames 88x88, "
+                                "Conv3d+ResNet-18 frontend, adaptive fusion), CTC/attention joint loss, batch 32 per GPU, fwd+bwd")
+                   if WORKLOAD == "avsr" else
+                   "BASELINE configs[1]: audio-only 12-layer Branchformer d=256 + Conv2dSubsampling + CTC + "
+                   "6L Transformer decoder, batch 32 x 400 mel frames x 80 per GPU, text length 40, fwd+bwd",
                    "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "dropout": 0.0,
                    "launch": "eager" if graph is None else "hipGraph replay (whole fwd+bwd)"},
-        "model_tflops_per_s": round(value * 3 * GFLOP_PER_UTT_FWD / 1e3, 2),
-        "frac_of_fp32_mfma_peak_whole_step": round(value * 3 * GFLOP_PER_UTT_FWD / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+        "model_tflops_per_s": round(value * 3 * GFLOP_PER_UTT_FWD[WORKLOAD] / 1e3, 2),
+        "frac_of_fp32_mfma_peak_whole_step": round(value * 3 * GFLOP_PER_UTT_FWD[WORKLOAD] / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
     }
 
     if rank == 0 and not args.no_roofline:

@@ -111,18 +111,27 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   if (ry == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
-// stage 2 (one thread per channel, partials summed in double in a fixed order):
+// stage 2 (one block per 64 channels, 16 part-groups of 64 lanes; partials summed in double, fixed order):
 //   mode 0: mean[c] = sum / M
 //   mode 1: var[c] = sum / M (biased), rstd[c] = 1/sqrt(var + eps); running stats updated like torch BatchNorm
-//           (momentum m, unbiased variance), num_batches_tracked += 1 by thread 0
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, int64_t M, int mode, float eps,
-                                   float momentum, float* __restrict__ mean, float* __restrict__ var,
-                                   float* __restrict__ rstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, int64_t* __restrict__ nbt) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+//           (momentum m, unbiased variance), num_batches_tracked += 1 by one thread
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, int64_t M,
+                                                           int mode, float eps, float momentum, float* __restrict__ mean,
+                                                           float* __restrict__ var, float* __restrict__ rstd,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+  __shared__ double red[16][64];
+  const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += (double)part[(int64_t)p * C + c];
+  if (c < C)
+    for (int p = g; p < nparts; p += 16) s += (double)part[(int64_t)p * C + c];
+  red[g][cx] = s;
+  __syncthreads();
+  if (g != 0 || c >= C) return;
+  s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += red[q][cx];
   if (mode == 0) {
     mean[c] = (float)(s / (double)M);
   } else {
@@ -361,10 +370,10 @@ extern "C" int tavsr_bn_stats(const float* x, int64_t M, int32_t C, float eps, f
   const int64_t rpb = (M + chunks - 1) / chunks;
   const dim3 g(cdiv(C, 64), chunks);
   hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, s, x, (const float*)nullptr, M, C, rpb, 0, ws);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, chunks, C, M, 0, eps, momentum, mean, var,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, ws, chunks, C, M, 0, eps, momentum, mean, var,
                      rstd, (float*)nullptr, (float*)nullptr, (int64_t*)nullptr);
   hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, s, x, mean, M, C, rpb, 1, ws);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, chunks, C, M, 1, eps, momentum, mean, var,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, ws, chunks, C, M, 1, eps, momentum, mean, var,
                      rstd, running_mean, running_var, num_batches_tracked);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
