@@ -269,6 +269,14 @@ int tavsr_fill(float* p, float value, int64_t n, tavsr_stream_t stream);
 /* dst[m*ldd + n] = src[m*lds + n], m < M, n < N (no alignment requirement) */
 int tavsr_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int64_t N, tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step of the reference's harness (avsr_main.py:50-54): torch.optim.Adam(betas (0.9, 0.98), eps 1e-9) under
+ * the Noam rate (src/schedulers/noam.py:29-46,72-81), fused over flat fp32 buffers.  `step` counts from 1 (bias
+ * correction), `lr` is the Noam rate of that step, gradients are multiplied by grad_scale first (1/world_size under DP).
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int64_t step, float grad_scale, tavsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

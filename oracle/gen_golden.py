@@ -397,12 +397,36 @@ def gen_avsr_models():
     _gen_avsr_model("av_model_conventional_1L", AVSR_CONV_YAML, 1, 111)
 
 
+def gen_noam_adam():
+    """src/schedulers/noam.py (imported as it is: pure torch): Noam rates and the parameters after 12 Adam steps on
+    seeded gradients, incl. the reference loop's accumulate-then-step cadence (avsr_main.py:36-54)."""
+    from src.schedulers.noam import get_noam_scheduler
+
+    shapes = [(37, 19), (256,), (5, 3, 7), (1,)]
+    params = [torch.nn.Parameter(synth(s, seed=121 + i)) for i, s in enumerate(shapes)]
+    opt = get_noam_scheduler(params, 1.6, 256, 5)
+    rates = []
+    for step in range(12):
+        opt.zero_grad()
+        for micro in range(3):                       # three accumulated micro-batches per optimizer step
+            for i, p in enumerate(params):
+                g = synth(tuple(p.shape), seed=1000 + 100 * step + 10 * micro + i) / 3
+                p.grad = g if p.grad is None else p.grad + g
+        opt.step()
+        rates.append(opt._rate)
+    _save("noam_adam", rates=np.array(rates, dtype=np.float64),
+          **{f"p{i}": _np(p) for i, p in enumerate(params)})
+
+
 def main():
     import sys
 
     _shim.install()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--optim-only" in sys.argv:
+        gen_noam_adam()
+        return
     if "--av-only" in sys.argv:
         gen_visual_frontend()
         gen_av_embed()
@@ -418,6 +442,7 @@ def main():
     gen_av_embed()
     gen_tailored()
     gen_avsr_models()
+    gen_noam_adam()
 
 
 if __name__ == "__main__":

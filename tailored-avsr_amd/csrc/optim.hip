@@ -1,0 +1,64 @@
+// Optimizer step of the reference's training harness (avsr_main.py:50-54): torch.optim.Adam(betas=(0.9, 0.98), eps=1e-9)
+// driven by the Noam learning-rate wrapper (src/schedulers/noam.py:29-46,72-81; src/utils/scheduler.py:27-34), fused
+// into ONE pass over flat fp32 buffers (parameters, gradient, exp_avg, exp_avg_sq): 7 x 4 bytes of HBM traffic per
+// parameter, HBM-bound.  Arithmetic follows torch's single-tensor Adam operation by operation so that parameters
+// track the reference's to fp32 rounding.
+#include <math.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace tavsr {
+
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                        int64_t n, float beta1, float beta2, float eps, float step_size,
+                                                        float bc2_sqrt, float grad_scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+    const float4 G4 = reinterpret_cast<const float4*>(g)[i];
+    float* pp = &P.x; float* mm = &M.x; float* vv = &V.x;
+    const float* gg = &G4.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * grad_scale;
+      mm[j] = mm[j] + (gr - mm[j]) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+      vv[j] = vv[j] * beta2 + (1.f - beta2) * gr * gr;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pp[j] = pp[j] - step_size * (mm[j] / denom);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
+  // tail (n % 4 elements) by the first threads of block 0
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t k = (n4 << 2) + threadIdx.x;
+    const float gr = g[k] * grad_scale;
+    m[k] = m[k] + (gr - m[k]) * (1.f - beta1);
+    v[k] = v[k] * beta2 + (1.f - beta2) * gr * gr;
+    p[k] = p[k] - step_size * (m[k] / (sqrtf(v[k]) / bc2_sqrt + eps));
+  }
+}
+
+}  // namespace tavsr
+
+using namespace tavsr;
+
+extern "C" int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, int64_t step, float grad_scale, tavsr_stream_t stream) {
+  TAVSR_REQUIRE((p && g && m && v) || n <= 0, TAVSR_EINVAL, "adam_step: null pointer");
+  TAVSR_REQUIRE(step >= 1, TAVSR_EINVAL, "adam_step: step counts from 1");
+  TAVSR_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                TAVSR_EALIGN, "adam_step: 16-byte aligned flat buffers required");
+  if (n <= 0) return TAVSR_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const int64_t n4 = n >> 2;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)std::max<int64_t>(1, (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     p, g, m, v, n4, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
