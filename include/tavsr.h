@@ -277,6 +277,16 @@ int tavsr_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t
 int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int64_t step, float grad_scale, tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Train-mode dropout (every torch Dropout / F.dropout site of the path).  y[i] = keep_i ? x[i] / (1 - p) : 0 where
+ * keep_i is a pure function of (seed_dev[0], offset + i) (Philox4x32-10): the SAME call on the upstream gradient is the
+ * backward pass, no mask is stored.  seed_dev is a device-resident uint64; tavsr_rng_advance steps it (captured inside
+ * a hipGraph it gives every replay fresh masks).  offset % 4 == 0; in place (y == x) allowed.
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* seed_dev, uint64_t offset,
+                  tavsr_stream_t stream);
+int tavsr_rng_advance(uint64_t* seed_dev, tavsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

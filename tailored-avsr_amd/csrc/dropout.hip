@@ -1,0 +1,73 @@
+// Train-mode dropout (torch.nn.Dropout / F.dropout sites of the reference: encoder_layer.py:194,212,224,232-309,314,
+// espnet attention.forward_attention, cgmlp csgu, positional encodings, decoder layers, src/ctc/ctc.py:143).
+// y = x * keep / (1 - p) with keep ~ Bernoulli(1 - p) from a counter-based generator (Philox4x32-10): the mask of an
+// element is a pure function of (seed, offset + element index), so the backward pass regenerates it instead of
+// storing it, and one captured hipGraph draws fresh masks every replay because the seed lives in DEVICE memory and is
+// advanced by a kernel inside the graph.  HBM-bound: 8 bytes per element.
+#include "common.h"
+
+namespace tavsr {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// element e of a call uses word (e & 3) of philox(counter = offset/4 + e/4); offset % 4 == 0
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                      uint32_t thr, float inv_keep, const uint64_t* __restrict__ seed,
+                                                      uint64_t offset4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // group of 4 elements
+  const int64_t e = i << 2;
+  if (e >= n) return;
+  const uint64_t s = seed[0], ctr = offset4 + (uint64_t)i;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)s, (uint32_t)(s >> 32), r);
+  if (e + 3 < n && (((uintptr_t)(x + e) | (uintptr_t)(y + e)) & 15) == 0) {
+    const float4 v = *reinterpret_cast<const float4*>(x + e);
+    float4 o;
+    o.x = r[0] >= thr ? v.x * inv_keep : 0.f;
+    o.y = r[1] >= thr ? v.y * inv_keep : 0.f;
+    o.z = r[2] >= thr ? v.z * inv_keep : 0.f;
+    o.w = r[3] >= thr ? v.w * inv_keep : 0.f;
+    *reinterpret_cast<float4*>(y + e) = o;
+  } else {
+    for (int j = 0; j < 4 && e + j < n; ++j) y[e + j] = r[j] >= thr ? x[e + j] * inv_keep : 0.f;
+  }
+}
+
+__global__ void rng_advance_kernel(uint64_t* __restrict__ seed) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) seed[0] = seed[0] * 6364136223846793005ull + 1442695040888963407ull;
+}
+
+}  // namespace tavsr
+
+using namespace tavsr;
+
+extern "C" int tavsr_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* seed_dev, uint64_t offset,
+                             tavsr_stream_t stream) {
+  TAVSR_REQUIRE((x && y && seed_dev) || n <= 0, TAVSR_EINVAL, "dropout: null pointer");
+  TAVSR_REQUIRE(p >= 0.f && p < 1.f, TAVSR_EINVAL, "dropout: p must be in [0, 1)");
+  TAVSR_REQUIRE(offset % 4 == 0, TAVSR_EALIGN, "dropout: offset must be a multiple of 4");
+  if (n <= 0) return TAVSR_OK;
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  const int64_t groups = (n + 3) / 4;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, thr,
+                     1.f / (1.f - p), seed_dev, offset / 4);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_rng_advance(uint64_t* seed_dev, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(seed_dev, TAVSR_EINVAL, "rng_advance: null pointer");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seed_dev);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}

@@ -28,9 +28,9 @@ class CTC(torch.nn.Module):
     def forward(self, hs_pad, hlens, ys_pad, ys_lens):
         """hs_pad (B,Tmax,D), hlens (B), ys_pad (B,Lmax) padded with -1, ys_lens (B) -> scalar loss."""
         if self.dropout_rate > 0:
-            # the reference applies F.dropout here even in eval mode (ctc.py:143, SURVEY Q7)
-            raise NotImplementedError("ctc_conf.dropout_rate > 0 is stochastic in the reference even in eval; "
-                                      "set ctc_conf:dropout_rate:0.0 on the HIP path")
+            # the reference applies F.dropout(hs_pad, p) with its default training=True: active in eval mode too
+            # (ctc.py:143, SURVEY Q7) - followed as it is
+            hs_pad = F_.DropoutFn.apply(hs_pad, self.dropout_rate)
         return F_.CTCLossFn.apply(hs_pad, self.ctc_lo.weight, self.ctc_lo.bias, hlens.to(torch.int64),
                                   ys_pad.to(torch.int64).contiguous(), ys_lens.to(torch.int64), self.reduce,
                                   self.zero_infinity)

@@ -51,11 +51,10 @@ class TransformerDecoder(torch.nn.Module):
 
     def forward(self, hs_pad, hlens, ys_in_pad, ys_in_lens):
         """hs_pad (B,T,D), hlens (B), ys_in_pad (B,L) int64, ys_in_lens (B) -> (logits (B,L,V), olens)."""
-        if self.training and any(r > 0 for r in self._rates):
-            raise NotImplementedError("train-mode dropout is not implemented on the HIP path yet: set decoder_conf "
-                                      "dropout rates to 0.0 or call .eval()")
         pe = self.embed[1].table(ys_in_pad.size(1), hs_pad.device)
         cfg = dict(heads=self.heads, num_blocks=self.num_blocks)
+        if self.training:    # (dropout_rate, positional, self-attention, source-attention) of the espnet2 decoder
+            cfg.update(p=self._rates[0], p_pos=self._rates[1], p_self=self._rates[2], p_src=self._rates[3])
         logits = F_.TransformerDecoderFn.apply(hs_pad, hlens.to(torch.int64), ys_in_pad.to(torch.int64),
                                                ys_in_lens.to(torch.int64), pe, cfg, *self._params())
         return logits, ys_in_lens

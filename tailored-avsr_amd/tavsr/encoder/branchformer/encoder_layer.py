@@ -90,10 +90,6 @@ class MyBranchformerEncoderLayer(torch.nn.Module):
         if not isinstance(x_input, tuple):
             raise NotImplementedError("the HIP path implements the rel_pos form: x_input = (x, pos_emb)")
         x, pos_emb = x_input
-        if self._active_dropout():
-            raise NotImplementedError(
-                "train-mode dropout is not implemented on the HIP path yet: set the *_dropout_rate "
-                "entries to 0.0 (e.g. --yaml-overrides encoder_conf:dropout_rate:0.0) or call .eval()")
         coeff = 1.0
         if self.training and self.stochastic_depth_rate > 0:
             skip = torch.rand(1).item() < self.stochastic_depth_rate
@@ -108,7 +104,11 @@ class MyBranchformerEncoderLayer(torch.nn.Module):
         cfg = dict(heads=self.attn.h if self.attn is not None else 1, ffn_act=self.feed_forward.activation,
                    merge=merge, has_attn=self.attn is not None, has_mlp=self.cgmlp is not None,
                    cgmlp_weight=self.cgmlp_weight, coeff=coeff,
-                   merge_identity=isinstance(self.merge_proj, torch.nn.Identity))
+                   merge_identity=isinstance(self.merge_proj, torch.nn.Identity),
+                   # train-mode dropout (self.dropout / PositionwiseFeedForward / csgu: dropout_rate; attention
+                   # probabilities: attention_dropout_rate); masks come from the device-resident generator (ops.dropout)
+                   p=self.dropout_rate if self.training else 0.0,
+                   p_att=(self.attn.dropout_rate if (self.training and self.attn is not None) else 0.0))
         y = F_.BranchformerLayerFn.apply(x, pos_emb, lens, cfg, *self._params())
         w = cfg.get("_last_w")
         if w is not None:  # (B,2) -> the reference's (B,1,1) views (encoder_layer.py:286-289)

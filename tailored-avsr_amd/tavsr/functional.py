@@ -25,22 +25,53 @@ EPS_ESPNET = 1e-12  # espnet LayerNorm eps
 # ------------------------------------------------------------------------------------------------
 # building blocks shared by the Functions (plain python, explicit saved state)
 # ------------------------------------------------------------------------------------------------
+def _drop_(x, p):
+    """in-place train-mode dropout; returns the token that regenerates the mask (None when p == 0)."""
+    if not p or p <= 0.0:
+        return None
+    return ops.dropout(x, p, out=x)[1]
+
+
+def _drop_bwd_(dy, tok):
+    """in-place backward of _drop_ (same mask, same scale); no-op without a token."""
+    if tok is not None:
+        ops.dropout(dy, tok[0], out=dy, token=tok)
+    return dy
+
+
+def _drop_bwd(dy, tok):
+    """out-of-place variant for gradients that are still needed unmasked (residual paths)."""
+    return dy if tok is None else ops.dropout(dy, tok[0], token=tok)[0]
+
+
 class _FFN:
-    """y = x + scale * W2 act(W1 LN(x) + b1) + b2   (encoder_layer.py:192-194,312-314; decoder FFN)."""
+    """y = x + scale * drop(W2 drop(act(W1 LN(x) + b1)) + b2)   (encoder_layer.py:192-194,312-314; decoder FFN;
+    the inner dropout is PositionwiseFeedForward's, the outer one the layer's: both rate ``p`` in the reference)."""
 
     @staticmethod
-    def fwd(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, eps=EPS_ESPNET):
+    def fwd(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, eps=EPS_ESPNET, p=0.0):
         n, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, eps)
         h, z = ops.linear(n, w1, b1, act=act, save_z=True)
-        y = ops.linear(h, w2, b2, alpha=scale, res=x)
-        return y, (x, mean, rstd, n, z, h)
+        t_in = _drop_(h, p)
+        if p and p > 0.0:
+            t = ops.linear(h, w2, b2)
+            t_out = _drop_(t, p)
+            y = ops.axpby(x, t, 1.0, scale)
+        else:
+            t_out = None
+            y = ops.linear(h, w2, b2, alpha=scale, res=x)
+        return y, (x, mean, rstd, n, z, h, t_in, t_out)
 
     @staticmethod
     def bwd(dy, saved, ln_w, w1, w2, act, scale):
         """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2)."""
-        x, mean, rstd, n, z, h = saved
-        gw2, gb2 = ops.linear_dw(dy, h, alpha=scale, bias_grad=True)
-        dz = ops.linear_dx(dy, w2, alpha=scale, DZ=z, dact=act)
+        x, mean, rstd, n, z, h, t_in, t_out = saved
+        dyd = _drop_bwd(dy, t_out)
+        gw2, gb2 = ops.linear_dw(dyd, h, alpha=scale, bias_grad=True)
+        if t_in is None:
+            dz = ops.linear_dx(dyd, w2, alpha=scale, DZ=z, dact=act)
+        else:
+            dz = ops.act_bwd_(_drop_bwd_(ops.linear_dx(dyd, w2, alpha=scale), t_in), z, act)
         gw1, gb1 = ops.linear_dw(dz, n, bias_grad=True)
         dn = ops.linear_dx(dz, w1)
         dx, gln_w, gln_b = ops.layernorm_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
@@ -54,7 +85,8 @@ class _SelfAttnCore:
     ``ctx`` [B*T1, D].  rel-pos (espnet RelPositionMultiHeadedAttention) when ``p`` is given."""
 
     @staticmethod
-    def fwd(qu, ldq, q_off, kbuf, ldk, k_off, vbuf, ldv, v_off, B, T1, T2, H, dk, klens, causal, qv=None, p=None):
+    def fwd(qu, ldq, q_off, kbuf, ldk, k_off, vbuf, ldv, v_off, B, T1, T2, H, dk, klens, causal, qv=None, p=None,
+            p_att=0.0):
         D = H * dk
         dev = qu
         S = ops.pad4(T2)   # padded score-row stride: 16-byte loads in the GEMMs that read the scores
@@ -71,15 +103,18 @@ class _SelfAttnCore:
             ops.gemm(T1, W, dk, qv, D, p, D, bd, Wp, nb1=B, nb2=H, sA=(T1 * D, dk), sB=(0, dk),
                      sC=(T1 * Wp, B * T1 * Wp))
         attn = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal, T2=T2, W=W)
+        pv, tok = attn, None
+        if p_att and p_att > 0.0:      # dropout on the probabilities (espnet forward_attention); attn itself is kept
+            pv, tok = ops.dropout(attn, p_att)
         ctx = ops.empty(B * T1, D, like=dev)
-        # ctx[b,:,h] = attn[h,b] V[b,:,h]
-        ops.gemm(T1, dk, T2, attn, S, vbuf, ldv, ctx, D, b_off=v_off, b_kmajor=True, nb1=B, nb2=H,
+        # ctx[b,:,h] = drop(attn)[h,b] V[b,:,h]
+        ops.gemm(T1, dk, T2, pv, S, vbuf, ldv, ctx, D, b_off=v_off, b_kmajor=True, nb1=B, nb2=H,
                  sA=(T1 * S, B * T1 * S), sB=(T2 * ldv, dk), sC=(T1 * D, dk))
-        return ctx, attn
+        return ctx, attn, tok
 
     @staticmethod
     def bwd(dctx, attn, qu, ldq, q_off, kbuf, ldk, k_off, vbuf, ldv, v_off, dq, lddq, dq_off, dk_buf, lddk, dk_off,
-            dv_buf, lddv, dv_off, B, T1, T2, H, dk, qv=None, p=None):
+            dv_buf, lddv, dv_off, B, T1, T2, H, dk, qv=None, p=None, tok=None):
         """Writes dQ(u) into dq, dK into dk_buf, dV into dv_buf (head-strided); returns (dqv, dp) for rel-pos."""
         D = H * dk
         S = attn.shape[-1]
@@ -88,9 +123,12 @@ class _SelfAttnCore:
         # dattn[h,b] = dctx[b,:,h] V[b,:,h]^T
         ops.gemm(T1, T2, dk, dctx, D, vbuf, ldv, dattn, S, b_off=v_off, nb1=B, nb2=H, sA=(T1 * D, dk),
                  sB=(T2 * ldv, dk), sC=sS)
-        # dV[b,:,h] = attn[h,b]^T dctx[b,:,h]
-        ops.gemm(T2, dk, T1, attn, S, dctx, D, dv_buf, lddv, c_off=dv_off, a_kmajor=True, b_kmajor=True, nb1=B, nb2=H,
+        # dV[b,:,h] = drop(attn)[h,b]^T dctx[b,:,h]   (the dropped probabilities are regenerated, not stored)
+        pv = attn if tok is None else ops.dropout(attn, tok[0], token=tok)[0]
+        ops.gemm(T2, dk, T1, pv, S, dctx, D, dv_buf, lddv, c_off=dv_off, a_kmajor=True, b_kmajor=True, nb1=B, nb2=H,
                  sA=sS, sB=(T1 * D, dk), sC=(T2 * lddv, dk))
+        del pv
+        _drop_bwd_(dattn, tok)
         ds, sk = ops.softmax_bwd(attn, dattn, 1.0 / math.sqrt(dk), skew=p is not None, T2=T2)
         # dQu[b,:,h] = ds[h,b] K[b,:,h]
         ops.gemm(T1, dk, T2, ds, S, kbuf, ldk, dq, lddq, b_off=k_off, c_off=dq_off, b_kmajor=True, nb1=B, nb2=H,
@@ -153,13 +191,14 @@ class BranchformerLayerFn(torch.autograd.Function):
         merge = cfg["merge"]  # learned_ave | fixed_ave | concat | attn_only | mlp_only (+ identity flag)
         has_attn, has_mlp = cfg["has_attn"], cfg["has_mlp"]
         coeff = cfg.get("coeff", 1.0)
+        pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)     # dropout rates (0 in eval)
         p = lambda n: P[_I[n]]
         x2d = x.reshape(M, D)
         sv = {}
 
         x1, sv["ffm"] = _FFN.fwd(x2d, p("norm_ff_macaron.weight"), p("norm_ff_macaron.bias"),
                                  p("feed_forward_macaron.w_1.weight"), p("feed_forward_macaron.w_1.bias"),
-                                 p("feed_forward_macaron.w_2.weight"), p("feed_forward_macaron.w_2.bias"), act, 0.5)
+                                 p("feed_forward_macaron.w_2.weight"), p("feed_forward_macaron.w_2.bias"), act, 0.5, p=pd)
         two = has_attn and has_mlp
         cat = ops.empty(M, 2 * D, like=x) if merge == "concat" else None
         xa = xm = None
@@ -172,14 +211,16 @@ class BranchformerLayerFn(torch.autograd.Function):
             pe2d = pos_emb.reshape(-1, D)
             pp = ops.linear(pe2d, p("attn.linear_pos.weight"))
             qu, qv = ops.add_head_bias(qkv[:, :D], p("attn.pos_bias_u").reshape(-1), p("attn.pos_bias_v").reshape(-1))
-            cx, attn = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
-                                         qv=qv, p=pp)
+            cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
+                                                qv=qv, p=pp, p_att=pa)
+            t_xa = None
             if merge == "concat":
                 ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), out=cat, out_off=0, ldc=2 * D)
                 xa = cat[:, :D]
             else:
                 xa = ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"))
-            sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn)
+                t_xa = _drop_(xa, pd)                       # x1 = dropout(x_att)  (encoder_layer.py:212)
+            sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
         if has_mlp:
             n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mlp.weight"), p("norm_mlp.bias"), EPS_ESPNET)
             g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu",
@@ -189,13 +230,17 @@ class BranchformerLayerFn(torch.autograd.Function):
                                                  EPS_ESPNET)
             cw = p("cgmlp.csgu.conv.weight")
             u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p("cgmlp.csgu.conv.bias"), B, T)
+            t_u = _drop_(u, pd)                             # csgu: dropout(x_r * x_g)
+            t_xm = None
             if merge == "concat":
                 ops.linear(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"), out=cat, out_off=D,
                            ldc=2 * D)
                 xm = cat[:, D:]
             else:
                 xm = ops.linear(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"))
-            sv["mlp"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv)
+                t_xm = _drop_(xm, pd)                       # x2 = dropout(x2)  (encoder_layer.py:224)
+            sv["mlp"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_xm)
+        t_cat = _drop_(cat, pd) if (merge == "concat" and cat is not None) else None   # both halves in one call (iid)
         wts = None
         if two and merge == "learned_ave":
             mp = [p(k) for k in ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias",
@@ -214,13 +259,22 @@ class BranchformerLayerFn(torch.autograd.Function):
         else:
             m = xa if has_attn else xm
             sv["merge"] = (m,)
+        t_m = None
         if cfg["merge_identity"]:
-            x2 = ops.axpby(x1, m, 1.0, coeff)
+            md = m
+            if pd > 0.0:                                    # x + coeff * dropout(x1 | x2)  (encoder_layer.py:302-309)
+                md, t_m = ops.dropout(m.contiguous(), pd)
+            x2 = ops.axpby(x1, md, 1.0, coeff)
+        elif pd > 0.0:                                      # x + coeff * dropout(merge_proj(.))  (:232-300)
+            t = ops.linear(m, p("merge_proj.weight"), p("merge_proj.bias"))
+            t_m = _drop_(t, pd)
+            x2 = ops.axpby(x1, t, 1.0, coeff)
         else:
             x2 = ops.linear(m, p("merge_proj.weight"), p("merge_proj.bias"), alpha=coeff, res=x1)
+        sv["drop"] = (t_cat, t_m)
         x3, sv["ff"] = _FFN.fwd(x2, p("norm_ff.weight"), p("norm_ff.bias"), p("feed_forward.w_1.weight"),
                                 p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
-                                act, 0.5)
+                                act, 0.5, p=pd)
         y, fmean, frstd = ops.layernorm_fwd(x3, p("norm_final.weight"), p("norm_final.bias"), EPS_ESPNET)
         sv["final"] = (x3, fmean, frstd)
         sv["x1"], sv["xa"], sv["xm"] = x1, xa, xm
@@ -257,12 +311,15 @@ class BranchformerLayerFn(torch.autograd.Function):
             put(n_, g)
         # merge projection: x2 = x1 + coeff * (m Wm^T + bm)
         m = sv["merge"][-1]
+        t_cat, t_m = sv["drop"]
         if cfg["merge_identity"]:
-            dm = ops.axpby(dx2, None, coeff, 0.0) if coeff != 1.0 else dx2
+            dm = ops.axpby(dx2, None, coeff, 0.0) if (coeff != 1.0 or t_m is not None) else dx2
+            _drop_bwd_(dm, t_m) if t_m is not None else None
         else:
-            gw_, gb_ = ops.linear_dw(dx2, m, alpha=coeff, bias_grad=True)
+            dxd = _drop_bwd(dx2, t_m)
+            gw_, gb_ = ops.linear_dw(dxd, m, alpha=coeff, bias_grad=True)
             put("merge_proj.weight", gw_); put("merge_proj.bias", gb_)
-            dm = ops.linear_dx(dx2, p("merge_proj.weight"), alpha=coeff)
+            dm = ops.linear_dx(dxd, p("merge_proj.weight"), alpha=coeff)
         xa, xm = sv["xa"], sv["xm"]
         if two and merge == "learned_ave":
             score, pooled, wts, _ = sv["merge"]
@@ -278,6 +335,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             dxa = ops.axpby(dm, None, 1.0 - cw_, 0.0)
             dxm = ops.axpby(dm, None, cw_, 0.0)
         elif two and merge == "concat":
+            _drop_bwd_(dm, t_cat)
             dxa, dxm = dm[:, :D], dm[:, D:]
         else:
             dxa = dm if has_attn else None
@@ -286,11 +344,13 @@ class BranchformerLayerFn(torch.autograd.Function):
         x1 = sv["x1"]
         dx1 = dx2  # residual path; branch gradients are folded in through dx_add
         if has_mlp:
-            mean, rstd, n, g, z, gn, gmean, grstd, u, conv = sv["mlp"]
+            mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_xm = sv["mlp"]
             Cn = g.shape[1] // 2
+            if t_xm is not None:
+                dxm = _drop_bwd(dxm.contiguous(), t_xm)
             gw_, gb_ = ops.linear_dw(dxm, u, bias_grad=True)
             put("cgmlp.channel_proj2.weight", gw_); put("cgmlp.channel_proj2.bias", gb_)
-            du = ops.linear_dx(dxm, p("cgmlp.channel_proj2.weight"))
+            du = _drop_bwd_(ops.linear_dx(dxm, p("cgmlp.channel_proj2.weight")), t_u)
             dg = torch.empty_like(g)
             cw = p("cgmlp.csgu.conv.weight")
             dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
@@ -304,14 +364,16 @@ class BranchformerLayerFn(torch.autograd.Function):
             dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1)
             put("norm_mlp.weight", g1); put("norm_mlp.bias", g2)
         if has_attn:
-            mean, rstd, n, qkv, pp, qu, qv, cx, attn = sv["attn"]
+            mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa = sv["attn"]
+            if t_xa is not None:
+                dxa = _drop_bwd(dxa.contiguous(), t_xa)
             gw_, gb_ = ops.linear_dw(dxa, cx, bias_grad=True)
             put("attn.linear_out.weight", gw_); put("attn.linear_out.bias", gb_)
             dcx = ops.linear_dx(dxa, p("attn.linear_out.weight"))
             dqkv = torch.empty_like(qkv)
             dqu = ops.empty(M, D, like=dy2)
             dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
-                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp)
+                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
             put("attn.pos_bias_u", ops.colsum(dqu), like=p("attn.pos_bias_u"))
             put("attn.pos_bias_v", ops.colsum(dqv), like=p("attn.pos_bias_v"))
             ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
@@ -356,6 +418,19 @@ class LayerNormFn(torch.autograd.Function):
         x2, mean, rstd, w = ctx.saved_tensors
         dx, gw, gb = ops.layernorm_bwd(dy.contiguous().view(x2.shape), x2, mean, rstd, w)
         return dx.view(dy.shape), gw, gb, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """stand-alone dropout node (positional-encoding dropouts, src/ctc/ctc.py:143)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        y, ctx.tok = ops.dropout(x.contiguous(), p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.tok[0], token=ctx.tok)[0], None
 
 
 class LinearFn(torch.autograd.Function):
@@ -486,7 +561,9 @@ class TransformerDecoderFn(torch.autograd.Function):
         M = B * L
         mem2 = memory.reshape(B * T, D)
         emb_w = P[0]
+        pd, ppos, pself, psrc = (cfg.get(k, 0.0) for k in ("p", "p_pos", "p_self", "p_src"))
         x = ops.embed_pe(ys_in.contiguous(), emb_w, pe, math.sqrt(D)).view(M, D)
+        t_pos = _drop_(x, ppos)                              # PositionalEncoding dropout
         saved = []
         for li in range(nb):
             p = lambda n, li=li: P[1 + li * _NL + _DI[n]]
@@ -497,27 +574,41 @@ class TransformerDecoderFn(torch.autograd.Function):
             ops.linear(n1, p("self_attn.linear_q.weight"), p("self_attn.linear_q.bias"), out=qkv, out_off=0, ldc=3 * D)
             ops.linear(n1, p("self_attn.linear_k.weight"), p("self_attn.linear_k.bias"), out=qkv, out_off=D, ldc=3 * D)
             ops.linear(n1, p("self_attn.linear_v.weight"), p("self_attn.linear_v.bias"), out=qkv, out_off=2 * D, ldc=3 * D)
-            cx, attn = _SelfAttnCore.fwd(qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, L, L, H, dk, ys_lens, True)
-            x1 = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"), res=x)
-            s["self"] = (x, m1, r1, n1, qkv, cx, attn)
+            cx, attn, tk_a = _SelfAttnCore.fwd(qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, L, L, H, dk, ys_lens, True,
+                                               p_att=pself)
+            tk_r = None
+            if pd > 0.0:                                     # x + dropout(self_attn(...))
+                t = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"))
+                tk_r = _drop_(t, pd)
+                x1 = ops.axpby(x, t, 1.0, 1.0)
+            else:
+                x1 = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"), res=x)
+            s["self"] = (x, m1, r1, n1, qkv, cx, attn, tk_a, tk_r)
             # --- source attention over the encoder memory
             n2, m2, r2 = ops.layernorm_fwd(x1, p("norm2.weight"), p("norm2.bias"), EPS_ESPNET)
             q2 = ops.linear(n2, p("src_attn.linear_q.weight"), p("src_attn.linear_q.bias"))
             kv = ops.empty(B * T, 2 * D, like=x)
             ops.linear(mem2, p("src_attn.linear_k.weight"), p("src_attn.linear_k.bias"), out=kv, out_off=0, ldc=2 * D)
             ops.linear(mem2, p("src_attn.linear_v.weight"), p("src_attn.linear_v.bias"), out=kv, out_off=D, ldc=2 * D)
-            cx2, attn2 = _SelfAttnCore.fwd(q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, B, L, T, H, dk, hlens, False)
-            x2 = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"), res=x1)
-            s["src"] = (x1, m2, r2, n2, q2, kv, cx2, attn2)
+            cx2, attn2, tk_a2 = _SelfAttnCore.fwd(q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, B, L, T, H, dk, hlens, False,
+                                                  p_att=psrc)
+            tk_r2 = None
+            if pd > 0.0:                                     # x + dropout(src_attn(...))
+                t = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"))
+                tk_r2 = _drop_(t, pd)
+                x2 = ops.axpby(x1, t, 1.0, 1.0)
+            else:
+                x2 = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"), res=x1)
+            s["src"] = (x1, m2, r2, n2, q2, kv, cx2, attn2, tk_a2, tk_r2)
             # --- position-wise FFN (ReLU, scale 1)
             x, s["ff"] = _FFN.fwd(x2, p("norm3.weight"), p("norm3.bias"), p("feed_forward.w_1.weight"),
                                   p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
-                                  "relu", 1.0)
+                                  "relu", 1.0, p=pd)
             saved.append(s)
         an_w, an_b, out_w, out_b = P[1 + nb * _NL: 1 + nb * _NL + 4]
         xn, mf, rf = ops.layernorm_fwd(x, an_w, an_b, EPS_ESPNET)
         logits = ops.linear(xn, out_w, out_b)
-        ctx.saved, ctx.final = saved, (x, mf, rf, xn)
+        ctx.saved, ctx.final, ctx.t_pos = saved, (x, mf, rf, xn), t_pos
         ctx.P, ctx.cfg, ctx.dims = P, cfg, (B, T, L, D, H, dk, nb)
         ctx.mem2, ctx.ys_in = mem2, ys_in
         return logits.view(B, L, -1)
@@ -551,14 +642,15 @@ class TransformerDecoderFn(torch.autograd.Function):
                               "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
                 put(n_, g)
             # --- source attention
-            x1, m2, r2, n2, q2, kv, cx2, attn2 = s["src"]
-            gw_, gb_ = ops.linear_dw(dx2, cx2, bias_grad=True)
+            x1, m2, r2, n2, q2, kv, cx2, attn2, tk_a2, tk_r2 = s["src"]
+            dt2 = _drop_bwd(dx2, tk_r2)
+            gw_, gb_ = ops.linear_dw(dt2, cx2, bias_grad=True)
             put("src_attn.linear_out.weight", gw_); put("src_attn.linear_out.bias", gb_)
-            dcx2 = ops.linear_dx(dx2, p("src_attn.linear_out.weight"))
+            dcx2 = ops.linear_dx(dt2, p("src_attn.linear_out.weight"))
             dq2 = ops.empty(M, D, like=dl)
             dkv = torch.empty_like(kv)
             _SelfAttnCore.bwd(dcx2, attn2, q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, dq2, D, 0, dkv, 2 * D, 0, dkv, 2 * D, D,
-                              B, L, T, H, dk)
+                              B, L, T, H, dk, tok=tk_a2)
             gw_, gb_ = ops.linear_dw(dq2, n2, bias_grad=True)
             put("src_attn.linear_q.weight", gw_); put("src_attn.linear_q.bias", gb_)
             gkv_w, gkv_b = ops.linear_dw(dkv, mem2, bias_grad=True)   # [2D, D], [2D]
@@ -573,13 +665,14 @@ class TransformerDecoderFn(torch.autograd.Function):
             dx1, g1, g2 = ops.layernorm_bwd(dn2, x1, m2, r2, p("norm2.weight"), dx_add=dx2)
             put("norm2.weight", g1); put("norm2.bias", g2)
             # --- self attention
-            x0, m1, r1, n1, qkv, cx, attn = s["self"]
-            gw_, gb_ = ops.linear_dw(dx1, cx, bias_grad=True)
+            x0, m1, r1, n1, qkv, cx, attn, tk_a, tk_r = s["self"]
+            dt1 = _drop_bwd(dx1, tk_r)
+            gw_, gb_ = ops.linear_dw(dt1, cx, bias_grad=True)
             put("self_attn.linear_out.weight", gw_); put("self_attn.linear_out.bias", gb_)
-            dcx = ops.linear_dx(dx1, p("self_attn.linear_out.weight"))
+            dcx = ops.linear_dx(dt1, p("self_attn.linear_out.weight"))
             dqkv = torch.empty_like(qkv)
             _SelfAttnCore.bwd(dcx, attn, qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqkv, 3 * D, 0, dqkv, 3 * D, D,
-                              dqkv, 3 * D, 2 * D, B, L, L, H, dk)
+                              dqkv, 3 * D, 2 * D, B, L, L, H, dk, tok=tk_a)
             gw, gb = ops.linear_dw(dqkv, n1, bias_grad=True)
             put("self_attn.linear_q.weight", gw[:D]); put("self_attn.linear_k.weight", gw[D:2 * D]); put("self_attn.linear_v.weight", gw[2 * D:])
             put("self_attn.linear_q.bias", gb[:D]); put("self_attn.linear_k.bias", gb[D:2 * D]); put("self_attn.linear_v.bias", gb[2 * D:])
@@ -588,6 +681,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             ops.linear_dx(dqkv[:, 2 * D:], p("self_attn.linear_v.weight"), res=dn1, out=dn1)
             dx, g1, g2 = ops.layernorm_bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1)
             put("norm1.weight", g1); put("norm1.bias", g2)
+        _drop_bwd_(dx, ctx.t_pos)
         G[0] = ops.embed_bwd(ctx.ys_in.contiguous(), dx, math.sqrt(D), P[0].shape[0])
         ctx.saved = None
         ops.join_side()

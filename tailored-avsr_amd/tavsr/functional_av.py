@@ -282,7 +282,7 @@ class TailoredStreamFn(torch.autograd.Function):
             ops.linear(n, p["attn.linear_v.weight"], p["attn.linear_v.bias"], out=qkv, out_off=2 * D, ldc=3 * D)
             pp = ops.linear(pos_emb.reshape(-1, D), p["attn.linear_pos.weight"])
             qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
-            cx, attn = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False, qv=qv, p=pp)
+            cx, attn, _ = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False, qv=qv, p=pp)
             x2 = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], alpha=coeff, res=x1)
             sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn)
         else:

@@ -175,6 +175,9 @@ class Conv2dSubsampling(nn.Module):
         y = F_.Conv2dSubsamplingFn.apply(x, self.conv[0].weight, self.conv[0].bias, self.conv[2].weight,
                                          self.conv[2].bias, self.out[0].weight, self.out[0].bias, pe.xscale)
         pos = pe.pos_emb(y.size(1), y.device)
+        if self.training and pe.dropout_rate > 0:    # RelPositionalEncoding: dropout(x), dropout(pos_emb)
+            y = F_.DropoutFn.apply(y, pe.dropout_rate)
+            pos = ops.dropout(pos, pe.dropout_rate)[0]
         if x_mask is None:
             return (y, pos), None
         return (y, pos), x_mask[:, :, :-2:2][:, :, :-2:2]

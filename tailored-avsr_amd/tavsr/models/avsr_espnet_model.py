@@ -11,6 +11,7 @@ from typing import List, Tuple, Union
 import torch
 
 from .. import functional_av as FA
+from .. import ops
 from ..ctc.ctc import CTC
 from .espnet_model import ErrorCalculator, ESPnetASRModel
 
@@ -83,6 +84,7 @@ class ESPnetAVSRModel(ESPnetASRModel):
                 == text_lengths.shape[0]), (audio.shape, audio_lengths.shape, video.shape, video_lengths.shape, text.shape,
                                             text_lengths.shape)
         batch_size = audio.shape[0]
+        ops.rng_step_begin(audio.device)
         text = text.to(torch.int64).masked_fill(text == -1, self.ignore_id)
         encoder_out, encoder_out_lens = self.encode(audio, audio_lengths, video, video_lengths)
         return self._hybrid_loss(encoder_out, encoder_out_lens, text, text_lengths, batch_size)

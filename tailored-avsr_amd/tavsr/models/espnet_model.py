@@ -142,6 +142,7 @@ class ESPnetASRModel(torch.nn.Module):
         assert speech.shape[0] == speech_lengths.shape[0] == text.shape[0] == text_lengths.shape[0], (
             speech.shape, speech_lengths.shape, text.shape, text_lengths.shape)
         batch_size = speech.shape[0]
+        ops.rng_step_begin(speech.device)    # fresh dropout masks for this step (a kernel: captured graphs replay it)
         text = text.to(torch.int64).masked_fill(text == -1, self.ignore_id)
         encoder_out, encoder_out_lens = self.encode(speech, speech_lengths)
         return self._hybrid_loss(encoder_out, encoder_out_lens, text, text_lengths, batch_size)

@@ -599,3 +599,46 @@ def copy2d(src, dst):
     check(lib().tavsr_copy2d(ptr(src), C.c_int64(src.stride(0)), ptr(dst), C.c_int64(dst.stride(0)), C.c_int64(src.shape[0]),
                              C.c_int64(src.shape[1]), stream()), "tavsr_copy2d")
     return dst
+
+
+# ---------------------------------------------------------------------------------------------- dropout
+# The generator state is ONE uint64 per device, resident in HBM; ``rng_step_begin`` advances it with a kernel (so a
+# captured step graph draws new masks at every replay) and rewinds the per-step site counter, which hands every dropout
+# call of a step its own, reproducible counter range.  A dropout call returns the token (p, offset) that regenerates its
+# mask in the backward pass.
+_RNG = {}
+_SITE = [0]
+
+
+def rng_state(device=None) -> torch.Tensor:
+    dev = torch.cuda.current_device() if device is None or device.index is None else device.index
+    t = _RNG.get(dev)
+    if t is None:
+        t = _RNG[dev] = torch.full((1,), 0x5EED5EED, dtype=torch.int64, device=f"cuda:{dev}")
+    return t
+
+
+def manual_seed(seed: int, device=None):
+    rng_state(device).fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    _SITE[0] = 0
+
+
+def rng_step_begin(device=None):
+    """call once per training step (before the forward pass)."""
+    check(lib().tavsr_rng_advance(ptr(rng_state(device)), stream()), "tavsr_rng_advance")
+    _SITE[0] = 0
+
+
+def dropout(x, p: float, out=None, token=None):
+    """y = dropout(x, p); returns (y, token).  ``token`` from a previous call reproduces that call's mask."""
+    require_cuda(x)
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    n = x.numel()
+    if token is None:
+        token = (float(p), _SITE[0])
+        _SITE[0] += (n + 3) // 4 * 4
+    check(lib().tavsr_dropout(ptr(x), ptr(out), C.c_int64(n), C.c_float(token[0]), ptr(rng_state(x.device)),
+                              C.c_uint64(token[1]), stream()), "tavsr_dropout")
+    return out, token

@@ -1,0 +1,119 @@
+"""GPU: train-mode dropout.  The reference's torch RNG stream cannot be reproduced, so the checks are (1) the kernel's
+statistics and its regenerate-the-mask contract, (2) determinism in the seed, fresh masks per step, (3) at model level a
+directional finite-difference test of the hand-written backward under a FROZEN mask, and that the expected train loss
+matches the no-dropout loss (inverted dropout is unbiased to first order)."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import asr_conf
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dropout_kernel_statistics_and_mask_regeneration():
+    from tavsr import ops
+    ops.manual_seed(123)
+    x = torch.randn(1 << 20, device="cuda") + 3.0
+    for p in (0.1, 0.5):
+        y, tok = ops.dropout(x, p)
+        kept = (y != 0)
+        assert abs(float(kept.float().mean()) - (1 - p)) < 3e-3          # 1M Bernoulli draws: sigma ~ 5e-4
+        assert torch.allclose(y[kept], x[kept] / (1 - p), rtol=1e-6)
+        g = torch.randn_like(x)
+        gy, _ = ops.dropout(g, p, token=tok)                              # backward: the SAME mask
+        assert torch.equal(gy != 0, kept)
+        y2, _ = ops.dropout(x, p)                                         # next site: a different mask
+        assert float(((y2 != 0) ^ kept).float().mean()) > 0.05
+    # lag-1 independence of neighbouring elements
+    k = (ops.dropout(x, 0.5)[0] != 0).float()
+    assert abs(float((k[1:] * k[:-1]).mean()) - 0.25) < 3e-3
+    # odd length / unaligned tail
+    z = torch.randn(1001, device="cuda")
+    yz, tz = ops.dropout(z, 0.3)
+    assert yz.shape == z.shape and 0.6 < float((yz != 0).float().mean()) < 0.8
+
+
+def test_dropout_seed_determinism_and_step_advance():
+    from tavsr import ops
+    x = torch.ones(4096, device="cuda")
+    ops.manual_seed(7)
+    a, _ = ops.dropout(x, 0.25)
+    ops.manual_seed(7)
+    b, _ = ops.dropout(x, 0.25)
+    assert torch.equal(a, b)
+    ops.manual_seed(7)
+    ops.rng_step_begin()              # the per-step advance changes every mask, the site counter restarts
+    c, _ = ops.dropout(x, 0.25)
+    assert not torch.equal(a, c)
+    ops.manual_seed(8)
+    d, _ = ops.dropout(x, 0.25)
+    assert not torch.equal(a, d)
+
+
+def _model(nb=2, dropout=0.1):
+    from oracle.model import fill_parameters_
+    from tavsr.tasks.asr import ASRTask
+    conf = asr_conf(num_blocks=nb, dec_blocks=1, dropout=dropout)
+    model = ASRTask.build_model(argparse.Namespace(**conf))
+    fill_parameters_(model, seed=17)
+    return model.cuda()
+
+
+def _batch():
+    from oracle.model import synth
+    text = synth((3, 8), seed=9, kind="int", lo=1, hi=40)
+    text[1, 5:] = -1
+    return (synth((3, 120, 80), seed=8).cuda(), torch.tensor([120, 100, 64]).cuda(), text.cuda(), torch.tensor([8, 5, 8]).cuda())
+
+
+def test_model_backward_under_frozen_masks():
+    """d loss / d theta along the gradient direction by central differences, masks frozen by re-seeding."""
+    from tavsr import ops
+    model = _model().train()
+    batch = _batch()
+
+    def loss_at():
+        ops.manual_seed(2024)
+        return model(*batch)[0]
+
+    model.zero_grad()
+    loss_at().backward()
+    params = [p for p in model.parameters() if p.grad is not None]
+    grads = [p.grad.detach().clone() for p in params]
+    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+    assert np.isfinite(gnorm) and gnorm > 0
+    eps = 2e-3 / gnorm * float(torch.sqrt(sum((p.double() ** 2).sum() for p in params)))   # ~0.2 % relative step
+    with torch.no_grad():
+        for p, g in zip(params, grads):
+            p.add_(g, alpha=eps / gnorm)
+        lp = float(loss_at())
+        for p, g in zip(params, grads):
+            p.add_(g, alpha=-2 * eps / gnorm)
+        lm = float(loss_at())
+        for p, g in zip(params, grads):
+            p.add_(g, alpha=eps / gnorm)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - gnorm) / gnorm < 3e-2, (fd, gnorm)
+
+
+def test_train_loss_is_stochastic_and_close_to_eval_loss():
+    from tavsr import ops
+    model = _model(dropout=0.1)
+    batch = _batch()
+    ref = float(_model(dropout=0.0).train()(*batch)[0])
+    model.train()
+    ops.manual_seed(1)
+    losses = []
+    with torch.no_grad():
+        for _ in range(16):
+            losses.append(float(model(*batch)[0]))      # forward() advances the generator: new masks each call
+    assert len(set(round(l, 4) for l in losses)) > 8
+    assert abs(np.mean(losses) - ref) / ref < 0.15, (np.mean(losses), ref)
+    model.eval()
+    model.ctc.dropout_rate = 0.0                         # (the reference's CTC dropout is active in eval too: Q7)
+    with torch.no_grad():
+        e1, e2 = float(model(*batch)[0]), float(model(*batch)[0])
+    assert e1 == e2
