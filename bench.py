@@ -50,18 +50,16 @@ DROPOUT = True   # --no-dropout sets every rate to 0 (parity-style run)
 
 
 def make_conf():
-    """The recipe as shipped: train mode WITH the reference's dropout rates (0.1 everywhere) for the audio-only headline,
-    on the GPU and in the CPU baseline alike.  The AV recipe's dropout sites (tailored layer, fusion, AV embedding) are
-    not wired to the dropout kernel yet: its rates are 0 on both sides."""
+    """The recipe as shipped: train mode WITH the reference's dropout rates (0.1 everywhere), on the GPU and in the
+    CPU baseline alike."""
     if WORKLOAD == "avsr":
         conf = yaml.safe_load(open(os.path.join(PKG, "configs", "avsr_tailored_transformer_ctc_english.yaml")))
         conf.update(acoustic_input_size=N_MEL, visual_input_size=None, specaug=None)
-        _zero_dropout(conf)
     else:
         conf = yaml.safe_load(open(os.path.join(PKG, "configs", "asr_branchformer_transformer_ctc_english.yaml")))
         conf.update(input_size=N_MEL, specaug=None)
-        if not DROPOUT:
-            _zero_dropout(conf)
+    if not DROPOUT:
+        _zero_dropout(conf)
     return conf
 
 
@@ -217,7 +215,7 @@ def main():
                    "BASELINE configs[1]: audio-only 12-layer Branchformer d=256 + Conv2dSubsampling + CTC + "
                    "6L Transformer decoder, batch 32 x 400 mel frames x 80 per GPU, text length 40, fwd+bwd",
                    "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
-                   "dropout": 0.1 if (DROPOUT and WORKLOAD == "asr") else 0.0,
+                   "dropout": 0.1 if DROPOUT else 0.0,
                    "launch": "eager" if graph is None else "hipGraph replay (whole fwd+bwd)"},
         "model_tflops_per_s": round(value * 3 * GFLOP_PER_UTT_FWD[WORKLOAD] / 1e3, 2),
         "frac_of_fp32_mfma_peak_whole_step": round(value * 3 * GFLOP_PER_UTT_FWD[WORKLOAD] / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),

@@ -41,15 +41,12 @@ class AdaptiveAudioVisualFusion(torch.nn.Module):
     def forward(self, audio_pad, audio_masks, video_pad, video_masks, cache=None):
         if cache is not None:
             raise NotImplementedError("cache is not None, which is not tested")
-        if self.training and self.dropout_rate > 0:
-            raise NotImplementedError("train-mode dropout is not implemented on the HIP path yet: set "
-                                      "audiovisual_fusion_conf:dropout_rate:0.0 or call .eval()")
         if self.training and self.acoustic_branch_drop_rate > 0:
             raise NotImplementedError("acoustic_branch_drop_rate > 0 is not used by the shipped configs")
         alens = audio_masks.squeeze(1).sum(-1).to(torch.int64)
         vlens = video_masks.squeeze(1).sum(-1).to(torch.int64)
         sd = dict(self.named_parameters())
-        cfg = dict(act=self.audiovisual_layer.activation)
+        cfg = dict(act=self.audiovisual_layer.activation, p=self.dropout_rate if self.training else 0.0)
         out = FA.FusionFn.apply(audio_pad, video_pad, alens, vlens, cfg, *[sd[n] for n in FA.FUSION_PARAM_NAMES])
         w = cfg["_last_w"]       # (B,2) -> the reference's (B,1,1) tensors (:186-191)
         self.acoustic_weight, self.visual_weight = w[:, 0].view(-1, 1, 1), w[:, 1].view(-1, 1, 1)

@@ -10,6 +10,7 @@ import torch
 
 from .. import functional as F_
 from .. import functional_av as FA
+from .. import ops
 from ..layers import RelPositionalEncoding, make_pad_mask
 
 
@@ -61,23 +62,23 @@ class DefaultEmbeddingLayerForAVSR(torch.nn.Module):
     def output_size(self) -> int:
         return self._output_size
 
-    def _check_dropout(self):
-        if self.training and (self.dropout_rate > 0 or self.positional_dropout_rate > 0):
-            raise NotImplementedError("train-mode dropout is not implemented on the HIP path yet: set the embed_conf "
-                                      "dropout rates to 0.0 or call .eval()")
-
     def apply_embed_layer(self, xs_pad: torch.Tensor, ilens: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        self._check_dropout()
         masks = (~make_pad_mask(ilens, xs_pad.size(1))[:, None, :]).to(xs_pad.device)
         if isinstance(self.embed, Conv2dSubsamplingWOPosEnc):
             xs_pad, masks = self.embed(xs_pad, masks)
         else:
             lin, ln = self.embed[0], self.embed[1]
             xs_pad = F_.LayerNormFn.apply(F_.LinearFn.apply(xs_pad, lin.weight, lin.bias, 1.0), ln.weight, ln.bias, ln.eps)
+            if self.training and self.dropout_rate > 0:          # Sequential(Linear, LayerNorm, Dropout)  (default.py:57-62)
+                xs_pad = F_.DropoutFn.apply(xs_pad, self.dropout_rate)
         return xs_pad, masks
 
     def apply_pos_enc(self, xs_pad: torch.Tensor):
-        return FA.ScaleFn.apply(xs_pad, self.pos_enc.xscale), self.pos_enc.pos_emb(xs_pad.size(1), xs_pad.device)
+        x, pos = FA.ScaleFn.apply(xs_pad, self.pos_enc.xscale), self.pos_enc.pos_emb(xs_pad.size(1), xs_pad.device)
+        if self.training and self.positional_dropout_rate > 0:   # RelPositionalEncoding: dropout(x), dropout(pos_emb)
+            x = F_.DropoutFn.apply(x, self.positional_dropout_rate)
+            pos = ops.dropout(pos, self.positional_dropout_rate)[0]
+        return x, pos
 
     def forward(self, xs_pad, ilens) -> Tuple[Union[Tuple, torch.Tensor], torch.Tensor]:
         xs_pad, masks = self.apply_embed_layer(xs_pad, ilens)

@@ -69,9 +69,6 @@ class TailoredEncoderLayer(torch.nn.Module):
             raise NotImplementedError("the HIP path implements the rel_pos form: inputs are (x, pos_emb) tuples")
         audio, apos = audio_input
         video, vpos = video_input
-        if self._active_dropout():
-            raise NotImplementedError("train-mode dropout is not implemented on the HIP path yet: set the *_dropout_rate "
-                                      "entries to 0.0 or call .eval()")
         coeff = 1.0
         if self.training and self.stochastic_depth_rate > 0:
             skip = torch.rand(1).item() < self.stochastic_depth_rate
@@ -87,8 +84,11 @@ class TailoredEncoderLayer(torch.nn.Module):
             vlens = video_masks.squeeze(1).sum(-1).to(torch.int64)
         act = self.feed_forward.activation
         ua, uv = self.acoustic_attn is not None, self.visual_attn is not None
-        cfg_a = dict(use_attn=ua, heads=self.acoustic_attn.h if ua else 1, ffn_act=act, coeff=coeff)
-        cfg_v = dict(use_attn=uv, heads=self.visual_attn.h if uv else 1, ffn_act=act, coeff=coeff)
+        pd = self.dropout_rate if self.training else 0.0
+        cfg_a = dict(use_attn=ua, heads=self.acoustic_attn.h if ua else 1, ffn_act=act, coeff=coeff, p=pd,
+                     p_att=self.acoustic_attn.dropout_rate if (ua and self.training) else 0.0)
+        cfg_v = dict(use_attn=uv, heads=self.visual_attn.h if uv else 1, ffn_act=act, coeff=coeff, p=pd,
+                     p_att=self.visual_attn.dropout_rate if (uv and self.training) else 0.0)
         audio = FA.TailoredStreamFn.apply(audio, apos, alens, cfg_a, *self._stream_params("acoustic", ua))
         video = FA.TailoredStreamFn.apply(video, vpos, vlens, cfg_v, *self._stream_params("visual", uv))
         return (audio, apos), audio_masks, (video, vpos), video_masks

@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .functional import EPS_ESPNET, _FFN, _SelfAttnCore
+from .functional import EPS_ESPNET, _FFN, _SelfAttnCore, _drop_, _drop_bwd, _drop_bwd_
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch.nn.BatchNorm defaults (conv3d_resnet18.py:57, resnet.py:39,68,84)
 
@@ -269,11 +269,12 @@ class TailoredStreamFn(torch.autograd.Function):
         H = cfg["heads"]
         dk = D // H
         act, coeff = cfg["ffn_act"], cfg.get("coeff", 1.0)
+        pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)      # dropout rates (0 in eval)
         x2d = x.contiguous().view(M, D)
         sv = {}
         x1, sv["ffm"] = _FFN.fwd(x2d, p["norm_ff_macaron.weight"], p["norm_ff_macaron.bias"],
                                  p["feed_forward_macaron.w_1.weight"], p["feed_forward_macaron.w_1.bias"],
-                                 p["feed_forward_macaron.w_2.weight"], p["feed_forward_macaron.w_2.bias"], act, 0.5)
+                                 p["feed_forward_macaron.w_2.weight"], p["feed_forward_macaron.w_2.bias"], act, 0.5, p=pd)
         if cfg["use_attn"]:
             n, mean, rstd = ops.layernorm_fwd(x1, p["norm_mha.weight"], p["norm_mha.bias"], EPS_ESPNET)
             qkv = ops.empty(M, 3 * D, like=x2d)
@@ -282,9 +283,16 @@ class TailoredStreamFn(torch.autograd.Function):
             ops.linear(n, p["attn.linear_v.weight"], p["attn.linear_v.bias"], out=qkv, out_off=2 * D, ldc=3 * D)
             pp = ops.linear(pos_emb.reshape(-1, D), p["attn.linear_pos.weight"])
             qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
-            cx, attn, _ = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False, qv=qv, p=pp)
-            x2 = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], alpha=coeff, res=x1)
-            sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn)
+            cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
+                                                qv=qv, p=pp, p_att=pa)
+            t_br = None
+            if pd > 0.0:                       # residual + coeff * dropout(att)  (encoder_layer.py:196,243)
+                t = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"])
+                t_br = _drop_(t, pd)
+                x2 = ops.axpby(x1, t, 1.0, coeff)
+            else:
+                x2 = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], alpha=coeff, res=x1)
+            sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
         else:
             n, mean, rstd = ops.layernorm_fwd(x1, p["norm_cgmlp.weight"], p["norm_cgmlp.bias"], EPS_ESPNET)
             g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
@@ -292,10 +300,17 @@ class TailoredStreamFn(torch.autograd.Function):
             gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET)
             cw = p["cgmlp.csgu.conv.weight"]
             u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T)
-            x2 = ops.linear(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], alpha=coeff, res=x1)
-            sv["br"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv)
+            t_u = _drop_(u, pd)                # csgu: dropout(x_r * x_g)
+            t_br = None
+            if pd > 0.0:                       # residual + coeff * dropout(cgmlp)  (encoder_layer.py:208,256)
+                t = ops.linear(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"])
+                t_br = _drop_(t, pd)
+                x2 = ops.axpby(x1, t, 1.0, coeff)
+            else:
+                x2 = ops.linear(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], alpha=coeff, res=x1)
+            sv["br"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
         x3, sv["ff"] = _FFN.fwd(x2, p["norm_ff.weight"], p["norm_ff.bias"], p["feed_forward.w_1.weight"],
-                                p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"], p["feed_forward.w_2.bias"], act, 0.5)
+                                p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"], p["feed_forward.w_2.bias"], act, 0.5, p=pd)
         y, fmean, frstd = ops.layernorm_fwd(x3, p["norm_final.weight"], p["norm_final.bias"], EPS_ESPNET)
         sv["final"] = (x3, fmean, frstd)
         sv["x1"] = x1
@@ -320,13 +335,14 @@ class TailoredStreamFn(torch.autograd.Function):
             G[n_] = g
         x1 = sv["x1"]
         if cfg["use_attn"]:
-            mean, rstd, n, qkv, pp, qu, qv, cx, attn = sv["br"]
-            G["attn.linear_out.weight"], G["attn.linear_out.bias"] = ops.linear_dw(dx2, cx, alpha=coeff, bias_grad=True)
-            dcx = ops.linear_dx(dx2, p["attn.linear_out.weight"], alpha=coeff)
+            mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br = sv["br"]
+            dbr = _drop_bwd(dx2, t_br)
+            G["attn.linear_out.weight"], G["attn.linear_out.bias"] = ops.linear_dw(dbr, cx, alpha=coeff, bias_grad=True)
+            dcx = ops.linear_dx(dbr, p["attn.linear_out.weight"], alpha=coeff)
             dqkv = torch.empty_like(qkv)
             dqu = ops.empty(M, D, like=dx2)
             dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
-                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp)
+                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
             G["attn.pos_bias_u"] = ops.colsum(dqu).view_as(p["attn.pos_bias_u"])
             G["attn.pos_bias_v"] = ops.colsum(dqv).view_as(p["attn.pos_bias_v"])
             ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
@@ -339,10 +355,11 @@ class TailoredStreamFn(torch.autograd.Function):
             ops.linear_dx(dqkv[:, 2 * D:], p["attn.linear_v.weight"], res=dn, out=dn)
             dx1, G["norm_mha.weight"], G["norm_mha.bias"] = ops.layernorm_bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2)
         else:
-            mean, rstd, n, g, z, gn, gmean, grstd, u, conv = sv["br"]
+            mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br = sv["br"]
             Cn = g.shape[1] // 2
-            G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = ops.linear_dw(dx2, u, alpha=coeff, bias_grad=True)
-            du = ops.linear_dx(dx2, p["cgmlp.channel_proj2.weight"], alpha=coeff)
+            dbr = _drop_bwd(dx2, t_br)
+            G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = ops.linear_dw(dbr, u, alpha=coeff, bias_grad=True)
+            du = _drop_bwd_(ops.linear_dx(dbr, p["cgmlp.channel_proj2.weight"], alpha=coeff), t_u)
             dg = torch.empty_like(g)
             cw = p["cgmlp.csgu.conv.weight"]
             dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
@@ -385,16 +402,17 @@ class FusionFn(torch.autograd.Function):
         score, pooled, wts = ops.merge_pool_fwd(a2, v2, alens, mp, B, T, lens2=vlens)
         m = ops.merge_combine(a2, v2, wts, B, T)
         h, z = ops.linear(m, w1, b1, act=cfg["act"], save_z=True)
+        t_in = _drop_(h, cfg.get("p", 0.0))       # PositionwiseFeedForward's inner dropout (the fusion has no outer one)
         y2 = ops.linear(h, w2, b2)
         out, mean, rstd = ops.layernorm_fwd(y2, lw, lb, EPS_ESPNET)
-        ctx.sv = (a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd)
+        ctx.sv = (a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd, t_in)
         ctx.P, ctx.cfg, ctx.lens, ctx.dims = P, cfg, (alens, vlens), (B, T, D)
         cfg["_last_w"] = wts
         return out.view(B, T, -1)
 
     @staticmethod
     def backward(ctx, dy):
-        a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd = ctx.sv
+        a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd, t_in = ctx.sv
         P, cfg = ctx.P, ctx.cfg
         B, T, D = ctx.dims
         alens, vlens = ctx.lens
@@ -402,7 +420,10 @@ class FusionFn(torch.autograd.Function):
         w1, b1, w2, b2, lw, lb = P[8:14]
         dy2, glw, glb = ops.layernorm_bwd(dy.contiguous().view(B * T, -1), y2, mean, rstd, lw)
         gw2, gb2 = ops.linear_dw(dy2, h, bias_grad=True)
-        dz = ops.linear_dx(dy2, w2, DZ=z, dact=cfg["act"])
+        if t_in is None:
+            dz = ops.linear_dx(dy2, w2, DZ=z, dact=cfg["act"])
+        else:
+            dz = ops.act_bwd_(_drop_bwd_(ops.linear_dx(dy2, w2), t_in), z, cfg["act"])
         gw1, gb1 = ops.linear_dw(dz, m, bias_grad=True)
         dm = ops.linear_dx(dz, w1)
         da, dv, mg = ops.merge_bwd(dm, a2, v2, alens, mp, score, pooled, wts, B, T, lens2=vlens)

@@ -117,3 +117,51 @@ def test_train_loss_is_stochastic_and_close_to_eval_loss():
     with torch.no_grad():
         e1, e2 = float(model(*batch)[0]), float(model(*batch)[0])
     assert e1 == e2
+
+
+def test_avsr_model_backward_under_frozen_masks():
+    """the AV path's dropout sites (tailored streams, fusion FFN, AV embeddings): same directional check"""
+    from helpers import AVSR_YAML, avsr_conf
+    from oracle.model import fill_parameters_, synth
+    from tavsr import ops
+    from tavsr.tasks.avsr import AVSRTask
+    import yaml
+    conf = avsr_conf(AVSR_YAML, num_blocks=2, dec_blocks=1)
+    ref = yaml.safe_load(open(AVSR_YAML))            # put the recipe's dropout rates back
+    for k in ("acoustic_embed_conf", "visual_embed_conf", "audiovisual_fusion_conf", "decoder_conf", "ctc_conf"):
+        for kk, v in ref[k].items():
+            if kk.endswith("dropout_rate"):
+                conf[k][kk] = v
+    for kk in ("dropout_rate", "positional_dropout_rate", "attention_dropout_rate"):
+        conf["encoder_conf"][kk] = ref["encoder_conf"][kk]
+    model = AVSRTask.build_model(argparse.Namespace(**conf))
+    fill_parameters_(model, seed=23)
+    model = model.cuda().train()
+    text = synth((2, 6), seed=9, kind="int", lo=1, hi=40)
+    batch = (synth((2, 40, 80), seed=1).cuda(), torch.tensor([40, 32]).cuda(), synth((2, 9, 88, 88), seed=2).cuda(),
+             torch.tensor([9, 8]).cuda(), text.cuda(), torch.tensor([6, 4]).cuda())
+    bufs0 = {k: v.clone() for k, v in model.named_buffers()}
+
+    def loss_at():
+        ops.manual_seed(99)
+        with torch.no_grad():                        # BatchNorm running buffers must not drift between evaluations
+            for k, v in model.named_buffers():
+                v.copy_(bufs0[k])
+        return model(*batch)[0]
+
+    model.zero_grad()
+    loss_at().backward()
+    params = [p for p in model.parameters() if p.grad is not None]
+    grads = [p.grad.detach().clone() for p in params]
+    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+    pnorm = float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in params)))
+    eps = 1e-3 * pnorm / gnorm
+    with torch.no_grad():
+        for p, g in zip(params, grads):
+            p.add_(g, alpha=eps / gnorm)
+        lp = float(loss_at())
+        for p, g in zip(params, grads):
+            p.add_(g, alpha=-2 * eps / gnorm)
+        lm = float(loss_at())
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - gnorm) / gnorm < 5e-2, (fd, gnorm)
