@@ -74,6 +74,12 @@ int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);
  * problems (weight gradients, K = B*T) are split so the whole chip works; each slice stores an fp32 slab and a
  * second kernel sums the slabs in slice order (deterministic) and applies the epilogue. */
 int64_t tavsr_gemm_ws(const tavsr_gemm_desc* desc);
+/* up to 12 independent, unbatched problems of ONE layout (a_kmajor, b_kmajor) in one launch, no K split: the weight
+ * gradients of a layer (16-128 output tiles each) fill the chip together.  Every problem must satisfy the fast
+ * kernel's conditions (16-byte aligned operands and leading dimensions, K %% 32 == 0, row-contiguous operands with a
+ * row count %% 4 == 0); otherwise TAVSR_EUNSUPPORTED is returned, nothing is launched and the caller issues the
+ * problems one by one with tavsr_gemm. */
+int tavsr_gemm_grouped(const tavsr_gemm_desc* descs, int32_t n, tavsr_stream_t stream);
 /* tuning/bench entry: force tile configuration cfg (see kCfgs in csrc/gemm.hip; BK = 32) and a K split (<= 1: none; needs ws/sync large enough) instead of the planner's choice. */
 int tavsr_gemm_tune(const tavsr_gemm_desc* desc, int32_t cfg, int32_t nsplit, tavsr_stream_t stream);
 

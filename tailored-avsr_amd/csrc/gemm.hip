@@ -195,10 +195,9 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int row, 
 // Common tail of both kernels: lane pairs complete the row sums, then either the split-K slab store or the fused
 // epilogue.  Accumulator layout: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <int TM, int TN>
-__device__ __forceinline__ void finish_tile(const GemmArgs& args, f32x16 (&acc)[TM][TN], float (&asum)[TM],
-                                            bool want_rowsum, int m0, int n0, int wm, int wn, int lr, int lk, int z1,
-                                            int z2, int64_t coff) {
-  const tavsr_gemm_desc& d = args.d;
+__device__ __forceinline__ void finish_tile(const tavsr_gemm_desc& d, int nsplit, f32x16 (&acc)[TM][TN],
+                                            float (&asum)[TM], bool want_rowsum, int m0, int n0, int wm, int wn, int lr,
+                                            int lk, int z1, int z2, int64_t coff) {
   if (want_rowsum) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] += __shfl_xor(asum[i], 32, 64);
@@ -206,11 +205,11 @@ __device__ __forceinline__ void finish_tile(const GemmArgs& args, f32x16 (&acc)[
 
   // ---- split-K: every slice stores its raw accumulators (and row sums) to its slab; splitk_epilogue_kernel
   //      sums the slabs in slice order (deterministic) and applies the epilogue
-  if (args.nsplit > 1) {
+  if (nsplit > 1) {
     const int64_t mn = (int64_t)d.M * d.N;
     const int nbatch = gridDim.y;
     float* slab = d.ws + ((int64_t)blockIdx.z * nbatch + blockIdx.y) * mn;
-    float* rsum0 = d.ws + (int64_t)args.nsplit * nbatch * mn;       // [nsplit][M] (only when nbatch == 1)
+    float* rsum0 = d.ws + (int64_t)nsplit * nbatch * mn;       // [nsplit][M] (only when nbatch == 1)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * TN * 32 + j * 32 + lr;
@@ -420,7 +419,7 @@ void gemm_kernel(const GemmArgs args) {
   if (fast) run_loop(std::true_type{});
   else run_loop(std::false_type{});
 
-  finish_tile<TM, TN>(args, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
+  finish_tile<TM, TN>(d, args.nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
 }
 
 // ---------------------------------------------------------------------------------------------- LDS-DMA kernel
@@ -482,10 +481,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM>
-__global__ __launch_bounds__(WM* WN * 64, MINW)
-void gemm_glds_kernel(const GemmArgs args) {
-  const tavsr_gemm_desc& d = args.d;
+// One output tile of one problem: `bid` is the (already XCD-remapped) linear tile index inside the problem.
+template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM>
+__device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid) {
   constexpr int BK = 32, NG = BK / 8;
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -502,13 +500,8 @@ void gemm_glds_kernel(const GemmArgs args) {
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lk = lane >> 5;
 
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int m0 = (bid / args.tiles_n) * BM;
-  const int n0 = (bid % args.tiles_n) * BN;
+  const int m0 = (bid / tiles_n) * BM;
+  const int n0 = (bid % tiles_n) * BN;
   const int z1 = blockIdx.y / d.nb2, z2 = blockIdx.y % d.nb2;
   const float* A = d.A + z1 * d.sA1 + z2 * d.sA2;
   const float* B = d.B + z1 * d.sB1 + z2 * d.sB2;
@@ -526,8 +519,8 @@ void gemm_glds_kernel(const GemmArgs args) {
   for (int i = 0; i < TM; ++i) asum[i] = 0.f;
   const bool want_rowsum = d.a_rowsum != nullptr && n0 == 0 && wn == 0;
 
-  const int kbeg = blockIdx.z * args.kchunk;
-  const int kend = min(d.K, kbeg + args.kchunk);
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(d.K, kbeg + kchunk);
   const int nk = (kend - kbeg) / BK;          // whole K-steps only (host guarantees it)
   const int64_t kstepA = AK ? (int64_t)BK * d.lda : BK;
   const int64_t kstepB = BKM ? (int64_t)BK * d.ldb : BK;
@@ -592,7 +585,41 @@ void gemm_glds_kernel(const GemmArgs args) {
     compute(st);
     st = st + 1 == S ? 0 : st + 1;
   }
-  finish_tile<TM, TN>(args, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
+  finish_tile<TM, TN>(d, nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
+}
+
+// XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (its L2): give them neighbouring tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM>
+__global__ __launch_bounds__(WM* WN * 64, MINW)
+void gemm_glds_kernel(const GemmArgs args) {
+  glds_tile<BM, BN, WM, WN, S, AK, BKM>(args.d, args.kchunk, args.nsplit, args.tiles_n, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Grouped launch: up to kMaxGroup independent problems of one layout share ONE grid (tile ranges by prefix sums).
+// The weight gradients of a layer have 16-128 tiles each: alone they need a K split (slabs + a second launch);
+// together they fill the chip without one.
+constexpr int kMaxGroup = 12;
+struct GroupArgs {
+  tavsr_gemm_desc d[kMaxGroup];
+  int tile_start[kMaxGroup + 1];
+  int tiles_n[kMaxGroup];
+  int n;
+};
+
+template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM>
+__global__ __launch_bounds__(WM* WN * 64, MINW)
+void gemm_glds_grouped_kernel(const GroupArgs g) {
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < g.n && bid >= g.tile_start[i]) pi = i;
+  glds_tile<BM, BN, WM, WN, S, AK, BKM>(g.d[pi], g.d[pi].K, 1, g.tiles_n[pi], bid - g.tile_start[pi]);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -752,6 +779,40 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
 
 extern "C" int tavsr_gemm(const tavsr_gemm_desc* dp, tavsr_stream_t stream) {
   return tavsr::run(dp, -1, 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tavsr_gemm_grouped(const tavsr_gemm_desc* descs, int32_t n, tavsr_stream_t stream) {
+  using namespace tavsr;
+  TAVSR_REQUIRE(descs != nullptr && n >= 1 && n <= kMaxGroup, TAVSR_EINVAL, "tavsr_gemm_grouped: 1..%d problems", kMaxGroup);
+  GroupArgs g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    tavsr_gemm_desc d = descs[i];
+    if (d.nb1 <= 0) d.nb1 = 1;
+    if (d.nb2 <= 0) d.nb2 = 1;
+    TAVSR_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, TAVSR_EINVAL, "tavsr_gemm_grouped: bad problem %d", i);
+    TAVSR_REQUIRE(d.a_kmajor == descs[0].a_kmajor && d.b_kmajor == descs[0].b_kmajor, TAVSR_EUNSUPPORTED,
+                  "tavsr_gemm_grouped: all problems must share one layout");
+    TAVSR_REQUIRE(d.nb1 * d.nb2 == 1, TAVSR_EUNSUPPORTED, "tavsr_gemm_grouped: unbatched problems only");
+    const bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0;
+    TAVSR_REQUIRE(glds_ok(d, vec), TAVSR_EUNSUPPORTED,
+                  "tavsr_gemm_grouped: problem %d needs the predicated kernel (alignment / K %% 32 / rows %% 4)", i);
+    if (d.R == nullptr) { d.ldr = 0; d.sR1 = d.sR2 = 0; }
+    g.d[i] = d;
+    g.tile_start[i] = total;
+    g.tiles_n[i] = cdiv(d.N, 64);
+    total += cdiv(d.M, 64) * g.tiles_n[i];
+  }
+  for (int i = n; i <= kMaxGroup; ++i) g.tile_start[i] = total;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = launch_layout(descs[0], [&](auto ak, auto bk) {
+    hipLaunchKernelGGL((gemm_glds_grouped_kernel<64, 64, 2, 2, 3, 3, decltype(ak)::value, decltype(bk)::value>), dim3(total),
+                       dim3(256), 0, s, g);
+    TAVSR_LAUNCH_CHECK();
+    return (int)TAVSR_OK;
+  });
+  return rc;
 }
 
 extern "C" int tavsr_gemm_tune(const tavsr_gemm_desc* dp, int32_t cfg, int32_t nsplit, tavsr_stream_t stream) {

@@ -63,16 +63,18 @@ class _FFN:
         return y, (x, mean, rstd, n, z, h, t_in, t_out)
 
     @staticmethod
-    def bwd(dy, saved, ln_w, w1, w2, act, scale):
-        """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2)."""
+    def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None):
+        """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2).  ``grp`` (ops.WgradGroup)
+        defers the two weight gradients to the caller's grouped launch."""
         x, mean, rstd, n, z, h, t_in, t_out = saved
+        wgrad = ops.linear_dw if grp is None else grp.add
         dyd = _drop_bwd(dy, t_out)
-        gw2, gb2 = ops.linear_dw(dyd, h, alpha=scale, bias_grad=True)
+        gw2, gb2 = wgrad(dyd, h, alpha=scale, bias_grad=True)
         if t_in is None:
             dz = ops.linear_dx(dyd, w2, alpha=scale, DZ=z, dact=act)
         else:
             dz = ops.act_bwd_(_drop_bwd_(ops.linear_dx(dyd, w2, alpha=scale), t_in), z, act)
-        gw1, gb1 = ops.linear_dw(dz, n, bias_grad=True)
+        gw1, gb1 = wgrad(dz, n, bias_grad=True)
         dn = ops.linear_dx(dz, w1)
         dx, gln_w, gln_b = ops.layernorm_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
         return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2)
@@ -300,12 +302,13 @@ class BranchformerLayerFn(torch.autograd.Function):
         def put(name, g, like=None):
             G[_I[name]] = g if like is None else g.view_as(like)
 
+        grp = ops.WgradGroup()     # every weight gradient of the layer in one grouped launch (flushed at the end)
         dy2 = dy.contiguous().view(M, D)
         x3, fmean, frstd = sv["final"]
         dx3, g1, g2 = ops.layernorm_bwd(dy2, x3, fmean, frstd, p("norm_final.weight"))
         put("norm_final.weight", g1); put("norm_final.bias", g2)
         dx2, gs = _FFN.bwd(dx3, sv["ff"], p("norm_ff.weight"), p("feed_forward.w_1.weight"),
-                           p("feed_forward.w_2.weight"), act, 0.5)
+                           p("feed_forward.w_2.weight"), act, 0.5, grp=grp)
         for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                           "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
             put(n_, g)
@@ -317,7 +320,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             _drop_bwd_(dm, t_m) if t_m is not None else None
         else:
             dxd = _drop_bwd(dx2, t_m)
-            gw_, gb_ = ops.linear_dw(dxd, m, alpha=coeff, bias_grad=True)
+            gw_, gb_ = grp.add(dxd, m, alpha=coeff, bias_grad=True)
             put("merge_proj.weight", gw_); put("merge_proj.bias", gb_)
             dm = ops.linear_dx(dxd, p("merge_proj.weight"), alpha=coeff)
         xa, xm = sv["xa"], sv["xm"]
@@ -348,7 +351,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             Cn = g.shape[1] // 2
             if t_xm is not None:
                 dxm = _drop_bwd(dxm.contiguous(), t_xm)
-            gw_, gb_ = ops.linear_dw(dxm, u, bias_grad=True)
+            gw_, gb_ = grp.add(dxm, u, bias_grad=True)
             put("cgmlp.channel_proj2.weight", gw_); put("cgmlp.channel_proj2.bias", gb_)
             du = _drop_bwd_(ops.linear_dx(dxm, p("cgmlp.channel_proj2.weight")), t_u)
             dg = torch.empty_like(g)
@@ -358,7 +361,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             _, g1, g2 = ops.layernorm_bwd(dgn, g[:, Cn:], gmean, grstd, p("cgmlp.csgu.norm.weight"), dx=dg[:, Cn:])
             put("cgmlp.csgu.norm.weight", g1); put("cgmlp.csgu.norm.bias", g2)
             ops.act_bwd_(dg, z, "gelu")
-            gw_, gb_ = ops.linear_dw(dg, n, bias_grad=True)
+            gw_, gb_ = grp.add(dg, n, bias_grad=True)
             put("cgmlp.channel_proj1.0.weight", gw_); put("cgmlp.channel_proj1.0.bias", gb_)
             dn = ops.linear_dx(dg, p("cgmlp.channel_proj1.0.weight"))
             dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1)
@@ -367,7 +370,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa = sv["attn"]
             if t_xa is not None:
                 dxa = _drop_bwd(dxa.contiguous(), t_xa)
-            gw_, gb_ = ops.linear_dw(dxa, cx, bias_grad=True)
+            gw_, gb_ = grp.add(dxa, cx, bias_grad=True)
             put("attn.linear_out.weight", gw_); put("attn.linear_out.bias", gb_)
             dcx = ops.linear_dx(dxa, p("attn.linear_out.weight"))
             dqkv = torch.empty_like(qkv)
@@ -378,17 +381,17 @@ class BranchformerLayerFn(torch.autograd.Function):
             put("attn.pos_bias_v", ops.colsum(dqv), like=p("attn.pos_bias_v"))
             ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
             pe2d = ctx.pos_emb.reshape(-1, D)
-            put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))
-            gw, gb = ops.linear_dw(dqkv, n, bias_grad=True)  # [3D, D], [3D]
-            put("attn.linear_q.weight", gw[:D]); put("attn.linear_k.weight", gw[D:2 * D]); put("attn.linear_v.weight", gw[2 * D:])
-            put("attn.linear_q.bias", gb[:D]); put("attn.linear_k.bias", gb[D:2 * D]); put("attn.linear_v.bias", gb[2 * D:])
+            put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))   # K = 2T-1: not a multiple of 32, stays alone
+            for j, nm in enumerate(("q", "k", "v")):   # three problems with their own outputs (no sliced gradients)
+                gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
+                put(f"attn.linear_{nm}.weight", gw_); put(f"attn.linear_{nm}.bias", gb_)
             dn = ops.linear_dx(dqkv[:, :D], p("attn.linear_q.weight"))
             ops.linear_dx(dqkv[:, D:2 * D], p("attn.linear_k.weight"), res=dn, out=dn)
             ops.linear_dx(dqkv[:, 2 * D:], p("attn.linear_v.weight"), res=dn, out=dn)
             dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mha.weight"), dx_add=dx1)
             put("norm_mha.weight", g1); put("norm_mha.bias", g2)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p("norm_ff_macaron.weight"), p("feed_forward_macaron.w_1.weight"),
-                          p("feed_forward_macaron.w_2.weight"), act, 0.5)
+                          p("feed_forward_macaron.w_2.weight"), act, 0.5, grp=grp)
         for n_, g in zip(("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight",
                           "feed_forward_macaron.w_1.bias", "feed_forward_macaron.w_2.weight",
                           "feed_forward_macaron.w_2.bias"), gs):
@@ -396,6 +399,7 @@ class BranchformerLayerFn(torch.autograd.Function):
         for i, prm in enumerate(P):
             if prm is None:
                 G[i] = None
+        grp.flush()
         ctx.sv = None
         ops.join_side()
         return (dx.view(B, T, D), None, None, None, *G)
@@ -636,26 +640,27 @@ class TransformerDecoderFn(torch.autograd.Function):
                 G[base + _DI[n]] = g
 
             s = ctx.saved[li]
+            grp = ops.WgradGroup()
             dx2, gs = _FFN.bwd(dx, s["ff"], p("norm3.weight"), p("feed_forward.w_1.weight"), p("feed_forward.w_2.weight"),
-                               "relu", 1.0)
+                               "relu", 1.0, grp=grp)
             for n_, g in zip(("norm3.weight", "norm3.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                               "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
                 put(n_, g)
             # --- source attention
             x1, m2, r2, n2, q2, kv, cx2, attn2, tk_a2, tk_r2 = s["src"]
             dt2 = _drop_bwd(dx2, tk_r2)
-            gw_, gb_ = ops.linear_dw(dt2, cx2, bias_grad=True)
+            gw_, gb_ = grp.add(dt2, cx2, bias_grad=True)
             put("src_attn.linear_out.weight", gw_); put("src_attn.linear_out.bias", gb_)
             dcx2 = ops.linear_dx(dt2, p("src_attn.linear_out.weight"))
             dq2 = ops.empty(M, D, like=dl)
             dkv = torch.empty_like(kv)
             _SelfAttnCore.bwd(dcx2, attn2, q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, dq2, D, 0, dkv, 2 * D, 0, dkv, 2 * D, D,
                               B, L, T, H, dk, tok=tk_a2)
-            gw_, gb_ = ops.linear_dw(dq2, n2, bias_grad=True)
+            gw_, gb_ = grp.add(dq2, n2, bias_grad=True)
             put("src_attn.linear_q.weight", gw_); put("src_attn.linear_q.bias", gb_)
-            gkv_w, gkv_b = ops.linear_dw(dkv, mem2, bias_grad=True)   # [2D, D], [2D]
-            put("src_attn.linear_k.weight", gkv_w[:D]); put("src_attn.linear_v.weight", gkv_w[D:])
-            put("src_attn.linear_k.bias", gkv_b[:D]); put("src_attn.linear_v.bias", gkv_b[D:])
+            for j, nm in enumerate(("k", "v")):
+                gw_, gb_ = grp.add(dkv[:, j * D:(j + 1) * D], mem2, bias_grad=True)
+                put(f"src_attn.linear_{nm}.weight", gw_); put(f"src_attn.linear_{nm}.bias", gb_)
             if dmem is None:
                 dmem = ops.linear_dx(dkv[:, :D], p("src_attn.linear_k.weight"))
             else:
@@ -667,20 +672,21 @@ class TransformerDecoderFn(torch.autograd.Function):
             # --- self attention
             x0, m1, r1, n1, qkv, cx, attn, tk_a, tk_r = s["self"]
             dt1 = _drop_bwd(dx1, tk_r)
-            gw_, gb_ = ops.linear_dw(dt1, cx, bias_grad=True)
+            gw_, gb_ = grp.add(dt1, cx, bias_grad=True)
             put("self_attn.linear_out.weight", gw_); put("self_attn.linear_out.bias", gb_)
             dcx = ops.linear_dx(dt1, p("self_attn.linear_out.weight"))
             dqkv = torch.empty_like(qkv)
             _SelfAttnCore.bwd(dcx, attn, qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqkv, 3 * D, 0, dqkv, 3 * D, D,
                               dqkv, 3 * D, 2 * D, B, L, L, H, dk, tok=tk_a)
-            gw, gb = ops.linear_dw(dqkv, n1, bias_grad=True)
-            put("self_attn.linear_q.weight", gw[:D]); put("self_attn.linear_k.weight", gw[D:2 * D]); put("self_attn.linear_v.weight", gw[2 * D:])
-            put("self_attn.linear_q.bias", gb[:D]); put("self_attn.linear_k.bias", gb[D:2 * D]); put("self_attn.linear_v.bias", gb[2 * D:])
+            for j, nm in enumerate(("q", "k", "v")):
+                gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n1, bias_grad=True)
+                put(f"self_attn.linear_{nm}.weight", gw_); put(f"self_attn.linear_{nm}.bias", gb_)
             dn1 = ops.linear_dx(dqkv[:, :D], p("self_attn.linear_q.weight"))
             ops.linear_dx(dqkv[:, D:2 * D], p("self_attn.linear_k.weight"), res=dn1, out=dn1)
             ops.linear_dx(dqkv[:, 2 * D:], p("self_attn.linear_v.weight"), res=dn1, out=dn1)
             dx, g1, g2 = ops.layernorm_bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1)
             put("norm1.weight", g1); put("norm1.bias", g2)
+            grp.flush()
         _drop_bwd_(dx, ctx.t_pos)
         G[0] = ops.embed_bwd(ctx.ys_in.contiguous(), dx, math.sqrt(D), P[0].shape[0])
         ctx.saved = None

@@ -326,10 +326,11 @@ class TailoredStreamFn(torch.autograd.Function):
         dk = D // H
         act, coeff = cfg["ffn_act"], cfg.get("coeff", 1.0)
         G = {}
+        grp = ops.WgradGroup()
         x3, fmean, frstd = sv["final"]
         dx3, G["norm_final.weight"], G["norm_final.bias"] = ops.layernorm_bwd(dy.contiguous().view(M, D), x3, fmean, frstd,
                                                                              p["norm_final.weight"])
-        dx2, gs = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act, 0.5)
+        dx2, gs = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act, 0.5, grp=grp)
         for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                           "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
             G[n_] = g
@@ -337,7 +338,7 @@ class TailoredStreamFn(torch.autograd.Function):
         if cfg["use_attn"]:
             mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br = sv["br"]
             dbr = _drop_bwd(dx2, t_br)
-            G["attn.linear_out.weight"], G["attn.linear_out.bias"] = ops.linear_dw(dbr, cx, alpha=coeff, bias_grad=True)
+            G["attn.linear_out.weight"], G["attn.linear_out.bias"] = grp.add(dbr, cx, alpha=coeff, bias_grad=True)
             dcx = ops.linear_dx(dbr, p["attn.linear_out.weight"], alpha=coeff)
             dqkv = torch.empty_like(qkv)
             dqu = ops.empty(M, D, like=dx2)
@@ -347,9 +348,8 @@ class TailoredStreamFn(torch.autograd.Function):
             G["attn.pos_bias_v"] = ops.colsum(dqv).view_as(p["attn.pos_bias_v"])
             ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
             G["attn.linear_pos.weight"] = ops.linear_dw(dp, ctx.pos_emb.reshape(-1, D))
-            gw, gb = ops.linear_dw(dqkv, n, bias_grad=True)
-            G["attn.linear_q.weight"], G["attn.linear_k.weight"], G["attn.linear_v.weight"] = gw[:D], gw[D:2 * D], gw[2 * D:]
-            G["attn.linear_q.bias"], G["attn.linear_k.bias"], G["attn.linear_v.bias"] = gb[:D], gb[D:2 * D], gb[2 * D:]
+            for j, nm in enumerate(("q", "k", "v")):
+                G[f"attn.linear_{nm}.weight"], G[f"attn.linear_{nm}.bias"] = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
             dn = ops.linear_dx(dqkv[:, :D], p["attn.linear_q.weight"])
             ops.linear_dx(dqkv[:, D:2 * D], p["attn.linear_k.weight"], res=dn, out=dn)
             ops.linear_dx(dqkv[:, 2 * D:], p["attn.linear_v.weight"], res=dn, out=dn)
@@ -358,7 +358,7 @@ class TailoredStreamFn(torch.autograd.Function):
             mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br = sv["br"]
             Cn = g.shape[1] // 2
             dbr = _drop_bwd(dx2, t_br)
-            G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = ops.linear_dw(dbr, u, alpha=coeff, bias_grad=True)
+            G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = grp.add(dbr, u, alpha=coeff, bias_grad=True)
             du = _drop_bwd_(ops.linear_dx(dbr, p["cgmlp.channel_proj2.weight"], alpha=coeff), t_u)
             dg = torch.empty_like(g)
             cw = p["cgmlp.csgu.conv.weight"]
@@ -367,14 +367,15 @@ class TailoredStreamFn(torch.autograd.Function):
             _, G["cgmlp.csgu.norm.weight"], G["cgmlp.csgu.norm.bias"] = ops.layernorm_bwd(
                 dgn, g[:, Cn:], gmean, grstd, p["cgmlp.csgu.norm.weight"], dx=dg[:, Cn:])
             ops.act_bwd_(dg, z, "gelu")
-            G["cgmlp.channel_proj1.0.weight"], G["cgmlp.channel_proj1.0.bias"] = ops.linear_dw(dg, n, bias_grad=True)
+            G["cgmlp.channel_proj1.0.weight"], G["cgmlp.channel_proj1.0.bias"] = grp.add(dg, n, bias_grad=True)
             dn = ops.linear_dx(dg, p["cgmlp.channel_proj1.0.weight"])
             dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"] = ops.layernorm_bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p["norm_ff_macaron.weight"], p["feed_forward_macaron.w_1.weight"],
-                          p["feed_forward_macaron.w_2.weight"], act, 0.5)
+                          p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp)
         for n_, g in zip(("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight",
                           "feed_forward_macaron.w_1.bias", "feed_forward_macaron.w_2.weight", "feed_forward_macaron.w_2.bias"), gs):
             G[n_] = g
+        grp.flush()
         ctx.sv = None
         ops.join_side()
         return (dx.view(B, T, D), None, None, None, *[G[n] for n in ctx.names])

@@ -206,6 +206,63 @@ def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False):
     return (out, gb) if bias_grad else out
 
 
+class WgradGroup:
+    """Deferred weight gradients of one backward node: ``add`` allocates the outputs and records the problem,
+    ``flush`` computes all of them with ONE grouped launch (tavsr_gemm_grouped; chunks of 12).  The operands must stay
+    unchanged between add and flush (the group keeps them alive).  Problems the fast kernel cannot take (unaligned,
+    K % 32 != 0) fall back to individual tavsr_gemm calls - same results either way."""
+
+    MAX = 12
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, dy, x, *, alpha=1.0, bias_grad=False):
+        M, N = dy.shape
+        K = x.shape[1]
+        require_cuda(dy, x)
+        out = empty(N, K, like=dy)
+        gb = empty(N, like=dy) if bias_grad else None
+        self.items.append((dy, x, float(alpha), out, gb))
+        return (out, gb) if bias_grad else out
+
+    @staticmethod
+    def _desc(d, dy, x, alpha, out, gb):
+        M, N = dy.shape
+        K = x.shape[1]
+        d.M, d.N, d.K = N, K, M
+        d.a_kmajor, d.b_kmajor = 1, 1
+        d.A, d.lda = dy.data_ptr(), dy.stride(0)
+        d.B, d.ldb = x.data_ptr(), x.stride(0)
+        d.C, d.ldc = out.data_ptr(), out.stride(0)
+        d.nb1 = d.nb2 = 1
+        d.alpha = alpha
+        d.a_rowsum = None if gb is None else gb.data_ptr()
+
+    def flush(self):
+        items, self.items = self.items, []
+        for i in range(0, len(items), self.MAX):
+            chunk = items[i: i + self.MAX]
+            arr = (GemmDesc * len(chunk))()
+            for d, it in zip(arr, chunk):
+                self._desc(d, *it)
+            if PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = lib().tavsr_gemm_grouped(arr, len(chunk), stream()) if len(chunk) > 1 else -3
+            if rc == -3:      # TAVSR_EUNSUPPORTED (or a single problem): one by one through the planner
+                for dy, x, alpha, out, gb in chunk:
+                    gemm(dy.shape[1], x.shape[1], dy.shape[0], dy, dy.stride(0), x, x.stride(0), out, out.stride(0),
+                         a_kmajor=True, b_kmajor=True, alpha=alpha, a_rowsum=gb)
+                continue
+            check(rc, "tavsr_gemm_grouped")
+            if PROFILE is not None:
+                e1.record()
+                fl = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _, _ in chunk)
+                key = "gemm_kernel<TN>" + (f" grouped x{len(chunk)}" if PROFILE.by_shape else "")
+                PROFILE.records.append((key, fl, e0, e1))
+
+
 def colsum(x, *, scale=1.0, out=None, accumulate=False):
     M, N = x.shape
     require_cuda(x)
