@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 from tavsr import ops  # noqa: E402
 
-CFG_NAMES = ["128x128s3", "128x128w8s3", "128x64s3", "64x128s3", "64x64s3", "64x64s4", "128x64s4"]
+CFG_NAMES = ["128x128s3", "128x128w8s3", "128x64s3", "64x128s3", "64x64s3", "64x64s4", "128x64s4", "64x64kw2"]
 # (mode, M, N, K, nb)
 SHAPES = [
     ("NT", 3168, 2048, 256, 1), ("NT", 3168, 256, 2048, 1), ("NT", 3168, 256, 256, 1), ("NT", 3168, 768, 256, 1),
@@ -22,7 +22,7 @@ SHAPES = [
     ("TN", 768, 256, 3168, 1), ("TN", 256, 2304, 60192, 1), ("TN", 256, 4864, 3168, 1), ("TN", 256, 256, 1312, 1),
     ("NT", 99, 99, 64, 128), ("NT", 99, 197, 64, 128), ("NN", 99, 64, 99, 128), ("TN", 99, 64, 99, 128),
 ]
-SPLITS = [1, 2, 3, 4, 6, 9]
+SPLITS = [1, 2, 3, 4, 6]
 
 
 def run(mode, M, N, K, nb, force, A, B, Cout, reps):

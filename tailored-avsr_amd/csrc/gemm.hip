@@ -482,10 +482,25 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // One output tile of one problem: `bid` is the (already XCD-remapped) linear tile index inside the problem.
-template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM>
+#ifdef TAVSR_GEMM_TRACE
+// Debug build only (scripts/gpu_trace.sh): per-workgroup timestamps of the LDS-DMA kernel's phases.
+constexpr int kTraceMax = 1 << 15;
+__device__ unsigned long long g_trace[kTraceMax][6];
+__device__ unsigned int g_trace_n;
+#define TAVSR_TRACE_DECL unsigned long long tr_t[4], tr_c[4]; tr_t[0] = wall_clock64(); tr_t[1] = tr_t[0]; tr_c[1] = tr_c[2] = 0;
+#define TAVSR_TRACE_AT(i) { tr_t[i] = wall_clock64(); tr_c[i] = __builtin_readcyclecounter(); }
+#else
+#define TAVSR_TRACE_DECL
+#define TAVSR_TRACE_AT(i)
+#endif
+
+// KW > 1: the k-groups of every K-step are dealt to KW wave sets (intra-block K split, summed through LDS at the end):
+// a lone 64x64 tile on a CU then runs 2 waves per SIMD with half the dependent-MFMA chain per K-step each.
+template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM, int KW = 1>
 __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid) {
   constexpr int BK = 32, NG = BK / 8;
-  constexpr int NT = WM * WN * 64;
+  static_assert(NG % KW == 0, "k-groups must divide over the wave sets");
+  constexpr int NT = WM * WN * KW * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   using LA = GLoader<BM, AK, NT>;
   using LB = GLoader<BN, BKM, NT>;
@@ -497,9 +512,11 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int kw = wave / (WM * WN), w2 = wave % (WM * WN);
+  const int wm = w2 / WN, wn = w2 % WN;
   const int lr = lane & 31, lk = lane >> 5;
 
+  TAVSR_TRACE_DECL
   const int m0 = (bid / tiles_n) * BM;
   const int n0 = (bid % tiles_n) * BN;
   const int z1 = blockIdx.y / d.nb2, z2 = blockIdx.y % d.nb2;
@@ -539,17 +556,17 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
     const float* b_s = a_s + ASZ;
     float af[2][TM][4], bf[2][TN][4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) read_frag_g<BM, AK>(a_s, arow + i * 32, 0, lk, af[0][i]);
+    for (int i = 0; i < TM; ++i) read_frag_g<BM, AK>(a_s, arow + i * 32, kw, lk, af[0][i]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) read_frag_g<BN, BKM>(b_s, brow + j * 32, 0, lk, bf[0][j]);
+    for (int j = 0; j < TN; ++j) read_frag_g<BN, BKM>(b_s, brow + j * 32, kw, lk, bf[0][j]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int c = g & 1;
-      if (g + 1 < NG) {
+    for (int q = 0; q < NG / KW; ++q) {      // this wave set's k-groups: kw, kw + KW, ...
+      const int c = q & 1;
+      if (q + 1 < NG / KW) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) read_frag_g<BM, AK>(a_s, arow + i * 32, g + 1, lk, af[c ^ 1][i]);
+        for (int i = 0; i < TM; ++i) read_frag_g<BM, AK>(a_s, arow + i * 32, kw + (q + 1) * KW, lk, af[c ^ 1][i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) read_frag_g<BN, BKM>(b_s, brow + j * 32, g + 1, lk, bf[c ^ 1][j]);
+        for (int j = 0; j < TN; ++j) read_frag_g<BN, BKM>(b_s, brow + j * 32, kw + (q + 1) * KW, lk, bf[c ^ 1][j]);
       }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -573,6 +590,9 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
   for (; kt + S - 1 < nk; ++kt) {
     wait_vmcnt<(S - 2) * G>();
     __builtin_amdgcn_s_barrier();      // every wave's part of tile kt is in LDS; everyone left stage (kt-1) % S
+#ifdef TAVSR_GEMM_TRACE
+    if (kt == 0) TAVSR_TRACE_AT(1)
+#endif
     const int sn = st == 0 ? S - 1 : st - 1;
     issue(kt + S - 1, sn);
     compute(st);
@@ -585,7 +605,52 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
     compute(st);
     st = st + 1 == S ? 0 : st + 1;
   }
+  TAVSR_TRACE_AT(2)
+  if (KW > 1) {     // sum the wave sets' accumulators (and row sums) through LDS; set 0 runs the epilogue
+    constexpr int PER = TM * TN * 16;
+    float* red = smem;                                         // [KW-1][WM*WN][PER][64]
+    float* rsum = smem + (KW - 1) * WM * WN * PER * 64;        // [KW-1][WM*WN][TM][64]
+    static_assert(((KW - 1) * WM * WN * (PER + TM) * 64) <= S * STAGE, "reduction must fit in the staging ring");
+    __syncthreads();                                           // all LDS reads of the K loop are done
+    if (kw > 0) {
+      float* r0 = red + ((kw - 1) * WM * WN + w2) * PER * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) r0[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) rsum[(((kw - 1) * WM * WN + w2) * TM + i) * 64 + lane] = asum[i];
+    }
+    __syncthreads();
+    if (kw > 0) return;
+#pragma unroll
+    for (int s2 = 0; s2 < KW - 1; ++s2) {
+      const float* r0 = red + (s2 * WM * WN + w2) * PER * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += r0[((i * TN + j) * 16 + r) * 64];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asum[i] += rsum[((s2 * WM * WN + w2) * TM + i) * 64 + lane];
+    }
+  }
   finish_tile<TM, TN>(d, nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
+#ifdef TAVSR_GEMM_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  TAVSR_TRACE_AT(3)
+  if (tid == 0) {
+    unsigned int slot = atomicAdd(&g_trace_n, 1u);
+    if (slot < (unsigned)kTraceMax) {
+      for (int i = 0; i < 4; ++i) g_trace[slot][i] = tr_t[i];
+      g_trace[slot][4] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      g_trace[slot][5] = tr_c[2] - tr_c[1];      // shader-clock cycles of the K loop
+    }
+  }
+#endif
 }
 
 // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (its L2): give them neighbouring tiles.
@@ -594,10 +659,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM>
-__global__ __launch_bounds__(WM* WN * 64, MINW)
+template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM, int KW = 1>
+__global__ __launch_bounds__(WM* WN * KW * 64, MINW)
 void gemm_glds_kernel(const GemmArgs args) {
-  glds_tile<BM, BN, WM, WN, S, AK, BKM>(args.d, args.kchunk, args.nsplit, args.tiles_n, xcd_remap(blockIdx.x, gridDim.x));
+  glds_tile<BM, BN, WM, WN, S, AK, BKM, KW>(args.d, args.kchunk, args.nsplit, args.tiles_n, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Grouped launch: up to kMaxGroup independent problems of one layout share ONE grid (tile ranges by prefix sums).
@@ -636,6 +701,7 @@ static const Cfg kCfgs[] = {
     {64, 64, 2, 2, 3},     // 4: wave tile 32x32, 48 KB, three blocks per CU
     {64, 64, 2, 2, 4},     // 5: wave tile 32x32, four stages (three tiles in flight), two blocks per CU
     {128, 64, 2, 2, 4},    // 6: wave tile 64x32, four stages, one block per CU
+    {64, 64, 2, 2, 3},     // 7: as 4 with the K-step split over 2 wave sets (8 waves)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kFallbackCfg = 9;
@@ -661,13 +727,13 @@ static int launch_epilogue(const GemmArgs& a, hipStream_t s) {
   return TAVSR_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int S, int MINW>
+template <int BM, int BN, int WM, int WN, int S, int MINW, int KW = 1>
 static int launch_glds(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStream_t s) {
   GemmArgs a{d, kchunk, nsplit, cdiv(d.M, BM), cdiv(d.N, BN)};
   dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
   int rc = launch_layout(d, [&](auto ak, auto bk) {
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, S, MINW, decltype(ak)::value, decltype(bk)::value>), grid,
-                       dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, S, MINW, decltype(ak)::value, decltype(bk)::value, KW>), grid,
+                       dim3(WM * WN * KW * 64), 0, s, a);
     TAVSR_LAUNCH_CHECK();
     return (int)TAVSR_OK;
   });
@@ -699,6 +765,7 @@ static int launch(int cfg, const tavsr_gemm_desc& d, bool vec, int nsplit, int k
     case 4: return launch_glds<64, 64, 2, 2, 3, 3>(d, nsplit, kchunk, s);
     case 5: return launch_glds<64, 64, 2, 2, 4, 2>(d, nsplit, kchunk, s);
     case 6: return launch_glds<128, 64, 2, 2, 4, 1>(d, nsplit, kchunk, s);
+    case 7: return launch_glds<64, 64, 2, 2, 3, 4, 2>(d, nsplit, kchunk, s);
     default: return launch_fallback(d, vec, nsplit, kchunk, s);
   }
 }
@@ -833,3 +900,18 @@ extern "C" int64_t tavsr_gemm_ws(const tavsr_gemm_desc* dp) {
   Plan p = plan(d, true, glds_ok(d, vec));
   return ws_floats_for(d, p.nsplit);
 }
+
+#ifdef TAVSR_GEMM_TRACE
+// Debug build only: copy out (and reset) the per-workgroup phase timestamps. out: [max_rows][6] uint64. Returns rows.
+extern "C" int tavsr_gemm_trace_read(unsigned long long* out, int max_rows) {
+  unsigned int n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(tavsr::g_trace_n), sizeof(n)) != hipSuccess) return -1;
+  int rows = (int)(n < (unsigned)tavsr::kTraceMax ? n : tavsr::kTraceMax);
+  if (rows > max_rows) rows = max_rows;
+  if (rows > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(tavsr::g_trace), (size_t)rows * 6 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  n = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(tavsr::g_trace_n), &n, sizeof(n)) != hipSuccess) return -1;
+  return rows;
+}
+#endif

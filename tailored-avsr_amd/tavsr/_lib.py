@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtavsr_hip.so")
+# TAVSR_LIB selects another build of the same library (profiles/gemm_trace.py's instrumented one); never a fallback.
+LIB_PATH = os.environ.get("TAVSR_LIB") or os.path.join(_HERE, "lib", "libtavsr_hip.so")
 
 ACT = {None: 0, "none": 0, "relu": 1, "swish": 2, "gelu": 3}
 

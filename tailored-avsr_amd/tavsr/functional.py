@@ -204,25 +204,27 @@ class BranchformerLayerFn(torch.autograd.Function):
         two = has_attn and has_mlp
         cat = ops.empty(M, 2 * D, like=x) if merge == "concat" else None
         xa = xm = None
-        if has_attn:
-            n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mha.weight"), p("norm_mha.bias"), EPS_ESPNET)
-            qkv = ops.empty(M, 3 * D, like=x)
-            ops.linear(n, p("attn.linear_q.weight"), p("attn.linear_q.bias"), out=qkv, out_off=0, ldc=3 * D)
-            ops.linear(n, p("attn.linear_k.weight"), p("attn.linear_k.bias"), out=qkv, out_off=D, ldc=3 * D)
-            ops.linear(n, p("attn.linear_v.weight"), p("attn.linear_v.bias"), out=qkv, out_off=2 * D, ldc=3 * D)
-            pe2d = pos_emb.reshape(-1, D)
-            pp = ops.linear(pe2d, p("attn.linear_pos.weight"))
-            qu, qv = ops.add_head_bias(qkv[:, :D], p("attn.pos_bias_u").reshape(-1), p("attn.pos_bias_v").reshape(-1))
-            cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
-                                                qv=qv, p=pp, p_att=pa)
-            t_xa = None
-            if merge == "concat":
-                ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), out=cat, out_off=0, ldc=2 * D)
-                xa = cat[:, :D]
-            else:
-                xa = ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"))
-                t_xa = _drop_(xa, pd)                       # x1 = dropout(x_att)  (encoder_layer.py:212)
-            sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
+        br = ops.BranchScope(two)     # attention branch beside the cgMLP branch (joined before the merge)
+        with br:
+            if has_attn:
+                n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mha.weight"), p("norm_mha.bias"), EPS_ESPNET)
+                qkv = ops.empty(M, 3 * D, like=x)
+                ops.linear(n, p("attn.linear_q.weight"), p("attn.linear_q.bias"), out=qkv, out_off=0, ldc=3 * D)
+                ops.linear(n, p("attn.linear_k.weight"), p("attn.linear_k.bias"), out=qkv, out_off=D, ldc=3 * D)
+                ops.linear(n, p("attn.linear_v.weight"), p("attn.linear_v.bias"), out=qkv, out_off=2 * D, ldc=3 * D)
+                pe2d = pos_emb.reshape(-1, D)
+                pp = ops.linear(pe2d, p("attn.linear_pos.weight"))
+                qu, qv = ops.add_head_bias(qkv[:, :D], p("attn.pos_bias_u").reshape(-1), p("attn.pos_bias_v").reshape(-1))
+                cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
+                                                    qv=qv, p=pp, p_att=pa)
+                t_xa = None
+                if merge == "concat":
+                    ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), out=cat, out_off=0, ldc=2 * D)
+                    xa = cat[:, :D]
+                else:
+                    xa = ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"))
+                    t_xa = _drop_(xa, pd)                       # x1 = dropout(x_att)  (encoder_layer.py:212)
+                sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
         if has_mlp:
             n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mlp.weight"), p("norm_mlp.bias"), EPS_ESPNET)
             g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu",
@@ -242,6 +244,7 @@ class BranchformerLayerFn(torch.autograd.Function):
                 xm = ops.linear(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"))
                 t_xm = _drop_(xm, pd)                       # x2 = dropout(x2)  (encoder_layer.py:224)
             sv["mlp"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_xm)
+        br.join()
         t_cat = _drop_(cat, pd) if (merge == "concat" and cat is not None) else None   # both halves in one call (iid)
         wts = None
         if two and merge == "learned_ave":
@@ -346,6 +349,32 @@ class BranchformerLayerFn(torch.autograd.Function):
 
         x1 = sv["x1"]
         dx1 = dx2  # residual path; branch gradients are folded in through dx_add
+        br = ops.BranchScope(two)     # attention-branch backward beside the cgMLP-branch backward
+        dn_a = None
+        with br:
+            if has_attn:
+                a_mean, a_rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa = sv["attn"]
+                br.keep(dxa)
+                if t_xa is not None:
+                    dxa = _drop_bwd(dxa.contiguous(), t_xa)
+                gw_, gb_ = grp.add(dxa, cx, bias_grad=True)
+                put("attn.linear_out.weight", gw_); put("attn.linear_out.bias", gb_)
+                dcx = ops.linear_dx(dxa, p("attn.linear_out.weight"))
+                dqkv = torch.empty_like(qkv)
+                dqu = ops.empty(M, D, like=dy2)
+                dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
+                                            dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
+                put("attn.pos_bias_u", ops.colsum(dqu), like=p("attn.pos_bias_u"))
+                put("attn.pos_bias_v", ops.colsum(dqv), like=p("attn.pos_bias_v"))
+                ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
+                pe2d = ctx.pos_emb.reshape(-1, D)
+                put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))   # K = 2T-1: not a multiple of 32, stays alone
+                for j, nm in enumerate(("q", "k", "v")):   # three problems with their own outputs (no sliced gradients)
+                    gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
+                    put(f"attn.linear_{nm}.weight", gw_); put(f"attn.linear_{nm}.bias", gb_)
+                dn_a = ops.linear_dx(dqkv[:, :D], p("attn.linear_q.weight"))
+                ops.linear_dx(dqkv[:, D:2 * D], p("attn.linear_k.weight"), res=dn_a, out=dn_a)
+                ops.linear_dx(dqkv[:, 2 * D:], p("attn.linear_v.weight"), res=dn_a, out=dn_a)
         if has_mlp:
             mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_xm = sv["mlp"]
             Cn = g.shape[1] // 2
@@ -366,29 +395,9 @@ class BranchformerLayerFn(torch.autograd.Function):
             dn = ops.linear_dx(dg, p("cgmlp.channel_proj1.0.weight"))
             dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1)
             put("norm_mlp.weight", g1); put("norm_mlp.bias", g2)
-        if has_attn:
-            mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa = sv["attn"]
-            if t_xa is not None:
-                dxa = _drop_bwd(dxa.contiguous(), t_xa)
-            gw_, gb_ = grp.add(dxa, cx, bias_grad=True)
-            put("attn.linear_out.weight", gw_); put("attn.linear_out.bias", gb_)
-            dcx = ops.linear_dx(dxa, p("attn.linear_out.weight"))
-            dqkv = torch.empty_like(qkv)
-            dqu = ops.empty(M, D, like=dy2)
-            dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
-                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
-            put("attn.pos_bias_u", ops.colsum(dqu), like=p("attn.pos_bias_u"))
-            put("attn.pos_bias_v", ops.colsum(dqv), like=p("attn.pos_bias_v"))
-            ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
-            pe2d = ctx.pos_emb.reshape(-1, D)
-            put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))   # K = 2T-1: not a multiple of 32, stays alone
-            for j, nm in enumerate(("q", "k", "v")):   # three problems with their own outputs (no sliced gradients)
-                gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
-                put(f"attn.linear_{nm}.weight", gw_); put(f"attn.linear_{nm}.bias", gb_)
-            dn = ops.linear_dx(dqkv[:, :D], p("attn.linear_q.weight"))
-            ops.linear_dx(dqkv[:, D:2 * D], p("attn.linear_k.weight"), res=dn, out=dn)
-            ops.linear_dx(dqkv[:, 2 * D:], p("attn.linear_v.weight"), res=dn, out=dn)
-            dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mha.weight"), dx_add=dx1)
+        br.join()
+        if has_attn:     # same accumulation order into dx1 as a single stream: cgMLP branch first, then attention
+            dx1, g1, g2 = ops.layernorm_bwd(dn_a, x1, a_mean, a_rstd, p("norm_mha.weight"), dx_add=dx1)
             put("norm_mha.weight", g1); put("norm_mha.bias", g2)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p("norm_ff_macaron.weight"), p("feed_forward_macaron.w_1.weight"),
                           p("feed_forward_macaron.w_2.weight"), act, 0.5, grp=grp)

@@ -186,6 +186,48 @@ class _SideScope:
         return False
 
 
+# The two Branchformer branches (attention | cgMLP) are independent between the fork after the macaron FFN and the
+# merge: the attention branch is a chain of small latency-bound launches that fits beside the cgMLP GEMMs.
+BRANCH_SIDE_STREAM = os.environ.get("TAVSR_BRANCH_STREAM", "1") == "1"
+
+
+class BranchScope:
+    """``with BranchScope() as br: <launches>`` enqueues the body on the side stream (ordered after everything
+    already on the main stream); ``br.join()`` orders the main stream after the body.  Tensors allocated in the
+    body live in the side stream's allocator pool: they are only handed out again to a later body, which starts
+    with a wait on the main stream, so main-stream readers enqueued before that are always finished.
+    Capturable (fork/join inside one hipGraph capture)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled and BRANCH_SIDE_STREAM
+        self._keep = []
+
+    def keep(self, *tensors):
+        """Main-stream tensors whose last reader is in the body must stay allocated until the join (the main
+        stream's allocator would otherwise hand their memory out while the side stream still reads it)."""
+        self._keep.extend(tensors)
+
+    def __enter__(self):
+        self.main = torch.cuda.current_stream()
+        self.side = side_stream()
+        self.on = self.enabled and self.main != self.side
+        if self.on:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+        self._keep.clear()
+
+
 def join_side():
     """main stream waits for every weight-gradient launch issued so far on the side stream."""
     if WGRAD_SIDE_STREAM and torch.cuda.current_device() in _SIDE:
