@@ -38,6 +38,22 @@ B_PER_GPU, T_IN, N_MEL, L_TXT, T_VID, HW = 32, 400, 80, 40, 100, 88
 WORKLOAD = "asr"   # set by --workload: "asr" = BASELINE configs[1] (the headline), "avsr" = configs[2]/[3]
 
 
+def hbm_traffic(layout_key):
+    """HBM bytes per launch of the dominant GEMM family, from the committed rocprofv3 PMC pass over this same step
+    (scripts/gpu_pmc_hbm.sh -> profiles/summarize_pmc.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes).  PMC
+    counters cannot be read from inside the process, so this is the profile's number, or None if it is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    if WORKLOAD != "asr" or not os.path.exists(path):
+        return None
+    ak, bkm = {"NT": ("false", "false"), "NN": ("false", "true"), "TN": ("true", "true"), "TT": ("true", "false")}[layout_key[-3:-1]]
+    tot = calls = 0.0
+    for name, v in json.load(open(path)).items():
+        if "gemm_glds_kernel" in name and name.rstrip(">").split(", ")[-3:-1] == [ak, bkm]:
+            tot += v["calls"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"])
+            calls += v["calls"]
+    return round(tot / calls) if calls else None
+
+
 def _zero_dropout(d):
     for k, v in d.items():
         if isinstance(v, dict):
@@ -236,7 +252,7 @@ def main():
         gemm_s = sum(v["seconds"] for v in summ.values()) / nprof
         out["roofline"] = {
             "bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic(key),
             "launches_per_step": d["calls"] // nprof,
             "avg_launch_us": round(1e6 * d["seconds"] / d["calls"], 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 4),

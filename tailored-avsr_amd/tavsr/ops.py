@@ -191,6 +191,19 @@ class _SideScope:
 BRANCH_SIDE_STREAM = os.environ.get("TAVSR_BRANCH_STREAM", "1") == "1"
 
 
+_BRANCH = {}
+
+
+def branch_stream(main: torch.cuda.Stream) -> torch.cuda.Stream:
+    """the side stream that belongs to ``main`` (one per forking stream, so nested forks never share a stream with
+    their siblings)."""
+    key = (main.device.index, main.cuda_stream)
+    s = _BRANCH.get(key)
+    if s is None:
+        s = _BRANCH[key] = torch.cuda.Stream(device=main.device)
+    return s
+
+
 class BranchScope:
     """``with BranchScope() as br: <launches>`` enqueues the body on the side stream (ordered after everything
     already on the main stream); ``br.join()`` orders the main stream after the body.  Tensors allocated in the
@@ -209,9 +222,9 @@ class BranchScope:
 
     def __enter__(self):
         self.main = torch.cuda.current_stream()
-        self.side = side_stream()
-        self.on = self.enabled and self.main != self.side
+        self.on = self.enabled
         if self.on:
+            self.side = branch_stream(self.main)
             self.side.wait_stream(self.main)
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
