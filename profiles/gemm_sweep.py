@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 from tavsr import ops  # noqa: E402
 
-CFG_NAMES = ["128x128s3", "128x128w8s3", "128x64s3", "64x128s3", "64x64s3", "64x64s4", "128x64s4", "64x64kw2"]
+CFG_NAMES = ["128x128s3", "128x128w8s3", "128x64s3", "64x128s3", "64x64s3", "64x64s4", "128x64s4", "64x64kw2", "64x64s2"]
 # (mode, M, N, K, nb)
 SHAPES = [
     ("NT", 3168, 2048, 256, 1), ("NT", 3168, 256, 2048, 1), ("NT", 3168, 256, 256, 1), ("NT", 3168, 768, 256, 1),

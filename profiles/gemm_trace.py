@@ -13,9 +13,9 @@ import torch  # noqa: E402
 
 from tavsr import _lib, ops  # noqa: E402
 
-SHAPES = [("NT", 3168, 2048, 256, (4, 1)), ("NT", 3168, 256, 2048, (4, 1)), ("NT", 3168, 256, 2048, (7, 1)),
-          ("NT", 3168, 256, 2048, (4, 4)), ("NT", 3168, 256, 256, (4, 1)), ("NN", 3168, 256, 2048, (4, 1)),
-          ("NT", 60192, 256, 2304, (4, 1)), ("TN", 2048, 256, 3168, (4, 4))]
+SHAPES = [("NT", 3168, 2048, 256, (4, 1)), ("NT", 3168, 2048, 256, (8, 1)), ("NT", 3168, 256, 2048, (4, 1)),
+          ("NT", 3168, 256, 2048, (8, 4)), ("NT", 3168, 256, 2048, (8, 5)), ("NT", 3168, 256, 256, (4, 1)),
+          ("NN", 3168, 256, 2048, (4, 1)), ("TN", 2048, 256, 3168, (4, 4))]
 
 
 def pct(x):

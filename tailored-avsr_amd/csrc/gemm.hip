@@ -197,7 +197,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int row, 
 template <int TM, int TN>
 __device__ __forceinline__ void finish_tile(const tavsr_gemm_desc& d, int nsplit, f32x16 (&acc)[TM][TN],
                                             float (&asum)[TM], bool want_rowsum, int m0, int n0, int wm, int wn, int lr,
-                                            int lk, int z1, int z2, int64_t coff) {
+                                            int lk, int z1, int z2, int64_t coff, const float* bias_pre = nullptr) {
   if (want_rowsum) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] += __shfl_xor(asum[i], 32, 64);
@@ -250,7 +250,7 @@ __device__ __forceinline__ void finish_tile(const tavsr_gemm_desc& d, int nsplit
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * TN * 32 + j * 32 + lr;
     if (n >= d.N) continue;
-    const float bv = d.bias ? d.bias[n] : 0.f;
+    const float bv = bias_pre ? bias_pre[j] : (d.bias ? d.bias[n] : 0.f);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lk;
@@ -535,6 +535,12 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
 #pragma unroll
   for (int i = 0; i < TM; ++i) asum[i] = 0.f;
   const bool want_rowsum = d.a_rowsum != nullptr && n0 == 0 && wn == 0;
+  float bpre[TN];      // the epilogue's bias values, fetched under the K loop instead of in front of the stores
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + lr;
+    bpre[j] = (d.bias && nsplit == 1 && n < d.N) ? d.bias[n] : 0.f;
+  }
 
   const int kbeg = blockIdx.z * kchunk;
   const int kend = min(d.K, kbeg + kchunk);
@@ -638,7 +644,7 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       for (int i = 0; i < TM; ++i) asum[i] += rsum[((s2 * WM * WN + w2) * TM + i) * 64 + lane];
     }
   }
-  finish_tile<TM, TN>(d, nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
+  finish_tile<TM, TN>(d, nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff, bpre);
 #ifdef TAVSR_GEMM_TRACE
   __builtin_amdgcn_s_waitcnt(0);
   TAVSR_TRACE_AT(3)
@@ -702,6 +708,7 @@ static const Cfg kCfgs[] = {
     {64, 64, 2, 2, 4},     // 5: wave tile 32x32, four stages (three tiles in flight), two blocks per CU
     {128, 64, 2, 2, 4},    // 6: wave tile 64x32, four stages, one block per CU
     {64, 64, 2, 2, 3},     // 7: as 4 with the K-step split over 2 wave sets (8 waves)
+    {64, 64, 2, 2, 2},     // 8: two stages (32 KB): five blocks per CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kFallbackCfg = 9;
@@ -766,6 +773,7 @@ static int launch(int cfg, const tavsr_gemm_desc& d, bool vec, int nsplit, int k
     case 5: return launch_glds<64, 64, 2, 2, 4, 2>(d, nsplit, kchunk, s);
     case 6: return launch_glds<128, 64, 2, 2, 4, 1>(d, nsplit, kchunk, s);
     case 7: return launch_glds<64, 64, 2, 2, 3, 4, 2>(d, nsplit, kchunk, s);
+    case 8: return launch_glds<64, 64, 2, 2, 2, 5>(d, nsplit, kchunk, s);
     default: return launch_fallback(d, vec, nsplit, kchunk, s);
   }
 }
@@ -787,8 +795,12 @@ static bool glds_ok(const tavsr_gemm_desc& d, bool vec) {
 // more in slab traffic than they gain in occupancy.
 static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
   const long nbatch = (long)d.nb1 * d.nb2;
-  Plan p{fast ? 4 : kFallbackCfg, 1, d.K};
+  Plan p{kFallbackCfg, 1, d.K};
   const long tiles = (long)cdiv(d.M, 64) * cdiv(d.N, 64) * nbatch;
+  // tile variant by block count (r01_gemm_sweep_v4): at most one block per CU -> the K-step split over two wave sets
+  // (two waves per SIMD); otherwise two LDS stages (32 KB, five blocks per CU cover each other's epilogues)
+  auto variant = [&](long blocks) { return !fast ? kFallbackCfg : (blocks <= 256 ? 7 : 8); };
+  p.cfg = variant(tiles);
   if (!allow_split || tiles >= 384 || d.K < 512) return p;
   if (d.K <= 1024 && tiles >= 150) return p;
   long want = std::min<long>((448 + tiles / 2) / tiles, d.K / 256);
@@ -796,6 +808,7 @@ static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
   p.kchunk = cdiv(cdiv(d.K, want), 32) * 32;
   p.nsplit = cdiv(d.K, p.kchunk);
   if (p.nsplit < 2) p = Plan{p.cfg, 1, d.K};
+  p.cfg = variant(tiles * p.nsplit);
   return p;
 }
 
@@ -874,7 +887,7 @@ extern "C" int tavsr_gemm_grouped(const tavsr_gemm_desc* descs, int32_t n, tavsr
   for (int i = n; i <= kMaxGroup; ++i) g.tile_start[i] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = launch_layout(descs[0], [&](auto ak, auto bk) {
-    hipLaunchKernelGGL((gemm_glds_grouped_kernel<64, 64, 2, 2, 3, 3, decltype(ak)::value, decltype(bk)::value>), dim3(total),
+    hipLaunchKernelGGL((gemm_glds_grouped_kernel<64, 64, 2, 2, 2, 5, decltype(ak)::value, decltype(bk)::value>), dim3(total),
                        dim3(256), 0, s, g);
     TAVSR_LAUNCH_CHECK();
     return (int)TAVSR_OK;

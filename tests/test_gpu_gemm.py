@@ -168,7 +168,7 @@ def test_gemm_fused_bias_grad(M, N, K):
     assert (gb.double() - ref_b).abs().max() / ref_b.abs().max() < 5e-6
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
 def test_gemm_every_tile_config(cfg, mode):
     """each tile configuration of the planner's table, forced, incl. ragged edges and a forced K split"""
