@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace tavsr {
@@ -797,9 +798,11 @@ static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
   const long nbatch = (long)d.nb1 * d.nb2;
   Plan p{kFallbackCfg, 1, d.K};
   const long tiles = (long)cdiv(d.M, 64) * cdiv(d.N, 64) * nbatch;
-  // tile variant by block count (r01_gemm_sweep_v4): at most one block per CU -> the K-step split over two wave sets
-  // (two waves per SIMD); otherwise two LDS stages (32 KB, five blocks per CU cover each other's epilogues)
-  auto variant = [&](long blocks) { return !fast ? kFallbackCfg : (blocks <= 256 ? 7 : 8); };
+  // tile variant: two LDS stages (32 KB, five blocks per CU cover each other's epilogues).  The K-step-split variant
+  // (cfg 7) wins isolated one-block-per-CU launches by 5-8 % but loses inside the two-stream step (end-to-end A/B).
+  // TAVSR_GEMM_CFG=<id> overrides the choice (tuning aid).
+  static const int forced = [] { const char* e = getenv("TAVSR_GEMM_CFG"); return e ? atoi(e) : -1; }();
+  auto variant = [&](long blocks) { (void)blocks; return !fast ? kFallbackCfg : forced >= 0 ? forced : 8; };
   p.cfg = variant(tiles);
   if (!allow_split || tiles >= 384 || d.K < 512) return p;
   if (d.K <= 1024 && tiles >= 150) return p;
