@@ -366,6 +366,8 @@ class AVSRModelOracle(nn.Module):
         self.acoustic_frontend, self.visual_frontend = acoustic_frontend, visual_frontend
         self.acoustic_embed, self.visual_embed = acoustic_embed, visual_embed
         self.encoder, self.audiovisual_fusion = encoder, audiovisual_fusion
+        if getattr(self.encoder, "interctc_use_conditioning", False):                  # avsr_espnet_model.py:119-124
+            self.encoder.conditioning_layer = nn.Linear(vocab_size, self.encoder.output_size())
         self.decoder = decoder if ctc_weight < 1.0 else None
         self.criterion_att = L.LabelSmoothingLoss(vocab_size, ignore_id, lsm_weight, length_normalized_loss)
         self.error_calculator = (L.ErrorCalculator(token_list, sym_space, sym_blank, report_cer, report_wer)
@@ -410,8 +412,9 @@ class AVSRModelOracle(nn.Module):
         text[text == -1] = self.ignore_id
         text = text[:, : text_lengths.max()]
         enc, enc_lens = self.encode(audio, audio_lengths, video, video_lengths)
+        inter = None
         if isinstance(enc, tuple):
-            enc = enc[0]
+            enc, inter = enc
         stats: Dict[str, object] = {}
         loss_ctc = loss_att = None
         if self.ctc_weight != 0.0:
@@ -420,6 +423,13 @@ class AVSRModelOracle(nn.Module):
             if not self.training and self.error_calculator is not None:
                 cer_ctc = self.error_calculator(self.ctc.argmax(enc).data.cpu(), text.cpu(), is_ctc=True)
             stats["loss_ctc"], stats["cer_ctc"] = loss_ctc.detach(), cer_ctc
+        if self.interctc_weight != 0.0 and inter is not None:                          # avsr_espnet_model.py:271-315
+            li = 0.0
+            for idx, o in inter:
+                l = self.ctc(o, enc_lens, text, text_lengths)
+                stats[f"loss_interctc_layer{idx}"] = l.detach()
+                li = li + l
+            loss_ctc = (1 - self.interctc_weight) * loss_ctc + self.interctc_weight * li / len(inter)
         acc = cer = wer = None
         if self.ctc_weight != 1.0:
             ys_in, ys_out = L.add_sos_eos(text, self.sos, self.eos, self.ignore_id)

@@ -397,6 +397,69 @@ def gen_avsr_models():
     _gen_avsr_model("av_model_conventional_1L", AVSR_CONV_YAML, 1, 111)
 
 
+def gen_interctc():
+    """Intermediate CTC with self-conditioning: the reference's own encoder loops (encoder.py:378-401,
+    tailored/encoder.py:270-318) and loss mix (espnet_model.py:260-304 == avsr_espnet_model.py:271-315)."""
+    from src.tasks.asr import ASRTask
+    from src.tasks.avsr import AVSRTask
+
+    conf = asr_conf(num_blocks=4, dec_blocks=1, interctc_layer_idx=[1, 3], interctc_use_conditioning=True)
+    conf["model_conf"]["interctc_weight"] = 0.3
+    conf["token_list"] = TOKENS
+    model = ASRTask.build_model(argparse.Namespace(**copy.deepcopy(conf)))
+    fill_parameters_(model, seed=301)
+    B, Tin, Lmax = 3, 120, 10
+    speech = synth((B, Tin, 80), seed=302)
+    slens, tlens = torch.tensor([120, 96, 72]), torch.tensor([10, 6, 8])
+    text = synth((B, Lmax), seed=303, kind="int", lo=1, hi=39)
+    for i, l in enumerate(tlens):
+        text[i, l:] = -1
+    model.train()
+    loss_t, stats_t, _ = model(speech.clone(), slens, text.clone(), tlens)
+    loss_t.backward()
+    params = dict(model.named_parameters())
+    gnorm = {n: float(p.grad.norm()) for n, p in params.items() if p.grad is not None}
+    pick = ["encoder.conditioning_layer.weight", "encoder.conditioning_layer.bias", "ctc.ctc_lo.weight", "ctc.ctc_lo.bias",
+            "encoder.encoders.0.feed_forward.w_1.weight", "encoder.encoders.3.attn.linear_q.weight", "encoder.after_norm.weight"]
+    grads = {"g_" + n: compact(params[n].grad) for n in pick}
+    model.eval()
+    with torch.no_grad():
+        loss_e, stats_e, _ = model(speech.clone(), slens, text.clone(), tlens)
+        enc, olens = model.encode(speech.clone(), slens)
+    _save("asr_model_interctc_4L", B=B, Tin=Tin, slens=_np(slens), tlens=_np(tlens), text=_np(text),
+          loss_train=_np(loss_t), loss_ctc_train=_np(stats_t["loss_ctc"]), loss_ic1=_np(stats_t["loss_interctc_layer1"]),
+          loss_ic3=_np(stats_t["loss_interctc_layer3"]), loss_eval=_np(loss_e), enc=_np(enc[0]), inter1=_np(enc[1][0][1]),
+          inter3=_np(enc[1][1][1]), olens=_np(olens),
+          gnorm_keys=np.array(list(gnorm.keys())), gnorm_vals=np.array(list(gnorm.values()), dtype=np.float64),
+          keys=np.array(sorted(model.state_dict().keys())), **grads)
+
+    for tag, avcond in (("av", True), ("sep", False)):
+        conf = avsr_conf(AVSR_YAML, num_blocks=3, dec_blocks=1, interctc_layer_idx=[2], interctc_use_conditioning=True,
+                         audiovisual_interctc_conditioning=avcond)
+        conf["model_conf"]["interctc_weight"] = 0.25
+        conf["token_list"] = TOKENS
+        model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf)))
+        fill_parameters_(model, seed=311)
+        B, Ta, Tv, Lmax = 2, 40, 9, 6
+        audio, video = synth((B, Ta, 80), seed=312), synth((B, Tv, 88, 88), seed=313)
+        alens, vlens, tlens = torch.tensor([40, 32]), torch.tensor([9, 8]), torch.tensor([6, 4])
+        text = synth((B, Lmax), seed=314, kind="int", lo=1, hi=39)
+        for i, l in enumerate(tlens):
+            text[i, l:] = -1
+        model.train()
+        loss_t, stats_t, _ = model(audio.clone(), alens, video.clone(), vlens, text.clone(), tlens)
+        loss_t.backward()
+        params = dict(model.named_parameters())
+        gnorm = {n: float(p.grad.norm()) for n, p in params.items() if p.grad is not None}
+        pick = ["encoder.conditioning_layer.weight", "ctc.ctc_lo.weight", "encoder.modality_encoding.weight",
+                "audiovisual_fusion.audiovisual_layer.w_1.weight"]
+        grads = {"g_" + n: compact(params[n].grad) for n in pick}
+        _save(f"av_model_interctc_{tag}_3L", B=B, Ta=Ta, Tv=Tv, alens=_np(alens), vlens=_np(vlens), tlens=_np(tlens), text=_np(text),
+              loss_train=_np(loss_t), loss_ctc_train=_np(stats_t["loss_ctc"]), loss_ic2=_np(stats_t["loss_interctc_layer2"]),
+              gnorm_keys=np.array(list(gnorm.keys())), gnorm_vals=np.array(list(gnorm.values()), dtype=np.float64),
+              keys=np.array(sorted(model.state_dict().keys())), **grads)
+
+
 def gen_noam_adam():
     """src/schedulers/noam.py (imported as it is: pure torch): Noam rates and the parameters after 12 Adam steps on
     seeded gradients, incl. the reference loop's accumulate-then-step cadence (avsr_main.py:36-54)."""
@@ -427,6 +490,9 @@ def main():
     if "--optim-only" in sys.argv:
         gen_noam_adam()
         return
+    if "--interctc-only" in sys.argv:
+        gen_interctc()
+        return
     if "--av-only" in sys.argv:
         gen_visual_frontend()
         gen_av_embed()
@@ -442,6 +508,7 @@ def main():
     gen_av_embed()
     gen_tailored()
     gen_avsr_models()
+    gen_interctc()
     gen_noam_adam()
 
 

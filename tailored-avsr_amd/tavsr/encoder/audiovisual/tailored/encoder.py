@@ -72,18 +72,32 @@ class TailoredEncoder(torch.nn.Module):
     def forward(self, audio_pad, audio_masks, video_pad, video_masks, prev_states=None, ctc=None, audiovisual_fusion=None):
         if not (isinstance(audio_pad, tuple) and isinstance(video_pad, tuple)):
             raise NotImplementedError("the HIP path implements the rel_pos form: inputs are (x, pos_emb) tuples")
-        if len(self.interctc_layer_idx) > 0:
-            raise NotImplementedError("intermediate CTC is not used by the shipped AVSR recipes (interctc_weight: 0.0)")
         x, pos = audio_pad
         audio_pad = (FA.AddRowFn.apply(x, self.modality_encoding.weight[0]), pos)
         x, pos = video_pad
         video_pad = (FA.AddRowFn.apply(x, self.modality_encoding.weight[1]), pos)
         alens = audio_masks.squeeze(1).sum(-1).to(torch.int64)
         vlens = video_masks.squeeze(1).sum(-1).to(torch.int64)
-        for layer in self.encoders:
+        intermediate_outs = []
+        for layer_idx, layer in enumerate(self.encoders):
             audio_pad, audio_masks, video_pad, video_masks = layer(audio_pad, audio_masks, video_pad, video_masks,
                                                                   alens=alens, vlens=vlens)
+            if layer_idx + 1 in self.interctc_layer_idx:          # tailored/encoder.py:272-318
+                a_out, v_out = audio_pad[0], video_pad[0]
+                if self.normalize_before:
+                    a_out, v_out = self.after_norm(a_out), self.after_norm(v_out)
+                av_out, _ = audiovisual_fusion(a_out, audio_masks, v_out, video_masks)
+                intermediate_outs.append((layer_idx + 1, av_out))
+                if self.interctc_use_conditioning:
+                    ha, hv = (av_out, av_out) if self.audiovisual_interctc_conditioning else (a_out, v_out)
+                    cw, cb = self.conditioning_layer.weight, self.conditioning_layer.bias
+                    audio_pad = (F_.InterCTCConditionFn.apply(audio_pad[0], ha, ctc.ctc_lo.weight, ctc.ctc_lo.bias, cw, cb),
+                                 audio_pad[1])
+                    video_pad = (F_.InterCTCConditionFn.apply(video_pad[0], hv, ctc.ctc_lo.weight, ctc.ctc_lo.bias, cw, cb),
+                                 video_pad[1])
         audio, video = audio_pad[0], video_pad[0]
         if self.normalize_before:
             audio, video = self.after_norm(audio), self.after_norm(video)
+        if len(intermediate_outs) > 0:
+            return (audio, intermediate_outs), audio_masks, video, video_masks, None
         return audio, audio_masks, video, video_masks, None

@@ -11,6 +11,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
+from ... import functional as F_
 from ...layers import (Conv2dSubsampling, ConvolutionalGatingMLP, LayerNorm, PositionwiseFeedForward,
                        RelPositionalEncoding, RelPositionMultiHeadedAttention, TooShortUttError, check_short_utt,
                        make_pad_mask)
@@ -101,8 +102,11 @@ class MyBranchformerEncoder(torch.nn.Module):
                 if self.normalize_before:
                     encoder_out = self.after_norm(encoder_out)
                 intermediate_outs.append((layer_idx + 1, encoder_out))
-                if self.interctc_use_conditioning:
-                    raise NotImplementedError("interctc_use_conditioning is not used by the shipped configs")
+                if self.interctc_use_conditioning:      # x + conditioning_layer(ctc.softmax(encoder_out))  (:389-401)
+                    x, pos_emb = xs_pad
+                    x = F_.InterCTCConditionFn.apply(x, encoder_out, ctc.ctc_lo.weight, ctc.ctc_lo.bias,
+                                                     self.conditioning_layer.weight, self.conditioning_layer.bias)
+                    xs_pad = (x, pos_emb)
         xs_pad = xs_pad[0]
         if self.normalize_before:
             xs_pad = self.after_norm(xs_pad)

@@ -433,6 +433,52 @@ class LayerNormFn(torch.autograd.Function):
         return dx.view(dy.shape), gw, gb, None
 
 
+class InterCTCConditionFn(torch.autograd.Function):
+    """x + conditioning_layer(softmax(ctc_lo(h)))  - self-conditioned intermediate CTC
+    (src/encoder/branchformer/encoder.py:389-401, tailored/encoder.py:296-318; ``CTC.softmax`` src/ctc/ctc.py:160-168).
+    ``h`` is the (normalised) intermediate output the posteriors are taken from, ``x`` the stream they are added to."""
+
+    @staticmethod
+    def forward(ctx, x, h, ctc_w, ctc_b, cond_w, cond_b):
+        shp = x.shape
+        D = shp[-1]
+        x2, h2 = x.reshape(-1, D), h.reshape(-1, D)
+        M, V = x2.shape[0], ctc_w.shape[0]
+        S = ops.pad4(V)
+        logits = ops.empty(1, 1, M, S, like=x)
+        ops.linear(h2, ctc_w, ctc_b, out=logits, ldc=S)
+        vlen = torch.full((1,), V, dtype=torch.int64, device=x.device)
+        prob = ops.softmax_fwd(logits, None, vlen, 1.0, T2=V)
+        y = ops.empty(M, D, like=x)
+        ops.gemm(M, D, V, prob, S, cond_w, cond_w.stride(0), y, D, bias=cond_b, R=x2, ldr=x2.stride(0))
+        ctx.save_for_backward(h2, prob, ctc_w, cond_w)
+        ctx.dims = (shp, M, V, S, D)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h2, prob, ctc_w, cond_w = ctx.saved_tensors
+        shp, M, V, S, D = ctx.dims
+        dy2 = dy.contiguous().view(M, D)
+        p2 = prob.view(M, S)
+        # conditioning layer: y = x + prob W_c^T + b_c
+        gcw = ops.empty(D, V, like=dy2)
+        ops.gemm(D, V, M, dy2, D, p2, S, gcw, V, a_kmajor=True, b_kmajor=True)
+        gcb = ops.colsum(dy2)
+        dprob = ops.empty(1, 1, M, S, like=dy2)
+        ops.gemm(M, V, D, dy2, D, cond_w, cond_w.stride(0), dprob, S, b_kmajor=True)
+        dlog, _ = ops.softmax_bwd(prob, dprob, 1.0, T2=V)
+        dl2 = dlog.view(M, S)
+        # ctc_lo: logits = h W^T + b
+        gw = ops.empty(V, D, like=dy2)
+        ops.gemm(V, D, M, dl2, S, h2, h2.stride(0), gw, D, a_kmajor=True, b_kmajor=True)
+        gb = ops.empty(V, like=dy2)
+        ops.colsum(dl2[:, :V], out=gb)
+        dh = ops.empty(M, D, like=dy2)
+        ops.gemm(M, D, V, dl2, S, ctc_w, ctc_w.stride(0), dh, D, b_kmajor=True)
+        return dy, dh.view(shp), gw, gb, gcw, gcb
+
+
 class DropoutFn(torch.autograd.Function):
     """stand-alone dropout node (positional-encoding dropouts, src/ctc/ctc.py:143)."""
 

@@ -73,8 +73,13 @@ class ESPnetAVSRModel(ESPnetASRModel):
             audio_feats, audio_masks, video_feats, video_masks,
             ctc=self.ctc if self.encoder.interctc_use_conditioning else None,
             audiovisual_fusion=self.audiovisual_fusion if len(self.encoder.interctc_layer_idx) > 0 else None)
+        intermediate_outs = None                      # avsr_espnet_model.py:460-487
+        if isinstance(audio_out, tuple):
+            audio_out, intermediate_outs = audio_out
         encoder_out, encoder_out_lens = self.audiovisual_fusion(audio_out, audio_out_masks, video_out, video_out_masks)
         assert encoder_out.size(0) == video.size(0), (encoder_out.size(), video.size(0))
+        if intermediate_outs is not None:
+            return (encoder_out, intermediate_outs), encoder_out_lens
         return encoder_out, encoder_out_lens
 
     # ---------------------------------------------------------------- avsr_espnet_model.py:211-367

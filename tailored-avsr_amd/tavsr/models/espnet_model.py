@@ -111,11 +111,13 @@ class ESPnetASRModel(torch.nn.Module):
         self.sos = token_list.index(sym_sos) if sym_sos in token_list else vocab_size - 1
         self.eos = token_list.index(sym_eos) if sym_eos in token_list else vocab_size - 1
         self.vocab_size, self.ignore_id = vocab_size, ignore_id
-        self.ctc_weight, self.interctc_weight = ctc_weight, interctc_weight
+        self.ctc_weight, self.interctc_weight, self.aux_ctc = ctc_weight, interctc_weight, aux_ctc
         self.token_list = list(token_list)
         self.frontend, self.specaug, self.normalize, self.encoder = frontend, specaug, normalize, encoder
         if not hasattr(self.encoder, "interctc_use_conditioning"):
             self.encoder.interctc_use_conditioning = False
+        if self.encoder.interctc_use_conditioning:       # espnet_model.py:109-112
+            self.encoder.conditioning_layer = torch.nn.Linear(vocab_size, self.encoder.output_size())
         self.decoder = decoder if ctc_weight < 1.0 else None
         self.lsm_weight, self.length_normalized_loss = lsm_weight, length_normalized_loss
         self.error_calculator = (ErrorCalculator(self.token_list, sym_space, sym_blank, report_cer, report_wer)
@@ -133,7 +135,10 @@ class ESPnetASRModel(torch.nn.Module):
             feats, feats_lengths = self.specaug(feats, feats_lengths)
         if self.normalize is not None:
             feats, feats_lengths = self.normalize(feats, feats_lengths)
-        encoder_out, encoder_out_lens, _ = self.encoder(feats, feats_lengths)
+        if self.encoder.interctc_use_conditioning:       # espnet_model.py:397-402
+            encoder_out, encoder_out_lens, _ = self.encoder(feats, feats_lengths, ctc=self.ctc)
+        else:
+            encoder_out, encoder_out_lens, _ = self.encoder(feats, feats_lengths)
         return encoder_out, encoder_out_lens
 
     # ---------------------------------------------------------------- espnet_model.py:206-356
@@ -161,8 +166,21 @@ class ESPnetASRModel(torch.nn.Module):
                 ys_hat = self.ctc.argmax(encoder_out).data
                 cer_ctc = self.error_calculator(ys_hat.cpu(), text.cpu(), is_ctc=True)
             stats["loss_ctc"], stats["cer_ctc"] = loss_ctc.detach(), cer_ctc
-        if self.interctc_weight != 0.0 and intermediate_outs is not None:
-            raise NotImplementedError("interctc_weight > 0 is not used by the shipped ASR/AVSR recipes")
+        if self.interctc_weight != 0.0 and intermediate_outs is not None:      # espnet_model.py:260-304
+            if self.aux_ctc is not None:
+                raise NotImplementedError("aux_ctc tasks are not used by any shipped recipe")
+            loss_interctc = None
+            for layer_idx, intermediate_out in intermediate_outs:
+                loss_ic = self.ctc(intermediate_out, encoder_out_lens, text, text_lengths)
+                cer_ic = None
+                if not self.training and self.error_calculator is not None:
+                    ys_hat = self.ctc.argmax(intermediate_out).data
+                    cer_ic = self.error_calculator(ys_hat.cpu(), text.cpu(), is_ctc=True)
+                loss_interctc = loss_ic if loss_interctc is None else F_.WeightedSumFn.apply(loss_interctc, loss_ic, 1.0, 1.0)
+                stats[f"loss_interctc_layer{layer_idx}"] = loss_ic.detach()
+                stats[f"cer_interctc_layer{layer_idx}"] = cer_ic
+            n_ic = len(intermediate_outs)
+            loss_ctc = F_.WeightedSumFn.apply(loss_ctc, loss_interctc, 1 - self.interctc_weight, self.interctc_weight / n_ic)
         acc_att = cer_att = wer_att = None
         if self.ctc_weight != 1.0:
             ys_in, ys_out = add_sos_eos(text, text_lengths, self.sos, self.eos, self.ignore_id)
