@@ -276,6 +276,32 @@ int tavsr_fill(float* p, float value, int64_t n, tavsr_stream_t stream);
 int tavsr_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int64_t N, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Log-mel frontend and SpecAug (espnet2 DefaultFrontend / SpecAug as configured by
+ * configs/ASR/branchformer_transformer+ctc_english.yaml:9-37, called at src/models/espnet_model.py:378-388).
+ * The DFT and the mel projection are tavsr_gemm calls; these are the steps around them.
+ *   tavsr_stft_frames : frames[b*T+t][n] = window[n] * reflect_pad(wav[b])[t*hop + n]   (window: hann(win_length)
+ *                       zero-padded to n_fft, centred, as torch.stft does; centre padding n_fft/2 when center != 0)
+ *   tavsr_power_spec  : P[row][k] = re_k^2 + im_k^2 from spec rows [re_0..re_{nfreq-1} | im_0..im_{nfreq-1}];
+ *                       0 in the padding columns k >= nfreq and in frames t >= olens[b]
+ *   tavsr_log_mask    : out = log(max(mel, floor)), 0 in frames t >= olens[b]
+ *   tavsr_time_warp   : espnet2 TimeWarp with torch's bicubic (A = -0.75, align_corners = False) on the first lens[b]
+ *                       frames of utterance b: [0, center[b]) resized to [0, warped[b]), [center[b], lens[b]) to
+ *                       [warped[b], lens[b]); center[b] == 0 copies; frames >= lens[b] become 0; device int64 [B]; y != x
+ *   tavsr_specaug_mask: espnet2 mask_along_axis on both axes, in place: zero where f is in one of utterance b's nf bands
+ *                       [fpos, fpos+flen) or t in one of its nt bands (arrays [B][nf] / [B][nt], device int64)
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_stft_frames(const float* wav, const float* window, float* frames, int32_t B, int64_t N, int32_t T, int32_t n_fft,
+                      int32_t hop, int32_t center, tavsr_stream_t stream);
+int tavsr_power_spec(const float* spec, int64_t ld_spec, float* P, int32_t ldp, int32_t nfreq, int32_t B, int32_t T,
+                     const int64_t* olens, tavsr_stream_t stream);
+int tavsr_log_mask(const float* mel, float* out, int32_t B, int32_t T, int32_t n_mels, const int64_t* olens, float floor_,
+                   tavsr_stream_t stream);
+int tavsr_time_warp(const float* x, float* y, int32_t B, int32_t T, int32_t F, const int64_t* center, const int64_t* warped,
+                    const int64_t* lens, tavsr_stream_t stream);
+int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t* fpos, const int64_t* flen, int32_t nf,
+                       const int64_t* tpos, const int64_t* tlen, int32_t nt, tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimizer step of the reference's harness (avsr_main.py:50-54): torch.optim.Adam(betas (0.9, 0.98), eps 1e-9) under
  * the Noam rate (src/schedulers/noam.py:29-46,72-81), fused over flat fp32 buffers.  `step` counts from 1 (bias
  * correction), `lr` is the Noam rate of that step, gradients are multiplied by grad_scale first (1/world_size under DP).

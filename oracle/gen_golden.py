@@ -490,6 +490,9 @@ def main():
     if "--optim-only" in sys.argv:
         gen_noam_adam()
         return
+    if "--cfg1-only" in sys.argv:
+        gen_cfg1_wav()
+        return
     if "--interctc-only" in sys.argv:
         gen_interctc()
         return

@@ -506,6 +506,81 @@ class DefaultFrontend(nn.Module):
         return mel, olens
 
 
+# --------------------------------------------------------------------------------------
+# A.8b espnet2 SpecAug (espnet2/asr/specaug/specaug.py, layers/time_warp.py, layers/mask_along_axis.py), configured at
+#      configs/ASR/branchformer_transformer+ctc_english.yaml:21-37, applied train-only at espnet_model.py:383-385.
+#      espnet2 is absent here: restated from its published source (parity unpinned for this leaf).  Draws use the
+#      torch HOST generator (the reference draws on the feature tensor's device).
+# --------------------------------------------------------------------------------------
+def time_warp(x, window=80, mode="bicubic"):
+    org_size = x.size()
+    if x.dim() == 3:
+        x = x[:, None]
+    t = x.shape[2]
+    if t - window <= window:
+        return x.view(*org_size)
+    center = torch.randint(window, t - window, (1,))[0]
+    warped = torch.randint(center - window, center + window, (1,))[0] + 1
+    left = F.interpolate(x[:, :, :center], (warped, x.shape[3]), mode=mode, align_corners=False)
+    right = F.interpolate(x[:, :, center:], (t - warped, x.shape[3]), mode=mode, align_corners=False)
+    x = torch.cat([left, right], dim=-2)
+    return x.view(*org_size)
+
+
+def mask_along_axis(spec, spec_lengths, mask_width_range=(0, 30), dim=1, num_mask=2, replace_with_zero=True):
+    org_size = spec.size()
+    if spec.dim() == 4:
+        spec = spec.view(-1, spec.size(2), spec.size(3))
+    B, D = spec.shape[0], spec.shape[dim]
+    mask_length = torch.randint(mask_width_range[0], mask_width_range[1], (B, num_mask)).unsqueeze(2)
+    mask_pos = torch.randint(0, max(1, D - int(mask_length.max())), (B, num_mask)).unsqueeze(2)
+    aran = torch.arange(D)[None, None, :]
+    mask = ((mask_pos <= aran) * (aran < (mask_pos + mask_length))).any(dim=1)
+    mask = mask.unsqueeze(2) if dim == 1 else mask.unsqueeze(1)
+    value = 0.0 if replace_with_zero else spec.mean()
+    spec = spec.masked_fill(mask, value)
+    return spec.view(*org_size), spec_lengths
+
+
+class SpecAug(nn.Module):
+    def __init__(self, apply_time_warp=True, time_warp_window=5, time_warp_mode="bicubic", apply_freq_mask=True,
+                 freq_mask_width_range=(0, 20), num_freq_mask=2, apply_time_mask=True, time_mask_width_range=None,
+                 time_mask_width_ratio_range=None, num_time_mask=2):
+        super().__init__()
+        assert apply_time_warp or apply_freq_mask or apply_time_mask
+        assert not (apply_time_mask and time_mask_width_range is not None and time_mask_width_ratio_range is not None)
+        self.apply_time_warp, self.window, self.mode = apply_time_warp, time_warp_window, time_warp_mode
+        self.apply_freq_mask, self.num_freq_mask = apply_freq_mask, num_freq_mask
+        self.freq_range = (0, freq_mask_width_range) if isinstance(freq_mask_width_range, int) else tuple(freq_mask_width_range)
+        self.apply_time_mask, self.num_time_mask = apply_time_mask, num_time_mask
+        self.time_range = time_mask_width_range
+        if isinstance(self.time_range, int):
+            self.time_range = (0, self.time_range)
+        self.time_ratio = time_mask_width_ratio_range
+        if isinstance(self.time_ratio, float):
+            self.time_ratio = (0.0, self.time_ratio)
+
+    def forward(self, x, x_lengths=None):
+        if self.apply_time_warp:                                      # TimeWarp.forward
+            if x_lengths is None or all(le == x_lengths[0] for le in x_lengths):
+                x = time_warp(x, window=self.window, mode=self.mode)
+            else:
+                ys = [time_warp(x[i][None, : x_lengths[i]], window=self.window, mode=self.mode)[0] for i in range(x.size(0))]
+                x = torch.nn.utils.rnn.pad_sequence(ys, batch_first=True, padding_value=0.0)
+        if self.apply_freq_mask:                                      # MaskAlongAxis(dim="freq")
+            x, x_lengths = mask_along_axis(x, x_lengths, self.freq_range, dim=2, num_mask=self.num_freq_mask)
+        if self.apply_time_mask:
+            if self.time_range is not None:                           # MaskAlongAxis(dim="time")
+                x, x_lengths = mask_along_axis(x, x_lengths, tuple(self.time_range), dim=1, num_mask=self.num_time_mask)
+            else:                                                     # MaskAlongAxisVariableMaxWidth
+                max_width = x.shape[1]
+                lo = max(0, math.floor(max_width * self.time_ratio[0]))
+                hi = min(max_width, math.floor(max_width * self.time_ratio[1]))
+                if hi > lo:
+                    x, x_lengths = mask_along_axis(x, x_lengths, (lo, hi), dim=1, num_mask=self.num_time_mask)
+        return x, x_lengths
+
+
 class UtteranceMVN(nn.Module):
     def __init__(self, norm_means=True, norm_vars=False, eps=1.0e-20):
         super().__init__()

@@ -126,8 +126,9 @@ class ESPnetASRModel(torch.nn.Module):
 
     # ---------------------------------------------------------------- espnet_model.py:369-430
     def encode(self, speech: torch.Tensor, speech_lengths: torch.Tensor):
-        speech = speech[:, : int(speech.size(1))]
         if self.frontend is not None:
+            # espnet_model.py:372: the batch is cut to its longest utterance (the STFT's reflect padding sees the tensor end)
+            speech = speech[:, : int(speech_lengths.max())]
             feats, feats_lengths = self.frontend(speech, speech_lengths)
         else:
             feats, feats_lengths = speech, speech_lengths

@@ -713,6 +713,55 @@ def copy2d(src, dst):
     return dst
 
 
+# ---------------------------------------------------------------------------------------------- log-mel frontend, SpecAug
+def stft_frames(wav, window, T, n_fft, hop, center=True):
+    """wav [B, N] -> windowed frames [B*T, n_fft] (reflect padding of n_fft/2 when center)."""
+    B, N = wav.shape
+    require_cuda(wav, window)
+    frames = empty(B * T, n_fft, like=wav)
+    check(lib().tavsr_stft_frames(ptr(wav), ptr(window), ptr(frames), B, C.c_int64(N), T, n_fft, hop, int(center), stream()),
+          "tavsr_stft_frames")
+    return frames
+
+
+def power_spec(spec, nfreq, ldp, B, T, olens):
+    """spec [B*T, >= 2*nfreq] (re | im) -> power [B*T, ldp] (zero K padding, zero past olens)."""
+    require_cuda(spec, olens)
+    P = empty(B * T, ldp, like=spec)
+    check(lib().tavsr_power_spec(ptr(spec), C.c_int64(spec.stride(0)), ptr(P), ldp, nfreq, B, T, ptr(olens), stream()),
+          "tavsr_power_spec")
+    return P
+
+
+def log_mask(mel, B, T, olens, floor=1e-10):
+    require_cuda(mel, olens)
+    out = torch.empty_like(mel)
+    check(lib().tavsr_log_mask(ptr(mel), ptr(out), B, T, mel.shape[-1], ptr(olens), C.c_float(floor), stream()), "tavsr_log_mask")
+    return out
+
+
+def time_warp(x, center, warped, lens):
+    """center / warped / lens: int64 [B] on the device (center 0 = leave that utterance unwarped)."""
+    B, T, F = x.shape
+    require_cuda(x, center, warped, lens)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib().tavsr_time_warp(ptr(x), ptr(y), B, T, F, ptr(center), ptr(warped), ptr(lens), stream()), "tavsr_time_warp")
+    return y
+
+
+def specaug_mask_(x, fpos=None, flen=None, tpos=None, tlen=None):
+    """in place; band arrays [B, n] int64 on the device (None: that axis is not masked)."""
+    B, T, F = x.shape
+    require_cuda(x, fpos, flen, tpos, tlen)
+    assert x.is_contiguous()
+    nf = 0 if fpos is None else fpos.shape[1]
+    nt = 0 if tpos is None else tpos.shape[1]
+    check(lib().tavsr_specaug_mask(ptr(x), B, T, F, ptr(fpos), ptr(flen), nf, ptr(tpos), ptr(tlen), nt, stream()),
+          "tavsr_specaug_mask")
+    return x
+
+
 # ---------------------------------------------------------------------------------------------- dropout
 # The generator state is ONE uint64 per device, resident in HBM; ``rng_step_begin`` advances it with a kernel (so a
 # captured step graph draws new masks at every replay) and rewinds the per-step site counter, which hands every dropout

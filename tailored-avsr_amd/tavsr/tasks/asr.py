@@ -7,9 +7,13 @@ import argparse
 from ..ctc.ctc import CTC
 from ..decoder.transformer_decoder import TransformerDecoder
 from ..encoder.branchformer.encoder import MyBranchformerEncoder
+from ..frontend.default import DefaultFrontend
 from ..models.espnet_model import ESPnetASRModel, UtteranceMVN
+from ..specaug.specaug import SpecAug
 from ..utils.tokens import load_token_list
 
+frontend_choices = {"default": DefaultFrontend}
+specaug_choices = {"specaug": SpecAug}
 encoder_choices = {"branchformer": MyBranchformerEncoder}
 decoder_choices = {"transformer": TransformerDecoder}
 normalize_choices = {"utterance_mvn": UtteranceMVN}
@@ -28,12 +32,15 @@ class ASRTask:
         token_list = load_token_list(args.token_list)
         args.token_list = list(token_list)
         vocab_size = len(token_list)
-        if args.input_size is None:
-            raise NotImplementedError("the log-mel frontend is the next row (SURVEY 8f-2): feed features with "
-                                      "input_size: 80")
-        frontend, input_size = None, args.input_size
+        if args.input_size is None:       # waveform in: the log-mel frontend is part of the model (src/tasks/asr.py:500-512)
+            frontend = _pick(frontend_choices, getattr(args, "frontend", "default"), "frontend")(
+                **(getattr(args, "frontend_conf", None) or {}))
+            input_size = frontend.output_size()
+        else:
+            frontend, input_size = None, args.input_size
+        specaug = None
         if getattr(args, "specaug", None) is not None:
-            raise NotImplementedError("SpecAug is a stochastic train-time op upstream of the path: set specaug: null")
+            specaug = _pick(specaug_choices, args.specaug, "specaug")(**(getattr(args, "specaug_conf", None) or {}))
         normalize = None
         if getattr(args, "normalize", None) is not None:
             normalize = _pick(normalize_choices, args.normalize, "normalize")(**(args.normalize_conf or {}))
@@ -44,7 +51,7 @@ class ASRTask:
                 vocab_size=vocab_size, encoder_output_size=encoder.output_size(), **args.decoder_conf)
         ctc = CTC(odim=vocab_size, encoder_output_size=encoder.output_size(), **args.ctc_conf)
         model_class = model_choices.get(getattr(args, "model", "espnet"), ESPnetASRModel)
-        model = model_class(vocab_size=vocab_size, frontend=frontend, specaug=None, normalize=normalize,
+        model = model_class(vocab_size=vocab_size, frontend=frontend, specaug=specaug, normalize=normalize,
                             preencoder=None, encoder=encoder, postencoder=None, decoder=decoder, ctc=ctc,
                             joint_network=None, token_list=token_list, **args.model_conf)
         if getattr(args, "init", None) is not None:

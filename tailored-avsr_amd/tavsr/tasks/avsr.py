@@ -11,12 +11,16 @@ from ..embedding_for_avsr.default import DefaultEmbeddingLayerForAVSR
 from ..encoder.audiovisual.conventional.encoder import ConventionalEncoder
 from ..encoder.audiovisual.tailored.encoder import TailoredEncoder
 from ..frontend.conv3d_resnet18 import Conv3dResNet18
+from ..frontend.default import DefaultFrontend
 from ..models.avsr_espnet_model import ESPnetAVSRModel
 from ..models.espnet_model import UtteranceMVN
+from ..specaug.specaug import SpecAug
 from ..utils.tokens import load_token_list
 from .asr import _pick
 
 visual_frontend_choices = {"conv3dresnet18": Conv3dResNet18}
+acoustic_frontend_choices = {"default": DefaultFrontend}
+specaug_choices = {"specaug": SpecAug}
 acoustic_embed_choices = {"default": DefaultEmbeddingLayerForAVSR}
 visual_embed_choices = {"default": DefaultEmbeddingLayerForAVSR}
 encoder_choices = {"tailored": TailoredEncoder, "conventional": ConventionalEncoder}
@@ -32,18 +36,21 @@ class AVSRTask:
         token_list = load_token_list(args.token_list)
         args.token_list = list(token_list)
         vocab_size = len(token_list)
-        if args.acoustic_input_size is None:
-            raise NotImplementedError("the log-mel frontend is the next row (SURVEY 8f-2): feed mel features with "
-                                      "acoustic_input_size: 80")
-        acoustic_frontend, acoustic_input_size = None, args.acoustic_input_size
+        if args.acoustic_input_size is None:      # waveform in (src/tasks/avsr.py:524-536)
+            acoustic_frontend = _pick(acoustic_frontend_choices, getattr(args, "acoustic_frontend", "default"),
+                                      "acoustic_frontend")(**(getattr(args, "acoustic_frontend_conf", None) or {}))
+            acoustic_input_size = acoustic_frontend.output_size()
+        else:
+            acoustic_frontend, acoustic_input_size = None, args.acoustic_input_size
         if args.visual_input_size is None:
             visual_frontend = _pick(visual_frontend_choices, args.visual_frontend, "visual_frontend")(
                 **(args.visual_frontend_conf or {}))
             visual_input_size = visual_frontend.output_size()
         else:
             visual_frontend, visual_input_size = None, args.visual_input_size
+        specaug = None
         if getattr(args, "specaug", None) is not None:
-            raise NotImplementedError("SpecAug is a stochastic train-time op upstream of the path: set specaug: null")
+            specaug = _pick(specaug_choices, args.specaug, "specaug")(**(getattr(args, "specaug_conf", None) or {}))
         normalize = None
         if getattr(args, "normalize", None) is not None:
             normalize = _pick(normalize_choices, args.normalize, "normalize")(**(args.normalize_conf or {}))
@@ -72,7 +79,7 @@ class AVSRTask:
                 vocab_size=vocab_size, encoder_output_size=encoder_output_size, **args.decoder_conf)
         ctc = CTC(odim=vocab_size, encoder_output_size=encoder_output_size, **args.ctc_conf)
         model_class = model_choices.get(getattr(args, "model", "espnet"), ESPnetAVSRModel)
-        model = model_class(vocab_size=vocab_size, token_list=token_list, specaug=None, normalize=normalize,
+        model = model_class(vocab_size=vocab_size, token_list=token_list, specaug=specaug, normalize=normalize,
                             acoustic_frontend=acoustic_frontend, visual_frontend=visual_frontend, acoustic_preencoder=None,
                             visual_preencoder=None, acoustic_embed=acoustic_embed, visual_embed=visual_embed, encoder=encoder,
                             audiovisual_fusion=fusion, postencoder=None, decoder=decoder, ctc=ctc, joint_network=None,
