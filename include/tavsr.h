@@ -302,6 +302,31 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
                        const int64_t* tpos, const int64_t* tlen, int32_t nt, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Decode steps of the hybrid CTC/attention beam search with LM scoring (src/inference/avsr_inference.py:141-304,
+ * 449-518: espnet BatchBeamSearch + TransformerDecoder.batch_score + TransformerLM.batch_score + CTCPrefixScorer).
+ *   tavsr_tree_attn_step : out[n][h] = softmax(scale * q[n][h] . K[anc[n][j]][h], j < nkeys) . V[anc[n][j]][h].
+ *       Keys/values of all hypotheses live in a pool (row = one token of one hypothesis, H*dk floats, row stride ldkv);
+ *       anc [N][ld_anc] int32 lists each hypothesis' own rows, so a beam re-order copies these lists only.
+ *   tavsr_ctc_prefix_step: espnet CTCPrefixScoreTH.__call__ (no attention window) for C candidate tokens per
+ *       hypothesis.  logp [U][T][V] log-softmax of the CTC head, lens [U] frames, hypotheses n belong to utterance n / K.
+ *       r_prev [N][T][2] / s_prev [N] / last_tok [N]: forward variables (non-blank, blank), log_psi and last token of
+ *       each hypothesis (ignored when out_len == 0: the <sos> state is used).  Writes r_new [N][T][2][C],
+ *       psi [N][C] = log_psi(cand) - s_prev, psi_abs [N][C] = log_psi(cand), eos [N] = log p(prefix ends) - s_prev,
+ *       eos_abs [N].  A candidate equal to <eos> must take the eos value (caller); blank scores -1e10.
+ *   tavsr_log_softmax_rows: y[m][:] = log_softmax(x[m][:V]).
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
+                         const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N, int32_t H,
+                         int32_t dk, float scale, tavsr_stream_t stream);
+int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,
+                          const int64_t* last_tok, const int64_t* cand, float* r_new, float* psi, float* psi_abs, float* eos,
+                          float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V, int32_t C, int32_t out_len,
+                          int32_t blank, tavsr_stream_t stream);
+int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t V, tavsr_stream_t stream);
+/* y = act(x) elementwise (the LM's Linear -> LayerNorm -> ReLU input layer); in place allowed */
+int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimizer step of the reference's harness (avsr_main.py:50-54): torch.optim.Adam(betas (0.9, 0.98), eps 1e-9) under
  * the Noam rate (src/schedulers/noam.py:29-46,72-81), fused over flat fp32 buffers.  `step` counts from 1 (bias
  * correction), `lr` is the Noam rate of that step, gradients are multiplied by grad_scale first (1/world_size under DP).

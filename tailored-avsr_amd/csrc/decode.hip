@@ -1,0 +1,204 @@
+// One-token decode steps of the hybrid CTC/attention beam search with LM scoring (the reference builds it
+// at src/inference/avsr_inference.py:141-304 from espnet's BatchBeamSearch, TransformerDecoder.batch_score,
+// TransformerLM.batch_score, CTCPrefixScorer / CTCPrefixScoreTH and runs it at :449-518, on the CPU, one utterance at
+// a time).  Here all hypotheses of all utterances of a batch advance together; these are the kernels that have no
+// counterpart on the training path:
+//   * tree_attn_step  - self-attention of ONE new query per hypothesis over its own history.  Keys/values live in a
+//     node pool (one row per (step, slot)); a hypothesis is the list of its ancestors' rows, so re-ordering the beam
+//     copies int32 ancestor lists instead of key/value caches.  HBM/L2-bound gather: 2 * L * dk * 4 B per (hyp, head).
+//   * ctc_prefix_step - CTCPrefixScoreTH.__call__ for the pre-beam candidates of every hypothesis: forward variables
+//     r^n_t, r^b_t in log space, sequential in t, one thread per (hypothesis, candidate).
+//   * log_softmax_rows - scorer outputs.
+#include "common.h"
+
+namespace tavsr {
+
+constexpr int kTreeMaxKeys = 1024;
+
+// one wave per (hypothesis n, head h)
+__global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __restrict__ q, int64_t ldq,
+                                                             const float* __restrict__ kpool, const float* __restrict__ vpool,
+                                                             int64_t ldkv, const int32_t* __restrict__ anc, int64_t ld_anc,
+                                                             int nkeys, float* __restrict__ out, int64_t ldo, int N, int H,
+                                                             int dk, float scale) {
+  __shared__ float s_p[4][kTreeMaxKeys];
+  __shared__ float s_q[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool live = blockIdx.x * 4 + wave < N * H;       // surplus waves recompute the last item and store nothing
+  const int item = min(blockIdx.x * 4 + wave, N * H - 1);
+  const int n = item / H, h = item % H;
+  const float* qv = q + (int64_t)n * ldq + h * dk;
+  for (int d = lane; d < dk; d += 64) s_q[wave][d] = qv[d] * scale;
+  __syncthreads();
+  const int32_t* a = anc + (int64_t)n * ld_anc;
+  float mx = -INFINITY;
+  for (int j = lane; j < nkeys; j += 64) {
+    const float* kr = kpool + (int64_t)a[j] * ldkv + h * dk;
+    float dot = 0.f;
+    for (int d = 0; d < dk; d += 4) {
+      const float4 kv = *reinterpret_cast<const float4*>(kr + d);
+      dot += s_q[wave][d] * kv.x + s_q[wave][d + 1] * kv.y + s_q[wave][d + 2] * kv.z + s_q[wave][d + 3] * kv.w;
+    }
+    s_p[wave][j] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < nkeys; j += 64) {
+    const float e = expf(s_p[wave][j] - mx);
+    s_p[wave][j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  const float inv = 1.f / sum;
+  for (int d = lane; d < dk; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < nkeys; ++j) acc += s_p[wave][j] * vpool[(int64_t)a[j] * ldkv + h * dk + d];
+    if (live) out[(int64_t)n * ldo + h * dk + d] = acc * inv;
+  }
+}
+
+__device__ __forceinline__ float logaddexp2(float a, float b) {
+  const float m = fmaxf(a, b);
+  return m + logf(expf(a - m) + expf(b - m));
+}
+
+// thread = (hypothesis n, candidate c).  logp [U][T][V] (log-softmax of the CTC head), lens [U].
+// r_prev [N][T][2] (nb, b) and s_prev [N] of the hypothesis (first == 1: the <sos> state is built here instead).
+// Writes r_new [N][T][2][C], psi [N][C] = log_psi(candidate) - s_prev  and  psi_abs [N][C] = log_psi(candidate);
+// thread c == 0 also writes eos [N] = r_sum[len-1] - s_prev and eos_abs.
+__global__ __launch_bounds__(256) void ctc_prefix_step_kernel(const float* __restrict__ logp, const int64_t* __restrict__ lens,
+                                                              const float* __restrict__ r_prev, const float* __restrict__ s_prev,
+                                                              const int64_t* __restrict__ last_tok,
+                                                              const int64_t* __restrict__ cand, float* __restrict__ r_new,
+                                                              float* __restrict__ psi, float* __restrict__ psi_abs,
+                                                              float* __restrict__ eos, float* __restrict__ eos_abs, int N,
+                                                              int K, int T, int V, int C, int out_len, int blank, int first) {
+  const float logzero = -10000000000.0f;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  const int u = n / K;
+  const int L = (int)lens[u];
+  const int tok = (int)cand[(int64_t)n * C + c];
+  const float* lp = logp + (int64_t)u * T * V;
+  const float* rp = r_prev + (int64_t)n * T * 2;
+  const float sp = first ? 0.f : s_prev[n];
+  const bool same = !first && tok == (int)last_tok[n];
+  float* rn = r_new + (int64_t)n * T * 2 * C + c;
+  // previous forward variables: (nb, b) per frame; <sos>: nb = logzero, b = cumulative blank
+  float cum = 0.f;
+  auto prev = [&](int t, float& pn, float& pb) {
+    if (first) { pn = logzero; pb = cum; }     // cum must already hold sum_{t' <= t} logp[t'][blank]
+    else { pn = rp[t * 2]; pb = rp[t * 2 + 1]; }
+  };
+  const int start = max(out_len, 1);
+  for (int t = 0; t < start && t < T; ++t) { rn[(int64_t)(t * 2) * C] = logzero; rn[(int64_t)(t * 2 + 1) * C] = logzero; }
+  float rn_n = logzero, rn_b = logzero;        // r[start - 1]
+  if (out_len == 0) {
+    rn_n = lp[tok];                            // r[0, nb] = x[0][tok]
+    rn[0] = rn_n;
+  }
+  if (first) { for (int t = 0; t < start - 1; ++t) cum += lp[(int64_t)t * V + blank]; }
+  // log_psi accumulates logsumexp over t in [start, L) of (phi[t-1] + x[t][tok]) and r[start-1, nb]
+  float acc = rn_n;
+  for (int t = start; t < L; ++t) {
+    float pn, pb;
+    if (first) cum += lp[(int64_t)(t - 1) * V + blank];
+    prev(t - 1, pn, pb);
+    const float phi = same ? pb : logaddexp2(pn, pb);
+    const float xt = lp[(int64_t)t * V + tok], xb = lp[(int64_t)t * V + blank];
+    const float nn = logaddexp2(rn_n, phi) + xt;
+    const float nb = logaddexp2(rn_n, rn_b) + xb;
+    acc = logaddexp2(acc, phi + xt);
+    rn_n = nn; rn_b = nb;
+    rn[(int64_t)(t * 2) * C] = nn;
+    rn[(int64_t)(t * 2 + 1) * C] = nb;
+  }
+  for (int t = max(L, start); t < T; ++t) { rn[(int64_t)(t * 2) * C] = logzero; rn[(int64_t)(t * 2 + 1) * C] = logzero; }
+  const float out_psi = tok == blank ? logzero : acc;
+  psi_abs[(int64_t)n * C + c] = out_psi;
+  psi[(int64_t)n * C + c] = out_psi - sp;
+  if (c == 0) {
+    float pn, pb;
+    if (first) { cum = 0.f; for (int t = 0; t < L; ++t) cum += lp[(int64_t)t * V + blank]; }
+    prev(L - 1, pn, pb);
+    const float e = logaddexp2(pn, pb);
+    eos_abs[n] = e;
+    eos[n] = e - sp;
+  }
+}
+
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                               int64_t ldy, int M, int V) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float mx = -INFINITY;
+  for (int j = lane; j < V; j += 64) mx = fmaxf(mx, xr[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < V; j += 64) s += expf(xr[j] - mx);
+  s = wave_sum(s);
+  const float lse = mx + logf(s);
+  for (int j = lane; j < V; j += 64) y[(int64_t)row * ldy + j] = xr[j] - lse;
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = act_fwd(act, x[i]);
+}
+
+}  // namespace tavsr
+
+using namespace tavsr;
+
+extern "C" int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, tavsr_stream_t stream) {
+  TAVSR_REQUIRE((x && y) || n <= 0, TAVSR_EINVAL, "act_fwd: null pointer");
+  if (n <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+
+extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
+                                    const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N,
+                                    int32_t H, int32_t dk, float scale, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(q && kpool && vpool && anc && out, TAVSR_EINVAL, "tree_attn_step: null pointer");
+  TAVSR_REQUIRE(nkeys > 0 && nkeys <= kTreeMaxKeys, TAVSR_EUNSUPPORTED, "tree_attn_step: 1..%d keys supported (got %d)",
+                kTreeMaxKeys, nkeys);
+  TAVSR_REQUIRE(dk % 4 == 0 && dk <= 128 && ldkv % 4 == 0 && ((uintptr_t)kpool & 15) == 0, TAVSR_EALIGN,
+                "tree_attn_step: dk %% 4, dk <= 128 and 16-byte aligned key rows are required");
+  if (N <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(tree_attn_step_kernel, dim3((unsigned)((N * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, kpool,
+                     vpool, ldkv, anc, ld_anc, nkeys, out, ldo, N, H, dk, scale);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,
+                                     const int64_t* last_tok, const int64_t* cand, float* r_new, float* psi, float* psi_abs,
+                                     float* eos, float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V, int32_t C,
+                                     int32_t out_len, int32_t blank, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(logp && lens && cand && r_new && psi && psi_abs && eos && eos_abs, TAVSR_EINVAL, "ctc_prefix_step: null pointer");
+  TAVSR_REQUIRE(out_len == 0 || (r_prev && s_prev && last_tok), TAVSR_EINVAL, "ctc_prefix_step: state needed after <sos>");
+  TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0 && C > 0, TAVSR_EINVAL, "ctc_prefix_step: bad sizes");
+  hipLaunchKernelGGL(ctc_prefix_step_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logp,
+                     lens, r_prev, s_prev, last_tok, cand, r_new, psi, psi_abs, eos, eos_abs, N, K, T, V, C, out_len, blank,
+                     out_len == 0 ? 1 : 0);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t V,
+                                      tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && y, TAVSR_EINVAL, "log_softmax_rows: null pointer");
+  if (M <= 0 || V <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M,
+                     V);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}

@@ -1,0 +1,312 @@
+"""Batched hybrid CTC/attention beam search with LM scoring on the MI355X (BASELINE config 5).
+
+Same search as the reference's decode path - espnet ``BatchBeamSearch`` with scorers {decoder, CTCPrefixScorer,
+LengthBonus, lm}, weights {decoder: 1 - ctc_weight, ctc: ctc_weight, lm: lm_weight, length_bonus: penalty}, pre-beam of
+``int(1.5 * beam)`` candidates on the weighted full scores, end detection of ``maxlenratio == 0``
+(src/inference/avsr_inference.py:141-153, 249-255, 277-304, 449-518) - but the hypotheses of ALL utterances of a batch
+advance together (the reference decodes one utterance at a time on the CPU):
+
+* N = U x beam slots.  One step = one token for every slot: decoder step (6 layers) and LM step (16 layers) as
+  [N, d] GEMMs on the MFMA kernel, self-attention over each hypothesis' own history by ``tavsr_tree_attn_step`` (keys
+  and values stay where they were written; a hypothesis is an int32 list of ancestor rows), source attention against
+  the per-utterance memory keys/values projected once, CTC prefix scores of the pre-beam candidates by
+  ``tavsr_ctc_prefix_step``.
+* The per-step bookkeeping (top-k, ancestor-list gathers, ended-hypothesis lists, end detection) is torch / host code:
+  index plumbing on [N]-sized tensors.
+
+``decode(enc, enc_lens)`` takes encoder outputs (``model.encode``), returns per utterance the ended hypotheses sorted
+by score as (token ids incl. <sos>/<eos>, score).  ``Speech2Text`` wraps model + search like the reference's class.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import ops
+
+EPS = 1e-12
+LOGZERO = -10000000000.0
+
+
+def _cat(ws):
+    return torch.cat([w.detach() for w in ws], dim=0).contiguous()
+
+
+class _DecoderStep:
+    """espnet2 TransformerDecoder.forward_one_step with K/V kept per token instead of per-layer output caches."""
+
+    def __init__(self, dec):
+        self.dec = dec
+        self.D = dec.after_norm.weight.numel()
+        self.H = dec.heads
+        self.dk = self.D // self.H
+        self.layers = []
+        for l in dec.decoders:
+            sa, ca, ff = l.self_attn, l.src_attn, l.feed_forward
+            self.layers.append(dict(
+                n1=(l.norm1.weight, l.norm1.bias), n2=(l.norm2.weight, l.norm2.bias), n3=(l.norm3.weight, l.norm3.bias),
+                wqkv=_cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight]),
+                bqkv=_cat([sa.linear_q.bias, sa.linear_k.bias, sa.linear_v.bias]),
+                wo=sa.linear_out.weight, bo=sa.linear_out.bias,
+                wq2=ca.linear_q.weight, bq2=ca.linear_q.bias,
+                wkv2=_cat([ca.linear_k.weight, ca.linear_v.weight]), bkv2=_cat([ca.linear_k.bias, ca.linear_v.bias]),
+                wo2=ca.linear_out.weight, bo2=ca.linear_out.bias,
+                w1=ff.w_1.weight, b1=ff.w_1.bias, w2=ff.w_2.weight, b2=ff.w_2.bias))
+
+    def start(self, enc, enc_lens, N, K, max_steps):
+        U, T, D = enc.shape
+        self.U, self.T, self.N, self.K = U, T, N, K
+        self.enc_lens = enc_lens
+        mem2 = enc.reshape(U * T, D)
+        self.memkv = [ops.linear(mem2, L["wkv2"], L["bkv2"]) for L in self.layers]          # [U*T, 2D] per layer
+        self.kpool = [ops.empty(max_steps * N, D, like=enc) for _ in self.layers]
+        self.vpool = [ops.empty(max_steps * N, D, like=enc) for _ in self.layers]
+        self.pe = self.dec.embed[1].table(max_steps, enc.device)
+        self.emb = self.dec.embed[0].weight
+        self.xscale = math.sqrt(D)
+
+    def step(self, i, tok, anc):
+        """tok [N] last tokens, anc int32 [N, >= i+1] (column i already points at this step's rows) -> logp [N, V]."""
+        N, D, H, dk, U, T, K = self.N, self.D, self.H, self.dk, self.U, self.T, self.K
+        x = ops.embed_pe(tok.view(N, 1).contiguous(), self.emb, self.pe[i:i + 1].contiguous(), self.xscale).view(N, D)
+        lo = i * N
+        for li, L in enumerate(self.layers):
+            n1 = ops.layernorm_fwd(x, *L["n1"], EPS, save=False)[0]
+            qkv = ops.linear(n1, L["wqkv"], L["bqkv"])
+            ops.copy2d(qkv[:, D:2 * D], self.kpool[li][lo:lo + N])
+            ops.copy2d(qkv[:, 2 * D:], self.vpool[li][lo:lo + N])
+            a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1, H, dk)
+            x = ops.linear(a, L["wo"], L["bo"], res=x)
+            n2 = ops.layernorm_fwd(x, *L["n2"], EPS, save=False)[0]
+            q2 = ops.linear(n2, L["wq2"], L["bq2"])
+            # source attention: the K slots of an utterance are K query rows against that utterance's memory
+            kv = self.memkv[li]
+            S = ops.pad4(T)
+            sc = ops.empty(H, U, K, S, like=x)
+            ops.gemm(K, T, dk, q2, D, kv, 2 * D, sc, S, nb1=U, nb2=H, sA=(K * D, dk), sB=(T * 2 * D, dk),
+                     sC=(K * S, U * K * S))
+            att = ops.softmax_fwd(sc, None, self.enc_lens, 1.0 / math.sqrt(dk), T2=T)
+            c2 = ops.empty(N, D, like=x)
+            ops.gemm(K, dk, T, att, S, kv, 2 * D, c2, D, b_off=D, b_kmajor=True, nb1=U, nb2=H, sA=(K * S, U * K * S),
+                     sB=(T * 2 * D, dk), sC=(K * D, dk))
+            x = ops.linear(c2, L["wo2"], L["bo2"], res=x)
+            n3 = ops.layernorm_fwd(x, *L["n3"], EPS, save=False)[0]
+            t = ops.linear(n3, L["w1"], L["b1"], act="relu")
+            x = ops.linear(t, L["w2"], L["b2"], res=x)
+        y = ops.layernorm_fwd(x, self.dec.after_norm.weight, self.dec.after_norm.bias, EPS, save=False)[0]
+        return ops.log_softmax_rows(ops.linear(y, self.dec.output_layer.weight, self.dec.output_layer.bias))
+
+
+class _LMStep:
+    """espnet2 TransformerLM.batch_score (encoder.forward_one_step) with per-token K/V."""
+
+    def __init__(self, lm):
+        self.lm = lm
+        self.D, self.H = lm.att_unit, lm.heads
+        self.dk = self.D // self.H
+        self.layers = []
+        for l in lm.encoder.encoders:
+            a, ff = l.self_attn, l.feed_forward
+            self.layers.append(dict(
+                n1=(l.norm1.weight, l.norm1.bias), n2=(l.norm2.weight, l.norm2.bias),
+                wqkv=_cat([a.linear_q.weight, a.linear_k.weight, a.linear_v.weight]),
+                bqkv=_cat([a.linear_q.bias, a.linear_k.bias, a.linear_v.bias]),
+                wo=a.linear_out.weight, bo=a.linear_out.bias,
+                w1=ff.w_1.weight, b1=ff.w_1.bias, w2=ff.w_2.weight, b2=ff.w_2.bias))
+
+    def start(self, like, N, max_steps):
+        self.N = N
+        self.kpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
+        self.vpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
+
+    def step(self, i, tok, anc):
+        N, D, H, dk = self.N, self.D, self.H, self.dk
+        lm = self.lm
+        e = lm.embed.weight[tok].contiguous()                        # row gather (index plumbing)
+        emb = lm.encoder.embed
+        h = ops.linear(e, emb[0].weight, emb[0].bias)
+        h = ops.layernorm_fwd(h, emb[1].weight, emb[1].bias, EPS, save=False)[0]
+        ops.act_(h, "relu")
+        lo = i * N
+        for li, L in enumerate(self.layers):
+            n1 = ops.layernorm_fwd(h, *L["n1"], EPS, save=False)[0]
+            qkv = ops.linear(n1, L["wqkv"], L["bqkv"])
+            ops.copy2d(qkv[:, D:2 * D], self.kpool[li][lo:lo + N])
+            ops.copy2d(qkv[:, 2 * D:], self.vpool[li][lo:lo + N])
+            a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1, H, dk)
+            h = ops.linear(a, L["wo"], L["bo"], res=h)
+            n2 = ops.layernorm_fwd(h, *L["n2"], EPS, save=False)[0]
+            t = ops.linear(n2, L["w1"], L["b1"], act="relu")
+            h = ops.linear(t, L["w2"], L["b2"], res=h)
+        y = ops.layernorm_fwd(h, lm.encoder.after_norm.weight, lm.encoder.after_norm.bias, EPS, save=False)[0]
+        return ops.log_softmax_rows(ops.linear(y, lm.decoder.weight, lm.decoder.bias))
+
+
+def _end_detect(ended: List[Tuple[int, float]], i: int, M: int = 3, D_end: float = math.log(1 * math.exp(-10))) -> bool:
+    """espnet end_detect on (length, score) pairs of the ended hypotheses of one utterance."""
+    if not ended:
+        return False
+    best = max(s for _, s in ended)
+    count = 0
+    for m in range(M):
+        same = [s for le, s in ended if le == i - m]
+        if same and max(same) - best < D_end:
+            count += 1
+    return count == M
+
+
+class BatchBeamSearch:
+    def __init__(self, model, lm=None, beam_size: int = 10, ctc_weight: float = 0.1, lm_weight: float = 0.6,
+                 penalty: float = 0.5, maxlenratio: float = 0.0, minlenratio: float = 0.0):
+        if model.decoder is None or model.ctc is None:
+            raise ValueError("the hybrid search needs both the attention decoder and the CTC head (0 < ctc_weight < 1)")
+        if not (0.0 < ctc_weight < 1.0):
+            raise NotImplementedError("ctc_weight in (0, 1): the shipped decode recipes (0.1); pure CTC / attention "
+                                      "searches are not built")
+        if maxlenratio != 0.0 or minlenratio != 0.0:
+            raise NotImplementedError("maxlenratio = minlenratio = 0 (end detection), as the shipped decode recipes")
+        self.model, self.lm = model, lm
+        self.K = beam_size
+        self.V = len(model.token_list)
+        self.sos, self.eos = model.sos, model.eos
+        self.w_dec, self.w_ctc = 1.0 - ctc_weight, ctc_weight
+        self.w_lm = lm_weight if lm is not None else 0.0
+        self.w_len = penalty
+        self.C = min(int(1.5 * beam_size), self.V)
+        self.dec_step = _DecoderStep(model.decoder)
+        self.lm_step = _LMStep(lm) if (lm is not None and lm_weight != 0.0) else None
+
+    @torch.no_grad()
+    def decode(self, enc: torch.Tensor, enc_lens: torch.Tensor, nbest: Optional[int] = None):
+        """enc [U, T, D] encoder outputs, enc_lens [U] -> per utterance [(yseq list incl. sos/eos, score), ...] sorted."""
+        U, T, D = enc.shape
+        K, V, C = self.K, self.V, self.C
+        N = U * K
+        dev = enc.device
+        enc = enc.contiguous().float()
+        enc_lens = enc_lens.to(dev).to(torch.int64)
+        lens_h = [int(v) for v in enc_lens.cpu()]
+        maxlen = max(lens_h)
+        steps = maxlen                                             # maxlenratio == 0: at most T tokens per utterance
+        ctc = self.model.ctc
+        logp_ctc = ops.log_softmax_rows(ops.linear(enc.reshape(U * T, D), ctc.ctc_lo.weight, ctc.ctc_lo.bias)).view(U, T, V)
+        self.dec_step.start(enc, enc_lens, N, K, steps)
+        if self.lm_step is not None:
+            self.lm_step.start(enc, N, steps)
+        # running state
+        tok = torch.full((N,), self.sos, dtype=torch.int64, device=dev)
+        yseq = torch.full((N, steps + 2), self.eos, dtype=torch.int64, device=dev)
+        yseq[:, 0] = self.sos
+        score = torch.full((U, K), -float("inf"), device=dev)
+        score[:, 0] = 0.0                                          # one <sos> hypothesis per utterance
+        score = score.view(N)
+        anc = torch.zeros(N, steps, dtype=torch.int32, device=dev)
+        slot_ids = torch.arange(N, dtype=torch.int32, device=dev)
+        r_prev = torch.zeros(N, T, 2, device=dev)
+        s_prev = torch.zeros(N, device=dev)
+        utt_base = (torch.arange(U, device=dev) * K).view(U, 1)
+        ended: List[List[Tuple[List[int], float]]] = [[] for _ in range(U)]
+        ended_ls: List[List[Tuple[int, float]]] = [[] for _ in range(U)]
+        active = [True] * U
+        for i in range(steps):
+            anc[:, i] = slot_ids + i * N
+            full = self.dec_step.step(i, tok, anc) * self.w_dec
+            if self.lm_step is not None:
+                full = full + self.lm_step.step(i, tok, anc) * self.w_lm
+            full = full + self.w_len                                # LengthBonus: 1 per token
+            cand = torch.topk(full, C, dim=-1)[1]                   # pre-beam on the weighted full scores
+            r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, cand, K, i)
+            is_eos_c = cand == self.eos
+            psi = torch.where(is_eos_c, eos_s.unsqueeze(1), psi)
+            psi_abs = torch.where(is_eos_c, eos_abs.unsqueeze(1), psi_abs)
+            ctc_full = torch.full((N, V), LOGZERO, device=dev) - s_prev.unsqueeze(1)
+            ctc_full[:, self.eos] = eos_s
+            ctc_full.scatter_(1, cand, psi)
+            weighted = full + self.w_ctc * ctc_full + score.unsqueeze(1)
+            top_s, top_i = torch.topk(weighted.view(U, K * V), K, dim=-1)
+            prev = (top_i // V + utt_base).view(N)                  # slot the new hypothesis extends
+            new_tok = (top_i % V).view(N)
+            new_score = top_s.view(N)
+            # CTC state of the chosen candidate
+            cidx = (cand[prev] == new_tok.unsqueeze(1)).float().argmax(dim=1)
+            r_prev = r_new[prev, :, :, cidx]
+            s_prev = psi_abs[prev, cidx]
+            yseq = yseq[prev]
+            yseq[:, i + 1] = new_tok
+            anc = anc[prev]
+            tok, score = new_tok, new_score
+            # ended hypotheses / last step / end detection: host bookkeeping on [N]-sized data
+            valid = torch.isfinite(score)
+            ends = (tok == self.eos) & valid
+            tok_h, score_h, valid_h, ends_h = tok.cpu(), score.cpu(), valid.cpu(), ends.cpu()
+            kill = torch.zeros(N, dtype=torch.bool)
+            fetch = []
+            for u in range(U):
+                if not active[u]:
+                    kill[u * K:(u + 1) * K] = True
+                    continue
+                last = i == lens_h[u] - 1
+                for k in range(K):
+                    n = u * K + k
+                    if not bool(valid_h[n]):
+                        continue
+                    if last:          # espnet appends <eos> to EVERY hypothesis of the last iteration (also ended ones)
+                        fetch.append((u, n, i + 3, float(score_h[n])))
+                        kill[n] = True
+                    elif bool(ends_h[n]):
+                        fetch.append((u, n, i + 2, float(score_h[n])))
+                        kill[n] = True
+            if fetch:
+                rows = yseq[torch.tensor([f[1] for f in fetch], device=dev)].cpu()
+                for (u, n, ln, sc), row in zip(fetch, rows):
+                    ys = row[:ln].tolist()
+                    ys[ln - 1] = self.eos
+                    ended[u].append((ys, sc))
+                    ended_ls[u].append((ln, sc))
+            for u in range(U):
+                if not active[u]:
+                    continue
+                running = int((~kill[u * K:(u + 1) * K] & valid_h[u * K:(u + 1) * K]).sum())
+                if _end_detect(ended_ls[u], i) or running == 0 or i == lens_h[u] - 1:
+                    active[u] = False
+                    kill[u * K:(u + 1) * K] = True
+            if kill.any():
+                score = torch.where(kill.to(dev), torch.full_like(score, -float("inf")), score)
+            if not any(active):
+                break
+        out = []
+        for u in range(U):
+            hyps = sorted(ended[u], key=lambda h: h[1], reverse=True)
+            out.append(hyps if nbest is None else hyps[:nbest])
+        return out
+
+
+class Speech2Text:
+    """src/inference/avsr_inference.py:Speech2Text for models that are already built: encode + beam search, results as
+    the reference returns them (:492-518): (text, tokens, token ids without sos/eos/blank, (yseq, score))."""
+
+    def __init__(self, asr_model, lm=None, beam_size: int = 20, ctc_weight: float = 0.5, lm_weight: float = 1.0,
+                 penalty: float = 0.0, nbest: int = 1, maxlenratio: float = 0.0, minlenratio: float = 0.0):
+        self.asr_model = asr_model.eval()
+        self.lm = None if lm is None else lm.eval()
+        self.nbest = nbest
+        self.beam_search = BatchBeamSearch(asr_model, lm, beam_size, ctc_weight, lm_weight, penalty, maxlenratio, minlenratio)
+
+    @torch.no_grad()
+    def __call__(self, *batch):
+        """batch: the tensors of ``asr_model.encode`` (speech, lengths) or (audio, lengths, video, lengths)."""
+        enc, enc_lens = self.asr_model.encode(*batch)
+        if isinstance(enc, tuple):
+            enc = enc[0]
+        results = []
+        for hyps in self.beam_search.decode(enc, enc_lens, nbest=self.nbest):
+            res = []
+            for ys, sc in hyps:
+                token_int = [t for t in ys[1:-1] if t != 0]
+                token = [self.asr_model.token_list[t] for t in token_int]
+                text = "".join(token).replace("<space>", " ")
+                res.append((text, token, token_int, (ys, sc)))
+            results.append(res)
+        return results

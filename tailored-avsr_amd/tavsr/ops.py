@@ -762,6 +762,53 @@ def specaug_mask_(x, fpos=None, flen=None, tpos=None, tlen=None):
     return x
 
 
+# ---------------------------------------------------------------------------------------------- decode steps
+def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None):
+    """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk]."""
+    N = q.shape[0]
+    require_cuda(q, kpool, vpool, anc)
+    assert anc.dtype == torch.int32 and kpool.stride(0) == vpool.stride(0)
+    if out is None:
+        out = empty(N, H * dk, like=q)
+    check(lib().tavsr_tree_attn_step(ptr(q), C.c_int64(q.stride(0)), ptr(kpool), ptr(vpool), C.c_int64(kpool.stride(0)),
+                                     ptr(anc), C.c_int64(anc.stride(0)), int(nkeys), ptr(out), C.c_int64(out.stride(0)), N, H, dk,
+                                     C.c_float(1.0 / (dk ** 0.5)), stream()), "tavsr_tree_attn_step")
+    return out
+
+
+def ctc_prefix_step(logp, lens, r_prev, s_prev, last_tok, cand, K, out_len, blank=0):
+    """-> (r_new [N,T,2,C], psi [N,C], psi_abs [N,C], eos [N], eos_abs [N]); see include/tavsr.h."""
+    U, T, V = logp.shape
+    N, Cn = cand.shape
+    require_cuda(logp, lens, r_prev, s_prev, last_tok, cand)
+    r_new = empty(N, T, 2, Cn, like=logp)
+    psi, psi_abs = empty(N, Cn, like=logp), empty(N, Cn, like=logp)
+    eos, eos_abs = empty(N, like=logp), empty(N, like=logp)
+    check(lib().tavsr_ctc_prefix_step(ptr(logp), ptr(lens), ptr(r_prev), ptr(s_prev), ptr(last_tok), ptr(cand), ptr(r_new),
+                                      ptr(psi), ptr(psi_abs), ptr(eos), ptr(eos_abs), N, K, T, V, Cn, int(out_len), blank,
+                                      stream()), "tavsr_ctc_prefix_step")
+    return r_new, psi, psi_abs, eos, eos_abs
+
+
+def act_(x, act):
+    """x = act(x) in place."""
+    require_cuda(x)
+    assert x.is_contiguous()
+    check(lib().tavsr_act_fwd(ptr(x), ptr(x), C.c_int64(x.numel()), ACT[act], stream()), "tavsr_act_fwd")
+    return x
+
+
+def log_softmax_rows(x, V=None, out=None):
+    M = x.shape[0]
+    V = x.shape[1] if V is None else V
+    require_cuda(x)
+    if out is None:
+        out = empty(M, V, like=x)
+    check(lib().tavsr_log_softmax_rows(ptr(x), C.c_int64(x.stride(0)), ptr(out), C.c_int64(out.stride(0)), M, V, stream()),
+          "tavsr_log_softmax_rows")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- dropout
 # The generator state is ONE uint64 per device, resident in HBM; ``rng_step_begin`` advances it with a kernel (so a
 # captured step graph draws new masks at every replay) and rewinds the per-step site counter, which hands every dropout

@@ -1,0 +1,98 @@
+"""Hybrid CTC/attention beam search + LM.  The oracle restates espnet's BatchBeamSearch and scorers
+(parity unpinned: espnet is not installed and the reference holds no decode fixtures); its CTC prefix scorer is pinned
+here against torch's CTC loss, and the HIP search is compared with it hypothesis by hypothesis."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOKENS_EN, asr_conf, rel_err
+from oracle import beam_search as BS
+from oracle.model import build_asr_oracle, fill_parameters_, synth
+
+LM_KW = dict(pos_enc=None, embed_unit=32, att_unit=64, head=4, unit=128, layer=2, dropout_rate=0.0)
+
+
+def _oracle_models(seed=5):
+    m = build_asr_oracle(asr_conf(num_blocks=2, dec_blocks=2), TOKENS_EN).eval()
+    fill_parameters_(m, seed=seed)
+    lm = BS.TransformerLMOracle(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(lm, seed=seed + 1)
+    return m, lm
+
+
+def test_ctc_prefix_score_of_a_complete_hypothesis_is_the_ctc_log_likelihood():
+    """sum of the prefix scorer's increments along y + <eos> == log p_ctc(y | x) == -ctc_loss (torch)."""
+    m, _ = _oracle_models()
+    x = synth((1, 96, 80), seed=3)
+    with torch.no_grad():
+        enc, _ = m.encode(x, torch.tensor([96]))
+        sc = BS.CTCPrefixScorer(m.ctc, m.eos)
+        sc.batch_init_state(enc[0])
+        y = [5, 9, 9, 14, 3]
+        yseq, state, total = torch.tensor([[m.sos]]), [None], 0.0
+        for tok in y + [m.eos]:
+            ids = torch.tensor([[tok, 1, 2]]) if tok not in (1, 2) else torch.tensor([[tok, 3, 4]])
+            s, st = sc.batch_score_partial(yseq, ids, state, enc[0])
+            total += float(s[0, tok])
+            state = [sc.select_state(st, 0, tok)]
+            yseq = torch.cat([yseq, torch.tensor([[tok]])], dim=1)
+        logp = m.ctc.log_softmax(enc).transpose(0, 1)
+        ref = -torch.nn.functional.ctc_loss(logp, torch.tensor([y]), torch.tensor([logp.size(0)]), torch.tensor([len(y)]),
+                                            blank=0, reduction="sum")
+    assert abs(total - float(ref)) < 1e-3 * abs(float(ref))
+
+
+def test_oracle_beam_search_is_deterministic_and_sorted():
+    m, lm = _oracle_models()
+    x = synth((1, 120, 80), seed=7)
+    with torch.no_grad():
+        enc, _ = m.encode(x, torch.tensor([120]))
+        bs = BS.build_beam_search(m, lm, beam_size=5, ctc_weight=0.3, lm_weight=0.6, penalty=0.5)
+        a, b = bs.forward(enc[0]), bs.forward(enc[0])
+    assert [h.yseq.tolist() for h in a] == [h.yseq.tolist() for h in b]
+    assert all(a[i].score >= a[i + 1].score for i in range(len(a) - 1))
+    assert all(int(h.yseq[0]) == m.sos and int(h.yseq[-1]) == m.eos for h in a)
+    # a hypothesis' score is the weighted sum of its scorers' accumulated scores
+    w = dict(decoder=0.7, ctc=0.3, lm=0.6, length_bonus=0.5)
+    for h in a[:3]:
+        assert abs(sum(w[k] * v for k, v in h.scores.items()) - h.score) < 1e-3 * abs(h.score)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beam,ctc_w,lm_w,pen", [(5, 0.3, 0.6, 0.5), (10, 0.1, 0.6, 0.5), (4, 0.5, 0.0, 0.0)])
+def test_hip_beam_search_matches_oracle(beam, ctc_w, lm_w, pen):
+    from tavsr.inference.beam_search import BatchBeamSearch
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.asr import ASRTask
+    m, lm = _oracle_models()
+    conf = asr_conf(num_blocks=2, dec_blocks=2)
+    conf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**conf)).eval()
+    fill_parameters_(pm, seed=5)
+    plm = TransformerLM(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(plm, seed=6)
+    assert sorted(plm.state_dict().keys()) == sorted(lm.state_dict().keys())
+    pm, plm = pm.cuda(), plm.cuda()
+    x = synth((3, 160, 80), seed=7)
+    lens = torch.tensor([160, 120, 88])
+    with torch.no_grad():
+        enc, olens = m.encode(x, lens)
+        ref = []
+        for u in range(3):
+            bs = BS.build_beam_search(m, lm if lm_w else None, beam, ctc_w, lm_w, pen)
+            ref.append(bs.forward(enc[u, : int(olens[u])]))
+        # LM logits of the product in teacher-forced form == oracle
+        toks = synth((2, 7), seed=1, kind="int", lo=1, hi=40)
+        assert rel_err(plm(toks.cuda())[0].cpu(), lm(toks)[0]) < 1e-4
+        hip = BatchBeamSearch(pm, plm if lm_w else None, beam, ctc_w, lm_w, pen).decode(enc.cuda(), olens.cuda())
+    for u in range(3):
+        assert len(hip[u]) > 0 and len(ref[u]) > 0
+        # best hypothesis: same tokens, same score
+        assert hip[u][0][0] == ref[u][0].yseq.tolist(), (u, hip[u][0], ref[u][0].yseq.tolist())
+        assert abs(hip[u][0][1] - ref[u][0].score) < 2e-4 * abs(ref[u][0].score)
+        # the n-best lists agree (ties aside: compare as score-sorted sets of the top 3)
+        top_h = {tuple(h[0]) for h in hip[u][:3]}
+        top_r = {tuple(h.yseq.tolist()) for h in ref[u][:3]}
+        assert len(top_h & top_r) >= 2, (u, top_h, top_r)
