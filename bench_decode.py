@@ -1,0 +1,164 @@
+"""BASELINE config 5: hybrid CTC/attention beam search (beam 10, ctc 0.1) + Transformer LM (configs/LM/lm-english.yaml:
+16 x 512, 8 heads, lm_weight 0.6, length bonus 0.5) on the tailored AV-Branchformer, synthetic 4 s utterances
+(mel 400 x 80 + 100 lip frames 88 x 88), random-init weights.  Real-time factor = wall time to decode / 4 s of speech.
+
+    python bench_decode.py --gpus 1 --utterances 256 --batch 64
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench_decode.py --gpus N ...
+
+Replicas only: rank r decodes utterances r, r + N, ...; no collective on the data path.  Utterances are
+decoded in batches of ``--batch``; an utterance's latency is the wall time of its batch (encoder + search), its RTF
+that latency / 4 s.  Prints ONE JSON line: value = p50 RTF over all utterances (lower is better), plus the throughput
+RTF (total wall / total audio) and the CPU oracle's RTF on a bounded sample.  bench.py stays the headline benchmark."""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "tailored-avsr_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+T_IN, N_MEL, T_VID, HW, DUR_S = 400, 80, 100, 88, 4.0
+LM_CONF = dict(pos_enc=None, embed_unit=128, att_unit=512, head=8, unit=2048, layer=16, dropout_rate=0.0)
+SEARCH = dict(beam_size=10, ctc_weight=0.1, lm_weight=0.6, penalty=0.5)
+
+
+def make_conf():
+    conf = yaml.safe_load(open(os.path.join(PKG, "configs", "avsr_tailored_transformer_ctc_english.yaml")))
+    conf.update(acoustic_input_size=N_MEL, visual_input_size=None, specaug=None)
+    from tavsr.utils.tokens import CHAR_ENGLISH
+    conf["token_list"] = list(CHAR_ENGLISH)
+    return conf
+
+
+def make_utts(n, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    audio = torch.randn(n, T_IN, N_MEL, generator=g)
+    video = torch.randn(n, T_VID, HW, HW, generator=g)
+    return (audio.to(device), torch.full((n,), T_IN, dtype=torch.int64, device=device), video.to(device),
+            torch.full((n,), T_VID, dtype=torch.int64, device=device))
+
+
+def cpu_baseline(n_utt=1):
+    """oracle (CPU restatement of the reference's decode path) on the host cores, same models and search settings."""
+    from oracle import beam_search as BS
+    from oracle.av import build_avsr_oracle
+    from oracle.model import fill_parameters_
+    conf = make_conf()
+    model = build_avsr_oracle(copy.deepcopy(conf), conf["token_list"]).eval()
+    fill_parameters_(model, seed=1)
+    lm = BS.TransformerLMOracle(len(conf["token_list"]), **LM_CONF).eval()
+    fill_parameters_(lm, seed=2)
+    batch = make_utts(n_utt, 99, "cpu")
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        enc, olens = model.encode(*batch)
+        for u in range(n_utt):
+            BS.build_beam_search(model, lm, SEARCH["beam_size"], SEARCH["ctc_weight"], SEARCH["lm_weight"],
+                                 SEARCH["penalty"]).forward(enc[u, : int(olens[u])])
+    el = time.perf_counter() - t0
+    return {"value": round(el / (n_utt * DUR_S), 4), "unit": "RTF", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_utt} utterance(s) of 4 s, encoder + beam-{SEARCH['beam_size']} + LM on the CPU oracle, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--utterances", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from oracle.model import fill_parameters_
+    from tavsr import dp
+    from tavsr.inference.beam_search import BatchBeamSearch
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.avsr import AVSRTask
+
+    rank, local, world = dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    conf = make_conf()
+    model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf))).eval()
+    fill_parameters_(model, seed=1)          # deterministic synthetic weights (bench only: same values as the CPU baseline)
+    lm = TransformerLM(len(conf["token_list"]), **LM_CONF).eval()
+    fill_parameters_(lm, seed=2)
+    model, lm = model.to(dev), lm.to(dev)
+    search = BatchBeamSearch(model, lm, **SEARCH)
+
+    mine = list(range(rank, args.utterances, world))
+    batches = [mine[i:i + args.batch] for i in range(0, len(mine), args.batch)]
+
+    def run(batch):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            enc, olens = model.encode(*batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hyps = search.decode(enc, olens, nbest=1)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, hyps
+
+    run(make_utts(min(args.batch, 8), 7, dev))      # warm-up (allocator pools, lazy module state)
+    data = [make_utts(len(b), 1234 + rank * 1000 + bi, dev) for bi, b in enumerate(batches)]   # resident in HBM
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    T0 = time.perf_counter()
+    lat, enc_s, dec_s, ntok = [], 0.0, 0.0, 0
+    for b, batch in zip(batches, data):
+        e, d, hyps = run(batch)
+        enc_s += e
+        dec_s += d
+        lat += [e + d] * len(b)
+        ntok += sum(len(h[0][0]) - 2 for h in hyps if h)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - T0
+    stats = torch.tensor([wall, float(len(lat)), enc_s, dec_s, float(ntok)], dtype=torch.float64, device=dev)
+    if world > 1:
+        allw = [torch.zeros_like(stats) for _ in range(world)]
+        torch.distributed.all_gather(allw, stats)
+        lats = [None] * world
+        torch.distributed.all_gather_object(lats, lat)
+        lat = [x for l in lats for x in l]
+        wall = max(float(a[0]) for a in allw)
+        enc_s, dec_s, ntok = (sum(float(a[k]) for a in allw) for k in (2, 3, 4))
+    if rank == 0:
+        rtf = np.array(lat) / DUR_S
+        out = {
+            "metric": "decode_rtf_p50", "value": round(float(np.percentile(rtf, 50)), 4), "unit": "RTF (latency / 4 s)",
+            "n_gpus": world, "higher_is_better": False, "scaling": "replicas", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "utterances": len(lat), "batch": args.batch,
+            "rtf_p90": round(float(np.percentile(rtf, 90)), 4),
+            "throughput_rtf": round(wall / (len(lat) * DUR_S), 6),
+            "utterances_per_s": round(len(lat) / wall, 2), "wall_s": round(wall, 3),
+            "encoder_s": round(enc_s, 3), "search_s": round(dec_s, 3), "tokens_decoded": int(ntok),
+            "config": {"workload": "BASELINE configs[4]: tailored AV-Branchformer 12L + 6L decoder, beam 10, ctc 0.1, "
+                                   "Transformer LM 16x512 (lm 0.6), length bonus 0.5, 4 s utterances, batched search",
+                       "parallelism": f"replicas x{world}"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,19 +144,6 @@ class _LMStep:
         return ops.log_softmax_rows(ops.linear(y, lm.decoder.weight, lm.decoder.bias))
 
 
-def _end_detect(ended: List[Tuple[int, float]], i: int, M: int = 3, D_end: float = math.log(1 * math.exp(-10))) -> bool:
-    """espnet end_detect on (length, score) pairs of the ended hypotheses of one utterance."""
-    if not ended:
-        return False
-    best = max(s for _, s in ended)
-    count = 0
-    for m in range(M):
-        same = [s for le, s in ended if le == i - m]
-        if same and max(same) - best < D_end:
-            count += 1
-    return count == M
-
-
 class BatchBeamSearch:
     def __init__(self, model, lm=None, beam_size: int = 10, ctc_weight: float = 0.1, lm_weight: float = 0.6,
                  penalty: float = 0.5, maxlenratio: float = 0.0, minlenratio: float = 0.0):
@@ -207,9 +194,13 @@ class BatchBeamSearch:
         r_prev = torch.zeros(N, T, 2, device=dev)
         s_prev = torch.zeros(N, device=dev)
         utt_base = (torch.arange(U, device=dev) * K).view(U, 1)
-        ended: List[List[Tuple[List[int], float]]] = [[] for _ in range(U)]
-        ended_ls: List[List[Tuple[int, float]]] = [[] for _ in range(U)]
-        active = [True] * U
+        # host-side bookkeeping, vectorised over utterances ([U] / [N]-sized CPU tensors)
+        lens_c = torch.tensor(lens_h)
+        active = torch.ones(U, dtype=torch.bool)
+        best = torch.full((U,), -float("inf"))                      # best ended score per utterance
+        best_len = torch.full((U, steps + 4), -float("inf"))        # best ended score per (utterance, hypothesis length)
+        D_end = math.log(1 * math.exp(-10))
+        ended_rows, ended_meta = [], []                             # yseq rows (CPU) and (utterance, length, score)
         for i in range(steps):
             anc[:, i] = slot_ids + i * N
             full = self.dec_step.step(i, tok, anc) * self.w_dec
@@ -237,45 +228,42 @@ class BatchBeamSearch:
             yseq[:, i + 1] = new_tok
             anc = anc[prev]
             tok, score = new_tok, new_score
-            # ended hypotheses / last step / end detection: host bookkeeping on [N]-sized data
-            valid = torch.isfinite(score)
-            ends = (tok == self.eos) & valid
-            tok_h, score_h, valid_h, ends_h = tok.cpu(), score.cpu(), valid.cpu(), ends.cpu()
-            kill = torch.zeros(N, dtype=torch.bool)
-            fetch = []
-            for u in range(U):
-                if not active[u]:
-                    kill[u * K:(u + 1) * K] = True
-                    continue
-                last = i == lens_h[u] - 1
-                for k in range(K):
-                    n = u * K + k
-                    if not bool(valid_h[n]):
-                        continue
-                    if last:          # espnet appends <eos> to EVERY hypothesis of the last iteration (also ended ones)
-                        fetch.append((u, n, i + 3, float(score_h[n])))
-                        kill[n] = True
-                    elif bool(ends_h[n]):
-                        fetch.append((u, n, i + 2, float(score_h[n])))
-                        kill[n] = True
-            if fetch:
-                rows = yseq[torch.tensor([f[1] for f in fetch], device=dev)].cpu()
-                for (u, n, ln, sc), row in zip(fetch, rows):
-                    ys = row[:ln].tolist()
-                    ys[ln - 1] = self.eos
-                    ended[u].append((ys, sc))
-                    ended_ls[u].append((ln, sc))
-            for u in range(U):
-                if not active[u]:
-                    continue
-                running = int((~kill[u * K:(u + 1) * K] & valid_h[u * K:(u + 1) * K]).sum())
-                if _end_detect(ended_ls[u], i) or running == 0 or i == lens_h[u] - 1:
-                    active[u] = False
-                    kill[u * K:(u + 1) * K] = True
-            if kill.any():
+            # ended hypotheses, last iteration, end detection (espnet post_process / end_detect per utterance)
+            tok_h, score_h = tok.cpu(), score.cpu()
+            valid = torch.isfinite(score_h).view(U, K) & active.view(U, 1)
+            last = (lens_c - 1 == i).view(U, 1)
+            # espnet appends <eos> to EVERY hypothesis of the last iteration (also to the ones that just ended)
+            take = valid & ((tok_h.view(U, K) == self.eos) | last)
+            if bool(take.any()):
+                idx = take.view(N).nonzero().view(-1)
+                rows = yseq[idx.to(dev)].cpu()
+                us = idx // K
+                lns = torch.where(last.view(U)[us], torch.full_like(us, i + 3), torch.full_like(us, i + 2))
+                scs = score_h[idx]
+                for r, u_, ln, sc in zip(rows, us.tolist(), lns.tolist(), scs.tolist()):
+                    ended_rows.append(r)
+                    ended_meta.append((u_, ln, sc))
+                best.index_reduce_(0, us, scs, "amax")
+                flat = us * best_len.shape[1] + lns
+                best_len.view(-1).index_reduce_(0, flat, scs, "amax")
+            running = (valid & ~take).sum(dim=1)
+            count = torch.zeros(U, dtype=torch.int64)
+            for m in range(3):                                     # end_detect: M = 3 most recent lengths
+                if i - m >= 0:
+                    bl = best_len[:, i - m]
+                    count += (torch.isfinite(bl) & (bl - best < D_end)).to(torch.int64)
+            stop = (count == 3) | (running == 0) | last.view(U)
+            active = active & ~stop
+            kill = (take | ~active.view(U, 1)).view(N)
+            if bool(kill.any()):
                 score = torch.where(kill.to(dev), torch.full_like(score, -float("inf")), score)
-            if not any(active):
+            if not bool(active.any()):
                 break
+        ended = [[] for _ in range(U)]
+        for r, (u_, ln, sc) in zip(ended_rows, ended_meta):
+            ys = r[:ln].tolist()
+            ys[ln - 1] = self.eos
+            ended[u_].append((ys, sc))
         out = []
         for u in range(U):
             hyps = sorted(ended[u], key=lambda h: h[1], reverse=True)
