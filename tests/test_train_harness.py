@@ -101,3 +101,42 @@ def test_training_epoch_on_gpu_model():
     l2 = training(model, [batch, batch], opt, None, 2)
     l3 = training(model, [batch, batch], opt, None, 2)
     assert np.isfinite([l1, l2, l3]).all() and l3 < l1
+
+
+def test_checkpoint_save_load_average_roundtrip(tmp_path):
+    """src/utils/model_checkpoint.py semantics: plain state_dict files, module-wise load, entry-wise mean."""
+    import argparse
+
+    import torch
+    from helpers import TOKENS_EN, asr_conf
+    from oracle.model import fill_parameters_
+    from tavsr.tasks.asr import ASRTask
+    from tavsr.utils import model_checkpoint as MC
+
+    def build(seed):
+        conf = asr_conf(num_blocks=1, dec_blocks=1)
+        conf["token_list"] = TOKENS_EN
+        m = ASRTask.build_model(argparse.Namespace(**conf))
+        fill_parameters_(m, seed=seed)
+        return m
+
+    a, b = build(1), build(2)
+    pa, pb = MC.save_model(str(tmp_path), a, "epoch001"), MC.save_model(str(tmp_path), b, "epoch002")
+    assert pa.endswith("models/model_epoch001.pth")
+    sd = torch.load(pa)
+    assert list(sd.keys()) == list(a.state_dict().keys())
+    c = build(3)
+    MC.average_model(c, [pa, pb])
+    for k, v in c.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert torch.allclose(v, (a.state_dict()[k] + b.state_dict()[k]) / 2, atol=1e-7), k
+    d = build(4)
+    MC.load_e2e(d, ["encoder", "ctc"], pa, ctc_weight=0.1)
+    assert all(torch.equal(v, a.encoder.state_dict()[k]) for k, v in d.encoder.state_dict().items())
+    assert all(torch.equal(v, a.ctc.state_dict()[k]) for k, v in d.ctc.state_dict().items())
+    assert not torch.equal(d.decoder.output_layer.weight, a.decoder.output_layer.weight)
+    MC.freeze_e2e(d, ["encoder", "ctc"], 0.1)
+    assert not any(p.requires_grad for p in d.encoder.parameters())
+    assert all(p.requires_grad for p in d.ctc.parameters())          # the reference's typo: the CTC head stays trainable
+    MC.save_val_stats(str(tmp_path), [(pa, 12.5), (pb, 11.0)])
+    assert open(tmp_path / "val_stats.csv").read().splitlines()[0] == ",model_check_path,cer"
