@@ -334,6 +334,12 @@ int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, tavsr_stream
 int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int64_t step, float grad_scale, tavsr_stream_t stream);
 
+/* Gradient buckets of the data-parallel exchange (tavsr/dp.py): tensor t = n[t] floats at ptrs[t], its slot in
+ * the flat bucket starts at off[t].  to_flat != 0: flat <- tensors (pack before the all-reduce); else tensors <-
+ * scale * flat (unpack, scale = 1 / world_size).  ptrs / off / n are DEVICE arrays; max_n = max n[t] sizes the grid. */
+int tavsr_bucket_copy(float* const* ptrs_dev, const int64_t* off_dev, const int64_t* n_dev, int32_t ntensors, float* flat,
+                      float scale, int32_t to_flat, int64_t max_n, tavsr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Train-mode dropout (every torch Dropout / F.dropout site of the path).  y[i] = keep_i ? x[i] / (1 - p) : 0 where
  * keep_i is a pure function of (seed_dev[0], offset + i) (Philox4x32-10): the SAME call on the upstream gradient is the

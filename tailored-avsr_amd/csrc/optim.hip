@@ -43,6 +43,21 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
   }
 }
 
+// Gradient bucket pack / unpack for the data-parallel exchange (tavsr/dp.py): tensor t (n[t] floats at ptrs[t]) <->
+// flat[off[t] .. off[t] + n[t]).  One launch for a whole bucket of hundreds of parameters: grid (chunks, tensors).
+__global__ __launch_bounds__(256) void bucket_copy_kernel(float* const* __restrict__ ptrs, const int64_t* __restrict__ off,
+                                                          const int64_t* __restrict__ n, float* __restrict__ flat, float scale,
+                                                          int to_flat) {
+  const int t = blockIdx.y;
+  float* p = ptrs[t];
+  float* f = flat + off[t];
+  const int64_t cnt = n[t];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) {
+    if (to_flat) f[i] = p[i];
+    else p[i] = f[i] * scale;
+  }
+}
+
 }  // namespace tavsr
 
 using namespace tavsr;
@@ -59,6 +74,18 @@ extern "C" int tavsr_adam_step(float* p, const float* g, float* m, float* v, int
   const int64_t n4 = n >> 2;
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)std::max<int64_t>(1, (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      p, g, m, v, n4, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_bucket_copy(float* const* ptrs_dev, const int64_t* off_dev, const int64_t* n_dev, int32_t ntensors,
+                                 float* flat, float scale, int32_t to_flat, int64_t max_n, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(ptrs_dev && off_dev && n_dev && flat, TAVSR_EINVAL, "bucket_copy: null pointer");
+  if (ntensors <= 0) return TAVSR_OK;
+  TAVSR_REQUIRE(ntensors <= 65535, TAVSR_EINVAL, "bucket_copy: at most 65535 tensors per launch");
+  const int64_t chunks = std::min<int64_t>(std::max<int64_t>(1, (max_n + 255) / 256), 64);
+  hipLaunchKernelGGL(tavsr::bucket_copy_kernel, dim3((unsigned)chunks, (unsigned)ntensors), dim3(256), 0, (hipStream_t)stream,
+                     ptrs_dev, off_dev, n_dev, flat, scale, to_flat);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

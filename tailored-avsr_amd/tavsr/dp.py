@@ -47,6 +47,7 @@ class GradBuckets:
         if cur:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
+        self._tab, self._flatbuf = {}, {}
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -60,14 +61,22 @@ class GradBuckets:
                 off += p.numel()
 
     def allreduce_mean(self) -> None:
-        """Sum gradients over ranks and divide by the world size (in place on ``p.grad``)."""
+        """Sum gradients over ranks and divide by the world size (in place on ``p.grad``).
+
+        On the GPU a bucket is packed and unpacked by ONE launch each (``tavsr_bucket_copy`` over a pointer table; the
+        1/world average rides on the unpack) and the flat buffers persist across steps; all buckets are packed and their
+        all-reduces issued before the first wait.  CPU tensors (gloo tests) take the torch path."""
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return
         world = dist.get_world_size()
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        if self.params and self.params[0].is_cuda:
+            return self._allreduce_mean_hip(world)
         works = []
         for i, bucket in enumerate(self.buckets):
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            flat = torch.cat([g.reshape(-1) for g in grads])
+            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
             self._flat[i] = flat
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
         for i, bucket in enumerate(self.buckets):
@@ -76,10 +85,39 @@ class GradBuckets:
             flat.mul_(1.0 / world)
             off = 0
             for p in bucket:
-                g = flat[off: off + p.numel()].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
+                p.grad.copy_(flat[off: off + p.numel()].view_as(p))
                 off += p.numel()
             self._flat[i] = None
+
+    def _tables(self, i, bucket):
+        """device pointer / offset / size tables of bucket i; rebuilt only when a gradient tensor moved (under hipGraph
+        replay the gradients are graph-owned buffers: the tables are built once)."""
+        ptrs = [p.grad.data_ptr() for p in bucket]
+        cached = self._tab.get(i)
+        if cached is not None and cached[0] == ptrs:
+            return cached[1:]
+        dev = bucket[0].device
+        sizes = [p.numel() for p in bucket]
+        offs = [0]
+        for n in sizes[:-1]:
+            offs.append(offs[-1] + (n + 3) // 4 * 4)                # 16-byte aligned slots
+        total = offs[-1] + sizes[-1]
+        assert all(p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in bucket)
+        t = tuple(torch.tensor(v, dtype=torch.int64).to(dev) for v in (ptrs, offs, sizes))
+        flat = self._flatbuf.get(i)
+        if flat is None or flat.numel() != total:
+            flat = self._flatbuf[i] = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._tab[i] = (ptrs,) + t + (flat, max(sizes))
+        return t + (flat, max(sizes))
+
+    def _allreduce_mean_hip(self, world):
+        from . import ops
+        works = []
+        for i, bucket in enumerate(self.buckets):
+            ptrs, offs, sizes, flat, mx = self._tables(i, bucket)
+            ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0, True, mx)
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        for i, bucket in enumerate(self.buckets):
+            works[i].wait()
+            ptrs, offs, sizes, flat, mx = self._tables(i, bucket)
+            ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0 / world, False, mx)

@@ -762,6 +762,13 @@ def specaug_mask_(x, fpos=None, flen=None, tpos=None, tlen=None):
     return x
 
 
+def bucket_copy(ptrs, offs, sizes, n, flat, scale, to_flat, max_n):
+    """pack (to_flat) or unpack-and-scale the tensors listed in the device tables into / from ``flat`` (tavsr/dp.py)."""
+    require_cuda(ptrs, offs, sizes, flat)
+    check(lib().tavsr_bucket_copy(ptr(ptrs), ptr(offs), ptr(sizes), int(n), ptr(flat), C.c_float(scale), int(bool(to_flat)),
+                                  C.c_int64(max_n), stream()), "tavsr_bucket_copy")
+
+
 # ---------------------------------------------------------------------------------------------- decode steps
 def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None):
     """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk]."""
