@@ -67,6 +67,15 @@ typedef struct tavsr_gemm_desc {
   float* a_rowsum;                /* optional [M]: alpha * sum_k A(m,k) (nb1*nb2 == 1).  With a_kmajor (weight
                                      gradient dW = dY^T X) this is the bias gradient sum_rows dY - fused, so no
                                      separate column-sum pass over dY is needed */
+  /* implicit 3x3 / stride 1 / pad 1 convolution over a channels-last image X [images*H*W][C] (the ResNet trunk of
+     src/frontend/conv3d_resnet18/modules/resnet.py:89-106), no im2col matrix:
+       conv_mode 1: A is X (row-major, lda = C), K = 9*C: A(m, tap*C + c) = X[m + (tap/3-1)*W + (tap%3-1)][c], 0 outside
+                    the image - forward with B = weights [Cout][9*C], data gradient with B = flipped weights;
+       conv_mode 2: B is X (k-major, ldb = C), N = 9*C, a_kmajor: weight gradient dW[co][tap*C + c] = sum_m dY[m][co] *
+                    patch(m, tap, c).
+     conv_zero: >= 16 readable zero bytes (16-byte aligned) that out-of-image loads are pointed at.  0: plain GEMM. */
+  int32_t conv_mode, conv_H, conv_W, conv_C;
+  const float* conv_zero;
 } tavsr_gemm_desc;
 
 int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);
@@ -273,6 +282,9 @@ int tavsr_avgpool_fwd(const float* x, float* y, int64_t N, int32_t P, int32_t C,
 int tavsr_avgpool_bwd(const float* dy, float* dx, int64_t N, int32_t P, int32_t C, tavsr_stream_t stream);
 int tavsr_fill(float* p, float value, int64_t n, tavsr_stream_t stream);
 /* dst[m*ldd + n] = src[m*lds + n], m < M, n < N (no alignment requirement) */
+/* data-gradient weights of a 3x3 convolution for the implicit GEMM (tavsr_gemm_desc.conv_mode 1 on dY):
+ * wflip[ci][tap*Cout + co] = w2d[co][(8 - tap)*Cin + ci],  w2d = [Cout][9*Cin] */
+int tavsr_conv_wflip(const float* w2d, float* wflip, int32_t Cout, int32_t Cin, tavsr_stream_t stream);
 int tavsr_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int64_t N, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -497,7 +497,13 @@ __device__ unsigned int g_trace_n;
 
 // KW > 1: the k-groups of every K-step are dealt to KW wave sets (intra-block K split, summed through LDS at the end):
 // a lone 64x64 tile on a CU then runs 2 waves per SIMD with half the dependent-MFMA chain per K-step each.
-template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM, int KW = 1>
+// CONV (implicit 3x3 / stride 1 / pad 1 convolution over a channels-last image, no im2col matrix in HBM):
+//   1: the A operand is the image X [n*H*W][C]; A(m, k = tap*C + c) = X[m + (tap/3-1)*W + (tap%3-1)][c] inside the
+//      image, 0 outside (forward and data gradient).  Per K-step the tap is uniform, so the row offsets of the plain
+//      loader move by one scalar and out-of-image rows are pointed at a zero page.
+//   2: the k-major B operand is the image (weight gradient dW = dY^T patches): B(k = m, n = tap*C + c); a 64-wide n
+//      tile lies in one tap, validity is per k row.
+template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM, int KW = 1, int CONV = 0>
 __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid) {
   constexpr int BK = 32, NG = BK / 8;
   static_assert(NG % KW == 0, "k-groups must divide over the wave sets");
@@ -553,9 +559,45 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
   LB::offsets(d.ldb, n0, d.N, tid, offB);
   const float* Ak = A + (AK ? (int64_t)kbeg * d.lda : kbeg);
   const float* Bk = B + (BKM ? (int64_t)kbeg * d.ldb : kbeg);
+  uint32_t cmask[LA::NR];               // CONV 1: bit tap = the tap's neighbour of this thread's row is inside the image
+  if (CONV == 1) {
+#pragma unroll
+    for (int i = 0; i < LA::NR; ++i) {
+      const int m = min(m0 + ((i * NT + tid) >> 3), d.M - 1);
+      const int x = m % d.conv_W, y = (m / d.conv_W) % d.conv_H;
+      uint32_t mk = 0;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        mk |= (uint32_t)((unsigned)(y + tap / 3 - 1) < (unsigned)d.conv_H && (unsigned)(x + tap % 3 - 1) < (unsigned)d.conv_W) << tap;
+      cmask[i] = mk;
+    }
+  }
   auto issue = [&](int kt, int st) {
-    LA::issue(Ak + kt * kstepA, offA, smem + st * STAGE, wave);
-    LB::issue(Bk + kt * kstepB, offB, smem + st * STAGE + ASZ, wave);
+    if (CONV == 1) {
+      const int kk = kbeg + kt * BK, tap = kk / d.conv_C;
+      const int64_t delta = (int64_t)((tap / 3 - 1) * d.conv_W + (tap % 3 - 1)) * d.conv_C + (kk - tap * d.conv_C);
+#pragma unroll
+      for (int i = 0; i < LA::NR; ++i) {
+        const float* src = ((cmask[i] >> tap) & 1u) ? A + offA[i] + delta : d.conv_zero;
+        __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + (i * NT + wave * 64) * 4), 16, 0, 0);
+      }
+    } else {
+      LA::issue(Ak + kt * kstepA, offA, smem + st * STAGE, wave);
+    }
+    if (CONV == 2) {
+      const int tap = n0 / d.conv_C, cb = n0 - tap * d.conv_C, dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+      for (int i = 0; i < LB::NR; ++i) {
+        const int q = i * NT + tid;
+        const int m = kbeg + kt * BK + q / (BN / 4), r = (q % (BN / 4)) * 4;
+        const int x = m % d.conv_W, y = (m / d.conv_W) % d.conv_H;
+        const bool ok = (unsigned)(y + dy) < (unsigned)d.conv_H && (unsigned)(x + dx) < (unsigned)d.conv_W;
+        const float* src = ok ? B + (int64_t)(m + dy * d.conv_W + dx) * d.conv_C + cb + r : d.conv_zero;
+        __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + ASZ + (i * NT + wave * 64) * 4), 16, 0, 0);
+      }
+    } else {
+      LB::issue(Bk + kt * kstepB, offB, smem + st * STAGE + ASZ, wave);
+    }
   };
   const int arow = wm * TM * 32 + lr, brow = wn * TN * 32 + lr;
   auto compute = [&](int st) {
@@ -666,10 +708,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM, int KW = 1>
+template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM, int KW = 1, int CONV = 0>
 __global__ __launch_bounds__(WM* WN * KW * 64, MINW)
 void gemm_glds_kernel(const GemmArgs args) {
-  glds_tile<BM, BN, WM, WN, S, AK, BKM, KW>(args.d, args.kchunk, args.nsplit, args.tiles_n, xcd_remap(blockIdx.x, gridDim.x));
+  glds_tile<BM, BN, WM, WN, S, AK, BKM, KW, CONV>(args.d, args.kchunk, args.nsplit, args.tiles_n,
+                                                  xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Grouped launch: up to kMaxGroup independent problems of one layout share ONE grid (tile ranges by prefix sums).
@@ -746,6 +789,20 @@ static int launch_glds(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
     return (int)TAVSR_OK;
   });
   return rc ? rc : launch_epilogue(a, s);
+}
+
+// implicit-convolution launches (two-stage 64x64 variant): mode 1 = A patches (NT / NN), mode 2 = B patches (TN)
+static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStream_t s) {
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64)};
+  dim3 grid(a.tiles_m * a.tiles_n, 1, nsplit);
+  if (d.conv_mode == 1 && !d.b_kmajor)
+    hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, false, false, 1, 1>), grid, dim3(256), 0, s, a);
+  else if (d.conv_mode == 1)
+    hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, false, true, 1, 1>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, true, true, 1, 2>), grid, dim3(256), 0, s, a);
+  TAVSR_LAUNCH_CHECK();
+  return launch_epilogue(a, s);
 }
 
 static int launch_fallback(const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
@@ -839,6 +896,24 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
                    d.sA2 % 4 == 0 && d.sB1 % 4 == 0 && d.sB2 % 4 == 0;
   const bool can_split = d.ws != nullptr;
   const bool fast = glds_ok(d, vec);
+  if (d.conv_mode != 0) {       // implicit 3x3/s1/p1 convolution: only the LDS-DMA kernel reads images as patch operands
+    TAVSR_REQUIRE(d.conv_mode == 1 || d.conv_mode == 2, TAVSR_EINVAL, "tavsr_gemm: conv_mode must be 0, 1 or 2");
+    TAVSR_REQUIRE(d.conv_zero && aligned16(d.conv_zero) && d.conv_H > 0 && d.conv_W > 0 && d.conv_C > 0, TAVSR_EINVAL,
+                  "tavsr_gemm: conv needs H, W, C and a 16-byte aligned zero page");
+    TAVSR_REQUIRE(d.nb1 * d.nb2 == 1 && fast && force_cfg < 0, TAVSR_EUNSUPPORTED,
+                  "tavsr_gemm: conv operands need an unbatched, aligned problem with K %% 32 == 0");
+    const int64_t pixels = d.conv_mode == 1 ? d.M : d.K;
+    TAVSR_REQUIRE(pixels % ((int64_t)d.conv_H * d.conv_W) == 0, TAVSR_EINVAL, "tavsr_gemm: conv rows are not whole images");
+    if (d.conv_mode == 1)
+      TAVSR_REQUIRE(!d.a_kmajor && d.K == 9 * d.conv_C && d.conv_C % 32 == 0 && d.lda == d.conv_C, TAVSR_EUNSUPPORTED,
+                    "tavsr_gemm: conv mode 1 needs a row-major image operand A, K = 9 C, C %% 32 == 0");
+    else
+      TAVSR_REQUIRE(d.a_kmajor && d.b_kmajor && d.N == 9 * d.conv_C && d.conv_C % 64 == 0 && d.ldb == d.conv_C,
+                    TAVSR_EUNSUPPORTED, "tavsr_gemm: conv mode 2 needs the TN layout, N = 9 C, C %% 64 == 0");
+    Plan pc = plan(d, can_split, true);
+    if (pc.nsplit > 1 && d.ws_floats < ws_floats_for(d, pc.nsplit)) pc = plan(d, false, true);
+    return launch_conv(d, pc.nsplit, pc.kchunk, s);
+  }
   Plan p = plan(d, can_split, fast);
   if (force_cfg >= 0) {
     TAVSR_REQUIRE(force_cfg < kNumCfgs || force_cfg == kFallbackCfg, TAVSR_EINVAL, "tavsr_gemm_tune: cfg %d out of range",

@@ -309,6 +309,18 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds, float*
   dst[m * ldd + n] = src[m * lds + n];
 }
 
+// weights of the data-gradient convolution: wflip[ci][tap'*Cout + co] = w2d[co][(8 - tap')*Cin + ci]
+// (w2d = [Cout][9*Cin] tap-major GEMM weight of a 3x3 convolution; the transposed convolution visits the taps mirrored)
+__global__ void conv_wflip_kernel(const float* __restrict__ w2d, float* __restrict__ wflip, int Cout, int Cin) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  const int tap = (int)((i / Cout) % 9);
+  const int ci = (int)(i / ((int64_t)Cout * 9));
+  wflip[i] = w2d[(int64_t)co * 9 * Cin + (int64_t)(8 - tap) * Cin + ci];
+}
+
 __global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -467,6 +479,13 @@ extern "C" int tavsr_copy2d(const float* src, int64_t lds, float* dst, int64_t l
   TAVSR_REQUIRE((src && dst) || M * N <= 0, TAVSR_EINVAL, "copy2d: null pointer");
   if (M * N <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(copy2d_kernel, grid1d(M * N), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, N, M * N);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_conv_wflip(const float* w2d, float* wflip, int32_t Cout, int32_t Cin, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(w2d && wflip && Cout > 0 && Cin > 0, TAVSR_EINVAL, "conv_wflip: bad arguments");
+  hipLaunchKernelGGL(conv_wflip_kernel, grid1d((int64_t)Cout * Cin * 9), dim3(256), 0, (hipStream_t)stream, w2d, wflip, Cout, Cin);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

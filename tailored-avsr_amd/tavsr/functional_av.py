@@ -47,6 +47,15 @@ def _w2d_grad(g, shape):
     return ops.transpose_inner(g, co, kh * kw, ci).view(shape)
 
 
+def _conv3x3_dw(dz, x, N, H, W, cin):
+    """weight gradient of a 3x3/s1/p1 convolution [Cout, 9*Cin]: implicit GEMM when the pixel count gives whole
+    32-row K-steps (every BASELINE shape), else through the im2col matrix."""
+    if (N * H * W) % 32 == 0:
+        return ops.conv3x3_dw(dz, x, H, W)
+    col, _, _ = ops.im2col2d(x, N, H, W, cin, 3, 3, 1, 1)
+    return ops.linear_dw(dz, col)
+
+
 class _BN:
     """(mean, rstd) for a [M,C] matrix: batch statistics (+ running update) in training, running statistics in eval."""
 
@@ -95,17 +104,19 @@ class VisualFrontendFn(torch.autograd.Function):
                 stride = 2 if (li > 1 and bi == 0) else 1
                 has_ds = (pre + "downsample.0.weight") in p
                 Xin, Hin, Win = cur, Hc, Wc
-                col1, Ho, Wo = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
                 w1 = _w2d(p[pre + "conv1.weight"])
-                z1 = ops.linear(col1, w1)
-                del col1
+                if stride == 1:       # implicit GEMM: the image itself is the A operand (no im2col matrix)
+                    Ho, Wo = Hin, Win
+                    z1 = ops.conv3x3_fwd(Xin, w1, Hin, Win)
+                else:
+                    col1, Ho, Wo = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
+                    z1 = ops.linear(col1, w1)
+                    del col1
                 m1, r1 = _BN.stats(z1, pre + "bn1.", bufs, training)
                 y1 = ops.bn_apply_fwd(z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
-                col2, _, _ = ops.im2col2d(y1, N, Ho, Wo, planes, 3, 3, 1, 1)
-                del y1
                 w2 = _w2d(p[pre + "conv2.weight"])
-                z2 = ops.linear(col2, w2)
-                del col2
+                z2 = ops.conv3x3_fwd(y1, w2, Ho, Wo)
+                del y1
                 m2, r2 = _BN.stats(z2, pre + "bn2.", bufs, training)
                 ds = None
                 if has_ds:
@@ -140,21 +151,21 @@ class VisualFrontendFn(torch.autograd.Function):
             dres, dz2, G[pre + "bn2.weight"], G[pre + "bn2.bias"] = ops.bn_bwd(
                 d, z2, m2, r2, p[pre + "bn2.weight"], p[pre + "bn2.bias"], res, "swish")
             y1 = ops.bn_apply_fwd(z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
-            col2, _, _ = ops.im2col2d(y1, N, Ho, Wo, planes, 3, 3, 1, 1)
+            G[pre + "conv2.weight"] = _w2d_grad(_conv3x3_dw(dz2, y1, N, Ho, Wo, planes), p[pre + "conv2.weight"].shape)
             del y1
-            G[pre + "conv2.weight"] = _w2d_grad(ops.linear_dw(dz2, col2), p[pre + "conv2.weight"].shape)
-            del col2
-            dcol2 = ops.linear_dx(dz2, w2)
-            dy1 = ops.col2im2d(dcol2, N, Ho, Wo, planes, 3, 3, 1, 1)
-            del dcol2
+            dy1 = ops.conv3x3_dx(dz2, ops.conv_wflip(w2, planes, planes), Ho, Wo)
             _, dz1, G[pre + "bn1.weight"], G[pre + "bn1.bias"] = ops.bn_bwd(
                 dy1, z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
-            col1, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
-            G[pre + "conv1.weight"] = _w2d_grad(ops.linear_dw(dz1, col1), p[pre + "conv1.weight"].shape)
-            del col1
-            dcol1 = ops.linear_dx(dz1, w1)
-            dX = ops.col2im2d(dcol1, N, Hin, Win, cin, 3, 3, stride, 1)
-            del dcol1
+            if stride == 1:
+                G[pre + "conv1.weight"] = _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin), p[pre + "conv1.weight"].shape)
+                dX = ops.conv3x3_dx(dz1, ops.conv_wflip(w1, planes, cin), Hin, Win)
+            else:
+                col1, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
+                G[pre + "conv1.weight"] = _w2d_grad(ops.linear_dw(dz1, col1), p[pre + "conv1.weight"].shape)
+                del col1
+                dcol1 = ops.linear_dx(dz1, w1)
+                dX = ops.col2im2d(dcol1, N, Hin, Win, cin, 3, 3, stride, 1)
+                del dcol1
             if ds is not None:
                 zd, md, rd, wd = ds
                 _, dzd, G[pre + "downsample.1.weight"], G[pre + "downsample.1.bias"] = ops.bn_bwd(

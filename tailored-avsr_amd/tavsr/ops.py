@@ -74,10 +74,20 @@ def sync_counters(device) -> torch.Tensor:
     return t
 
 
+_ZERO = {}
+
+
+def _zero_page(device) -> torch.Tensor:
+    z = _ZERO.get(device)
+    if z is None:
+        z = _ZERO[device] = torch.zeros(64, dtype=f32, device=device)
+    return z
+
+
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
-         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, force=None):
+         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, conv=None, force=None):
     """Raw descriptor call; offsets are in elements into the given tensors.  ``force=(cfg, nsplit)`` bypasses
     the planner (tuning / tests)."""
     require_cuda(A, B, Cc, bias, Z, R, DZ, a_rowsum)
@@ -101,6 +111,9 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.DZ, d.dact = _addr(DZ, c_off), ACT[dact]
     if a_rowsum is not None:
         d.a_rowsum = a_rowsum.data_ptr()
+    if conv is not None:       # (mode, H, W, C): implicit 3x3/s1/p1 convolution operand (include/tavsr.h)
+        d.conv_mode, d.conv_H, d.conv_W, d.conv_C = conv
+        d.conv_zero = _zero_page(Cc.device).data_ptr()
     if force is not None and force[1] > 1:
         need = force[1] * max(1, nb1) * max(1, nb2) * M * N + force[1] * M
     else:
@@ -695,6 +708,40 @@ def avgpool_bwd(dy, N, P, Cn):
     dx = empty(N * P, Cn, like=dy)
     check(lib().tavsr_avgpool_bwd(ptr(dy), ptr(dx), C.c_int64(N), P, Cn, stream()), "tavsr_avgpool_bwd")
     return dx
+
+
+def conv_wflip(w2d, cout, cin):
+    require_cuda(w2d)
+    out = empty(cin, 9 * cout, like=w2d)
+    check(lib().tavsr_conv_wflip(ptr(w2d), ptr(out), cout, cin, stream()), "tavsr_conv_wflip")
+    return out
+
+
+def conv3x3_fwd(x, w2d, H, W):
+    """implicit 3x3/s1/p1 convolution: x [pixels, Cin] channels-last image rows, w2d [Cout, 9*Cin] -> [pixels, Cout]."""
+    M, cin = x.shape
+    cout = w2d.shape[0]
+    z = empty(M, cout, like=x)
+    gemm(M, cout, 9 * cin, x, cin, w2d, 9 * cin, z, cout, conv=(1, H, W, cin))
+    return z
+
+
+def conv3x3_dx(dz, wflip, H, W):
+    """data gradient: dz [pixels, Cout], wflip [Cin, 9*Cout] (conv_wflip) -> [pixels, Cin]."""
+    M, cout = dz.shape
+    cin = wflip.shape[0]
+    dx = empty(M, cin, like=dz)
+    gemm(M, cin, 9 * cout, dz, cout, wflip, 9 * cout, dx, cin, conv=(1, H, W, cout))
+    return dx
+
+
+def conv3x3_dw(dz, x, H, W):
+    """weight gradient: dz [pixels, Cout], x [pixels, Cin] -> [Cout, 9*Cin]; needs pixels % 32 == 0."""
+    M, cout = dz.shape
+    cin = x.shape[1]
+    dw = empty(cout, 9 * cin, like=dz)
+    gemm(cout, 9 * cin, M, dz, cout, x, cin, dw, 9 * cin, a_kmajor=True, b_kmajor=True, conv=(2, H, W, cin))
+    return dw
 
 
 def fill_(t, value):

@@ -313,3 +313,32 @@ def test_av_realistic_size_vs_oracle_cfg3():
     binding = (top2[..., 0] - top2[..., 1]) > 1e-4
     ids, hyp, hl = model.ctc.greedy(eg, og)
     assert torch.equal(ids.cpu()[binding], logits.argmax(-1)[binding])
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 22, 22, 64, 64), (3, 11, 11, 128, 128), (5, 6, 6, 256, 256), (32, 3, 3, 512, 512),
+                                            (1, 7, 5, 64, 128)])
+def test_implicit_conv3x3_vs_conv2d(N, H, W, Cin, Cout):
+    """tavsr_gemm conv_mode 1 / 2 (no im2col matrix) against torch conv2d fp32 on the CPU: forward, data gradient,
+    weight gradient; the weight gradient needs whole 32-pixel K-steps."""
+    from tavsr import ops
+    from tavsr.functional_av import _w2d, _w2d_grad
+    torch.manual_seed(0)
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)
+    dz = torch.randn(N, Cout, H, W)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    zr = torch.nn.functional.conv2d(xr, wr, padding=1)
+    zr.backward(dz)
+    xl = x.permute(0, 2, 3, 1).reshape(N * H * W, Cin).contiguous().cuda()
+    dzl = dz.permute(0, 2, 3, 1).reshape(N * H * W, Cout).contiguous().cuda()
+    w2d = _w2d(w.cuda())
+    z = ops.conv3x3_fwd(xl, w2d, H, W)
+    assert rel_err(z.cpu().view(N, H, W, Cout).permute(0, 3, 1, 2), zr) < 2e-5
+    dx = ops.conv3x3_dx(dzl, ops.conv_wflip(w2d, Cout, Cin), H, W)
+    assert rel_err(dx.cpu().view(N, H, W, Cin).permute(0, 3, 1, 2), xr.grad) < 2e-5
+    if (N * H * W) % 32 == 0:
+        dw = _w2d_grad(ops.conv3x3_dw(dzl, xl, H, W), w.shape)
+        assert rel_err(dw.cpu(), wr.grad) < 2e-5
+    else:
+        with pytest.raises(Exception):
+            ops.conv3x3_dw(dzl, xl, H, W)
