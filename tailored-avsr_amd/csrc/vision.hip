@@ -85,30 +85,38 @@ __global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restric
 
 // ---- BatchNorm (training mode: batch statistics over the M rows of [M, C]) ----------------------------------
 // stage 1: per-block partial column sums of (x - shift)^p, p = 1 (shift = 0) or 2 (shift = mean): part[blk][C]
+// thread = 4 channels (16-byte loads) x one of 16 row lanes; a block covers 64 channels
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ shift,
                                                          int64_t M, int C, int64_t rows_per_block, int square,
                                                          float* __restrict__ part) {
-  __shared__ float red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  __shared__ float4 red[16][16];
+  const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cq * 4;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  float s0 = 0.f, s1 = 0.f;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
   if (c < C) {
-    const float sh = shift ? shift[c] : 0.f;
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto acc = [&](float4& s, const float4 v) {
+      const float a = v.x - sh.x, b = v.y - sh.y, cc = v.z - sh.z, d = v.w - sh.w;
+      s.x += square ? a * a : a; s.y += square ? b * b : b; s.z += square ? cc * cc : cc; s.w += square ? d * d : d;
+    };
     int64_t r = r0 + ry;
-    for (; r + 4 < r1; r += 8) {
-      float a = x[r * C + c] - sh, b = x[(r + 4) * C + c] - sh;
-      s0 += square ? a * a : a;
-      s1 += square ? b * b : b;
+    for (; r + 16 < r1; r += 32) {
+      const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
+      const float4 b = *reinterpret_cast<const float4*>(x + (r + 16) * C + c);
+      acc(s0, a);
+      acc(s1, b);
     }
-    for (; r < r1; r += 4) {
-      float a = x[r * C + c] - sh;
-      s0 += square ? a * a : a;
-    }
+    for (; r < r1; r += 16) acc(s0, *reinterpret_cast<const float4*>(x + r * C + c));
   }
-  red[ry][cx] = s0 + s1;
+  red[ry][cq] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
   __syncthreads();
-  if (ry == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+  if (ry == 0 && c < C) {
+    float4 t = red[0][cq];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 u = red[k][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + c) = t;
+  }
 }
 
 // stage 2 (one block per 64 channels, 16 part-groups of 64 lanes; partials summed in double, fixed order):
@@ -177,29 +185,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ res, float* __restrict__ dz,
                                                             int64_t M, int C, int64_t rows_per_block, int act,
                                                             float* __restrict__ part) {
-  __shared__ float red[4][2][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  __shared__ float4 red[16][2][16];
+  const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;      // 4 channels x one of 16 row lanes (16-byte accesses)
+  const int c = blockIdx.x * 64 + cq * 4;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  float sb = 0.f, sg = 0.f;
+  float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
   if (c < C) {
-    const float mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
-    for (int64_t r = r0 + ry; r < r1; r += 4) {
-      const float xh = (x[r * C + c] - mu) * rs;
-      float z = xh * g + b;
-      if (res) z += res[r * C + c];
-      const float d = dy[r * C + c] * act_bwd(act, z);
-      dz[r * C + c] = d;
-      sb += d;
-      sg += d * xh;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+    auto one = [&](float xv, float rv, float dv, float m_, float r_, float g_, float b_, float& osb, float& osg) {
+      const float xh = (xv - m_) * r_;
+      const float d = dv * act_bwd(act, xh * g_ + b_ + rv);
+      osb += d;
+      osg += d * xh;
+      return d;
+    };
+    for (int64_t r = r0 + ry; r < r1; r += 16) {
+      const int64_t o = r * C + c;
+      const float4 xv = *reinterpret_cast<const float4*>(x + o), dv = *reinterpret_cast<const float4*>(dy + o);
+      const float4 rv = res ? *reinterpret_cast<const float4*>(res + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 d;
+      d.x = one(xv.x, rv.x, dv.x, mu.x, rs.x, g.x, b.x, sb.x, sg.x);
+      d.y = one(xv.y, rv.y, dv.y, mu.y, rs.y, g.y, b.y, sb.y, sg.y);
+      d.z = one(xv.z, rv.z, dv.z, mu.z, rs.z, g.z, b.z, sb.z, sg.z);
+      d.w = one(xv.w, rv.w, dv.w, mu.w, rs.w, g.w, b.w, sb.w, sg.w);
+      *reinterpret_cast<float4*>(dz + o) = d;
     }
   }
-  red[ry][0][cx] = sb;
-  red[ry][1][cx] = sg;
+  red[ry][0][cq] = sb;
+  red[ry][1][cq] = sg;
   __syncthreads();
-  if (ry == 0 && c < C) {
-    part[((int64_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][cx] + red[1][0][cx]) + (red[2][0][cx] + red[3][0][cx]);
-    part[((int64_t)blockIdx.y * 2 + 1) * C + c] = (red[0][1][cx] + red[1][1][cx]) + (red[2][1][cx] + red[3][1][cx]);
+  if (ry < 2 && c < C) {        // row lane 0 sums dbeta, row lane 1 dgamma (fixed order)
+    float4 t = red[0][ry][cq];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 u = red[k][ry][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2 + ry) * C + c) = t;
   }
 }
 
@@ -377,6 +397,7 @@ extern "C" int tavsr_bn_stats(const float* x, int64_t M, int32_t C, float eps, f
                               tavsr_stream_t stream) {
   TAVSR_REQUIRE(x && mean && var && rstd && ws, TAVSR_EINVAL, "bn_stats: null pointer");
   TAVSR_REQUIRE(M > 0 && C > 0, TAVSR_EINVAL, "bn_stats: empty input");
+  TAVSR_REQUIRE(C % 4 == 0 && ((uintptr_t)x & 15) == 0, TAVSR_EUNSUPPORTED, "bn_stats: C %% 4 == 0 and 16-byte aligned rows required");
   hipStream_t s = (hipStream_t)stream;
   const int chunks = bn_chunks(M);
   const int64_t rpb = (M + chunks - 1) / chunks;

@@ -20,7 +20,8 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch.nn.BatchNorm defaults (conv3d_resnet18
 # visual frontend: Conv3d stem + ResNet-18 trunk  (src/frontend/conv3d_resnet18/conv3d_resnet18.py:77-97,
 # modules/resnet.py:89-106,167-178).  Activations are [N*H*W, C] matrices (N = B*T frames), convolutions are
 # im2col + tavsr_gemm, BatchNorm uses batch statistics in training (running buffers updated in place) and the
-# running statistics in eval.  im2col matrices and BN/Swish outputs are recomputed in backward instead of kept.
+# running statistics in eval.  3x3/stride-1 convolutions are implicit GEMMs (no im2col matrix); the stem patch matrix and the
+# BN/Swish outputs feeding the second convolutions stay resident for the backward pass (HBM is plentiful).
 # ------------------------------------------------------------------------------------------------
 def frontend_param_names() -> List[str]:
     """differentiable parameters of Conv3dResNet18 in the order VisualFrontendFn takes them."""
@@ -89,12 +90,11 @@ class VisualFrontendFn(torch.autograd.Function):
         w0 = ops.fill_(ops.empty(64, 256, like=x), 0.0)
         ops.copy2d(p["frontend3D.0.weight"].reshape(64, 245), w0[:, :245])
         z0 = ops.linear(col0, w0)
-        del col0
         m0, r0 = _BN.stats(z0, "frontend3D.1.", bufs, training)
         y0 = ops.bn_apply_fwd(z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
         cur, idx0, Hc, Wc = ops.maxpool3x3s2_fwd(y0, N, H0, W0, 64)
         del y0
-        saved["stem"] = (x, z0, m0, r0, idx0, H0, W0, w0)
+        saved["stem"] = (x, z0, m0, r0, idx0, H0, W0, w0, col0)     # 288 GB of HBM: the 6 GB patch matrix stays resident
         # ---- trunk
         blocks = []
         cin = 64
@@ -116,7 +116,6 @@ class VisualFrontendFn(torch.autograd.Function):
                 y1 = ops.bn_apply_fwd(z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
                 w2 = _w2d(p[pre + "conv2.weight"])
                 z2 = ops.conv3x3_fwd(y1, w2, Ho, Wo)
-                del y1
                 m2, r2 = _BN.stats(z2, pre + "bn2.", bufs, training)
                 ds = None
                 if has_ds:
@@ -130,7 +129,7 @@ class VisualFrontendFn(torch.autograd.Function):
                 else:
                     res = Xin
                 cur = ops.bn_apply_fwd(z2, m2, r2, p[pre + "bn2.weight"], p[pre + "bn2.bias"], res, "swish")
-                blocks.append((pre, stride, cin, planes, Hin, Win, Ho, Wo, Xin, z1, m1, r1, w1, z2, m2, r2, w2, res, ds))
+                blocks.append((pre, stride, cin, planes, Hin, Win, Ho, Wo, Xin, z1, m1, r1, w1, z2, m2, r2, w2, res, ds, y1))
                 cin, Hc, Wc = planes, Ho, Wo
         feat = ops.avgpool_fwd(cur, N, Hc * Wc, cin)
         ctx.saved, ctx.blocks, ctx.p, ctx.names = saved, blocks, p, names
@@ -146,11 +145,10 @@ class VisualFrontendFn(torch.autograd.Function):
         B, T, N, Hc, Wc, cl = ctx.dims
         G = {}
         d = ops.avgpool_bwd(dfeat.contiguous().view(N, cl), N, Hc * Wc, cl)
-        for (pre, stride, cin, planes, Hin, Win, Ho, Wo, Xin, z1, m1, r1, w1, z2, m2, r2, w2, res, ds) in reversed(ctx.blocks):
+        for (pre, stride, cin, planes, Hin, Win, Ho, Wo, Xin, z1, m1, r1, w1, z2, m2, r2, w2, res, ds, y1) in reversed(ctx.blocks):
             # out = swish(bn2(z2) + res)
             dres, dz2, G[pre + "bn2.weight"], G[pre + "bn2.bias"] = ops.bn_bwd(
                 d, z2, m2, r2, p[pre + "bn2.weight"], p[pre + "bn2.bias"], res, "swish")
-            y1 = ops.bn_apply_fwd(z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
             G[pre + "conv2.weight"] = _w2d_grad(_conv3x3_dw(dz2, y1, N, Ho, Wo, planes), p[pre + "conv2.weight"].shape)
             del y1
             dy1 = ops.conv3x3_dx(dz2, ops.conv_wflip(w2, planes, planes), Ho, Wo)
@@ -179,11 +177,10 @@ class VisualFrontendFn(torch.autograd.Function):
             else:
                 d = ops.axpby(dX, dres, 1.0, 1.0)
         # ---- stem
-        x, z0, m0, r0, idx0, H0, W0, w0 = ctx.saved["stem"]
+        x, z0, m0, r0, idx0, H0, W0, w0, col0 = ctx.saved["stem"]
         dy0 = ops.maxpool3x3s2_bwd(d, idx0, N, H0, W0, 64)
         _, dz0, G["frontend3D.1.weight"], G["frontend3D.1.bias"] = ops.bn_bwd(
             dy0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
-        col0, _, _ = ops.im2col_stem(x)
         gw0 = ops.linear_dw(dz0, col0)            # [64, 256], columns >= 245 are padding
         del col0
         g0 = ops.empty(64, 245, like=gw0)
