@@ -48,7 +48,7 @@ def hbm_traffic(layout_key):
     ak, bkm = {"NT": ("false", "false"), "NN": ("false", "true"), "TN": ("true", "true"), "TT": ("true", "false")}[layout_key[-3:-1]]
     tot = calls = 0.0
     for name, v in json.load(open(path)).items():
-        if "gemm_glds_kernel" in name and name.rstrip(">").split(", ")[-3:-1] == [ak, bkm]:
+        if "gemm_glds_kernel" in name and [t for t in name.rstrip(">").split(", ") if t in ("true", "false")] == [ak, bkm]:
             tot += v["calls"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"])
             calls += v["calls"]
     return round(tot / calls) if calls else None
