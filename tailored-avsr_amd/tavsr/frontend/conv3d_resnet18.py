@@ -71,11 +71,20 @@ class Conv3dResNet18(nn.Module):
     def output_size(self) -> int:
         return self.trunk.layer4[1].conv2.out_channels
 
+    EVAL_CHUNK = 32
+
     def forward(self, speech: torch.Tensor, speech_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """speech (B, T, 88, 88) lip crops -> (B, T, 512) per-frame features."""
         if speech.dim() != 4:
             raise ValueError(f"expected (batch, time, height, width), got {tuple(speech.shape)}")
         params = dict(self.named_parameters())
         cfg = dict(names=self._names, buffers=dict(self.named_buffers()), training=self.training)
-        feats = FA.VisualFrontendFn.apply(speech, cfg, *[params[n] for n in self._names])
+        P = [params[n] for n in self._names]
+        if not self.training and not torch.is_grad_enabled() and speech.shape[0] > self.EVAL_CHUNK:
+            # eval: BatchNorm uses the running statistics, so utterances are independent - decode batches of hundreds
+            # of clips go through in slices (the stem's patch matrix is 197 MB per clip)
+            feats = torch.cat([FA.VisualFrontendFn.apply(speech[i:i + self.EVAL_CHUNK], cfg, *P)
+                               for i in range(0, speech.shape[0], self.EVAL_CHUNK)], dim=0)
+        else:
+            feats = FA.VisualFrontendFn.apply(speech, cfg, *P)
         return feats, speech_lengths

@@ -96,3 +96,40 @@ def test_hip_beam_search_matches_oracle(beam, ctc_w, lm_w, pen):
         top_h = {tuple(h[0]) for h in hip[u][:3]}
         top_r = {tuple(h.yseq.tolist()) for h in ref[u][:3]}
         assert len(top_h & top_r) >= 2, (u, top_h, top_r)
+
+
+@pytest.mark.gpu
+def test_speech2text_from_waveforms_end_to_end():
+    """waveform batch -> log-mel -> encoder -> beam search + LM -> (text, tokens, ids, hyp) as the reference's
+    Speech2Text returns them; the best hypothesis equals the oracle's on the oracle's own encoder output."""
+    from tavsr.inference.beam_search import Speech2Text
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.asr import ASRTask
+    conf = asr_conf(num_blocks=2, dec_blocks=2)
+    conf["input_size"] = None
+    om = build_asr_oracle(conf, TOKENS_EN).eval()
+    fill_parameters_(om, seed=5)
+    olm = BS.TransformerLMOracle(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(olm, seed=6)
+    pconf = asr_conf(num_blocks=2, dec_blocks=2)
+    pconf["input_size"] = None
+    pconf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**pconf)).eval()
+    fill_parameters_(pm, seed=5)
+    plm = TransformerLM(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(plm, seed=6)
+    wav = 0.1 * synth((2, 24000), seed=21, kind="uniform")
+    lens = torch.tensor([24000, 17600])
+    wav[1, 17600:] = 0
+    s2t = Speech2Text(pm.cuda(), plm.cuda(), beam_size=5, ctc_weight=0.3, lm_weight=0.6, penalty=0.5, nbest=2)
+    res = s2t(wav.cuda(), lens.cuda())
+    assert len(res) == 2 and all(1 <= len(r) <= 2 for r in res)
+    with torch.no_grad():
+        enc, olens = om.encode(wav, lens)
+    for u in range(2):
+        text, token, token_int, (ys, sc) = res[u][0]
+        ref = BS.build_beam_search(om, olm, 5, 0.3, 0.6, 0.5).forward(enc[u, : int(olens[u])])
+        assert ys == ref[0].yseq.tolist()
+        assert abs(sc - ref[0].score) < 5e-4 * abs(ref[0].score)
+        assert token_int == [t for t in ys[1:-1] if t != 0] and len(token) == len(token_int)
+        assert text == "".join(token).replace("<space>", " ")
