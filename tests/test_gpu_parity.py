@@ -152,3 +152,64 @@ def test_full_size_vs_oracle_cfg2():
         if float(po[n].grad.abs().max()) > 1e-6:
             worst = max(worst, rel_err(p.grad.cpu(), po[n].grad))
     print("worst grad rel err", worst)
+
+
+def test_full_size_batch_permutation_invariance():
+    """Size-independent property at BASELINE configs[1] size (12L, B=32 x 4 s, ragged): every utterance's encoder output
+    and greedy hypothesis are bit-identical wherever it sits in the batch - each output row of every kernel is a
+    function of its own utterance only, accumulated in a fixed order.  (Invariance to extra padding does NOT hold in the
+    reference itself: the cgMLP's depthwise convolution reads the padded frames, and the subsampled lengths depend on
+    the padded length; neither is asserted.)"""
+    from oracle.model import fill_parameters_, synth
+    from tavsr.tasks.asr import ASRTask
+    model = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=12, dec_blocks=6)))
+    fill_parameters_(model, seed=77)
+    model = model.cuda().eval()
+    B = 32
+    speech = synth((B, 400, 80), seed=5).cuda()
+    slens = torch.tensor([400 - 8 * (i % 13) for i in range(B)]).cuda()
+    for i in range(B):
+        speech[i, int(slens[i]):] = 0
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        e0, l0 = model.encode(speech, slens)
+        ids0, hyp0, hl0 = model.ctc.greedy(e0, l0)
+        e1, l1 = model.encode(speech[perm].contiguous(), slens[perm].contiguous())
+        ids1, hyp1, hl1 = model.ctc.greedy(e1, l1)
+    assert torch.equal(l0[perm], l1)
+    for j in range(B):
+        i = int(perm[j])
+        n = int(l0[i])
+        assert torch.equal(e0[i, :n], e1[j, :n]), (i, j)
+        assert torch.equal(hyp0[i, : int(hl0[i])], hyp1[j, : int(hl1[j])])
+
+
+def test_full_size_training_step_is_bitwise_reproducible():
+    """BASELINE configs[1] size, train mode with the recipe's dropout: two fwd+bwd runs from the same generator state give
+    bit-identical loss and gradients (fixed-order two-stage reductions, no float atomics, also with the two branches
+    on two streams)."""
+    from oracle.model import fill_parameters_, synth
+    from tavsr import ops
+    from tavsr.tasks.asr import ASRTask
+    model = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=12, dec_blocks=6, dropout=0.1)))
+    fill_parameters_(model, seed=3)
+    model = model.cuda().train()
+    B = 32
+    speech = synth((B, 400, 80), seed=6).cuda()
+    slens = torch.tensor([400 - 4 * (i % 20) for i in range(B)]).cuda()
+    text = synth((B, 40), seed=7, kind="int", lo=1, hi=40).cuda()
+    tlens = torch.tensor([40 - (i % 31) for i in range(B)]).cuda()
+    for i, l in enumerate(tlens):
+        text[i, int(l):] = -1
+    runs = []
+    for _ in range(2):
+        ops.manual_seed(11)
+        for p in model.parameters():
+            p.grad = None
+        loss = model(speech, slens, text, tlens)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for (n, _), a, b in zip(model.named_parameters(), runs[0][1], runs[1][1]):
+        assert torch.equal(a, b), n
