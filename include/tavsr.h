@@ -361,6 +361,13 @@ int tavsr_bucket_copy(float* const* ptrs_dev, const int64_t* off_dev, const int6
 int tavsr_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* seed_dev, uint64_t offset,
                   tavsr_stream_t stream);
 int tavsr_rng_advance(uint64_t* seed_dev, tavsr_stream_t stream);
+/* fused forms with the same mask as tavsr_dropout(x = t / dh, same p, seed, offset):
+ *   tavsr_dropout_add    : y = a + alpha * dropout(t)        (x + ff_scale * dropout(f(x)), encoder_layer.py:194,309,314)
+ *   tavsr_dropout_act_bwd: dz = dropout(dh) * act'(z)        (backward of dropout(act(z)), PositionwiseFeedForward) */
+int tavsr_dropout_add(const float* a, const float* t, float* y, int64_t n, float p, float alpha, const uint64_t* seed_dev,
+                      uint64_t offset, tavsr_stream_t stream);
+int tavsr_dropout_act_bwd(const float* dh, const float* z, float* dz, int64_t n, float p, int32_t act,
+                          const uint64_t* seed_dev, uint64_t offset, tavsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -55,8 +55,7 @@ class _FFN:
         t_in = _drop_(h, p)
         if p and p > 0.0:
             t = ops.linear(h, w2, b2)
-            t_out = _drop_(t, p)
-            y = ops.axpby(x, t, 1.0, scale)
+            y, t_out = ops.dropout_add(x, t, p, alpha=scale)       # x + scale * dropout(t), one pass
         else:
             t_out = None
             y = ops.linear(h, w2, b2, alpha=scale, res=x)
@@ -73,7 +72,8 @@ class _FFN:
         if t_in is None:
             dz = ops.linear_dx(dyd, w2, alpha=scale, DZ=z, dact=act)
         else:
-            dz = ops.act_bwd_(_drop_bwd_(ops.linear_dx(dyd, w2, alpha=scale), t_in), z, act)
+            dh = ops.linear_dx(dyd, w2, alpha=scale)
+            dz = ops.dropout_act_bwd(dh, z, act, t_in, out=dh)     # inner mask and act'(z), one pass
         gw1, gb1 = wgrad(dz, n, bias_grad=True)
         dn = ops.linear_dx(dz, w1)
         dx, gln_w, gln_b = ops.layernorm_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
@@ -272,8 +272,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             x2 = ops.axpby(x1, md, 1.0, coeff)
         elif pd > 0.0:                                      # x + coeff * dropout(merge_proj(.))  (:232-300)
             t = ops.linear(m, p("merge_proj.weight"), p("merge_proj.bias"))
-            t_m = _drop_(t, pd)
-            x2 = ops.axpby(x1, t, 1.0, coeff)
+            x2, t_m = ops.dropout_add(x1, t, pd, alpha=coeff)
         else:
             x2 = ops.linear(m, p("merge_proj.weight"), p("merge_proj.bias"), alpha=coeff, res=x1)
         sv["drop"] = (t_cat, t_m)
@@ -638,8 +637,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             tk_r = None
             if pd > 0.0:                                     # x + dropout(self_attn(...))
                 t = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"))
-                tk_r = _drop_(t, pd)
-                x1 = ops.axpby(x, t, 1.0, 1.0)
+                x1, tk_r = ops.dropout_add(x, t, pd)
             else:
                 x1 = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"), res=x)
             s["self"] = (x, m1, r1, n1, qkv, cx, attn, tk_a, tk_r)
@@ -654,8 +652,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             tk_r2 = None
             if pd > 0.0:                                     # x + dropout(src_attn(...))
                 t = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"))
-                tk_r2 = _drop_(t, pd)
-                x2 = ops.axpby(x1, t, 1.0, 1.0)
+                x2, tk_r2 = ops.dropout_add(x1, t, pd)
             else:
                 x2 = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"), res=x1)
             s["src"] = (x1, m2, r2, n2, q2, kv, cx2, attn2, tk_a2, tk_r2)

@@ -296,8 +296,7 @@ class TailoredStreamFn(torch.autograd.Function):
             t_br = None
             if pd > 0.0:                       # residual + coeff * dropout(att)  (encoder_layer.py:196,243)
                 t = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"])
-                t_br = _drop_(t, pd)
-                x2 = ops.axpby(x1, t, 1.0, coeff)
+                x2, t_br = ops.dropout_add(x1, t, pd, alpha=coeff)
             else:
                 x2 = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], alpha=coeff, res=x1)
             sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
@@ -312,8 +311,7 @@ class TailoredStreamFn(torch.autograd.Function):
             t_br = None
             if pd > 0.0:                       # residual + coeff * dropout(cgmlp)  (encoder_layer.py:208,256)
                 t = ops.linear(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"])
-                t_br = _drop_(t, pd)
-                x2 = ops.axpby(x1, t, 1.0, coeff)
+                x2, t_br = ops.dropout_add(x1, t, pd, alpha=coeff)
             else:
                 x2 = ops.linear(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], alpha=coeff, res=x1)
             sv["br"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
@@ -432,7 +430,8 @@ class FusionFn(torch.autograd.Function):
         if t_in is None:
             dz = ops.linear_dx(dy2, w2, DZ=z, dact=cfg["act"])
         else:
-            dz = ops.act_bwd_(_drop_bwd_(ops.linear_dx(dy2, w2), t_in), z, cfg["act"])
+            dh = ops.linear_dx(dy2, w2)
+            dz = ops.dropout_act_bwd(dh, z, cfg["act"], t_in, out=dh)
         gw1, gb1 = ops.linear_dw(dz, m, bias_grad=True)
         dm = ops.linear_dx(dz, w1)
         da, dv, mg = ops.merge_bwd(dm, a2, v2, alens, mp, score, pooled, wts, B, T, lens2=vlens)

@@ -904,3 +904,28 @@ def dropout(x, p: float, out=None, token=None):
     check(lib().tavsr_dropout(ptr(x), ptr(out), C.c_int64(n), C.c_float(token[0]), ptr(rng_state(x.device)),
                               C.c_uint64(token[1]), stream()), "tavsr_dropout")
     return out, token
+
+
+def dropout_add(a, t, p: float, alpha: float = 1.0, out=None):
+    """y = a + alpha * dropout(t, p) in one pass; returns (y, token) - the token is the one ``dropout(t)`` would give."""
+    require_cuda(a, t)
+    assert a.is_contiguous() and t.is_contiguous() and a.numel() == t.numel()
+    if out is None:
+        out = torch.empty_like(a)
+    n = t.numel()
+    token = (float(p), _SITE[0])
+    _SITE[0] += (n + 3) // 4 * 4
+    check(lib().tavsr_dropout_add(ptr(a), ptr(t), ptr(out), C.c_int64(n), C.c_float(p), C.c_float(alpha),
+                                  ptr(rng_state(a.device)), C.c_uint64(token[1]), stream()), "tavsr_dropout_add")
+    return out, token
+
+
+def dropout_act_bwd(dh, z, act, token, out=None):
+    """dz = dropout_mask(dh) * act'(z) with the mask of ``token`` (the site that dropped act(z) in the forward pass)."""
+    require_cuda(dh, z)
+    assert dh.is_contiguous() and z.is_contiguous() and dh.numel() == z.numel()
+    if out is None:
+        out = torch.empty_like(dh)
+    check(lib().tavsr_dropout_act_bwd(ptr(dh), ptr(z), ptr(out), C.c_int64(dh.numel()), C.c_float(token[0]), ACT[act],
+                                      ptr(rng_state(dh.device)), C.c_uint64(token[1]), stream()), "tavsr_dropout_act_bwd")
+    return out

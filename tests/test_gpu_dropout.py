@@ -165,3 +165,27 @@ def test_avsr_model_backward_under_frozen_masks():
         lm = float(loss_at())
     fd = (lp - lm) / (2 * eps)
     assert abs(fd - gnorm) / gnorm < 5e-2, (fd, gnorm)
+
+
+@pytest.mark.gpu
+def test_fused_dropout_kernels_equal_the_unfused_sequence():
+    """dropout_add == dropout then axpby; dropout_act_bwd == dropout (same token) then act'(z) multiply: same masks, and
+    the same roundings up to the order of the two scalings."""
+    from tavsr import ops
+    torch.manual_seed(0)
+    a, t = torch.randn(3168, 256, device="cuda"), torch.randn(3168, 256, device="cuda")
+    ops.manual_seed(5)
+    y, tok = ops.dropout_add(a, t, 0.1, alpha=0.5)
+    ops.manual_seed(5)
+    td, tok2 = ops.dropout(t, 0.1)
+    assert tok == tok2
+    ref = ops.axpby(a, td, 1.0, 0.5)
+    assert torch.equal(y, ref)
+    for act in ("swish", "relu", "gelu"):
+        dh, z = torch.randn(777, 2048, device="cuda"), torch.randn(777, 2048, device="cuda")
+        ops.manual_seed(9)
+        _, tk = ops.dropout(torch.zeros_like(dh), 0.1)
+        dz = ops.dropout_act_bwd(dh, z, act, tk)
+        ref = ops.act_bwd_(ops.dropout(dh, 0.1, token=tk)[0], z, act)
+        assert torch.equal(dz == 0, ref == 0)
+        assert float((dz - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
