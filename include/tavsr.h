@@ -110,6 +110,11 @@ int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t l
 
 /* Column sums out[n] (+)= scale * sum_m x[m*ldx + n]: bias gradients of every Linear, pos_bias_u/v
  * gradients.  ws >= tavsr_colsum_ws(M, N) floats.  Deterministic (two-stage, no atomics). */
+/* main pass only: dx and per-block partials (dgamma | dbeta) at ws[blk*ws_ld + 0..2D), blk < tavsr_layernorm_bwd_ws(M,D)/(2D);
+ * several LayerNorms of one backward node write into one slab and share one tavsr_sum_partials launch */
+int tavsr_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd, float* dx,
+                                int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D, tavsr_stream_t stream);
 int64_t tavsr_colsum_ws(int32_t M, int32_t N);
 int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, float scale, float* out,
                  int32_t accumulate, float* ws, tavsr_stream_t stream);

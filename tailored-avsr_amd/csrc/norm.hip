@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ dx_add, int64_t ldadd,
                                                             float* __restrict__ dx, int64_t lddx,
-                                                            float* __restrict__ part, int M, int D) {
+                                                            float* __restrict__ part, int64_t ld_part, int M, int D) {
   __shared__ float red[4][2][NV * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float4 ag[NV], ab[NV], g[NV];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int c = threadIdx.x; c < 2 * D; c += 256) {
     int which = c / D, col = c % D;
     float s = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
-    part[((int64_t)blockIdx.x * 2 + which) * D + col] = s;
+    part[(int64_t)blockIdx.x * ld_part + (int64_t)which * D + col] = s;
   }
 }
 
@@ -221,13 +221,16 @@ extern "C" int tavsr_layernorm_fwd(const float* x, int64_t ldx, const float* gam
 
 extern "C" int64_t tavsr_layernorm_bwd_ws(int32_t M, int32_t D) { return (int64_t)ln_blocks(M) * 2 * D; }
 
-extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
-                                   const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd,
-                                   float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
-                                   float* ws, int32_t M, int32_t D, tavsr_stream_t stream) {
-  TAVSR_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, TAVSR_EINVAL,
-                "layernorm_bwd: null pointer");
+// main pass only: dx and the per-block partials of (dgamma | dbeta) at ws[blk * ws_ld + (0..2D)); the caller reduces them
+// (tavsr_sum_partials over `tavsr_layernorm_bwd_ws(M, D) / (2 D)` blocks) - lets several LayerNorms of one backward node
+// share ONE reduction launch (ws_ld = total columns of the shared slab).
+extern "C" int tavsr_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                           const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd,
+                                           float* dx, int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D,
+                                           tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, TAVSR_EINVAL, "layernorm_bwd: null pointer");
   TAVSR_REQUIRE(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, TAVSR_EUNSUPPORTED, "layernorm_bwd: unsupported D=%d", D);
+  TAVSR_REQUIRE(ws_ld >= 2 * (int64_t)D, TAVSR_EINVAL, "layernorm_bwd: partial slab rows too short");
   TAVSR_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldadd % 4 == 0 && ((uintptr_t)x % 16 == 0) &&
                     ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) && ((uintptr_t)dx_add % 16 == 0),
                 TAVSR_EALIGN, "layernorm_bwd: rows must be 16-byte aligned");
@@ -236,16 +239,27 @@ extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x
   hipStream_t s = (hipStream_t)stream;
   if (D <= 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, M, D);
+                       ldadd, dx, lddx, ws, ws_ld, M, D);
   else if (D <= 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, M, D);
+                       ldadd, dx, lddx, ws, ws_ld, M, D);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, M, D);
+                       ldadd, dx, lddx, ws, ws_ld, M, D);
   TAVSR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, s, ws, nb, (int64_t)2 * D, dgamma, dbeta,
-                     D, 2 * D, accumulate, 1.f);
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                   const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd,
+                                   float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                                   float* ws, int32_t M, int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dgamma && dbeta, TAVSR_EINVAL, "layernorm_bwd: null pointer");
+  int rc = tavsr_layernorm_bwd_partial(dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx, lddx, ws, 2 * (int64_t)D, M, D,
+                                       stream);
+  if (rc || M <= 0) return rc;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, (hipStream_t)stream, ws, ln_blocks(M),
+                     (int64_t)2 * D, dgamma, dbeta, D, 2 * D, accumulate, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -62,7 +62,7 @@ class _FFN:
         return y, (x, mean, rstd, n, z, h, t_in, t_out)
 
     @staticmethod
-    def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None):
+    def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None, lng=None):
         """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2).  ``grp`` (ops.WgradGroup)
         defers the two weight gradients to the caller's grouped launch."""
         x, mean, rstd, n, z, h, t_in, t_out = saved
@@ -76,7 +76,8 @@ class _FFN:
             dz = ops.dropout_act_bwd(dh, z, act, t_in, out=dh)     # inner mask and act'(z), one pass
         gw1, gb1 = wgrad(dz, n, bias_grad=True)
         dn = ops.linear_dx(dz, w1)
-        dx, gln_w, gln_b = ops.layernorm_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
+        ln_bwd = ops.layernorm_bwd if lng is None else lng.bwd      # lng: the node's shared (dgamma, dbeta) reduction
+        dx, gln_w, gln_b = ln_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
         return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2)
 
 
@@ -305,12 +306,13 @@ class BranchformerLayerFn(torch.autograd.Function):
             G[_I[name]] = g if like is None else g.view_as(like)
 
         grp = ops.WgradGroup()     # every weight gradient of the layer in one grouped launch (flushed at the end)
+        lng = ops.LNGroup()        # ... and the five d=256 LayerNorms' (dgamma, dbeta) partials in one reduction
         dy2 = dy.contiguous().view(M, D)
         x3, fmean, frstd = sv["final"]
-        dx3, g1, g2 = ops.layernorm_bwd(dy2, x3, fmean, frstd, p("norm_final.weight"))
+        dx3, g1, g2 = lng.bwd(dy2, x3, fmean, frstd, p("norm_final.weight"))
         put("norm_final.weight", g1); put("norm_final.bias", g2)
         dx2, gs = _FFN.bwd(dx3, sv["ff"], p("norm_ff.weight"), p("feed_forward.w_1.weight"),
-                           p("feed_forward.w_2.weight"), act, 0.5, grp=grp)
+                           p("feed_forward.w_2.weight"), act, 0.5, grp=grp, lng=lng)
         for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                           "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
             put(n_, g)
@@ -392,14 +394,14 @@ class BranchformerLayerFn(torch.autograd.Function):
             gw_, gb_ = grp.add(dg, n, bias_grad=True)
             put("cgmlp.channel_proj1.0.weight", gw_); put("cgmlp.channel_proj1.0.bias", gb_)
             dn = ops.linear_dx(dg, p("cgmlp.channel_proj1.0.weight"))
-            dx1, g1, g2 = ops.layernorm_bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1)
+            dx1, g1, g2 = lng.bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1)
             put("norm_mlp.weight", g1); put("norm_mlp.bias", g2)
         br.join()
         if has_attn:     # same accumulation order into dx1 as a single stream: cgMLP branch first, then attention
-            dx1, g1, g2 = ops.layernorm_bwd(dn_a, x1, a_mean, a_rstd, p("norm_mha.weight"), dx_add=dx1)
+            dx1, g1, g2 = lng.bwd(dn_a, x1, a_mean, a_rstd, p("norm_mha.weight"), dx_add=dx1)
             put("norm_mha.weight", g1); put("norm_mha.bias", g2)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p("norm_ff_macaron.weight"), p("feed_forward_macaron.w_1.weight"),
-                          p("feed_forward_macaron.w_2.weight"), act, 0.5, grp=grp)
+                          p("feed_forward_macaron.w_2.weight"), act, 0.5, grp=grp, lng=lng)
         for n_, g in zip(("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight",
                           "feed_forward_macaron.w_1.bias", "feed_forward_macaron.w_2.weight",
                           "feed_forward_macaron.w_2.bias"), gs):
@@ -408,6 +410,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             if prm is None:
                 G[i] = None
         grp.flush()
+        lng.flush()
         ctx.sv = None
         ops.join_side()
         return (dx.view(B, T, D), None, None, None, *G)
@@ -681,7 +684,8 @@ class TransformerDecoderFn(torch.autograd.Function):
         dl = dlogits.contiguous().view(M, -1)
         G[an_i + 2], G[an_i + 3] = ops.linear_dw(dl, xn, bias_grad=True)
         dxn = ops.linear_dx(dl, out_w)
-        dx, G[an_i], G[an_i + 1] = ops.layernorm_bwd(dxn, x, mf, rf, an_w)
+        lng = ops.LNGroup(cap=3 * nb + 1)     # all LayerNorms of the decoder: one (dgamma, dbeta) reduction at the end
+        dx, G[an_i], G[an_i + 1] = lng.bwd(dxn, x, mf, rf, an_w)
         dmem = None
         mem2 = ctx.mem2
         for li in reversed(range(nb)):
@@ -694,7 +698,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             s = ctx.saved[li]
             grp = ops.WgradGroup()
             dx2, gs = _FFN.bwd(dx, s["ff"], p("norm3.weight"), p("feed_forward.w_1.weight"), p("feed_forward.w_2.weight"),
-                               "relu", 1.0, grp=grp)
+                               "relu", 1.0, grp=grp, lng=lng)
             for n_, g in zip(("norm3.weight", "norm3.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                               "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
                 put(n_, g)
@@ -719,7 +723,7 @@ class TransformerDecoderFn(torch.autograd.Function):
                 ops.linear_dx(dkv[:, :D], p("src_attn.linear_k.weight"), res=dmem, out=dmem)
             ops.linear_dx(dkv[:, D:], p("src_attn.linear_v.weight"), res=dmem, out=dmem)
             dn2 = ops.linear_dx(dq2, p("src_attn.linear_q.weight"))
-            dx1, g1, g2 = ops.layernorm_bwd(dn2, x1, m2, r2, p("norm2.weight"), dx_add=dx2)
+            dx1, g1, g2 = lng.bwd(dn2, x1, m2, r2, p("norm2.weight"), dx_add=dx2)
             put("norm2.weight", g1); put("norm2.bias", g2)
             # --- self attention
             x0, m1, r1, n1, qkv, cx, attn, tk_a, tk_r = s["self"]
@@ -736,9 +740,10 @@ class TransformerDecoderFn(torch.autograd.Function):
             dn1 = ops.linear_dx(dqkv[:, :D], p("self_attn.linear_q.weight"))
             ops.linear_dx(dqkv[:, D:2 * D], p("self_attn.linear_k.weight"), res=dn1, out=dn1)
             ops.linear_dx(dqkv[:, 2 * D:], p("self_attn.linear_v.weight"), res=dn1, out=dn1)
-            dx, g1, g2 = ops.layernorm_bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1)
+            dx, g1, g2 = lng.bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1)
             put("norm1.weight", g1); put("norm1.bias", g2)
             grp.flush()
+        lng.flush()
         _drop_bwd_(dx, ctx.t_pos)
         G[0] = ops.embed_bwd(ctx.ys_in.contiguous(), dx, math.sqrt(D), P[0].shape[0])
         ctx.saved = None

@@ -376,6 +376,46 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dx_add=None, dx=None):
     return dx, dg, db
 
 
+class LNGroup:
+    """LayerNorm backward passes of one backward node whose (dgamma, dbeta) partials share ONE reduction launch:
+    ``bwd`` runs the main pass (dx is ready when it returns) and parks the per-block partials in a common slab,
+    ``flush`` sums the slab once; the gradient tensors handed out by ``bwd`` are views that are valid after ``flush``.
+    LayerNorms of another shape than the group's first one are reduced immediately (same results either way)."""
+
+    def __init__(self, cap: int = 8):
+        self.CAP = cap
+        self.key, self.slab, self.out, self.k = None, None, None, 0
+
+    def bwd(self, dy, x, mean, rstd, gamma, *, dx_add=None, dx=None):
+        M, D = x.shape
+        if self.key is None:
+            self.key = (M, D)
+            self.nb = lib_i64("tavsr_layernorm_bwd_ws", M, D) // (2 * D)
+            self.slab = empty(self.nb, self.CAP * 2 * D, like=x)
+            self.out = empty(self.CAP * 2 * D, like=x)
+        if (M, D) != self.key or self.k >= self.CAP:
+            return layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=dx_add, dx=dx)
+        require_cuda(dy, x, mean, rstd, gamma, dx_add)
+        if dx is None:
+            dx = empty(M, D, like=x)
+        off = self.k * 2 * D
+        check(lib().tavsr_layernorm_bwd_partial(ptr(dy), C.c_int64(dy.stride(0)), ptr(x), C.c_int64(x.stride(0)), ptr(mean),
+                                                ptr(rstd), ptr(gamma), ptr(dx_add),
+                                                C.c_int64(0 if dx_add is None else dx_add.stride(0)), ptr(dx),
+                                                C.c_int64(dx.stride(0)), C.c_void_p(self.slab.data_ptr() + 4 * off),
+                                                C.c_int64(self.slab.stride(0)), M, D, stream()),
+              "tavsr_layernorm_bwd_partial")
+        self.k += 1
+        return dx, self.out[off: off + D], self.out[off + D: off + 2 * D]
+
+    def flush(self):
+        if self.k:
+            n = self.k * 2 * self.key[1]
+            check(lib().tavsr_sum_partials(ptr(self.slab), self.nb, C.c_int64(self.slab.stride(0)), ptr(self.out), n, 0,
+                                           stream()), "tavsr_sum_partials")
+            self.k = 0
+
+
 # ---------------------------------------------------------------------------------------------- attention glue
 def add_head_bias(q, u, v):
     M, D = q.shape
