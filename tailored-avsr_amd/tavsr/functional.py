@@ -210,9 +210,8 @@ class BranchformerLayerFn(torch.autograd.Function):
             if has_attn:
                 n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mha.weight"), p("norm_mha.bias"), EPS_ESPNET)
                 qkv = ops.empty(M, 3 * D, like=x)
-                ops.linear(n, p("attn.linear_q.weight"), p("attn.linear_q.bias"), out=qkv, out_off=0, ldc=3 * D)
-                ops.linear(n, p("attn.linear_k.weight"), p("attn.linear_k.bias"), out=qkv, out_off=D, ldc=3 * D)
-                ops.linear(n, p("attn.linear_v.weight"), p("attn.linear_v.bias"), out=qkv, out_off=2 * D, ldc=3 * D)
+                ops.linear_group(n, [(p(f"attn.linear_{c}.weight"), p(f"attn.linear_{c}.bias"), j * D)
+                                     for j, c in enumerate("qkv")], qkv)
                 pe2d = pos_emb.reshape(-1, D)
                 pp = ops.linear(pe2d, p("attn.linear_pos.weight"))
                 qu, qv = ops.add_head_bias(qkv[:, :D], p("attn.pos_bias_u").reshape(-1), p("attn.pos_bias_v").reshape(-1))
@@ -632,9 +631,8 @@ class TransformerDecoderFn(torch.autograd.Function):
             # --- masked self attention
             n1, m1, r1 = ops.layernorm_fwd(x, p("norm1.weight"), p("norm1.bias"), EPS_ESPNET)
             qkv = ops.empty(M, 3 * D, like=x)
-            ops.linear(n1, p("self_attn.linear_q.weight"), p("self_attn.linear_q.bias"), out=qkv, out_off=0, ldc=3 * D)
-            ops.linear(n1, p("self_attn.linear_k.weight"), p("self_attn.linear_k.bias"), out=qkv, out_off=D, ldc=3 * D)
-            ops.linear(n1, p("self_attn.linear_v.weight"), p("self_attn.linear_v.bias"), out=qkv, out_off=2 * D, ldc=3 * D)
+            ops.linear_group(n1, [(p(f"self_attn.linear_{c}.weight"), p(f"self_attn.linear_{c}.bias"), j * D)
+                                  for j, c in enumerate("qkv")], qkv)
             cx, attn, tk_a = _SelfAttnCore.fwd(qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, L, L, H, dk, ys_lens, True,
                                                p_att=pself)
             tk_r = None
@@ -648,8 +646,8 @@ class TransformerDecoderFn(torch.autograd.Function):
             n2, m2, r2 = ops.layernorm_fwd(x1, p("norm2.weight"), p("norm2.bias"), EPS_ESPNET)
             q2 = ops.linear(n2, p("src_attn.linear_q.weight"), p("src_attn.linear_q.bias"))
             kv = ops.empty(B * T, 2 * D, like=x)
-            ops.linear(mem2, p("src_attn.linear_k.weight"), p("src_attn.linear_k.bias"), out=kv, out_off=0, ldc=2 * D)
-            ops.linear(mem2, p("src_attn.linear_v.weight"), p("src_attn.linear_v.bias"), out=kv, out_off=D, ldc=2 * D)
+            ops.linear_group(mem2, [(p(f"src_attn.linear_{c}.weight"), p(f"src_attn.linear_{c}.bias"), j * D)
+                                    for j, c in enumerate("kv")], kv)
             cx2, attn2, tk_a2 = _SelfAttnCore.fwd(q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, B, L, T, H, dk, hlens, False,
                                                   p_att=psrc)
             tk_r2 = None

@@ -331,6 +331,32 @@ class WgradGroup:
                 PROFILE.records.append((key, fl, e0, e1))
 
 
+def linear_group(x, wbs, out, ldc=None):
+    """several y_j = x @ w_j.T + b_j of ONE input in one grouped launch (query/key/value projections): ``wbs`` is a
+    list of (w_j, b_j, column offset of y_j in ``out``); out rows have stride ``ldc``.  Falls back to one GEMM per
+    projection when the grouped kernel cannot take the problems (alignment / K % 32) - same results."""
+    M, K = x.shape
+    ldc = out.stride(0) if ldc is None else ldc
+    require_cuda(x, out)
+    arr = (GemmDesc * len(wbs))()
+    for d, (w, b, off) in zip(arr, wbs):
+        d.M, d.N, d.K = M, w.shape[0], K
+        d.a_kmajor, d.b_kmajor = 0, 0
+        d.A, d.lda = x.data_ptr(), x.stride(0)
+        d.B, d.ldb = w.data_ptr(), w.stride(0)
+        d.C, d.ldc = _addr(out, off), ldc
+        d.nb1 = d.nb2 = 1
+        d.bias = None if b is None else b.data_ptr()
+        d.alpha = 1.0
+    rc = lib().tavsr_gemm_grouped(arr, len(wbs), stream()) if (len(wbs) > 1 and PROFILE is None) else -3
+    if rc == -3:
+        for w, b, off in wbs:
+            gemm(M, w.shape[0], K, x, x.stride(0), w, w.stride(0), out, ldc, c_off=off, bias=b)
+        return out
+    check(rc, "tavsr_gemm_grouped")
+    return out
+
+
 def colsum(x, *, scale=1.0, out=None, accumulate=False):
     M, N = x.shape
     require_cuda(x)
