@@ -286,9 +286,8 @@ class TailoredStreamFn(torch.autograd.Function):
         if cfg["use_attn"]:
             n, mean, rstd = ops.layernorm_fwd(x1, p["norm_mha.weight"], p["norm_mha.bias"], EPS_ESPNET)
             qkv = ops.empty(M, 3 * D, like=x2d)
-            ops.linear(n, p["attn.linear_q.weight"], p["attn.linear_q.bias"], out=qkv, out_off=0, ldc=3 * D)
-            ops.linear(n, p["attn.linear_k.weight"], p["attn.linear_k.bias"], out=qkv, out_off=D, ldc=3 * D)
-            ops.linear(n, p["attn.linear_v.weight"], p["attn.linear_v.bias"], out=qkv, out_off=2 * D, ldc=3 * D)
+            ops.linear_group(n, [(p[f"attn.linear_{c}.weight"], p[f"attn.linear_{c}.bias"], j * D) for j, c in enumerate("qkv")],
+                             qkv)
             pp = ops.linear(pos_emb.reshape(-1, D), p["attn.linear_pos.weight"])
             qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
             cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
@@ -333,10 +332,12 @@ class TailoredStreamFn(torch.autograd.Function):
         act, coeff = cfg["ffn_act"], cfg.get("coeff", 1.0)
         G = {}
         grp = ops.WgradGroup()
+        lng = ops.LNGroup()        # the stream's four d-wide LayerNorms: one (dgamma, dbeta) reduction
         x3, fmean, frstd = sv["final"]
-        dx3, G["norm_final.weight"], G["norm_final.bias"] = ops.layernorm_bwd(dy.contiguous().view(M, D), x3, fmean, frstd,
-                                                                             p["norm_final.weight"])
-        dx2, gs = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act, 0.5, grp=grp)
+        dx3, G["norm_final.weight"], G["norm_final.bias"] = lng.bwd(dy.contiguous().view(M, D), x3, fmean, frstd,
+                                                                   p["norm_final.weight"])
+        dx2, gs = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act, 0.5,
+                           grp=grp, lng=lng)
         for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                           "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
             G[n_] = g
@@ -359,7 +360,7 @@ class TailoredStreamFn(torch.autograd.Function):
             dn = ops.linear_dx(dqkv[:, :D], p["attn.linear_q.weight"])
             ops.linear_dx(dqkv[:, D:2 * D], p["attn.linear_k.weight"], res=dn, out=dn)
             ops.linear_dx(dqkv[:, 2 * D:], p["attn.linear_v.weight"], res=dn, out=dn)
-            dx1, G["norm_mha.weight"], G["norm_mha.bias"] = ops.layernorm_bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2)
+            dx1, G["norm_mha.weight"], G["norm_mha.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2)
         else:
             mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br = sv["br"]
             Cn = g.shape[1] // 2
@@ -375,13 +376,14 @@ class TailoredStreamFn(torch.autograd.Function):
             ops.act_bwd_(dg, z, "gelu")
             G["cgmlp.channel_proj1.0.weight"], G["cgmlp.channel_proj1.0.bias"] = grp.add(dg, n, bias_grad=True)
             dn = ops.linear_dx(dg, p["cgmlp.channel_proj1.0.weight"])
-            dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"] = ops.layernorm_bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2)
+            dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p["norm_ff_macaron.weight"], p["feed_forward_macaron.w_1.weight"],
-                          p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp)
+                          p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng)
         for n_, g in zip(("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight",
                           "feed_forward_macaron.w_1.bias", "feed_forward_macaron.w_2.weight", "feed_forward_macaron.w_2.bias"), gs):
             G[n_] = g
         grp.flush()
+        lng.flush()
         ctx.sv = None
         ops.join_side()
         return (dx.view(B, T, D), None, None, None, *[G[n] for n in ctx.names])
