@@ -89,6 +89,8 @@ class TailoredEncoderLayer(torch.nn.Module):
                      p_att=self.acoustic_attn.dropout_rate if (ua and self.training) else 0.0)
         cfg_v = dict(use_attn=uv, heads=self.visual_attn.h if uv else 1, ffn_act=act, coeff=coeff, p=pd,
                      p_att=self.visual_attn.dropout_rate if (uv and self.training) else 0.0)
-        audio = FA.TailoredStreamFn.apply(audio, apos, alens, cfg_a, *self._stream_params("acoustic", ua))
-        video = FA.TailoredStreamFn.apply(video, vpos, vlens, cfg_v, *self._stream_params("visual", uv))
+        ns = len(FA.TS_SHARED)
+        pa, pv = self._stream_params("acoustic", ua), self._stream_params("visual", uv)
+        # one node for both streams: the video stream runs on the forked stream beside the audio stream
+        audio, video = FA.TailoredLayerFn.apply(audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, *pa, *pv[ns:])
         return (audio, apos), audio_masks, (video, vpos), video_masks

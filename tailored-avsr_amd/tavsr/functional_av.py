@@ -389,6 +389,44 @@ class TailoredStreamFn(torch.autograd.Function):
         return (dx.view(B, T, D), None, None, None, *[G[n] for n in ctx.names])
 
 
+class TailoredLayerFn(torch.autograd.Function):
+    """Both modality streams of one TailoredEncoderLayer as ONE autograd node, so that the video stream can run on the
+    forked stream beside the audio stream, forward and backward (two separate nodes would leave the stream hand-over
+    to autograd).  P = shared (14) + audio-only + video-only parameters; the shared FFNs / norms receive the sum of
+    the two streams' gradients."""
+
+    @staticmethod
+    def forward(ctx, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, *P):
+        import types
+        na, nv = len(tailored_stream_param_names(cfg_a["use_attn"])), len(tailored_stream_param_names(cfg_v["use_attn"]))
+        ns = len(TS_SHARED)
+        Pa, Pv = P[:na], P[:ns] + P[na: na + nv - ns]
+        ca, cv = types.SimpleNamespace(), types.SimpleNamespace()
+        br = ops.BranchScope(audio.is_cuda)
+        with br:
+            yv = TailoredStreamFn.forward(cv, video, vpos, vlens, cfg_v, *Pv)
+        ya = TailoredStreamFn.forward(ca, audio, apos, alens, cfg_a, *Pa)
+        br.join()
+        ctx.ca, ctx.cv, ctx.n = ca, cv, (ns, na, nv)
+        return ya, yv
+
+    @staticmethod
+    def backward(ctx, dya, dyv):
+        ns, na, nv = ctx.n
+        br = ops.BranchScope(dya.is_cuda)
+        dyv = dyv.contiguous()
+        br.keep(dyv)
+        with br:
+            gv = TailoredStreamFn.backward(ctx.cv, dyv)
+        ga = TailoredStreamFn.backward(ctx.ca, dya)
+        br.join()
+        dxa, dxv = ga[0], gv[0]
+        Ga, Gv = ga[4:], gv[4:]
+        shared = [ops.axpby(a.contiguous().view(-1), b.contiguous().view(-1), 1.0, 1.0).view_as(a) for a, b in zip(Ga[:ns], Gv[:ns])]
+        ctx.ca = ctx.cv = None
+        return (dxa, None, None, None, dxv, None, None, None, *shared, *Ga[ns:], *Gv[ns:])
+
+
 # ------------------------------------------------------------------------------------------------
 # AdaptiveAudioVisualFusion, merge_method="learned_ave" (src/audiovisual_fusion/adaptive_audiovisual_fusion.py:137-205):
 # attention pooling of each stream under its own mask -> softmax over {audio, video} -> weighted sum ->
