@@ -116,6 +116,10 @@ int tavsr_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, i
                                 const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd, float* dx,
                                 int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D, tavsr_stream_t stream);
 int64_t tavsr_colsum_ws(int32_t M, int32_t N);
+/* out = x + y, sum_x[n] = sum_m x[m][n], sum_y[n] = sum_m y[m][n] in two launches (dQ = dQu + dQv with the pos_bias_u/v
+ * gradients of RelPositionMultiHeadedAttention); ws >= 2 * tavsr_colsum_ws(M, N) floats */
+int tavsr_add2_colsum(const float* x, int64_t ldx, const float* y, int64_t ldy, float* out, int64_t ldo, int32_t M, int32_t N,
+                      float* sum_x, float* sum_y, float* ws, tavsr_stream_t stream);
 int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, float scale, float* out,
                  int32_t accumulate, float* ws, tavsr_stream_t stream);
 /* out[i] (+)= sum_{p < nparts} part[p*stride + i], i < n */

@@ -196,6 +196,32 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   if (ry == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
+// out = x + y with the column sums of x and of y on the way (dQ = dQu + dQv and the pos_bias_u / pos_bias_v gradients of
+// the rel-pos attention in one pass): part[chunk][0][N] = partial column sums of x, part[chunk][1][N] of y
+__global__ __launch_bounds__(256) void add2_colsum_part_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const float* __restrict__ y, int64_t ldy,
+                                                               float* __restrict__ out, int64_t ldo, int M, int N,
+                                                               int rows_per_chunk, float* __restrict__ part) {
+  __shared__ float red[4][2][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(M, r0 + rows_per_chunk);
+  float sx = 0.f, sy = 0.f;
+  if (col < N)
+    for (int r = r0 + ry; r < r1; r += 4) {
+      const float a = x[(int64_t)r * ldx + col], b = y[(int64_t)r * ldy + col];
+      out[(int64_t)r * ldo + col] = a + b;
+      sx += a;
+      sy += b;
+    }
+  red[ry][0][cx] = sx;
+  red[ry][1][cx] = sy;
+  __syncthreads();
+  if (ry < 2 && col < N)
+    part[((int64_t)blockIdx.y * 2 + ry) * N + col] = (red[0][ry][cx] + red[1][ry][cx]) + (red[2][ry][cx] + red[3][ry][cx]);
+}
+
 static inline int ln_blocks(int M) { return min(cdiv(M, 4 * LN_RPW * 2), 512); }   // ~2 row pairs per wave
 static inline int colsum_chunks(int M) { return min(cdiv(M, 64), 64); }
 
@@ -277,6 +303,21 @@ extern "C" int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, f
   TAVSR_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, ws, chunks, (int64_t)N, out, out, N, N,
                      accumulate, scale);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_add2_colsum(const float* x, int64_t ldx, const float* y, int64_t ldy, float* out, int64_t ldo, int32_t M,
+                                 int32_t N, float* sum_x, float* sum_y, float* ws, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && y && out && sum_x && sum_y && ws, TAVSR_EINVAL, "add2_colsum: null pointer");
+  if (N <= 0 || M <= 0) return TAVSR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = colsum_chunks(M);
+  const int rpc = cdiv(M, chunks);
+  hipLaunchKernelGGL(add2_colsum_part_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, s, x, ldx, y, ldy, out, ldo, M, N, rpc, ws);
+  TAVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * N, 64)), dim3(256), 0, s, ws, chunks, (int64_t)2 * N, sum_x, sum_y, N,
+                     2 * N, 0, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

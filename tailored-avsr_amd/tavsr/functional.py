@@ -109,6 +109,7 @@ class _SelfAttnCore:
         pv, tok = attn, None
         if p_att and p_att > 0.0:      # dropout on the probabilities (espnet forward_attention); attn itself is kept
             pv, tok = ops.dropout(attn, p_att)
+            tok = tok + (pv,)          # the dropped probabilities stay resident for dV (5 MB per layer)
         ctx = ops.empty(B * T1, D, like=dev)
         # ctx[b,:,h] = drop(attn)[h,b] V[b,:,h]
         ops.gemm(T1, dk, T2, pv, S, vbuf, ldv, ctx, D, b_off=v_off, b_kmajor=True, nb1=B, nb2=H,
@@ -126,8 +127,8 @@ class _SelfAttnCore:
         # dattn[h,b] = dctx[b,:,h] V[b,:,h]^T
         ops.gemm(T1, T2, dk, dctx, D, vbuf, ldv, dattn, S, b_off=v_off, nb1=B, nb2=H, sA=(T1 * D, dk),
                  sB=(T2 * ldv, dk), sC=sS)
-        # dV[b,:,h] = drop(attn)[h,b]^T dctx[b,:,h]   (the dropped probabilities are regenerated, not stored)
-        pv = attn if tok is None else ops.dropout(attn, tok[0], token=tok)[0]
+        # dV[b,:,h] = drop(attn)[h,b]^T dctx[b,:,h]
+        pv = attn if tok is None else tok[2]
         ops.gemm(T2, dk, T1, pv, S, dctx, D, dv_buf, lddv, c_off=dv_off, a_kmajor=True, b_kmajor=True, nb1=B, nb2=H,
                  sA=sS, sB=(T1 * D, dk), sC=(T2 * lddv, dk))
         del pv
@@ -364,9 +365,9 @@ class BranchformerLayerFn(torch.autograd.Function):
                 dqu = ops.empty(M, D, like=dy2)
                 dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
                                             dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
-                put("attn.pos_bias_u", ops.colsum(dqu), like=p("attn.pos_bias_u"))
-                put("attn.pos_bias_v", ops.colsum(dqv), like=p("attn.pos_bias_v"))
-                ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
+                gu_, gv_ = ops.add2_colsum(dqu, dqv, dqkv[:, :D])      # dQ = dQu + dQv and both bias gradients, one pass
+                put("attn.pos_bias_u", gu_, like=p("attn.pos_bias_u"))
+                put("attn.pos_bias_v", gv_, like=p("attn.pos_bias_v"))
                 pe2d = ctx.pos_emb.reshape(-1, D)
                 put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))   # K = 2T-1: not a multiple of 32, stays alone
                 for j, nm in enumerate(("q", "k", "v")):   # three problems with their own outputs (no sliced gradients)

@@ -351,9 +351,8 @@ class TailoredStreamFn(torch.autograd.Function):
             dqu = ops.empty(M, D, like=dx2)
             dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
                                         dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
-            G["attn.pos_bias_u"] = ops.colsum(dqu).view_as(p["attn.pos_bias_u"])
-            G["attn.pos_bias_v"] = ops.colsum(dqv).view_as(p["attn.pos_bias_v"])
-            ops.axpby2d(dqu, dqv, 1.0, 1.0, dqkv[:, :D])
+            gu_, gv_ = ops.add2_colsum(dqu, dqv, dqkv[:, :D])
+            G["attn.pos_bias_u"], G["attn.pos_bias_v"] = gu_.view_as(p["attn.pos_bias_u"]), gv_.view_as(p["attn.pos_bias_v"])
             G["attn.linear_pos.weight"] = ops.linear_dw(dp, ctx.pos_emb.reshape(-1, D))
             for j, nm in enumerate(("q", "k", "v")):
                 G[f"attn.linear_{nm}.weight"], G[f"attn.linear_{nm}.bias"] = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)

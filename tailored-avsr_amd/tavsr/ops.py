@@ -368,6 +368,17 @@ def colsum(x, *, scale=1.0, out=None, accumulate=False):
     return out
 
 
+def add2_colsum(x, y, out):
+    """out = x + y (row-strided 2-D views); returns (column sums of x, column sums of y)."""
+    M, N = x.shape
+    require_cuda(x, y, out)
+    sx, sy = empty(N, like=x), empty(N, like=x)
+    ws = empty(2 * lib_i64("tavsr_colsum_ws", M, N), like=x)
+    check(lib().tavsr_add2_colsum(ptr(x), C.c_int64(x.stride(0)), ptr(y), C.c_int64(y.stride(0)), ptr(out),
+                                  C.c_int64(out.stride(0)), M, N, ptr(sx), ptr(sy), ptr(ws), stream()), "tavsr_add2_colsum")
+    return sx, sy
+
+
 def lib_i64(name, *args) -> int:
     fn = getattr(lib(), name)
     fn.restype = C.c_int64
