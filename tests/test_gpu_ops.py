@@ -250,3 +250,40 @@ def test_lsm_loss_and_embed():
     dt = ops.embed_bwd(ids, do, 16.0, V)
     ref = torch.zeros(V, D, dtype=torch.float64, device="cuda").index_add_(0, ids.view(-1), do.double() * 16)
     _close(dt, ref, 1e-5)
+
+
+def test_grouped_helpers_match_the_plain_calls():
+    """LNGroup (shared reduction, and its immediate path for an odd shape), linear_group (grouped launch and its
+    per-projection fallback for K % 32 != 0) and add2_colsum against the single-call forms."""
+    from tavsr import ops
+    torch.manual_seed(0)
+    M, D = 777, 256
+    xs = [torch.randn(M, D, device="cuda") for _ in range(3)]
+    dys = [torch.randn(M, D, device="cuda") for _ in range(3)]
+    gam = [torch.randn(D, device="cuda") for _ in range(3)]
+    stats = [ops.layernorm_fwd(x, g, g, 1e-12)[1:] for x, g in zip(xs, gam)]
+    ref = [ops.layernorm_bwd(dy, x, m, r, g) for dy, x, (m, r), g in zip(dys, xs, stats, gam)]
+    lng = ops.LNGroup(cap=2)                       # the third one overflows the slab: reduced immediately
+    got = [lng.bwd(dy, x, m, r, g) for dy, x, (m, r), g in zip(dys, xs, stats, gam)]
+    x4, dy4, g4 = torch.randn(50, 1024, device="cuda"), torch.randn(50, 1024, device="cuda"), torch.randn(1024, device="cuda")
+    m4, r4 = ops.layernorm_fwd(x4, g4, g4, 1e-12)[1:]
+    odd = lng.bwd(dy4, x4, m4, r4, g4)             # other shape than the group's: immediate
+    lng.flush()
+    for a, b in zip(got, ref):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    for u, v in zip(odd, ops.layernorm_bwd(dy4, x4, m4, r4, g4)):
+        assert torch.equal(u, v)
+    for K in (256, 200):                           # 200: not a multiple of 32 -> one GEMM per projection
+        x = torch.randn(M, K, device="cuda")
+        ws = [torch.randn(D, K, device="cuda") for _ in range(3)]
+        bs = [torch.randn(D, device="cuda") for _ in range(3)]
+        out = torch.empty(M, 3 * D, device="cuda")
+        ops.linear_group(x, [(w, b, j * D) for j, (w, b) in enumerate(zip(ws, bs))], out)
+        for j, (w, b) in enumerate(zip(ws, bs)):
+            assert torch.equal(out[:, j * D:(j + 1) * D], ops.linear(x, w, b))
+    a, b = torch.randn(M, D, device="cuda"), torch.randn(M, D, device="cuda")
+    buf = torch.empty(M, 3 * D, device="cuda")
+    sa, sb = ops.add2_colsum(a, b, buf[:, :D])
+    assert torch.equal(buf[:, :D], a + b)
+    assert torch.equal(sa, ops.colsum(a)) and torch.equal(sb, ops.colsum(b))
