@@ -65,10 +65,12 @@ __global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restric
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int k4 = (int)(i & 63);
-  const int64_t m = i >> 6;
-  const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho);
-  const int t = (int)((m / ((int64_t)Wo * Ho)) % T);
-  const int64_t b = m / ((int64_t)Wo * Ho * T);
+  const uint32_t m = (uint32_t)(i >> 6);                  // < 2^31 rows (host-checked): 32-bit index arithmetic
+  const uint32_t wo = m % (uint32_t)Wo, q1 = m / (uint32_t)Wo;
+  const uint32_t ho = q1 % (uint32_t)Ho, q2 = q1 / (uint32_t)Ho;
+  const int t = (int)(q2 % (uint32_t)T);
+  const uint32_t b = q2 / (uint32_t)T;
+  const float* xb = x + (int64_t)b * T * H * W;
   float v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -76,8 +78,8 @@ __global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restric
     v[j] = 0.f;
     if (k < 245) {
       const int kw = k % 7, kh = (k / 7) % 7, kt = k / 49;
-      const int tt = t - 2 + kt, h = ho * 2 - 3 + kh, w = wo * 2 - 3 + kw;
-      if (tt >= 0 && tt < T && h >= 0 && h < H && w >= 0 && w < W) v[j] = x[((b * T + tt) * H + h) * W + w];
+      const int tt = t - 2 + kt, h = (int)ho * 2 - 3 + kh, w = (int)wo * 2 - 3 + kw;
+      if ((unsigned)tt < (unsigned)T && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v[j] = xb[(tt * H + h) * W + w];
     }
   }
   reinterpret_cast<float4*>(col)[i] = make_float4(v[0], v[1], v[2], v[3]);
@@ -246,37 +248,43 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
 
 // ---- pooling ------------------------------------------------------------------------------------------------
 // MaxPool 3x3 stride 2 pad 1 per frame, NHWC (the (1,3,3)/(1,2,2) MaxPool3d of the stem); idx = winning tap 0..8
+// thread = 4 channels of one output pixel (16-byte loads; C % 4 == 0)
 __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
-                                        int H, int W, int Ho, int Wo, int C, int64_t total) {
+                                        int H, int W, int Ho, int Wo, int C, int64_t total4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int c = (int)(i % C);
-  int64_t r = i / C;
+  if (i >= total4) return;
+  const int C4 = C >> 2;
+  const int c4 = (int)(i % C4);
+  int64_t r = i / C4;
   const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
   const int64_t n = r / ((int64_t)Wo * Ho);
-  float best = -FLT_MAX;
-  int bi = 0;
+  float best[4] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  uint32_t bi[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     const int h = ho * 2 - 1 + k / 3, w = wo * 2 - 1 + k % 3;
     if (h < 0 || h >= H || w < 0 || w >= W) continue;
-    const float v = x[((n * H + h) * W + w) * C + c];
-    if (v > best || v != v) { best = v; bi = k; }     // first maximum wins (torch scan order); NaN propagates
+    const float4 v4 = *reinterpret_cast<const float4*>(x + ((n * H + h) * W + w) * C + c4 * 4);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = k; }   // first maximum wins (torch scan order); NaN propagates
   }
-  y[i] = best;
-  idx[i] = (uint8_t)bi;
+  reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
+  reinterpret_cast<uint32_t*>(idx)[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
 }
 
 // dx[n,h,w,c] = sum of dy over the (at most 4) windows that selected this pixel (gather form, deterministic)
 __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
-                                        float* __restrict__ dx, int H, int W, int Ho, int Wo, int C, int64_t total) {
+                                        float* __restrict__ dx, int H, int W, int Ho, int Wo, int C, int64_t total4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int c = (int)(i % C);
-  int64_t r = i / C;
+  if (i >= total4) return;
+  const int C4 = C >> 2;
+  const int c4 = (int)(i % C4);
+  int64_t r = i / C4;
   const int w = (int)(r % W), h = (int)((r / W) % H);
   const int64_t n = r / ((int64_t)W * H);
-  float acc = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int hn = h + 1 - kh;
@@ -289,11 +297,17 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const uint
       if (wn < 0 || (wn & 1)) continue;
       const int wo = wn >> 1;
       if (wo >= Wo) continue;
-      const int64_t o = ((n * Ho + ho) * Wo + wo) * C + c;
-      if (idx[o] == kh * 3 + kw) acc += dy[o];
+      const int64_t o4 = ((n * Ho + ho) * Wo + wo) * C4 + c4;
+      const uint32_t sel = reinterpret_cast<const uint32_t*>(idx)[o4];
+      const float4 d = reinterpret_cast<const float4*>(dy)[o4];
+      const uint32_t k = kh * 3 + kw;
+      if ((sel & 0xFFu) == k) acc[0] += d.x;
+      if (((sel >> 8) & 0xFFu) == k) acc[1] += d.y;
+      if (((sel >> 16) & 0xFFu) == k) acc[2] += d.z;
+      if ((sel >> 24) == k) acc[3] += d.w;
     }
   }
-  dx[i] = acc;
+  reinterpret_cast<float4*>(dx)[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 // global average pool over the P pixels of each frame: y[n,c] = mean_p x[n,p,c]; bwd: dx[n,p,c] = dy[n,c] / P
@@ -385,6 +399,8 @@ extern "C" int tavsr_im2col_stem(const float* x, float* col, int32_t B, int32_t 
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int64_t total4 = (int64_t)B * T * Ho * Wo * 64;
   if (total4 <= 0) return TAVSR_OK;
+  TAVSR_REQUIRE((int64_t)B * T * Ho * Wo < (1ll << 31) && (int64_t)T * H * W < (1ll << 31), TAVSR_EUNSUPPORTED,
+                "im2col_stem: more than 2^31 patch rows (decode/eval goes through in slices)");
   hipLaunchKernelGGL(im2col_stem_kernel, grid1d(total4), dim3(256), 0, (hipStream_t)stream, x, col, T, H, W, Ho, Wo, total4);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
@@ -452,7 +468,9 @@ extern "C" int tavsr_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, in
                                       tavsr_stream_t stream) {
   TAVSR_REQUIRE(x && y && idx, TAVSR_EINVAL, "maxpool_fwd: null pointer");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int64_t total = N * Ho * Wo * C;
+  TAVSR_REQUIRE(C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && ((uintptr_t)idx & 3) == 0, TAVSR_EUNSUPPORTED,
+                "maxpool_fwd: C %% 4 == 0 and aligned tensors required");
+  const int64_t total = N * Ho * Wo * (C / 4);
   if (total <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo, C, total);
   TAVSR_LAUNCH_CHECK();
@@ -463,7 +481,9 @@ extern "C" int tavsr_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float
                                       tavsr_stream_t stream) {
   TAVSR_REQUIRE(dy && idx && dx, TAVSR_EINVAL, "maxpool_bwd: null pointer");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int64_t total = N * H * W * C;
+  TAVSR_REQUIRE(C % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && ((uintptr_t)idx & 3) == 0, TAVSR_EUNSUPPORTED,
+                "maxpool_bwd: C %% 4 == 0 and aligned tensors required");
+  const int64_t total = N * H * W * (C / 4);
   if (total <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, H, W, Ho, Wo, C, total);
   TAVSR_LAUNCH_CHECK();
