@@ -9,33 +9,44 @@
 namespace tavsr {
 
 // y[b,to,fo,c] = relu(bias[c] + sum_{kh,kw} w[c,kh,kw] * x[b, 2to+kh, 2fo+kw]),  x: [B,T,F] (1 channel)
+constexpr int kConv1Pos = 64;     // output positions per block
+
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
                                                         int T, int F, int To, int Fo, int C) {
-  // one block: 4 output positions x 64 channel-quads; thread -> (pos, 4 channels)
+  // thread -> 4 channels (its 36 weights stay in registers) x one of 4 position lanes; a block walks 64 positions:
+  // the kernel is bound by the 1 KB it writes per position, not by re-reading weights
   const int cq = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int64_t pos = (int64_t)blockIdx.x * 4 + pl;
   const int64_t npos = (int64_t)B * To * Fo;
-  if (pos >= npos) return;
-  const int fo = (int)(pos % Fo);
-  const int to = (int)((pos / Fo) % To);
-  const int b = (int)(pos / ((int64_t)Fo * To));
-  float xv[9];
-#pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = x[((int64_t)b * T + 2 * to + kh) * F + 2 * fo + kw];
+  const int64_t p0 = (int64_t)blockIdx.x * kConv1Pos;
   for (int c = cq * 4; c < C; c += 256) {
-    float4 o = *reinterpret_cast<const float4*>(bias + c);
-    float* op = &o.x;
+    float wr[4][9];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float acc = op[j];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) acc += w[(int64_t)(c + j) * 9 + k] * xv[k];
-      op[j] = fmaxf(acc, 0.f);
+      for (int k = 0; k < 9; ++k) wr[j][k] = w[(int64_t)(c + j) * 9 + k];
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    for (int q = pl; q < kConv1Pos; q += 4) {
+      const int64_t pos = p0 + q;
+      if (pos >= npos) break;
+      const int fo = (int)(pos % Fo);
+      const int to = (int)((pos / Fo) % To);
+      const int b = (int)(pos / ((int64_t)Fo * To));
+      const float* xp = x + ((int64_t)b * T + 2 * to) * F + 2 * fo;
+      float xv[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xp[kh * F + kw];
+      float o[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[j] += wr[j][k] * xv[k];
+        o[j] = fmaxf(o[j], 0.f);
+      }
+      *reinterpret_cast<float4*>(y + pos * C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    *reinterpret_cast<float4*>(y + pos * C + c) = o;
   }
 }
 
@@ -195,8 +206,8 @@ extern "C" int tavsr_conv1_fwd(const float* x, const float* w, const float* bias
   const int To = (T - 3) / 2 + 1, Fo = (F - 3) / 2 + 1;
   int64_t npos = (int64_t)B * To * Fo;
   if (npos <= 0) return TAVSR_OK;
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(cdiv(npos, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, T, F, To,
-                     Fo, C);
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(cdiv(npos, kConv1Pos)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, T, F,
+                     To, Fo, C);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
