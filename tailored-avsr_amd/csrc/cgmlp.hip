@@ -60,6 +60,63 @@ __global__ __launch_bounds__(256) void dwconv_gate_fwd_kernel(const float* __res
   }
 }
 
+// Same, with the kernel size a compile-time constant (the recipe's 31): the taps live in registers and four consecutive
+// outputs share one sliding window of LDS reads (K + 3 reads for 4 outputs instead of 8 K).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_gate_fwd_kfix_kernel(const float* __restrict__ gn, const float* __restrict__ r,
+                                                                   int64_t ldr, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, float* __restrict__ out,
+                                                                   float* __restrict__ conv, int B, int T, int C) {
+  extern __shared__ float sm[];
+  constexpr int pad = (K - 1) / 2, rows = CG_TT + K - 1;
+  float* s_x = sm;                             // [rows][CG_CH]
+  const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * CG_CH, t0 = blockIdx.y * CG_TT, b = blockIdx.z;
+  const int c = c0 + cx;
+  for (int ib = ty * 4; ib < rows; ib += 16) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ib + q, t = t0 + i - pad;
+      v[q] = (i < rows && t >= 0 && t < T && c < C) ? gn[((int64_t)b * T + t) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ib + q < rows) s_x[(ib + q) * CG_CH + cx] = v[q];
+  }
+  float wr[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) wr[k] = c < C ? w[(int64_t)c * K + k] : 0.f;
+  __syncthreads();
+  if (c >= C) return;
+  const float bv = bias[c];
+  constexpr int RPW = CG_TT / 4;               // rows per wave, contiguous
+  for (int g = 0; g < RPW / 4; ++g) {
+    const int tb = ty * RPW + g * 4;
+    if (t0 + tb >= T) break;
+    float rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rv[q] = (t0 + tb + q < T) ? r[((int64_t)b * T + t0 + tb + q) * ldr + c] : 0.f;
+    float o[4] = {bv, bv, bv, bv};
+#pragma unroll
+    for (int u = 0; u < K + 3; ++u) {
+      const float v = s_x[(tb + u) * CG_CH + cx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (u - q >= 0 && u - q < K) o[q] += wr[u - q] * v;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t0 + tb + q;
+      if (t < T) {
+        const int64_t m = (int64_t)b * T + t;
+        if (conv) conv[m * C + c] = o[q];
+        out[m * C + c] = rv[q] * o[q];
+      }
+    }
+  }
+}
+
 // du -> dr = du*conv ; dconv = du*r ; dgn[t] = sum_k w[c,k]*dconv[t-k+pad] ;
 // dw[c,k] = sum_{b,t} dconv[t]*gn[t+k-pad], dbias[c] = sum_{b,t} dconv[t].
 // One block per (64 channels, utterance): it walks the utterance in time tiles of CG_TB steps (dconv and gn tiles
@@ -152,6 +209,109 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < CG_TAPS; ++j)
       if (j < ntap) pw[ty + 4 * j] = acc[j];   // [C][K+1]: k == K holds the bias partial
+  }
+}
+
+// Backward with a compile-time kernel size: taps in registers, four consecutive data gradients per sliding window, and
+// the weight gradient in groups of four rows 4 apart (rows r, r+4, r+8, r+12 need gn rows r+ty+4s, s = 0..10: the taps
+// this thread owns, k = ty + 4j, line up across them) - 4x fewer LDS reads than the generic kernel.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_gate_bwd_kfix_kernel(const float* __restrict__ du, const float* __restrict__ gn,
+                                                                   const float* __restrict__ r, int64_t ldr,
+                                                                   const float* __restrict__ conv,
+                                                                   const float* __restrict__ w, float* __restrict__ dr,
+                                                                   int64_t lddr, float* __restrict__ dgn,
+                                                                   float* __restrict__ part, int B, int T, int C) {
+  extern __shared__ float sm[];
+  constexpr int pad = (K - 1) / 2, rows = CG_TB + K - 1;
+  constexpr int NTAP = (K + 1 + 3) / 4;        // taps per thread (tap K is the bias)
+  static_assert(CG_TB == 64 && NTAP == 8, "row grouping below assumes 64-step tiles and 8 taps per thread");
+  float* s_d = sm;                         // dconv with halo [rows][CG_CH]
+  float* s_g = s_d + rows * CG_CH;         // gn with halo    [rows][CG_CH]
+  const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * CG_CH, b = blockIdx.y;
+  const int c = c0 + cx;
+  const bool cok = c < C;
+  float wr[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) wr[k] = cok ? w[(int64_t)c * K + k] : 0.f;
+  float acc[NTAP];
+#pragma unroll
+  for (int j = 0; j < NTAP; ++j) acc[j] = 0.f;
+  for (int t0 = 0; t0 < T; t0 += CG_TB) {
+    __syncthreads();
+    for (int ib = ty * 4; ib < rows; ib += 16) {
+      float duv[4], rv[4], gv[4], cv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ib + q, t = t0 + i - pad;
+        duv[q] = rv[q] = gv[q] = cv[q] = 0.f;
+        if (i < rows && t >= 0 && t < T && cok) {
+          const int64_t m = (int64_t)b * T + t;
+          duv[q] = du[m * C + c];
+          rv[q] = r[m * ldr + c];
+          gv[q] = gn[m * C + c];
+          if (i >= pad && i < pad + CG_TB) cv[q] = conv[m * C + c];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ib + q, t = t0 + i - pad;
+        if (i < rows) {
+          s_d[i * CG_CH + cx] = duv[q] * rv[q];
+          s_g[i * CG_CH + cx] = gv[q];
+          if (i >= pad && i < pad + CG_TB && t < T && cok) dr[((int64_t)b * T + t) * lddr + c] = duv[q] * cv[q];
+        }
+      }
+    }
+    __syncthreads();
+    const int nt = min(CG_TB, T - t0);
+    if (cok) {
+      // data gradients: wave ty owns rows [16 ty, 16 ty + 16), four at a time; dgn[tt] = sum_k w[k] * s_d[tt + 2 pad - k]
+      for (int g = 0; g < 4; ++g) {
+        const int tb = ty * 16 + g * 4;
+        if (tb >= nt) break;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = -3; u < K; ++u) {          // LDS row tb + 2 pad - u feeds output q with tap u + q
+          const float v = s_d[(tb + 2 * pad - u) * CG_CH + cx];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (u + q >= 0 && u + q < K) o[q] += wr[u + q] * v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (tb + q < nt) dgn[((int64_t)b * T + t0 + tb + q) * C + c] = o[q];
+      }
+      // weight gradient: acc[j] += dconv[tt] * gn row (tt + ty + 4 j); the bias tap (k == K: ty == 3, j == 7) adds dconv
+      for (int m4 = 0; m4 < 4; ++m4) {
+#pragma unroll
+        for (int r0 = 0; r0 < 4; ++r0) {
+          const int rb = m4 * 16 + r0;          // rows rb, rb + 4, rb + 8, rb + 12
+          if (rb >= nt) continue;
+          float dv[4], G[11];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) dv[a] = (rb + 4 * a < nt) ? s_d[(rb + 4 * a + pad) * CG_CH + cx] : 0.f;
+#pragma unroll
+          for (int sidx = 0; sidx < 11; ++sidx) {
+            const int row = rb + ty + 4 * sidx;
+            G[sidx] = row < rows ? s_g[row * CG_CH + cx] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < NTAP; ++j) {
+            const bool is_bias = (ty + 4 * j == K);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[j] += dv[a] * (is_bias ? 1.f : G[a + j]);
+          }
+        }
+      }
+    }
+  }
+  if (cok) {
+    float* pw = part + ((int64_t)b * C + c) * (K + 1);
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j)
+      if (ty + 4 * j <= K) pw[ty + 4 * j] = acc[j];
   }
 }
 
@@ -413,8 +573,12 @@ extern "C" int tavsr_dwconv_gate_fwd(const float* gn, const float* r, int64_t ld
   TAVSR_REQUIRE(K >= 1 && K <= CG_KMAX && (K & 1), TAVSR_EUNSUPPORTED, "dwconv_gate_fwd: odd K <= %d required", CG_KMAX);
   if (B <= 0 || T <= 0 || C <= 0) return TAVSR_OK;
   size_t lds = ((CG_TT + K - 1) * CG_CH + K * CG_CH) * sizeof(float);
-  hipLaunchKernelGGL(dwconv_gate_fwd_kernel, dim3(cdiv(C, CG_CH), cdiv(T, CG_TT), B), dim3(256), lds,
-                     (hipStream_t)stream, gn, r, ldr, w, bias, out, conv, B, T, C, K);
+  if (K == 31)
+    hipLaunchKernelGGL(dwconv_gate_fwd_kfix_kernel<31>, dim3(cdiv(C, CG_CH), cdiv(T, CG_TT), B), dim3(256),
+                       (CG_TT + 30) * CG_CH * sizeof(float), (hipStream_t)stream, gn, r, ldr, w, bias, out, conv, B, T, C);
+  else
+    hipLaunchKernelGGL(dwconv_gate_fwd_kernel, dim3(cdiv(C, CG_CH), cdiv(T, CG_TT), B), dim3(256), lds,
+                       (hipStream_t)stream, gn, r, ldr, w, bias, out, conv, B, T, C, K);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
@@ -434,8 +598,12 @@ extern "C" int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const flo
   if (B <= 0 || T <= 0 || C <= 0) return TAVSR_OK;
   hipStream_t s = (hipStream_t)stream;
   size_t lds = (2 * (CG_TB + K - 1) * CG_CH + K * CG_CH) * sizeof(float);
-  hipLaunchKernelGGL(dwconv_gate_bwd_kernel, dim3(cdiv(C, CG_CH), B), dim3(256), lds, s, du, gn, r, ldr, conv, w, dr,
-                     lddr, dgn, ws, B, T, C, K);
+  if (K == 31)
+    hipLaunchKernelGGL(dwconv_gate_bwd_kfix_kernel<31>, dim3(cdiv(C, CG_CH), B), dim3(256),
+                       2 * (CG_TB + 30) * CG_CH * sizeof(float), s, du, gn, r, ldr, conv, w, dr, lddr, dgn, ws, B, T, C);
+  else
+    hipLaunchKernelGGL(dwconv_gate_bwd_kernel, dim3(cdiv(C, CG_CH), B), dim3(256), lds, s, du, gn, r, ldr, conv, w, dr,
+                       lddr, dgn, ws, B, T, C, K);
   TAVSR_LAUNCH_CHECK();
   const int nblk = B, n = C * (K + 1);
   float* sum = ws + (int64_t)nblk * n;
