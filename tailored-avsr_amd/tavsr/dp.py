@@ -23,10 +23,12 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:      # TAVSR_DP_BACKEND=gloo: several ranks on ONE GPU (RCCL needs a device per rank) - test rigs only
+            backend = os.environ.get("TAVSR_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
