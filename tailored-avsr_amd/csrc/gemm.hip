@@ -846,11 +846,11 @@ static bool glds_ok(const tavsr_gemm_desc& d, bool vec) {
   return vec && d.K % 32 == 0 && d.K >= 32 && (!d.a_kmajor || d.M % 4 == 0) && (!d.b_kmajor || d.N % 4 == 0);
 }
 
-// Planner (fitted to profiles/r01_gemm_sweep_v3.txt, MI355X).  The 64x64 tile with three LDS stages wins or
-// ties every hot-path shape (three blocks per CU hide each other's barrier and LDS latency; larger tiles lose more
-// to tile quantisation at M = 3168 than they gain).  Few-tile, long-K problems (weight gradients: K = B*T; the
-// N = 256 projections with K >= 2048) are split over K so that ~450 blocks exist; more slices than that cost
-// more in slab traffic than they gain in occupancy.
+// Planner (fitted to profiles/r01_gemm_sweep_v3/v4.txt and end-to-end A/B runs, MI355X).  The 64x64 tile wins or ties every
+// hot-path shape (larger tiles lose more to tile quantisation at M = 3168 than they gain).  Few-tile, long-K problems
+// (weight gradients: K = B*T; the N = 256 projections with K >= 2048) are split over K until about 1000 blocks exist
+// (four of the five block slots of every CU: 5 slices for the 200-tile shapes); more slices than that cost more in
+// slab traffic than they gain in balance.
 static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
   const long nbatch = (long)d.nb1 * d.nb2;
   Plan p{kFallbackCfg, 1, d.K};
@@ -863,13 +863,30 @@ static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
   p.cfg = variant(tiles);
   if (!allow_split || tiles >= 384 || d.K < 512) return p;
   if (d.K <= 1024 && tiles >= 150) return p;
-  long want = std::min<long>((448 + tiles / 2) / tiles, d.K / 256);
+  static const long target = [] { const char* e = getenv("TAVSR_SPLIT_TARGET"); return e ? atol(e) : 1000L; }();   // tuning aid
+  long want = std::min<long>((target + tiles / 2) / tiles, d.K / 256);
   if (want < 2) return p;
   p.kchunk = cdiv(cdiv(d.K, want), 32) * 32;
   p.nsplit = cdiv(d.K, p.kchunk);
   if (p.nsplit < 2) p = Plan{p.cfg, 1, d.K};
   p.cfg = variant(tiles * p.nsplit);
   return p;
+}
+
+// plan of an implicit-convolution launch: the weight gradient (mode 2) has an enormous K = frames*H*W and few tiles, so K
+// is split until all five block slots of every CU are filled (the slabs stay tiny); TAVSR_CONV_DW_BLOCKS tunes the target
+static Plan plan_conv(const tavsr_gemm_desc& d, bool can_split) {
+  Plan pc = plan(d, can_split, true);
+  if (d.conv_mode == 2 && can_split) {
+    const long tiles = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
+    static const long target = [] { const char* e = getenv("TAVSR_CONV_DW_BLOCKS"); return e ? atol(e) : 2560L; }();
+    const long want = std::min<long>(std::max<long>(1, target / tiles), d.K / 512);
+    if (want > pc.nsplit) {
+      pc.kchunk = cdiv(cdiv(d.K, want), 32) * 32;
+      pc.nsplit = cdiv(d.K, pc.kchunk);
+    }
+  }
+  return pc;
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -910,7 +927,7 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
     else
       TAVSR_REQUIRE(d.a_kmajor && d.b_kmajor && d.N == 9 * d.conv_C && d.conv_C % 64 == 0 && d.ldb == d.conv_C,
                     TAVSR_EUNSUPPORTED, "tavsr_gemm: conv mode 2 needs the TN layout, N = 9 C, C %% 64 == 0");
-    Plan pc = plan(d, can_split, true);
+    Plan pc = plan_conv(d, can_split);
     if (pc.nsplit > 1 && d.ws_floats < ws_floats_for(d, pc.nsplit)) pc = plan(d, false, true);
     return launch_conv(d, pc.nsplit, pc.kchunk, s);
   }
@@ -988,7 +1005,7 @@ extern "C" int64_t tavsr_gemm_ws(const tavsr_gemm_desc* dp) {
   if (d.M <= 0 || d.N <= 0) return 0;
   const bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.sA1 % 4 == 0 &&
                    d.sA2 % 4 == 0 && d.sB1 % 4 == 0 && d.sB2 % 4 == 0;
-  Plan p = plan(d, true, glds_ok(d, vec));
+  Plan p = d.conv_mode != 0 ? plan_conv(d, true) : plan(d, true, glds_ok(d, vec));
   return ws_floats_for(d, p.nsplit);
 }
 

@@ -85,3 +85,12 @@ def avsr_conf(yaml_path=AVSR_YAML, num_blocks=12, dec_blocks=6, visual_input_siz
     conf["decoder_conf"]["num_blocks"] = dec_blocks
     conf["encoder_conf"].update(enc_over)
     return copy.deepcopy(conf)
+
+
+def relu_gated_tol(name, tol):
+    """Tolerance for a gradient of the product against the reference: the two 3x3 convolutions of Conv2dSubsampling sit
+    behind ReLU masks over ~0.4 M pre-activations computed as K = 2304 fp32 sums; a unit whose pre-activation is 0 to
+    within the rounding of the summation ORDER (observed: 1.5e-8 against values of order 1) is on in one order and off
+    in another, and one such unit moves these gradients by ~3e-3 of their norm (1 / sqrt(active units)).  The reference's
+    own order is one arbitrary choice; the product's depends on its K split.  Everything else keeps ``tol``."""
+    return max(tol, 1e-2) if (".embed.conv." in name or name.startswith("embed.conv.")) else tol

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import AVSR_YAML, TOKENS_EN, asr_conf, avsr_conf, golden, grad_ok, max_rel, rel_err
+from helpers import AVSR_YAML, TOKENS_EN, relu_gated_tol, asr_conf, avsr_conf, golden, grad_ok, max_rel, rel_err
 from oracle.av import build_avsr_oracle
 from oracle.model import build_asr_oracle, compact, fill_parameters_, synth
 
@@ -37,9 +37,9 @@ def _check_asr(model, g, dev, tol_g):
     params = dict(model.named_parameters())
     for k in g.files:
         if k.startswith("g_"):
-            assert grad_ok(compact(params[k[2:]].grad.cpu()), g[k], tol_g), k
+            assert grad_ok(compact(params[k[2:]].grad.cpu()), g[k], relu_gated_tol(k[2:], tol_g)), k
     for n, v in zip(g["gnorm_keys"], g["gnorm_vals"]):
-        assert abs(float(params[str(n)].grad.norm()) - v) <= tol_g * max(v, 1e-6) + 1e-6, n
+        assert abs(float(params[str(n)].grad.norm()) - v) <= relu_gated_tol(str(n), tol_g) * max(v, 1e-6) + 1e-6, n
     model.eval()
     with torch.no_grad():
         loss_e, _, _ = model(speech.clone(), slens, text.clone(), tlens)
@@ -79,9 +79,9 @@ def _check_av(model, g, dev, tol_g):
     params = dict(model.named_parameters())
     for k in g.files:
         if k.startswith("g_"):
-            assert grad_ok(compact(params[k[2:]].grad.cpu()), g[k], tol_g), k
+            assert grad_ok(compact(params[k[2:]].grad.cpu()), g[k], relu_gated_tol(k[2:], tol_g)), k
     for n, v in zip(g["gnorm_keys"], g["gnorm_vals"]):
-        assert abs(float(params[str(n)].grad.norm()) - v) <= tol_g * max(v, 1e-6) + 1e-6, n
+        assert abs(float(params[str(n)].grad.norm()) - v) <= relu_gated_tol(str(n), tol_g) * max(v, 1e-6) + 1e-6, n
 
 
 @pytest.mark.parametrize("tag,avcond", [("av", True), ("sep", False)])
