@@ -52,28 +52,6 @@ def _gemm_kernel_key(d) -> str:
     return f"gemm_kernel<{'T' if d.a_kmajor else 'N'}{'N' if d.b_kmajor else 'T'}>"
 
 
-_SYNC = {}
-SYNC_INTS = 1 << 16
-
-
-def sync_counters(device) -> torch.Tensor:
-    """Zero-initialised int32 tile counters shared by all split-K GEMMs / last-block reductions issued on
-    one stream (every kernel leaves them zero).  Created outside any graph capture (first eager call)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream if not torch.cuda.is_current_stream_capturing() else "cap")
-    t = _SYNC.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            # inside a capture: reuse any buffer made by the eager warm-up on this device
-            for (dev, _), v in _SYNC.items():
-                if dev == key[0]:
-                    return v
-            raise L.TavsrError("run one eager step before capturing a graph (split-K counters are allocated lazily)")
-        t = torch.zeros(SYNC_INTS, dtype=torch.int32, device=device)
-        _SYNC[key] = t
-    return t
-
-
 _ZERO = {}
 
 
