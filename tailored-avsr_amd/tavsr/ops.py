@@ -285,8 +285,29 @@ class WgradGroup:
         d.alpha = alpha
         d.a_rowsum = None if gb is None else gb.data_ptr()
 
+    @staticmethod
+    def _tiles(it):
+        dy, x = it[0], it[1]
+        return -(-dy.shape[1] // 64) * -(-x.shape[1] // 64)
+
     def flush(self):
         items, self.items = self.items, []
+        # All tiles of a group are resident at once (5 block slots x 256 CUs) and equally long (same K), so the launch
+        # lasts as long as the fullest CU: with 784 tiles 16 CUs hold 4 blocks and the other 240 idle a quarter of the
+        # time.  Shedding the smallest problems down to a multiple of 256 tiles (they go through the planner's own
+        # K split) evens that out; only worth it when one or two small problems do it.
+        total = sum(self._tiles(it) for it in items)
+        if len(items) <= self.MAX and total > 256 and total % 256:
+            target, shed, rest = total // 256 * 256, [], sorted(items, key=self._tiles)
+            while rest and total > target and self._tiles(rest[0]) <= total - target:
+                total -= self._tiles(rest[0])
+                shed.append(rest.pop(0))
+            if total == target and len(shed) <= 2:       # every shed problem costs a launch of its own
+                for dy, x, alpha, out, gb in shed:
+                    gemm(dy.shape[1], x.shape[1], dy.shape[0], dy, dy.stride(0), x, x.stride(0), out, out.stride(0),
+                         a_kmajor=True, b_kmajor=True, alpha=alpha, a_rowsum=gb)
+                keep = set(id(it) for it in rest)
+                items = [it for it in items if id(it) in keep]
         for i in range(0, len(items), self.MAX):
             chunk = items[i: i + self.MAX]
             arr = (GemmDesc * len(chunk))()
