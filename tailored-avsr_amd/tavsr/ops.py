@@ -298,10 +298,13 @@ class WgradGroup:
         # K split) evens that out; only worth it when one or two small problems do it.
         total = sum(self._tiles(it) for it in items)
         if len(items) <= self.MAX and total > 256 and total % 256:
-            target, shed, rest = total // 256 * 256, [], sorted(items, key=self._tiles)
-            while rest and total > target and self._tiles(rest[0]) <= total - target:
-                total -= self._tiles(rest[0])
-                shed.append(rest.pop(0))
+            target, shed, rest = total // 256 * 256, [], []
+            for it in sorted(items, key=self._tiles, reverse=True):      # fewest problems that add up to the surplus
+                if self._tiles(it) <= total - target:
+                    total -= self._tiles(it)
+                    shed.append(it)
+                else:
+                    rest.append(it)
             if total == target and len(shed) <= 2:       # every shed problem costs a launch of its own
                 for dy, x, alpha, out, gb in shed:
                     gemm(dy.shape[1], x.shape[1], dy.shape[0], dy, dy.stride(0), x, x.stride(0), out, out.stride(0),
