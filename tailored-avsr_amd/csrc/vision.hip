@@ -86,75 +86,70 @@ __global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restric
 }
 
 // ---- BatchNorm (training mode: batch statistics over the M rows of [M, C]) ----------------------------------
-// stage 1: per-block partial column sums of (x - shift)^p, p = 1 (shift = 0) or 2 (shift = mean): part[blk][C]
-// thread = 4 channels (16-byte loads) x one of 16 row lanes; a block covers 64 channels
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ shift,
-                                                         int64_t M, int C, int64_t rows_per_block, int square,
-                                                         float* __restrict__ part) {
-  __shared__ float4 red[16][16];
+// Single pass: per-block partial sums of (x - s) and (x - s)^2 with the shift s[c] = x[0][c] (any sample is within a few
+// sigma of the mean, so var = E[(x-s)^2] - E[x-s]^2 loses no digits to cancellation): part[blk][2][C].  One read of x
+// instead of the two of the mean-then-variance form.
+__global__ __launch_bounds__(256) void bn_partial2_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                          int64_t rows_per_block, float* __restrict__ part) {
+  __shared__ float4 red[16][2][16];
   const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + cq * 4;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (c < C) {
-    const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    auto acc = [&](float4& s, const float4 v) {
+    const float4 sh = *reinterpret_cast<const float4*>(x + c);
+    for (int64_t r = r0 + ry; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
       const float a = v.x - sh.x, b = v.y - sh.y, cc = v.z - sh.z, d = v.w - sh.w;
-      s.x += square ? a * a : a; s.y += square ? b * b : b; s.z += square ? cc * cc : cc; s.w += square ? d * d : d;
-    };
-    int64_t r = r0 + ry;
-    for (; r + 16 < r1; r += 32) {
-      const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
-      const float4 b = *reinterpret_cast<const float4*>(x + (r + 16) * C + c);
-      acc(s0, a);
-      acc(s1, b);
+      s1.x += a; s1.y += b; s1.z += cc; s1.w += d;
+      s2.x += a * a; s2.y += b * b; s2.z += cc * cc; s2.w += d * d;
     }
-    for (; r < r1; r += 16) acc(s0, *reinterpret_cast<const float4*>(x + r * C + c));
   }
-  red[ry][cq] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+  red[ry][0][cq] = s1;
+  red[ry][1][cq] = s2;
   __syncthreads();
-  if (ry == 0 && c < C) {
-    float4 t = red[0][cq];
+  if (ry < 2 && c < C) {
+    float4 t = red[0][ry][cq];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) { const float4 u = red[k][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + c) = t;
+    for (int k = 1; k < 16; ++k) { const float4 u = red[k][ry][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2 + ry) * C + c) = t;
   }
 }
 
-// stage 2 (one block per 64 channels, 16 part-groups of 64 lanes; partials summed in double, fixed order):
-//   mode 0: mean[c] = sum / M
-//   mode 1: var[c] = sum / M (biased), rstd[c] = 1/sqrt(var + eps); running stats updated like torch BatchNorm
-//           (momentum m, unbiased variance), num_batches_tracked += 1 by one thread
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, int64_t M,
-                                                           int mode, float eps, float momentum, float* __restrict__ mean,
-                                                           float* __restrict__ var, float* __restrict__ rstd,
-                                                           float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var, int64_t* __restrict__ nbt) {
-  __shared__ double red[16][64];
+// mean, biased variance, rstd and the running statistics from the single-pass partials (combined in double)
+__global__ __launch_bounds__(1024) void bn_finalize2_kernel(const float* __restrict__ part, int nparts, int C, int64_t M,
+                                                            const float* __restrict__ x, float eps, float momentum,
+                                                            float* __restrict__ mean, float* __restrict__ var,
+                                                            float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+  __shared__ double red[16][2][64];
   const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
-  double s = 0.0;
+  double a = 0.0, b = 0.0;
   if (c < C)
-    for (int p = g; p < nparts; p += 16) s += (double)part[(int64_t)p * C + c];
-  red[g][cx] = s;
+    for (int p = g; p < nparts; p += 16) {
+      a += (double)part[((int64_t)p * 2 + 0) * C + c];
+      b += (double)part[((int64_t)p * 2 + 1) * C + c];
+    }
+  red[g][0][cx] = a;
+  red[g][1][cx] = b;
   __syncthreads();
   if (g != 0 || c >= C) return;
-  s = 0.0;
+  a = b = 0.0;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) s += red[q][cx];
-  if (mode == 0) {
-    mean[c] = (float)(s / (double)M);
-  } else {
-    const float v = (float)(s / (double)M);
-    var[c] = v;
-    rstd[c] = 1.f / sqrtf(v + eps);
-    if (running_mean) {
-      const float unb = M > 1 ? (float)(s / (double)(M - 1)) : v;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
-    }
-    if (nbt && c == 0) nbt[0] += 1;
+  for (int q = 0; q < 16; ++q) { a += red[q][0][cx]; b += red[q][1][cx]; }
+  const double d = a / (double)M;                          // E[x - s]
+  const double v = fmax(b / (double)M - d * d, 0.0);       // biased variance
+  const float mu = (float)((double)x[c] + d);
+  mean[c] = mu;
+  var[c] = (float)v;
+  rstd[c] = 1.f / sqrtf((float)v + eps);
+  if (running_mean) {
+    const float unb = M > 1 ? (float)(v * (double)M / (double)(M - 1)) : (float)v;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
   }
+  if (nbt && c == 0) nbt[0] += 1;
 }
 
 // y = act( (x - mean) * rstd * gamma + beta (+ res) ),  act = swish or identity;  float4 over C
@@ -418,12 +413,9 @@ extern "C" int tavsr_bn_stats(const float* x, int64_t M, int32_t C, float eps, f
   const int chunks = bn_chunks(M);
   const int64_t rpb = (M + chunks - 1) / chunks;
   const dim3 g(cdiv(C, 64), chunks);
-  hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, s, x, (const float*)nullptr, M, C, rpb, 0, ws);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, ws, chunks, C, M, 0, eps, momentum, mean, var,
-                     rstd, (float*)nullptr, (float*)nullptr, (int64_t*)nullptr);
-  hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, s, x, mean, M, C, rpb, 1, ws);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, ws, chunks, C, M, 1, eps, momentum, mean, var,
-                     rstd, running_mean, running_var, num_batches_tracked);
+  hipLaunchKernelGGL(bn_partial2_kernel, g, dim3(256), 0, s, x, M, C, rpb, ws);
+  hipLaunchKernelGGL(bn_finalize2_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, ws, chunks, C, M, x, eps, momentum, mean, var, rstd,
+                     running_mean, running_var, num_batches_tracked);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
