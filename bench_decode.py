@@ -50,16 +50,16 @@ def make_utts(n, seed, device):
             torch.full((n,), T_VID, dtype=torch.int64, device=device))
 
 
-def cpu_baseline(n_utt=1):
-    """oracle (CPU restatement of the reference's decode path) on the host cores, same models and search settings."""
+def cpu_baseline(model_state, lm_state, n_utt=1):
+    """oracle (CPU restatement of the reference's decode path) on the host cores: same weights (the product's state
+    dicts load into the oracle classes key for key), same search settings."""
     from oracle import beam_search as BS
     from oracle.av import build_avsr_oracle
-    from oracle.model import fill_parameters_
     conf = make_conf()
     model = build_avsr_oracle(copy.deepcopy(conf), conf["token_list"]).eval()
-    fill_parameters_(model, seed=1)
+    model.load_state_dict(model_state)
     lm = BS.TransformerLMOracle(len(conf["token_list"]), **LM_CONF).eval()
-    fill_parameters_(lm, seed=2)
+    lm.load_state_dict(lm_state)
     batch = make_utts(n_utt, 99, "cpu")
     t0 = time.perf_counter()
     with torch.no_grad():
@@ -80,7 +80,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    from oracle.model import fill_parameters_
     from tavsr import dp
     from tavsr.inference.beam_search import BatchBeamSearch
     from tavsr.lm.transformer_lm import TransformerLM
@@ -92,10 +91,9 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     conf = make_conf()
+    torch.manual_seed(1)                     # random-init weights (no checkpoints offline), the same on every rank
     model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf))).eval()
-    fill_parameters_(model, seed=1)          # deterministic synthetic weights (bench only: same values as the CPU baseline)
     lm = TransformerLM(len(conf["token_list"]), **LM_CONF).eval()
-    fill_parameters_(lm, seed=2)
     model, lm = model.to(dev), lm.to(dev)
     search = BatchBeamSearch(model, lm, **SEARCH)
 
@@ -153,7 +151,8 @@ def main():
                        "parallelism": f"replicas x{world}"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in model.state_dict().items()},
+                                               {k: v.cpu() for k, v in lm.state_dict().items()})
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
