@@ -328,6 +328,9 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
  *   tavsr_tree_attn_step : out[n][h] = softmax(scale * q[n][h] . K[anc[n][j]][h], j < nkeys) . V[anc[n][j]][h].
  *       Keys/values of all hypotheses live in a pool (row = one token of one hypothesis, H*dk floats, row stride ldkv);
  *       anc [N][ld_anc] int32 lists each hypothesis' own rows, so a beam re-order copies these lists only.
+ *       step_dev (nullable): device int32 holding the step index; the kernel then uses min(*step_dev + 1, nkeys) keys,
+ *       so one captured hipGraph of the scorer step can be replayed for every step of the search.
+ *   tavsr_kv_append      : kpool/vpool row (*step_dev * N + n) = k[n] / v[n] (the rows this step's anc column names).
  *   tavsr_ctc_prefix_step: espnet CTCPrefixScoreTH.__call__ (no attention window) for C candidate tokens per
  *       hypothesis.  logp [U][T][V] log-softmax of the CTC head, lens [U] frames, hypotheses n belong to utterance n / K.
  *       r_prev [N][T][2] / s_prev [N] / last_tok [N]: forward variables (non-blank, blank), log_psi and last token of
@@ -338,7 +341,9 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
  * ------------------------------------------------------------------------------------------- */
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                          const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N, int32_t H,
-                         int32_t dk, float scale, tavsr_stream_t stream);
+                         int32_t dk, float scale, const int32_t* step_dev, tavsr_stream_t stream);
+int tavsr_kv_append(const float* k, const float* v, int64_t ld_src, float* kpool, float* vpool, int64_t ldkv, int32_t N,
+                    int32_t D, int32_t max_steps, const int32_t* step_dev, tavsr_stream_t stream);
 int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,
                           const int64_t* last_tok, const int64_t* cand, float* r_new, float* psi, float* psi_abs, float* eos,
                           float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V, int32_t C, int32_t out_len,

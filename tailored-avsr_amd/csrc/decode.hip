@@ -20,8 +20,9 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
                                                              const float* __restrict__ kpool, const float* __restrict__ vpool,
                                                              int64_t ldkv, const int32_t* __restrict__ anc, int64_t ld_anc,
                                                              int nkeys, float* __restrict__ out, int64_t ldo, int N, int H,
-                                                             int dk, float scale) {
+                                                             int dk, float scale, const int32_t* __restrict__ step_dev) {
   __shared__ float s_p[4][kTreeMaxKeys];
+  if (step_dev) nkeys = min(*step_dev + 1, nkeys);        // replayed graphs: the step counter lives in device memory
   __shared__ float s_q[4][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool live = blockIdx.x * 4 + wave < N * H;       // surplus waves recompute the last item and store nothing
@@ -57,6 +58,20 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
     for (int j = 0; j < nkeys; ++j) acc += s_p[wave][j] * vpool[(int64_t)a[j] * ldkv + h * dk + d];
     if (live) out[(int64_t)n * ldo + h * dk + d] = acc * inv;
   }
+}
+
+// kpool/vpool row (step * N + n) = this step's key / value of hypothesis n; step read from device memory so that one
+// captured graph serves every step of the search (steps past the pool are dropped)
+__global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict__ k, const float* __restrict__ v, int64_t ld_src,
+                                                        float* __restrict__ kpool, float* __restrict__ vpool, int64_t ldkv, int N,
+                                                        int D4, int max_steps, const int32_t* __restrict__ step_dev) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int step = *step_dev;
+  if (i >= (int64_t)N * D4 || step < 0 || step >= max_steps) return;
+  const int n = (int)(i / D4), c = (int)(i % D4) * 4;
+  const int64_t dst = ((int64_t)step * N + n) * ldkv + c;
+  *reinterpret_cast<float4*>(kpool + dst) = *reinterpret_cast<const float4*>(k + (int64_t)n * ld_src + c);
+  *reinterpret_cast<float4*>(vpool + dst) = *reinterpret_cast<const float4*>(v + (int64_t)n * ld_src + c);
 }
 
 __device__ __forceinline__ float logaddexp2(float a, float b) {
@@ -166,7 +181,7 @@ extern "C" int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, t
 
 extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                                     const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N,
-                                    int32_t H, int32_t dk, float scale, tavsr_stream_t stream) {
+                                    int32_t H, int32_t dk, float scale, const int32_t* step_dev, tavsr_stream_t stream) {
   TAVSR_REQUIRE(q && kpool && vpool && anc && out, TAVSR_EINVAL, "tree_attn_step: null pointer");
   TAVSR_REQUIRE(nkeys > 0 && nkeys <= kTreeMaxKeys, TAVSR_EUNSUPPORTED, "tree_attn_step: 1..%d keys supported (got %d)",
                 kTreeMaxKeys, nkeys);
@@ -174,7 +189,20 @@ extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kp
                 "tree_attn_step: dk %% 4, dk <= 128 and 16-byte aligned key rows are required");
   if (N <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(tree_attn_step_kernel, dim3((unsigned)((N * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, kpool,
-                     vpool, ldkv, anc, ld_anc, nkeys, out, ldo, N, H, dk, scale);
+                     vpool, ldkv, anc, ld_anc, nkeys, out, ldo, N, H, dk, scale, step_dev);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_kv_append(const float* k, const float* v, int64_t ld_src, float* kpool, float* vpool, int64_t ldkv,
+                               int32_t N, int32_t D, int32_t max_steps, const int32_t* step_dev, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(k && v && kpool && vpool && step_dev, TAVSR_EINVAL, "kv_append: null pointer");
+  TAVSR_REQUIRE(D % 4 == 0 && ld_src % 4 == 0 && ldkv % 4 == 0 && (((uintptr_t)k | (uintptr_t)v | (uintptr_t)kpool | (uintptr_t)vpool) & 15) == 0,
+                TAVSR_EALIGN, "kv_append: rows must be float4-aligned");
+  if (N <= 0) return TAVSR_OK;
+  const int64_t n4 = (int64_t)N * (D / 4);
+  hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k, v, ld_src, kpool,
+                     vpool, ldkv, N, D / 4, max_steps, step_dev);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -896,8 +896,9 @@ def bucket_copy(ptrs, offs, sizes, n, flat, scale, to_flat, max_n):
 
 
 # ---------------------------------------------------------------------------------------------- decode steps
-def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None):
-    """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk]."""
+def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None):
+    """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk].
+    ``step_dev`` (int32 device scalar): use min(step + 1, nkeys) keys (graph replays)."""
     N = q.shape[0]
     require_cuda(q, kpool, vpool, anc)
     assert anc.dtype == torch.int32 and kpool.stride(0) == vpool.stride(0)
@@ -905,8 +906,17 @@ def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None):
         out = empty(N, H * dk, like=q)
     check(lib().tavsr_tree_attn_step(ptr(q), C.c_int64(q.stride(0)), ptr(kpool), ptr(vpool), C.c_int64(kpool.stride(0)),
                                      ptr(anc), C.c_int64(anc.stride(0)), int(nkeys), ptr(out), C.c_int64(out.stride(0)), N, H, dk,
-                                     C.c_float(1.0 / (dk ** 0.5)), stream()), "tavsr_tree_attn_step")
+                                     C.c_float(1.0 / (dk ** 0.5)), ptr(step_dev), stream()), "tavsr_tree_attn_step")
     return out
+
+
+def kv_append(k, v, kpool, vpool, N, max_steps, step_dev):
+    """kpool/vpool[step * N + n] = k[n] / v[n] with the step index read from device memory."""
+    require_cuda(k, v, kpool, vpool, step_dev)
+    assert step_dev.dtype == torch.int32 and k.stride(0) == v.stride(0) and kpool.stride(0) == vpool.stride(0)
+    assert kpool.shape[0] >= max_steps * N
+    check(lib().tavsr_kv_append(ptr(k), ptr(v), C.c_int64(k.stride(0)), ptr(kpool), ptr(vpool), C.c_int64(kpool.stride(0)),
+                                N, k.shape[1], int(max_steps), ptr(step_dev), stream()), "tavsr_kv_append")
 
 
 def ctc_prefix_step(logp, lens, r_prev, s_prev, last_tok, cand, K, out_len, blank=0):

@@ -99,6 +99,54 @@ def test_hip_beam_search_matches_oracle(beam, ctc_w, lm_w, pen):
 
 
 @pytest.mark.gpu
+def test_graph_replayed_scorer_step_equals_eager_launches(monkeypatch):
+    """The captured scorer step (device-side step counter, kv_append, in-place token / ancestor buffers) yields the
+    same hypotheses, bit for bit in the scores, as the eager launches with host-side step arguments."""
+    from tavsr.inference import beam_search as PBS
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.asr import ASRTask
+    conf = asr_conf(num_blocks=2, dec_blocks=2)
+    conf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**conf)).eval()
+    fill_parameters_(pm, seed=5)
+    plm = TransformerLM(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(plm, seed=6)
+    pm, plm = pm.cuda(), plm.cuda()
+    x = synth((4, 120, 80), seed=9).cuda()
+    lens = torch.tensor([120, 120, 96, 64]).cuda()
+    with torch.no_grad():
+        enc, olens = pm.encode(x, lens)
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(PBS, "GRAPH_STEP", flag)
+        outs.append(PBS.BatchBeamSearch(pm, plm, 6, 0.2, 0.5, 0.3).decode(enc, olens))
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_kv_append_and_device_step_tree_attention():
+    from tavsr import ops
+    N, H, dk, steps = 6, 4, 16, 5
+    D = H * dk
+    kpool, vpool = torch.zeros(steps * N, D).cuda(), torch.zeros(steps * N, D).cuda()
+    qkv = [synth((N, 3 * D), seed=30 + i).cuda() for i in range(steps)]
+    anc = (torch.arange(N).view(N, 1) + torch.arange(steps).view(1, steps) * N).to(torch.int32).cuda()
+    step_dev = torch.zeros(1, dtype=torch.int32).cuda()
+    for i in range(steps):
+        step_dev.fill_(i)
+        ops.kv_append(qkv[i][:, D:2 * D], qkv[i][:, 2 * D:], kpool, vpool, N, steps, step_dev)
+        got = ops.tree_attn_step(qkv[i][:, :D], kpool, vpool, anc, steps, H, dk, step_dev=step_dev)
+        want = ops.tree_attn_step(qkv[i][:, :D], kpool, vpool, anc, i + 1, H, dk)
+        assert torch.equal(got, want)
+    assert torch.equal(kpool, torch.cat([q[:, D:2 * D] for q in qkv]))
+    assert torch.equal(vpool, torch.cat([q[:, 2 * D:] for q in qkv]))
+    step_dev.fill_(steps)                                    # a step past the pool is dropped, not written
+    before = kpool.clone()
+    ops.kv_append(qkv[0][:, D:2 * D], qkv[0][:, 2 * D:], kpool, vpool, N, steps, step_dev)
+    assert torch.equal(kpool, before)
+
+
+@pytest.mark.gpu
 def test_speech2text_from_waveforms_end_to_end():
     """waveform batch -> log-mel -> encoder -> beam search + LM -> (text, tokens, ids, hyp) as the reference's
     Speech2Text returns them; the best hypothesis equals the oracle's on the oracle's own encoder output."""
