@@ -1,8 +1,10 @@
-"""Headline benchmark (BASELINE.json): utterances/s, forward+backward, 12-layer Branchformer ASR model
-(Conv2dSubsampling + 12 x MyBranchformerEncoderLayer + CTC + 6-layer Transformer decoder,
-configs/ASR/branchformer_transformer+ctc_english.yaml), batch 32 x 4 s clips (400 mel frames x 80)
-per GPU, fp32, synthetic data, random-init weights.  Weak scaling: every rank steps its own batch of 32;
-ranks exchange gradients once per step (RCCL all-reduce, tavsr.dp).
+"""Headline benchmark (BASELINE.json: "utterances/sec fwd+bwd, 12L AV-Branchformer, 4 s clips, batch 32, 1->8 MI355X"):
+utterances/s, forward+backward, of the tailored audio-visual Branchformer (BASELINE configs[2]/[3]: Conv3d + ResNet-18
+lip frontend, Conv2dSubsampling audio embed, 12 tailored AV layers, adaptive fusion, CTC + 6-layer Transformer decoder,
+configs/AVSR/tailored_transformer+ctc_english.yaml), batch 32 x 4 s clips (400 mel frames x 80 + 100 lip frames 88 x 88)
+per GPU, fp32, train mode with the recipe's dropout, synthetic data, random-init weights.  Weak scaling: every rank steps
+its own batch of 32; ranks exchange gradients once per step (RCCL all-reduce, tavsr.dp).
+``--workload asr`` runs BASELINE configs[1] instead (audio-only 12-layer Branchformer + CTC + decoder, same batch).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -35,15 +37,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 25
 # Algorithmic work, forward, per utterance (BASELINE.md section 2 / SURVEY Appendix C); fwd+bwd = 3x.
 GFLOP_PER_UTT_FWD = {"asr": 11.35, "avsr": 79.14}
 B_PER_GPU, T_IN, N_MEL, L_TXT, T_VID, HW = 32, 400, 80, 40, 100, 88
-WORKLOAD = "asr"   # set by --workload: "asr" = BASELINE configs[1] (the headline), "avsr" = configs[2]/[3]
+WORKLOAD = "avsr"  # set by --workload: "avsr" = BASELINE configs[2]/[3] (the AV-Branchformer the metric names), "asr" = configs[1]
 
 
 def hbm_traffic(layout_key):
     """HBM bytes per launch of the dominant GEMM family, from the committed rocprofv3 PMC pass over this same step
     (scripts/gpu_pmc_hbm.sh -> profiles/summarize_pmc.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes).  PMC
     counters cannot be read from inside the process, so this is the profile's number, or None if it is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-    if WORKLOAD != "asr" or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_av.json" if WORKLOAD == "avsr" else "r01_pmc_hbm.json")
+    if not os.path.exists(path):
         return None
     ak, bkm = {"NT": ("false", "false"), "NN": ("false", "true"), "TN": ("true", "true"), "TT": ("true", "false")}[layout_key[-3:-1]]
     tot = calls = 0.0
@@ -143,7 +145,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="all dropout rates 0 (the parity configuration)")
-    ap.add_argument("--workload", choices=("asr", "avsr"), default="asr",
+    ap.add_argument("--workload", choices=("asr", "avsr"), default="avsr",
                     help="asr: BASELINE configs[1] (headline); avsr: configs[2] tailored AV-Branchformer incl. the visual frontend")
     args = ap.parse_args()
     global WORKLOAD, DROPOUT
@@ -233,6 +235,7 @@ def main():
                    "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
                    "dropout": 0.1 if DROPOUT else 0.0,
                    "launch": "eager" if graph is None else "hipGraph replay (whole fwd+bwd)"},
+        "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
         "model_tflops_per_s": round(value * 3 * GFLOP_PER_UTT_FWD[WORKLOAD] / 1e3, 2),
         "frac_of_fp32_mfma_peak_whole_step": round(value * 3 * GFLOP_PER_UTT_FWD[WORKLOAD] / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
     }
@@ -256,6 +259,7 @@ def main():
             "launches_per_step": d["calls"] // nprof,
             "avg_launch_us": round(1e6 * d["seconds"] / d["calls"], 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 4),
+            "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]),   # every operand and the output once
             "all_gemm_ms_per_step": round(1e3 * gemm_s, 3),
             "all_gemm_tflops": round(sum(v["flops"] for v in summ.values()) / nprof / gemm_s / 1e12, 2),
             "by_kernel": {k: {"calls_per_step": v["calls"] // nprof, "ms_per_step": round(1e3 * v["seconds"] / nprof, 3),

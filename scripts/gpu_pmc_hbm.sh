@@ -1,4 +1,5 @@
-# HBM byte counters of the headline step: one rocprofv3 pass per counter (both together exceed the hardware's
+# usage: [OUT=name] bash scripts/gpu_pmc_hbm.sh [bench.py flags, e.g. --workload asr]
+# HBM byte counters of the benchmark step: one rocprofv3 pass per counter (both together exceed the hardware's
 # counter budget), --pmc with --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -23,5 +24,6 @@ with open("gpurun_out/pmc_hbm_counters.csv", "w") as out:
         except FileNotFoundError as e:
             print("missing", e)
 PY
-python profiles/summarize_pmc.py gpurun_out/pmc_hbm_counters.csv 2 gpurun_out/pmc_hbm.json > gpurun_out/pmc_hbm.txt; head -14 gpurun_out/pmc_hbm.txt
+OUT=${OUT:-pmc_hbm}
+python profiles/summarize_pmc.py gpurun_out/pmc_hbm_counters.csv 2 gpurun_out/$OUT.json > gpurun_out/$OUT.txt; head -14 gpurun_out/$OUT.txt
 rm -rf gpurun_out/pmc_hbm_counters.csv gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE

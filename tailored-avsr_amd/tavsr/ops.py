@@ -30,18 +30,19 @@ class GemmProfile:
     leg).  Off on the product path (``PROFILE is None``): zero overhead."""
 
     def __init__(self, by_shape: bool = False):
-        self.records = []  # (key, flops, start_event, end_event)
+        self.records = []  # (key, flops, operand bytes, start_event, end_event)
         self.by_shape = by_shape
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, flops, e0, e1 in self.records:
-            a = agg.setdefault(key, [0, 0.0, 0.0])
+        for key, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += e0.elapsed_time(e1) * 1e-3
-        return {k: dict(calls=v[0], flops=v[1], seconds=v[2]) for k, v in agg.items()}
+            a[3] += nbytes
+        return {k: dict(calls=v[0], flops=v[1], seconds=v[2], bytes=v[3]) for k, v in agg.items()}
 
 
 PROFILE: Optional[GemmProfile] = None
@@ -116,7 +117,12 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
     key = _gemm_kernel_key(d)
     if PROFILE.by_shape:
         key += f" M={M} N={N} K={K} nb={max(1, nb1) * max(1, nb2)}"
-    PROFILE.records.append((key, 2.0 * M * N * K * max(1, nb1) * max(1, nb2), e0, e1))
+    nb = max(1, nb1) * max(1, nb2)
+    a_el, b_el = M * K, K * N                 # each operand once; an implicit-conv operand is the image, not its 9 taps
+    if conv is not None:
+        a_el, b_el = (a_el // 9, b_el) if conv[0] == 1 else (a_el, b_el // 9)
+    c_el = M * N * (1 + (R is not None) + (Z is not None) + (DZ is not None))
+    PROFILE.records.append((key, 2.0 * M * N * K * nb, 4.0 * nb * (a_el + b_el + c_el), e0, e1))
 
 
 def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None):
@@ -329,8 +335,9 @@ class WgradGroup:
             if PROFILE is not None:
                 e1.record()
                 fl = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _, _ in chunk)
+                nby = sum(4.0 * (dy.numel() + x.numel() + dy.shape[1] * x.shape[1]) for dy, x, _, _, _ in chunk)
                 key = "gemm_kernel<TN>" + (f" grouped x{len(chunk)}" if PROFILE.by_shape else "")
-                PROFILE.records.append((key, fl, e0, e1))
+                PROFILE.records.append((key, fl, nby, e0, e1))
 
 
 def linear_group(x, wbs, out, ldc=None):
