@@ -4,7 +4,7 @@ positional encoding so that the two streams can be length-aligned in between."""
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple, Union
+from typing import Tuple, Union
 
 import torch
 

@@ -5,7 +5,6 @@ Reference semantics followed are cited per Function.
 """
 from __future__ import annotations
 
-import math
 from typing import List, Optional
 
 import torch

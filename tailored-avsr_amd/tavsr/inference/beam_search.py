@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import List, Optional, Tuple
+from typing import Optional
 
 import torch
 

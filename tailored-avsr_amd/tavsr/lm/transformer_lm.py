@@ -5,7 +5,6 @@ scorer of the beam search (src/inference/avsr_inference.py:155-170).  Its one-to
 teacher-forced form and exists for checking."""
 from __future__ import annotations
 
-import math
 
 import torch
 

@@ -13,7 +13,7 @@ import torch
 from .. import functional_av as FA
 from .. import ops
 from ..ctc.ctc import CTC
-from .espnet_model import ErrorCalculator, ESPnetASRModel
+from .espnet_model import ESPnetASRModel
 
 
 class ESPnetAVSRModel(ESPnetASRModel):

@@ -13,7 +13,6 @@
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Iterable, List, Optional
 
 import torch

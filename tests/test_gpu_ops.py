@@ -1,5 +1,4 @@
 """GPU: each HIP op through the C ABI vs a plain torch fp32/fp64 restatement of the same op."""
-import math
 
 import pytest
 import torch
