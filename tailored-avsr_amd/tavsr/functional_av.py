@@ -155,7 +155,8 @@ class VisualFrontendFn(torch.autograd.Function):
                 dy1, z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
             if stride == 1:
                 G[pre + "conv1.weight"] = _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin), p[pre + "conv1.weight"].shape)
-                dX = ops.conv3x3_dx(dz1, ops.conv_wflip(w1, planes, cin), Hin, Win)
+                # identity skip: its gradient joins in the GEMM epilogue (no separate add over the 0.4 GB maps)
+                dX = ops.conv3x3_dx(dz1, ops.conv_wflip(w1, planes, cin), Hin, Win, res=None if ds is not None else dres)
             else:
                 col1, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
                 G[pre + "conv1.weight"] = _w2d_grad(ops.linear_dw(dz1, col1), p[pre + "conv1.weight"].shape)
@@ -173,6 +174,8 @@ class VisualFrontendFn(torch.autograd.Function):
                 dcold = ops.linear_dx(dzd, wd)
                 dXd = ops.col2im2d(dcold, N, Hin, Win, cin, 1, 1, stride, 0)
                 d = ops.axpby(dX, dXd, 1.0, 1.0)
+            elif stride == 1:
+                d = dX
             else:
                 d = ops.axpby(dX, dres, 1.0, 1.0)
         # ---- stem

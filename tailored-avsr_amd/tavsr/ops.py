@@ -812,12 +812,13 @@ def conv3x3_fwd(x, w2d, H, W):
     return z
 
 
-def conv3x3_dx(dz, wflip, H, W):
-    """data gradient: dz [pixels, Cout], wflip [Cin, 9*Cout] (conv_wflip) -> [pixels, Cin]."""
+def conv3x3_dx(dz, wflip, H, W, res=None):
+    """data gradient: dz [pixels, Cout], wflip [Cin, 9*Cout] (conv_wflip) -> [pixels, Cin] (+ res: the skip path's
+    gradient, added in the GEMM epilogue)."""
     M, cout = dz.shape
     cin = wflip.shape[0]
     dx = empty(M, cin, like=dz)
-    gemm(M, cin, 9 * cout, dz, cout, wflip, 9 * cout, dx, cin, conv=(1, H, W, cout))
+    gemm(M, cin, 9 * cout, dz, cout, wflip, 9 * cout, dx, cin, conv=(1, H, W, cout), R=res, ldr=0 if res is None else cin)
     return dx
 
 
