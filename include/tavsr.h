@@ -366,6 +366,11 @@ int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int tavsr_bucket_copy(float* const* ptrs_dev, const int64_t* off_dev, const int64_t* n_dev, int32_t ntensors, float* flat,
                       float scale, int32_t to_flat, int64_t max_n, tavsr_stream_t stream);
 
+/* dst[t][i] += src[t][i], t < ntensors: the gradients of parameters shared by the two modality streams of a tailored AV
+ * layer (src/encoder/audiovisual/tailored/encoder_layer.py:118-274 applies the same FFN / norm modules to both streams;
+ * autograd sums their gradients).  dst / src / n are HOST arrays (the pointers ride in the kernel arguments). */
+int tavsr_multi_add(float* const* dst, const float* const* src, const int64_t* n, int32_t ntensors, tavsr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Train-mode dropout (every torch Dropout / F.dropout site of the path).  y[i] = keep_i ? x[i] / (1 - p) : 0 where
  * keep_i is a pure function of (seed_dev[0], offset + i) (Philox4x32-10): the SAME call on the upstream gradient is the

@@ -58,9 +58,56 @@ __global__ __launch_bounds__(256) void bucket_copy_kernel(float* const* __restri
   }
 }
 
+// dst[t][i] += src[t][i] for up to kMultiAddMax tensors in one launch (pointers travel in the kernel arguments: nothing to
+// stage in device memory, capturable).  Sums the shared parameters' gradients of the two modality streams of a tailored
+// AV layer (14 tensors per layer, most of them a few hundred floats).
+constexpr int kMultiAddMax = 24;
+struct MultiAddArgs {
+  float* dst[kMultiAddMax];
+  const float* src[kMultiAddMax];
+  int64_t n[kMultiAddMax];
+};
+__global__ __launch_bounds__(256) void multi_add_kernel(const MultiAddArgs a) {
+  const int t = blockIdx.y;
+  float* d = a.dst[t];
+  const float* s = a.src[t];
+  const int64_t cnt = a.n[t];
+  const bool vec = (((uintptr_t)d | (uintptr_t)s) & 15) == 0;
+  const int64_t n4 = vec ? cnt >> 2 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 u = reinterpret_cast<float4*>(d)[i];
+    const float4 v = reinterpret_cast<const float4*>(s)[i];
+    u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+    reinterpret_cast<float4*>(d)[i] = u;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) d[i] += s[i];
+}
+
 }  // namespace tavsr
 
 using namespace tavsr;
+
+extern "C" int tavsr_multi_add(float* const* dst, const float* const* src, const int64_t* n, int32_t ntensors,
+                               tavsr_stream_t stream) {
+  TAVSR_REQUIRE(ntensors <= 0 || (dst && src && n), TAVSR_EINVAL, "multi_add: null table");
+  for (int t0 = 0; t0 < ntensors; t0 += kMultiAddMax) {
+    MultiAddArgs a{};
+    const int cnt = std::min(kMultiAddMax, ntensors - t0);
+    int64_t mx = 0;
+    for (int t = 0; t < cnt; ++t) {
+      TAVSR_REQUIRE(n[t0 + t] == 0 || (dst[t0 + t] && src[t0 + t]), TAVSR_EINVAL, "multi_add: null tensor %d", t0 + t);
+      a.dst[t] = dst[t0 + t];
+      a.src[t] = src[t0 + t];
+      a.n[t] = n[t0 + t];
+      mx = std::max(mx, n[t0 + t]);
+    }
+    if (mx <= 0) continue;
+    const int64_t chunks = std::min<int64_t>(std::max<int64_t>(1, (mx / 4 + 255) / 256), 512);
+    hipLaunchKernelGGL(tavsr::multi_add_kernel, dim3((unsigned)chunks, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, a);
+    TAVSR_LAUNCH_CHECK();
+  }
+  return TAVSR_OK;
+}
 
 extern "C" int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                float eps, int64_t step, float grad_scale, tavsr_stream_t stream) {

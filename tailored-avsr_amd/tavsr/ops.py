@@ -903,6 +903,22 @@ def bucket_copy(ptrs, offs, sizes, n, flat, scale, to_flat, max_n):
                                   C.c_int64(max_n), stream()), "tavsr_bucket_copy")
 
 
+def multi_add_(dst, src):
+    """dst[t] += src[t] for lists of contiguous fp32 tensors, one launch per 24 tensors."""
+    assert len(dst) == len(src)
+    if not dst:
+        return dst
+    require_cuda(*dst, *src)
+    n = len(dst)
+    for a, b in zip(dst, src):
+        assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() and a.dtype == f32 and b.dtype == f32
+    dp = (C.c_void_p * n)(*[t.data_ptr() for t in dst])
+    sp = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+    cnt = (C.c_int64 * n)(*[t.numel() for t in dst])
+    check(lib().tavsr_multi_add(dp, sp, cnt, n, stream()), "tavsr_multi_add")
+    return dst
+
+
 # ---------------------------------------------------------------------------------------------- decode steps
 def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None):
     """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk].

@@ -286,3 +286,19 @@ def test_grouped_helpers_match_the_plain_calls():
     sa, sb = ops.add2_colsum(a, b, buf[:, :D])
     assert torch.equal(buf[:, :D], a + b)
     assert torch.equal(sa, ops.colsum(a)) and torch.equal(sb, ops.colsum(b))
+
+
+def test_multi_add_sums_lists_of_tensors_in_place():
+    from tavsr import ops
+    torch.manual_seed(4)
+    sizes = [1, 3, 256, 257, 2048 * 256, 5, 64] * 5            # 35 tensors: two launches; unaligned views included
+    base = torch.randn(sum(sizes) + 1, device="cuda")
+    dst, src, off = [], [], 1                                   # off = 1: views that are not 16-byte aligned
+    for n in sizes:
+        dst.append(base[off: off + n])
+        src.append(torch.randn(n, device="cuda"))
+        off += n
+    want = [d.clone() + s for d, s in zip(dst, src)]
+    out = ops.multi_add_(dst, src)
+    for o, d, w in zip(out, dst, want):
+        assert o.data_ptr() == d.data_ptr() and torch.equal(d, w)
