@@ -388,6 +388,20 @@ int tavsr_dropout_add(const float* a, const float* t, float* y, int64_t n, float
 int tavsr_dropout_act_bwd(const float* dh, const float* z, float* dz, int64_t n, float p, int32_t act,
                           const uint64_t* seed_dev, uint64_t offset, tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Error rates of the decode output: what src/evaluation/bootstrap_wer.py:3-16 obtains from the
+ * tasas / tasasIntervalo programs (src/evaluation/tasas/tasas.c: gp() unit-cost alignment, tasa_ie; tasasIntervalo.c:
+ * 1000 bootstrap resamples, 1.64 sigma).
+ *   tavsr_edit_distance  : dist[p] = Levenshtein distance of ref[ref_off[p] .. ref_off[p+1]) and hyp[hyp_off[p] .. ) (symbol
+ *       ids; offsets have n_pairs + 1 entries; max_len >= every sequence length, <= 4095).
+ *   tavsr_bootstrap_rates: rates[it] = 100 * sum dist[idx] / sum reflen[idx] over n indices drawn uniformly with
+ *       replacement (Philox, counter = (position, it), key = seed), it < iters.
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_edit_distance(const int32_t* ref, const int64_t* ref_off, const int32_t* hyp, const int64_t* hyp_off, int32_t n_pairs,
+                        int32_t max_len, int32_t* dist, tavsr_stream_t stream);
+int tavsr_bootstrap_rates(const int32_t* dist, const int32_t* reflen, int32_t n, int32_t iters, uint64_t seed, double* rates,
+                          tavsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,5 @@
 """Which host-side calls produce device-to-device copies in one eager fwd+bwd step (torch profiler, stacks).
-usage: python profiles/find_copies.py > gpurun_out/copies.txt"""
+usage: python profiles/find_copies.py [asr|avsr] > gpurun_out/copies.txt"""
 import collections
 import os
 import sys
@@ -13,6 +13,8 @@ import bench  # noqa: E402
 
 
 def main():
+    if len(sys.argv) > 1:
+        bench.WORKLOAD = sys.argv[1]
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model = bench.build_product_model().to(dev).train()
@@ -39,6 +41,18 @@ def main():
             cnt[(ev.name, str(ev.input_shapes)[:60], " <- ".join(s.split("/")[-1][:70] for s in stack))] += 1
     for (name, shp, st), n in cnt.most_common(60):
         print(f"{n:5d} {name:18s} {shp:60s} {st}")
+    print()
+    # device-to-device copies by the op that issued them (autograd's AccumulateGrad clones views / non-stealable grads)
+    by = collections.Counter()
+    for ev in prof.events():
+        if "copy" in ev.name.lower() or "clone" in ev.name.lower():
+            par, chain = ev.cpu_parent, []
+            while par is not None and len(chain) < 3:
+                chain.append(par.name[:50])
+                par = par.cpu_parent
+            by[(ev.name[:40], str(ev.input_shapes)[:50], " <- ".join(chain))] += 1
+    for (name, shp, chain), n in by.most_common(40):
+        print(f"{n:5d} {name:40s} {shp:50s} {chain}")
     print()
     print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=25, max_name_column_width=60))
 

@@ -919,6 +919,28 @@ def multi_add_(dst, src):
     return dst
 
 
+# ---------------------------------------------------------------------------------------------- error rates
+def edit_distance(ref, ref_off, hyp, hyp_off, n_pairs, max_len):
+    """Levenshtein distance of n_pairs (reference, hypothesis) id sequences packed as (int32 ids, int64 offsets)."""
+    require_cuda(ref, ref_off, hyp, hyp_off)
+    assert ref.dtype == torch.int32 and hyp.dtype == torch.int32 and ref_off.dtype == torch.int64 and hyp_off.dtype == torch.int64
+    assert ref_off.numel() == n_pairs + 1 and hyp_off.numel() == n_pairs + 1
+    dist = torch.empty(n_pairs, dtype=torch.int32, device=ref.device)
+    check(lib().tavsr_edit_distance(ptr(ref), ptr(ref_off), ptr(hyp), ptr(hyp_off), int(n_pairs), int(max_len), ptr(dist),
+                                    stream()), "tavsr_edit_distance")
+    return dist
+
+
+def bootstrap_rates(dist, reflen, iters, seed):
+    """100 * sum(dist[idx]) / sum(reflen[idx]) for ``iters`` resamples idx of the n sentences -> float64 [iters]."""
+    require_cuda(dist, reflen)
+    assert dist.dtype == torch.int32 and reflen.dtype == torch.int32 and dist.numel() == reflen.numel()
+    rates = torch.empty(iters, dtype=torch.float64, device=dist.device)
+    check(lib().tavsr_bootstrap_rates(ptr(dist), ptr(reflen), dist.numel(), int(iters), C.c_uint64(seed), ptr(rates), stream()),
+          "tavsr_bootstrap_rates")
+    return rates
+
+
 # ---------------------------------------------------------------------------------------------- decode steps
 def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None):
     """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk].
