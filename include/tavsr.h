@@ -402,6 +402,22 @@ int tavsr_edit_distance(const int32_t* ref, const int64_t* ref_off, const int32_
 int tavsr_bootstrap_rates(const int32_t* dist, const int32_t* reflen, int32_t n, int32_t iters, uint64_t seed, double* rates,
                           tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batch assembly: the video pipeline of avsr_main.py:168-179 (src/transforms/video_transforms.py:59-147 +
+ * torchvision RandomCrop / RandomHorizontalFlip) fused with the padding of src/utils/avsr_dataloader.py:102-142.
+ *   tavsr_video_prep: dst[t][y][x], t < Tpad, of one clip: for t < T the source pixel
+ *       src[frames ? frames[t] : t][y0 + y][x0 + (flip ? tw-1-x : x)] (uint8 or float) through n_affine steps
+ *       v = (v - mean[k]) / std[k]; frames with masked[t] != 0 take the clip's mean frame (mean over t < T of those values,
+ *       computed first into mean_frame_ws [th*tw]); frames t >= T take `pad`.  mean / std are HOST arrays (they ride in the
+ *       kernel arguments); src, frames, masked, mean_frame_ws, dst are device pointers.
+ *   tavsr_add_noise : out = audio + (inv_snr * noise) * sqrt(mean(audio^2) / mean(noise^2))  (audio_transforms.py:126-133).
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_video_prep(const void* src, int32_t is_u8, int32_t Ts, int32_t H, int32_t W, const int32_t* frames, int32_t T,
+                     int32_t y0, int32_t x0, int32_t th, int32_t tw, int32_t flip, const float* mean, const float* std,
+                     int32_t n_affine, const uint8_t* masked, float* mean_frame_ws, float* dst, int32_t Tpad, float pad,
+                     tavsr_stream_t stream);
+int tavsr_add_noise(const float* audio, const float* noise, float* out, int64_t n, float inv_snr, tavsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -919,6 +919,35 @@ def multi_add_(dst, src):
     return dst
 
 
+# ---------------------------------------------------------------------------------------------- batch assembly
+def video_prep(src, index, T, y0, x0, th, tw, flip, affine, masked, out, pad_value):
+    """one clip -> its row of the padded batch (tavsr_video_prep); ``index`` / ``masked`` are host lists / arrays or None."""
+    require_cuda(src, out)
+    dev = src.device
+    Ts, H, W = src.shape
+    frames = None if index is None else torch.tensor(index, dtype=torch.int32).to(dev)
+    if frames is not None and T > 0 and (min(index) < 0 or max(index) >= Ts):
+        raise ValueError("frame index outside the clip")
+    m = None if masked is None or not masked.any() else torch.from_numpy(masked.astype("uint8")).to(dev)
+    ws = empty(th * tw, like=out) if m is not None else None
+    n = len(affine)
+    mean = (C.c_float * 4)(*[a[0] for a in affine], *([0.0] * (4 - n)))
+    std = (C.c_float * 4)(*[a[1] for a in affine], *([1.0] * (4 - n)))
+    check(lib().tavsr_video_prep(ptr(src), int(src.dtype == torch.uint8), Ts, H, W, ptr(frames), int(T), int(y0), int(x0), int(th),
+                                 int(tw), int(bool(flip)), mean, std, n, ptr(m), ptr(ws), ptr(out), int(out.shape[0]),
+                                 C.c_float(pad_value), stream()), "tavsr_video_prep")
+    return out
+
+
+def add_noise(audio, noise, inv_snr):
+    require_cuda(audio, noise)
+    assert audio.numel() == noise.numel() and audio.is_contiguous() and noise.is_contiguous()
+    out = torch.empty_like(audio)
+    check(lib().tavsr_add_noise(ptr(audio), ptr(noise), ptr(out), C.c_int64(audio.numel()), C.c_float(inv_snr), stream()),
+          "tavsr_add_noise")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- error rates
 def edit_distance(ref, ref_off, hyp, hyp_off, n_pairs, max_len):
     """Levenshtein distance of n_pairs (reference, hypothesis) id sequences packed as (int32 ids, int64 offsets)."""
