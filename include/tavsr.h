@@ -73,9 +73,14 @@ typedef struct tavsr_gemm_desc {
                     the image - forward with B = weights [Cout][9*C], data gradient with B = flipped weights;
        conv_mode 2: B is X (k-major, ldb = C), N = 9*C, a_kmajor: weight gradient dW[co][tap*C + c] = sum_m dY[m][co] *
                     patch(m, tap, c).
-     conv_zero: >= 16 readable zero bytes (16-byte aligned) that out-of-image loads are pointed at.  0: plain GEMM. */
+     conv_zero: >= 16 readable zero bytes (16-byte aligned) that out-of-image loads are pointed at.  0: plain GEMM.
+     conv_stride s (0 = 1) and conv_taps (0 = 9, or 1): the strided 3x3 / pad 1 and 1x1 / pad 0 convolutions of the blocks
+     that halve the maps (resnet.py:68-87 downsample, :95-97 conv1).  conv_H x conv_W is always the INPUT image; the rows
+     of the patch operand are the OUTPUT pixels (n, ho, wo), Ho = (H-1)/s + 1, centred on input pixel (s*ho, s*wo);
+     K (mode 1) / N (mode 2) = taps * C. */
   int32_t conv_mode, conv_H, conv_W, conv_C;
   const float* conv_zero;
+  int32_t conv_stride, conv_taps;
 } tavsr_gemm_desc;
 
 int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);

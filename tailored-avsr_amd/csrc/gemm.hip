@@ -560,22 +560,28 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
   const float* Ak = A + (AK ? (int64_t)kbeg * d.lda : kbeg);
   const float* Bk = B + (BKM ? (int64_t)kbeg * d.ldb : kbeg);
   uint32_t cmask[LA::NR];               // CONV 1: bit tap = the tap's neighbour of this thread's row is inside the image
+  const int cs = d.conv_stride > 1 ? d.conv_stride : 1;         // CONV: stride; 9 taps (3x3, pad 1) or 1 (1x1, pad 0)
+  const bool c9 = d.conv_taps != 1;
+  const int cHo = CONV ? (d.conv_H - 1) / cs + 1 : 1, cWo = CONV ? (d.conv_W - 1) / cs + 1 : 1;
   if (CONV == 1) {
 #pragma unroll
     for (int i = 0; i < LA::NR; ++i) {
       const int m = min(m0 + ((i * NT + tid) >> 3), d.M - 1);
-      const int x = m % d.conv_W, y = (m / d.conv_W) % d.conv_H;
+      // row m = output pixel (n, ho, wo), centred on input pixel (cs*ho, cs*wo)
+      const int x = (m % cWo) * cs, y = ((m / cWo) % cHo) * cs;
+      if (cs > 1) offA[i] += ((int64_t)((m / (cWo * cHo)) * d.conv_H + y) * d.conv_W + x - m) * d.conv_C;
       uint32_t mk = 0;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap)
         mk |= (uint32_t)((unsigned)(y + tap / 3 - 1) < (unsigned)d.conv_H && (unsigned)(x + tap % 3 - 1) < (unsigned)d.conv_W) << tap;
-      cmask[i] = mk;
+      cmask[i] = c9 ? mk : 1u;
     }
   }
   auto issue = [&](int kt, int st) {
     if (CONV == 1) {
       const int kk = kbeg + kt * BK, tap = kk / d.conv_C;
-      const int64_t delta = (int64_t)((tap / 3 - 1) * d.conv_W + (tap % 3 - 1)) * d.conv_C + (kk - tap * d.conv_C);
+      const int toff = c9 ? (tap / 3 - 1) * d.conv_W + (tap % 3 - 1) : 0;
+      const int64_t delta = (int64_t)toff * d.conv_C + (kk - tap * d.conv_C);
 #pragma unroll
       for (int i = 0; i < LA::NR; ++i) {
         const float* src = ((cmask[i] >> tap) & 1u) ? A + offA[i] + delta : d.conv_zero;
@@ -585,14 +591,15 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       LA::issue(Ak + kt * kstepA, offA, smem + st * STAGE, wave);
     }
     if (CONV == 2) {
-      const int tap = n0 / d.conv_C, cb = n0 - tap * d.conv_C, dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int tap = n0 / d.conv_C, cb = n0 - tap * d.conv_C, dy = c9 ? tap / 3 - 1 : 0, dx = c9 ? tap % 3 - 1 : 0;
 #pragma unroll
       for (int i = 0; i < LB::NR; ++i) {
         const int q = i * NT + tid;
         const int m = kbeg + kt * BK + q / (BN / 4), r = (q % (BN / 4)) * 4;
-        const int x = m % d.conv_W, y = (m / d.conv_W) % d.conv_H;
+        const int x = (m % cWo) * cs, y = ((m / cWo) % cHo) * cs;
         const bool ok = (unsigned)(y + dy) < (unsigned)d.conv_H && (unsigned)(x + dx) < (unsigned)d.conv_W;
-        const float* src = ok ? B + (int64_t)(m + dy * d.conv_W + dx) * d.conv_C + cb + r : d.conv_zero;
+        const int64_t pix = cs > 1 ? (int64_t)((m / (cWo * cHo)) * d.conv_H + y) * d.conv_W + x : m;
+        const float* src = ok ? B + (pix + dy * d.conv_W + dx) * d.conv_C + cb + r : d.conv_zero;
         __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + ASZ + (i * NT + wave * 64) * 4), 16, 0, 0);
       }
     } else {
@@ -919,14 +926,17 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
                   "tavsr_gemm: conv needs H, W, C and a 16-byte aligned zero page");
     TAVSR_REQUIRE(d.nb1 * d.nb2 == 1 && fast && force_cfg < 0, TAVSR_EUNSUPPORTED,
                   "tavsr_gemm: conv operands need an unbatched, aligned problem with K %% 32 == 0");
-    const int64_t pixels = d.conv_mode == 1 ? d.M : d.K;
-    TAVSR_REQUIRE(pixels % ((int64_t)d.conv_H * d.conv_W) == 0, TAVSR_EINVAL, "tavsr_gemm: conv rows are not whole images");
+    const int cs = d.conv_stride > 1 ? d.conv_stride : 1, taps = d.conv_taps == 1 ? 1 : 9;
+    TAVSR_REQUIRE(d.conv_taps == 0 || d.conv_taps == 1 || d.conv_taps == 9, TAVSR_EINVAL, "tavsr_gemm: conv_taps must be 1 or 9");
+    const int64_t pixels = d.conv_mode == 1 ? d.M : d.K;       // output pixels
+    const int64_t per_image = (int64_t)((d.conv_H - 1) / cs + 1) * ((d.conv_W - 1) / cs + 1);
+    TAVSR_REQUIRE(pixels % per_image == 0, TAVSR_EINVAL, "tavsr_gemm: conv rows are not whole images");
     if (d.conv_mode == 1)
-      TAVSR_REQUIRE(!d.a_kmajor && d.K == 9 * d.conv_C && d.conv_C % 32 == 0 && d.lda == d.conv_C, TAVSR_EUNSUPPORTED,
-                    "tavsr_gemm: conv mode 1 needs a row-major image operand A, K = 9 C, C %% 32 == 0");
+      TAVSR_REQUIRE(!d.a_kmajor && d.K == taps * d.conv_C && d.conv_C % 32 == 0 && d.lda == d.conv_C, TAVSR_EUNSUPPORTED,
+                    "tavsr_gemm: conv mode 1 needs a row-major image operand A, K = taps * C, C %% 32 == 0");
     else
-      TAVSR_REQUIRE(d.a_kmajor && d.b_kmajor && d.N == 9 * d.conv_C && d.conv_C % 64 == 0 && d.ldb == d.conv_C,
-                    TAVSR_EUNSUPPORTED, "tavsr_gemm: conv mode 2 needs the TN layout, N = 9 C, C %% 64 == 0");
+      TAVSR_REQUIRE(d.a_kmajor && d.b_kmajor && d.N == taps * d.conv_C && d.conv_C % 64 == 0 && d.ldb == d.conv_C,
+                    TAVSR_EUNSUPPORTED, "tavsr_gemm: conv mode 2 needs the TN layout, N = taps * C, C %% 64 == 0");
     Plan pc = plan_conv(d, can_split);
     if (pc.nsplit > 1 && d.ws_floats < ws_floats_for(d, pc.nsplit)) pc = plan(d, false, true);
     return launch_conv(d, pc.nsplit, pc.kchunk, s);

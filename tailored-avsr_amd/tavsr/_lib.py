@@ -41,7 +41,7 @@ class GemmDesc(C.Structure):
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("a_rowsum", C.c_void_p),
         ("conv_mode", C.c_int32), ("conv_H", C.c_int32), ("conv_W", C.c_int32), ("conv_C", C.c_int32),
-        ("conv_zero", C.c_void_p),
+        ("conv_zero", C.c_void_p), ("conv_stride", C.c_int32), ("conv_taps", C.c_int32),
     ]
 
 

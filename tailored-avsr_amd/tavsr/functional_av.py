@@ -47,12 +47,13 @@ def _w2d_grad(g, shape):
     return ops.transpose_inner(g, co, kh * kw, ci).view(shape)
 
 
-def _conv3x3_dw(dz, x, N, H, W, cin):
-    """weight gradient of a 3x3/s1/p1 convolution [Cout, 9*Cin]: implicit GEMM when the pixel count gives whole
-    32-row K-steps (every BASELINE shape), else through the im2col matrix."""
-    if (N * H * W) % 32 == 0:
-        return ops.conv3x3_dw(dz, x, H, W)
-    col, _, _ = ops.im2col2d(x, N, H, W, cin, 3, 3, 1, 1)
+def _conv3x3_dw(dz, x, N, H, W, cin, stride=1, taps=9):
+    """weight gradient of a 3x3/p1 (taps 9) or 1x1/p0 (taps 1) convolution [Cout, taps*Cin]: implicit GEMM when the output
+    pixel count gives whole 32-row K-steps (every BASELINE shape), else through the im2col matrix."""
+    if dz.shape[0] % 32 == 0 and cin % 64 == 0:
+        return ops.conv3x3_dw(dz, x, H, W, stride, taps)
+    k = 3 if taps == 9 else 1
+    col, _, _ = ops.im2col2d(x, N, H, W, cin, k, k, stride, k // 2)
     return ops.linear_dw(dz, col)
 
 
@@ -104,13 +105,9 @@ class VisualFrontendFn(torch.autograd.Function):
                 has_ds = (pre + "downsample.0.weight") in p
                 Xin, Hin, Win = cur, Hc, Wc
                 w1 = _w2d(p[pre + "conv1.weight"])
-                if stride == 1:       # implicit GEMM: the image itself is the A operand (no im2col matrix)
-                    Ho, Wo = Hin, Win
-                    z1 = ops.conv3x3_fwd(Xin, w1, Hin, Win)
-                else:
-                    col1, Ho, Wo = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
-                    z1 = ops.linear(col1, w1)
-                    del col1
+                # implicit GEMM: the image itself is the A operand (no im2col matrix), also for the stride-2 blocks
+                Ho, Wo = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+                z1 = ops.conv3x3_fwd(Xin, w1, Hin, Win, stride)
                 m1, r1 = _BN.stats(z1, pre + "bn1.", bufs, training)
                 y1 = ops.bn_apply_fwd(z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
                 w2 = _w2d(p[pre + "conv2.weight"])
@@ -118,10 +115,8 @@ class VisualFrontendFn(torch.autograd.Function):
                 m2, r2 = _BN.stats(z2, pre + "bn2.", bufs, training)
                 ds = None
                 if has_ds:
-                    cold, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 1, 1, stride, 0)
                     wd = _w2d(p[pre + "downsample.0.weight"])
-                    zd = ops.linear(cold, wd)
-                    del cold
+                    zd = ops.conv3x3_fwd(Xin, wd, Hin, Win, stride, taps=1)
                     md, rd = _BN.stats(zd, pre + "downsample.1.", bufs, training)
                     res = ops.bn_apply_fwd(zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None)
                     ds = (zd, md, rd, wd)
@@ -158,9 +153,7 @@ class VisualFrontendFn(torch.autograd.Function):
                 # identity skip: its gradient joins in the GEMM epilogue (no separate add over the 0.4 GB maps)
                 dX = ops.conv3x3_dx(dz1, ops.conv_wflip(w1, planes, cin), Hin, Win, res=None if ds is not None else dres)
             else:
-                col1, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 3, 3, stride, 1)
-                G[pre + "conv1.weight"] = _w2d_grad(ops.linear_dw(dz1, col1), p[pre + "conv1.weight"].shape)
-                del col1
+                G[pre + "conv1.weight"] = _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin, stride), p[pre + "conv1.weight"].shape)
                 dcol1 = ops.linear_dx(dz1, w1)
                 dX = ops.col2im2d(dcol1, N, Hin, Win, cin, 3, 3, stride, 1)
                 del dcol1
@@ -168,9 +161,8 @@ class VisualFrontendFn(torch.autograd.Function):
                 zd, md, rd, wd = ds
                 _, dzd, G[pre + "downsample.1.weight"], G[pre + "downsample.1.bias"] = ops.bn_bwd(
                     dres, zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None)
-                cold, _, _ = ops.im2col2d(Xin, N, Hin, Win, cin, 1, 1, stride, 0)
-                G[pre + "downsample.0.weight"] = _w2d_grad(ops.linear_dw(dzd, cold), p[pre + "downsample.0.weight"].shape)
-                del cold
+                G[pre + "downsample.0.weight"] = _w2d_grad(_conv3x3_dw(dzd, Xin, N, Hin, Win, cin, stride, taps=1),
+                                                           p[pre + "downsample.0.weight"].shape)
                 dcold = ops.linear_dx(dzd, wd)
                 dXd = ops.col2im2d(dcold, N, Hin, Win, cin, 1, 1, stride, 0)
                 d = ops.axpby(dX, dXd, 1.0, 1.0)

@@ -90,8 +90,10 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.DZ, d.dact = _addr(DZ, c_off), ACT[dact]
     if a_rowsum is not None:
         d.a_rowsum = a_rowsum.data_ptr()
-    if conv is not None:       # (mode, H, W, C): implicit 3x3/s1/p1 convolution operand (include/tavsr.h)
-        d.conv_mode, d.conv_H, d.conv_W, d.conv_C = conv
+    if conv is not None:       # (mode, H, W, C[, stride, taps]): implicit convolution operand (include/tavsr.h)
+        d.conv_mode, d.conv_H, d.conv_W, d.conv_C = conv[:4]
+        if len(conv) > 4:
+            d.conv_stride, d.conv_taps = conv[4], conv[5]
         d.conv_zero = _zero_page(Cc.device).data_ptr()
     if force is not None and force[1] > 1:
         need = force[1] * max(1, nb1) * max(1, nb2) * M * N + force[1] * M
@@ -803,12 +805,15 @@ def conv_wflip(w2d, cout, cin):
     return out
 
 
-def conv3x3_fwd(x, w2d, H, W):
-    """implicit 3x3/s1/p1 convolution: x [pixels, Cin] channels-last image rows, w2d [Cout, 9*Cin] -> [pixels, Cout]."""
+def conv3x3_fwd(x, w2d, H, W, stride=1, taps=9):
+    """implicit 3x3/p1 (taps 9) or 1x1/p0 (taps 1) convolution with stride: x [images*H*W, Cin] channels-last image rows,
+    w2d [Cout, taps*Cin] -> [images*Ho*Wo, Cout]."""
     M, cin = x.shape
     cout = w2d.shape[0]
-    z = empty(M, cout, like=x)
-    gemm(M, cout, 9 * cin, x, cin, w2d, 9 * cin, z, cout, conv=(1, H, W, cin))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    Mo = M // (H * W) * Ho * Wo
+    z = empty(Mo, cout, like=x)
+    gemm(Mo, cout, taps * cin, x, cin, w2d, taps * cin, z, cout, conv=(1, H, W, cin, stride, taps))
     return z
 
 
@@ -822,12 +827,12 @@ def conv3x3_dx(dz, wflip, H, W, res=None):
     return dx
 
 
-def conv3x3_dw(dz, x, H, W):
-    """weight gradient: dz [pixels, Cout], x [pixels, Cin] -> [Cout, 9*Cin]; needs pixels % 32 == 0."""
+def conv3x3_dw(dz, x, H, W, stride=1, taps=9):
+    """weight gradient: dz [output pixels, Cout], x [images*H*W, Cin] -> [Cout, taps*Cin]; needs output pixels % 32 == 0."""
     M, cout = dz.shape
     cin = x.shape[1]
-    dw = empty(cout, 9 * cin, like=dz)
-    gemm(cout, 9 * cin, M, dz, cout, x, cin, dw, 9 * cin, a_kmajor=True, b_kmajor=True, conv=(2, H, W, cin))
+    dw = empty(cout, taps * cin, like=dz)
+    gemm(cout, taps * cin, M, dz, cout, x, cin, dw, taps * cin, a_kmajor=True, b_kmajor=True, conv=(2, H, W, cin, stride, taps))
     return dw
 
 

@@ -343,3 +343,31 @@ def test_implicit_conv3x3_vs_conv2d(N, H, W, Cin, Cout):
     else:
         with pytest.raises(Exception):
             ops.conv3x3_dw(dzl, xl, H, W)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k", [(4, 22, 22, 64, 128, 3), (4, 22, 22, 64, 128, 1), (32, 11, 11, 128, 256, 3),
+                                              (32, 11, 11, 128, 256, 1), (32, 6, 6, 256, 512, 3), (16, 6, 6, 256, 512, 1),
+                                              (32, 7, 9, 64, 64, 3)])
+def test_strided_implicit_conv_vs_conv2d(N, H, W, Cin, Cout, k):
+    """conv_stride 2 with 9 taps (3x3, pad 1) or 1 tap (1x1, pad 0): the blocks that halve the maps (resnet.py:68-97),
+    forward and weight gradient against torch conv2d; odd map sizes included."""
+    from tavsr import ops
+    from tavsr.functional_av import _conv3x3_dw, _w2d, _w2d_grad
+    torch.manual_seed(1)
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    zr = torch.nn.functional.conv2d(xr, wr, stride=2, padding=k // 2)
+    dz = torch.randn_like(zr)
+    zr.backward(dz)
+    Ho, Wo = zr.shape[2:]
+    xl = x.permute(0, 2, 3, 1).reshape(N * H * W, Cin).contiguous().cuda()
+    dzl = dz.permute(0, 2, 3, 1).reshape(N * Ho * Wo, Cout).contiguous().cuda()
+    w2d = _w2d(w.cuda())
+    z = ops.conv3x3_fwd(xl, w2d, H, W, 2, k * k)
+    assert z.shape == (N * Ho * Wo, Cout)
+    assert rel_err(z.cpu().view(N, Ho, Wo, Cout).permute(0, 3, 1, 2), zr.detach()) < 2e-5
+    dw = _w2d_grad(_conv3x3_dw(dzl, xl, N, H, W, Cin, 2, k * k), w.shape)          # implicit when N*Ho*Wo % 32 == 0
+    assert rel_err(dw.cpu(), wr.grad) < 2e-5
+    if (N * Ho * Wo) % 32 == 0:
+        assert rel_err(_w2d_grad(ops.conv3x3_dw(dzl, xl, H, W, 2, k * k), w.shape).cpu(), wr.grad) < 2e-5
