@@ -342,6 +342,7 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
  *       each hypothesis (ignored when out_len == 0: the <sos> state is used).  Writes r_new [N][T][2][C],
  *       psi [N][C] = log_psi(cand) - s_prev, psi_abs [N][C] = log_psi(cand), eos [N] = log p(prefix ends) - s_prev,
  *       eos_abs [N].  A candidate equal to <eos> must take the eos value (caller); blank scores -1e10.
+ *       step_dev (nullable): device int32 that replaces out_len (graph replays, as in tavsr_tree_attn_step).
  *   tavsr_log_softmax_rows: y[m][:] = log_softmax(x[m][:V]).
  * ------------------------------------------------------------------------------------------- */
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
@@ -352,7 +353,7 @@ int tavsr_kv_append(const float* k, const float* v, int64_t ld_src, float* kpool
 int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,
                           const int64_t* last_tok, const int64_t* cand, float* r_new, float* psi, float* psi_abs, float* eos,
                           float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V, int32_t C, int32_t out_len,
-                          int32_t blank, tavsr_stream_t stream);
+                          int32_t blank, const int32_t* step_dev, tavsr_stream_t stream);
 int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t V, tavsr_stream_t stream);
 /* y = act(x) elementwise (the LM's Linear -> LayerNorm -> ReLU input layer); in place allowed */
 int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, tavsr_stream_t stream);

@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256) void ctc_prefix_step_kernel(const float* __res
                                                               const int64_t* __restrict__ cand, float* __restrict__ r_new,
                                                               float* __restrict__ psi, float* __restrict__ psi_abs,
                                                               float* __restrict__ eos, float* __restrict__ eos_abs, int N,
-                                                              int K, int T, int V, int C, int out_len, int blank, int first) {
+                                                              int K, int T, int V, int C, int out_len, int blank, int first,
+                                                              const int32_t* __restrict__ step_dev) {
   const float logzero = -10000000000.0f;
+  if (step_dev) { out_len = *step_dev; first = out_len == 0; }     // replayed graphs: the step counter lives in device memory
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N * C) return;
   const int n = i / C, c = i % C;
@@ -210,13 +212,13 @@ extern "C" int tavsr_kv_append(const float* k, const float* v, int64_t ld_src, f
 extern "C" int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,
                                      const int64_t* last_tok, const int64_t* cand, float* r_new, float* psi, float* psi_abs,
                                      float* eos, float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V, int32_t C,
-                                     int32_t out_len, int32_t blank, tavsr_stream_t stream) {
+                                     int32_t out_len, int32_t blank, const int32_t* step_dev, tavsr_stream_t stream) {
   TAVSR_REQUIRE(logp && lens && cand && r_new && psi && psi_abs && eos && eos_abs, TAVSR_EINVAL, "ctc_prefix_step: null pointer");
-  TAVSR_REQUIRE(out_len == 0 || (r_prev && s_prev && last_tok), TAVSR_EINVAL, "ctc_prefix_step: state needed after <sos>");
+  TAVSR_REQUIRE((out_len == 0 && !step_dev) || (r_prev && s_prev && last_tok), TAVSR_EINVAL, "ctc_prefix_step: state needed after <sos>");
   TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0 && C > 0, TAVSR_EINVAL, "ctc_prefix_step: bad sizes");
   hipLaunchKernelGGL(ctc_prefix_step_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logp,
                      lens, r_prev, s_prev, last_tok, cand, r_new, psi, psi_abs, eos, eos_abs, N, K, T, V, C, out_len, blank,
-                     out_len == 0 ? 1 : 0);
+                     out_len == 0 ? 1 : 0, step_dev);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

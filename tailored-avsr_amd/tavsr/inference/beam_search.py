@@ -214,40 +214,29 @@ class BatchBeamSearch:
         best_len = torch.full((U, steps + 4), -float("inf"))        # best ended score per (utterance, hypothesis length)
         D_end = math.log(1 * math.exp(-10))
         ended_rows, ended_meta = [], []                             # yseq rows (CPU) and (utterance, length, score)
-        def scorers(i, dyn):
-            full = self.dec_step.step(i, tok, anc, dyn) * self.w_dec
-            if self.lm_step is not None:
-                full = full + self.lm_step.step(i, tok, anc, dyn) * self.w_lm
-            full = full + self.w_len                                # LengthBonus: 1 per token
-            return full, torch.topk(full, C, dim=-1)[1]             # pre-beam on the weighted full scores
+        NEG_INF = -float("inf")
+        state = dict(r_prev=r_prev, s_prev=s_prev, yseq=yseq, score=score)
 
-        graph = None
-        if GRAPH_STEP:
-            # One step of both scorers is ~300 small launches on [N, d] operands.  Capture it once per decode() (step
-            # index, positional row, tokens and ancestor lists live in fixed device buffers) and replay it per token:
-            # the host then only issues the search bookkeeping (measured: search -5 %; the step is GPU-bound at
-            # ~3 ms, 1.7 ms of it in 109 GEMMs, and a second stream for the LM does not shorten it).
-            step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-            pe_row = self.dec_step.pe[0:1].clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                anc[:, 0] = slot_ids
-                scorers(steps, (step_dev, pe_row))                  # warm-up outside the capture (step 0 rows, rewritten)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                g_full, g_cand = scorers(steps, (step_dev, pe_row))
-        for i in range(steps):
-            anc[:, i] = slot_ids + i * N
-            if graph is not None:
-                step_dev.fill_(i)
-                pe_row.copy_(self.dec_step.pe[i:i + 1])
-                graph.replay()
-                full, cand = g_full, g_cand
+        def device_step(i, dyn):
+            """everything the device does for one token: both scorers, the pre-beam, CTC prefix scores of the candidates,
+            the beam update and the re-ordering of the running state.  ``dyn`` = None: eager launches with the host's
+            step index i.  ``dyn`` = device counters: every buffer is updated IN PLACE and the step index is read from
+            device memory, so the whole step is one captured hipGraph (i is then the pool capacity in steps)."""
+            r_prev, s_prev, yseq, score = state["r_prev"], state["s_prev"], state["yseq"], state["score"]
+            if dyn is None:
+                anc[:, i] = slot_ids + i * N
+                sdyn = None
             else:
-                full, cand = scorers(i, None)
-            r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, cand, K, i)
+                score.masked_fill_(dyn["kill"], NEG_INF)            # hypotheses the host ended after the previous token
+                anc.index_copy_(1, dyn["step64"], (slot_ids + dyn["step"] * N).view(N, 1))
+                sdyn = (dyn["step"], self.dec_step.pe.index_select(0, dyn["step64"]))
+            full = self.dec_step.step(i, tok, anc, sdyn) * self.w_dec
+            if self.lm_step is not None:
+                full = full + self.lm_step.step(i, tok, anc, sdyn) * self.w_lm
+            full = full + self.w_len                                # LengthBonus: 1 per token
+            cand = torch.topk(full, C, dim=-1)[1]                   # pre-beam on the weighted full scores
+            r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, cand, K, i,
+                                                                      step_dev=None if dyn is None else dyn["step"])
             is_eos_c = cand == self.eos
             psi = torch.where(is_eos_c, eos_s.unsqueeze(1), psi)
             psi_abs = torch.where(is_eos_c, eos_abs.unsqueeze(1), psi_abs)
@@ -258,19 +247,63 @@ class BatchBeamSearch:
             top_s, top_i = torch.topk(weighted.view(U, K * V), K, dim=-1)
             prev = (top_i // V + utt_base).view(N)                  # slot the new hypothesis extends
             new_tok = (top_i % V).view(N)
-            new_score = top_s.view(N)
             # CTC state of the chosen candidate
             cidx = (cand[prev] == new_tok.unsqueeze(1)).float().argmax(dim=1)
-            r_prev = r_new[prev, :, :, cidx]
-            s_prev = psi_abs[prev, cidx]
-            yseq = yseq[prev]
-            yseq[:, i + 1] = new_tok
-            if graph is not None:                                   # the captured launches read these buffers in place
-                anc.copy_(anc[prev])
-                tok.copy_(new_tok)
+            if dyn is None:
+                state["r_prev"], state["s_prev"] = r_new[prev, :, :, cidx], psi_abs[prev, cidx]
+                yseq = yseq[prev]
+                yseq[:, i + 1] = new_tok
+                state["yseq"], state["score"] = yseq, top_s.view(N)
+                return anc[prev], new_tok
+            r_prev.copy_(r_new[prev, :, :, cidx])
+            s_prev.copy_(psi_abs[prev, cidx])
+            yseq.copy_(yseq[prev])
+            yseq.index_copy_(1, dyn["stepp1"], new_tok.view(N, 1))
+            anc.copy_(anc[prev])
+            tok.copy_(new_tok)
+            score.copy_(top_s.view(N))
+            for k in ("step", "step64", "stepp1"):
+                dyn[k].add_(1)
+            return anc, tok
+
+        def reset_state():
+            tok.fill_(self.sos)
+            yseq.fill_(self.eos)
+            yseq[:, 0] = self.sos
+            score.fill_(NEG_INF)
+            score.view(U, K)[:, 0] = 0.0
+            anc.zero_()
+            r_prev.zero_()
+            s_prev.zero_()
+
+        graph = dyn = None
+        if GRAPH_STEP:
+            # One token costs ~300 scorer launches plus ~90 small ones for the beam update, all on [N, d]-sized operands.
+            # The whole device side of a step is captured once per decode() - the step index, the positional row, tokens,
+            # ancestor lists, CTC state and scores live in fixed device buffers updated in place - and replayed per token;
+            # the host then only reads the new tokens / scores back (end detection) and uploads the kill mask.
+            # Measured: -5 % against eager launches at 64 utterances; the step stays bound by the chain of ~390 dependent
+            # small kernels (5-6 us each: 2.2 ms per token at ONE utterance, 3.4 ms at 64), not by the host.
+            dyn = dict(step=torch.zeros(1, dtype=torch.int32, device=dev), step64=torch.zeros(1, dtype=torch.int64, device=dev),
+                       stepp1=torch.ones(1, dtype=torch.int64, device=dev), kill=torch.zeros(N, dtype=torch.bool, device=dev))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                device_step(steps, dyn)                             # warm-up outside the capture; the state is reset below
+                reset_state()
+                dyn["step"].zero_()
+                dyn["step64"].zero_()
+                dyn["stepp1"].fill_(1)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                device_step(steps, dyn)
+        for i in range(steps):
+            if graph is not None:
+                graph.replay()
             else:
-                anc, tok = anc[prev], new_tok
-            score = new_score
+                anc, tok = device_step(i, None)
+            yseq, score = state["yseq"], state["score"]
             # ended hypotheses, last iteration, end detection (espnet post_process / end_detect per utterance)
             tok_h, score_h = tok.cpu(), score.cpu()
             valid = torch.isfinite(score_h).view(U, K) & active.view(U, 1)
@@ -298,8 +331,10 @@ class BatchBeamSearch:
             stop = (count == 3) | (running == 0) | last.view(U)
             active = active & ~stop
             kill = (take | ~active.view(U, 1)).view(N)
-            if bool(kill.any()):
-                score = torch.where(kill.to(dev), torch.full_like(score, -float("inf")), score)
+            if graph is not None:
+                dyn["kill"].copy_(kill)                             # applied at the head of the next replay
+            elif bool(kill.any()):
+                state["score"] = torch.where(kill.to(dev), torch.full_like(score, NEG_INF), score)
             if not bool(active.any()):
                 break
         ended = [[] for _ in range(U)]

@@ -999,8 +999,9 @@ def kv_append(k, v, kpool, vpool, N, max_steps, step_dev):
                                 N, k.shape[1], int(max_steps), ptr(step_dev), stream()), "tavsr_kv_append")
 
 
-def ctc_prefix_step(logp, lens, r_prev, s_prev, last_tok, cand, K, out_len, blank=0):
-    """-> (r_new [N,T,2,C], psi [N,C], psi_abs [N,C], eos [N], eos_abs [N]); see include/tavsr.h."""
+def ctc_prefix_step(logp, lens, r_prev, s_prev, last_tok, cand, K, out_len, blank=0, step_dev=None):
+    """-> (r_new [N,T,2,C], psi [N,C], psi_abs [N,C], eos [N], eos_abs [N]); see include/tavsr.h.
+    ``step_dev`` (int32 device scalar) replaces ``out_len`` (graph replays)."""
     U, T, V = logp.shape
     N, Cn = cand.shape
     require_cuda(logp, lens, r_prev, s_prev, last_tok, cand)
@@ -1008,8 +1009,9 @@ def ctc_prefix_step(logp, lens, r_prev, s_prev, last_tok, cand, K, out_len, blan
     psi, psi_abs = empty(N, Cn, like=logp), empty(N, Cn, like=logp)
     eos, eos_abs = empty(N, like=logp), empty(N, like=logp)
     check(lib().tavsr_ctc_prefix_step(ptr(logp), ptr(lens), ptr(r_prev), ptr(s_prev), ptr(last_tok), ptr(cand), ptr(r_new),
-                                      ptr(psi), ptr(psi_abs), ptr(eos), ptr(eos_abs), N, K, T, V, Cn, int(out_len), blank,
-                                      stream()), "tavsr_ctc_prefix_step")
+                                      ptr(psi), ptr(psi_abs), ptr(eos), ptr(eos_abs), N, K, T, V, Cn,
+                                      0 if step_dev is not None else int(out_len), blank, ptr(step_dev), stream()),
+          "tavsr_ctc_prefix_step")
     return r_new, psi, psi_abs, eos, eos_abs
 
 
