@@ -335,6 +335,8 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
  *       anc [N][ld_anc] int32 lists each hypothesis' own rows, so a beam re-order copies these lists only.
  *       step_dev (nullable): device int32 holding the step index; the kernel then uses min(*step_dev + 1, nkeys) keys,
  *       so one captured hipGraph of the scorer step can be replayed for every step of the search.
+ *       k_new / v_new (nullable, row stride ldq): this step's keys / values [N][H*dk].  They are key number nkeys-1 of every
+ *       hypothesis (pool row (nkeys-1)*N + n, which anc must name): read from here and written to the pool by the same launch.
  *   tavsr_kv_append      : kpool/vpool row (*step_dev * N + n) = k[n] / v[n] (the rows this step's anc column names).
  *   tavsr_ctc_prefix_step: espnet CTCPrefixScoreTH.__call__ (no attention window) for C candidate tokens per
  *       hypothesis.  logp [U][T][V] log-softmax of the CTC head, lens [U] frames, hypotheses n belong to utterance n / K.
@@ -343,18 +345,37 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
  *       psi [N][C] = log_psi(cand) - s_prev, psi_abs [N][C] = log_psi(cand), eos [N] = log p(prefix ends) - s_prev,
  *       eos_abs [N].  A candidate equal to <eos> must take the eos value (caller); blank scores -1e10.
  *       step_dev (nullable): device int32 that replaces out_len (graph replays, as in tavsr_tree_attn_step).
- *   tavsr_log_softmax_rows: y[m][:] = log_softmax(x[m][:V]).
+ *   tavsr_log_softmax_rows: y[m][:] = (accumulate ? y[m][:] : 0) + alpha * log_softmax(x[m][:V]) + add  (the weighted sum of
+ *       the scorers: decoder 1 - ctc_weight, lm lm_weight, length bonus as `add`).
  * ------------------------------------------------------------------------------------------- */
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                          const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N, int32_t H,
-                         int32_t dk, float scale, const int32_t* step_dev, tavsr_stream_t stream);
+                         int32_t dk, float scale, const int32_t* step_dev, const float* k_new, const float* v_new,
+                         tavsr_stream_t stream);
 int tavsr_kv_append(const float* k, const float* v, int64_t ld_src, float* kpool, float* vpool, int64_t ldkv, int32_t N,
                     int32_t D, int32_t max_steps, const int32_t* step_dev, tavsr_stream_t stream);
 int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,
                           const int64_t* last_tok, const int64_t* cand, float* r_new, float* psi, float* psi_abs, float* eos,
                           float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V, int32_t C, int32_t out_len,
                           int32_t blank, const int32_t* step_dev, tavsr_stream_t stream);
-int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t V, tavsr_stream_t stream);
+int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t V, float alpha, float add,
+                           int32_t accumulate, tavsr_stream_t stream);
+/* Beam update around the top-k (espnet BatchBeamSearch.search / batch_beam, avsr_inference.py:449-518):
+ *   tavsr_beam_combine: weighted [N][V] = full + w_ctc * ctc_full + score[n], where the partial CTC scorer's row ctc_full is
+ *       -1e10 - s_prev[n] everywhere except [eos] = eos_s[n] and the C pre-beam candidates [cand[n][c]] = psi[n][c]; an <eos>
+ *       candidate takes eos_s[n], and its psi_abs entry is overwritten with eos_abs[n].
+ *   tavsr_beam_reorder: top_i [U][K] (= slot * V + token, from the top-k over weighted viewed as [U][K*V]) and top_s select,
+ *       for every new hypothesis n, the slot `prev` it extends: *_out[n] = state[prev] for the CTC forward variables
+ *       (r_new [N][T][2][C] at the token's candidate column -> r_out [N][T][2]), log_psi (s_out), the token history
+ *       (yseq_out, row stride ld_y, new token written at column *step_dev + 1), the ancestor lists (anc_out, stride ld_a),
+ *       tok_out and score_out.  Outputs must not alias the inputs. */
+int tavsr_beam_combine(const float* full, const int64_t* cand, const float* psi, float* psi_abs, const float* eos_s,
+                       const float* eos_abs, const float* s_prev, const float* score, float* weighted, int32_t N, int32_t V,
+                       int32_t C, int32_t eos, float w_ctc, tavsr_stream_t stream);
+int tavsr_beam_reorder(const int64_t* top_i, const float* top_s, const int64_t* cand, const float* r_new, const float* psi_abs,
+                       const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out, int64_t* yseq_out, int32_t* anc_out,
+                       int64_t* tok_out, float* score_out, int32_t N, int32_t K, int32_t V, int32_t C, int32_t T, int32_t ld_y,
+                       int32_t ld_a, const int32_t* step_dev, tavsr_stream_t stream);
 /* y = act(x) elementwise (the LM's Linear -> LayerNorm -> ReLU input layer); in place allowed */
 int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, tavsr_stream_t stream);
 
@@ -376,6 +397,8 @@ int tavsr_bucket_copy(float* const* ptrs_dev, const int64_t* off_dev, const int6
  * layer (src/encoder/audiovisual/tailored/encoder_layer.py:118-274 applies the same FFN / norm modules to both streams;
  * autograd sums their gradients).  dst / src / n are HOST arrays (the pointers ride in the kernel arguments). */
 int tavsr_multi_add(float* const* dst, const float* const* src, const int64_t* n, int32_t ntensors, tavsr_stream_t stream);
+/* dst[t] <- src[t], nbytes[t] bytes each (any dtype), nbuffers <= 24, one launch; HOST tables as in tavsr_multi_add. */
+int tavsr_multi_copy(void* const* dst, const void* const* src, const int64_t* nbytes, int32_t nbuffers, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Train-mode dropout (every torch Dropout / F.dropout site of the path).  y[i] = keep_i ? x[i] / (1 - p) : 0 where

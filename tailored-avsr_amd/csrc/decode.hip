@@ -20,9 +20,13 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
                                                              const float* __restrict__ kpool, const float* __restrict__ vpool,
                                                              int64_t ldkv, const int32_t* __restrict__ anc, int64_t ld_anc,
                                                              int nkeys, float* __restrict__ out, int64_t ldo, int N, int H,
-                                                             int dk, float scale, const int32_t* __restrict__ step_dev) {
+                                                             int dk, float scale, const int32_t* __restrict__ step_dev,
+                                                             const float* __restrict__ k_new, const float* __restrict__ v_new,
+                                                             float* __restrict__ kpool_w, float* __restrict__ vpool_w) {
   __shared__ float s_p[4][kTreeMaxKeys];
   if (step_dev) nkeys = min(*step_dev + 1, nkeys);        // replayed graphs: the step counter lives in device memory
+  // k_new / v_new (row stride ldq): this step's own key / value rows.  They are the LAST key of every hypothesis (pool row
+  // (nkeys-1) * N + n): read from here instead of the pool, and appended to the pool by the same wave (no append launch).
   __shared__ float s_q[4][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool live = blockIdx.x * 4 + wave < N * H;       // surplus waves recompute the last item and store nothing
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
   const int32_t* a = anc + (int64_t)n * ld_anc;
   float mx = -INFINITY;
   for (int j = lane; j < nkeys; j += 64) {
-    const float* kr = kpool + (int64_t)a[j] * ldkv + h * dk;
+    const float* kr = (k_new && j == nkeys - 1) ? k_new + (int64_t)n * ldq + h * dk : kpool + (int64_t)a[j] * ldkv + h * dk;
     float dot = 0.f;
     for (int d = 0; d < dk; d += 4) {
       const float4 kv = *reinterpret_cast<const float4*>(kr + d);
@@ -53,9 +57,19 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
   sum = wave_sum(sum);
   __syncthreads();
   const float inv = 1.f / sum;
+  const int nold = v_new ? nkeys - 1 : nkeys;
   for (int d = lane; d < dk; d += 64) {
     float acc = 0.f;
-    for (int j = 0; j < nkeys; ++j) acc += s_p[wave][j] * vpool[(int64_t)a[j] * ldkv + h * dk + d];
+    for (int j = 0; j < nold; ++j) acc += s_p[wave][j] * vpool[(int64_t)a[j] * ldkv + h * dk + d];
+    if (v_new) {
+      const float vn = v_new[(int64_t)n * ldq + h * dk + d];
+      acc += s_p[wave][nkeys - 1] * vn;
+      if (live) {
+        const int64_t row = (int64_t)(nkeys - 1) * N + n;
+        vpool_w[row * ldkv + h * dk + d] = vn;
+        kpool_w[row * ldkv + h * dk + d] = k_new[(int64_t)n * ldq + h * dk + d];
+      }
+    }
     if (live) out[(int64_t)n * ldo + h * dk + d] = acc * inv;
   }
 }
@@ -147,8 +161,9 @@ __global__ __launch_bounds__(256) void ctc_prefix_step_kernel(const float* __res
   }
 }
 
+// y = [y +] alpha * log_softmax(x) [+ add]: the weighted sum of scorer outputs is built by the scorers' own launches
 __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
-                                                               int64_t ldy, int M, int V) {
+                                                               int64_t ldy, int M, int V, float alpha, float add, int accumulate) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -160,7 +175,73 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
   for (int j = lane; j < V; j += 64) s += expf(xr[j] - mx);
   s = wave_sum(s);
   const float lse = mx + logf(s);
-  for (int j = lane; j < V; j += 64) y[(int64_t)row * ldy + j] = xr[j] - lse;
+  for (int j = lane; j < V; j += 64) {
+    float v = xr[j] - lse;
+    if (alpha != 1.f) v *= alpha;
+    if (accumulate) v = y[(int64_t)row * ldy + j] + v;
+    if (add != 0.f) v += add;
+    y[(int64_t)row * ldy + j] = v;
+  }
+}
+
+// ---- beam update (espnet BatchBeamSearch.search / batch_beam: the index plumbing around the top-k) ------------------
+// weighted[n][v] = full[n][v] + w_ctc * ctc_full[n][v] + score[n]  with the partial CTC scorer's row
+//   ctc_full[n][v] = -1e10 - s_prev[n], [eos] = eos_s[n], [cand[n][c]] = psi[n][c] (eos_s[n] when the candidate IS <eos>);
+// psi_abs[n][c] of an <eos> candidate becomes eos_abs[n] (the state the search stores for it).  One wave per hypothesis.
+__global__ __launch_bounds__(256) void beam_combine_kernel(const float* __restrict__ full, const int64_t* __restrict__ cand,
+                                                           const float* __restrict__ psi, float* __restrict__ psi_abs,
+                                                           const float* __restrict__ eos_s, const float* __restrict__ eos_abs,
+                                                           const float* __restrict__ s_prev, const float* __restrict__ score,
+                                                           float* __restrict__ weighted, int N, int V, int C, int eos,
+                                                           float w_ctc) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  const float base = -10000000000.0f - s_prev[n], es = eos_s[n], sc = score[n];
+  for (int v = lane; v < V; v += 64) {
+    float cf = v == eos ? es : base;
+    for (int c = 0; c < C; ++c)
+      if ((int)cand[(int64_t)n * C + c] == v) cf = v == eos ? es : psi[(int64_t)n * C + c];
+    {
+      // separately rounded multiply and adds (no fused multiply-add): the scores equal the elementwise torch expression bit for bit
+#pragma clang fp contract(off)
+      const float prod = w_ctc * cf;
+      const float sum = full[(int64_t)n * V + v] + prod;
+      weighted[(int64_t)n * V + v] = sum + sc;
+    }
+  }
+  for (int c = lane; c < C; c += 64)
+    if ((int)cand[(int64_t)n * C + c] == eos) psi_abs[(int64_t)n * C + c] = eos_abs[n];
+}
+
+// After the top-k over (beam slot, token) of every utterance (top_i [U][K] = slot * V + token): hypothesis n extends slot
+// prev = top_i / V + u * K with token top_i % V.  Gathers the running state of `prev` into the *_out buffers (the state
+// arrays are re-ordered, so they cannot be updated in place): CTC forward variables r_new[prev][:, :, cidx] (cidx = the
+// candidate column holding the token), log_psi, token history (+ the new token at column *step + 1), ancestor lists.
+__global__ __launch_bounds__(256) void beam_reorder_kernel(const int64_t* __restrict__ top_i, const float* __restrict__ top_s,
+                                                           const int64_t* __restrict__ cand, const float* __restrict__ r_new,
+                                                           const float* __restrict__ psi_abs, const int64_t* __restrict__ yseq,
+                                                           const int32_t* __restrict__ anc, float* __restrict__ r_out,
+                                                           float* __restrict__ s_out, int64_t* __restrict__ yseq_out,
+                                                           int32_t* __restrict__ anc_out, int64_t* __restrict__ tok_out,
+                                                           float* __restrict__ score_out, int N, int K, int V, int C, int T,
+                                                           int ld_y, int ld_a, const int32_t* __restrict__ step_dev) {
+  const int n = blockIdx.x;
+  const int u = n / K;
+  const int64_t ti = top_i[n];
+  const int prev = (int)(ti / V) + u * K, tk = (int)(ti % V);
+  int cidx = 0;                                                   // first candidate column equal to the token (argmax of ==)
+  for (int c = C - 1; c >= 0; --c)
+    if ((int)cand[(int64_t)prev * C + c] == tk) cidx = c;
+  const int step = *step_dev;
+  for (int e = threadIdx.x; e < T * 2; e += 256) r_out[(int64_t)n * T * 2 + e] = r_new[((int64_t)prev * T * 2 + e) * C + cidx];
+  for (int e = threadIdx.x; e < ld_y; e += 256) yseq_out[(int64_t)n * ld_y + e] = e == step + 1 ? (int64_t)tk : yseq[(int64_t)prev * ld_y + e];
+  for (int e = threadIdx.x; e < ld_a; e += 256) anc_out[(int64_t)n * ld_a + e] = anc[(int64_t)prev * ld_a + e];
+  if (threadIdx.x == 0) {
+    s_out[n] = psi_abs[(int64_t)prev * C + cidx];
+    tok_out[n] = tk;
+    score_out[n] = top_s[n];
+  }
 }
 
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
@@ -183,15 +264,18 @@ extern "C" int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, t
 
 extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                                     const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N,
-                                    int32_t H, int32_t dk, float scale, const int32_t* step_dev, tavsr_stream_t stream) {
+                                    int32_t H, int32_t dk, float scale, const int32_t* step_dev, const float* k_new,
+                                    const float* v_new, tavsr_stream_t stream) {
   TAVSR_REQUIRE(q && kpool && vpool && anc && out, TAVSR_EINVAL, "tree_attn_step: null pointer");
+  TAVSR_REQUIRE((k_new == nullptr) == (v_new == nullptr), TAVSR_EINVAL, "tree_attn_step: k_new and v_new go together");
   TAVSR_REQUIRE(nkeys > 0 && nkeys <= kTreeMaxKeys, TAVSR_EUNSUPPORTED, "tree_attn_step: 1..%d keys supported (got %d)",
                 kTreeMaxKeys, nkeys);
   TAVSR_REQUIRE(dk % 4 == 0 && dk <= 128 && ldkv % 4 == 0 && ((uintptr_t)kpool & 15) == 0, TAVSR_EALIGN,
                 "tree_attn_step: dk %% 4, dk <= 128 and 16-byte aligned key rows are required");
   if (N <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(tree_attn_step_kernel, dim3((unsigned)((N * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, kpool,
-                     vpool, ldkv, anc, ld_anc, nkeys, out, ldo, N, H, dk, scale, step_dev);
+                     vpool, ldkv, anc, ld_anc, nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool),
+                     const_cast<float*>(vpool));
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
@@ -223,12 +307,40 @@ extern "C" int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, con
   return TAVSR_OK;
 }
 
-extern "C" int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t V,
-                                      tavsr_stream_t stream) {
+extern "C" int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t V, float alpha,
+                                      float add, int32_t accumulate, tavsr_stream_t stream) {
   TAVSR_REQUIRE(x && y, TAVSR_EINVAL, "log_softmax_rows: null pointer");
   if (M <= 0 || V <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M,
-                     V);
+                     V, alpha, add, accumulate);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_beam_combine(const float* full, const int64_t* cand, const float* psi, float* psi_abs, const float* eos_s,
+                                  const float* eos_abs, const float* s_prev, const float* score, float* weighted, int32_t N,
+                                  int32_t V, int32_t C, int32_t eos, float w_ctc, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(full && cand && psi && psi_abs && eos_s && eos_abs && s_prev && score && weighted, TAVSR_EINVAL,
+                "beam_combine: null pointer");
+  if (N <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(beam_combine_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, full, cand, psi, psi_abs,
+                     eos_s, eos_abs, s_prev, score, weighted, N, V, C, eos, w_ctc);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_beam_reorder(const int64_t* top_i, const float* top_s, const int64_t* cand, const float* r_new,
+                                  const float* psi_abs, const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out,
+                                  int64_t* yseq_out, int32_t* anc_out, int64_t* tok_out, float* score_out, int32_t N, int32_t K,
+                                  int32_t V, int32_t C, int32_t T, int32_t ld_y, int32_t ld_a, const int32_t* step_dev,
+                                  tavsr_stream_t stream) {
+  TAVSR_REQUIRE(top_i && top_s && cand && r_new && psi_abs && yseq && anc && r_out && s_out && yseq_out && anc_out && tok_out &&
+                    score_out && step_dev, TAVSR_EINVAL, "beam_reorder: null pointer");
+  TAVSR_REQUIRE(r_out != r_new && (const int64_t*)yseq_out != yseq && (const int32_t*)anc_out != anc, TAVSR_EINVAL,
+                "beam_reorder: the state is re-ordered, outputs must not alias the inputs");
+  TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0, TAVSR_EINVAL, "beam_reorder: bad sizes");
+  hipLaunchKernelGGL(beam_reorder_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, top_i, top_s, cand, r_new, psi_abs, yseq,
+                     anc, r_out, s_out, yseq_out, anc_out, tok_out, score_out, N, K, V, C, T, ld_y, ld_a, step_dev);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -83,9 +83,47 @@ __global__ __launch_bounds__(256) void multi_add_kernel(const MultiAddArgs a) {
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) d[i] += s[i];
 }
 
+// dst[t] <- src[t] (nbytes[t] bytes, any dtype) for up to kMultiAddMax buffers in one launch: the commit of the beam
+// search's re-ordered state (six arrays of three dtypes) back into the buffers the captured step reads
+struct MultiCopyArgs {
+  void* dst[kMultiAddMax];
+  const void* src[kMultiAddMax];
+  int64_t n[kMultiAddMax];
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyArgs a) {
+  const int t = blockIdx.y;
+  char* d = static_cast<char*>(a.dst[t]);
+  const char* s = static_cast<const char*>(a.src[t]);
+  const int64_t cnt = a.n[t];
+  const bool vec = (((uintptr_t)d | (uintptr_t)s) & 15) == 0;
+  const int64_t n16 = vec ? cnt >> 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+    reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+  for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+
 }  // namespace tavsr
 
 using namespace tavsr;
+
+extern "C" int tavsr_multi_copy(void* const* dst, const void* const* src, const int64_t* nbytes, int32_t nbuffers,
+                                tavsr_stream_t stream) {
+  TAVSR_REQUIRE(nbuffers <= 0 || (dst && src && nbytes), TAVSR_EINVAL, "multi_copy: null table");
+  TAVSR_REQUIRE(nbuffers <= kMultiAddMax, TAVSR_EUNSUPPORTED, "multi_copy: at most %d buffers per call", kMultiAddMax);
+  if (nbuffers <= 0) return TAVSR_OK;
+  MultiCopyArgs a{};
+  int64_t mx = 0;
+  for (int t = 0; t < nbuffers; ++t) {
+    TAVSR_REQUIRE(nbytes[t] == 0 || (dst[t] && src[t]), TAVSR_EINVAL, "multi_copy: null buffer %d", t);
+    a.dst[t] = dst[t]; a.src[t] = src[t]; a.n[t] = nbytes[t];
+    mx = std::max(mx, nbytes[t]);
+  }
+  if (mx <= 0) return TAVSR_OK;
+  const int64_t chunks = std::min<int64_t>(std::max<int64_t>(1, (mx / 16 + 255) / 256), 512);
+  hipLaunchKernelGGL(tavsr::multi_copy_kernel, dim3((unsigned)chunks, (unsigned)nbuffers), dim3(256), 0, (hipStream_t)stream, a);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
 
 extern "C" int tavsr_multi_add(float* const* dst, const float* const* src, const int64_t* n, int32_t ntensors,
                                tavsr_stream_t stream) {

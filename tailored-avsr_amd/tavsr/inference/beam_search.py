@@ -69,24 +69,19 @@ class _DecoderStep:
         self.emb = self.dec.embed[0].weight
         self.xscale = math.sqrt(D)
 
-    def step(self, i, tok, anc, dyn=None):
+    def step(self, i, tok, anc, dyn=None, **score):
         """tok [N] last tokens, anc int32 [N, >= i+1] (column i already points at this step's rows) -> logp [N, V].
         ``dyn`` = (step_dev, pe_row): the step index and its positional row come from device buffers (``i`` is then the
         pool capacity in steps), so the launches can be captured once and replayed for every step."""
         N, D, H, dk, U, T, K = self.N, self.D, self.H, self.dk, self.U, self.T, self.K
         pe = self.pe[i:i + 1].contiguous() if dyn is None else dyn[1]
         x = ops.embed_pe(tok.view(N, 1), self.emb, pe, self.xscale).view(N, D)
-        lo = i * N
         for li, L in enumerate(self.layers):
             n1 = ops.layernorm_fwd(x, *L["n1"], EPS, save=False)[0]
             qkv = ops.linear(n1, L["wqkv"], L["bqkv"])
-            if dyn is None:
-                ops.copy2d(qkv[:, D:2 * D], self.kpool[li][lo:lo + N])
-                ops.copy2d(qkv[:, 2 * D:], self.vpool[li][lo:lo + N])
-                a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1, H, dk)
-            else:
-                ops.kv_append(qkv[:, D:2 * D], qkv[:, 2 * D:], self.kpool[li], self.vpool[li], N, i, dyn[0])
-                a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i, H, dk, step_dev=dyn[0])
+            # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
+            a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
+                                   step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
             x = ops.linear(a, L["wo"], L["bo"], res=x)
             n2 = ops.layernorm_fwd(x, *L["n2"], EPS, save=False)[0]
             q2 = ops.linear(n2, L["wq2"], L["bq2"])
@@ -105,7 +100,7 @@ class _DecoderStep:
             t = ops.linear(n3, L["w1"], L["b1"], act="relu")
             x = ops.linear(t, L["w2"], L["b2"], res=x)
         y = ops.layernorm_fwd(x, self.dec.after_norm.weight, self.dec.after_norm.bias, EPS, save=False)[0]
-        return ops.log_softmax_rows(ops.linear(y, self.dec.output_layer.weight, self.dec.output_layer.bias))
+        return ops.log_softmax_rows(ops.linear(y, self.dec.output_layer.weight, self.dec.output_layer.bias), **score)
 
 
 class _LMStep:
@@ -130,7 +125,7 @@ class _LMStep:
         self.kpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
         self.vpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
 
-    def step(self, i, tok, anc, dyn=None):
+    def step(self, i, tok, anc, dyn=None, **score):
         N, D, H, dk = self.N, self.D, self.H, self.dk
         lm = self.lm
         e = lm.embed.weight[tok].contiguous()                        # row gather (index plumbing)
@@ -138,23 +133,18 @@ class _LMStep:
         h = ops.linear(e, emb[0].weight, emb[0].bias)
         h = ops.layernorm_fwd(h, emb[1].weight, emb[1].bias, EPS, save=False)[0]
         ops.act_(h, "relu")
-        lo = i * N
         for li, L in enumerate(self.layers):
             n1 = ops.layernorm_fwd(h, *L["n1"], EPS, save=False)[0]
             qkv = ops.linear(n1, L["wqkv"], L["bqkv"])
-            if dyn is None:
-                ops.copy2d(qkv[:, D:2 * D], self.kpool[li][lo:lo + N])
-                ops.copy2d(qkv[:, 2 * D:], self.vpool[li][lo:lo + N])
-                a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1, H, dk)
-            else:
-                ops.kv_append(qkv[:, D:2 * D], qkv[:, 2 * D:], self.kpool[li], self.vpool[li], N, i, dyn[0])
-                a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i, H, dk, step_dev=dyn[0])
+            # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
+            a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
+                                   step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
             h = ops.linear(a, L["wo"], L["bo"], res=h)
             n2 = ops.layernorm_fwd(h, *L["n2"], EPS, save=False)[0]
             t = ops.linear(n2, L["w1"], L["b1"], act="relu")
             h = ops.linear(t, L["w2"], L["b2"], res=h)
         y = ops.layernorm_fwd(h, lm.encoder.after_norm.weight, lm.encoder.after_norm.bias, EPS, save=False)[0]
-        return ops.log_softmax_rows(ops.linear(y, lm.decoder.weight, lm.decoder.bias))
+        return ops.log_softmax_rows(ops.linear(y, lm.decoder.weight, lm.decoder.bias), **score)
 
 
 class BatchBeamSearch:
@@ -230,13 +220,23 @@ class BatchBeamSearch:
                 score.masked_fill_(dyn["kill"], NEG_INF)            # hypotheses the host ended after the previous token
                 anc.index_copy_(1, dyn["step64"], (slot_ids + dyn["step"] * N).view(N, 1))
                 sdyn = (dyn["step"], self.dec_step.pe.index_select(0, dyn["step64"]))
-            full = self.dec_step.step(i, tok, anc, sdyn) * self.w_dec
-            if self.lm_step is not None:
-                full = full + self.lm_step.step(i, tok, anc, sdyn) * self.w_lm
-            full = full + self.w_len                                # LengthBonus: 1 per token
+            # full = w_dec * decoder + w_lm * lm + w_len (LengthBonus: 1 per token), summed by the scorers' last launches
+            has_lm = self.lm_step is not None
+            full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
+            if has_lm:
+                self.lm_step.step(i, tok, anc, sdyn, out=full, alpha=self.w_lm, add=self.w_len, accumulate=True)
             cand = torch.topk(full, C, dim=-1)[1]                   # pre-beam on the weighted full scores
             r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, cand, K, i,
                                                                       step_dev=None if dyn is None else dyn["step"])
+            if dyn is not None:
+                # beam update in three launches: weighted scores, top-k, gather of the extended slots' state into the
+                # shadow buffers + one multi-buffer commit (+ the counters); same arithmetic as the torch ops below
+                weighted = ops.beam_combine(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, self.eos, self.w_ctc)
+                top_s, top_i = torch.topk(weighted.view(U, K * V), K, dim=-1)
+                ops.beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, dyn["shadow"], K, V, dyn["step"])
+                ops.multi_copy_([r_prev, s_prev, yseq, anc, tok, score], list(dyn["shadow"]))
+                dyn["ctr"].add_(1)                                  # step, step64, stepp1 are views of this one tensor
+                return anc, tok
             is_eos_c = cand == self.eos
             psi = torch.where(is_eos_c, eos_s.unsqueeze(1), psi)
             psi_abs = torch.where(is_eos_c, eos_abs.unsqueeze(1), psi_abs)
@@ -249,22 +249,11 @@ class BatchBeamSearch:
             new_tok = (top_i % V).view(N)
             # CTC state of the chosen candidate
             cidx = (cand[prev] == new_tok.unsqueeze(1)).float().argmax(dim=1)
-            if dyn is None:
-                state["r_prev"], state["s_prev"] = r_new[prev, :, :, cidx], psi_abs[prev, cidx]
-                yseq = yseq[prev]
-                yseq[:, i + 1] = new_tok
-                state["yseq"], state["score"] = yseq, top_s.view(N)
-                return anc[prev], new_tok
-            r_prev.copy_(r_new[prev, :, :, cidx])
-            s_prev.copy_(psi_abs[prev, cidx])
-            yseq.copy_(yseq[prev])
-            yseq.index_copy_(1, dyn["stepp1"], new_tok.view(N, 1))
-            anc.copy_(anc[prev])
-            tok.copy_(new_tok)
-            score.copy_(top_s.view(N))
-            for k in ("step", "step64", "stepp1"):
-                dyn[k].add_(1)
-            return anc, tok
+            state["r_prev"], state["s_prev"] = r_new[prev, :, :, cidx], psi_abs[prev, cidx]
+            yseq = yseq[prev]
+            yseq[:, i + 1] = new_tok
+            state["yseq"], state["score"] = yseq, top_s.view(N)
+            return anc[prev], new_tok
 
         def reset_state():
             tok.fill_(self.sos)
@@ -282,18 +271,20 @@ class BatchBeamSearch:
             # The whole device side of a step is captured once per decode() - the step index, the positional row, tokens,
             # ancestor lists, CTC state and scores live in fixed device buffers updated in place - and replayed per token;
             # the host then only reads the new tokens / scores back (end detection) and uploads the kill mask.
-            # Measured: -5 % against eager launches at 64 utterances; the step stays bound by the chain of ~390 dependent
-            # small kernels (5-6 us each: 2.2 ms per token at ONE utterance, 3.4 ms at 64), not by the host.
-            dyn = dict(step=torch.zeros(1, dtype=torch.int32, device=dev), step64=torch.zeros(1, dtype=torch.int64, device=dev),
-                       stepp1=torch.ones(1, dtype=torch.int64, device=dev), kill=torch.zeros(N, dtype=torch.bool, device=dev))
+            # The step is bound by its chain of dependent small kernels (5-6 us each), not by the host: what shortens it is
+            # fewer launches - the K/V append rides in the attention launch, the scorer weights in the log-softmax
+            # launches, the beam update is three launches (beam_combine, top-k, beam_reorder) plus one commit.
+            ctr = torch.tensor([0, 1], dtype=torch.int64, device=dev)          # (i, i + 1); the kernels read i as int32
+            dyn = dict(ctr=ctr, step64=ctr[0:1], stepp1=ctr[1:2], step=ctr.view(torch.int32)[0:1],     # (low word: little endian)
+                       kill=torch.zeros(N, dtype=torch.bool, device=dev),
+                       shadow=(torch.empty_like(r_prev), torch.empty_like(s_prev), torch.empty_like(yseq), torch.empty_like(anc),
+                               torch.empty_like(tok), torch.empty_like(score)))
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 device_step(steps, dyn)                             # warm-up outside the capture; the state is reset below
                 reset_state()
-                dyn["step"].zero_()
-                dyn["step64"].zero_()
-                dyn["stepp1"].fill_(1)
+                ctr.copy_(torch.tensor([0, 1], dtype=torch.int64))
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):

@@ -924,6 +924,20 @@ def multi_add_(dst, src):
     return dst
 
 
+def multi_copy_(dst, src):
+    """dst[t].copy_(src[t]) for lists of contiguous same-shape/dtype tensors in ONE launch (<= 24 tensors)."""
+    assert len(dst) == len(src)
+    require_cuda(*dst, *src)
+    n = len(dst)
+    for a, b in zip(dst, src):
+        assert a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.numel() == b.numel()
+    dp = (C.c_void_p * n)(*[t.data_ptr() for t in dst])
+    sp = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+    cnt = (C.c_int64 * n)(*[t.numel() * t.element_size() for t in dst])
+    check(lib().tavsr_multi_copy(dp, sp, cnt, n, stream()), "tavsr_multi_copy")
+    return dst
+
+
 # ---------------------------------------------------------------------------------------------- batch assembly
 def video_prep(src, index, T, y0, x0, th, tw, flip, affine, masked, out, pad_value):
     """one clip -> its row of the padded batch (tavsr_video_prep); ``index`` / ``masked`` are host lists / arrays or None."""
@@ -976,17 +990,20 @@ def bootstrap_rates(dist, reflen, iters, seed):
 
 
 # ---------------------------------------------------------------------------------------------- decode steps
-def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None):
+def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None, k_new=None, v_new=None):
     """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk].
-    ``step_dev`` (int32 device scalar): use min(step + 1, nkeys) keys (graph replays)."""
+    ``step_dev`` (int32 device scalar): use min(step + 1, nkeys) keys (graph replays).  ``k_new`` / ``v_new`` (row stride of
+    q): this step's keys / values - the last key of every hypothesis - appended to the pools by the same launch."""
     N = q.shape[0]
     require_cuda(q, kpool, vpool, anc)
     assert anc.dtype == torch.int32 and kpool.stride(0) == vpool.stride(0)
+    assert k_new is None or (k_new.stride(0) == q.stride(0) and v_new.stride(0) == q.stride(0))
     if out is None:
         out = empty(N, H * dk, like=q)
     check(lib().tavsr_tree_attn_step(ptr(q), C.c_int64(q.stride(0)), ptr(kpool), ptr(vpool), C.c_int64(kpool.stride(0)),
                                      ptr(anc), C.c_int64(anc.stride(0)), int(nkeys), ptr(out), C.c_int64(out.stride(0)), N, H, dk,
-                                     C.c_float(1.0 / (dk ** 0.5)), ptr(step_dev), stream()), "tavsr_tree_attn_step")
+                                     C.c_float(1.0 / (dk ** 0.5)), ptr(step_dev), ptr(k_new), ptr(v_new), stream()),
+          "tavsr_tree_attn_step")
     return out
 
 
@@ -1023,15 +1040,41 @@ def act_(x, act):
     return x
 
 
-def log_softmax_rows(x, V=None, out=None):
+def log_softmax_rows(x, V=None, out=None, alpha=1.0, add=0.0, accumulate=False):
+    """out = (out if accumulate else 0) + alpha * log_softmax(x[:, :V]) + add"""
     M = x.shape[0]
     V = x.shape[1] if V is None else V
     require_cuda(x)
     if out is None:
         out = empty(M, V, like=x)
-    check(lib().tavsr_log_softmax_rows(ptr(x), C.c_int64(x.stride(0)), ptr(out), C.c_int64(out.stride(0)), M, V, stream()),
-          "tavsr_log_softmax_rows")
+    assert not accumulate or out is not None
+    check(lib().tavsr_log_softmax_rows(ptr(x), C.c_int64(x.stride(0)), ptr(out), C.c_int64(out.stride(0)), M, V, C.c_float(alpha),
+                                       C.c_float(add), int(bool(accumulate)), stream()), "tavsr_log_softmax_rows")
     return out
+
+
+def beam_combine(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, eos, w_ctc):
+    """weighted = full + w_ctc * (partial CTC scorer row) + score; fixes psi_abs of <eos> candidates in place (tavsr.h)."""
+    N, V = full.shape
+    Cn = cand.shape[1]
+    require_cuda(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score)
+    weighted = empty(N, V, like=full)
+    check(lib().tavsr_beam_combine(ptr(full), ptr(cand), ptr(psi), ptr(psi_abs), ptr(eos_s), ptr(eos_abs), ptr(s_prev), ptr(score),
+                                   ptr(weighted), N, V, Cn, int(eos), C.c_float(w_ctc), stream()), "tavsr_beam_combine")
+    return weighted
+
+
+def beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, outs, K, V, step_dev):
+    """gathers the state of the extended slots into ``outs`` = (r, s, yseq, anc, tok, score) buffers (tavsr.h)."""
+    N, Cn = cand.shape
+    T = r_new.shape[1]
+    r_out, s_out, y_out, a_out, t_out, sc_out = outs
+    require_cuda(top_i, top_s, cand, r_new, psi_abs, yseq, anc, *outs, step_dev)
+    assert top_i.is_contiguous() and top_s.is_contiguous() and top_i.numel() == N and yseq.dtype == torch.int64
+    assert anc.dtype == torch.int32 and y_out.shape == yseq.shape and a_out.shape == anc.shape and r_out.shape == (N, T, 2)
+    check(lib().tavsr_beam_reorder(ptr(top_i), ptr(top_s), ptr(cand), ptr(r_new), ptr(psi_abs), ptr(yseq), ptr(anc), ptr(r_out),
+                                   ptr(s_out), ptr(y_out), ptr(a_out), ptr(t_out), ptr(sc_out), N, K, V, Cn, T, yseq.stride(0),
+                                   anc.stride(0), ptr(step_dev), stream()), "tavsr_beam_reorder")
 
 
 # ---------------------------------------------------------------------------------------------- dropout

@@ -140,6 +140,15 @@ def test_kv_append_and_device_step_tree_attention():
         assert torch.equal(got, want)
     assert torch.equal(kpool, torch.cat([q[:, D:2 * D] for q in qkv]))
     assert torch.equal(vpool, torch.cat([q[:, 2 * D:] for q in qkv]))
+    # the same steps with the append fused into the attention launch (the step's own row is read from k_new / v_new)
+    kp2, vp2 = torch.zeros_like(kpool), torch.zeros_like(vpool)
+    for i in range(steps):
+        step_dev.fill_(i)
+        want = ops.tree_attn_step(qkv[i][:, :D], kpool, vpool, anc, i + 1, H, dk)
+        got = ops.tree_attn_step(qkv[i][:, :D], kp2, vp2, anc, steps, H, dk, step_dev=step_dev, k_new=qkv[i][:, D:2 * D],
+                                 v_new=qkv[i][:, 2 * D:])
+        assert torch.equal(got, want)
+    assert torch.equal(kp2, kpool) and torch.equal(vp2, vpool)
     step_dev.fill_(steps)                                    # a step past the pool is dropped, not written
     before = kpool.clone()
     ops.kv_append(qkv[0][:, D:2 * D], qkv[0][:, 2 * D:], kpool, vpool, N, steps, step_dev)
@@ -181,3 +190,50 @@ def test_speech2text_from_waveforms_end_to_end():
         assert abs(sc - ref[0].score) < 5e-4 * abs(ref[0].score)
         assert token_int == [t for t in ys[1:-1] if t != 0] and len(token) == len(token_int)
         assert text == "".join(token).replace("<space>", " ")
+
+
+@pytest.mark.gpu
+def test_beam_update_kernels_equal_the_torch_expressions():
+    """tavsr_beam_combine / tavsr_beam_reorder / tavsr_multi_copy against the elementwise + gather torch code of the eager
+    path, bit for bit (separately rounded multiply / adds, first matching candidate column, <eos> candidates)."""
+    from tavsr import ops
+    torch.manual_seed(0)
+    N, V, C, K, T, eos, steps = 24, 41, 9, 6, 15, 40, 12
+    U = N // K
+    full = (torch.randn(N, V) * 3 - 5).cuda()
+    cand = torch.stack([torch.randperm(V)[:C] for _ in range(N)]).cuda()
+    cand[5, 2] = eos
+    psi, psi_abs = (torch.randn(N, C) * 4 - 20).cuda(), (torch.randn(N, C) * 4 - 40).cuda()
+    eos_s, eos_abs, s_prev = (torch.randn(N) * 3 - 10).cuda(), (torch.randn(N) * 3 - 30).cuda(), (torch.randn(N) * 3 - 20).cuda()
+    score = (torch.randn(N) * 5 - 30).cuda()
+    score[3] = -float("inf")
+    is_eos_c = cand == eos
+    psi_t = torch.where(is_eos_c, eos_s.unsqueeze(1), psi)
+    psi_abs_t = torch.where(is_eos_c, eos_abs.unsqueeze(1), psi_abs)
+    ctc_full = torch.full((N, V), -10000000000.0, device="cuda") - s_prev.unsqueeze(1)
+    ctc_full[:, eos] = eos_s
+    ctc_full.scatter_(1, cand, psi_t)
+    want = full + 0.2 * ctc_full + score.unsqueeze(1)
+    pa = psi_abs.clone()
+    got = ops.beam_combine(full, cand, psi, pa, eos_s, eos_abs, s_prev, score, eos, 0.2)
+    assert torch.equal(got, want) and torch.equal(pa, psi_abs_t)
+    # re-ordering
+    top_s, top_i = torch.topk(want.view(U, K * V), K, dim=-1)
+    r_new = torch.randn(N, T, 2, C).cuda()
+    yseq = torch.randint(0, V, (N, steps + 2)).cuda()
+    anc = torch.randint(0, 1000, (N, steps), dtype=torch.int32).cuda()
+    i = 4
+    ctr = torch.tensor([i, i + 1], dtype=torch.int64).cuda()
+    outs = (torch.empty(N, T, 2).cuda(), torch.empty(N).cuda(), torch.empty_like(yseq), torch.empty_like(anc),
+            torch.empty(N, dtype=torch.int64).cuda(), torch.empty(N).cuda())
+    ops.beam_reorder(top_i, top_s, cand, r_new, pa, yseq, anc, outs, K, V, ctr.view(torch.int32)[0:1])
+    prev = (top_i // V + (torch.arange(U).cuda() * K).view(U, 1)).view(N)
+    new_tok = (top_i % V).view(N)
+    cidx = (cand[prev] == new_tok.unsqueeze(1)).float().argmax(dim=1)
+    y_want = yseq[prev]
+    y_want[:, i + 1] = new_tok
+    for g, w in zip(outs, (r_new[prev, :, :, cidx], pa[prev, cidx], y_want, anc[prev], new_tok, top_s.view(N))):
+        assert torch.equal(g, w)
+    dst = [torch.zeros_like(o) for o in outs]
+    ops.multi_copy_(dst, list(outs))
+    assert all(torch.equal(d, o) for d, o in zip(dst, outs))
