@@ -284,6 +284,7 @@ int tavsr_bn_stats(const float* x, int64_t M, int32_t C, float eps, float moment
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float* ws, tavsr_stream_t stream);
 int tavsr_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        const float* res, float* y, int64_t M, int32_t C, int32_t act, tavsr_stream_t stream);
+/* dz may be NULL when res is NULL (nobody reads the pre-activation gradient): one [M, C] write less. */
 int tavsr_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                  const float* res, float* dz, float* dx, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t act,
                  float* ws, tavsr_stream_t stream);

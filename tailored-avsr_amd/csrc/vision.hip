@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       d.y = one(xv.y, rv.y, dv.y, mu.y, rs.y, g.y, b.y, sb.y, sg.y);
       d.z = one(xv.z, rv.z, dv.z, mu.z, rs.z, g.z, b.z, sb.z, sg.z);
       d.w = one(xv.w, rv.w, dv.w, mu.w, rs.w, g.w, b.w, sb.w, sg.w);
-      *reinterpret_cast<float4*>(dz + o) = d;
+      if (dz) *reinterpret_cast<float4*>(dz + o) = d;      // dz == nullptr: recomputed by the apply pass (no skip path wants it)
     }
   }
   red[ry][0][cq] = sb;
@@ -228,18 +228,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // backward, pass 2: dx = gamma * rstd * (dz - dbeta/M - xhat * dgamma/M)
+// dy != nullptr: dz was not stored by pass 1 (no residual input): it is recomputed here as dy * act'(z), z from x
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                     const float* __restrict__ dbeta, float* __restrict__ dx, int C4, float invM,
-                                    int64_t total4) {
+                                    int64_t total4, const float* __restrict__ dy, const float* __restrict__ beta, int act) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int c4 = (int)(i % C4);
-  const float4 d = reinterpret_cast<const float4*>(dz)[i], xv = reinterpret_cast<const float4*>(x)[i];
+  const float4 xv = reinterpret_cast<const float4*>(x)[i];
   const float4 mu = reinterpret_cast<const float4*>(mean)[c4], rs = reinterpret_cast<const float4*>(rstd)[c4];
   const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
   const float4 dg = reinterpret_cast<const float4*>(dgamma)[c4], db = reinterpret_cast<const float4*>(dbeta)[c4];
+  float4 d;
+  if (dy) {
+    const float4 dv = reinterpret_cast<const float4*>(dy)[i], b = reinterpret_cast<const float4*>(beta)[c4];
+    d.x = dv.x * act_bwd(act, (xv.x - mu.x) * rs.x * g.x + b.x);
+    d.y = dv.y * act_bwd(act, (xv.y - mu.y) * rs.y * g.y + b.y);
+    d.z = dv.z * act_bwd(act, (xv.z - mu.z) * rs.z * g.z + b.z);
+    d.w = dv.w * act_bwd(act, (xv.w - mu.w) * rs.w * g.w + b.w);
+  } else {
+    d = reinterpret_cast<const float4*>(dz)[i];
+  }
   float4 o;
   o.x = g.x * rs.x * (d.x - db.x * invM - (xv.x - mu.x) * rs.x * dg.x * invM);
   o.y = g.y * rs.y * (d.y - db.y * invM - (xv.y - mu.y) * rs.y * dg.y * invM);
@@ -457,11 +468,13 @@ extern "C" int tavsr_bn_apply_fwd(const float* x, const float* mean, const float
   return TAVSR_OK;
 }
 
-// dz (the gradient w.r.t. the pre-activation = the gradient of `res`), dx, dgamma, dbeta from dy; ws >= tavsr_bn_ws floats
+// dz (the gradient w.r.t. the pre-activation = the gradient of `res`), dx, dgamma, dbeta from dy; ws >= tavsr_bn_ws floats.
+// dz == nullptr (allowed without res): the [M, C] intermediate is never written - pass 2 recomputes it from dy and x.
 extern "C" int tavsr_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                             const float* beta, const float* res, float* dz, float* dx, float* dgamma, float* dbeta, int64_t M,
                             int32_t C, int32_t act, float* ws, tavsr_stream_t stream) {
-  TAVSR_REQUIRE(dy && x && mean && rstd && gamma && beta && dz && dx && dgamma && dbeta && ws, TAVSR_EINVAL, "bn_bwd: null pointer");
+  TAVSR_REQUIRE(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && ws, TAVSR_EINVAL, "bn_bwd: null pointer");
+  TAVSR_REQUIRE(dz || !res, TAVSR_EINVAL, "bn_bwd: dz (the gradient of res) is needed when there is a residual input");
   TAVSR_REQUIRE(C % 4 == 0, TAVSR_EUNSUPPORTED, "bn_bwd: C %% 4 == 0 required");
   if (M <= 0) return TAVSR_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -476,7 +489,7 @@ extern "C" int tavsr_bn_bwd(const float* dy, const float* x, const float* mean, 
   if (rc) return rc;
   const int64_t total4 = M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1d(total4), dim3(256), 0, s, dz, x, mean, rstd, gamma, dgamma, dbeta, dx, C / 4,
-                     1.f / (float)M, total4);
+                     1.f / (float)M, total4, dz ? nullptr : dy, beta, act);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

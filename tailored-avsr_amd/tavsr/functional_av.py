@@ -147,7 +147,7 @@ class VisualFrontendFn(torch.autograd.Function):
             del y1
             dy1 = ops.conv3x3_dx(dz2, ops.conv_wflip(w2, planes, planes), Ho, Wo)
             _, dz1, G[pre + "bn1.weight"], G[pre + "bn1.bias"] = ops.bn_bwd(
-                dy1, z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish")
+                dy1, z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish", need_dz=False)
             if stride == 1:
                 G[pre + "conv1.weight"] = _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin), p[pre + "conv1.weight"].shape)
                 # identity skip: its gradient joins in the GEMM epilogue (no separate add over the 0.4 GB maps)
@@ -160,7 +160,7 @@ class VisualFrontendFn(torch.autograd.Function):
             if ds is not None:
                 zd, md, rd, wd = ds
                 _, dzd, G[pre + "downsample.1.weight"], G[pre + "downsample.1.bias"] = ops.bn_bwd(
-                    dres, zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None)
+                    dres, zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None, need_dz=False)
                 G[pre + "downsample.0.weight"] = _w2d_grad(_conv3x3_dw(dzd, Xin, N, Hin, Win, cin, stride, taps=1),
                                                            p[pre + "downsample.0.weight"].shape)
                 dcold = ops.linear_dx(dzd, wd)
@@ -174,7 +174,7 @@ class VisualFrontendFn(torch.autograd.Function):
         x, z0, m0, r0, idx0, H0, W0, w0, col0 = ctx.saved["stem"]
         dy0 = ops.maxpool3x3s2_bwd(d, idx0, N, H0, W0, 64)
         _, dz0, G["frontend3D.1.weight"], G["frontend3D.1.bias"] = ops.bn_bwd(
-            dy0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
+            dy0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish", need_dz=False)
         gw0 = ops.linear_dw(dz0, col0)            # [64, 256], columns >= 245 are padding
         del col0
         g0 = ops.empty(64, 245, like=gw0)

@@ -760,11 +760,13 @@ def bn_apply_fwd(x, mean, rstd, gamma, beta, res=None, act=None):
     return y
 
 
-def bn_bwd(dy, x, mean, rstd, gamma, beta, res=None, act=None):
-    """returns dz (gradient w.r.t. the pre-activation, = gradient of ``res``), dx, dgamma, dbeta."""
+def bn_bwd(dy, x, mean, rstd, gamma, beta, res=None, act=None, need_dz=True):
+    """returns dz (gradient w.r.t. the pre-activation, = gradient of ``res``), dx, dgamma, dbeta.  ``need_dz=False`` (only
+    without ``res``): dz is not materialised (returned as None), which saves one [M, C] write."""
     M, Cn = x.shape
     require_cuda(dy, x, mean, rstd, gamma, beta, res)
-    dz, dx = torch.empty_like(x), torch.empty_like(x)
+    assert need_dz or res is None
+    dz, dx = (torch.empty_like(x) if need_dz else None), torch.empty_like(x)
     dg, db = empty(Cn, like=x), empty(Cn, like=x)
     ws = empty(lib_i64("tavsr_bn_ws", C.c_int64(M), Cn), like=x)
     check(lib().tavsr_bn_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), ptr(dz), ptr(dx), ptr(dg),

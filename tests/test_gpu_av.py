@@ -88,6 +88,10 @@ def test_batchnorm_train_vs_torch(act, with_res):
     assert rel_err(dg.cpu(), bn.weight.grad.cpu()) < 1e-4 and rel_err(db.cpu(), bn.bias.grad.cpu()) < 1e-4
     if with_res:
         assert rel_err(dz.cpu(), rd.grad.cpu()) < 1e-4
+    else:     # without a residual input the pre-activation gradient need not be materialised (pass 2 recomputes it)
+        none, dx2, dg2, db2 = ops.bn_bwd(r.float(), x, mean, rstd, g, b, None, act, need_dz=False)
+        assert none is None and torch.equal(dg2, dg) and torch.equal(db2, db)
+        assert rel_err(dx2.cpu(), dx.cpu()) < 1e-6 and rel_err(dx2.cpu(), xd.grad.cpu()) < 1e-4
 
 
 @pytest.mark.parametrize("H,W", [(44, 44), (9, 13), (12, 7)])
