@@ -276,8 +276,10 @@ int tavsr_embed_bwd(const int64_t* ids, const float* dout, float scale, float* d
  * ------------------------------------------------------------------------------------------- */
 int tavsr_im2col2d(const float* x, float* col, int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
                    int32_t stride, int32_t pad, tavsr_stream_t stream);
+/* extra (nullable, [N][Ho][Wo][C]): gradient rows of a parallel 1x1 / same stride / pad 0 convolution of the same input (the
+ * downsample path, resnet.py:68-87), added at pixels (stride*ho, stride*wo): dx = col2im(dcol) + scatter(extra) in one pass */
 int tavsr_col2im2d(const float* dcol, float* dx, int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
-                   int32_t stride, int32_t pad, tavsr_stream_t stream);
+                   int32_t stride, int32_t pad, const float* extra, tavsr_stream_t stream);
 int tavsr_im2col_stem(const float* x, float* col, int32_t B, int32_t T, int32_t H, int32_t W, tavsr_stream_t stream);
 int64_t tavsr_bn_ws(int64_t M, int32_t C);
 int tavsr_bn_stats(const float* x, int64_t M, int32_t C, float eps, float momentum, float* mean, float* var, float* rstd,

@@ -32,8 +32,11 @@ __global__ void im2col2d_kernel(const float* __restrict__ x, float* __restrict__
 }
 
 // dx[n,h,w,c] = sum over the (kh,kw) whose output position (h+p-kh)/s, (w+p-kw)/s exists of dcol[...]   (gather form)
+// extra (nullable, [n][Ho][Wo][C]): the data gradient of a parallel 1x1 / same-stride / pad-0 convolution of the same input
+// (the downsample path of a ResNet block): added at the pixels (stride*ho, stride*wo) it touches, so that neither its
+// mostly-zero scatter nor the sum of the two gradients needs a pass of its own
 __global__ void col2im2d_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int H, int W, int Ho, int Wo,
-                                int C4, int KH, int KW, int stride, int pad, int64_t total4) {
+                                int C4, int KH, int KW, int stride, int pad, int64_t total4, const float* __restrict__ extra) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int c4 = (int)(i % C4);
@@ -54,6 +57,10 @@ __global__ void col2im2d_kernel(const float* __restrict__ dcol, float* __restric
       const float4 v = reinterpret_cast<const float4*>(dcol)[(((n * Ho + ho) * Wo + wo) * (KH * KW) + kh * KW + kw) * C4 + c4];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+  }
+  if (extra && h % stride == 0 && w % stride == 0 && h / stride < Ho && w / stride < Wo) {
+    const float4 v = reinterpret_cast<const float4*>(extra)[((n * Ho + h / stride) * Wo + w / stride) * C4 + c4];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
   reinterpret_cast<float4*>(dx)[i] = acc;
 }
@@ -412,14 +419,14 @@ extern "C" int tavsr_im2col2d(const float* x, float* col, int64_t N, int32_t H, 
 }
 
 extern "C" int tavsr_col2im2d(const float* dcol, float* dx, int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
-                              int32_t stride, int32_t pad, tavsr_stream_t stream) {
+                              int32_t stride, int32_t pad, const float* extra, tavsr_stream_t stream) {
   TAVSR_REQUIRE(dcol && dx, TAVSR_EINVAL, "col2im2d: null pointer");
   TAVSR_REQUIRE(C % 4 == 0 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, TAVSR_EUNSUPPORTED, "col2im2d: C %% 4 == 0 required");
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const int64_t total4 = N * H * W * (C / 4);
   if (total4 <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(col2im2d_kernel, grid1d(total4), dim3(256), 0, (hipStream_t)stream, dcol, dx, H, W, Ho, Wo, C / 4, KH, KW,
-                     stride, pad, total4);
+                     stride, pad, total4, extra);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

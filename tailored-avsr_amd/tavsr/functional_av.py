@@ -139,6 +139,17 @@ class VisualFrontendFn(torch.autograd.Function):
         B, T, N, Hc, Wc, cl = ctx.dims
         G = {}
         d = ops.avgpool_bwd(dfeat.contiguous().view(N, cl), N, Hc * Wc, cl)
+
+        def self_ds_bwd(ds, dres, pre, Xin, N, Hin, Win, cin, stride):
+            """backward of the 1x1 downsample convolution + its BatchNorm: parameter gradients into G, returns the data
+            gradient rows [N*Ho*Wo, cin] (still to be scattered to the stride-s pixels)"""
+            zd, md, rd, wd = ds
+            _, dzd, G[pre + "downsample.1.weight"], G[pre + "downsample.1.bias"] = ops.bn_bwd(
+                dres, zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None, need_dz=False)
+            G[pre + "downsample.0.weight"] = _w2d_grad(_conv3x3_dw(dzd, Xin, N, Hin, Win, cin, stride, taps=1),
+                                                       p[pre + "downsample.0.weight"].shape)
+            return ops.linear_dx(dzd, wd)
+
         for (pre, stride, cin, planes, Hin, Win, Ho, Wo, Xin, z1, m1, r1, w1, z2, m2, r2, w2, res, ds, y1) in reversed(ctx.blocks):
             # out = swish(bn2(z2) + res)
             dres, dz2, G[pre + "bn2.weight"], G[pre + "bn2.bias"] = ops.bn_bwd(
@@ -148,6 +159,7 @@ class VisualFrontendFn(torch.autograd.Function):
             dy1 = ops.conv3x3_dx(dz2, ops.conv_wflip(w2, planes, planes), Ho, Wo)
             _, dz1, G[pre + "bn1.weight"], G[pre + "bn1.bias"] = ops.bn_bwd(
                 dy1, z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish", need_dz=False)
+            fused_ds = False
             if stride == 1:
                 G[pre + "conv1.weight"] = _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin), p[pre + "conv1.weight"].shape)
                 # identity skip: its gradient joins in the GEMM epilogue (no separate add over the 0.4 GB maps)
@@ -155,18 +167,17 @@ class VisualFrontendFn(torch.autograd.Function):
             else:
                 G[pre + "conv1.weight"] = _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin, stride), p[pre + "conv1.weight"].shape)
                 dcol1 = ops.linear_dx(dz1, w1)
-                dX = ops.col2im2d(dcol1, N, Hin, Win, cin, 3, 3, stride, 1)
+                dcold = None
+                if ds is not None:   # the downsample path's data gradient joins inside the col2im pass (same stride, same input)
+                    dcold = self_ds_bwd(ds, dres, pre, Xin, N, Hin, Win, cin, stride)
+                dX = ops.col2im2d(dcol1, N, Hin, Win, cin, 3, 3, stride, 1, extra=dcold)
                 del dcol1
-            if ds is not None:
-                zd, md, rd, wd = ds
-                _, dzd, G[pre + "downsample.1.weight"], G[pre + "downsample.1.bias"] = ops.bn_bwd(
-                    dres, zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None, need_dz=False)
-                G[pre + "downsample.0.weight"] = _w2d_grad(_conv3x3_dw(dzd, Xin, N, Hin, Win, cin, stride, taps=1),
-                                                           p[pre + "downsample.0.weight"].shape)
-                dcold = ops.linear_dx(dzd, wd)
+                fused_ds = ds is not None
+            if ds is not None and not fused_ds:
+                dcold = self_ds_bwd(ds, dres, pre, Xin, N, Hin, Win, cin, stride)
                 dXd = ops.col2im2d(dcold, N, Hin, Win, cin, 1, 1, stride, 0)
                 d = ops.axpby(dX, dXd, 1.0, 1.0)
-            elif stride == 1:
+            elif stride == 1 or fused_ds:     # the skip / downsample gradient is already inside dX
                 d = dX
             else:
                 d = ops.axpby(dX, dres, 1.0, 1.0)

@@ -718,10 +718,14 @@ def im2col2d(x, N, H, W, Cn, KH, KW, stride, pad):
     return col, Ho, Wo
 
 
-def col2im2d(dcol, N, H, W, Cn, KH, KW, stride, pad):
-    require_cuda(dcol)
+def col2im2d(dcol, N, H, W, Cn, KH, KW, stride, pad, extra=None):
+    """``extra`` [N*Ho*Wo, C]: data-gradient rows of a parallel 1x1 convolution with the same stride (downsample path),
+    added at the pixels it touches."""
+    require_cuda(dcol, extra)
+    assert extra is None or (extra.is_contiguous() and extra.shape == (dcol.shape[0], Cn))
     dx = empty(N * H * W, Cn, like=dcol)
-    check(lib().tavsr_col2im2d(ptr(dcol), ptr(dx), C.c_int64(N), H, W, Cn, KH, KW, stride, pad, stream()), "tavsr_col2im2d")
+    check(lib().tavsr_col2im2d(ptr(dcol), ptr(dx), C.c_int64(N), H, W, Cn, KH, KW, stride, pad, ptr(extra), stream()),
+          "tavsr_col2im2d")
     return dx
 
 

@@ -375,3 +375,16 @@ def test_strided_implicit_conv_vs_conv2d(N, H, W, Cin, Cout, k):
     assert rel_err(dw.cpu(), wr.grad) < 2e-5
     if (N * Ho * Wo) % 32 == 0:
         assert rel_err(_w2d_grad(ops.conv3x3_dw(dzl, xl, H, W, 2, k * k), w.shape).cpu(), wr.grad) < 2e-5
+
+
+def test_col2im_with_the_downsample_gradient_joined():
+    """col2im2d(extra=...) == col2im2d(3x3/s2/p1 patches) + col2im2d(1x1/s2/p0 rows), odd and even map sizes"""
+    from tavsr import ops
+    torch.manual_seed(8)
+    for N, H, W, C in ((3, 22, 22, 64), (2, 7, 9, 128)):
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        dcol = torch.randn(N * Ho * Wo, 9 * C, device="cuda")
+        rows = torch.randn(N * Ho * Wo, C, device="cuda")
+        want = ops.col2im2d(dcol, N, H, W, C, 3, 3, 2, 1) + ops.col2im2d(rows, N, H, W, C, 1, 1, 2, 0)
+        got = ops.col2im2d(dcol, N, H, W, C, 3, 3, 2, 1, extra=rows)
+        assert torch.equal(got, want)
