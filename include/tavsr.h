@@ -152,6 +152,15 @@ int tavsr_softmax_fwd(const float* ac, const float* bd, const int64_t* klens, fl
 int tavsr_softmax_bwd(const float* attn, const float* dattn, float* ds, float* ds_skew, int32_t H,
                       int32_t B, int32_t T1, int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w, float scale,
                       tavsr_stream_t stream);
+/* tavsr_softmax_fwd / _bwd with the dropout of the attention probabilities (espnet forward_attention: self.dropout(attn))
+ * folded in: pv = dropout(attn, p) with exactly the mask tavsr_dropout(attn, ..., offset) draws (rows padded to ld_s % 4 == 0);
+ * the backward takes the gradient w.r.t. pv and regenerates the mask. */
+int tavsr_softmax_dropout_fwd(const float* ac, const float* bd, const int64_t* klens, float* attn, float* pv, int32_t H, int32_t B,
+                              int32_t T1, int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w, float scale, int32_t causal, float p,
+                              const uint64_t* seed_dev, uint64_t offset, tavsr_stream_t stream);
+int tavsr_softmax_dropout_bwd(const float* attn, const float* dpv, float* ds, float* ds_skew, int32_t H, int32_t B, int32_t T1,
+                              int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w, float scale, float p, const uint64_t* seed_dev,
+                              uint64_t offset, tavsr_stream_t stream);
 
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);

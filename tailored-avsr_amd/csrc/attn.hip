@@ -32,7 +32,9 @@ __global__ void add_head_bias_kernel(const float* __restrict__ q, int64_t ldq, c
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ ac, const float* __restrict__ bd,
                                                           const int64_t* __restrict__ klens, float* __restrict__ attn,
                                                           int H, int B, int T1, int T2, int W, int64_t ld_s,
-                                                          int64_t ld_w, float scale, int causal) {
+                                                          int64_t ld_w, float scale, int causal, float* __restrict__ pv,
+                                                          uint32_t thr, float inv_keep, const uint64_t* __restrict__ seed,
+                                                          uint64_t offset4) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (int64_t)H * B * T1) return;
@@ -63,7 +65,15 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
       r = expf(s - mx) * inv;
     }
     o[j] = r;
+    if (pv) {      // dropout of the probabilities in the same pass: element e = row*ld_s + j of the flat tensor, as tavsr_dropout
+      const uint64_t ctr = offset4 + (uint64_t)(row * (ld_s >> 2)) + (uint64_t)(j >> 2), sd = seed[0];
+      uint32_t w[4];
+      philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), w);
+      pv[row * ld_s + j] = w[j & 3] >= thr ? r * inv_keep : 0.f;
+    }
   }
+  if (pv)
+    for (int j = T2 + lane; j < ld_s; j += 64) pv[row * ld_s + j] = 0.f;      // row padding (dropout of the zeros there)
 }
 
 // ds = attn * (dattn - sum_j attn*dattn) * scale ; optionally also the skewed copy
@@ -71,15 +81,27 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ attn,
                                                           const float* __restrict__ dattn, float* __restrict__ ds,
                                                           float* __restrict__ ds_skew, int64_t rows, int T1, int T2,
-                                                          int W, int64_t ld_s, int64_t ld_w, float scale) {
+                                                          int W, int64_t ld_s, int64_t ld_w, float scale, int drop, uint32_t thr,
+                                                          float inv_keep, const uint64_t* __restrict__ seed, uint64_t offset4) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int i = (int)(row % T1);
   const float* a = attn + row * ld_s;
-  const float* g = dattn + row * ld_s;
+  const float* g0 = dattn + row * ld_s;
+  // drop: dattn is the gradient w.r.t. the DROPPED probabilities; the mask of the forward site is regenerated here
+  auto grad = [&](int j) {
+    float v = g0[j];
+    if (drop) {
+      const uint64_t ctr = offset4 + (uint64_t)(row * (ld_s >> 2)) + (uint64_t)(j >> 2), sd = seed[0];
+      uint32_t w[4];
+      philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), w);
+      v = w[j & 3] >= thr ? v * inv_keep : 0.f;
+    }
+    return v;
+  };
   float dot = 0.f;
-  for (int j = lane; j < T2; j += 64) dot += a[j] * g[j];
+  for (int j = lane; j < T2; j += 64) dot += a[j] * grad(j);
   dot = wave_sum(dot);
   float* o = ds + row * ld_s;
   float* sk = ds_skew ? ds_skew + row * ld_w : nullptr;
@@ -88,7 +110,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     for (int c = lane; c < W; c += 64)
       if (c < off || c >= off + T2) sk[c] = 0.f;
   for (int j = lane; j < T2; j += 64) {
-    float v = a[j] * (g[j] - dot) * scale;
+    float v = a[j] * (grad(j) - dot) * scale;
     o[j] = v;
     if (sk) sk[off + j] = v;
   }
@@ -184,7 +206,26 @@ extern "C" int tavsr_softmax_fwd(const float* ac, const float* bd, const int64_t
   int64_t rows = (int64_t)H * B * T1;
   if (rows <= 0 || T2 <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, ac, bd, klens, attn, H,
-                     B, T1, T2, W, ld_s, ld_w, scale, causal);
+                     B, T1, T2, W, ld_s, ld_w, scale, causal, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// softmax_fwd that also writes pv = dropout(attn, p) with the mask tavsr_dropout(attn, ..., offset) would draw (the
+// probabilities' dropout of espnet's forward_attention) - one launch and one read of the probabilities less
+extern "C" int tavsr_softmax_dropout_fwd(const float* ac, const float* bd, const int64_t* klens, float* attn, float* pv, int32_t H,
+                                         int32_t B, int32_t T1, int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w, float scale,
+                                         int32_t causal, float p, const uint64_t* seed_dev, uint64_t offset,
+                                         tavsr_stream_t stream) {
+  TAVSR_REQUIRE(ac && attn && pv && seed_dev, TAVSR_EINVAL, "softmax_dropout_fwd: null pointer");
+  TAVSR_REQUIRE(ld_s >= T2 && ld_s % 4 == 0 && (!bd || ld_w >= W), TAVSR_EINVAL, "softmax_dropout_fwd: rows must be padded to 4");
+  TAVSR_REQUIRE(!bd || (T1 == T2 && W == 2 * T1 - 1), TAVSR_EINVAL, "softmax_dropout_fwd: bad rel-pos geometry");
+  TAVSR_REQUIRE(p >= 0.f && p < 1.f && offset % 4 == 0, TAVSR_EINVAL, "softmax_dropout_fwd: p in [0, 1), offset %% 4 == 0");
+  int64_t rows = (int64_t)H * B * T1;
+  if (rows <= 0 || T2 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, ac, bd, klens, attn, H,
+                     B, T1, T2, W, ld_s, ld_w, scale, causal, pv, (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed_dev,
+                     offset / 4);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
@@ -198,7 +239,23 @@ extern "C" int tavsr_softmax_bwd(const float* attn, const float* dattn, float* d
   int64_t rows = (int64_t)H * B * T1;
   if (rows <= 0 || T2 <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, attn, dattn, ds,
-                     ds_skew, rows, T1, T2, W, ld_s, ld_w, scale);
+                     ds_skew, rows, T1, T2, W, ld_s, ld_w, scale, 0, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// softmax_bwd whose dattn is the gradient of the dropped probabilities of tavsr_softmax_dropout_fwd (same p, offset)
+extern "C" int tavsr_softmax_dropout_bwd(const float* attn, const float* dpv, float* ds, float* ds_skew, int32_t H, int32_t B,
+                                         int32_t T1, int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w, float scale, float p,
+                                         const uint64_t* seed_dev, uint64_t offset, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(attn && dpv && ds && seed_dev, TAVSR_EINVAL, "softmax_dropout_bwd: null pointer");
+  TAVSR_REQUIRE(ld_s >= T2 && ld_s % 4 == 0 && (!ds_skew || ld_w >= W), TAVSR_EINVAL, "softmax_dropout_bwd: rows must be padded to 4");
+  TAVSR_REQUIRE(!ds_skew || (T1 == T2 && W == 2 * T1 - 1), TAVSR_EINVAL, "softmax_dropout_bwd: bad skew geometry");
+  TAVSR_REQUIRE(p >= 0.f && p < 1.f && offset % 4 == 0, TAVSR_EINVAL, "softmax_dropout_bwd: p in [0, 1), offset %% 4 == 0");
+  int64_t rows = (int64_t)H * B * T1;
+  if (rows <= 0 || T2 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, attn, dpv, ds, ds_skew, rows, T1,
+                     T2, W, ld_s, ld_w, scale, 1, (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed_dev, offset / 4);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

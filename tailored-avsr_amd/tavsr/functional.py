@@ -105,11 +105,12 @@ class _SelfAttnCore:
             bd = ops.empty(H, B, T1, Wp, like=dev)
             ops.gemm(T1, W, dk, qv, D, p, D, bd, Wp, nb1=B, nb2=H, sA=(T1 * D, dk), sB=(0, dk),
                      sC=(T1 * Wp, B * T1 * Wp))
-        attn = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal, T2=T2, W=W)
-        pv, tok = attn, None
-        if p_att and p_att > 0.0:      # dropout on the probabilities (espnet forward_attention); attn itself is kept
-            pv, tok = ops.dropout(attn, p_att)
-            tok = tok + (pv,)          # the dropped probabilities stay resident for dV (5 MB per layer)
+        if p_att and p_att > 0.0:      # dropout on the probabilities (espnet forward_attention) by the softmax launch itself;
+            attn, pv, tok = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal, T2=T2, W=W, p_drop=p_att)
+            tok = tok + (pv,)          # attn is kept; the dropped probabilities stay resident for dV (5 MB per layer)
+        else:
+            attn = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal, T2=T2, W=W)
+            pv, tok = attn, None
         ctx = ops.empty(B * T1, D, like=dev)
         # ctx[b,:,h] = drop(attn)[h,b] V[b,:,h]
         ops.gemm(T1, dk, T2, pv, S, vbuf, ldv, ctx, D, b_off=v_off, b_kmajor=True, nb1=B, nb2=H,
@@ -132,8 +133,9 @@ class _SelfAttnCore:
         ops.gemm(T2, dk, T1, pv, S, dctx, D, dv_buf, lddv, c_off=dv_off, a_kmajor=True, b_kmajor=True, nb1=B, nb2=H,
                  sA=sS, sB=(T1 * D, dk), sC=(T2 * lddv, dk))
         del pv
-        _drop_bwd_(dattn, tok)
-        ds, sk = ops.softmax_bwd(attn, dattn, 1.0 / math.sqrt(dk), skew=p is not None, T2=T2)
+        # dattn is the gradient of the dropped probabilities: the softmax backward regenerates the mask itself
+        ds, sk = ops.softmax_bwd(attn, dattn, 1.0 / math.sqrt(dk), skew=p is not None, T2=T2,
+                                 token=None if tok is None else tok[:2])
         # dQu[b,:,h] = ds[h,b] K[b,:,h]
         ops.gemm(T1, dk, T2, ds, S, kbuf, ldk, dq, lddq, b_off=k_off, c_off=dq_off, b_kmajor=True, nb1=B, nb2=H,
                  sA=sS, sB=(T2 * ldk, dk), sC=(T1 * lddq, dk))

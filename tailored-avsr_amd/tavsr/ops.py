@@ -478,8 +478,10 @@ def pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
-def softmax_fwd(ac, bd, klens, scale, causal=False, T2=None, W=0):
-    """ac [H,B,T1,ld_s] (ld_s >= T2, padded rows), bd [H,B,T1,ld_w] or None -> attn like ac."""
+def softmax_fwd(ac, bd, klens, scale, causal=False, T2=None, W=0, p_drop=0.0, token=None):
+    """ac [H,B,T1,ld_s] (ld_s >= T2, padded rows), bd [H,B,T1,ld_w] or None -> attn like ac.
+    ``p_drop`` > 0: also returns (pv, token) = dropout(attn, p_drop) computed by the same launch, with the mask and token
+    ``dropout(attn, p_drop)`` would give (``token`` from a previous call reproduces its mask)."""
     H, B, T1, ld_s = ac.shape
     T2 = ld_s if T2 is None else T2
     attn = torch.empty_like(ac)
@@ -488,18 +490,36 @@ def softmax_fwd(ac, bd, klens, scale, causal=False, T2=None, W=0):
         ld_w = bd.shape[-1]
         W = W or ld_w
     require_cuda(ac, bd, klens)
+    if p_drop and p_drop > 0.0:
+        assert ac.is_contiguous() and ld_s % 4 == 0
+        pv = torch.empty_like(ac)
+        if token is None:
+            token = (float(p_drop), _SITE[0])
+            _SITE[0] += (ac.numel() + 3) // 4 * 4
+        check(lib().tavsr_softmax_dropout_fwd(ptr(ac), ptr(bd), ptr(klens), ptr(attn), ptr(pv), H, B, T1, T2, W, C.c_int64(ld_s),
+                                              C.c_int64(ld_w), C.c_float(scale), int(causal), C.c_float(token[0]),
+                                              ptr(rng_state(ac.device)), C.c_uint64(token[1]), stream()),
+              "tavsr_softmax_dropout_fwd")
+        return attn, pv, token
     check(lib().tavsr_softmax_fwd(ptr(ac), ptr(bd), ptr(klens), ptr(attn), H, B, T1, T2, W, C.c_int64(ld_s),
                                   C.c_int64(ld_w), C.c_float(scale), int(causal), stream()), "tavsr_softmax_fwd")
     return attn
 
 
-def softmax_bwd(attn, dattn, scale, skew=False, T2=None):
+def softmax_bwd(attn, dattn, scale, skew=False, T2=None, token=None):
+    """``token`` (p, offset): dattn is the gradient of the DROPPED probabilities of softmax_fwd(p_drop=...): the mask is
+    regenerated inside the launch."""
     H, B, T1, ld_s = attn.shape
     T2 = ld_s if T2 is None else T2
     ds = torch.empty_like(attn)
     W = 2 * T1 - 1 if skew else 0
     ld_w = pad4(W)
     sk = empty(H, B, T1, ld_w, like=attn) if skew else None
+    if token is not None:
+        check(lib().tavsr_softmax_dropout_bwd(ptr(attn), ptr(dattn), ptr(ds), ptr(sk), H, B, T1, T2, W, C.c_int64(ld_s),
+                                              C.c_int64(ld_w), C.c_float(scale), C.c_float(token[0]), ptr(rng_state(attn.device)),
+                                              C.c_uint64(token[1]), stream()), "tavsr_softmax_dropout_bwd")
+        return ds, sk
     check(lib().tavsr_softmax_bwd(ptr(attn), ptr(dattn), ptr(ds), ptr(sk), H, B, T1, T2, W, C.c_int64(ld_s),
                                   C.c_int64(ld_w), C.c_float(scale), stream()), "tavsr_softmax_bwd")
     return ds, sk

@@ -190,3 +190,37 @@ def test_fused_dropout_kernels_equal_the_unfused_sequence():
         ref = ops.act_bwd_(ops.dropout(dh, 0.1, token=tk)[0], z, act)
         assert torch.equal(dz == 0, ref == 0)
         assert float((dz - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T1,T2,rel,causal", [(99, 99, True, False), (41, 41, False, True), (41, 99, False, False)])
+def test_softmax_with_fused_probability_dropout_equals_the_separate_launches(T1, T2, rel, causal):
+    """tavsr_softmax_dropout_fwd / _bwd == softmax_fwd -> dropout and dropout -> softmax_bwd with the same token, bit for bit
+    (rel-pos self-attention of the encoder, causal decoder self-attention, source attention)."""
+    from tavsr import ops
+    torch.manual_seed(3)
+    ops.manual_seed(77)
+    H, B = 4, 3
+    S = ops.pad4(T2)
+    ac = torch.randn(H, B, T1, S, device="cuda")
+    W = 2 * T1 - 1
+    bd = torch.randn(H, B, T1, ops.pad4(W), device="cuda") if rel else None
+    klens = torch.tensor([T2, T2 - 7, T2 // 2], device="cuda")
+    scale = 0.125
+    attn = ops.softmax_fwd(ac, bd, klens, scale, causal, T2=T2, W=W if rel else 0)
+    pv, tok = ops.dropout(attn, 0.1)
+    attn_f, pv_f, tok_f = ops.softmax_fwd(ac, bd, klens, scale, causal, T2=T2, W=W if rel else 0, p_drop=0.1, token=tok)
+    # (the padding columns T2.. of a row are never read by the GEMMs: attn leaves them unwritten, the fused pv zeroes them)
+    assert tok_f == tok and torch.equal(attn_f[..., :T2], attn[..., :T2]) and torch.equal(pv_f[..., :T2], pv[..., :T2])
+    assert bool((pv_f[..., T2:] == 0).all())
+    kept = float((pv[..., :T2] != 0).sum()) / float((attn[..., :T2] != 0).sum())
+    assert 0.88 < kept < 0.92
+    dpv = torch.randn_like(attn)
+    want_ds, want_sk = ops.softmax_bwd(attn, ops.dropout(dpv, tok[0], token=tok)[0], scale, skew=rel, T2=T2)
+    got_ds, got_sk = ops.softmax_bwd(attn, dpv, scale, skew=rel, T2=T2, token=tok)
+    assert torch.equal(got_ds[..., :T2], want_ds[..., :T2])
+    if rel:
+        assert torch.equal(got_sk[..., :W], want_sk[..., :W])
+    # a fresh site draws a different mask and advances the site counter by the tensor's size
+    _, pv2, tok2 = ops.softmax_fwd(ac, bd, klens, scale, causal, T2=T2, W=W if rel else 0, p_drop=0.1)
+    assert tok2[1] == tok[1] + attn.numel() and not torch.equal(pv2[..., :T2], pv[..., :T2])
