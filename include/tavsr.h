@@ -299,6 +299,12 @@ int tavsr_bn_apply_fwd(const float* x, const float* mean, const float* rstd, con
 int tavsr_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                  const float* res, float* dz, float* dx, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t act,
                  float* ws, tavsr_stream_t stream);
+/* tavsr_bn_bwd for the stem (conv -> BatchNorm -> activation -> MaxPool(1,3,3)/(1,2,2), conv3d_resnet18.py:57-59): the incoming
+ * gradient is the POOLED one (dpool [N,Ho,Wo,C] + the winning taps idx of tavsr_maxpool3x3s2_fwd); the gradient of the pool's
+ * [N*H*W, C] input is rebuilt per 2x2 pixel block inside both passes and never written.  ws >= tavsr_bn_ws(N*H*W, C). */
+int tavsr_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const float* x, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int64_t N, int32_t H,
+                        int32_t W, int32_t C, int32_t act, float* ws, tavsr_stream_t stream);
 int tavsr_rsqrt_eps(const float* v, float eps, float* out, int64_t n, tavsr_stream_t stream);
 int tavsr_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int64_t N, int32_t H, int32_t W, int32_t C,
                            tavsr_stream_t stream);

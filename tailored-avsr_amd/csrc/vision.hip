@@ -294,19 +294,17 @@ __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __re
   reinterpret_cast<uint32_t*>(idx)[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
 }
 
-// dx[n,h,w,c] = sum of dy over the (at most 4) windows that selected this pixel (gather form, deterministic).
-// thread = 4 channels of a 2x2 block of input pixels: the block lies under the 4 windows (a..a+1, b..b+1), each read once
-// (idx + dy) for its 9 window references - 2 loads per output instead of 4.5.
-__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
-                                        float* __restrict__ dx, int H, int W, int Ho, int Wo, int C, int64_t total4) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total4) return;
-  const int C4 = C >> 2, H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
-  const int c4 = (int)(i % C4);
-  int64_t r = i / C4;
-  const int b = (int)(r % W2), a = (int)((r / W2) % H2);
-  const int64_t n = r / ((int64_t)W2 * H2);
-  float acc[2][2][4] = {};
+// Gradient of MaxPool 3x3/s2/p1 for the 2x2 block of input pixels (2a..2a+1, 2b..2b+1), channels 4*c4..: the block lies
+// under the 4 windows (a..a+1, b..b+1), each read once (idx + dy) for its 9 window references - 2 loads per output
+// instead of 4.5; deterministic (gather form).
+__device__ __forceinline__ void maxpool_block_grad(const float* __restrict__ dy, const uint8_t* __restrict__ idx, int64_t n, int a,
+                                                   int b, int c4, int Ho, int Wo, int C4, float (&acc)[2][2][4]) {
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[ph][pw][j] = 0.f;
 #pragma unroll
   for (int dh = 0; dh < 2; ++dh) {
     const int ho = a + dh;
@@ -336,6 +334,20 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const uint
       }
     }
   }
+}
+
+// dx[n,h,w,c] = sum of dy over the (at most 4) windows that selected this pixel; thread = 4 channels of a 2x2 pixel block
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                        float* __restrict__ dx, int H, int W, int Ho, int Wo, int C, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int C4 = C >> 2, H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const int c4 = (int)(i % C4);
+  int64_t r = i / C4;
+  const int b = (int)(r % W2), a = (int)((r / W2) % H2);
+  const int64_t n = r / ((int64_t)W2 * H2);
+  float acc[2][2][4];
+  maxpool_block_grad(dy, idx, n, a, b, c4, Ho, Wo, C4, acc);
 #pragma unroll
   for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -344,6 +356,99 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const uint
       if (h < H && w < W)
         reinterpret_cast<float4*>(dx)[((n * H + h) * W + w) * C4 + c4] =
             make_float4(acc[ph][pw][0], acc[ph][pw][1], acc[ph][pw][2], acc[ph][pw][3]);
+    }
+}
+
+// ---- BatchNorm backward whose incoming gradient is the POOLED one (the stem: conv -> BN -> act -> max-pool): the
+// [N*H*W, C] gradient of the pool's input is never materialised - both passes rebuild it per 2x2 pixel block from the pooled
+// gradient and the winning taps (0.5 GB instead of three 1.6 GB round trips at the benchmark size).
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                 const float* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int64_t nblocks, int H, int W,
+                                                                 int Ho, int Wo, int C, int64_t blocks_per_wg, int act,
+                                                                 float* __restrict__ part) {
+  __shared__ float4 red[16][2][16];
+  const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cq * 4;
+  const int C4 = C >> 2, H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const int64_t r0 = (int64_t)blockIdx.y * blocks_per_wg, r1 = min(nblocks, r0 + blocks_per_wg);
+  float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float4 mu4 = *reinterpret_cast<const float4*>(mean + c), rs4 = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+    for (int64_t r = r0 + ry; r < r1; r += 16) {
+      const int b = (int)(r % W2), a = (int)((r / W2) % H2);
+      const int64_t n = r / ((int64_t)W2 * H2);
+      float acc[2][2][4];
+      maxpool_block_grad(dpool, idx, n, a, b, c >> 2, Ho, Wo, C4, acc);
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+          const int h = 2 * a + ph, w = 2 * b + pw;
+          if (h >= H || w >= W) continue;
+          const float4 xv4 = *reinterpret_cast<const float4*>(x + ((n * H + h) * W + w) * C + c);
+          const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            const float d = acc[ph][pw][j] * act_bwd(act, xh * g[j] + bt[j]);
+            sb[j] += d;
+            sg[j] += d * xh;
+          }
+        }
+    }
+  }
+  red[ry][0][cq] = make_float4(sb[0], sb[1], sb[2], sb[3]);
+  red[ry][1][cq] = make_float4(sg[0], sg[1], sg[2], sg[3]);
+  __syncthreads();
+  if (ry < 2 && c < C) {        // row lane 0 sums dbeta, row lane 1 dgamma (fixed order)
+    float4 t = red[0][ry][cq];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 u = red[k][ry][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2 + ry) * C + c) = t;
+  }
+}
+
+__global__ void bn_pool_bwd_apply_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                         const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ dgamma, const float* __restrict__ dbeta, float* __restrict__ dx,
+                                         int H, int W, int Ho, int Wo, int C, int act, float invM, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int C4 = C >> 2, H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const int c4 = (int)(i % C4);
+  int64_t r = i / C4;
+  const int b = (int)(r % W2), a = (int)((r / W2) % H2);
+  const int64_t n = r / ((int64_t)W2 * H2);
+  float acc[2][2][4];
+  maxpool_block_grad(dpool, idx, n, a, b, c4, Ho, Wo, C4, acc);
+  const float4 mu4 = reinterpret_cast<const float4*>(mean)[c4], rs4 = reinterpret_cast<const float4*>(rstd)[c4];
+  const float4 g4 = reinterpret_cast<const float4*>(gamma)[c4], b4 = reinterpret_cast<const float4*>(beta)[c4];
+  const float4 dg4 = reinterpret_cast<const float4*>(dgamma)[c4], db4 = reinterpret_cast<const float4*>(dbeta)[c4];
+  const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+  const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+  const float dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w}, db[4] = {db4.x, db4.y, db4.z, db4.w};
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw) {
+      const int h = 2 * a + ph, w = 2 * b + pw;
+      if (h >= H || w >= W) continue;
+      const int64_t o = ((n * H + h) * W + w) * C4 + c4;
+      const float4 xv4 = reinterpret_cast<const float4*>(x)[o];
+      const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+      float out[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = acc[ph][pw][j] * act_bwd(act, (xv[j] - mu[j]) * rs[j] * g[j] + bt[j]);
+        out[j] = g[j] * rs[j] * (d - db[j] * invM - (xv[j] - mu[j]) * rs[j] * dg[j] * invM);
+      }
+      reinterpret_cast<float4*>(dx)[o] = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
 
@@ -497,6 +602,35 @@ extern "C" int tavsr_bn_bwd(const float* dy, const float* x, const float* mean, 
   const int64_t total4 = M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1d(total4), dim3(256), 0, s, dz, x, mean, rstd, gamma, dgamma, dbeta, dx, C / 4,
                      1.f / (float)M, total4, dz ? nullptr : dy, beta, act);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// tavsr_bn_bwd for a BatchNorm whose activated output went through MaxPool 3x3/s2/p1: dpool [N,Ho,Wo,C] + idx are the pool's
+// gradient and winning taps; dx, dgamma, dbeta as tavsr_bn_bwd (no residual input)
+extern "C" int tavsr_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const float* x, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int64_t N,
+                                   int32_t H, int32_t W, int32_t C, int32_t act, float* ws, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dpool && idx && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && ws, TAVSR_EINVAL,
+                "bn_bwd_pooled: null pointer");
+  TAVSR_REQUIRE(C % 4 == 0 && ((uintptr_t)idx & 3) == 0 && (((uintptr_t)dpool | (uintptr_t)x | (uintptr_t)dx) & 15) == 0,
+                TAVSR_EUNSUPPORTED, "bn_bwd_pooled: C %% 4 == 0 and aligned tensors required");
+  if (N <= 0 || H <= 0 || W <= 0) return TAVSR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t M = N * H * W, nblocks = N * ((H + 1) / 2) * ((W + 1) / 2);
+  const int chunks = bn_chunks(M);                               // ws sized by tavsr_bn_ws(M, C)
+  const int64_t bpw = (nblocks + chunks - 1) / chunks;
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(cdiv(C, 64), chunks), dim3(256), 0, s, dpool, idx, x, mean, rstd, gamma, beta,
+                     nblocks, H, W, Ho, Wo, C, bpw, act, ws);
+  TAVSR_LAUNCH_CHECK();
+  int rc = tavsr_sum_partials(ws, chunks, (int64_t)2 * C, dbeta, C, 0, stream);
+  if (rc) return rc;
+  rc = tavsr_sum_partials(ws + C, chunks, (int64_t)2 * C, dgamma, C, 0, stream);
+  if (rc) return rc;
+  const int64_t total4 = nblocks * (C / 4);
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, grid1d(total4), dim3(256), 0, s, dpool, idx, x, mean, rstd, gamma, beta, dgamma, dbeta,
+                     dx, H, W, Ho, Wo, C, act, 1.f / (float)M, total4);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -183,9 +183,9 @@ class VisualFrontendFn(torch.autograd.Function):
                 d = ops.axpby(dX, dres, 1.0, 1.0)
         # ---- stem
         x, z0, m0, r0, idx0, H0, W0, w0, col0 = ctx.saved["stem"]
-        dy0 = ops.maxpool3x3s2_bwd(d, idx0, N, H0, W0, 64)
-        _, dz0, G["frontend3D.1.weight"], G["frontend3D.1.bias"] = ops.bn_bwd(
-            dy0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish", need_dz=False)
+        # max-pool backward inside the BatchNorm backward passes: the 1.6 GB gradient of the pool's input is never written
+        dz0, G["frontend3D.1.weight"], G["frontend3D.1.bias"] = ops.bn_bwd_pooled(
+            d.contiguous(), idx0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], N, H0, W0, "swish")
         gw0 = ops.linear_dw(dz0, col0)            # [64, 256], columns >= 245 are padding
         del col0
         g0 = ops.empty(64, 245, like=gw0)

@@ -798,6 +798,19 @@ def bn_bwd(dy, x, mean, rstd, gamma, beta, res=None, act=None, need_dz=True):
     return dz, dx, dg, db
 
 
+def bn_bwd_pooled(dpool, idx, x, mean, rstd, gamma, beta, N, H, W, act=None):
+    """bn_bwd (no residual) whose incoming gradient is the pooled one of maxpool3x3s2_fwd(act(bn(x))): -> dx, dgamma, dbeta."""
+    M, Cn = x.shape
+    require_cuda(dpool, idx, x, mean, rstd, gamma, beta)
+    assert M == N * H * W and dpool.is_contiguous() and idx.dtype == torch.uint8 and idx.is_contiguous()
+    dx = torch.empty_like(x)
+    dg, db = empty(Cn, like=x), empty(Cn, like=x)
+    ws = empty(lib_i64("tavsr_bn_ws", C.c_int64(M), Cn), like=x)
+    check(lib().tavsr_bn_bwd_pooled(ptr(dpool), ptr(idx), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dg),
+                                    ptr(db), C.c_int64(N), H, W, Cn, ACT[act], ptr(ws), stream()), "tavsr_bn_bwd_pooled")
+    return dx, dg, db
+
+
 def maxpool3x3s2_fwd(x, N, H, W, Cn):
     Ho, Wo = conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1)
     y = empty(N * Ho * Wo, Cn, like=x)

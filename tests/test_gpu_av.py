@@ -388,3 +388,22 @@ def test_col2im_with_the_downsample_gradient_joined():
         want = ops.col2im2d(dcol, N, H, W, C, 3, 3, 2, 1) + ops.col2im2d(rows, N, H, W, C, 1, 1, 2, 0)
         got = ops.col2im2d(dcol, N, H, W, C, 3, 3, 2, 1, extra=rows)
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 10, 12), (2, 9, 7), (5, 44, 44)])
+def test_batchnorm_backward_with_the_pooled_gradient(N, H, W):
+    """tavsr_bn_bwd_pooled == maxpool3x3s2_bwd followed by bn_bwd (the stem's tail), odd map sizes included"""
+    from tavsr import ops
+    torch.manual_seed(5)
+    C = 64
+    x = torch.randn(N * H * W, C, device="cuda") * 1.5 + 0.3
+    g, b = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.2
+    rm, rv, nbt = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    mean, rstd = ops.bn_stats(x, 1e-5, 0.1, rm, rv, nbt)
+    y = ops.bn_apply_fwd(x, mean, rstd, g, b, None, "swish")
+    yp, idx, Ho, Wo = ops.maxpool3x3s2_fwd(y, N, H, W, C)
+    dp = torch.randn_like(yp)
+    _, dx_w, dg_w, db_w = ops.bn_bwd(ops.maxpool3x3s2_bwd(dp, idx, N, H, W, C), x, mean, rstd, g, b, None, "swish")
+    dx, dg, db = ops.bn_bwd_pooled(dp, idx, x, mean, rstd, g, b, N, H, W, "swish")
+    assert rel_err(dg.cpu(), dg_w.cpu()) < 1e-5 and rel_err(db.cpu(), db_w.cpu()) < 1e-5      # other summation order
+    assert rel_err(dx.cpu(), dx_w.cpu()) < 1e-5
