@@ -800,6 +800,26 @@ static int launch_glds(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
 
 // implicit-convolution launches (two-stage 64x64 variant): mode 1 = A patches (NT / NN), mode 2 = B patches (TN)
 static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStream_t s) {
+  // Wider tiles where the shape allows - the gathered patch operand is the expensive one to load:
+  //   forward / data gradient: a 64x128 tile reads the image rows once for two column tiles of weights (Cout % 128 == 0):
+  //     +0.6 % on the AV step (128x64 and 128x128 tiles: nothing / worse);
+  //   weight gradient: a 128x64 tile (Cout % 128 == 0) shares one patch tile between 128 output channels: +1.6 %, and
+  //     another +0.7 % with the K split re-fitted to its three block slots per CU (2304 blocks).
+  // TAVSR_CONV_TILE=0 / TAVSR_CONV_DW_TILE=0 keep 64x64 everywhere (A/B switches).
+  static const int wide = [] { const char* e = getenv("TAVSR_CONV_TILE"); return e ? atoi(e) : 1; }();
+  static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
+  if (d.conv_mode == 1 && !d.b_kmajor && nsplit == 1 && wide && d.N % 128 == 0) {
+    GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 128)};
+    hipLaunchKernelGGL((gemm_glds_kernel<64, 128, 2, 2, 2, 3, false, false, 1, 1>), dim3(a2.tiles_m * a2.tiles_n, 1, 1), dim3(256), 0, s, a2);
+    TAVSR_LAUNCH_CHECK();
+    return TAVSR_OK;
+  }
+  if (d.conv_mode == 2 && dw_wide && d.M % 128 == 0) {     // weight gradient: 128 output channels share one patch tile
+    GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 128), cdiv(d.N, 64)};
+    hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, 3, true, true, 1, 2>), dim3(a2.tiles_m * a2.tiles_n, 1, nsplit), dim3(256), 0, s, a2);
+    TAVSR_LAUNCH_CHECK();
+    return launch_epilogue(a2, s);
+  }
   GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64)};
   dim3 grid(a.tiles_m * a.tiles_n, 1, nsplit);
   if (d.conv_mode == 1 && !d.b_kmajor)
@@ -885,8 +905,12 @@ static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
 static Plan plan_conv(const tavsr_gemm_desc& d, bool can_split) {
   Plan pc = plan(d, can_split, true);
   if (d.conv_mode == 2 && can_split) {
-    const long tiles = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
-    static const long target = [] { const char* e = getenv("TAVSR_CONV_DW_BLOCKS"); return e ? atol(e) : 2560L; }();
+    static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
+    const bool wide = dw_wide && d.M % 128 == 0;                 // 128x64 tiles (launch_conv): three block slots per CU
+    const long tiles = (long)cdiv(d.M, wide ? 128 : 64) * cdiv(d.N, 64);
+    static const long target64 = [] { const char* e = getenv("TAVSR_CONV_DW_BLOCKS"); return e ? atol(e) : 2560L; }();
+    static const long target128 = [] { const char* e = getenv("TAVSR_CONV_DW_BLOCKS_WIDE"); return e ? atol(e) : 2304L; }();
+    const long target = wide ? target128 : target64;
     const long want = std::min<long>(std::max<long>(1, target / tiles), d.K / 512);
     if (want > pc.nsplit) {
       pc.kchunk = cdiv(cdiv(d.K, want), 32) * 32;
