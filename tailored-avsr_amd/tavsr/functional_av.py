@@ -5,6 +5,7 @@ Reference semantics followed are cited per Function.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -55,6 +56,19 @@ def _conv3x3_dw(dz, x, N, H, W, cin, stride=1, taps=9):
     k = 3 if taps == 9 else 1
     col, _, _ = ops.im2col2d(x, N, H, W, cin, k, k, stride, k // 2)
     return ops.linear_dw(dz, col)
+
+
+def _plan_env(name, default):
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    return None if v in ("", "0") else tuple(int(t) for t in v.split(","))
+
+
+# tile variant and K split (tavsr_gemm_tune) of the stem's weight gradient [64 x 256] = dz0^T col0 over 6.2 M patch rows:
+# 64x128 tiles read dz0 twice instead of four times (the launch is HBM-bound: 12.7 GB -> 9.5 GB); +0.35 % on the AV step
+# against the planner's 64x64 / 250 slices (in-call A/B).  TAVSR_STEM_DW_PLAN=0 returns to the planner.
+STEM_DW_PLAN = _plan_env("TAVSR_STEM_DW_PLAN", (3, 512))
 
 
 class _BN:
@@ -186,7 +200,7 @@ class VisualFrontendFn(torch.autograd.Function):
         # max-pool backward inside the BatchNorm backward passes: the 1.6 GB gradient of the pool's input is never written
         dz0, G["frontend3D.1.weight"], G["frontend3D.1.bias"] = ops.bn_bwd_pooled(
             d.contiguous(), idx0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], N, H0, W0, "swish")
-        gw0 = ops.linear_dw(dz0, col0)            # [64, 256], columns >= 245 are padding
+        gw0 = ops.linear_dw(dz0, col0, force=STEM_DW_PLAN)            # [64, 256], columns >= 245 are padding
         del col0
         g0 = ops.empty(64, 245, like=gw0)
         ops.copy2d(gw0[:, :245], g0)

@@ -246,7 +246,7 @@ def join_side():
         torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
 
 
-def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False):
+def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False, force=None):
     """dW = alpha * dy.T @ x;  dy [M,N], x [M,K] -> [N,K] (torch weight layout).  With ``bias_grad`` also returns
     db = alpha * dy.sum(0), computed by the same launch from the A fragments (tavsr_gemm a_rowsum)."""
     M, N = dy.shape
@@ -256,7 +256,7 @@ def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False):
             out = empty(N, K, like=dy)
         gb = empty(N, like=dy) if bias_grad else None
         gemm(N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), a_kmajor=True, b_kmajor=True, alpha=alpha,
-             a_rowsum=gb)
+             a_rowsum=gb, force=force)
     return (out, gb) if bias_grad else out
 
 
