@@ -127,7 +127,7 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
     PROFILE.records.append((key, 2.0 * M * N * K * nb, 4.0 * nb * (a_el + b_el + c_el), e0, e1))
 
 
-def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None):
+def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None, force=None):
     """y = res + alpha*act(x @ w.T + b); x [M,K] (row stride x.stride(0)), w [N,K] torch layout."""
     M, K = x.shape
     N = w.shape[0]
@@ -137,18 +137,18 @@ def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=Non
     z = empty(M, N, like=x) if save_z else None
     assert not save_z or (out_off == 0 and ldc == N)
     gemm(M, N, K, x, x.stride(0), w, w.stride(0), out, ldc, c_off=out_off, bias=b, act=act, alpha=alpha, Z=z,
-         R=res, ldr=0 if res is None else res.stride(0))
+         R=res, ldr=0 if res is None else res.stride(0), force=force)
     return (out, z) if save_z else out
 
 
-def linear_dx(dy, w, *, alpha=1.0, DZ=None, dact=None, res=None, out=None):
+def linear_dx(dy, w, *, alpha=1.0, DZ=None, dact=None, res=None, out=None, force=None):
     """dx = res + alpha * (dy @ w) * act'(DZ);  dy [M,N], w [N,K] -> [M,K]."""
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = empty(M, K, like=dy)
     gemm(M, K, N, dy, dy.stride(0), w, w.stride(0), out, out.stride(0), b_kmajor=True, alpha=alpha, DZ=DZ, dact=dact,
-         R=res, ldr=0 if res is None else res.stride(0))
+         R=res, ldr=0 if res is None else res.stride(0), force=force)
     return out
 
 
