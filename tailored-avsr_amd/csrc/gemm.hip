@@ -477,6 +477,9 @@ __device__ __forceinline__ void read_frag_g(const float* __restrict__ s, int row
   }
 }
 
+// 16 readable zero floats for LDS-DMA loads that must deliver zeros (K tails)
+__device__ float g_zero_page[16];
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -551,7 +554,7 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
 
   const int kbeg = blockIdx.z * kchunk;
   const int kend = min(d.K, kbeg + kchunk);
-  const int nk = (kend - kbeg) / BK;          // whole K-steps only (host guarantees it)
+  const int nk = CONV == 3 ? (kend - kbeg + BK - 1) / BK : (kend - kbeg) / BK;     // whole K-steps (host guarantees it); CONV 3: K tail
   const int64_t kstepA = AK ? (int64_t)BK * d.lda : BK;
   const int64_t kstepB = BKM ? (int64_t)BK * d.ldb : BK;
   int64_t offA[LA::NR], offB[LB::NR];
@@ -577,7 +580,36 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       cmask[i] = c9 ? mk : 1u;
     }
   }
+  // CONV 3 (K tail: K % 32 != 0): chunks whose first k lies at or past K are fetched from a zero page; a k-contiguous chunk
+  // that straddles K (K % 4 != 0) is fetched whole and its k >= K elements are zeroed in LDS before the last K-step
+  int kofsA[LA::NR], kofsB[LB::NR];
+  if (CONV == 3) {
+#pragma unroll
+    for (int i = 0; i < LA::NR; ++i) {
+      const int q = i * NT + tid;
+      kofsA[i] = AK ? q / (BM / 4) : ((q & 7) ^ (((q >> 3) >> 1) & 7)) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < LB::NR; ++i) {
+      const int q = i * NT + tid;
+      kofsB[i] = BKM ? q / (BN / 4) : ((q & 7) ^ (((q >> 3) >> 1) & 7)) * 4;
+    }
+  }
   auto issue = [&](int kt, int st) {
+    if (CONV == 3) {
+      const int kleft = kend - (kbeg + kt * BK);                 // k values of this step that exist
+#pragma unroll
+      for (int i = 0; i < LA::NR; ++i) {
+        const float* src = kofsA[i] < kleft ? Ak + kt * kstepA + offA[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + (i * NT + wave * 64) * 4), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < LB::NR; ++i) {
+        const float* src = kofsB[i] < kleft ? Bk + kt * kstepB + offB[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + ASZ + (i * NT + wave * 64) * 4), 16, 0, 0);
+      }
+      return;
+    }
     if (CONV == 1) {
       const int kk = kbeg + kt * BK, tap = kk / d.conv_C;
       const int toff = c9 ? (tap / 3 - 1) * d.conv_W + (tap % 3 - 1) : 0;
@@ -658,6 +690,20 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
   for (; kt < nk; ++kt) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (CONV == 3 && kt == nk - 1 && ((kend - kbeg) & 3) != 0) {
+      // k-contiguous operands: the chunk that straddles K brought 1..3 elements of k >= K along: zero them (row r,
+      // element kk of a stage lives at r*32 + (((kk >> 2) ^ ((r >> 1) & 7)) << 2) + (kk & 3))
+      const int kt_len = (kend - kbeg) - kt * BK, k4 = (kt_len + 3) & ~3;
+      float* a_s = smem + st * STAGE;
+      float* b_s = a_s + ASZ;
+      if (!AK)
+        for (int r = tid; r < BM; r += NT)
+          for (int kk = kt_len; kk < k4; ++kk) a_s[r * 32 + ((((kk >> 2) ^ ((r >> 1) & 7))) << 2) + (kk & 3)] = 0.f;
+      if (!BKM)
+        for (int r = tid; r < BN; r += NT)
+          for (int kk = kt_len; kk < k4; ++kk) b_s[r * 32 + ((((kk >> 2) ^ ((r >> 1) & 7))) << 2) + (kk & 3)] = 0.f;
+      __syncthreads();
+    }
     compute(st);
     st = st + 1 == S ? 0 : st + 1;
   }
@@ -848,6 +894,17 @@ static int launch_fallback(const tavsr_gemm_desc& d, bool vec, int nsplit, int k
   return rc ? rc : launch_epilogue(a, s);
 }
 
+static int launch_tail(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStream_t s) {
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64)};
+  dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
+  int rc = launch_layout(d, [&](auto ak, auto bk) {
+    hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, decltype(ak)::value, decltype(bk)::value, 1, 3>), grid, dim3(256), 0, s, a);
+    TAVSR_LAUNCH_CHECK();
+    return (int)TAVSR_OK;
+  });
+  return rc ? rc : launch_epilogue(a, s);
+}
+
 static int launch(int cfg, const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
   switch (cfg) {
     case 0: return launch_glds<128, 128, 2, 2, 3, 1>(d, nsplit, kchunk, s);
@@ -871,6 +928,15 @@ struct Plan {
 // K slice, row-contiguous operands with a row count that is a multiple of 4)
 static bool glds_ok(const tavsr_gemm_desc& d, bool vec) {
   return vec && d.K % 32 == 0 && d.K >= 32 && (!d.a_kmajor || d.M % 4 == 0) && (!d.b_kmajor || d.N % 4 == 0);
+}
+
+// K % 32 != 0 on the LDS-DMA kernel (tail variant): 16-byte chunks past K come from a zero page; a k-contiguous operand
+// must hold the (up to 3) elements between K and the next multiple of 4 inside its rows (ld >= roundup4(K))
+static bool tail_ok(const tavsr_gemm_desc& d, bool vec) {
+  static const int on = [] { const char* e = getenv("TAVSR_GEMM_TAIL"); return e ? atoi(e) : 1; }();
+  const int64_t k4 = (d.K + 3) / 4 * 4;
+  return on && vec && d.K % 32 != 0 && d.K >= 32 && (!d.a_kmajor || d.M % 4 == 0) && (!d.b_kmajor || d.N % 4 == 0) &&
+         (d.a_kmajor || d.lda >= k4) && (d.b_kmajor || d.ldb >= k4) && d.conv_mode == 0;
 }
 
 // Planner (fitted to profiles/r01_gemm_sweep_v3/v4.txt and end-to-end A/B runs, MI355X).  The 64x64 tile wins or ties every
@@ -965,7 +1031,12 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
     if (pc.nsplit > 1 && d.ws_floats < ws_floats_for(d, pc.nsplit)) pc = plan(d, false, true);
     return launch_conv(d, pc.nsplit, pc.kchunk, s);
   }
-  Plan p = plan(d, can_split, fast);
+  const bool tail = !fast && force_cfg < 0 && tail_ok(d, vec);
+  Plan p = plan(d, can_split, fast || tail);
+  if (tail) {
+    if (p.nsplit > 1 && d.ws_floats < ws_floats_for(d, p.nsplit)) p = plan(d, false, true);
+    return launch_tail(d, p.nsplit, p.kchunk, s);
+  }
   if (force_cfg >= 0) {
     TAVSR_REQUIRE(force_cfg < kNumCfgs || force_cfg == kFallbackCfg, TAVSR_EINVAL, "tavsr_gemm_tune: cfg %d out of range",
                   force_cfg);
@@ -1039,7 +1110,7 @@ extern "C" int64_t tavsr_gemm_ws(const tavsr_gemm_desc* dp) {
   if (d.M <= 0 || d.N <= 0) return 0;
   const bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.sA1 % 4 == 0 &&
                    d.sA2 % 4 == 0 && d.sB1 % 4 == 0 && d.sB2 % 4 == 0;
-  Plan p = d.conv_mode != 0 ? plan_conv(d, true) : plan(d, true, glds_ok(d, vec));
+  Plan p = d.conv_mode != 0 ? plan_conv(d, true) : plan(d, true, glds_ok(d, vec) || tail_ok(d, vec));
   return ws_floats_for(d, p.nsplit);
 }
 

@@ -184,3 +184,41 @@ def test_gemm_every_tile_config(cfg, mode):
         ops.gemm(M, N, K, A, A.stride(0), B, B.stride(0), out, N, a_kmajor=mode == "TN", b_kmajor=mode != "NT",
                  force=(cfg, ns))
         assert (out.double() - ref).abs().max() / ref.abs().max() < 2e-6, (cfg, mode, ns)
+
+
+@pytest.mark.parametrize("M,N,K", [(99, 64, 99), (64, 99 + 1, 100), (200, 132, 77), (99, 64, 197), (3168, 256, 99)])
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN", "TT"])
+def test_gemm_k_tail_on_the_lds_dma_kernel(M, N, K, mode):
+    """K % 32 != 0 with 16-byte aligned rows takes the tail variant of the fast kernel: chunks past K come from a zero
+    page and the 1..3 elements between K and the next multiple of 4 of a k-contiguous operand (here NaN) are zeroed in
+    LDS - the result equals the fp64 product over exactly K terms."""
+    from tavsr import ops
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda")
+    b = torch.randn(K, N, device="cuda")
+    ref = a.double() @ b.double()
+    a_km, b_km = mode[0] == "T", mode[1] == "N"
+    k4, m4, n4 = (K + 3) // 4 * 4, (M + 3) // 4 * 4, (N + 3) // 4 * 4
+    if a_km:                                            # A given as [K, ld >= M]
+        A = torch.full((K, m4), float("nan"), device="cuda")
+        A[:, :M] = a.t()
+        lda = m4
+    else:                                               # A as [M, ld >= roundup4(K)], NaN in the row padding
+        A = torch.full((M, k4), float("nan"), device="cuda")
+        A[:, :K] = a
+        lda = k4
+    if b_km:
+        B = torch.full((K, n4), float("nan"), device="cuda")
+        B[:, :N] = b
+        ldb = n4
+    else:
+        B = torch.full((N, k4), float("nan"), device="cuda")
+        B[:, :K] = b.t()
+        ldb = k4
+    if (a_km and M % 4) or (b_km and N % 4):
+        pytest.skip("k-major operands of the vector kernels need M / N % 4 == 0")
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm(M, N, K, A, lda, B, ldb, out, N, a_kmajor=a_km, b_kmajor=b_km)
+    assert bool(torch.isfinite(out).all())
+    err = (out.double() - ref).abs().max() / ref.abs().max()
+    assert err < 2e-6, (mode, float(err))
