@@ -34,8 +34,13 @@ import torch  # noqa: E402
 import yaml  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
-# Algorithmic work, forward, per utterance (BASELINE.md section 2 / SURVEY Appendix C); fwd+bwd = 3x.
+# Algorithmic work, forward, per utterance (BASELINE.md section 2 / SURVEY Appendix C).  fwd+bwd = 3x fwd MINUS the data
+# gradients nobody needs and the step never computes: the inputs' own (Conv3d stem 1->64, k 5x7x7 on 100x44x44 outputs:
+# 2*245*64*193600 = 6.07 GFLOP/utt; Conv2dSubsampling conv1 1->256 k3 on 199x39 outputs: 0.036 GFLOP/utt).
 GFLOP_PER_UTT_FWD = {"asr": 11.35, "avsr": 79.14}
+GFLOP_PER_UTT_STEP = {"asr": 3 * 11.35 - 0.036, "avsr": 3 * 79.14 - 6.07 - 0.036}
+GFLOP_12L_FWD_PER_UTT = 7.95      # the 12 MyBranchformerEncoderLayers alone: 254 GFLOP at B = 32 (north_star's forward target)
+GFLOP_EMBED_FWD_PER_UTT = 2.50    # Conv2dSubsampling
 B_PER_GPU, T_IN, N_MEL, L_TXT, T_VID, HW = 32, 400, 80, 40, 100, 88
 WORKLOAD = "avsr"  # set by --workload: "avsr" = BASELINE configs[2]/[3] (the AV-Branchformer the metric names), "asr" = configs[1]
 
@@ -103,16 +108,39 @@ def build_product_model():
     return ASRTask.build_model(argparse.Namespace(**_copy.deepcopy(make_conf())))
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle's fwd+bwd of the same model/workload on the host cores (bounded sample)."""
+def host_cores():
+    """(physical cores of the box per lscpu, hardware threads this process may run on)."""
+    import re
+    import subprocess
+    phys = None
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        get = lambda k: int(re.search(rf"^{k}:\s*(\d+)", txt, re.M).group(1))
+        phys = get(r"Core\(s\) per socket") * get(r"Socket\(s\)")
+    except Exception:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    return phys or allowed, allowed
+
+
+def cpu_baseline(budget_s=30.0):
+    """The oracle's fwd+bwd of the same model/workload on the host cores (bounded sample, SURVEY 8d / task section 4).
+    Threads = the physical cores this process may use (lscpu cores, capped by the affinity mask).  Batch: the GPU
+    run's batch of 32 costs the oracle ~80 s per AV step on this class of host, far beyond the bounded sample the default
+    run allows, so the sample is batch 4 (AV) / 8 (audio-only) of the same clips: 1 warm-up + >= 3 timed steps, median."""
     from oracle.av import build_avsr_oracle
     from oracle.model import build_asr_oracle
     from tavsr.utils.tokens import CHAR_ENGLISH
 
+    phys, allowed = host_cores()
+    threads = max(1, min(phys, allowed))
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     build = build_avsr_oracle if WORKLOAD == "avsr" else build_asr_oracle
     model = build(copy.deepcopy(make_conf()), CHAR_ENGLISH).train()
-    cores = torch.get_num_threads()
     bs = 4 if WORKLOAD == "avsr" else 8
     batch = make_batch(bs, 1234, "cpu")
 
@@ -123,17 +151,100 @@ def cpu_baseline(budget_s=20.0):
         loss.backward()
 
     step()  # warm-up (allocator, oneDNN primitives)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_all < budget_s and len(times) < 10):
+        t0 = time.perf_counter()
         step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 10:
-            break
-    return {"value": round(bs * n / el, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fwd+bwd steps of batch {bs} x 4 s (same model/config, same dropout rates), eager torch fp32, "
-                      f"{cores} threads, {el:.1f} s"}
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(bs / med, 3), "unit": "utterances/s", "cores": phys, "threads": threads, "kind": "port",
+            "sample": f"median of {len(times)} timed fwd+bwd steps (1 warm-up) of batch {bs} x 4 s clips (same model/config, "
+                      f"same dropout rates; batch 32 would take ~{32 / (bs / med):.0f} s per step), eager torch fp32 oracle, "
+                      f"{threads} threads on {phys} physical cores ({allowed} hardware threads allowed), "
+                      f"{sum(times):.1f} s timed"}
+
+
+def bench_fwd_encoder(dev, steps=20, warmup=5):
+    """north_star's forward target: the 12-layer Branchformer encoder FORWARD at batch 32 (T = 99 after Conv2dSubsampling),
+    BASELINE configs[1] shapes.  Times (a) the 12 MyBranchformerEncoderLayers + after_norm alone - the 254 GFLOP the
+    ">= 50 % MFMA" target is stated on - and (b) the whole MyBranchformerEncoder.forward incl. Conv2dSubsampling, each in
+    eval mode and in train mode (recipe dropout; everything the backward needs is kept), as hipGraph replays and as eager
+    launches.  fp32; HIP events on the launch stream."""
+    global WORKLOAD
+    saved = WORKLOAD
+    WORKLOAD = "asr"
+    try:
+        torch.manual_seed(0)
+        model = build_product_model().to(dev)
+    finally:
+        WORKLOAD = saved
+    enc = model.encoder
+    from tavsr import ops
+    from tavsr.layers import make_pad_mask
+    g = torch.Generator().manual_seed(1234)
+    speech = torch.randn(B_PER_GPU, T_IN, N_MEL, generator=g).to(dev)
+    ilens = torch.full((B_PER_GPU,), T_IN, dtype=torch.int64, device=dev)
+    res = {"batch": B_PER_GPU, "T": None, "dtype": "f32", "peak_tflops": PEAK_FP32_MFMA_TFLOPS,
+           "gflop_12_layers": round(GFLOP_12L_FWD_PER_UTT * B_PER_GPU, 1),
+           "gflop_encoder_forward": round((GFLOP_12L_FWD_PER_UTT + GFLOP_EMBED_FWD_PER_UTT) * B_PER_GPU, 1)}
+
+    def timed(fn, graph):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        run = fn
+        if graph:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                keep = fn()      # noqa: F841  (graph-owned outputs)
+            run = gr.replay
+        for _ in range(warmup):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    for mode in ("eval", "train"):
+        model.train(mode == "train")
+        with torch.set_grad_enabled(mode == "train"):
+            masks = (~make_pad_mask(ilens, speech.size(1))[:, None, :]).to(dev)
+            with torch.no_grad():
+                (x0, pos), m0 = enc.embed(speech, masks)
+            lens = m0.squeeze(1).sum(1).to(torch.int64)
+            res["T"] = int(x0.shape[1])
+            x0 = x0.detach().requires_grad_(mode == "train")
+
+            def layers():
+                ops.rng_step_begin(dev)
+                xs = (x0, pos)
+                for layer in enc.encoders:
+                    xs, _ = layer(xs, m0, lens=lens)
+                return enc.after_norm(xs[0])
+
+            def whole():
+                ops.rng_step_begin(dev)
+                return enc(speech, ilens)[0]
+
+            for name, fn, gf in (("layers12", layers, GFLOP_12L_FWD_PER_UTT),
+                                 ("encoder_forward", whole, GFLOP_12L_FWD_PER_UTT + GFLOP_EMBED_FWD_PER_UTT)):
+                for launch, graph in (("graph", True), ("eager", False)):
+                    ms = timed(fn, graph)
+                    tf = gf * B_PER_GPU / ms          # GFLOP / ms = TFLOP/s
+                    res[f"{name}_{mode}_{launch}"] = {"ms": round(ms, 3), "tflops": round(tf, 2),
+                                                      "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -145,6 +256,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="all dropout rates 0 (the parity configuration)")
+    ap.add_argument("--mode", choices=("step", "fwd-encoder"), default="step",
+                    help="step: the fwd+bwd training step (the metric); fwd-encoder: ONLY the 12-layer encoder forward "
+                         "measurement (north_star's >= 50 %% MFMA target), printed as its own JSON line (profiling runs)")
+    ap.add_argument("--no-fwd-encoder", action="store_true", help="skip the fwd_encoder object of the default run")
+    ap.add_argument("--no-eager", action="store_true", help="skip the eager (no-graph) timing beside the graph number")
     ap.add_argument("--workload", choices=("asr", "avsr"), default="avsr",
                     help="asr: BASELINE configs[1] (headline); avsr: configs[2] tailored AV-Branchformer incl. the visual frontend")
     args = ap.parse_args()
@@ -159,6 +275,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+
+    if args.mode == "fwd-encoder":
+        if rank == 0:
+            print(json.dumps({"metric": "ms per forward of the 12-layer Branchformer encoder, batch 32 x 4 s (north_star target: "
+                                        ">= 50 % of fp32 MFMA peak on the 254 GFLOP of the 12 layers)", "unit": "ms",
+                              "n_gpus": 1, "higher_is_better": False, "data": "synthetic",
+                              "fwd_encoder": bench_fwd_encoder(dev, args.steps, args.warmup)}), flush=True)
+        return
 
     torch.manual_seed(0)
     model = build_product_model().to(dev).train()
@@ -236,9 +360,29 @@ def main():
                    "dropout": 0.1 if DROPOUT else 0.0,
                    "launch": "eager" if graph is None else "hipGraph replay (whole fwd+bwd)"},
         "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-        "model_tflops_per_s": round(value * 3 * GFLOP_PER_UTT_FWD[WORKLOAD] / 1e3, 2),
-        "frac_of_fp32_mfma_peak_whole_step": round(value * 3 * GFLOP_PER_UTT_FWD[WORKLOAD] / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+        "model_tflops_per_s": round(value * GFLOP_PER_UTT_STEP[WORKLOAD] / 1e3, 2),
+        "frac_of_fp32_mfma_peak_whole_step": round(value * GFLOP_PER_UTT_STEP[WORKLOAD] / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+        "gflop_per_utt_step": round(GFLOP_PER_UTT_STEP[WORKLOAD], 2),
     }
+
+    if graph is not None and not args.no_eager:
+        # the same step as eager launches (what a ragged, un-captured training loop pays): reported beside the graph number
+        n_eager = max(3, args.steps // 4)
+        for _ in range(2):
+            fwd_bwd()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_eager):
+            fwd_bwd()
+            buckets.allreduce_mean()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t)
+        out["eager"] = {"value": round(B_PER_GPU * world * n_eager / el, 2), "unit": "utterances/s",
+                        "ms_per_step": round(1e3 * el / n_eager, 3), "steps": n_eager}
 
     if rank == 0 and not args.no_roofline:
         # Instrumented eager replay of the same step: HIP events around every tavsr_gemm launch on the launch stream.
@@ -265,6 +409,13 @@ def main():
             "by_kernel": {k: {"calls_per_step": v["calls"] // nprof, "ms_per_step": round(1e3 * v["seconds"] / nprof, 3),
                               "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)} for k, v in summ.items()},
         }
+    if rank == 0 and world == 1 and not args.no_fwd_encoder:
+        del graph, static_loss
+        for p in params:
+            p.grad = None
+        model = None
+        torch.cuda.empty_cache()
+        out["fwd_encoder"] = bench_fwd_encoder(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

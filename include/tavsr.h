@@ -427,6 +427,9 @@ int tavsr_multi_copy(void* const* dst, const void* const* src, const int64_t* nb
 int tavsr_dropout(const float* x, float* y, int64_t n, float p, const uint64_t* seed_dev, uint64_t offset,
                   tavsr_stream_t stream);
 int tavsr_rng_advance(uint64_t* seed_dev, tavsr_stream_t stream);
+/* tavsr_rng_advance that also writes the advanced value to step_seed_dev: the per-step seed copy the dropout sites of ONE
+ * forward pass and of its backward pass read (a later forward advances seed_dev without touching earlier steps' masks). */
+int tavsr_rng_step(uint64_t* seed_dev, uint64_t* step_seed_dev, tavsr_stream_t stream);
 /* fused forms with the same mask as tavsr_dropout(x = t / dh, same p, seed, offset):
  *   tavsr_dropout_add    : y = a + alpha * dropout(t)        (x + ff_scale * dropout(f(x)), encoder_layer.py:194,309,314)
  *   tavsr_dropout_act_bwd: dz = dropout(dh) * act'(z)        (backward of dropout(act(z)), PositionwiseFeedForward) */

@@ -3,7 +3,7 @@ libs=$1; shift
 mkdir -p gpurun_out
 for rep in 1 2; do
 for l in $libs; do
-  TAVSR_LIB=$GRAFT_REPO_ROOT/$l python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline "$@" > gpurun_out/ab_lib.json 2> gpurun_out/ab_lib.err; echo "$l rc=$?"
+  TAVSR_LIB=$GRAFT_REPO_ROOT/$l python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-fwd-encoder --no-eager "$@" > gpurun_out/ab_lib.json 2> gpurun_out/ab_lib.err; echo "$l rc=$?"
   python - <<PY
 import json
 try:

@@ -78,8 +78,15 @@ __global__ __launch_bounds__(256) void dropout_act_bwd_kernel(const float* __res
   }
 }
 
-__global__ void rng_advance_kernel(uint64_t* __restrict__ seed) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) seed[0] = seed[0] * 6364136223846793005ull + 1442695040888963407ull;
+// step_out (optional): this step's own copy of the advanced seed - the dropout sites of ONE forward pass and of ITS backward
+// pass read that copy, so a second forward before the first backward (micro-batches, a validation pass, a second model)
+// cannot change the masks the backward regenerates
+__global__ void rng_advance_kernel(uint64_t* __restrict__ seed, uint64_t* __restrict__ step_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint64_t s = seed[0] * 6364136223846793005ull + 1442695040888963407ull;
+    seed[0] = s;
+    if (step_out) step_out[0] = s;
+  }
 }
 
 }  // namespace tavsr
@@ -102,7 +109,14 @@ extern "C" int tavsr_dropout(const float* x, float* y, int64_t n, float p, const
 
 extern "C" int tavsr_rng_advance(uint64_t* seed_dev, tavsr_stream_t stream) {
   TAVSR_REQUIRE(seed_dev, TAVSR_EINVAL, "rng_advance: null pointer");
-  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seed_dev);
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seed_dev, (uint64_t*)nullptr);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_rng_step(uint64_t* seed_dev, uint64_t* step_seed_dev, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(seed_dev && step_seed_dev, TAVSR_EINVAL, "rng_step: null pointer");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seed_dev, step_seed_dev);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

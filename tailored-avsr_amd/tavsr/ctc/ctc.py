@@ -50,7 +50,24 @@ class CTC(torch.nn.Module):
         with torch.no_grad():
             return ops.ctc_greedy(self._logits(hs_pad), hlens.to(torch.int64), blank, collapse=True)
 
-    def log_softmax(self, hs_pad):
-        raise NotImplementedError("frame posteriors are only needed by beam search (SURVEY 8f-1, next row)")
+    def softmax(self, hs_pad):
+        """(B,Tmax,eprojs) -> frame posteriors (B,Tmax,odim)  (src/ctc/ctc.py:160-168).  Forward only: the differentiable
+        use of the posteriors (self-conditioned intermediate CTC) is ``functional.InterCTCConditionFn``."""
+        B, T, D = hs_pad.shape
+        with torch.no_grad():
+            logits = self._logits(hs_pad)
+            V, S = logits.shape[-1], ops.pad4(logits.shape[-1])
+            if S != V:      # the softmax kernel reads 4-padded rows
+                padded = ops.empty(B * T, S, like=logits)
+                ops.copy2d(logits.view(B * T, V), padded[:, :V])
+            else:
+                padded = logits.view(B * T, S)
+            vlen = torch.full((1,), V, dtype=torch.int64, device=hs_pad.device)
+            prob = ops.softmax_fwd(padded.view(1, 1, B * T, S), None, vlen, 1.0, T2=V)
+        return prob.view(B * T, S)[:, :V].reshape(B, T, V)
 
-    softmax = log_softmax
+    def log_softmax(self, hs_pad):
+        """(B,Tmax,eprojs) -> frame log-posteriors (B,Tmax,odim)  (src/ctc/ctc.py:170-178); forward only (beam search)."""
+        B, T, D = hs_pad.shape
+        with torch.no_grad():
+            return ops.log_softmax_rows(self._logits(hs_pad).view(B * T, -1)).view(B, T, -1)

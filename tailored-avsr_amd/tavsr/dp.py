@@ -13,8 +13,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
-    """(rank, local_rank, world) from the torch.distributed.run environment; initialises the group."""
+def init_from_env(backend: str | None = None, seed: int | None = 0) -> tuple[int, int, int]:
+    """(rank, local_rank, world) from the torch.distributed.run environment; initialises the group.
+
+    ``seed`` (None: leave the generators alone): every rank seeds its generators with ``seed + rank`` - the device
+    generator of the dropout masks (``ops.manual_seed``) and torch's host generator (SpecAug draws, stochastic depth) -
+    so that data-parallel ranks do not draw identical masks.  Parameters are made equal separately
+    (``GradBuckets.broadcast_parameters``)."""
     import os
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -30,6 +35,11 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         elif torch.cuda.is_available():
             local = local % torch.cuda.device_count()
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if seed is not None:
+        torch.manual_seed(int(seed) + rank)
+        if torch.cuda.is_available():
+            from . import ops
+            ops.manual_seed(0x5EED5EED + int(seed) + rank, torch.device("cuda", local))
     return rank, local, world
 
 

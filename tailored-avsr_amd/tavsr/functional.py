@@ -107,7 +107,7 @@ class _SelfAttnCore:
                      sC=(T1 * Wp, B * T1 * Wp))
         if p_att and p_att > 0.0:      # dropout on the probabilities (espnet forward_attention) by the softmax launch itself;
             attn, pv, tok = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal, T2=T2, W=W, p_drop=p_att)
-            tok = tok + (pv,)          # attn is kept; the dropped probabilities stay resident for dV (5 MB per layer)
+            tok = (tok, pv)            # attn is kept; the dropped probabilities stay resident for dV (5 MB per layer)
         else:
             attn = ops.softmax_fwd(ac, bd, klens, 1.0 / math.sqrt(dk), causal, T2=T2, W=W)
             pv, tok = attn, None
@@ -129,13 +129,13 @@ class _SelfAttnCore:
         ops.gemm(T1, T2, dk, dctx, D, vbuf, ldv, dattn, S, b_off=v_off, nb1=B, nb2=H, sA=(T1 * D, dk),
                  sB=(T2 * ldv, dk), sC=sS)
         # dV[b,:,h] = drop(attn)[h,b]^T dctx[b,:,h]
-        pv = attn if tok is None else tok[2]
+        pv = attn if tok is None else tok[1]
         ops.gemm(T2, dk, T1, pv, S, dctx, D, dv_buf, lddv, c_off=dv_off, a_kmajor=True, b_kmajor=True, nb1=B, nb2=H,
                  sA=sS, sB=(T1 * D, dk), sC=(T2 * lddv, dk))
         del pv
         # dattn is the gradient of the dropped probabilities: the softmax backward regenerates the mask itself
         ds, sk = ops.softmax_bwd(attn, dattn, 1.0 / math.sqrt(dk), skew=p is not None, T2=T2,
-                                 token=None if tok is None else tok[:2])
+                                 token=None if tok is None else tok[0])
         # dQu[b,:,h] = ds[h,b] K[b,:,h]
         ops.gemm(T1, dk, T2, ds, S, kbuf, ldk, dq, lddq, b_off=k_off, c_off=dq_off, b_kmajor=True, nb1=B, nb2=H,
                  sA=sS, sB=(T2 * ldk, dk), sC=(T1 * lddq, dk))

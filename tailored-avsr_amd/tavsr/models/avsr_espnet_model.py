@@ -13,7 +13,7 @@ import torch
 from .. import functional_av as FA
 from .. import ops
 from ..ctc.ctc import CTC
-from .espnet_model import ESPnetASRModel
+from .espnet_model import ESPnetASRModel, cut_to_longest
 
 
 class ESPnetAVSRModel(ESPnetASRModel):
@@ -51,6 +51,8 @@ class ESPnetAVSRModel(ESPnetASRModel):
 
     # ---------------------------------------------------------------- avsr_espnet_model.py:383-488
     def encode(self, audio, audio_lengths, video, video_lengths):
+        audio = cut_to_longest(audio, audio_lengths)        # _extract_feats, avsr_espnet_model.py:499
+        video = cut_to_longest(video, video_lengths)
         if self.acoustic_frontend is not None:
             audio_feats, audio_feats_lengths = self.acoustic_frontend(audio, audio_lengths)
         else:
@@ -90,7 +92,7 @@ class ESPnetAVSRModel(ESPnetASRModel):
                                             text_lengths.shape)
         batch_size = audio.shape[0]
         ops.rng_step_begin(audio.device)
-        text = text.to(torch.int64).masked_fill(text == -1, self.ignore_id)
+        text = cut_to_longest(text.to(torch.int64).masked_fill(text == -1, self.ignore_id), text_lengths)
         encoder_out, encoder_out_lens = self.encode(audio, audio_lengths, video, video_lengths)
         return self._hybrid_loss(encoder_out, encoder_out_lens, text, text_lengths, batch_size)
 

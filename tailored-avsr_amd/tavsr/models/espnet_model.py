@@ -82,6 +82,17 @@ class ErrorCalculator:
         return cer, wer
 
 
+def cut_to_longest(x: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+    """``x[:, : lengths.max()]`` - the reference's "for data-parallel" cut of an over-padded batch
+    (src/models/espnet_model.py:372 / avsr_espnet_model.py:499 ``_extract_feats``, ``forward`` text cut :247).  The
+    maximum is read on the host (one sync, as in the reference); while a hipGraph is being captured no sync is possible
+    and the batch must already be tightly padded (a captured step has static shapes anyway)."""
+    if x.is_cuda and torch.cuda.is_current_stream_capturing():
+        return x
+    m = int(lengths.max())
+    return x if m >= x.shape[1] else x[:, :m].contiguous()
+
+
 class UtteranceMVN(torch.nn.Module):
     """espnet2 UtteranceMVN(norm_means=True, norm_vars=False) on the HIP path."""
 
@@ -126,9 +137,9 @@ class ESPnetASRModel(torch.nn.Module):
 
     # ---------------------------------------------------------------- espnet_model.py:369-430
     def encode(self, speech: torch.Tensor, speech_lengths: torch.Tensor):
+        # espnet_model.py:372: the batch is cut to its longest utterance (the STFT's reflect padding sees the tensor end)
+        speech = cut_to_longest(speech, speech_lengths)
         if self.frontend is not None:
-            # espnet_model.py:372: the batch is cut to its longest utterance (the STFT's reflect padding sees the tensor end)
-            speech = speech[:, : int(speech_lengths.max())]
             feats, feats_lengths = self.frontend(speech, speech_lengths)
         else:
             feats, feats_lengths = speech, speech_lengths
@@ -149,7 +160,7 @@ class ESPnetASRModel(torch.nn.Module):
             speech.shape, speech_lengths.shape, text.shape, text_lengths.shape)
         batch_size = speech.shape[0]
         ops.rng_step_begin(speech.device)    # fresh dropout masks for this step (a kernel: captured graphs replay it)
-        text = text.to(torch.int64).masked_fill(text == -1, self.ignore_id)
+        text = cut_to_longest(text.to(torch.int64).masked_fill(text == -1, self.ignore_id), text_lengths)
         encoder_out, encoder_out_lens = self.encode(speech, speech_lengths)
         return self._hybrid_loss(encoder_out, encoder_out_lens, text, text_lengths, batch_size)
 

@@ -66,9 +66,9 @@ def _zero_page(device) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
-         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, conv=None, force=None):
+         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, conv=None, force=None, ws_cap=None):
     """Raw descriptor call; offsets are in elements into the given tensors.  ``force=(cfg, nsplit)`` bypasses
-    the planner (tuning / tests)."""
+    the planner (tuning / tests); ``ws_cap`` caps the split-K workspace handed to the library (tests of its fallback)."""
     require_cuda(A, B, Cc, bias, Z, R, DZ, a_rowsum)
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -99,6 +99,8 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         need = force[1] * max(1, nb1) * max(1, nb2) * M * N + force[1] * M
     else:
         need = lib().tavsr_gemm_ws(C.byref(d))
+    if ws_cap is not None:
+        need = min(need, int(ws_cap))
     if need > 0:
         ws = torch.empty(need, dtype=f32, device=Cc.device)
         d.ws, d.ws_floats = ws.data_ptr(), need
@@ -494,11 +496,10 @@ def softmax_fwd(ac, bd, klens, scale, causal=False, T2=None, W=0, p_drop=0.0, to
         assert ac.is_contiguous() and ld_s % 4 == 0
         pv = torch.empty_like(ac)
         if token is None:
-            token = (float(p_drop), _SITE[0])
-            _SITE[0] += (ac.numel() + 3) // 4 * 4
+            token = _new_token(p_drop, ac.numel(), ac.device)
         check(lib().tavsr_softmax_dropout_fwd(ptr(ac), ptr(bd), ptr(klens), ptr(attn), ptr(pv), H, B, T1, T2, W, C.c_int64(ld_s),
                                               C.c_int64(ld_w), C.c_float(scale), int(causal), C.c_float(token[0]),
-                                              ptr(rng_state(ac.device)), C.c_uint64(token[1]), stream()),
+                                              ptr(token[2]), C.c_uint64(token[1]), stream()),
               "tavsr_softmax_dropout_fwd")
         return attn, pv, token
     check(lib().tavsr_softmax_fwd(ptr(ac), ptr(bd), ptr(klens), ptr(attn), H, B, T1, T2, W, C.c_int64(ld_s),
@@ -517,7 +518,7 @@ def softmax_bwd(attn, dattn, scale, skew=False, T2=None, token=None):
     sk = empty(H, B, T1, ld_w, like=attn) if skew else None
     if token is not None:
         check(lib().tavsr_softmax_dropout_bwd(ptr(attn), ptr(dattn), ptr(ds), ptr(sk), H, B, T1, T2, W, C.c_int64(ld_s),
-                                              C.c_int64(ld_w), C.c_float(scale), C.c_float(token[0]), ptr(rng_state(attn.device)),
+                                              C.c_int64(ld_w), C.c_float(scale), C.c_float(token[0]), ptr(token[2]),
                                               C.c_uint64(token[1]), stream()), "tavsr_softmax_dropout_bwd")
         return ds, sk
     check(lib().tavsr_softmax_bwd(ptr(attn), ptr(dattn), ptr(ds), ptr(sk), H, B, T1, T2, W, C.c_int64(ld_s),
@@ -1117,16 +1118,23 @@ def beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, outs, K, V, step
 
 
 # ---------------------------------------------------------------------------------------------- dropout
-# The generator state is ONE uint64 per device, resident in HBM; ``rng_step_begin`` advances it with a kernel (so a
-# captured step graph draws new masks at every replay) and rewinds the per-step site counter, which hands every dropout
-# call of a step its own, reproducible counter range.  A dropout call returns the token (p, offset) that regenerates its
-# mask in the backward pass.
+# The generator state is ONE uint64 per device, resident in HBM.  ``rng_step_begin`` advances it with a kernel (so a
+# captured step graph draws new masks at every replay), writes the advanced value into a fresh one-element tensor that
+# belongs to THIS forward pass, and rewinds the per-step site counter, which hands every dropout call of the pass its own,
+# reproducible counter range.  A dropout call returns the token (p, offset, step seed tensor) that regenerates its mask
+# in the backward pass: the token owns the seed it was drawn with, so a second forward pass (micro-batches, a validation
+# pass, another model) before the first backward cannot change the masks that backward regenerates.
 _RNG = {}
+_STEP_SEED = {}
 _SITE = [0]
 
 
+def _dev_index(device=None) -> int:
+    return torch.cuda.current_device() if device is None or device.index is None else device.index
+
+
 def rng_state(device=None) -> torch.Tensor:
-    dev = torch.cuda.current_device() if device is None or device.index is None else device.index
+    dev = _dev_index(device)
     t = _RNG.get(dev)
     if t is None:
         t = _RNG[dev] = torch.full((1,), 0x5EED5EED, dtype=torch.int64, device=f"cuda:{dev}")
@@ -1134,14 +1142,31 @@ def rng_state(device=None) -> torch.Tensor:
 
 
 def manual_seed(seed: int, device=None):
+    """the seeding hook of the device generator (dropout masks); data-parallel ranks seed with base + rank (dp.init_from_env)."""
     rng_state(device).fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    _STEP_SEED.pop(_dev_index(device), None)
     _SITE[0] = 0
 
 
 def rng_step_begin(device=None):
-    """call once per training step (before the forward pass)."""
-    check(lib().tavsr_rng_advance(ptr(rng_state(device)), stream()), "tavsr_rng_advance")
+    """call once per forward pass (before its first dropout site)."""
+    dev = _dev_index(device)
+    step = torch.empty(1, dtype=torch.int64, device=f"cuda:{dev}")     # inside a graph capture: lives in the graph's pool
+    check(lib().tavsr_rng_step(ptr(rng_state(device)), ptr(step), stream()), "tavsr_rng_step")
+    _STEP_SEED[dev] = step
     _SITE[0] = 0
+
+
+def step_seed(device=None) -> torch.Tensor:
+    """the seed tensor new dropout sites draw from: the current pass's copy (the live state before any rng_step_begin)."""
+    t = _STEP_SEED.get(_dev_index(device))
+    return rng_state(device) if t is None else t
+
+
+def _new_token(p, n, device):
+    tok = (float(p), _SITE[0], step_seed(device))
+    _SITE[0] += (n + 3) // 4 * 4
+    return tok
 
 
 def dropout(x, p: float, out=None, token=None):
@@ -1152,9 +1177,8 @@ def dropout(x, p: float, out=None, token=None):
         out = torch.empty_like(x)
     n = x.numel()
     if token is None:
-        token = (float(p), _SITE[0])
-        _SITE[0] += (n + 3) // 4 * 4
-    check(lib().tavsr_dropout(ptr(x), ptr(out), C.c_int64(n), C.c_float(token[0]), ptr(rng_state(x.device)),
+        token = _new_token(p, n, x.device)
+    check(lib().tavsr_dropout(ptr(x), ptr(out), C.c_int64(n), C.c_float(token[0]), ptr(token[2]),
                               C.c_uint64(token[1]), stream()), "tavsr_dropout")
     return out, token
 
@@ -1166,10 +1190,9 @@ def dropout_add(a, t, p: float, alpha: float = 1.0, out=None):
     if out is None:
         out = torch.empty_like(a)
     n = t.numel()
-    token = (float(p), _SITE[0])
-    _SITE[0] += (n + 3) // 4 * 4
+    token = _new_token(p, n, a.device)
     check(lib().tavsr_dropout_add(ptr(a), ptr(t), ptr(out), C.c_int64(n), C.c_float(p), C.c_float(alpha),
-                                  ptr(rng_state(a.device)), C.c_uint64(token[1]), stream()), "tavsr_dropout_add")
+                                  ptr(token[2]), C.c_uint64(token[1]), stream()), "tavsr_dropout_add")
     return out, token
 
 
@@ -1180,5 +1203,5 @@ def dropout_act_bwd(dh, z, act, token, out=None):
     if out is None:
         out = torch.empty_like(dh)
     check(lib().tavsr_dropout_act_bwd(ptr(dh), ptr(z), ptr(out), C.c_int64(dh.numel()), C.c_float(token[0]), ACT[act],
-                                      ptr(rng_state(dh.device)), C.c_uint64(token[1]), stream()), "tavsr_dropout_act_bwd")
+                                      ptr(token[2]), C.c_uint64(token[1]), stream()), "tavsr_dropout_act_bwd")
     return out

@@ -48,6 +48,7 @@ class FusedAdam:
         self.grad = torch.zeros_like(self.flat)
         self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps)]
         self._step = 0
+        self._steps = [0] * len(self.params)      # per-parameter step counts (torch.optim.Adam keeps one per parameter)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -55,25 +56,44 @@ class FusedAdam:
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
+        """torch.optim.Adam semantics incl. its treatment of missing gradients: a parameter whose ``grad`` is None is
+        skipped (no moment decay, no update) and keeps its own step count for the bias correction.  Gradients are packed
+        by multi-tensor launches (24 tensors each); the update is one launch per maximal run of neighbouring parameters
+        that have a gradient and the same step count - ONE launch in the usual case where every parameter has one."""
+        from . import ops
         g = self.param_groups[0]
-        for p, off in zip(self.params, self.offsets):   # pack (a missing gradient counts as zero)
-            k = p.numel()
-            if p.grad is None:
-                self.grad[off: off + k].zero_()
-            else:
-                self.grad[off: off + k].copy_(p.grad.reshape(-1))
+        live = [i for i, p in enumerate(self.params) if p.grad is not None]
+        dst = [self.grad[self.offsets[i]: self.offsets[i] + self.params[i].numel()] for i in live]
+        src = [self.params[i].grad.contiguous().reshape(-1) for i in live]
+        for j in range(0, len(live), 24):
+            ops.multi_copy_(dst[j: j + 24], src[j: j + 24])
+        for i in live:
+            self._steps[i] += 1
         self._step += 1
-        L.check(L.lib().tavsr_adam_step(L.ptr(self.flat), L.ptr(self.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-                                        C.c_int64(self.flat.numel()), C.c_float(g["lr"]), C.c_float(g["betas"][0]),
-                                        C.c_float(g["betas"][1]), C.c_float(g["eps"]), C.c_int64(self._step),
-                                        C.c_float(grad_scale), L.stream()), "tavsr_adam_step")
+        runs, k = [], 0
+        while k < len(live):                 # maximal runs of adjacent parameters with equal step counts
+            a = b = k
+            while b + 1 < len(live) and live[b + 1] == live[b] + 1 and self._steps[live[b + 1]] == self._steps[live[a]]:
+                b += 1
+            runs.append((live[a], live[b]))
+            k = b + 1
+        for ia, ib in runs:
+            lo = self.offsets[ia]
+            hi = self.offsets[ib + 1] if ib + 1 < len(self.params) else self.flat.numel()
+            L.check(L.lib().tavsr_adam_step(C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad.data_ptr() + 4 * lo),
+                                            C.c_void_p(self.exp_avg.data_ptr() + 4 * lo),
+                                            C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * lo), C.c_int64(hi - lo),
+                                            C.c_float(g["lr"]), C.c_float(g["betas"][0]), C.c_float(g["betas"][1]),
+                                            C.c_float(g["eps"]), C.c_int64(self._steps[ia]), C.c_float(grad_scale), L.stream()),
+                    "tavsr_adam_step")
 
     def state_dict(self):
-        return dict(step=self._step, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, param_groups=[
+        return dict(step=self._step, steps=list(self._steps), exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, param_groups=[
             {k: v for k, v in self.param_groups[0].items() if k != "params"}])
 
     def load_state_dict(self, sd):
         self._step = sd["step"]
+        self._steps = list(sd.get("steps", [sd["step"]] * len(self.params)))
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.param_groups[0].update(sd["param_groups"][0])

@@ -100,6 +100,35 @@ def test_model_backward_under_frozen_masks():
     assert abs(fd - gnorm) / gnorm < 3e-2, (fd, gnorm)
 
 
+def test_backward_regenerates_its_own_forward_masks():
+    """fwd(A), fwd(B), bwd(A): the second forward advances the device generator, the backward of the first must still
+    regenerate the masks ITS forward drew (the dropout tokens own their step's seed) - gradients bit-identical to a lone
+    fwd(A) -> bwd(A) step."""
+    from oracle.model import synth
+    from tavsr import ops
+    model = _model().train()
+    batch = _batch()
+    other = (synth((3, 120, 80), seed=31).cuda(), batch[1], batch[2], batch[3])
+
+    ops.manual_seed(4242)
+    model.zero_grad()
+    model(*batch)[0].backward()
+    want = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    ops.manual_seed(4242)
+    model.zero_grad()
+    loss_a = model(*batch)[0]
+    with torch.no_grad():
+        model(*other)                  # a validation-style forward in between (CTC dropout is live in eval as well)
+    loss_b = model(*other)[0]          # ... and a second micro-batch forward
+    loss_a.backward()
+    for n, p in model.named_parameters():
+        if n in want:
+            assert torch.equal(p.grad, want[n]), n
+    loss_b.backward()                  # the second pass's own masks are intact as well
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
 def test_train_loss_is_stochastic_and_close_to_eval_loss():
     from tavsr import ops
     model = _model(dropout=0.1)

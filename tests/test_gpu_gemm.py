@@ -186,9 +186,14 @@ def test_gemm_every_tile_config(cfg, mode):
         assert (out.double() - ref).abs().max() / ref.abs().max() < 2e-6, (cfg, mode, ns)
 
 
-@pytest.mark.parametrize("M,N,K", [(99, 64, 99), (64, 99 + 1, 100), (200, 132, 77), (99, 64, 197), (3168, 256, 99)])
+@pytest.mark.parametrize("M,N,K,ws_cap", [(99, 64, 99, None), (64, 99 + 1, 100, None), (200, 132, 77, None), (99, 64, 197, None),
+                                           (3168, 256, 99, None),
+                                           # K tail AND a K split (few tiles, K >= 512): last slice ends at K, slab epilogue
+                                           (128, 256, 2052, None), (256, 256, 4099, None), (256, 256, 3170, None),
+                                           # ... and the planner's fallback when the caller's workspace cannot hold the slabs
+                                           (128, 256, 2052, 4096)])
 @pytest.mark.parametrize("mode", ["NT", "NN", "TN", "TT"])
-def test_gemm_k_tail_on_the_lds_dma_kernel(M, N, K, mode):
+def test_gemm_k_tail_on_the_lds_dma_kernel(M, N, K, ws_cap, mode):
     """K % 32 != 0 with 16-byte aligned rows takes the tail variant of the fast kernel: chunks past K come from a zero
     page and the 1..3 elements between K and the next multiple of 4 of a k-contiguous operand (here NaN) are zeroed in
     LDS - the result equals the fp64 product over exactly K terms."""
@@ -218,7 +223,7 @@ def test_gemm_k_tail_on_the_lds_dma_kernel(M, N, K, mode):
     if (a_km and M % 4) or (b_km and N % 4):
         pytest.skip("k-major operands of the vector kernels need M / N % 4 == 0")
     out = torch.empty(M, N, device="cuda")
-    ops.gemm(M, N, K, A, lda, B, ldb, out, N, a_kmajor=a_km, b_kmajor=b_km)
+    ops.gemm(M, N, K, A, lda, B, ldb, out, N, a_kmajor=a_km, b_kmajor=b_km, ws_cap=ws_cap)
     assert bool(torch.isfinite(out).all())
     err = (out.double() - ref).abs().max() / ref.abs().max()
-    assert err < 2e-6, (mode, float(err))
+    assert err < (2e-6 if K < 512 else 5e-6), (mode, float(err))

@@ -213,3 +213,48 @@ def test_full_size_training_step_is_bitwise_reproducible():
     assert torch.equal(runs[0][0], runs[1][0])
     for (n, _), a, b in zip(model.named_parameters(), runs[0][1], runs[1][1]):
         assert torch.equal(a, b), n
+
+
+def test_ctc_direct_reference_vectors_on_hip():
+    """tavsr.ctc.CTC on the GPU against the vectors the reference's own src/ctc/ctc.py produced (no stand-in involved):
+    loss with a zero-infinity utterance and a repeated label, gradients through ctc_lo, argmax ids, frame posteriors."""
+    from oracle.model import fill_parameters_, synth
+    from tavsr.ctc.ctc import CTC
+    g = golden("ctc_direct")
+    B, T, D, V = int(g["B"]), int(g["T"]), int(g["D"]), int(g["V"])
+    ctc = CTC(odim=V, encoder_output_size=D, dropout_rate=0.0)
+    fill_parameters_(ctc, seed=11)
+    ctc = ctc.cuda()
+    hs = synth((B, T, D), seed=12).cuda().requires_grad_(True)
+    loss = ctc(hs, torch.from_numpy(g["hlens"]).cuda(), torch.from_numpy(g["ys"]).cuda(), torch.from_numpy(g["ys_lens"]).cuda())
+    loss.backward()
+    assert rel_err(loss.cpu(), g["loss"]) < 1e-5
+    assert rel_err(hs.grad.cpu(), g["grad_hs"]) < 1e-4
+    assert rel_err(ctc.ctc_lo.weight.grad.cpu(), g["grad_w"]) < 1e-4
+    assert rel_err(ctc.ctc_lo.bias.grad.cpu(), g["grad_b"]) < 1e-4
+    assert float(hs.grad[3].abs().max()) == 0.0          # 2L+1 > T: infinite loss -> zero_infinity
+    assert np.array_equal(ctc.argmax(hs.detach()).cpu().numpy(), g["argmax"])
+    # src/ctc/ctc.py:160-178 on the reference's own logits
+    logits = torch.from_numpy(g["logits"]).double()
+    assert max_rel(ctc.log_softmax(hs.detach()).cpu(), logits.log_softmax(2)) < 1e-5
+    assert max_rel(ctc.softmax(hs.detach()).cpu(), logits.softmax(2)) < 1e-5
+
+
+def test_overpadded_batch_is_cut_like_the_reference():
+    """a batch padded beyond its longest utterance (fixed-size DP batches, external collate): the reference cuts speech
+    and text to lengths.max() before anything else (espnet_model.py:236,438): same loss / encoder output as the tight batch."""
+    from oracle.model import synth
+    from tavsr.tasks.asr import ASRTask
+    g = golden("asr_model_3L")
+    model = _fill(ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=3, dec_blocks=2))), 41).eval()
+    B, Tin = int(g["B"]), int(g["Tin"])
+    speech = synth((B, Tin, 80), seed=42)
+    slens, tlens, text = (torch.from_numpy(g[k]) for k in ("slens", "tlens", "text"))
+    pad_s = torch.cat([speech, torch.full((B, 37, 80), 3.0)], dim=1).cuda()         # junk past every length
+    pad_t = torch.cat([text, torch.full((B, 5), -1, dtype=text.dtype)], dim=1).cuda()
+    with torch.no_grad():
+        loss, stats, _ = model(pad_s, slens.cuda(), pad_t, tlens.cuda())
+        enc, _ = model.encode(pad_s, slens.cuda())
+    assert enc.shape[1] == g["enc"].shape[1]
+    assert max_rel(enc.cpu(), g["enc"]) < ACT_TOL
+    assert rel_err(loss.cpu(), g["loss_eval"]) < 1e-4

@@ -83,6 +83,27 @@ def test_fused_adam_matches_reference_golden():
 
 
 @pytest.mark.gpu
+def test_fused_adam_skips_missing_gradients_like_torch_adam():
+    """a parameter whose grad is None is skipped by torch.optim.Adam (no moment decay, no update, its own step count);
+    the fused optimizer must do the same: parameters 1 and 3 miss steps 2-4, parameter 0 misses step 6."""
+    from tavsr.train import FusedAdam
+    ref = [torch.nn.Parameter(synth(s, seed=121 + i).cuda()) for i, s in enumerate(SHAPES)]
+    got = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    oa = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.98), eps=1e-9)
+    ob = FusedAdam(got, lr=3e-3, betas=(0.9, 0.98), eps=1e-9)
+    for step in range(8):
+        missing = {1, 3} if 2 <= step <= 4 else ({0} if step == 6 else set())
+        for i, (pa, pb) in enumerate(zip(ref, got)):
+            g = None if i in missing else synth(tuple(pa.shape), seed=500 + 10 * step + i).cuda()
+            pa.grad = None if g is None else g.clone()
+            pb.grad = g
+        oa.step()
+        ob.step()
+    for i, (pa, pb) in enumerate(zip(ref, got)):
+        assert rel_err(pb.detach().cpu(), pa.detach().cpu()) < 2e-6, i
+
+
+@pytest.mark.gpu
 def test_training_epoch_on_gpu_model():
     """two optimizer steps of the real ASR model through the harness: loss finite and decreasing on a repeated batch"""
     import argparse
