@@ -162,6 +162,44 @@ int tavsr_softmax_dropout_bwd(const float* attn, const float* dpv, float* ds, fl
                               int32_t T2, int32_t W, int64_t ld_s, int64_t ld_w, float scale, float p, const uint64_t* seed_dev,
                               uint64_t offset, tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused attention core (csrc/attn_fused.hip) - replaces, in ONE launch per direction, the add_head_bias / QK^T /
+ * (q+v)P^T / rel_shift / mask / softmax / dropout / PV chain of espnet RelPositionMultiHeadedAttention.forward
+ * (called at src/encoder/branchformer/encoder_layer.py:196-210, src/encoder/audiovisual/tailored/encoder_layer.py:
+ * 185-196,232-243) and of MultiHeadedAttention.forward_attention (decoder self / source attention): no [H,B,T,T] score
+ * tensor ever exists in HBM.  Head size 64.  q / k / v are row buffers whose row (b*T + t) holds head h at columns
+ * h*64 .. h*64+63 (q, k, v may be three column windows of one [B*T, 3*256] projection output: pass the window base
+ * pointers and the shared row stride).
+ *   scores[i][j] = ((q_i + bias_u) . k_j + (q_i + bias_v) . pos[T1-1-i+j]) * scale     (second term iff pos != NULL)
+ *   attn = softmax over keys j < klens[b] (and j <= i when causal), exactly 0 on masked keys; ctx = dropout(attn) v
+ * Dropout: element (b, h, i, j) uses Philox counter drop_offset/4 + ((b*H + h)*T1 + i) * roundup4(T2)/4 + j/4, word j%4,
+ * of the device seed - the backward regenerates it; a call consumes B*H*T1*roundup4(T2) counter elements.
+ * tavsr_attn_fwd writes ctx [B*T1][ldo] and lse [B*H][T1] (log-sum-exp of the scaled masked scores, +inf for a row
+ * without keys), all the backward needs besides its inputs.
+ * tavsr_attn_bwd: dq = d/d(q+bias_u) rows, dqv = d/d(q+bias_v) rows (rel-pos only; d/dq = dq + dqv, the bias gradients
+ * are their column sums), dk / dv laid out like k / v (every row written), and for rel-pos ds_skew [H][B][T1][ldw]:
+ * ds_skew[i][T1-1-i+j] = dscores[i][j] - the caller passes it ZERO-FILLED, the kernel writes the band; the positional
+ * projection gradient is then one tavsr_gemm per head over K = B*T1 rows.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tavsr_attn_desc {
+  const float *q, *k, *v;
+  int64_t ldq, ldk, ldv;
+  const float* pos;          /* [2*T1-1][ldp] = linear_pos(pos_emb), or NULL */
+  int64_t ldp;
+  const float *bias_u, *bias_v; /* [H*64] or NULL */
+  const int64_t* klens;      /* [B] or NULL */
+  int32_t B, H, T1, T2, dk;
+  float scale;
+  int32_t causal;
+  float p_drop;              /* 0: no dropout */
+  const uint64_t* seed_dev;
+  uint64_t drop_offset;
+} tavsr_attn_desc;
+int tavsr_attn_fwd(const tavsr_attn_desc* d, float* ctx, int64_t ldo, float* lse, tavsr_stream_t stream);
+int tavsr_attn_bwd(const tavsr_attn_desc* d, const float* dctx, const float* ctx, int64_t ldo, const float* lse, float* dq,
+                   float* dqv, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* ds_skew, int64_t ldw,
+                   tavsr_stream_t stream);
+
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);
 int tavsr_axpby2d(const float* x, int64_t ldx, const float* y, int64_t ldy, float a, float b, float* out,

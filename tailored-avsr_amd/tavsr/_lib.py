@@ -45,6 +45,20 @@ class GemmDesc(C.Structure):
     ]
 
 
+class AttnDesc(C.Structure):
+    """tavsr_attn_desc (include/tavsr.h)"""
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+        ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64),
+        ("pos", C.c_void_p), ("ldp", C.c_int64),
+        ("bias_u", C.c_void_p), ("bias_v", C.c_void_p),
+        ("klens", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("T1", C.c_int32), ("T2", C.c_int32), ("dk", C.c_int32),
+        ("scale", C.c_float), ("causal", C.c_int32), ("p_drop", C.c_float),
+        ("seed_dev", C.c_void_p), ("drop_offset", C.c_uint64),
+    ]
+
+
 _lib = None
 
 

@@ -81,6 +81,39 @@ class _FFN:
         return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2)
 
 
+class _AttnFused:
+    """Attention core on the fused kernels (ops.attn_fwd / attn_bwd): scores, rel_shift, mask, softmax, dropout and the
+    context product in one launch; only the per-row log-sum-exp is kept for the backward, which recomputes the
+    probabilities.  q / k / v are 2-D row buffers with element offsets of their column windows (as _SelfAttnCore)."""
+
+    @staticmethod
+    def fwd(q, q_off, kbuf, k_off, vbuf, v_off, B, T1, T2, H, dk, klens, causal, pos=None, bias_u=None, bias_v=None,
+            p_att=0.0):
+        ctx, lse, tok = ops.attn_fwd(q, q_off, kbuf, k_off, vbuf, v_off, B, T1, T2, H, dk, klens=klens, causal=causal,
+                                     pos=pos, bias_u=bias_u, bias_v=bias_v, p_drop=p_att)
+        return ctx, (lse, tok)
+
+    @staticmethod
+    def bwd(dctx, ctx, saved, q, q_off, kbuf, k_off, vbuf, v_off, dq, dq_off, dk_buf, dk_off, dv_buf, dv_off, B, T1, T2, H,
+            dk, klens, causal, pos=None, bias_u=None, bias_v=None):
+        """writes d/d(q+u) into dq, dK, dV into their windows; rel-pos: returns (dqv, dp) with dp the gradient of the
+        projected positional rows [2*T1-1, H*dk]."""
+        lse, tok = saved
+        dqv, sk = ops.attn_bwd(dctx, ctx, lse, tok, q, q_off, kbuf, k_off, vbuf, v_off, B, T1, T2, H, dk, dq, dq_off,
+                               dk_buf, dk_off, dv_buf, dv_off, klens=klens, causal=causal, pos=pos, bias_u=bias_u,
+                               bias_v=bias_v)
+        if pos is None:
+            return None, None
+        D = H * dk
+        W, Wp = 2 * T1 - 1, sk.shape[-1]
+        # dP[:,h] = sum_b ds_skew[h,b]^T (q + v)[b,:,h]  == one K = B*T1 GEMM per head
+        _, qv = ops.add_head_bias(q[:, q_off: q_off + D], bias_u, bias_v)
+        dp = ops.empty(W, D, like=dctx)
+        ops.gemm(W, dk, B * T1, sk, Wp, qv, D, dp, D, a_kmajor=True, b_kmajor=True, nb1=H, sA=(B * T1 * Wp, 0),
+                 sB=(dk, 0), sC=(dk, 0))
+        return dqv, dp
+
+
 class _SelfAttnCore:
     """Scores/softmax/context of one attention call on head-strided buffers.
 
@@ -217,9 +250,15 @@ class BranchformerLayerFn(torch.autograd.Function):
                                      for j, c in enumerate("qkv")], qkv)
                 pe2d = pos_emb.reshape(-1, D)
                 pp = ops.linear(pe2d, p("attn.linear_pos.weight"))
-                qu, qv = ops.add_head_bias(qkv[:, :D], p("attn.pos_bias_u").reshape(-1), p("attn.pos_bias_v").reshape(-1))
-                cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
-                                                    qv=qv, p=pp, p_att=pa)
+                if ops.ATTN_FUSED and dk == 64:
+                    qu = qv = t_att = None
+                    cx, attn = _AttnFused.fwd(qkv, 0, qkv, D, qkv, 2 * D, B, T, T, H, dk, lens, False, pos=pp,
+                                              bias_u=p("attn.pos_bias_u").reshape(-1), bias_v=p("attn.pos_bias_v").reshape(-1),
+                                              p_att=pa)
+                else:
+                    qu, qv = ops.add_head_bias(qkv[:, :D], p("attn.pos_bias_u").reshape(-1), p("attn.pos_bias_v").reshape(-1))
+                    cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
+                                                        qv=qv, p=pp, p_att=pa)
                 t_xa = None
                 if merge == "concat":
                     ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), out=cat, out_off=0, ldc=2 * D)
@@ -365,8 +404,13 @@ class BranchformerLayerFn(torch.autograd.Function):
                 dcx = ops.linear_dx(dxa, p("attn.linear_out.weight"))
                 dqkv = torch.empty_like(qkv)
                 dqu = ops.empty(M, D, like=dy2)
-                dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
-                                            dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
+                if qu is None:       # fused attention core
+                    dqv, dp = _AttnFused.bwd(dcx, cx, attn, qkv, 0, qkv, D, qkv, 2 * D, dqu, 0, dqkv, D, dqkv, 2 * D, B, T, T,
+                                             H, dk, ctx.lens, False, pos=pp, bias_u=p("attn.pos_bias_u").reshape(-1),
+                                             bias_v=p("attn.pos_bias_v").reshape(-1))
+                else:
+                    dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
+                                                dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
                 gu_, gv_ = ops.add2_colsum(dqu, dqv, dqkv[:, :D])      # dQ = dQu + dQv and both bias gradients, one pass
                 put("attn.pos_bias_u", gu_, like=p("attn.pos_bias_u"))
                 put("attn.pos_bias_v", gv_, like=p("attn.pos_bias_v"))
@@ -636,8 +680,13 @@ class TransformerDecoderFn(torch.autograd.Function):
             qkv = ops.empty(M, 3 * D, like=x)
             ops.linear_group(n1, [(p(f"self_attn.linear_{c}.weight"), p(f"self_attn.linear_{c}.bias"), j * D)
                                   for j, c in enumerate("qkv")], qkv)
-            cx, attn, tk_a = _SelfAttnCore.fwd(qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, L, L, H, dk, ys_lens, True,
-                                               p_att=pself)
+            fused = ops.ATTN_FUSED and dk == 64
+            if fused:
+                tk_a = "fused"
+                cx, attn = _AttnFused.fwd(qkv, 0, qkv, D, qkv, 2 * D, B, L, L, H, dk, ys_lens, True, p_att=pself)
+            else:
+                cx, attn, tk_a = _SelfAttnCore.fwd(qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, L, L, H, dk, ys_lens, True,
+                                                   p_att=pself)
             tk_r = None
             if pd > 0.0:                                     # x + dropout(self_attn(...))
                 t = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"))
@@ -651,8 +700,12 @@ class TransformerDecoderFn(torch.autograd.Function):
             kv = ops.empty(B * T, 2 * D, like=x)
             ops.linear_group(mem2, [(p(f"src_attn.linear_{c}.weight"), p(f"src_attn.linear_{c}.bias"), j * D)
                                     for j, c in enumerate("kv")], kv)
-            cx2, attn2, tk_a2 = _SelfAttnCore.fwd(q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, B, L, T, H, dk, hlens, False,
-                                                  p_att=psrc)
+            if fused:
+                tk_a2 = "fused"
+                cx2, attn2 = _AttnFused.fwd(q2, 0, kv, 0, kv, D, B, L, T, H, dk, hlens, False, p_att=psrc)
+            else:
+                cx2, attn2, tk_a2 = _SelfAttnCore.fwd(q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, B, L, T, H, dk, hlens, False,
+                                                      p_att=psrc)
             tk_r2 = None
             if pd > 0.0:                                     # x + dropout(src_attn(...))
                 t = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"))
@@ -670,7 +723,7 @@ class TransformerDecoderFn(torch.autograd.Function):
         logits = ops.linear(xn, out_w, out_b)
         ctx.saved, ctx.final, ctx.t_pos = saved, (x, mf, rf, xn), t_pos
         ctx.P, ctx.cfg, ctx.dims = P, cfg, (B, T, L, D, H, dk, nb)
-        ctx.mem2, ctx.ys_in = mem2, ys_in
+        ctx.mem2, ctx.ys_in, ctx.hlens, ctx.ys_lens = mem2, ys_in, hlens, ys_lens
         return logits.view(B, L, -1)
 
     @staticmethod
@@ -711,8 +764,11 @@ class TransformerDecoderFn(torch.autograd.Function):
             dcx2 = ops.linear_dx(dt2, p("src_attn.linear_out.weight"))
             dq2 = ops.empty(M, D, like=dl)
             dkv = torch.empty_like(kv)
-            _SelfAttnCore.bwd(dcx2, attn2, q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, dq2, D, 0, dkv, 2 * D, 0, dkv, 2 * D, D,
-                              B, L, T, H, dk, tok=tk_a2)
+            if tk_a2 == "fused":
+                _AttnFused.bwd(dcx2, cx2, attn2, q2, 0, kv, 0, kv, D, dq2, 0, dkv, 0, dkv, D, B, L, T, H, dk, ctx.hlens, False)
+            else:
+                _SelfAttnCore.bwd(dcx2, attn2, q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, dq2, D, 0, dkv, 2 * D, 0, dkv, 2 * D, D,
+                                  B, L, T, H, dk, tok=tk_a2)
             gw_, gb_ = grp.add(dq2, n2, bias_grad=True)
             put("src_attn.linear_q.weight", gw_); put("src_attn.linear_q.bias", gb_)
             for j, nm in enumerate(("k", "v")):
@@ -733,8 +789,12 @@ class TransformerDecoderFn(torch.autograd.Function):
             put("self_attn.linear_out.weight", gw_); put("self_attn.linear_out.bias", gb_)
             dcx = ops.linear_dx(dt1, p("self_attn.linear_out.weight"))
             dqkv = torch.empty_like(qkv)
-            _SelfAttnCore.bwd(dcx, attn, qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqkv, 3 * D, 0, dqkv, 3 * D, D,
-                              dqkv, 3 * D, 2 * D, B, L, L, H, dk, tok=tk_a)
+            if tk_a == "fused":
+                _AttnFused.bwd(dcx, cx, attn, qkv, 0, qkv, D, qkv, 2 * D, dqkv, 0, dqkv, D, dqkv, 2 * D, B, L, L, H, dk,
+                               ctx.ys_lens, True)
+            else:
+                _SelfAttnCore.bwd(dcx, attn, qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqkv, 3 * D, 0, dqkv, 3 * D, D,
+                                  dqkv, 3 * D, 2 * D, B, L, L, H, dk, tok=tk_a)
             for j, nm in enumerate(("q", "k", "v")):
                 gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n1, bias_grad=True)
                 put(f"self_attn.linear_{nm}.weight", gw_); put(f"self_attn.linear_{nm}.bias", gb_)

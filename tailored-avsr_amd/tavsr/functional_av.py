@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .functional import EPS_ESPNET, _FFN, _SelfAttnCore, _drop_, _drop_bwd, _drop_bwd_
+from .functional import EPS_ESPNET, _FFN, _AttnFused, _SelfAttnCore, _drop_, _drop_bwd, _drop_bwd_
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch.nn.BatchNorm defaults (conv3d_resnet18.py:57, resnet.py:39,68,84)
 
@@ -308,9 +308,15 @@ class TailoredStreamFn(torch.autograd.Function):
             ops.linear_group(n, [(p[f"attn.linear_{c}.weight"], p[f"attn.linear_{c}.bias"], j * D) for j, c in enumerate("qkv")],
                              qkv)
             pp = ops.linear(pos_emb.reshape(-1, D), p["attn.linear_pos.weight"])
-            qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
-            cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
-                                                qv=qv, p=pp, p_att=pa)
+            if ops.ATTN_FUSED and dk == 64:
+                qu = qv = t_att = None
+                cx, attn = _AttnFused.fwd(qkv, 0, qkv, D, qkv, 2 * D, B, T, T, H, dk, lens, False, pos=pp,
+                                          bias_u=p["attn.pos_bias_u"].reshape(-1), bias_v=p["attn.pos_bias_v"].reshape(-1),
+                                          p_att=pa)
+            else:
+                qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
+                cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
+                                                    qv=qv, p=pp, p_att=pa)
             t_br = None
             if pd > 0.0:                       # residual + coeff * dropout(att)  (encoder_layer.py:196,243)
                 t = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"])
@@ -338,7 +344,7 @@ class TailoredStreamFn(torch.autograd.Function):
         y, fmean, frstd = ops.layernorm_fwd(x3, p["norm_final.weight"], p["norm_final.bias"], EPS_ESPNET)
         sv["final"] = (x3, fmean, frstd)
         sv["x1"] = x1
-        ctx.sv, ctx.cfg, ctx.p, ctx.names, ctx.pos_emb, ctx.shape = sv, cfg, p, names, pos_emb, (B, T, D)
+        ctx.sv, ctx.cfg, ctx.p, ctx.names, ctx.pos_emb, ctx.shape, ctx.lens = sv, cfg, p, names, pos_emb, (B, T, D), lens
         return y.view(B, T, D)
 
     @staticmethod
@@ -368,8 +374,13 @@ class TailoredStreamFn(torch.autograd.Function):
             dcx = ops.linear_dx(dbr, p["attn.linear_out.weight"], alpha=coeff)
             dqkv = torch.empty_like(qkv)
             dqu = ops.empty(M, D, like=dx2)
-            dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
-                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
+            if qu is None:           # fused attention core
+                dqv, dp = _AttnFused.bwd(dcx, cx, attn, qkv, 0, qkv, D, qkv, 2 * D, dqu, 0, dqkv, D, dqkv, 2 * D, B, T, T, H, dk,
+                                         ctx.lens, False, pos=pp, bias_u=p["attn.pos_bias_u"].reshape(-1),
+                                         bias_v=p["attn.pos_bias_v"].reshape(-1))
+            else:
+                dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
+                                            dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
             gu_, gv_ = ops.add2_colsum(dqu, dqv, dqkv[:, :D])
             G["attn.pos_bias_u"], G["attn.pos_bias_v"] = gu_.view_as(p["attn.pos_bias_u"]), gv_.view_as(p["attn.pos_bias_v"])
             G["attn.linear_pos.weight"] = ops.linear_dw(dp, ctx.pos_emb.reshape(-1, D))

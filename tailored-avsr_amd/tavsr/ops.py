@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from ._lib import ACT, GemmDesc, check, lib, ptr, require_cuda, stream
+from ._lib import ACT, AttnDesc, GemmDesc, check, lib, ptr, require_cuda, stream
 
 f32 = torch.float32
 
@@ -524,6 +524,62 @@ def softmax_bwd(attn, dattn, scale, skew=False, T2=None, token=None):
     check(lib().tavsr_softmax_bwd(ptr(attn), ptr(dattn), ptr(ds), ptr(sk), H, B, T1, T2, W, C.c_int64(ld_s),
                                   C.c_int64(ld_w), C.c_float(scale), stream()), "tavsr_softmax_bwd")
     return ds, sk
+
+
+# Fused attention core (csrc/attn_fused.hip): scores, rel_shift, mask, softmax, dropout and the context product in one
+# launch per direction.  TAVSR_ATTN_FUSED=0 keeps the GEMM + softmax chain (A/B switch; also the path for head sizes != 64).
+ATTN_FUSED = os.environ.get("TAVSR_ATTN_FUSED", "1") == "1"
+
+
+def _attn_desc(q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk, klens, causal, pos, bias_u, bias_v, token):
+    require_cuda(q, k, v, klens, pos, bias_u, bias_v)
+    d = AttnDesc()
+    d.q, d.k, d.v = _addr(q, q_off), _addr(k, k_off), _addr(v, v_off)
+    d.ldq, d.ldk, d.ldv = q.stride(0), k.stride(0), v.stride(0)
+    if pos is not None:
+        d.pos, d.ldp = pos.data_ptr(), pos.stride(0)
+    d.bias_u = None if bias_u is None else bias_u.data_ptr()
+    d.bias_v = None if bias_v is None else bias_v.data_ptr()
+    d.klens = None if klens is None else klens.data_ptr()
+    d.B, d.H, d.T1, d.T2, d.dk = B, H, T1, T2, dk
+    d.scale, d.causal = 1.0 / (dk ** 0.5), int(bool(causal))
+    if token is not None:
+        d.p_drop, d.drop_offset, d.seed_dev = token[0], token[1], token[2].data_ptr()
+    return d
+
+
+def attn_fwd(q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk, klens=None, causal=False, pos=None, bias_u=None, bias_v=None,
+             p_drop=0.0):
+    """q / k / v: 2-D row buffers (row b*T + t; head h at columns off + h*dk ..); pos [2*T1-1, H*dk] projected positions
+    (rel-pos form) with the flat pos_bias_u / pos_bias_v.  -> (ctx [B*T1, H*dk], lse [B*H, T1], dropout token or None)."""
+    tok = _new_token(p_drop, B * H * T1 * pad4(T2), q.device) if p_drop and p_drop > 0.0 else None
+    d = _attn_desc(q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk, klens, causal, pos, bias_u, bias_v, tok)
+    ctx = empty(B * T1, H * dk, like=q)
+    lse = empty(B * H, T1, like=q)
+    check(lib().tavsr_attn_fwd(C.byref(d), ptr(ctx), C.c_int64(ctx.stride(0)), ptr(lse), stream()), "tavsr_attn_fwd")
+    return ctx, lse, tok
+
+
+def attn_bwd(dctx, ctx, lse, tok, q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk, dq, dq_off, dk_buf, dk_off, dv_buf, dv_off,
+             klens=None, causal=False, pos=None, bias_u=None, bias_v=None):
+    """writes d/d(q + u) rows into dq, dK / dV into dk_buf / dv_buf (head-strided windows at the given offsets); rel-pos:
+    returns (dqv [B*T1, H*dk], ds_skew [H, B, T1, pad4(2*T1-1)]) else (None, None)."""
+    d = _attn_desc(q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk, klens, causal, pos, bias_u, bias_v, tok)
+    require_cuda(dctx, ctx, lse, dq, dk_buf, dv_buf)
+    assert dctx.stride(0) == ctx.stride(0)
+    dqv = sk = None
+    ldw = 0
+    if pos is not None:
+        dqv = empty(B * T1, H * dk, like=q)
+        ldw = pad4(2 * T1 - 1)
+        sk = torch.zeros(H, B, T1, ldw, dtype=f32, device=q.device)      # the kernel writes the band of every row
+        assert dqv.stride(0) == dq.stride(0)
+    check(lib().tavsr_attn_bwd(C.byref(d), ptr(dctx), ptr(ctx), C.c_int64(ctx.stride(0)), ptr(lse),
+                               C.c_void_p(_addr(dq, dq_off)), ptr(dqv), C.c_int64(dq.stride(0)),
+                               C.c_void_p(_addr(dk_buf, dk_off)), C.c_int64(dk_buf.stride(0)),
+                               C.c_void_p(_addr(dv_buf, dv_off)), C.c_int64(dv_buf.stride(0)), ptr(sk), C.c_int64(ldw),
+                               stream()), "tavsr_attn_bwd")
+    return dqv, sk
 
 
 def axpby(x, y=None, a=1.0, b=1.0, out=None):
