@@ -200,6 +200,32 @@ int tavsr_attn_bwd(const tavsr_attn_desc* d, const float* dctx, const float* ctx
                    float* dqv, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* ds_skew, int64_t ldw,
                    tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused position-wise feed-forward block (csrc/ffn.hip) - espnet PositionwiseFeedForward inside its residual block
+ * (src/encoder/branchformer/encoder_layer.py:191-194,311-314; tailored AV layer; decoder FFN), d_model D in {256, 512},
+ * hidden N1 % 128 == 0, weights in torch Linear layout (w1 [N1][D], w2 [D][N1]):
+ *   tavsr_ffn_fwd   : y = x + scale * dropout(w2 dropout(act(w1 LN(x) + b1)) + b2)  - LayerNorm prologue, both GEMMs in
+ *                     one launch (the hidden activations go from the first product's accumulators through LDS into the
+ *                     second product), then a finishing launch (fixed-order sum of the hidden-split partials, bias,
+ *                     dropout, residual).  n_out / mean / rstd / z / h (all optional, NULL in eval): what the backward
+ *                     needs - LN(x) [M][D], its statistics [M], pre-activations and dropped activations [M][N1].
+ *   tavsr_ffn_bwd_dx: dz = ((alpha * dy) w2) * mask / keep * act'(z)  [M][N1] (operand of the w1 weight gradient) and
+ *                     dn = dz w1 [M][D] (the gradient w.r.t. LN(x)), same structure; takes the weights TRANSPOSED
+ *                     (w1t = w1^T [D][N1], w2t = w2^T [N1][D]) so that both products read k-contiguous rows.
+ * z, h and dz are buffers of roundup32(M) rows (whole 32-row tiles are stored; rows >= M are scratch).
+ * Inner dropout (between the GEMMs): element (m, c) keeps iff word (m & 3) of Philox counter offset_in/4 + (m >> 2)*N1 + c
+ * is >= p * 2^32 (the layout the accumulators have); a call consumes roundup4(M) * N1 counter elements.  Outer dropout
+ * (on the block output): the tavsr_dropout mapping at offset_out.  ws: tavsr_ffn_ws(M, D, N1) floats.
+ * ------------------------------------------------------------------------------------------- */
+int64_t tavsr_ffn_ws(int32_t M, int32_t D, int32_t N1);
+int tavsr_ffn_fwd(const float* x, int64_t ldx, const float* ln_w, const float* ln_b, float eps, const float* w1, const float* b1,
+                  const float* w2, const float* b2, int32_t act, float scale, int32_t M, int32_t D, int32_t N1, float p_drop,
+                  const uint64_t* seed_dev, uint64_t offset_in, uint64_t offset_out, float* n_out, float* mean, float* rstd,
+                  float* z, float* h, float* y, float* ws, tavsr_stream_t stream);
+int tavsr_ffn_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w1t, const float* w2t, const float* z, int32_t act,
+                     int32_t M, int32_t D, int32_t N1, float p_drop, const uint64_t* seed_dev, uint64_t offset_in, float* dz,
+                     float* dn, float* ws, tavsr_stream_t stream);
+
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);
 int tavsr_axpby2d(const float* x, int64_t ldx, const float* y, int64_t ldy, float a, float b, float* out,

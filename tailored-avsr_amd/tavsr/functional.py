@@ -49,7 +49,10 @@ class _FFN:
     the inner dropout is PositionwiseFeedForward's, the outer one the layer's: both rate ``p`` in the reference)."""
 
     @staticmethod
-    def fwd(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, eps=EPS_ESPNET, p=0.0):
+    def fwd(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, eps=EPS_ESPNET, p=0.0, save=True):
+        if ops.ffn_fusable(x, w1, act):      # LayerNorm + both GEMMs in one launch (csrc/ffn.hip) + one finishing launch
+            y, (n, mean, rstd, z, h, t_in, t_out) = ops.ffn_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=p, save=save)
+            return y, ("fused", x, mean, rstd, n, z, h, t_in, t_out)
         n, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, eps)
         h, z = ops.linear(n, w1, b1, act=act, save_z=True)
         t_in = _drop_(h, p)
@@ -65,17 +68,24 @@ class _FFN:
     def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None, lng=None):
         """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2).  ``grp`` (ops.WgradGroup)
         defers the two weight gradients to the caller's grouped launch."""
+        fused = saved[0] == "fused" if isinstance(saved[0], str) else False
+        if fused:
+            saved = saved[1:]
         x, mean, rstd, n, z, h, t_in, t_out = saved
         wgrad = ops.linear_dw if grp is None else grp.add
         dyd = _drop_bwd(dy, t_out)
         gw2, gb2 = wgrad(dyd, h, alpha=scale, bias_grad=True)
-        if t_in is None:
-            dz = ops.linear_dx(dyd, w2, alpha=scale, DZ=z, dact=act)
+        if fused:
+            dz, dn = ops.ffn_bwd_dx(dyd, scale, w1, w2, z, act, t_in)
         else:
-            dh = ops.linear_dx(dyd, w2, alpha=scale)
-            dz = ops.dropout_act_bwd(dh, z, act, t_in, out=dh)     # inner mask and act'(z), one pass
+            if t_in is None:
+                dz = ops.linear_dx(dyd, w2, alpha=scale, DZ=z, dact=act)
+            else:
+                dh = ops.linear_dx(dyd, w2, alpha=scale)
+                dz = ops.dropout_act_bwd(dh, z, act, t_in, out=dh)     # inner mask and act'(z), one pass
         gw1, gb1 = wgrad(dz, n, bias_grad=True)
-        dn = ops.linear_dx(dz, w1)
+        if not fused:
+            dn = ops.linear_dx(dz, w1)
         ln_bwd = ops.layernorm_bwd if lng is None else lng.bwd      # lng: the node's shared (dgamma, dbeta) reduction
         dx, gln_w, gln_b = ln_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
         return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2)

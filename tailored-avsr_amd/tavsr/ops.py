@@ -582,6 +582,61 @@ def attn_bwd(dctx, ctx, lse, tok, q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk
     return dqv, sk
 
 
+# Fused feed-forward block (csrc/ffn.hip): LayerNorm + both GEMMs of a direction in one launch.  Correct and tested
+# (tests/test_gpu_ffn.py) but OFF by default: at M = 3168 it measures 101 us forward / 122 us backward per block against
+# ~105 / ~112 us for the LayerNorm + GEMM + GEMM + dropout launches it replaces, and the audio-only step 1430 vs 1507 utt/s
+# (in-call A/B, profiles/r02_ffn_fusion_notes.md) - fp32 MFMA bound either way, and 99 row tiles x 4 hidden splits fill
+# the 512 workgroup slots to 77 % only.  TAVSR_FFN_FUSED=1 selects it.
+FFN_FUSED = os.environ.get("TAVSR_FFN_FUSED", "0") == "1"
+
+
+def ffn_fusable(x, w1, act) -> bool:
+    return (FFN_FUSED and x.shape[1] in (256, 512) and w1.shape[0] % 128 == 0 and x.is_contiguous()
+            and act in ("relu", "swish"))
+
+
+def ffn_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=0.0, save=True):
+    """y = x + scale * dropout(w2 dropout(act(w1 LN(x) + b1)) + b2) -> (y, saved) with saved = (n, mean, rstd, z, h, tok_in,
+    tok_out) (tensors None when ``save`` is false)."""
+    M, D = x.shape
+    N1 = w1.shape[0]
+    require_cuda(x, ln_w, ln_b, w1, b1, w2, b2)
+    assert w1.is_contiguous() and w2.is_contiguous() and w1.shape == (N1, D) and w2.shape == (D, N1)
+    y = empty(M, D, like=x)
+    n = mean = rstd = z = h = None
+    if save:
+        n, mean, rstd = empty(M, D, like=x), empty(M, like=x), empty(M, like=x)
+        Mp = (M + 31) // 32 * 32          # whole 32-row tiles are stored
+        z, h = empty(Mp, N1, like=x)[:M], empty(Mp, N1, like=x)[:M]
+    tok_in = tok_out = None
+    if p and p > 0.0:
+        tok_in = _new_token(p, (M + 3) // 4 * 4 * N1, x.device)
+        tok_out = _new_token(p, M * D, x.device)
+    ws = empty(lib_i64("tavsr_ffn_ws", M, D, N1), like=x)
+    check(lib().tavsr_ffn_fwd(ptr(x), C.c_int64(x.stride(0)), ptr(ln_w), ptr(ln_b), C.c_float(eps), ptr(w1), ptr(b1), ptr(w2),
+                              ptr(b2), ACT[act], C.c_float(scale), M, D, N1, C.c_float(p or 0.0),
+                              ptr(tok_in[2] if tok_in else None), C.c_uint64(tok_in[1] if tok_in else 0),
+                              C.c_uint64(tok_out[1] if tok_out else 0), ptr(n), ptr(mean), ptr(rstd), ptr(z), ptr(h), ptr(y),
+                              ptr(ws), stream()), "tavsr_ffn_fwd")
+    return y, (n, mean, rstd, z, h, tok_in, tok_out)
+
+
+def ffn_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
+    """(dz [M, N1], dn [M, D]) of the fused block: dz = ((alpha * dyd) w2) * mask / keep * act'(z), dn = dz w1."""
+    M, D = dyd.shape
+    N1 = w1.shape[0]
+    require_cuda(dyd, w1, w2, z)
+    dz, dn = empty((M + 31) // 32 * 32, N1, like=dyd)[:M], empty(M, D, like=dyd)
+    ws = empty(lib_i64("tavsr_ffn_ws", M, D, N1), like=dyd)
+    w1t = transpose_inner(w1, 1, N1, D)          # [D, N1]: both products of the chain read k-contiguous weight rows
+    w2t = transpose_inner(w2, 1, D, N1)          # [N1, D]
+    check(lib().tavsr_ffn_bwd_dx(ptr(dyd), C.c_int64(dyd.stride(0)), C.c_float(alpha), ptr(w1t), ptr(w2t), ptr(z), ACT[act], M, D,
+                                 N1, C.c_float(tok_in[0] if tok_in else 0.0), ptr(tok_in[2] if tok_in else None),
+                                 C.c_uint64(tok_in[1] if tok_in else 0), ptr(dz), ptr(dn), ptr(ws), stream()),
+          "tavsr_ffn_bwd_dx")
+    return dz, dn
+
+
 def axpby(x, y=None, a=1.0, b=1.0, out=None):
     if out is None:
         out = torch.empty_like(x)
