@@ -475,6 +475,25 @@ int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int tavsr_bucket_copy(float* const* ptrs_dev, const int64_t* off_dev, const int64_t* n_dev, int32_t ntensors, float* flat,
                       float scale, int32_t to_flat, int64_t max_n, tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (csrc/dp.cpp): one process per GPU, RCCL over xGMI, the ONLY collective on
+ * the path (the reference is single-process: avsr_main.py:27-58 steps one device).  RCCL is resolved at run time
+ * (dlopen; a copy the process already holds - torch's - is shared), so the library loads on hosts without it.
+ *   tavsr_dp_unique_id : rank 0 obtains the 128-byte communicator id; the caller ships it to every rank.
+ *   tavsr_dp_init      : collective; every rank calls it on its own device with the same id.
+ *   tavsr_dp_allreduce : in-place fp32 sum over all ranks of flat[0..n), enqueued on `stream` (no host sync): the flat
+ *                        gradient buckets packed by tavsr_bucket_copy; 1/world rides on the unpack.
+ *   tavsr_dp_broadcast : flat[0..n) of `root` to every rank (identical initial parameters).
+ *   tavsr_dp_world     : ranks of the live communicator (0: none).   tavsr_dp_destroy: frees it.
+ * Errors: 1000 + ncclResult_t for RCCL failures.
+ * ------------------------------------------------------------------------------------------- */
+int tavsr_dp_unique_id(void* id128);
+int tavsr_dp_init(int32_t rank, int32_t nranks, const void* id128);
+int32_t tavsr_dp_world(void);
+int tavsr_dp_allreduce(float* flat, int64_t n, tavsr_stream_t stream);
+int tavsr_dp_broadcast(float* flat, int64_t n, int32_t root, tavsr_stream_t stream);
+int tavsr_dp_destroy(void);
+
 /* dst[t][i] += src[t][i], t < ntensors: the gradients of parameters shared by the two modality streams of a tailored AV
  * layer (src/encoder/audiovisual/tailored/encoder_layer.py:118-274 applies the same FFN / norm modules to both streams;
  * autograd sums their gradients).  dst / src / n are HOST arrays (the pointers ride in the kernel arguments). */

@@ -61,7 +61,6 @@ __device__ __forceinline__ int swz(int c, int r) { return (c & ~15) | ((c ^ r) &
 template <int D, bool BWD, bool SAVE, bool DROP, int ACT>
 __global__ __launch_bounds__(256, D == 256 ? FFN_WPS : 1) void ffn_chain_kernel(const FfnArgs a) {
   constexpr int NT2 = D / 128;                     // 32-column tiles of the second product per wave
-  constexpr int KQ = D / 64;                       // 64-wide k quarters of the first product
   constexpr int HB = (D == 256 && FFN_WPS == 3) ? 1 : 2;      // LDS: 32*D*4 + HB*16 KB per workgroup (48 KB: three per CU)
   __shared__ __attribute__((aligned(16))) float As[32 * D];
   __shared__ __attribute__((aligned(16))) float Hsm[HB][32 * 128];

@@ -1,16 +1,38 @@
-"""Utterance-level data parallelism: one process per GPU, gradients summed once per step with RCCL
-(``torch.distributed`` backend "nccl" on ROCm) over xGMI.  The reference is single-process
-(SURVEY 2.1); this is the only collective on the path - no data-path exchange.
+"""Utterance-level data parallelism: one process per GPU, gradients summed once per step with RCCL over xGMI.
+The reference is single-process; this is the only collective on the path - no data-path exchange.
 
-Gradients are packed into a few large flat fp32 buckets (xGMI is point-to-point: few large messages beat
-many small ones), all-reduced asynchronously in reverse-parameter order and unpacked.  The 1/world
-average is folded into the unpack.  Works unchanged on CPU tensors with the gloo backend (tests)."""
+Gradients are packed into a few large flat fp32 buckets (xGMI is point-to-point: few large messages beat many small
+ones) in reverse-parameter order, all-reduced and unpacked; the 1/world average is folded into the unpack.  On GPUs the
+all-reduce is the C ABI's own RCCL call (``tavsr_dp_allreduce``, csrc/dp.cpp) on a communication stream;
+``torch.distributed`` provides the rendezvous (the 128-byte communicator id travels through it) and the barriers.  With
+``overlap`` (eager training loops) a bucket's all-reduce is enqueued from a gradient hook the moment its last gradient
+has been produced, so the exchange runs under the rest of the backward pass.  CPU tensors (gloo tests) and several ranks
+on ONE GPU (``TAVSR_DP_BACKEND=gloo`` test rigs; RCCL needs a device per rank) go through ``torch.distributed``."""
 from __future__ import annotations
 
+import ctypes as C
+import os
+import warnings
 from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
+
+RCCL_ABI = False          # set by init_from_env once tavsr_dp_init has succeeded on this rank
+
+
+def _rccl_init(rank: int, world: int, device: torch.device) -> bool:
+    """communicator of the C ABI: rank 0 draws the id, torch.distributed ships it, every rank joins."""
+    from ._lib import check, lib
+    ident = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        buf = (C.c_char * 128)()
+        check(lib().tavsr_dp_unique_id(buf), "tavsr_dp_unique_id")
+        ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+    dist.broadcast(ident, 0)
+    raw = bytes(ident.cpu().tolist())
+    check(lib().tavsr_dp_init(rank, world, C.c_char_p(raw)), "tavsr_dp_init")
+    return True
 
 
 def init_from_env(backend: str | None = None, seed: int | None = 0) -> tuple[int, int, int]:
@@ -20,8 +42,7 @@ def init_from_env(backend: str | None = None, seed: int | None = 0) -> tuple[int
     generator of the dropout masks (``ops.manual_seed``) and torch's host generator (SpecAug draws, stochastic depth) -
     so that data-parallel ranks do not draw identical masks.  Parameters are made equal separately
     (``GradBuckets.broadcast_parameters``)."""
-    import os
-
+    global RCCL_ABI
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -35,12 +56,32 @@ def init_from_env(backend: str | None = None, seed: int | None = 0) -> tuple[int
         elif torch.cuda.is_available():
             local = local % torch.cuda.device_count()
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl" and os.environ.get("TAVSR_DP_RCCL", "1") == "1":
+            try:
+                RCCL_ABI = _rccl_init(rank, world, torch.device("cuda", local))
+            except Exception as e:          # both are GPU paths; say which one runs
+                warnings.warn(f"tavsr_dp_init failed ({e}); gradients go through torch.distributed's RCCL instead")
+                RCCL_ABI = False
+            flag = torch.tensor([int(RCCL_ABI)], device=f"cuda:{local}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # all ranks or none
+            RCCL_ABI = bool(int(flag))
     if seed is not None:
         torch.manual_seed(int(seed) + rank)
         if torch.cuda.is_available():
             from . import ops
             ops.manual_seed(0x5EED5EED + int(seed) + rank, torch.device("cuda", local))
     return rank, local, world
+
+
+def shutdown():
+    """frees the C ABI's communicator and the process group."""
+    global RCCL_ABI
+    if RCCL_ABI:
+        from ._lib import check, lib
+        check(lib().tavsr_dp_destroy(), "tavsr_dp_destroy")
+        RCCL_ABI = False
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 class GradBuckets:
@@ -60,13 +101,22 @@ class GradBuckets:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
         self._tab, self._flatbuf = {}, {}
+        self._comm = None
+        self._works = [None] * len(self.buckets)
+        self._pending = [len(b) for b in self.buckets]
+        self._hooked, self.overlap = False, True
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return
         for bucket in self.buckets:
             flat = torch.cat([p.data.reshape(-1) for p in bucket])
-            dist.broadcast(flat, src)
+            if RCCL_ABI and flat.is_cuda:
+                from ._lib import check, lib
+                check(lib().tavsr_dp_broadcast(C.c_void_p(flat.data_ptr()), C.c_int64(flat.numel()), src,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tavsr_dp_broadcast")
+            else:
+                dist.broadcast(flat, src)
             off = 0
             for p in bucket:
                 p.data.copy_(flat[off: off + p.numel()].view_as(p))
@@ -122,14 +172,61 @@ class GradBuckets:
         self._tab[i] = (ptrs,) + t + (flat, max(sizes))
         return t + (flat, max(sizes))
 
+    # ---- GPU path: pack (one launch per bucket) -> all-reduce on the communication stream -> unpack * 1/world
+    def _comm_stream(self):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        return self._comm
+
+    def _launch_bucket(self, i):
+        """pack bucket i on the current stream and enqueue its all-reduce behind the pack on the communication stream."""
+        from . import ops
+        from ._lib import check, lib
+        bucket = self.buckets[i]
+        ptrs, offs, sizes, flat, mx = self._tables(i, bucket)
+        ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0, True, mx)
+        if RCCL_ABI:
+            comm = self._comm_stream()
+            comm.wait_stream(torch.cuda.current_stream())
+            check(lib().tavsr_dp_allreduce(C.c_void_p(flat.data_ptr()), C.c_int64(flat.numel()), C.c_void_p(comm.cuda_stream)),
+                  "tavsr_dp_allreduce")
+            self._works[i] = "rccl"
+        else:
+            self._works[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
     def _allreduce_mean_hip(self, world):
         from . import ops
-        works = []
+        for i in range(len(self.buckets)):
+            if self._works[i] is None:          # not already enqueued by the gradient hooks
+                self._launch_bucket(i)
+        if RCCL_ABI:
+            torch.cuda.current_stream().wait_stream(self._comm_stream())
         for i, bucket in enumerate(self.buckets):
-            ptrs, offs, sizes, flat, mx = self._tables(i, bucket)
-            ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0, True, mx)
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for i, bucket in enumerate(self.buckets):
-            works[i].wait()
+            if self._works[i] != "rccl":
+                self._works[i].wait()
             ptrs, offs, sizes, flat, mx = self._tables(i, bucket)
             ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0 / world, False, mx)
+            self._works[i] = None
+        self._pending = [len(b) for b in self.buckets]
+
+    # ---- overlap with the backward pass (eager loops): a bucket leaves as soon as its last gradient exists
+    def attach_overlap_hooks(self) -> None:
+        """``p.grad`` must be None at the start of every backward pass (``optimizer.zero_grad()`` does that): each
+        parameter's hook then fires exactly once per pass.  Not for captured (hipGraph) steps - set ``overlap = False``
+        around a capture; ``allreduce_mean`` enqueues whatever the hooks did not."""
+        if self._hooked or not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        self._hooked = True
+        index = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+
+        def hook(p):
+            if not self.overlap or not p.is_cuda:
+                return
+            i = index[id(p)]
+            self._pending[i] -= 1
+            if self._pending[i] == 0 and self._works[i] is None:
+                self._launch_bucket(i)
+
+        for b in self.buckets:
+            for p in b:
+                p.register_post_accumulate_grad_hook(hook)

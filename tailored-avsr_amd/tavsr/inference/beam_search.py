@@ -36,6 +36,20 @@ def _cat(ws):
     return torch.cat([w.detach() for w in ws], dim=0).contiguous()
 
 
+# One-token scorer steps are chains of small launches: the fused feed-forward block (LayerNorm + both GEMMs, csrc/ffn.hip)
+# and the fused source attention cut the chain.  TAVSR_DECODE_FUSED=0 keeps the GEMM launches (A/B switch).
+FUSED_STEP = os.environ.get("TAVSR_DECODE_FUSED", "1") == "1"
+
+
+def _ffn_step(x, norm, L):
+    """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows."""
+    if FUSED_STEP and x.shape[1] in (256, 512) and L["w1"].shape[0] % 128 == 0:
+        return ops.ffn_fwd(x, norm[0], norm[1], EPS, L["w1"], L["b1"], L["w2"], L["b2"], "relu", 1.0, save=False)[0]
+    n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
+    t = ops.linear(n, L["w1"], L["b1"], act="relu")
+    return ops.linear(t, L["w2"], L["b2"], res=x)
+
+
 class _DecoderStep:
     """espnet2 TransformerDecoder.forward_one_step with K/V kept per token instead of per-layer output caches."""
 
@@ -87,18 +101,19 @@ class _DecoderStep:
             q2 = ops.linear(n2, L["wq2"], L["bq2"])
             # source attention: the K slots of an utterance are K query rows against that utterance's memory
             kv = self.memkv[li]
-            S = ops.pad4(T)
-            sc = ops.empty(H, U, K, S, like=x)
-            ops.gemm(K, T, dk, q2, D, kv, 2 * D, sc, S, nb1=U, nb2=H, sA=(K * D, dk), sB=(T * 2 * D, dk),
-                     sC=(K * S, U * K * S))
-            att = ops.softmax_fwd(sc, None, self.enc_lens, 1.0 / math.sqrt(dk), T2=T)
-            c2 = ops.empty(N, D, like=x)
-            ops.gemm(K, dk, T, att, S, kv, 2 * D, c2, D, b_off=D, b_kmajor=True, nb1=U, nb2=H, sA=(K * S, U * K * S),
-                     sB=(T * 2 * D, dk), sC=(K * D, dk))
+            if FUSED_STEP and dk == 64:      # scores, mask, softmax and context in one launch (csrc/attn_fused.hip)
+                c2 = ops.attn_fwd(q2, 0, kv, 0, kv, D, U, K, T, H, dk, klens=self.enc_lens)[0]
+            else:
+                S = ops.pad4(T)
+                sc = ops.empty(H, U, K, S, like=x)
+                ops.gemm(K, T, dk, q2, D, kv, 2 * D, sc, S, nb1=U, nb2=H, sA=(K * D, dk), sB=(T * 2 * D, dk),
+                         sC=(K * S, U * K * S))
+                att = ops.softmax_fwd(sc, None, self.enc_lens, 1.0 / math.sqrt(dk), T2=T)
+                c2 = ops.empty(N, D, like=x)
+                ops.gemm(K, dk, T, att, S, kv, 2 * D, c2, D, b_off=D, b_kmajor=True, nb1=U, nb2=H, sA=(K * S, U * K * S),
+                         sB=(T * 2 * D, dk), sC=(K * D, dk))
             x = ops.linear(c2, L["wo2"], L["bo2"], res=x)
-            n3 = ops.layernorm_fwd(x, *L["n3"], EPS, save=False)[0]
-            t = ops.linear(n3, L["w1"], L["b1"], act="relu")
-            x = ops.linear(t, L["w2"], L["b2"], res=x)
+            x = _ffn_step(x, L["n3"], L)
         y = ops.layernorm_fwd(x, self.dec.after_norm.weight, self.dec.after_norm.bias, EPS, save=False)[0]
         return ops.log_softmax_rows(ops.linear(y, self.dec.output_layer.weight, self.dec.output_layer.bias), **score)
 
@@ -140,9 +155,7 @@ class _LMStep:
             a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
                                    step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
             h = ops.linear(a, L["wo"], L["bo"], res=h)
-            n2 = ops.layernorm_fwd(h, *L["n2"], EPS, save=False)[0]
-            t = ops.linear(n2, L["w1"], L["b1"], act="relu")
-            h = ops.linear(t, L["w2"], L["b2"], res=h)
+            h = _ffn_step(h, L["n2"], L)
         y = ops.layernorm_fwd(h, lm.encoder.after_norm.weight, lm.encoder.after_norm.bias, EPS, save=False)[0]
         return ops.log_softmax_rows(ops.linear(y, lm.decoder.weight, lm.decoder.bias), **score)
 

@@ -166,11 +166,16 @@ def training(e2e, train_loader, optimizer, scheduler, accum_grad, device="cuda",
     total = None
     optimizer.zero_grad()
     n = len(train_loader)
+    if buckets is not None:
+        buckets.attach_overlap_hooks()      # a bucket's all-reduce leaves while the rest of the backward pass still runs
     for batch_idx, batch in enumerate(train_loader):
         batch = _to_device(batch, device)
         loss = e2e(**batch)[0] / accum_grad
+        stepping = ((batch_idx + 1) % accum_grad == 0) or (batch_idx + 1 == n)
+        if buckets is not None:             # gradients are exchanged once per optimizer step: the hooks launch buckets
+            buckets.overlap = stepping      # only during the window's LAST micro-batch (every hook fires once in it)
         loss.backward()
-        if ((batch_idx + 1) % accum_grad == 0) or (batch_idx + 1 == n):
+        if stepping:
             if buckets is not None:
                 buckets.allreduce_mean()
             optimizer.step()

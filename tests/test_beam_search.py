@@ -237,3 +237,45 @@ def test_beam_update_kernels_equal_the_torch_expressions():
     dst = [torch.zeros_like(o) for o in outs]
     ops.multi_copy_(dst, list(outs))
     assert all(torch.equal(d, o) for d, o in zip(dst, outs))
+
+
+@pytest.mark.gpu
+def test_config5_full_av_model_beam10_lm16x512_matches_oracle():
+    """BASELINE configs[4] at its own sizes: the full tailored AV-Branchformer (12 layers, Conv3d + ResNet-18 frontend,
+    fusion, 6-layer decoder) with beam 10, ctc_weight 0.1 and the 16-layer x 512 x 8-head Transformer LM
+    (configs/LM/lm-english.yaml) at lm_weight 0.6, length bonus 0.5 - two 4 s / 2.4 s utterances, HIP search against the
+    oracle's (about a minute of host time): best hypothesis and score, n-best overlap."""
+    from helpers import AVSR_YAML, avsr_conf
+    from oracle.av import build_avsr_oracle
+    from tavsr.inference.beam_search import BatchBeamSearch
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.avsr import AVSRTask
+    lm_kw = dict(pos_enc=None, embed_unit=128, att_unit=512, head=8, unit=2048, layer=16, dropout_rate=0.0)
+    conf = avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)
+    m = build_avsr_oracle(conf, TOKENS_EN).eval()
+    fill_parameters_(m, seed=77)
+    lm = BS.TransformerLMOracle(len(TOKENS_EN), **lm_kw).eval()
+    fill_parameters_(lm, seed=78)
+    pconf = avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)
+    pconf["token_list"] = TOKENS_EN
+    pm = AVSRTask.build_model(argparse.Namespace(**pconf)).eval()
+    pm.load_state_dict(m.state_dict())
+    plm = TransformerLM(len(TOKENS_EN), **lm_kw).eval()
+    plm.load_state_dict(lm.state_dict())
+    pm, plm = pm.cuda(), plm.cuda()
+    audio, video = synth((2, 400, 80), seed=79), synth((2, 100, 88, 88), seed=80)
+    alens, vlens = torch.tensor([400, 240]), torch.tensor([100, 60])
+    with torch.no_grad():
+        enc, olens = m.encode(audio, alens, video, vlens)
+        genc, golens = pm.encode(audio.cuda(), alens.cuda(), video.cuda(), vlens.cuda())
+        assert torch.equal(golens.cpu(), olens)
+        assert float((genc.cpu() - enc).abs().max() / enc.abs().max()) < 1e-4
+        ref = [BS.build_beam_search(m, lm, 10, 0.1, 0.6, 0.5).forward(enc[u, : int(olens[u])]) for u in range(2)]
+        hip = BatchBeamSearch(pm, plm, 10, 0.1, 0.6, 0.5).decode(genc, golens)
+    for u in range(2):
+        assert len(hip[u]) > 0 and len(ref[u]) > 0
+        assert hip[u][0][0] == ref[u][0].yseq.tolist(), (u, hip[u][0], ref[u][0].yseq.tolist())
+        assert abs(hip[u][0][1] - ref[u][0].score) < 5e-4 * abs(ref[u][0].score)
+        top_h = {tuple(h[0]) for h in hip[u][:5]}
+        top_r = {tuple(h.yseq.tolist()) for h in ref[u][:5]}
+        assert len(top_h & top_r) >= 3, (u, top_h, top_r)

@@ -86,3 +86,102 @@ def test_dp_allreduce_mean_world2_hip_buckets():
         for ga, gb, la, lb in zip(a["avg"], b["avg"], a["local"], b["local"]):
             assert torch.equal(ga, gb)
             assert torch.allclose(ga, (la + lb) / 2, atol=1e-6)
+
+
+def _real_model_worker(rank, world, port, ret):
+    """two ranks sharing cuda:0 over gloo, the real 2-layer ASR model: each rank steps its half of a batch of four through
+    the product's training harness (overlap hooks on, fused Adam under Noam)."""
+    import argparse
+    sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    from helpers import asr_conf
+    from oracle.model import fill_parameters_, synth
+    from tavsr import dp
+    from tavsr.tasks.asr import ASRTask
+    from tavsr.train import get_noam_scheduler, training
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dp.init_from_env("gloo")
+    torch.cuda.set_device(0)
+
+    def build(seed):
+        m = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=2, dec_blocks=1)))
+        fill_parameters_(m, seed=seed)
+        return m.cuda().train()
+
+    speech = synth((4, 100, 80), seed=8)
+    slens = torch.tensor([100, 100, 100, 100])
+    text = synth((4, 6), seed=9, kind="int", lo=1, hi=40)
+    tlens = torch.tensor([6, 6, 6, 6])
+    half = slice(2 * rank, 2 * rank + 2)
+    mine = dict(speech=speech[half], speech_lengths=slens[half], text=text[half], text_lengths=tlens[half])
+
+    model = build(7 + rank)                                   # different init per rank: the broadcast must fix it
+    buckets = dp.GradBuckets(model.parameters(), bucket_bytes=4 << 20)
+    assert len(buckets.buckets) >= 3
+    buckets.broadcast_parameters(0)
+    buckets.attach_overlap_hooks()
+    for p in model.parameters():
+        p.grad = None
+    model(**{k: v.cuda() for k, v in mine.items()})[0].backward()      # hooks enqueue the buckets during this backward
+    buckets.allreduce_mean()
+    torch.cuda.synchronize()
+    avg = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+    out = dict(avg=avg)
+    if rank == 0:                                             # the same model on the concatenated batch, one process
+        ref = build(7)
+        ref(speech.cuda(), slens.cuda(), text.cuda(), tlens.cuda())[0].backward()
+        out["cat"] = {n: p.grad.detach().cpu().clone() for n, p in ref.named_parameters()}
+    opt = get_noam_scheduler(model.parameters(), 0.05, 256, 10)
+    for _ in range(3):
+        training(model, [mine], opt, None, 1, buckets=buckets)
+    torch.cuda.synchronize()
+    out["params"] = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_dp_real_model_equals_single_process_on_the_concatenated_batch():
+    """the two-rank averaged gradients equal the single-process gradients of the concatenated batch, and
+    after three optimizer steps the replicas' parameters are bitwise equal."""
+    world, port = 2, 29751
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_real_model_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    for n, g in a["avg"].items():
+        assert torch.equal(g, b["avg"][n]), n                  # both ranks hold the same reduced gradient
+        ref = a["cat"][n]
+        scale = float(ref.abs().max())
+        if scale < 1e-6:
+            assert float(g.abs().max()) < 1e-5, n
+        else:
+            assert float((g - ref).abs().max()) / scale < 2e-4, (n, float((g - ref).abs().max()) / scale)
+    for n, p in a["params"].items():
+        assert torch.equal(p, b["params"][n]), n               # replicas stay bitwise identical
+
+
+@pytest.mark.gpu
+def test_rccl_c_abi_single_rank_roundtrip():
+    """tavsr_dp_* on a one-rank communicator (the box has one GPU): id, init, in-place all-reduce and broadcast on a
+    stream, destroy - the calls the multi-GPU path makes, with RCCL resolved by dlopen."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
+    from tavsr._lib import check, lib
+    torch.cuda.set_device(0)
+    ident = (C.c_char * 128)()
+    check(lib().tavsr_dp_unique_id(ident), "tavsr_dp_unique_id")
+    check(lib().tavsr_dp_init(0, 1, ident), "tavsr_dp_init")
+    assert lib().tavsr_dp_world() == 1
+    x = torch.randn(1 << 20, device="cuda")
+    want = x.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    check(lib().tavsr_dp_allreduce(C.c_void_p(x.data_ptr()), C.c_int64(x.numel()), C.c_void_p(s.cuda_stream)), "tavsr_dp_allreduce")
+    check(lib().tavsr_dp_broadcast(C.c_void_p(x.data_ptr()), C.c_int64(x.numel()), 0, C.c_void_p(s.cuda_stream)), "tavsr_dp_broadcast")
+    s.synchronize()
+    assert torch.equal(x, want)
+    check(lib().tavsr_dp_destroy(), "tavsr_dp_destroy")
+    assert lib().tavsr_dp_world() == 0

@@ -320,8 +320,92 @@ def test_av_realistic_size_vs_oracle_cfg3():
     assert torch.equal(ids.cpu()[binding], logits.argmax(-1)[binding])
 
 
+def _bench_batch(B):
+    from oracle.model import synth
+    audio, video = synth((B, 400, 80), seed=5321), synth((B, 100, 88, 88), seed=5322)
+    alens = torch.tensor([400 - 20 * (i % 3) for i in range(B)])
+    vlens = torch.tensor([100 - 5 * (i % 3) for i in range(B)])
+    text = synth((B, 40), seed=5323, kind="int", lo=1, hi=40)
+    tlens = torch.tensor([40 - (i % 7) for i in range(B)])
+    for i, l in enumerate(tlens):
+        text[i, l:] = -1
+    return audio, alens, video, vlens, text, tlens
+
+
+def test_av_benchmark_batch_32_vs_oracle_cfg3():
+    """BASELINE configs[2] at the BENCHMARKED batch of 32 (M = 387 200-row implicit convolutions, the K-split plans of the
+    convolution weight gradients, the 6.3 GB stem patch matrix, train-mode BatchNorm over 3200 frames): HIP vs the pinned
+    oracle on the host cores - loss 1e-4, every parameter gradient 5e-3, BatchNorm running statistics 1e-4, then the
+    encoder output in eval mode 1e-4.  The oracle's training pass keeps ~20 GB of activations: skipped on a host with
+    less than 48 GB available."""
+    import psutil
+    if psutil.virtual_memory().available < 48 * 2**30:
+        pytest.skip("the CPU oracle needs ~20 GB for a batch-32 AV training pass")
+    from oracle.av import build_avsr_oracle
+    from oracle.model import fill_parameters_
+    from tavsr.tasks.avsr import AVSRTask
+    conf = avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)
+    oracle = build_avsr_oracle(conf, TOKENS_EN)
+    fill_parameters_(oracle, seed=4321)
+    model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)))
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    oracle.train()
+    batch = _bench_batch(32)
+    lg, _, _ = model(*[t.cuda() for t in batch])
+    lg.backward()
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
+    bufs = {n: b.detach().float().cpu() for n, b in model.named_buffers()}
+    lo, _, _ = oracle(*batch)
+    lo.backward()
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 1e-4
+    for n, p in oracle.named_parameters():
+        assert grad_ok(got[n], p.grad, 5e-3), n
+    for n, b in oracle.named_buffers():
+        assert rel_err(bufs[n], b.float()) < 1e-4, n
+    for p in oracle.parameters():
+        p.grad = None
+    model.eval()
+    oracle.eval()
+    audio, alens, video, vlens = batch[:4]
+    with torch.no_grad():
+        eo, oo = oracle.encode(audio, alens, video, vlens)
+        eg, og = model.encode(audio.cuda(), alens.cuda(), video.cuda(), vlens.cuda())
+    assert max_rel(eg.cpu(), eo) < ACT_TOL
+    assert torch.equal(og.cpu(), oo)
+
+
+def test_av_benchmark_batch_32_equals_its_chunks():
+    """size-independent property at the benchmarked batch: in eval mode (BatchNorm on its running statistics) the
+    utterances are independent, so the batch-32 encoder output and loss equal those of the eight batch-4 slices (the shape
+    checked against the oracle) - the forward convolutions run on their large-M tile plans here."""
+    from oracle.model import fill_parameters_
+    from tavsr.tasks.avsr import AVSRTask
+    model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)))
+    fill_parameters_(model, seed=4321)
+    model = model.cuda().eval()
+    batch = [t.cuda() for t in _bench_batch(32)]
+    with torch.no_grad():
+        enc32, olens32 = model.encode(*batch[:4])
+        loss32 = float(model(*[t.clone() for t in batch])[0])
+        tot = 0.0
+        for c in range(8):
+            sl = slice(4 * c, 4 * c + 4)
+            chunk = [t[sl].contiguous() for t in batch]
+            e4, o4 = model.encode(*chunk[:4])
+            T4 = e4.shape[1]
+            assert torch.equal(o4, olens32[sl])
+            assert max_rel(enc32[sl, :T4].cpu(), e4.cpu()) < 2e-5, c
+            tot += float(model(*chunk)[0]) / 8
+    assert abs(loss32 - tot) / abs(tot) < 2e-5
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 22, 22, 64, 64), (3, 11, 11, 128, 128), (5, 6, 6, 256, 256), (32, 3, 3, 512, 512),
-                                            (1, 7, 5, 64, 128)])
+                                            (1, 7, 5, 64, 128),
+                                            # the four ResNet stages at the BENCHMARKED batch (32 clips x 100 frames): the tile
+                                            # and K-split plans bench.py runs (M up to 1.5 M rows, K up to 1.5 M in the weight gradient)
+                                            (3200, 22, 22, 64, 64), (3200, 11, 11, 128, 128), (3200, 6, 6, 256, 256),
+                                            (3200, 3, 3, 512, 512)])
 def test_implicit_conv3x3_vs_conv2d(N, H, W, Cin, Cout):
     """tavsr_gemm conv_mode 1 / 2 (no im2col matrix) against torch conv2d fp32 on the CPU: forward, data gradient,
     weight gradient; the weight gradient needs whole 32-pixel K-steps."""
@@ -331,9 +415,11 @@ def test_implicit_conv3x3_vs_conv2d(N, H, W, Cin, Cout):
     x = torch.randn(N, Cin, H, W)
     w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)
     dz = torch.randn(N, Cout, H, W)
-    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref_dt = torch.float64 if N >= 100 else torch.float32       # benchmark sizes: sums over 1.5 M pixels want an fp64 reference
+    xr, wr = x.to(ref_dt).requires_grad_(True), w.to(ref_dt).requires_grad_(True)
     zr = torch.nn.functional.conv2d(xr, wr, padding=1)
-    zr.backward(dz)
+    zr.backward(dz.to(ref_dt))
+    zr = zr.detach()
     xl = x.permute(0, 2, 3, 1).reshape(N * H * W, Cin).contiguous().cuda()
     dzl = dz.permute(0, 2, 3, 1).reshape(N * H * W, Cout).contiguous().cuda()
     w2d = _w2d(w.cuda())
@@ -351,7 +437,10 @@ def test_implicit_conv3x3_vs_conv2d(N, H, W, Cin, Cout):
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k", [(4, 22, 22, 64, 128, 3), (4, 22, 22, 64, 128, 1), (32, 11, 11, 128, 256, 3),
                                               (32, 11, 11, 128, 256, 1), (32, 6, 6, 256, 512, 3), (16, 6, 6, 256, 512, 1),
-                                              (32, 7, 9, 64, 64, 3)])
+                                              (32, 7, 9, 64, 64, 3),
+                                              # the stage transitions at the benchmarked batch (3200 frames)
+                                              (3200, 22, 22, 64, 128, 3), (3200, 22, 22, 64, 128, 1), (3200, 11, 11, 128, 256, 3),
+                                              (3200, 6, 6, 256, 512, 1)])
 def test_strided_implicit_conv_vs_conv2d(N, H, W, Cin, Cout, k):
     """conv_stride 2 with 9 taps (3x3, pad 1) or 1 tap (1x1, pad 0): the blocks that halve the maps (resnet.py:68-97),
     forward and weight gradient against torch conv2d; odd map sizes included."""
@@ -360,10 +449,11 @@ def test_strided_implicit_conv_vs_conv2d(N, H, W, Cin, Cout, k):
     torch.manual_seed(1)
     x = torch.randn(N, Cin, H, W)
     w = torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5)
-    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref_dt = torch.float64 if N >= 100 else torch.float32
+    xr, wr = x.to(ref_dt).requires_grad_(True), w.to(ref_dt).requires_grad_(True)
     zr = torch.nn.functional.conv2d(xr, wr, stride=2, padding=k // 2)
-    dz = torch.randn_like(zr)
-    zr.backward(dz)
+    dz = torch.randn(zr.shape)
+    zr.backward(dz.to(ref_dt))
     Ho, Wo = zr.shape[2:]
     xl = x.permute(0, 2, 3, 1).reshape(N * H * W, Cin).contiguous().cuda()
     dzl = dz.permute(0, 2, 3, 1).reshape(N * Ho * Wo, Cout).contiguous().cuda()
@@ -371,10 +461,11 @@ def test_strided_implicit_conv_vs_conv2d(N, H, W, Cin, Cout, k):
     z = ops.conv3x3_fwd(xl, w2d, H, W, 2, k * k)
     assert z.shape == (N * Ho * Wo, Cout)
     assert rel_err(z.cpu().view(N, Ho, Wo, Cout).permute(0, 3, 1, 2), zr.detach()) < 2e-5
+    tol = 2e-5
     dw = _w2d_grad(_conv3x3_dw(dzl, xl, N, H, W, Cin, 2, k * k), w.shape)          # implicit when N*Ho*Wo % 32 == 0
-    assert rel_err(dw.cpu(), wr.grad) < 2e-5
+    assert rel_err(dw.cpu(), wr.grad) < tol
     if (N * Ho * Wo) % 32 == 0:
-        assert rel_err(_w2d_grad(ops.conv3x3_dw(dzl, xl, H, W, 2, k * k), w.shape).cpu(), wr.grad) < 2e-5
+        assert rel_err(_w2d_grad(ops.conv3x3_dw(dzl, xl, H, W, 2, k * k), w.shape).cpu(), wr.grad) < tol
 
 
 def test_col2im_with_the_downsample_gradient_joined():
