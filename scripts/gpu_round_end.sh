@@ -1,10 +1,17 @@
-# round-end verification and records: smoke, full GPU suite, default bench (AV) + ASR bench, kernel table, PMC HBM passes
+# round-end records: default bench (AV) + ASR bench, forward-encoder bench, kernel tables, per-shape GEMM tables, PMC passes
+# (HBM bytes, MFMA utilisation), decode bench.  usage: bash scripts/gpu_round_end.sh   (outputs under gpurun_out/)
 mkdir -p gpurun_out
-timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu.log
 ( time timeout 900 python bench.py ) > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "default rc=$?"; tail -4 gpurun_out/bench_default.err
 cut -c1-330 gpurun_out/bench_default.json
 timeout 900 python bench.py --workload asr --steps 20 --warmup 5 > gpurun_out/bench_asr.json 2> gpurun_out/bench_asr.err; echo "asr rc=$?"
 cut -c1-300 gpurun_out/bench_asr.json
-bash scripts/gpu_prof.sh | tail -3
-OUT=pmc_hbm_av bash scripts/gpu_pmc_hbm.sh | tail -8
+timeout 600 python profiles/gemm_shapes.py --workload avsr > gpurun_out/gemm_shapes_av.txt 2>&1; echo "shapes av rc=$?"
+timeout 600 python profiles/gemm_shapes.py --workload asr > gpurun_out/gemm_shapes_asr.txt 2>&1; echo "shapes asr rc=$?"
+bash scripts/gpu_prof.sh | tail -3; cp gpurun_out/prof_stats.txt gpurun_out/kernel_stats_av.txt
+bash scripts/gpu_prof.sh --workload asr | tail -3; cp gpurun_out/prof_stats.txt gpurun_out/kernel_stats_asr.txt
+OUT=pmc_hbm_av bash scripts/gpu_pmc_hbm.sh | tail -4
+OUT=pmc_mfma_av bash scripts/gpu_pmc_mfma.sh | tail -4
+OUT=pmc_mfma_asr bash scripts/gpu_pmc_mfma.sh --workload asr | tail -4
+OUT=pmc_mfma_fwd_encoder bash scripts/gpu_pmc_mfma.sh --mode fwd-encoder | tail -4
+timeout 900 python bench_decode.py --utterances 256 --batch 64 > gpurun_out/decode_b64.json 2> gpurun_out/decode_b64.err; echo "decode rc=$?"; cut -c1-300 gpurun_out/decode_b64.json
+timeout 900 python bench_decode.py --utterances 16 --batch 1 --no-cpu-baseline > gpurun_out/decode_b1.json 2> gpurun_out/decode_b1.err; echo "decode1 rc=$?"; cut -c1-300 gpurun_out/decode_b1.json

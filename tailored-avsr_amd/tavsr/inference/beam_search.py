@@ -39,11 +39,12 @@ def _cat(ws):
 # One-token scorer steps are chains of small launches: the fused feed-forward block (LayerNorm + both GEMMs, csrc/ffn.hip)
 # and the fused source attention cut the chain.  TAVSR_DECODE_FUSED=0 keeps the GEMM launches (A/B switch).
 FUSED_STEP = os.environ.get("TAVSR_DECODE_FUSED", "1") == "1"
+FUSED_FFN = os.environ.get("TAVSR_DECODE_FUSED_FFN", "0") == "1"      # measured: 153 vs 166 utt/s at batch 64 (in-call A/B): off
 
 
 def _ffn_step(x, norm, L):
     """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows."""
-    if FUSED_STEP and x.shape[1] in (256, 512) and L["w1"].shape[0] % 128 == 0:
+    if FUSED_FFN and x.shape[1] in (256, 512) and L["w1"].shape[0] % 128 == 0:
         return ops.ffn_fwd(x, norm[0], norm[1], EPS, L["w1"], L["b1"], L["w2"], L["b2"], "relu", 1.0, save=False)[0]
     n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
     t = ops.linear(n, L["w1"], L["b1"], act="relu")
