@@ -41,6 +41,7 @@ struct GemmArgs {
   int kchunk;     // K elements per split (multiple of BK)
   int nsplit;
   int tiles_m, tiles_n;
+  int vec_epi;    // LDS-DMA kernels: epilogue through LDS with 16-byte row accesses (finish_tile_vec)
 };
 
 // Fixed-order sum of the split-K slabs + the fused epilogue (same math as the in-kernel one); one thread per
@@ -423,6 +424,77 @@ void gemm_kernel(const GemmArgs args) {
   finish_tile<TM, TN>(d, args.nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
 }
 
+// Epilogue through LDS (the staging ring is free once the K loop is over): the accumulators (lane = column, registers =
+// rows) are written to a [BM][BN] image and read back row-wise, so that bias / pre-activation store / activation /
+// act' / alpha / residual and the C (or split-K slab) store all move 16 bytes per lane along rows - a wave instruction
+// covers whole 256-byte row segments instead of 2 x 128 bytes, and a 64x64 tile with a pre-activation output issues 8
+// store instructions per lane instead of 32.  At K = 256 the old per-register epilogue was a third of a block's life
+// (profiles/r01_gemm_trace.txt).  Needs N % 4 == 0 and 16-byte aligned rows of every output / epilogue operand.
+template <int BM, int BN, int NT, int TM, int TN>
+__device__ __forceinline__ void finish_tile_vec(const tavsr_gemm_desc& d, int nsplit, f32x16 (&acc)[TM][TN], float* __restrict__ img,
+                                                int m0, int n0, int wm, int wn, int lr, int lk, int z1, int z2, int64_t coff,
+                                                int tid) {
+  __syncthreads();                                   // every wave has finished reading the staging ring
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        img[(wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * BN + wn * TN * 32 + j * 32 + lr] = acc[i][j][r];
+  __syncthreads();
+  constexpr int V4R = BN / 4, PER = BM * BN / 4 / NT;
+  static_assert(BM * BN % (4 * NT) == 0, "tile must divide over the block");
+  const bool split = nsplit > 1;
+  float* base;
+  int64_t ld;
+  if (split) {
+    base = d.ws + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * ((int64_t)d.M * d.N);
+    ld = d.N;
+  } else {
+    base = d.C + coff;
+    ld = d.ldc;
+  }
+  const float* R = (!split && d.R) ? d.R + z1 * d.sR1 + z2 * d.sR2 : nullptr;
+  float* Z = (!split && d.Z) ? d.Z + coff : nullptr;
+  const float* DZ = (!split && d.DZ) ? d.DZ + coff : nullptr;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int idx = q * NT + tid, row = idx / V4R, c4 = idx % V4R;
+    const int m = m0 + row, n = n0 + 4 * c4;
+    if (m >= d.M || n >= d.N) continue;
+    float4 v = *reinterpret_cast<const float4*>(img + row * BN + 4 * c4);
+    const int64_t o = (int64_t)m * ld + n;
+    if (!split) {
+      if (d.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(d.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if (Z) *reinterpret_cast<float4*>(Z + o) = v;
+      v.x = act_fwd(d.act, v.x); v.y = act_fwd(d.act, v.y); v.z = act_fwd(d.act, v.z); v.w = act_fwd(d.act, v.w);
+      if (DZ) {
+        const float4 z = *reinterpret_cast<const float4*>(DZ + o);
+        v.x *= act_bwd(d.dact, z.x); v.y *= act_bwd(d.dact, z.y); v.z *= act_bwd(d.dact, z.z); v.w *= act_bwd(d.dact, z.w);
+      }
+      v.x *= d.alpha; v.y *= d.alpha; v.z *= d.alpha; v.w *= d.alpha;
+      if (R) {
+        const float4 rr = *reinterpret_cast<const float4*>(R + (int64_t)m * d.ldr + n);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+    }
+    *reinterpret_cast<float4*>(base + o) = v;
+  }
+}
+
+// host-side test of the vectorised epilogue's requirements (TAVSR_GEMM_VEC_EPI=0 switches it off: A/B aid)
+static bool vec_epi_ok(const tavsr_gemm_desc& d) {
+  static const int on = [] { const char* e = getenv("TAVSR_GEMM_VEC_EPI"); return e ? atoi(e) : 1; }();
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return on && d.N % 4 == 0 && d.ldc % 4 == 0 && d.sC1 % 4 == 0 && d.sC2 % 4 == 0 && al(d.C) && (!d.bias || al(d.bias)) &&
+         (!d.Z || al(d.Z)) && (!d.DZ || al(d.DZ)) && (!d.R || (al(d.R) && d.ldr % 4 == 0 && d.sR1 % 4 == 0 && d.sR2 % 4 == 0)) &&
+         (!d.ws || al(d.ws));
+}
+
 // ---------------------------------------------------------------------------------------------- LDS-DMA kernel
 // Fast path for tiles whose operands can be fetched with unpredicated 16-byte loads (aligned, K a multiple of 32,
 // row-contiguous operands with rows % 4 == 0).  Operand tiles go global -> LDS directly (global_load_lds_dwordx4:
@@ -507,7 +579,7 @@ __device__ unsigned int g_trace_n;
 //   2: the k-major B operand is the image (weight gradient dW = dY^T patches): B(k = m, n = tap*C + c); a 64-wide n
 //      tile lies in one tap, validity is per k row.
 template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM, int KW = 1, int CONV = 0>
-__device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid) {
+__device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid, bool vec_epi) {
   constexpr int BK = 32, NG = BK / 8;
   static_assert(NG % KW == 0, "k-groups must divide over the wave sets");
   constexpr int NT = WM * WN * KW * 64;
@@ -740,7 +812,26 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       for (int i = 0; i < TM; ++i) asum[i] += rsum[((s2 * WM * WN + w2) * TM + i) * 64 + lane];
     }
   }
-  finish_tile<TM, TN>(d, nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff, bpre);
+  if (KW == 1 && vec_epi) {
+    static_assert(KW > 1 || BM * BN <= S * STAGE, "the output tile image must fit in the staging ring");
+    if (want_rowsum) {              // bias gradients (row sums of op(A)): as finish_tile
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asum[i] += __shfl_xor(asum[i], 32, 64);
+      if (lk == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = m0 + wm * TM * 32 + i * 32 + lr;
+          if (m < d.M) {
+            if (nsplit > 1) (d.ws + (int64_t)nsplit * gridDim.y * d.M * d.N)[(int64_t)blockIdx.z * d.M + m] = asum[i];
+            else d.a_rowsum[m] = d.alpha * asum[i];
+          }
+        }
+      }
+    }
+    finish_tile_vec<BM, BN, NT, TM, TN>(d, nsplit, acc, smem, m0, n0, wm, wn, lr, lk, z1, z2, coff, tid);
+  } else {
+    finish_tile<TM, TN>(d, nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff, bpre);
+  }
 #ifdef TAVSR_GEMM_TRACE
   __builtin_amdgcn_s_waitcnt(0);
   TAVSR_TRACE_AT(3)
@@ -765,7 +856,7 @@ template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM, in
 __global__ __launch_bounds__(WM* WN * KW * 64, MINW)
 void gemm_glds_kernel(const GemmArgs args) {
   glds_tile<BM, BN, WM, WN, S, AK, BKM, KW, CONV>(args.d, args.kchunk, args.nsplit, args.tiles_n,
-                                                  xcd_remap(blockIdx.x, gridDim.x));
+                                                  xcd_remap(blockIdx.x, gridDim.x), args.vec_epi != 0);
 }
 
 // Grouped launch: up to kMaxGroup independent problems of one layout share ONE grid (tile ranges by prefix sums).
@@ -777,6 +868,7 @@ struct GroupArgs {
   int tile_start[kMaxGroup + 1];
   int tiles_n[kMaxGroup];
   int n;
+  int vec_epi;    // every problem of the group qualifies for finish_tile_vec
 };
 
 template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM>
@@ -787,7 +879,7 @@ void gemm_glds_grouped_kernel(const GroupArgs g) {
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
     if (i < g.n && bid >= g.tile_start[i]) pi = i;
-  glds_tile<BM, BN, WM, WN, S, AK, BKM>(g.d[pi], g.d[pi].K, 1, g.tiles_n[pi], bid - g.tile_start[pi]);
+  glds_tile<BM, BN, WM, WN, S, AK, BKM>(g.d[pi], g.d[pi].K, 1, g.tiles_n[pi], bid - g.tile_start[pi], g.vec_epi != 0);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -833,7 +925,7 @@ static int launch_epilogue(const GemmArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int S, int MINW, int KW = 1>
 static int launch_glds(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStream_t s) {
-  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, BM), cdiv(d.N, BN)};
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, BM), cdiv(d.N, BN), (int)vec_epi_ok(d)};
   dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
   int rc = launch_layout(d, [&](auto ak, auto bk) {
     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, S, MINW, decltype(ak)::value, decltype(bk)::value, KW>), grid,
@@ -846,6 +938,7 @@ static int launch_glds(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
 
 // implicit-convolution launches (two-stage 64x64 variant): mode 1 = A patches (NT / NN), mode 2 = B patches (TN)
 static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStream_t s) {
+  const int ve = (int)vec_epi_ok(d);
   // Wider tiles where the shape allows - the gathered patch operand is the expensive one to load:
   //   forward / data gradient: a 64x128 tile reads the image rows once for two column tiles of weights (Cout % 128 == 0):
   //     +0.6 % on the AV step (128x64 and 128x128 tiles: nothing / worse);
@@ -855,18 +948,18 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
   static const int wide = [] { const char* e = getenv("TAVSR_CONV_TILE"); return e ? atoi(e) : 1; }();
   static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
   if (d.conv_mode == 1 && !d.b_kmajor && nsplit == 1 && wide && d.N % 128 == 0) {
-    GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 128)};
+    GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 128), (int)vec_epi_ok(d)};
     hipLaunchKernelGGL((gemm_glds_kernel<64, 128, 2, 2, 2, 3, false, false, 1, 1>), dim3(a2.tiles_m * a2.tiles_n, 1, 1), dim3(256), 0, s, a2);
     TAVSR_LAUNCH_CHECK();
     return TAVSR_OK;
   }
   if (d.conv_mode == 2 && dw_wide && d.M % 128 == 0) {     // weight gradient: 128 output channels share one patch tile
-    GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 128), cdiv(d.N, 64)};
+    GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 128), cdiv(d.N, 64), (int)vec_epi_ok(d)};
     hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, 3, true, true, 1, 2>), dim3(a2.tiles_m * a2.tiles_n, 1, nsplit), dim3(256), 0, s, a2);
     TAVSR_LAUNCH_CHECK();
     return launch_epilogue(a2, s);
   }
-  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64)};
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve};
   dim3 grid(a.tiles_m * a.tiles_n, 1, nsplit);
   if (d.conv_mode == 1 && !d.b_kmajor)
     hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, false, false, 1, 1>), grid, dim3(256), 0, s, a);
@@ -879,7 +972,7 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
 }
 
 static int launch_fallback(const tavsr_gemm_desc& d, bool vec, int nsplit, int kchunk, hipStream_t s) {
-  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64)};
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), 0};
   dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
   int rc = launch_layout(d, [&](auto ak, auto bk) {
     if (vec)
@@ -895,7 +988,7 @@ static int launch_fallback(const tavsr_gemm_desc& d, bool vec, int nsplit, int k
 }
 
 static int launch_tail(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStream_t s) {
-  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64)};
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), (int)vec_epi_ok(d)};
   dim3 grid(a.tiles_m * a.tiles_n, d.nb1 * d.nb2, nsplit);
   int rc = launch_layout(d, [&](auto ak, auto bk) {
     hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, decltype(ak)::value, decltype(bk)::value, 1, 3>), grid, dim3(256), 0, s, a);
@@ -1085,6 +1178,8 @@ extern "C" int tavsr_gemm_grouped(const tavsr_gemm_desc* descs, int32_t n, tavsr
     total += cdiv(d.M, 64) * g.tiles_n[i];
   }
   for (int i = n; i <= kMaxGroup; ++i) g.tile_start[i] = total;
+  g.vec_epi = 1;
+  for (int i = 0; i < n; ++i) g.vec_epi &= (int)vec_epi_ok(g.d[i]);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = launch_layout(descs[0], [&](auto ak, auto bk) {
     hipLaunchKernelGGL((gemm_glds_grouped_kernel<64, 64, 2, 2, 2, 5, decltype(ak)::value, decltype(bk)::value>), dim3(total),
