@@ -309,6 +309,7 @@ class AdaptiveFusionOracle(nn.Module):
             raise ValueError("Support only upsampling positionwise feed forward fusion.")
         self.input_size, self._output_size = input_size, output_size
         self.acoustic_weight, self.merge_method = acoustic_weight, merge_method
+        self.acoustic_branch_drop_rate = acoustic_branch_drop_rate
         act = L.get_activation(activation_type)
         if merge_method == "concat":
             self.audiovisual_layer = L.PositionwiseFeedForward(2 * input_size, hidden_units, dropout_rate, act)
@@ -334,10 +335,14 @@ class AdaptiveFusionOracle(nn.Module):
             def pooled_weight(x, m, pool, wproj):
                 score = _masked_time_softmax(pool(x).transpose(1, 2) / self.input_size ** 0.5, m)
                 return wproj(torch.matmul(score, x).squeeze(1))
-            wa = pooled_weight(audio_pad, audio_masks, self.acoustic_pooling_proj, self.acoustic_weight_proj)
-            wv = pooled_weight(video_pad, video_masks, self.visual_pooling_proj, self.visual_weight_proj)
-            mw = torch.softmax(torch.cat([wa, wv], dim=-1), dim=-1).unsqueeze(-1).unsqueeze(-1)
-            self.acoustic_weight, self.visual_weight = mw[:, 0], mw[:, 1]
+            if (self.training and self.acoustic_branch_drop_rate > 0
+                    and torch.rand(1).item() < self.acoustic_branch_drop_rate):                    # :138-144
+                self.acoustic_weight, self.visual_weight = 0.0, 1.0
+            else:
+                wa = pooled_weight(audio_pad, audio_masks, self.acoustic_pooling_proj, self.acoustic_weight_proj)
+                wv = pooled_weight(video_pad, video_masks, self.visual_pooling_proj, self.visual_weight_proj)
+                mw = torch.softmax(torch.cat([wa, wv], dim=-1), dim=-1).unsqueeze(-1).unsqueeze(-1)
+                self.acoustic_weight, self.visual_weight = mw[:, 0], mw[:, 1]
             av = self.audiovisual_layer(self.acoustic_weight * audio_pad + self.visual_weight * video_pad)
         else:
             av = self.audiovisual_layer(self.acoustic_weight * audio_pad + (1.0 - self.acoustic_weight) * video_pad)

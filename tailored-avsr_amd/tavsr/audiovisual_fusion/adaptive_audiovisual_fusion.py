@@ -41,14 +41,19 @@ class AdaptiveAudioVisualFusion(torch.nn.Module):
     def forward(self, audio_pad, audio_masks, video_pad, video_masks, cache=None):
         if cache is not None:
             raise NotImplementedError("cache is not None, which is not tested")
-        if self.training and self.acoustic_branch_drop_rate > 0:
-            raise NotImplementedError("acoustic_branch_drop_rate > 0 is not used by the shipped configs")
+        # adaptive_audiovisual_fusion.py:138-144: with probability acoustic_branch_drop_rate the step fuses with the constant
+        # weights (0, 1) - the video stream alone; the pooling / weight projections are not part of that step
+        dropped = (self.training and self.acoustic_branch_drop_rate > 0
+                   and torch.rand(1).item() < self.acoustic_branch_drop_rate)
         alens = audio_masks.squeeze(1).sum(-1).to(torch.int64)
         vlens = video_masks.squeeze(1).sum(-1).to(torch.int64)
         sd = dict(self.named_parameters())
-        cfg = dict(act=self.audiovisual_layer.activation, p=self.dropout_rate if self.training else 0.0)
+        cfg = dict(act=self.audiovisual_layer.activation, p=self.dropout_rate if self.training else 0.0, drop_acoustic=dropped)
         out = FA.FusionFn.apply(audio_pad, video_pad, alens, vlens, cfg, *[sd[n] for n in FA.FUSION_PARAM_NAMES])
-        w = cfg["_last_w"]       # (B,2) -> the reference's (B,1,1) tensors (:186-191)
-        self.acoustic_weight, self.visual_weight = w[:, 0].view(-1, 1, 1), w[:, 1].view(-1, 1, 1)
+        if dropped:
+            self.acoustic_weight, self.visual_weight = 0.0, 1.0
+        else:
+            w = cfg["_last_w"]   # (B,2) -> the reference's (B,1,1) tensors (:186-191)
+            self.acoustic_weight, self.visual_weight = w[:, 0].view(-1, 1, 1), w[:, 1].view(-1, 1, 1)
         olens = torch.maximum(alens, vlens)      # logical_or of two prefix masks, summed (:208-209)
         return out, olens

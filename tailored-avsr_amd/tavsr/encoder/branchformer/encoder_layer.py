@@ -97,13 +97,19 @@ class MyBranchformerEncoderLayer(torch.nn.Module):
             if skip:
                 return (x, pos_emb), mask
         merge = self.merge_method
-        if self.training and merge == "learned_ave" and self.attn_branch_drop_rate > 0:
-            raise NotImplementedError("attn_branch_drop_rate > 0 is not used by the shipped configs")
+        cgmlp_weight = self.cgmlp_weight
+        dropped = False
+        if (self.training and self.use_two_branches and merge == "learned_ave" and self.attn_branch_drop_rate > 0
+                and torch.rand(1).item() < self.attn_branch_drop_rate):
+            # encoder_layer.py:233-240: the attention branch is dropped for this step: w1, w2 = 0.0, 1.0 - the merge is a
+            # constant-weight one (the branch still runs and receives zero gradients, the pooling / weight projections
+            # are not part of the step)
+            merge, cgmlp_weight, dropped = "fixed_ave", 1.0, True
         if lens is None and mask is not None:
             lens = mask.squeeze(1).sum(-1).to(torch.int64)
         cfg = dict(heads=self.attn.h if self.attn is not None else 1, ffn_act=self.feed_forward.activation,
                    merge=merge, has_attn=self.attn is not None, has_mlp=self.cgmlp is not None,
-                   cgmlp_weight=self.cgmlp_weight, coeff=coeff,
+                   cgmlp_weight=cgmlp_weight, coeff=coeff,
                    merge_identity=isinstance(self.merge_proj, torch.nn.Identity),
                    # train-mode dropout (self.dropout / PositionwiseFeedForward / csgu: dropout_rate; attention
                    # probabilities: attention_dropout_rate); masks come from the device-resident generator (ops.dropout)
@@ -111,7 +117,9 @@ class MyBranchformerEncoderLayer(torch.nn.Module):
                    p_att=(self.attn.dropout_rate if (self.training and self.attn is not None) else 0.0))
         y = F_.BranchformerLayerFn.apply(x, pos_emb, lens, cfg, *self._params())
         w = cfg.get("_last_w")
-        if w is not None:  # (B,2) -> the reference's (B,1,1) views (encoder_layer.py:286-289)
+        if dropped:
+            self.weight_global, self.weight_local = 0.0, 1.0
+        elif w is not None:  # (B,2) -> the reference's (B,1,1) views (encoder_layer.py:286-289)
             self.weight_global = w[:, 0].view(-1, 1, 1)
             self.weight_local = w[:, 1].view(-1, 1, 1)
         return (y, pos_emb), mask

@@ -475,8 +475,12 @@ class FusionFn(torch.autograd.Function):
         a2, v2 = audio.contiguous().view(B * T, D), video.contiguous().view(B * T, D)
         mp = list(P[:8])
         w1, b1, w2, b2, lw, lb = P[8:14]
-        score, pooled, wts = ops.merge_pool_fwd(a2, v2, alens, mp, B, T, lens2=vlens)
-        m = ops.merge_combine(a2, v2, wts, B, T)
+        if cfg.get("drop_acoustic"):      # constant weights (0, 1): the fused stream is the video stream
+            score = pooled = wts = None
+            m = v2
+        else:
+            score, pooled, wts = ops.merge_pool_fwd(a2, v2, alens, mp, B, T, lens2=vlens)
+            m = ops.merge_combine(a2, v2, wts, B, T)
         h, z = ops.linear(m, w1, b1, act=cfg["act"], save_z=True)
         t_in = _drop_(h, cfg.get("p", 0.0))       # PositionwiseFeedForward's inner dropout (the fusion has no outer one)
         y2 = ops.linear(h, w2, b2)
@@ -503,8 +507,11 @@ class FusionFn(torch.autograd.Function):
             dz = ops.dropout_act_bwd(dh, z, cfg["act"], t_in, out=dh)
         gw1, gb1 = ops.linear_dw(dz, m, bias_grad=True)
         dm = ops.linear_dx(dz, w1)
-        da, dv, mg = ops.merge_bwd(dm, a2, v2, alens, mp, score, pooled, wts, B, T, lens2=vlens)
-        mg = [g.view_as(q) for g, q in zip(mg, mp)]
+        if wts is None:                   # acoustic branch dropped: d/d audio = 0, the merge projections took no part
+            da, dv, mg = torch.zeros_like(dm), dm, [None] * 8
+        else:
+            da, dv, mg = ops.merge_bwd(dm, a2, v2, alens, mp, score, pooled, wts, B, T, lens2=vlens)
+            mg = [g.view_as(q) for g, q in zip(mg, mp)]
         ops.join_side()
         ctx.sv = None
         return (da.view(B, T, D), dv.view(B, T, D), None, None, None, *mg, gw1, gb1, gw2, gb2, glw, glb)

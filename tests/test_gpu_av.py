@@ -498,3 +498,37 @@ def test_batchnorm_backward_with_the_pooled_gradient(N, H, W):
     dx, dg, db = ops.bn_bwd_pooled(dp, idx, x, mean, rstd, g, b, N, H, W, "swish")
     assert rel_err(dg.cpu(), dg_w.cpu()) < 1e-5 and rel_err(db.cpu(), db_w.cpu()) < 1e-5      # other summation order
     assert rel_err(dx.cpu(), dx_w.cpu()) < 1e-5
+
+
+def test_acoustic_branch_drop_matches_the_oracle():
+    """acoustic_branch_drop_rate (src/audiovisual_fusion/adaptive_audiovisual_fusion.py:138-144) at rate 1.0: the fusion
+    runs on the video stream alone - output and gradients against the oracle, no gradient for the merge projections."""
+    from oracle.av import AdaptiveFusionOracle
+    from oracle.model import fill_parameters_, synth
+    from tavsr.audiovisual_fusion.adaptive_audiovisual_fusion import AdaptiveAudioVisualFusion
+    kw = dict(avsr_conf()["audiovisual_fusion_conf"])
+    kw.update(acoustic_branch_drop_rate=1.0, dropout_rate=0.0)
+    fo = AdaptiveFusionOracle(input_size=256, **kw).train()
+    fill_parameters_(fo, seed=82)
+    fg = AdaptiveAudioVisualFusion(input_size=256, **kw)
+    fg.load_state_dict(fo.state_dict())
+    fg = fg.cuda().train()
+    B, T, D = 3, 29, 256
+    am = (torch.arange(T)[None, :] < torch.tensor([29, 20, 11])[:, None])[:, None, :]
+    vm = (torch.arange(T)[None, :] < torch.tensor([27, 22, 11])[:, None])[:, None, :]
+    a, v, r = synth((B, T, D), seed=1), synth((B, T, D), seed=2), synth((B, T, D), seed=3)
+    ao, vo = a.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    yo, lo = fo(ao, am, vo, vm)
+    (yo * r).sum().backward()
+    ag, vg = a.cuda().requires_grad_(True), v.cuda().requires_grad_(True)
+    yg, lg = fg(ag, am.cuda(), vg, vm.cuda())
+    (yg * r.cuda()).sum().backward()
+    assert fg.acoustic_weight == 0.0 and fg.visual_weight == 1.0
+    assert max_rel(yg.detach().cpu(), yo.detach()) < ACT_TOL and torch.equal(lg.cpu(), lo)
+    assert float(ag.grad.abs().max()) == 0.0 and rel_err(vg.grad.cpu(), vo.grad) < GRAD_TOL
+    po = dict(fo.named_parameters())
+    for n, p in fg.named_parameters():
+        if po[n].grad is None:
+            assert p.grad is None, n
+        else:
+            assert grad_ok(p.grad.cpu(), po[n].grad, GRAD_TOL), n

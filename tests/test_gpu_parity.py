@@ -258,3 +258,44 @@ def test_overpadded_batch_is_cut_like_the_reference():
     assert enc.shape[1] == g["enc"].shape[1]
     assert max_rel(enc.cpu(), g["enc"]) < ACT_TOL
     assert rel_err(loss.cpu(), g["loss_eval"]) < 1e-4
+
+
+def test_attention_branch_drop_matches_the_oracle():
+    """attn_branch_drop_rate (src/encoder/branchformer/encoder_layer.py:233-240): with rate 1.0 every training step merges
+    with the constant weights (0, 1) - output, input gradient and parameter gradients against the oracle's same branch;
+    the pooling / weight projections take no part (no gradient), the dropped branch gets zero gradients."""
+    from oracle.model import BranchformerEncoderOracle, fill_parameters_, synth
+    from tavsr.encoder.branchformer.encoder import MyBranchformerEncoder
+    from tavsr.layers import RelPositionalEncoding
+    from oracle import leaves as OL
+    kw = dict(input_size=256, num_blocks=1, input_layer=None, dropout_rate=0.0, positional_dropout_rate=0.0,
+              attention_dropout_rate=0.0, ffn_activation_type="swish", merge_method="learned_ave", attn_branch_drop_rate=1.0)
+    ol = BranchformerEncoderOracle(**kw).encoders[0].train()
+    fill_parameters_(ol, seed=21)
+    pl = MyBranchformerEncoder(**kw).encoders[0]
+    pl.load_state_dict(ol.state_dict())
+    pl = pl.cuda().train()
+    B, T, D = 3, 23, 256
+    lens = torch.tensor([23, 17, 9])
+    mask = (torch.arange(T)[None, :] < lens[:, None])[:, None, :]
+    x = synth((B, T, D), seed=22)
+    r = synth((B, T, D), seed=23)
+    xo, pos = OL.RelPositionalEncoding(D, 0.0)(x)
+    xo = xo.detach().requires_grad_(True)
+    (yo, _), _ = ol((xo, pos), mask)
+    (yo * r).sum().backward()
+    xg, posg = RelPositionalEncoding(D, 0.0)(x.cuda())
+    xg = xg.detach().requires_grad_(True)
+    (yg, _), _ = pl((xg, posg), mask.cuda())
+    (yg * r.cuda()).sum().backward()
+    assert pl.weight_global == 0.0 and pl.weight_local == 1.0
+    assert max_rel(yg.detach().cpu(), yo.detach()) < ACT_TOL
+    assert rel_err(xg.grad.cpu(), xo.grad) < GRAD_TOL
+    po = dict(ol.named_parameters())
+    for n, p in pl.named_parameters():
+        if po[n].grad is None:
+            assert p.grad is None, n                       # pooling_proj* / weight_proj*: not part of the step
+        elif n.startswith("attn.") or n.startswith("norm_mha."):
+            assert float(p.grad.abs().max()) == 0.0 and float(po[n].grad.abs().max()) == 0.0, n
+        else:
+            assert grad_ok(p.grad.cpu(), po[n].grad, GRAD_TOL), n
