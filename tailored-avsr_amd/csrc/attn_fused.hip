@@ -126,10 +126,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   const float* vbase = a.v + (int64_t)b * a.T2 * a.ldv + h * 64 + li;
   const float* pbase = POS ? a.pos + h * 64 + 4 * h2 : nullptr;
 
-  auto raw_tile = [&](int ct) {      // raw^T tile ct -> ring slot ct & 1
-    float pf[32];
+  // All global loads of a key tile (K rows, the next positional tile, the V rows of the context product) are issued
+  // together before its first MFMA: one exposed L2 latency per tile instead of one per product.
+  auto raw_load = [&](int ct, float (&pf)[32]) {
     const int c = min(max(cb0 + 32 * ct + li, 0), W - 1);
     load_row32(pbase + (int64_t)c * a.ldp, pf);
+  };
+  auto raw_mma = [&](int ct, const float (&pf)[32]) {      // raw^T tile ct -> ring slot ct & 1
     f32x16 rt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) rt[r] = 0.f;
@@ -142,20 +145,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 
   for (int kb0 = 0; kb0 < nkt; kb0 += KB) {
     f32x16 st[KB];
-    if (POS && kb0 == 0) raw_tile(0);       // later blocks: tile kb0 was computed as tile jt + 1 of the previous block
+    float vv[KB][32];                         // V^T operands of the context product (two 32-wide d tiles per key row)
+    if (POS && kb0 == 0) {                    // later blocks: tile kb0 was computed as tile jt + 1 of the previous block
+      float pf0[32];
+      raw_load(0, pf0);
+      raw_mma(0, pf0);
+    }
 #pragma unroll
     for (int t = 0; t < KB; ++t) {
       const int jt = kb0 + t;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
       if (jt < nkt) {
-        float kf[32];
+        float kf[32], pf[32];
         const int jr = min(jt * 32 + li, a.T2 - 1);
         load_row32(kbase + (int64_t)jr * a.ldk, kf);
+        if (POS) raw_load(jt + 1, pf);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* vr = vbase + (int64_t)min(jt * 32 + rho(r) + 4 * h2, a.T2 - 1) * a.ldv;
+          vv[t][2 * r] = vr[0];
+          vv[t][2 * r + 1] = vr[32];
+        }
 #pragma unroll
         for (int s = 0; s < 32; ++s) st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qu[s], st[t], 0, 0, 0);
         if (POS) {
-          raw_tile(jt + 1);
+          raw_mma(jt + 1, pf);
           wave_lds_sync();
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -226,14 +241,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int t = 0; t < KB; ++t) {
-      const int j0 = (kb0 + t) * 32;
-      if (j0 < nk) {
+      if (kb0 + t < nkt) {                  // the tiles whose V rows were loaded (a skipped tile's registers are garbage)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float* vr = vbase + (int64_t)min(j0 + rho(r) + 4 * h2, a.T2 - 1) * a.ldv;
-          const float v0 = vr[0], v1 = vr[32];
-          ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[t][r], ot[0], 0, 0, 0);
-          ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[t][r], ot[1], 0, 0, 0);
+          ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[t][2 * r], st[t][r], ot[0], 0, 0, 0);
+          ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[t][2 * r + 1], st[t][r], ot[1], 0, 0, 0);
         }
       }
     }
@@ -313,10 +325,11 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnArgs& a, float* scr, int q
   float* raw_scr = scr;              // ring of two raw^T tiles
   float* ds_scr = scr + 2048;        // ring of two dS^T tiles
 
-  auto raw_tile = [&](int ct) {
-    float pf[32];
+  auto raw_load = [&](int ct, float (&pf)[32]) {
     const int c = min(max(cb0 + 32 * ct + li, 0), W - 1);
     load_row32(pbase + 4 * h2 + (int64_t)c * a.ldp, pf);
+  };
+  auto raw_mma = [&](int ct, const float (&pf)[32]) {
     f32x16 rt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) rt[r] = 0.f;
@@ -326,8 +339,17 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnArgs& a, float* scr, int q
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[(rho(r) + 4 * h2) * 32] = rt[r];
   };
+  auto pt_load = [&](int ct, float (&pt)[32]) {          // P^T operands of dQv for positional tile ct
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = min(max(cb0 + 32 * ct + rho(r) + 4 * h2, 0), W - 1);
+      const float* pr = pbase + (int64_t)c * a.ldp + li;
+      pt[2 * r] = pr[0];
+      pt[2 * r + 1] = pr[32];
+    }
+  };
   // dQv^T += P^T(tile ct) draw^T(tile ct), draw^T[c][i] = dS^T[c - (T-1-i)][i] gathered from the dS^T tiles ct and ct - 1
-  auto dqv_tile = [&](int ct, bool have_cur, bool have_prev) {
+  auto dqv_tile = [&](int ct, bool have_cur, bool have_prev, const float (&pt)[32]) {
     f32x16 dr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -342,32 +364,39 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnArgs& a, float* scr, int q
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = min(max(cb0 + 32 * ct + rho(r) + 4 * h2, 0), W - 1);
-      const float* pr = pbase + (int64_t)c * a.ldp + li;
-      const float p0 = pr[0], p1 = pr[32];
-      gv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0, dr[r], gv[0], 0, 0, 0);
-      gv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1, dr[r], gv[1], 0, 0, 0);
+      gv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[2 * r], dr[r], gv[0], 0, 0, 0);
+      gv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[2 * r + 1], dr[r], gv[1], 0, 0, 0);
     }
   };
 
-  if (POS && nkt > 0) raw_tile(0);
+  if (POS && nkt > 0) {
+    float pf0[32];
+    raw_load(0, pf0);
+    raw_mma(0, pf0);
+  }
   for (int jt = 0; jt < nkt; ++jt) {
+    // ---- every global load of this key tile up front: one exposed L2 latency per tile instead of one per product
+    float kf[32], vf[32], pf[32], kt[32], pt[32];
+    const int jr = min(jt * 32 + li, a.T2 - 1);
+    load_row32(kbase + 4 * h2 + (int64_t)jr * a.ldk, kf);
+    load_row32(vbase + (int64_t)jr * a.ldv, vf);
+    if (POS) raw_load(jt + 1, pf);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* kr = kbase + (int64_t)min(jt * 32 + rho(r) + 4 * h2, a.T2 - 1) * a.ldk + li;
+      kt[2 * r] = kr[0];
+      kt[2 * r + 1] = kr[32];
+    }
+    if (POS) pt_load(jt, pt);
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
-    {
-      float kf[32];
-      const int jr = min(jt * 32 + li, a.T2 - 1);
-      load_row32(kbase + 4 * h2 + (int64_t)jr * a.ldk, kf);
 #pragma unroll
-      for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qu[s], st, 0, 0, 0);
-      float vf[32];
-      load_row32(vbase + (int64_t)jr * a.ldv, vf);
+    for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qu[s], st, 0, 0, 0);
 #pragma unroll
-      for (int s = 0; s < 32; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], dof[s], dp, 0, 0, 0);
-    }
+    for (int s = 0; s < 32; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], dof[s], dp, 0, 0, 0);
     if (POS) {
-      raw_tile(jt + 1);
+      raw_mma(jt + 1, pf);
       wave_lds_sync();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -402,10 +431,8 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnArgs& a, float* scr, int q
     // dQu^T += K^T dS^T
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float* kr = kbase + (int64_t)min(jt * 32 + rho(r) + 4 * h2, a.T2 - 1) * a.ldk + li;
-      const float k0 = kr[0], k1 = kr[32];
-      gu[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, st[r], gu[0], 0, 0, 0);
-      gu[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, st[r], gu[1], 0, 0, 0);
+      gu[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[2 * r], st[r], gu[0], 0, 0, 0);
+      gu[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[2 * r + 1], st[r], gu[1], 0, 0, 0);
     }
     if (POS) {
       wave_lds_sync();                                // raw reads done; dS^T slot (jt & 1) free (tile jt - 2 consumed)
@@ -413,12 +440,14 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnArgs& a, float* scr, int q
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[(rho(r) + 4 * h2) * 32] = st[r];
       wave_lds_sync();
-      dqv_tile(jt, true, jt > 0);
+      dqv_tile(jt, true, jt > 0, pt);
     }
   }
   if (POS && nkt > 0) {
+    float pt[32];
+    pt_load(nkt, pt);
     wave_lds_sync();
-    dqv_tile(nkt, false, true);                       // the positional rows only the last key tile reaches
+    dqv_tile(nkt, false, true, pt);                   // the positional rows only the last key tile reaches
   }
   if (i < a.T1) {
     float* o = a.dq + (int64_t)(b * a.T1 + i) * a.lddq + h * 64 + 4 * h2;
@@ -462,14 +491,32 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnArgs& a, float* scr, int 
   const int it0 = a.causal ? (j0 >> 5) : 0;       // causal: queries i >= j
   const float* ubias = a.bias_u ? a.bias_u + h * 64 : nullptr;
   const float* vbias = (POS && a.bias_v) ? a.bias_v + h * 64 : nullptr;
+  const float ub0 = ubias ? ubias[li] : 0.f, ub1 = ubias ? ubias[32 + li] : 0.f;
   for (int it = it0; it < nqt && live; ++it) {
     const int i0 = it * 32;
     const int irow = min(i0 + li, a.T1 - 1);
+    // ---- every global load of this query tile up front (one exposed L2 latency per tile instead of one per product):
+    //      rows i of dO, ctx, q (k-contiguous A operands), the bias rows, the two positional tiles, and the row-contiguous
+    //      dO / q operands of the dV / dK products
+    float dof[32], cf[32], qf[32], qa[32], pf0[32], pf1[32], dq_[32], qq_[32];
+    load_row32(a.dout + (int64_t)(b * a.T1 + irow) * a.ldo + h * 64 + 4 * h2, dof);
+    load_row32(a.ctx + (int64_t)(b * a.T1 + irow) * a.ldo + h * 64 + 4 * h2, cf);
+    load_row32(a.q + (int64_t)(b * a.T1 + irow) * a.ldq + h * 64 + 4 * h2, qf);
+    const int cb = a.T1 - 1 - i0 - 31 + j0;          // raw[i][c]: c = cb + 32*ct' + lane for the two positional tiles touched
+    if (POS) {
+      load_row32(a.pos + h * 64 + 4 * h2 + (int64_t)min(max(cb + li, 0), W - 1) * a.ldp, pf0);
+      load_row32(a.pos + h * 64 + 4 * h2 + (int64_t)min(max(cb + 32 + li, 0), W - 1) * a.ldp, pf1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = min(i0 + rho(r) + 4 * h2, a.T1 - 1);
+      const float* dr = a.dout + (int64_t)(b * a.T1 + i) * a.ldo + h * 64 + li;
+      const float* qr = a.q + (int64_t)(b * a.T1 + i) * a.ldq + h * 64 + li;
+      dq_[2 * r] = dr[0]; dq_[2 * r + 1] = dr[32];
+      qq_[2 * r] = qr[0] + ub0; qq_[2 * r + 1] = qr[32] + ub1;
+    }
     // per-row statistics of this query tile: lane li (both halves) handles row i0 + li
     {
-      float dof[32], cf[32];
-      load_row32(a.dout + (int64_t)(b * a.T1 + irow) * a.ldo + h * 64 + 4 * h2, dof);
-      load_row32(a.ctx + (int64_t)(b * a.T1 + irow) * a.ldo + h * 64 + 4 * h2, cf);
       float Di = 0.f;
 #pragma unroll
       for (int s = 0; s < 32; ++s) Di += dof[s] * cf[s];
@@ -483,50 +530,39 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnArgs& a, float* scr, int 
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
-    {
-      // A operands: rows i of (q + u) and dO, k-contiguous
-      float qf[32];
-      load_row32(a.q + (int64_t)(b * a.T1 + irow) * a.ldq + h * 64 + 4 * h2, qf);
-      float qa[32];
 #pragma unroll
-      for (int s = 0; s < 32; ++s) qa[s] = qf[s];
-      if (ubias) {
-        float t[32];
-        load_row32(ubias + 4 * h2, t);
+    for (int s = 0; s < 32; ++s) qa[s] = qf[s];
+    if (ubias) {
+      float t[32];
+      load_row32(ubias + 4 * h2, t);
 #pragma unroll
-        for (int s = 0; s < 32; ++s) qa[s] += t[s];
-      }
-#pragma unroll
-      for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kf[s], st, 0, 0, 0);
-      if (POS) {
-        if (vbias) {
-          float t[32];
-          load_row32(vbias + 4 * h2, t);
-#pragma unroll
-          for (int s = 0; s < 32; ++s) qf[s] += t[s];
-        }
-        // raw[i][c] for the two positional tiles this (query tile, key tile) pair touches: c = cb + 32*ct' + lane
-        const int cb = a.T1 - 1 - i0 - 31 + j0;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          float pf[32];
-          const int c = min(max(cb + 32 * ct + li, 0), W - 1);
-          load_row32(a.pos + h * 64 + 4 * h2 + (int64_t)c * a.ldp, pf);
-          f32x16 rt;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rt[r] = 0.f;
-#pragma unroll
-          for (int s = 0; s < 32; ++s) rt = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s], pf[s], rt, 0, 0, 0);
-          float* dst = raw_scr + ct * 1024 + li;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dst[(rho(r) + 4 * h2) * 32] = rt[r];
-        }
-      }
-      float dof[32];
-      load_row32(a.dout + (int64_t)(b * a.T1 + irow) * a.ldo + h * 64 + 4 * h2, dof);
-#pragma unroll
-      for (int s = 0; s < 32; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dof[s], vf[s], dp, 0, 0, 0);
+      for (int s = 0; s < 32; ++s) qa[s] += t[s];
     }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kf[s], st, 0, 0, 0);
+    if (POS) {
+      if (vbias) {
+        float t[32];
+        load_row32(vbias + 4 * h2, t);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) qf[s] += t[s];
+      }
+      f32x16 rt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rt[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) rt = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s], pf0[s], rt, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) raw_scr[(rho(r) + 4 * h2) * 32 + li] = rt[r];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rt[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) rt = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s], pf1[s], rt, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) raw_scr[1024 + (rho(r) + 4 * h2) * 32 + li] = rt[r];
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dof[s], vf[s], dp, 0, 0, 0);
     wave_lds_sync();
     const uint64_t sd = a.thr ? a.seed[0] : 0;
     const int T2p = (a.T2 + 3) & ~3;
@@ -557,16 +593,10 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnArgs& a, float* scr, int 
     // dV^T += dO^T Pd ;  dK^T += Qu^T dS   (A operands: dword loads along d of rows i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = min(i0 + rho(r) + 4 * h2, a.T1 - 1);
-      const float* dr = a.dout + (int64_t)(b * a.T1 + i) * a.ldo + h * 64 + li;
-      const float* qr = a.q + (int64_t)(b * a.T1 + i) * a.ldq + h * 64 + li;
-      const float d0 = dr[0], d1 = dr[32];
-      float q0 = qr[0], q1 = qr[32];
-      if (ubias) { q0 += ubias[li]; q1 += ubias[32 + li]; }
-      gvv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, pd[r], gvv[0], 0, 0, 0);
-      gvv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, pd[r], gvv[1], 0, 0, 0);
-      gk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, st[r], gk[0], 0, 0, 0);
-      gk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, st[r], gk[1], 0, 0, 0);
+      gvv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dq_[2 * r], pd[r], gvv[0], 0, 0, 0);
+      gvv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dq_[2 * r + 1], pd[r], gvv[1], 0, 0, 0);
+      gk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qq_[2 * r], st[r], gk[0], 0, 0, 0);
+      gk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qq_[2 * r + 1], st[r], gk[1], 0, 0, 0);
     }
   }
   if (j < a.T2) {
