@@ -385,12 +385,13 @@ __global__ __launch_bounds__(512) void merge_pool_fwd_kernel(const float* __rest
                                                              const int64_t* __restrict__ lens2, MergeParams p,
                                                              float* __restrict__ score, float* __restrict__ pooled,
                                                              float* __restrict__ wout, int B, int T, int D) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int k = threadIdx.x >> 8;            // branch of this half
   const int ht = threadIdx.x & 255;          // thread within the half
+  const int T2 = (2 * T + 3) & ~3;           // regions start on 16-byte boundaries (float4 LDS accesses below)
   float* s_sc = sm + k * T;                  // [2][T]
-  float* s_red = sm + 2 * T + k * 4;         // [2][4]
-  float* s_w = sm + 2 * T + 8;               // [2] branch logits
+  float* s_red = sm + T2 + k * 4;            // [2][4]
+  float* s_w = sm + T2 + 8;                  // [2] branch logits
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = ht >> 6;
   const int64_t* lk = (k == 1 && lens2) ? lens2 : lens;     // per-branch valid length (AV fusion: audio / video masks)
   const int len = lk ? (int)min((int64_t)T, lk[b]) : T;
@@ -412,18 +413,26 @@ __global__ __launch_bounds__(512) void merge_pool_fwd_kernel(const float* __rest
     score[((int64_t)k * B + b) * T + t] = v;
   }
   __syncthreads();
+  // pooled_k = sum_t score[t] x[t,:]: the four waves of the half take rows t = wv, wv + 4, ... with 16-byte lanes along the
+  // channels (a quarter of the serial chain of a thread-per-channel loop), partial sums meet in LDS
+  float* s_part = sm + T2 + 16;                    // [2][4][D]
+  {
+    const int D4 = D >> 2;
+    for (int c4 = lane; c4 < D4; c4 += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = wv; t < len; t += 4) {
+        const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)t * D)[c4];
+        const float sv = s_sc[t];
+        acc.x += sv * xv.x; acc.y += sv * xv.y; acc.z += sv * xv.z; acc.w += sv * xv.w;
+      }
+      *reinterpret_cast<float4*>(s_part + (k * 4 + wv) * D + 4 * c4) = acc;
+    }
+  }
+  __syncthreads();
   float wacc = 0.f;
   for (int c = ht; c < D; c += 256) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int t = 0;
-    for (; t + 3 < len; t += 4) {
-      a0 += s_sc[t] * x[(int64_t)t * D + c];
-      a1 += s_sc[t + 1] * x[(int64_t)(t + 1) * D + c];
-      a2 += s_sc[t + 2] * x[(int64_t)(t + 2) * D + c];
-      a3 += s_sc[t + 3] * x[(int64_t)(t + 3) * D + c];
-    }
-    for (; t < len; ++t) a0 += s_sc[t] * x[(int64_t)t * D + c];
-    const float acc = (a0 + a1) + (a2 + a3);
+    const float* pp = s_part + k * 4 * D + c;
+    const float acc = (pp[0] + pp[D]) + (pp[2 * D] + pp[3 * D]);
     pooled[((int64_t)k * B + b) * D + c] = acc;
     wacc += acc * p.ww[k][c];
   }
@@ -459,12 +468,13 @@ __global__ __launch_bounds__(512) void merge_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ pooled, const float* __restrict__ w,
                                                         float* __restrict__ dx1, float* __restrict__ dx2,
                                                         float* __restrict__ part, int B, int T, int D) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int k = threadIdx.x >> 8, ht = threadIdx.x & 255;
+  const int T2 = (2 * T + 3) & ~3;          // regions start on 16-byte boundaries (float4 LDS accesses below)
   float* s_ds = sm + k * T;                 // [2][T]  d(score) then ds_pre
-  float* s_dp = sm + 2 * T + k * D;         // [2][D]  dpooled
-  float* s_red = sm + 2 * T + 2 * D + k * 4;   // [2][4]
-  float* s_a = sm + 2 * T + 2 * D + 8;      // [2][8] per-wave partials of <dm,x1>, <dm,x2>
+  float* s_dp = sm + T2 + k * D;            // [2][D]  dpooled
+  float* s_red = sm + T2 + 2 * D + k * 4;   // [2][4]
+  float* s_a = sm + T2 + 2 * D + 8;         // [2][8] per-wave partials of <dm,x1>, <dm,x2>
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = ht >> 6, wv8 = threadIdx.x >> 6;
   const int64_t* lk = (k == 1 && lens2) ? lens2 : lens;
   const int len = lk ? (int)min((int64_t)T, lk[b]) : T;
@@ -522,33 +532,31 @@ __global__ __launch_bounds__(512) void merge_bwd_kernel(const float* __restrict_
     pb[4 * D + k] = sb;            // dbp_k
     pb[4 * D + 2 + k] = dweight;   // dbw_k
   }
-  // dx_k and dwp_k: thread = channel, four time steps per iteration in flight
+  // dx_k and dwp_k: the four waves of the half take rows t = wv, wv + 4, ... with 16-byte lanes along the channels;
+  // the dwp partials of the waves meet in LDS
+  float* s_part = sm + T2 + 2 * D + 32;            // [2][4][D]
+  {
+    const int D4 = D >> 2;
+    for (int c4 = lane; c4 < D4; c4 += 64) {
+      const float4 wpc = reinterpret_cast<const float4*>(p.wp[k])[c4];
+      const float4 dpc = *reinterpret_cast<const float4*>(s_dp + 4 * c4);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = wv; t < T; t += 4) {
+        const int64_t o = (int64_t)t * D + 4 * c4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + o);
+        const float4 gv = *reinterpret_cast<const float4*>(dm + base + o);
+        const float sv = t < len ? sc[t] : 0.f, dsv = s_ds[t];
+        *reinterpret_cast<float4*>(dx + o) = make_float4(wk * gv.x + sv * dpc.x + dsv * wpc.x, wk * gv.y + sv * dpc.y + dsv * wpc.y,
+                                                          wk * gv.z + sv * dpc.z + dsv * wpc.z, wk * gv.w + sv * dpc.w + dsv * wpc.w);
+        acc.x += dsv * xv.x; acc.y += dsv * xv.y; acc.z += dsv * xv.z; acc.w += dsv * xv.w;
+      }
+      *reinterpret_cast<float4*>(s_part + (k * 4 + wv) * D + 4 * c4) = acc;
+    }
+  }
+  __syncthreads();
   for (int c = ht; c < D; c += 256) {
-    const float wpc = p.wp[k][c], dpc = s_dp[c];
-    float acc = 0.f;
-    int t = 0;
-    for (; t + 3 < T; t += 4) {
-      float xv[4], gv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t o = (int64_t)(t + i) * D + c;
-        xv[i] = x[o];
-        gv[i] = dm[base + o];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float s = t + i < len ? sc[t + i] : 0.f;
-        dx[(int64_t)(t + i) * D + c] = wk * gv[i] + s * dpc + s_ds[t + i] * wpc;
-        acc += s_ds[t + i] * xv[i];
-      }
-    }
-    for (; t < T; ++t) {
-      const int64_t o = (int64_t)t * D + c;
-      const float s = t < len ? sc[t] : 0.f;
-      dx[o] = wk * dm[base + o] + s * dpc + s_ds[t] * wpc;
-      acc += s_ds[t] * x[o];
-    }
-    pb[k * D + c] = acc;  // dwp_k
+    const float* pp = s_part + k * 4 * D + c;
+    pb[k * D + c] = (pp[0] + pp[D]) + (pp[2 * D] + pp[3 * D]);  // dwp_k
   }
 }
 
@@ -634,7 +642,7 @@ extern "C" int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int6
   if (B <= 0) return TAVSR_OK;
   TAVSR_REQUIRE(D % 4 == 0 && ((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0), TAVSR_EALIGN,
                 "merge_pool_fwd: D %% 4 == 0 and 16-byte aligned rows required");
-  size_t lds = (2 * T + 16) * sizeof(float);
+  size_t lds = (2 * T + 4 + 16 + 8 * D) * sizeof(float);
   TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_pool_fwd: T=%d too long", T);
   hipLaunchKernelGGL(merge_pool_fwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, x1, x2, lens, lens2, mk(params),
                      score, pooled, w, B, T, D);
@@ -667,7 +675,7 @@ extern "C" int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2
   if (B <= 0) return TAVSR_OK;
   TAVSR_REQUIRE(D % 4 == 0 && ((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0) && ((uintptr_t)dm % 16 == 0),
                 TAVSR_EALIGN, "merge_bwd: D %% 4 == 0 and 16-byte aligned rows required");
-  size_t lds = (2 * T + 2 * D + 32) * sizeof(float);
+  size_t lds = (2 * T + 4 + 2 * D + 32 + 8 * D) * sizeof(float);
   TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_bwd: T=%d too long", T);
   hipLaunchKernelGGL(merge_bwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, dm, x1, x2, lens, lens2, mk(params), score,
                      pooled, w, dx1, dx2, ws, B, T, D);

@@ -429,9 +429,7 @@ class BranchformerLayerFn(torch.autograd.Function):
                 for j, nm in enumerate(("q", "k", "v")):   # three problems with their own outputs (no sliced gradients)
                     gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
                     put(f"attn.linear_{nm}.weight", gw_); put(f"attn.linear_{nm}.bias", gb_)
-                dn_a = ops.linear_dx(dqkv[:, :D], p("attn.linear_q.weight"))
-                ops.linear_dx(dqkv[:, D:2 * D], p("attn.linear_k.weight"), res=dn_a, out=dn_a)
-                ops.linear_dx(dqkv[:, 2 * D:], p("attn.linear_v.weight"), res=dn_a, out=dn_a)
+                dn_a = ops.linear_dx_cat(dqkv, [p(f"attn.linear_{c}.weight") for c in "qkv"])    # one K = 3D GEMM
         if has_mlp:
             mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_xm = sv["mlp"]
             Cn = g.shape[1] // 2
@@ -784,11 +782,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             for j, nm in enumerate(("k", "v")):
                 gw_, gb_ = grp.add(dkv[:, j * D:(j + 1) * D], mem2, bias_grad=True)
                 put(f"src_attn.linear_{nm}.weight", gw_); put(f"src_attn.linear_{nm}.bias", gb_)
-            if dmem is None:
-                dmem = ops.linear_dx(dkv[:, :D], p("src_attn.linear_k.weight"))
-            else:
-                ops.linear_dx(dkv[:, :D], p("src_attn.linear_k.weight"), res=dmem, out=dmem)
-            ops.linear_dx(dkv[:, D:], p("src_attn.linear_v.weight"), res=dmem, out=dmem)
+            dmem = ops.linear_dx_cat(dkv, [p("src_attn.linear_k.weight"), p("src_attn.linear_v.weight")], res=dmem, out=dmem)
             dn2 = ops.linear_dx(dq2, p("src_attn.linear_q.weight"))
             dx1, g1, g2 = lng.bwd(dn2, x1, m2, r2, p("norm2.weight"), dx_add=dx2)
             put("norm2.weight", g1); put("norm2.bias", g2)
@@ -808,9 +802,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             for j, nm in enumerate(("q", "k", "v")):
                 gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n1, bias_grad=True)
                 put(f"self_attn.linear_{nm}.weight", gw_); put(f"self_attn.linear_{nm}.bias", gb_)
-            dn1 = ops.linear_dx(dqkv[:, :D], p("self_attn.linear_q.weight"))
-            ops.linear_dx(dqkv[:, D:2 * D], p("self_attn.linear_k.weight"), res=dn1, out=dn1)
-            ops.linear_dx(dqkv[:, 2 * D:], p("self_attn.linear_v.weight"), res=dn1, out=dn1)
+            dn1 = ops.linear_dx_cat(dqkv, [p(f"self_attn.linear_{c}.weight") for c in "qkv"])
             dx, g1, g2 = lng.bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1)
             put("norm1.weight", g1); put("norm1.bias", g2)
             grp.flush()

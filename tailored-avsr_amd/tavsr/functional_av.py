@@ -386,9 +386,7 @@ class TailoredStreamFn(torch.autograd.Function):
             G["attn.linear_pos.weight"] = ops.linear_dw(dp, ctx.pos_emb.reshape(-1, D))
             for j, nm in enumerate(("q", "k", "v")):
                 G[f"attn.linear_{nm}.weight"], G[f"attn.linear_{nm}.bias"] = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
-            dn = ops.linear_dx(dqkv[:, :D], p["attn.linear_q.weight"])
-            ops.linear_dx(dqkv[:, D:2 * D], p["attn.linear_k.weight"], res=dn, out=dn)
-            ops.linear_dx(dqkv[:, 2 * D:], p["attn.linear_v.weight"], res=dn, out=dn)
+            dn = ops.linear_dx_cat(dqkv, [p[f"attn.linear_{c}.weight"] for c in "qkv"])      # one K = 3D GEMM
             dx1, G["norm_mha.weight"], G["norm_mha.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2)
         else:
             mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br = sv["br"]

@@ -154,6 +154,19 @@ def linear_dx(dy, w, *, alpha=1.0, DZ=None, dact=None, res=None, out=None, force
     return out
 
 
+def linear_dx_cat(dy_cat, ws, *, res=None, out=None):
+    """dx = res + sum_j dy_j @ w_j for projections of ONE input whose output gradients sit side by side in ``dy_cat``
+    [M, sum_j N_j] (query / key / value): the weights are stacked into one [sum_j N_j, K] operand (one multi-tensor copy)
+    and the sum over j becomes the K loop of a single GEMM instead of a chain of accumulating launches."""
+    K = ws[0].shape[1]
+    rows = [w.shape[0] for w in ws]
+    assert dy_cat.shape[1] == sum(rows) and all(w.shape[1] == K and w.is_contiguous() for w in ws)
+    wcat = empty(sum(rows), K, like=dy_cat)
+    offs = [sum(rows[:j]) for j in range(len(ws))]
+    multi_copy_([wcat[o: o + r] for o, r in zip(offs, rows)], list(ws))
+    return linear_dx(dy_cat, wcat, res=res, out=out)
+
+
 # Weight-gradient GEMMs have few output tiles and a long K (= B*T rows): alone they fill a fraction of the 256 CUs.
 # They are leaves of the backward graph, so they are issued on a side stream and run beside the data-gradient chain
 # of the main stream (inside a captured hipGraph this is simply a parallel branch).  Every backward Function calls
