@@ -41,7 +41,7 @@ const char* tavsr_last_error_string(void);   /* host string, thread-local */
  * Conv2dSubsampling conv (as im2col GEMM) and out Linear (encoder.py:149-155,364), ctc_lo
  * (src/ctc/ctc.py:143), decoder projections (espnet_model.py:557-560) - and their backward.
  *
- *   C[z][m][n] = R[z][m][n] + alpha * act( sum_k A(z,m,k) * B(z,k,n) + bias[n] ) * act'(DZ[z][m][n])
+ *   C[z][m][n] = R[z][m][n] + alpha * dropout( act( sum_k A(z,m,k) * B(z,k,n) + bias[n] ) * act'(DZ[z][m][n]) )
  *
  *   A(z,m,k) = A[z*sA + (a_kmajor ? k*lda + m : m*lda + k)]
  *   B(z,k,n) = B[z*sB + (b_kmajor ? k*ldb + n : n*ldb + k)]     (b_kmajor=0 is torch's W[N,K])
@@ -81,6 +81,15 @@ typedef struct tavsr_gemm_desc {
   int32_t conv_mode, conv_H, conv_W, conv_C;
   const float* conv_zero;
   int32_t conv_stride, conv_taps;
+  /* train-mode dropout in the epilogue (drop_p > 0): element (m, n) keeps iff word (n & 3) of the Philox counter
+     drop_offset/4 + (m*N + n)/4 of *drop_seed is >= drop_p * 2^32 - exactly the mask tavsr_dropout draws for the
+     contiguous [M][N] result at that offset, so either side of a forward / backward pair may be the fused or the
+     stand-alone form (x + s * dropout(f(x)) of encoder_layer.py:194,309,314; PositionwiseFeedForward's inner dropout and
+     its backward mask * act'(z)).  Unbatched plain GEMMs on the 16-byte path only (N % 4 == 0, aligned operands,
+     K % 32 == 0 or the K-tail variant): otherwise TAVSR_EUNSUPPORTED and nothing is launched. */
+  float drop_p;
+  const uint64_t* drop_seed;
+  uint64_t drop_offset;
 } tavsr_gemm_desc;
 
 int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);

@@ -78,6 +78,17 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs arg
   }
   const int64_t o = z1 * d.sC1 + z2 * d.sC2 + (int64_t)m * d.ldc + n;
   const int64_t ro = z1 * d.sR1 + z2 * d.sR2 + (int64_t)m * d.ldr + n;
+  uint32_t keep[4] = {1u, 1u, 1u, 1u};
+  float inv_keep = 1.f;
+  if (V == 4 && d.drop_p > 0.f) {        // the four columns of this thread are one Philox call (host: unbatched, N % 4 == 0)
+    const uint64_t sd = d.drop_seed[0], ctr = (d.drop_offset >> 2) + (uint64_t)(i >> 2);
+    const uint32_t thr = (uint32_t)((double)d.drop_p * 4294967296.0);
+    uint32_t w[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), w);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) keep[q] = w[q] >= thr;
+    inv_keep = 1.f / (1.f - d.drop_p);
+  }
 #pragma unroll
   for (int q = 0; q < V; ++q) {
     float x = v[q];
@@ -85,6 +96,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs arg
     if (d.Z) d.Z[o + q] = x;
     x = act_fwd(d.act, x);
     if (d.DZ) x *= act_bwd(d.dact, d.DZ[o + q]);
+    x = keep[q % 4] ? x * inv_keep : 0.f;
     x *= d.alpha;
     if (d.R) x += d.R[ro + q];
     d.C[o + q] = x;
@@ -475,6 +487,15 @@ __device__ __forceinline__ void finish_tile_vec(const tavsr_gemm_desc& d, int ns
       if (DZ) {
         const float4 z = *reinterpret_cast<const float4*>(DZ + o);
         v.x *= act_bwd(d.dact, z.x); v.y *= act_bwd(d.dact, z.y); v.z *= act_bwd(d.dact, z.z); v.w *= act_bwd(d.dact, z.w);
+      }
+      if (d.drop_p > 0.f) {              // one Philox call per 16-byte group (the mask tavsr_dropout draws for [M][N])
+        const uint64_t sd = d.drop_seed[0], ctr = (d.drop_offset >> 2) + (uint64_t)(((int64_t)m * d.N + n) >> 2);
+        const uint32_t thr = (uint32_t)((double)d.drop_p * 4294967296.0);
+        const float ik = 1.f / (1.f - d.drop_p);
+        uint32_t w[4];
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), w);
+        v.x = w[0] >= thr ? v.x * ik : 0.f; v.y = w[1] >= thr ? v.y * ik : 0.f;
+        v.z = w[2] >= thr ? v.z * ik : 0.f; v.w = w[3] >= thr ? v.w * ik : 0.f;
       }
       v.x *= d.alpha; v.y *= d.alpha; v.z *= d.alpha; v.w *= d.alpha;
       if (R) {
@@ -1105,6 +1126,7 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
   const bool fast = glds_ok(d, vec);
   if (d.conv_mode != 0) {       // implicit 3x3/s1/p1 convolution: only the LDS-DMA kernel reads images as patch operands
     TAVSR_REQUIRE(d.conv_mode == 1 || d.conv_mode == 2, TAVSR_EINVAL, "tavsr_gemm: conv_mode must be 0, 1 or 2");
+    TAVSR_REQUIRE(d.drop_p == 0.f, TAVSR_EUNSUPPORTED, "tavsr_gemm: no epilogue dropout on convolution operands");
     TAVSR_REQUIRE(d.conv_zero && aligned16(d.conv_zero) && d.conv_H > 0 && d.conv_W > 0 && d.conv_C > 0, TAVSR_EINVAL,
                   "tavsr_gemm: conv needs H, W, C and a 16-byte aligned zero page");
     TAVSR_REQUIRE(d.nb1 * d.nb2 == 1 && fast && force_cfg < 0, TAVSR_EUNSUPPORTED,
@@ -1125,6 +1147,12 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
     return launch_conv(d, pc.nsplit, pc.kchunk, s);
   }
   const bool tail = !fast && force_cfg < 0 && tail_ok(d, vec);
+  if (d.drop_p > 0.f) {
+    TAVSR_REQUIRE(d.drop_p < 1.f && d.drop_seed && d.drop_offset % 4 == 0, TAVSR_EINVAL,
+                  "tavsr_gemm: dropout needs p in (0, 1), a device seed and an offset %% 4 == 0");
+    TAVSR_REQUIRE((fast || tail) && force_cfg < 0 && d.nb1 * d.nb2 == 1 && vec_epi_ok(d), TAVSR_EUNSUPPORTED,
+                  "tavsr_gemm: epilogue dropout needs an unbatched problem on the 16-byte path");
+  }
   Plan p = plan(d, can_split, fast || tail);
   if (tail) {
     if (p.nsplit > 1 && d.ws_floats < ws_floats_for(d, p.nsplit)) p = plan(d, false, true);
@@ -1167,7 +1195,7 @@ extern "C" int tavsr_gemm_grouped(const tavsr_gemm_desc* descs, int32_t n, tavsr
     TAVSR_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, TAVSR_EINVAL, "tavsr_gemm_grouped: bad problem %d", i);
     TAVSR_REQUIRE(d.a_kmajor == descs[0].a_kmajor && d.b_kmajor == descs[0].b_kmajor, TAVSR_EUNSUPPORTED,
                   "tavsr_gemm_grouped: all problems must share one layout");
-    TAVSR_REQUIRE(d.nb1 * d.nb2 == 1, TAVSR_EUNSUPPORTED, "tavsr_gemm_grouped: unbatched problems only");
+    TAVSR_REQUIRE(d.nb1 * d.nb2 == 1 && d.drop_p == 0.f, TAVSR_EUNSUPPORTED, "tavsr_gemm_grouped: unbatched problems without epilogue dropout only");
     const bool vec = aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0;
     TAVSR_REQUIRE(glds_ok(d, vec), TAVSR_EUNSUPPORTED,
                   "tavsr_gemm_grouped: problem %d needs the predicated kernel (alignment / K %% 32 / rows %% 4)", i);

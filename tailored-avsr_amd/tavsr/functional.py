@@ -54,14 +54,8 @@ class _FFN:
             y, (n, mean, rstd, z, h, t_in, t_out) = ops.ffn_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=p, save=save)
             return y, ("fused", x, mean, rstd, n, z, h, t_in, t_out)
         n, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, eps)
-        h, z = ops.linear(n, w1, b1, act=act, save_z=True)
-        t_in = _drop_(h, p)
-        if p and p > 0.0:
-            t = ops.linear(h, w2, b2)
-            y, t_out = ops.dropout_add(x, t, p, alpha=scale)       # x + scale * dropout(t), one pass
-        else:
-            t_out = None
-            y = ops.linear(h, w2, b2, alpha=scale, res=x)
+        h, z, t_in = ops.linear_drop(n, w1, b1, p, act=act, save_z=True)         # both dropouts ride in the GEMM epilogues
+        y, t_out = ops.linear_drop(h, w2, b2, p, alpha=scale, res=x)             # x + scale * dropout(.)
         return y, (x, mean, rstd, n, z, h, t_in, t_out)
 
     @staticmethod
@@ -78,11 +72,7 @@ class _FFN:
         if fused:
             dz, dn = ops.ffn_bwd_dx(dyd, scale, w1, w2, z, act, t_in)
         else:
-            if t_in is None:
-                dz = ops.linear_dx(dyd, w2, alpha=scale, DZ=z, dact=act)
-            else:
-                dh = ops.linear_dx(dyd, w2, alpha=scale)
-                dz = ops.dropout_act_bwd(dh, z, act, t_in, out=dh)     # inner mask and act'(z), one pass
+            dz = ops.linear_dx_drop(dyd, w2, t_in, alpha=scale, DZ=z, dact=act)    # inner mask and act'(z) in the epilogue
         gw1, gb1 = wgrad(dz, n, bias_grad=True)
         if not fused:
             dn = ops.linear_dx(dz, w1)
@@ -274,8 +264,7 @@ class BranchformerLayerFn(torch.autograd.Function):
                     ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), out=cat, out_off=0, ldc=2 * D)
                     xa = cat[:, :D]
                 else:
-                    xa = ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"))
-                    t_xa = _drop_(xa, pd)                       # x1 = dropout(x_att)  (encoder_layer.py:212)
+                    xa, t_xa = ops.linear_drop(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), pd)   # x1 = dropout(x_att)  (encoder_layer.py:212)
                 sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
         if has_mlp:
             n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mlp.weight"), p("norm_mlp.bias"), EPS_ESPNET)
@@ -293,8 +282,7 @@ class BranchformerLayerFn(torch.autograd.Function):
                            ldc=2 * D)
                 xm = cat[:, D:]
             else:
-                xm = ops.linear(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"))
-                t_xm = _drop_(xm, pd)                       # x2 = dropout(x2)  (encoder_layer.py:224)
+                xm, t_xm = ops.linear_drop(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"), pd)   # x2 = dropout(x2)  (encoder_layer.py:224)
             sv["mlp"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_xm)
         br.join()
         t_cat = _drop_(cat, pd) if (merge == "concat" and cat is not None) else None   # both halves in one call (iid)
@@ -322,11 +310,8 @@ class BranchformerLayerFn(torch.autograd.Function):
             if pd > 0.0:                                    # x + coeff * dropout(x1 | x2)  (encoder_layer.py:302-309)
                 md, t_m = ops.dropout(m.contiguous(), pd)
             x2 = ops.axpby(x1, md, 1.0, coeff)
-        elif pd > 0.0:                                      # x + coeff * dropout(merge_proj(.))  (:232-300)
-            t = ops.linear(m, p("merge_proj.weight"), p("merge_proj.bias"))
-            x2, t_m = ops.dropout_add(x1, t, pd, alpha=coeff)
-        else:
-            x2 = ops.linear(m, p("merge_proj.weight"), p("merge_proj.bias"), alpha=coeff, res=x1)
+        else:                                               # x + coeff * dropout(merge_proj(.))  (:232-300)
+            x2, t_m = ops.linear_drop(m, p("merge_proj.weight"), p("merge_proj.bias"), pd, alpha=coeff, res=x1)
         sv["drop"] = (t_cat, t_m)
         x3, sv["ff"] = _FFN.fwd(x2, p("norm_ff.weight"), p("norm_ff.bias"), p("feed_forward.w_1.weight"),
                                 p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
@@ -437,7 +422,7 @@ class BranchformerLayerFn(torch.autograd.Function):
                 dxm = _drop_bwd(dxm.contiguous(), t_xm)
             gw_, gb_ = grp.add(dxm, u, bias_grad=True)
             put("cgmlp.channel_proj2.weight", gw_); put("cgmlp.channel_proj2.bias", gb_)
-            du = _drop_bwd_(ops.linear_dx(dxm, p("cgmlp.channel_proj2.weight")), t_u)
+            du = ops.linear_dx_drop(dxm, p("cgmlp.channel_proj2.weight"), t_u)
             dg = torch.empty_like(g)
             cw = p("cgmlp.csgu.conv.weight")
             dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
@@ -695,12 +680,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             else:
                 cx, attn, tk_a = _SelfAttnCore.fwd(qkv, 3 * D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, L, L, H, dk, ys_lens, True,
                                                    p_att=pself)
-            tk_r = None
-            if pd > 0.0:                                     # x + dropout(self_attn(...))
-                t = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"))
-                x1, tk_r = ops.dropout_add(x, t, pd)
-            else:
-                x1 = ops.linear(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"), res=x)
+            x1, tk_r = ops.linear_drop(cx, p("self_attn.linear_out.weight"), p("self_attn.linear_out.bias"), pd, res=x)   # x + dropout(self_attn(...))
             s["self"] = (x, m1, r1, n1, qkv, cx, attn, tk_a, tk_r)
             # --- source attention over the encoder memory
             n2, m2, r2 = ops.layernorm_fwd(x1, p("norm2.weight"), p("norm2.bias"), EPS_ESPNET)
@@ -714,12 +694,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             else:
                 cx2, attn2, tk_a2 = _SelfAttnCore.fwd(q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, B, L, T, H, dk, hlens, False,
                                                       p_att=psrc)
-            tk_r2 = None
-            if pd > 0.0:                                     # x + dropout(src_attn(...))
-                t = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"))
-                x2, tk_r2 = ops.dropout_add(x1, t, pd)
-            else:
-                x2 = ops.linear(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"), res=x1)
+            x2, tk_r2 = ops.linear_drop(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"), pd, res=x1)   # x + dropout(src_attn(...))
             s["src"] = (x1, m2, r2, n2, q2, kv, cx2, attn2, tk_a2, tk_r2)
             # --- position-wise FFN (ReLU, scale 1)
             x, s["ff"] = _FFN.fwd(x2, p("norm3.weight"), p("norm3.bias"), p("feed_forward.w_1.weight"),

@@ -317,12 +317,8 @@ class TailoredStreamFn(torch.autograd.Function):
                 qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
                 cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
                                                     qv=qv, p=pp, p_att=pa)
-            t_br = None
-            if pd > 0.0:                       # residual + coeff * dropout(att)  (encoder_layer.py:196,243)
-                t = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"])
-                x2, t_br = ops.dropout_add(x1, t, pd, alpha=coeff)
-            else:
-                x2 = ops.linear(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], alpha=coeff, res=x1)
+            # residual + coeff * dropout(att)  (encoder_layer.py:196,243): the dropout rides in the GEMM epilogue
+            x2, t_br = ops.linear_drop(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], pd, alpha=coeff, res=x1)
             sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
         else:
             n, mean, rstd = ops.layernorm_fwd(x1, p["norm_cgmlp.weight"], p["norm_cgmlp.bias"], EPS_ESPNET)
@@ -332,12 +328,8 @@ class TailoredStreamFn(torch.autograd.Function):
             cw = p["cgmlp.csgu.conv.weight"]
             u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T)
             t_u = _drop_(u, pd)                # csgu: dropout(x_r * x_g)
-            t_br = None
-            if pd > 0.0:                       # residual + coeff * dropout(cgmlp)  (encoder_layer.py:208,256)
-                t = ops.linear(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"])
-                x2, t_br = ops.dropout_add(x1, t, pd, alpha=coeff)
-            else:
-                x2 = ops.linear(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], alpha=coeff, res=x1)
+            # residual + coeff * dropout(cgmlp)  (encoder_layer.py:208,256)
+            x2, t_br = ops.linear_drop(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], pd, alpha=coeff, res=x1)
             sv["br"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
         x3, sv["ff"] = _FFN.fwd(x2, p["norm_ff.weight"], p["norm_ff.bias"], p["feed_forward.w_1.weight"],
                                 p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"], p["feed_forward.w_2.bias"], act, 0.5, p=pd)
@@ -393,7 +385,7 @@ class TailoredStreamFn(torch.autograd.Function):
             Cn = g.shape[1] // 2
             dbr = _drop_bwd(dx2, t_br)
             G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = grp.add(dbr, u, alpha=coeff, bias_grad=True)
-            du = _drop_bwd_(ops.linear_dx(dbr, p["cgmlp.channel_proj2.weight"], alpha=coeff), t_u)
+            du = ops.linear_dx_drop(dbr, p["cgmlp.channel_proj2.weight"], t_u, alpha=coeff)
             dg = torch.empty_like(g)
             cw = p["cgmlp.csgu.conv.weight"]
             dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)

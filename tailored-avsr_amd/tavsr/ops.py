@@ -66,7 +66,8 @@ def _zero_page(device) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
-         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, conv=None, force=None, ws_cap=None):
+         R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, conv=None, force=None, ws_cap=None,
+         drop=None):
     """Raw descriptor call; offsets are in elements into the given tensors.  ``force=(cfg, nsplit)`` bypasses
     the planner (tuning / tests); ``ws_cap`` caps the split-K workspace handed to the library (tests of its fallback)."""
     require_cuda(A, B, Cc, bias, Z, R, DZ, a_rowsum)
@@ -90,6 +91,8 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.DZ, d.dact = _addr(DZ, c_off), ACT[dact]
     if a_rowsum is not None:
         d.a_rowsum = a_rowsum.data_ptr()
+    if drop is not None:        # dropout token (p, offset, seed tensor): the mask rides in the epilogue
+        d.drop_p, d.drop_offset, d.drop_seed = drop[0], drop[1], drop[2].data_ptr()
     if conv is not None:       # (mode, H, W, C[, stride, taps]): implicit convolution operand (include/tavsr.h)
         d.conv_mode, d.conv_H, d.conv_W, d.conv_C = conv[:4]
         if len(conv) > 4:
@@ -152,6 +155,59 @@ def linear_dx(dy, w, *, alpha=1.0, DZ=None, dact=None, res=None, out=None, force
     gemm(M, K, N, dy, dy.stride(0), w, w.stride(0), out, out.stride(0), b_kmajor=True, alpha=alpha, DZ=DZ, dact=dact,
          R=res, ldr=0 if res is None else res.stride(0), force=force)
     return out
+
+
+# Dropout fused into GEMM epilogues (tavsr_gemm_desc.drop_*): same mask as the stand-alone kernels draw for the contiguous
+# [M, N] result, so a fused forward pairs with a stand-alone backward and vice versa.  TAVSR_GEMM_DROP=0: separate launches.
+GEMM_DROP = os.environ.get("TAVSR_GEMM_DROP", "1") == "1"
+
+
+def _drop_fusable(x, N, K) -> bool:
+    return (GEMM_DROP and N % 4 == 0 and K % 32 == 0 and K >= 32 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and os.environ.get("TAVSR_GEMM_VEC_EPI", "1") == "1")
+
+
+def linear_drop(x, w, b, p, *, act=None, alpha=1.0, res=None, save_z=False):
+    """out = res + alpha * dropout(act(x @ w.T + b), p) -> (out[, z], token); one launch when the GEMM's 16-byte epilogue
+    can carry the mask (else GEMM + dropout / dropout_add launches with the same mask and token)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if not p or p <= 0.0:
+        r = linear(x, w, b, act=act, alpha=alpha, res=res, save_z=save_z)
+        return (r[0], r[1], None) if save_z else (r, None)
+    if _drop_fusable(x, N, K) and w.stride(0) % 4 == 0 and (res is None or res.stride(0) % 4 == 0):
+        tok = _new_token(p, M * N, x.device)
+        out = empty(M, N, like=x)
+        z = empty(M, N, like=x) if save_z else None
+        gemm(M, N, K, x, x.stride(0), w, w.stride(0), out, N, bias=b, act=act, alpha=alpha, Z=z, R=res,
+             ldr=0 if res is None else res.stride(0), drop=tok)
+        return (out, z, tok) if save_z else (out, tok)
+    r = linear(x, w, b, act=act, save_z=save_z)
+    t, z = (r if save_z else (r, None))
+    if res is None:
+        out, tok = dropout(t, p, out=t)
+        if alpha != 1.0:
+            out = axpby(out, None, alpha, 0.0, out=out)
+    else:
+        out, tok = dropout_add(res, t, p, alpha=alpha)
+    return (out, z, tok) if save_z else (out, tok)
+
+
+def linear_dx_drop(dy, w, tok, *, alpha=1.0, DZ=None, dact=None):
+    """dx = mask(tok) / keep * alpha * (dy @ w) * act'(DZ): the backward of y = dropout(act(z)) in the data-gradient GEMM's
+    epilogue (tok None: no mask)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if tok is None:
+        return linear_dx(dy, w, alpha=alpha, DZ=DZ, dact=dact)
+    if _drop_fusable(dy, K, N) and w.stride(0) % 4 == 0:
+        out = empty(M, K, like=dy)
+        gemm(M, K, N, dy, dy.stride(0), w, w.stride(0), out, K, b_kmajor=True, alpha=alpha, DZ=DZ, dact=dact, drop=tok)
+        return out
+    dh = linear_dx(dy, w, alpha=alpha)
+    if DZ is not None:
+        return dropout_act_bwd(dh, DZ, dact, tok, out=dh)
+    return dropout(dh, tok[0], out=dh, token=tok)[0]
 
 
 def linear_dx_cat(dy_cat, ws, *, res=None, out=None):

@@ -227,3 +227,30 @@ def test_gemm_k_tail_on_the_lds_dma_kernel(M, N, K, ws_cap, mode):
     assert bool(torch.isfinite(out).all())
     err = (out.double() - ref).abs().max() / ref.abs().max()
     assert err < (2e-6 if K < 512 else 5e-6), (mode, float(err))
+
+
+@pytest.mark.parametrize("M,N,K,split", [(3168, 2048, 256, False), (3168, 256, 2048, True), (100, 64, 96, False), (777, 256, 1056, True)])
+def test_gemm_epilogue_dropout_equals_the_standalone_mask(M, N, K, split):
+    """tavsr_gemm with drop_p: the same mask (bit for bit) as tavsr_dropout on the contiguous [M, N] result with the same
+    token - in the in-kernel epilogue and in the split-K epilogue kernel; forward (bias, activation, residual) and backward
+    (mask * act'(z)) forms."""
+    from tavsr import ops
+    torch.manual_seed(M + N)
+    x, w, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") / K ** 0.5, torch.randn(N, device="cuda")
+    res = torch.randn(M, N, device="cuda")
+    ops.manual_seed(17)
+    out, z, tok = ops.linear_drop(x, w, b, 0.3, act="swish", alpha=0.5, res=res, save_z=True)
+    plain, z2 = ops.linear(x, w, b, act="swish", save_z=True)
+    assert torch.equal(z, z2)
+    want = res + 0.5 * ops.dropout(plain, 0.3, token=tok)[0]
+    assert float((out - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    kept = float(((out - res) != 0).float().mean())
+    assert abs(kept - 0.7) < 0.01
+    # backward form: dx = mask * (dy @ w2) * act'(z), w2 [N2, K2] -> [M, K2]
+    dy = torch.randn(M, N, device="cuda")
+    w2 = torch.randn(N, K, device="cuda") / N ** 0.5
+    zz = torch.randn(M, K, device="cuda")
+    tok2 = ops._new_token(0.2, M * K, dy.device)
+    got = ops.linear_dx_drop(dy, w2, tok2, alpha=0.5, DZ=zz, dact="swish")
+    ref = ops.dropout_act_bwd(ops.linear_dx(dy, w2, alpha=0.5), zz, "swish", tok2)
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
