@@ -446,6 +446,53 @@ class TailoredLayerFn(torch.autograd.Function):
         return (dxa, None, None, None, dxv, None, None, None, *shared, *Ga[ns:], *Gv[ns:])
 
 
+class _Ctx:
+    """stand-in for an autograd ctx when a Function's forward / backward bodies are reused inside another node"""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+# Run two independent nodes side by side?  TAVSR_FRONT_PAIR=0 keeps them as two nodes on one stream (A/B switch).
+import os as _os
+FRONT_PAIR = _os.environ.get("TAVSR_FRONT_PAIR", "1") == "1"
+
+
+class FrontendPairFn(torch.autograd.Function):
+    """The lip front-end (Conv3dResNet18) and the audio embedding (Conv2dSubsamplingWOPosEnc) of the AV model as ONE
+    autograd node: the two are independent until the streams are aligned (src/models/avsr_espnet_model.py:400-434), so the
+    audio embedding's launches go to the forked stream and run beside the front-end's HBM-bound BatchNorm phases, forward
+    and backward (two separate nodes would be serialised by autograd on one stream).
+    P = front-end parameters (cfg["names"] order) + (conv.0.weight, conv.0.bias, conv.2.weight, conv.2.bias, out.weight,
+    out.bias) of the audio embedding."""
+
+    @staticmethod
+    def forward(ctx, video, cfg, audio, *P):
+        from .functional import Conv2dSubsamplingFn
+        npv = len(cfg["names"])
+        cv, ca = _Ctx(), _Ctx()
+        br = ops.BranchScope(video.is_cuda)
+        with br:
+            ya = Conv2dSubsamplingFn.forward(ca, audio, *P[npv:], 1.0)
+        yv = VisualFrontendFn.forward(cv, video, cfg, *P[:npv])
+        br.join()
+        ctx.cv, ctx.ca = cv, ca
+        return yv, ya
+
+    @staticmethod
+    def backward(ctx, dyv, dya):
+        from .functional import Conv2dSubsamplingFn
+        br = ops.BranchScope(dyv.is_cuda)
+        dya = dya.contiguous()
+        br.keep(dya)
+        with br:
+            ga = Conv2dSubsamplingFn.backward(ctx.ca, dya)
+        gv = VisualFrontendFn.backward(ctx.cv, dyv)
+        br.join()
+        ctx.cv = ctx.ca = None
+        return (None, None, None, *gv[2:], *ga[1:7])
+
+
 # ------------------------------------------------------------------------------------------------
 # AdaptiveAudioVisualFusion, merge_method="learned_ave" (src/audiovisual_fusion/adaptive_audiovisual_fusion.py:137-205):
 # attention pooling of each stream under its own mask -> softmax over {audio, video} -> weighted sum ->

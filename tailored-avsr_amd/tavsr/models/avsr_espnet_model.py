@@ -49,6 +49,31 @@ class ESPnetAVSRModel(ESPnetASRModel):
             video_feats_masks = torch.nn.functional.pad(video_feats_masks, (0, padding_frames), value=False)
         return audio_feats, audio_feats_masks, video_feats, video_feats_masks
 
+    def _front_pair(self, video):
+        """the paired node applies when the lip front-end is the Conv3d + ResNet-18 one (one un-chunked call) and the audio
+        embedding the two-convolution subsampling: returns a callable or None (then the two run one after the other)."""
+        from ..embedding_for_avsr.default import Conv2dSubsamplingWOPosEnc
+        from ..frontend.conv3d_resnet18 import Conv3dResNet18
+        from ..layers import make_pad_mask
+        vf, emb = self.visual_frontend, getattr(self.acoustic_embed, "embed", None)
+        if not (FA.FRONT_PAIR and isinstance(vf, Conv3dResNet18) and isinstance(emb, Conv2dSubsamplingWOPosEnc) and video.is_cuda):
+            return None
+        if not vf.training and not torch.is_grad_enabled() and video.shape[0] > vf.EVAL_CHUNK:
+            return None                  # chunked eval decoding of large batches stays on its own path
+
+        def run(video, audio_feats, audio_lens):
+            params = dict(vf.named_parameters())
+            cfg = dict(names=vf._names, buffers=dict(vf.named_buffers()), training=vf.training)
+            P = [params[n] for n in vf._names] + [emb.conv[0].weight, emb.conv[0].bias, emb.conv[2].weight, emb.conv[2].bias,
+                                                   emb.out.weight, emb.out.bias]
+            yv, ya = FA.FrontendPairFn.apply(video, cfg, audio_feats, *P)
+            masks = (~make_pad_mask(audio_lens, audio_feats.size(1))[:, None, :]).to(audio_feats.device)
+            for k, s_ in zip(emb.kernels, emb.strides):
+                masks = masks[:, :, : -k + 1: s_]
+            return yv, ya, masks
+
+        return run
+
     # ---------------------------------------------------------------- avsr_espnet_model.py:383-488
     def encode(self, audio, audio_lengths, video, video_lengths):
         audio = cut_to_longest(audio, audio_lengths)        # _extract_feats, avsr_espnet_model.py:499
@@ -57,15 +82,21 @@ class ESPnetAVSRModel(ESPnetASRModel):
             audio_feats, audio_feats_lengths = self.acoustic_frontend(audio, audio_lengths)
         else:
             audio_feats, audio_feats_lengths = audio, audio_lengths
-        if self.visual_frontend is not None:
-            video_feats, video_feats_lengths = self.visual_frontend(video, video_lengths)
-        else:
-            video_feats, video_feats_lengths = video, video_lengths
         if self.specaug is not None and self.training:
             audio_feats, audio_feats_lengths = self.specaug(audio_feats, audio_feats_lengths)
         if self.normalize is not None:
             audio_feats, audio_feats_lengths = self.normalize(audio_feats, audio_feats_lengths)
-        audio_feats, audio_masks = self.acoustic_embed.apply_embed_layer(audio_feats, audio_feats_lengths)
+        pair = self._front_pair(video)
+        if pair is not None:
+            # lip front-end and audio embedding side by side as one autograd node (the same arithmetic, two streams)
+            video_feats, audio_feats, audio_masks = pair(video, audio_feats, audio_feats_lengths)
+            video_feats_lengths = video_lengths
+        else:
+            if self.visual_frontend is not None:
+                video_feats, video_feats_lengths = self.visual_frontend(video, video_lengths)
+            else:
+                video_feats, video_feats_lengths = video, video_lengths
+            audio_feats, audio_masks = self.acoustic_embed.apply_embed_layer(audio_feats, audio_feats_lengths)
         video_feats, video_masks = self.visual_embed.apply_embed_layer(video_feats, video_feats_lengths)
         audio_feats, audio_masks, video_feats, video_masks = self.audiovisual_alignment(audio_feats, audio_masks,
                                                                                         video_feats, video_masks)
