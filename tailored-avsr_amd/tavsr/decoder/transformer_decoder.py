@@ -43,11 +43,16 @@ class TransformerDecoder(torch.nn.Module):
         self._rates = (dropout_rate, positional_dropout_rate, self_attention_dropout_rate, src_attention_dropout_rate)
 
     def _params(self):
+        cached = self.__dict__.get("_tavsr_pcache")                        # Parameter identities never change: look up once
+        if cached is not None:
+            return cached
         P = [self.embed[0].weight]
         for layer in self.decoders:
             sd = dict(layer.named_parameters())
             P += [sd[n] for n in F_.DEC_LAYER_PARAM_NAMES]
-        return P + [self.after_norm.weight, self.after_norm.bias, self.output_layer.weight, self.output_layer.bias]
+        P = self.__dict__["_tavsr_pcache"] = P + [self.after_norm.weight, self.after_norm.bias, self.output_layer.weight,
+                                                   self.output_layer.bias]
+        return P
 
     def forward(self, hs_pad, hlens, ys_in_pad, ys_in_lens):
         """hs_pad (B,T,D), hlens (B), ys_in_pad (B,L) int64, ys_in_lens (B) -> (logits (B,L,V), olens)."""

@@ -44,8 +44,11 @@ class TailoredEncoderLayer(torch.nn.Module):
         self.stochastic_depth_rate = stochastic_depth_rate
 
     def _stream_params(self, prefix: str, use_attn: bool):
+        cache = self.__dict__.setdefault("_tavsr_stream_pcache", {})      # Parameter identities never change: look up once
+        if (prefix, use_attn) in cache:
+            return cache[(prefix, use_attn)]
         sd = dict(self.named_parameters())
-        out = []
+        out = cache[(prefix, use_attn)] = []
         for n in FA.tailored_stream_param_names(use_attn):
             if n.startswith(("attn.", "cgmlp.")):
                 out.append(sd[prefix + "_" + n])

@@ -71,8 +71,8 @@ class MyBranchformerEncoderLayer(torch.nn.Module):
 
     # ---- gather parameters in the order BranchformerLayerFn expects (None for absent modules)
     def _params(self):
-        sd = dict(self.named_parameters())
-        return [sd.get(n) for n in F_.BF_PARAM_NAMES]
+        from ..._lib import cached_params
+        return cached_params(self, F_.BF_PARAM_NAMES)
 
     def _active_dropout(self) -> bool:
         rates = [self.dropout_rate]
