@@ -21,6 +21,15 @@ from . import ops
 
 EPS_ESPNET = 1e-12  # espnet LayerNorm eps
 
+# Does the node being run have a backward pass?  Set by every Function.forward from ctx.needs_input_grad: a forward under
+# no_grad / in eval mode does not write the [M, 2048] pre-activations of its feed-forward and cgMLP blocks (26 MB each).
+_NEED_BWD = [True]
+
+
+def _note_ctx(ctx):
+    nig = getattr(ctx, "needs_input_grad", None)
+    _NEED_BWD[0] = True if nig is None else any(nig)
+
 
 # ------------------------------------------------------------------------------------------------
 # building blocks shared by the Functions (plain python, explicit saved state)
@@ -54,7 +63,10 @@ class _FFN:
             y, (n, mean, rstd, z, h, t_in, t_out) = ops.ffn_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=p, save=save)
             return y, ("fused", x, mean, rstd, n, z, h, t_in, t_out)
         n, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, eps)
-        h, z, t_in = ops.linear_drop(n, w1, b1, p, act=act, save_z=True)         # both dropouts ride in the GEMM epilogues
+        if _NEED_BWD[0]:
+            h, z, t_in = ops.linear_drop(n, w1, b1, p, act=act, save_z=True)     # both dropouts ride in the GEMM epilogues
+        else:
+            (h, t_in), z = ops.linear_drop(n, w1, b1, p, act=act), None
         y, t_out = ops.linear_drop(h, w2, b2, p, alpha=scale, res=x)             # x + scale * dropout(.)
         return y, (x, mean, rstd, n, z, h, t_in, t_out)
 
@@ -222,6 +234,7 @@ class BranchformerLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos_emb, lens, cfg, *P):
+        _note_ctx(ctx)
         B, T, D = x.shape
         M = B * T
         H = cfg["heads"]
@@ -268,8 +281,11 @@ class BranchformerLayerFn(torch.autograd.Function):
                 sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
         if has_mlp:
             n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mlp.weight"), p("norm_mlp.bias"), EPS_ESPNET)
-            g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu",
-                              save_z=True)
+            if _NEED_BWD[0]:
+                g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu",
+                                  save_z=True)
+            else:
+                g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu"), None
             Cn = g.shape[1] // 2
             gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p("cgmlp.csgu.norm.weight"), p("cgmlp.csgu.norm.bias"),
                                                  EPS_ESPNET)
@@ -653,6 +669,7 @@ class TransformerDecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, memory, hlens, ys_in, ys_lens, pe, cfg, *P):
+        _note_ctx(ctx)
         B, T, D = memory.shape
         L = ys_in.shape[1]
         H = cfg["heads"]

@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .functional import EPS_ESPNET, _FFN, _AttnFused, _SelfAttnCore, _drop_, _drop_bwd, _drop_bwd_
+from .functional import EPS_ESPNET, _FFN, _AttnFused, _SelfAttnCore, _drop_, _drop_bwd, _drop_bwd_, _NEED_BWD, _note_ctx
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch.nn.BatchNorm defaults (conv3d_resnet18.py:57, resnet.py:39,68,84)
 
@@ -322,7 +322,10 @@ class TailoredStreamFn(torch.autograd.Function):
             sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
         else:
             n, mean, rstd = ops.layernorm_fwd(x1, p["norm_cgmlp.weight"], p["norm_cgmlp.bias"], EPS_ESPNET)
-            g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
+            if _NEED_BWD[0]:
+                g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
+            else:
+                g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu"), None
             Cn = g.shape[1] // 2
             gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET)
             cw = p["cgmlp.csgu.conv.weight"]
@@ -417,6 +420,7 @@ class TailoredLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, *P):
         import types
+        _note_ctx(ctx)
         na, nv = len(tailored_stream_param_names(cfg_a["use_attn"])), len(tailored_stream_param_names(cfg_v["use_attn"]))
         ns = len(TS_SHARED)
         Pa, Pv = P[:na], P[:ns] + P[na: na + nv - ns]
