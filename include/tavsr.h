@@ -438,7 +438,15 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
  *       step_dev (nullable): device int32 that replaces out_len (graph replays, as in tavsr_tree_attn_step).
  *   tavsr_log_softmax_rows: y[m][:] = (accumulate ? y[m][:] : 0) + alpha * log_softmax(x[m][:V]) + add  (the weighted sum of
  *       the scorers: decoder 1 - ctc_weight, lm lm_weight, length bonus as `add`).
+ *   tavsr_rowlin         : out[n][c] = res[n][c] + act(LN(x[g(n)])[:K] . W[c][:K] + bias[c]), n < N, c < Nout - one Linear of
+ *       forward_one_step / batch_score (espnet transformer decoder_layer.py / encoder_layer.py with cache) with the
+ *       LayerNorm in front of it (gamma/beta nullable: none), bias, activation (TAVSR_ACT_*) and residual (nullable; may
+ *       alias out) in ONE launch.  gather (nullable): g(n) = gather[n] (embedding rows), else g(n) = n.  K % 32 == 0,
+ *       16-byte aligned rows; out must not alias x.
  * ------------------------------------------------------------------------------------------- */
+int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, const float* gamma, const float* beta, float eps,
+                 const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr, float* out,
+                 int64_t ldo, int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                          const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N, int32_t H,
                          int32_t dk, float scale, const int32_t* step_dev, const float* k_new, const float* v_new,

@@ -15,7 +15,10 @@ namespace tavsr {
 
 constexpr int kTreeMaxKeys = 1024;
 
-// one wave per (hypothesis n, head h)
+// one wave per (hypothesis n, head h).  Latency-bound at small N (a chain of dependent gathers): the ancestor list is
+// read once into LDS, the scores use one lane per key (16 float4 loads in flight per lane), the weighted value sum uses
+// 64 / DL key groups x DL lanes of float4 so that a wave has 8 independent row gathers in flight per lane.
+template <int DL>      // lanes along the head dimension (float4 each): 16 (dk <= 64) or 32 (dk <= 128)
 __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __restrict__ q, int64_t ldq,
                                                              const float* __restrict__ kpool, const float* __restrict__ vpool,
                                                              int64_t ldkv, const int32_t* __restrict__ anc, int64_t ld_anc,
@@ -23,7 +26,9 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
                                                              int dk, float scale, const int32_t* __restrict__ step_dev,
                                                              const float* __restrict__ k_new, const float* __restrict__ v_new,
                                                              float* __restrict__ kpool_w, float* __restrict__ vpool_w) {
+  constexpr int KG = 64 / DL;
   __shared__ float s_p[4][kTreeMaxKeys];
+  __shared__ int32_t s_a[4][kTreeMaxKeys];
   if (step_dev) nkeys = min(*step_dev + 1, nkeys);        // replayed graphs: the step counter lives in device memory
   // k_new / v_new (row stride ldq): this step's own key / value rows.  They are the LAST key of every hypothesis (pool row
   // (nkeys-1) * N + n): read from here instead of the pool, and appended to the pool by the same wave (no append launch).
@@ -33,12 +38,13 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
   const int item = min(blockIdx.x * 4 + wave, N * H - 1);
   const int n = item / H, h = item % H;
   const float* qv = q + (int64_t)n * ldq + h * dk;
-  for (int d = lane; d < dk; d += 64) s_q[wave][d] = qv[d] * scale;
-  __syncthreads();
   const int32_t* a = anc + (int64_t)n * ld_anc;
+  for (int d = lane; d < dk; d += 64) s_q[wave][d] = qv[d] * scale;
+  for (int j = lane; j < nkeys; j += 64) s_a[wave][j] = a[j];
+  __syncthreads();
   float mx = -INFINITY;
   for (int j = lane; j < nkeys; j += 64) {
-    const float* kr = (k_new && j == nkeys - 1) ? k_new + (int64_t)n * ldq + h * dk : kpool + (int64_t)a[j] * ldkv + h * dk;
+    const float* kr = (k_new && j == nkeys - 1) ? k_new + (int64_t)n * ldq + h * dk : kpool + (int64_t)s_a[wave][j] * ldkv + h * dk;
     float dot = 0.f;
     for (int d = 0; d < dk; d += 4) {
       const float4 kv = *reinterpret_cast<const float4*>(kr + d);
@@ -57,20 +63,41 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
   sum = wave_sum(sum);
   __syncthreads();
   const float inv = 1.f / sum;
-  const int nold = v_new ? nkeys - 1 : nkeys;
-  for (int d = lane; d < dk; d += 64) {
-    float acc = 0.f;
-    for (int j = 0; j < nold; ++j) acc += s_p[wave][j] * vpool[(int64_t)a[j] * ldkv + h * dk + d];
-    if (v_new) {
-      const float vn = v_new[(int64_t)n * ldq + h * dk + d];
-      acc += s_p[wave][nkeys - 1] * vn;
-      if (live) {
-        const int64_t row = (int64_t)(nkeys - 1) * N + n;
-        vpool_w[row * ldkv + h * dk + d] = vn;
-        kpool_w[row * ldkv + h * dk + d] = k_new[(int64_t)n * ldq + h * dk + d];
-      }
+  const int dl = lane & (DL - 1), kg = lane / DL;
+  const bool dok = dl * 4 < dk;
+  const int doff = h * dk + (dok ? dl * 4 : 0);
+  const float* vb = vpool + doff;
+  const float* vlast = v_new ? v_new + (int64_t)n * ldq + doff : nullptr;       // key nkeys - 1 of this hypothesis
+  auto vrow = [&](int j) { return (vlast && j == nkeys - 1) ? vlast : vb + (int64_t)s_a[wave][j] * ldkv; };
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int j = kg;
+  for (; j + 7 * KG < nkeys; j += 8 * KG) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(vrow(j + u * KG));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float pj = s_p[wave][j + u * KG];
+      acc.x += pj * v[u].x; acc.y += pj * v[u].y; acc.z += pj * v[u].z; acc.w += pj * v[u].w;
     }
-    if (live) out[(int64_t)n * ldo + h * dk + d] = acc * inv;
+  }
+  for (; j < nkeys; j += KG) {
+    const float4 v = *reinterpret_cast<const float4*>(vrow(j));
+    const float pj = s_p[wave][j];
+    acc.x += pj * v.x; acc.y += pj * v.y; acc.z += pj * v.z; acc.w += pj * v.w;
+  }
+#pragma unroll
+  for (int o = DL; o < 64; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (kg == 0 && dok && live) {
+    if (v_new) {
+      const int64_t rowp = (int64_t)(nkeys - 1) * N + n;
+      *reinterpret_cast<float4*>(vpool_w + rowp * ldkv + doff) = *reinterpret_cast<const float4*>(vlast);
+      *reinterpret_cast<float4*>(kpool_w + rowp * ldkv + doff) = *reinterpret_cast<const float4*>(k_new + (int64_t)n * ldq + doff);
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)n * ldo + doff) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
   }
 }
 
@@ -244,6 +271,138 @@ __global__ __launch_bounds__(256) void beam_reorder_kernel(const int64_t* __rest
   }
 }
 
+// ---- one-token linear layers -----------------------------------------------------------------------------------------
+// y[n][c] = res[n][c] + act(LN(x)[n] . W[c] + bias[c]) for the N = utterances x beam current-token rows of a scorer step
+// (espnet TransformerDecoder.forward_one_step / TransformerLM.batch_score: every Linear sees ONE row per hypothesis).
+// With few rows the step is a chain of ~150 dependent launches, each bound by the latency of its global loads, not by
+// arithmetic.  This kernel is built for that regime: LayerNorm, Linear, bias, activation and residual in one launch, ONE
+// round trip to memory per launch:
+//   block = R rows (R = 16 or 32 >= N) x R output columns, WPB waves; wave w owns k in [w KW, (w + 1) KW), K = WPB KW;
+//   lane (r, g) issues all its float4 loads of x[r][.], W[col0 + r][.] (and gamma / beta) up front - they are the operands
+//   of v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32 (exact fp32);
+//   the LayerNorm statistics come from the same registers (the block's waves hold whole rows between them): sum, then
+//   squared deviations, each reduced over the lane groups by shuffles and over the waves through LDS;
+//   the WPB partial tiles meet in LDS and the first R * R threads finish the outputs.
+struct RowLinArgs {
+  const float* x; int64_t ldx; const int64_t* gather;
+  const float *gamma, *beta; float eps;
+  const float* W; int64_t ldw; const float* bias;
+  const float* res; int64_t ldr; float* out; int64_t ldo;
+  int N, K, Nout, act;
+};
+
+template <int R, int WPB, int KW>
+__global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
+  constexpr int G = 64 / R;                 // lane groups along k
+  constexpr int NJ = KW / (4 * G);          // float4 loads per operand per lane
+  constexpr int NACC = R * R / 64;          // accumulator registers (4 / 16)
+  typedef float accv __attribute__((ext_vector_type(NACC)));
+  __shared__ float s_acc[WPB][NACC][64];
+  __shared__ float s_red[2][WPB][R];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & (R - 1), g = lane / R;
+  const int col0 = blockIdx.x * R;
+  const int row = min(r, a.N - 1), col = min(col0 + r, a.Nout - 1);     // surplus lanes repeat the last row / column
+  const int kb = wave * KW + 4 * g;
+  const float* xr = a.x + (a.gather ? a.gather[row] : (int64_t)row) * a.ldx + kb;
+  const float* wr = a.W + (int64_t)col * a.ldw + kb;
+  float4 av[NJ], bv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(wr + 4 * G * j);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) av[j] = *reinterpret_cast<const float4*>(xr + 4 * G * j);
+  if (a.gamma) {
+    float4 gv[NJ], ev[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      gv[j] = *reinterpret_cast<const float4*>(a.gamma + kb + 4 * G * j);
+      ev[j] = *reinterpret_cast<const float4*>(a.beta + kb + 4 * G * j);
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sm += (av[j].x + av[j].y) + (av[j].z + av[j].w);
+#pragma unroll
+    for (int o = R; o < 64; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    if (g == 0) s_red[0][wave][r] = sm;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) mean += s_red[0][w][r];
+    mean /= (float)a.K;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      av[j].x -= mean; av[j].y -= mean; av[j].z -= mean; av[j].w -= mean;
+      sq += (av[j].x * av[j].x + av[j].y * av[j].y) + (av[j].z * av[j].z + av[j].w * av[j].w);
+    }
+#pragma unroll
+    for (int o = R; o < 64; o <<= 1) sq += __shfl_xor(sq, o, 64);
+    if (g == 0) s_red[1][wave][r] = sq;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) var += s_red[1][w][r];
+    const float rstd = rsqrtf(var / (float)a.K + a.eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      av[j].x = av[j].x * rstd * gv[j].x + ev[j].x;
+      av[j].y = av[j].y * rstd * gv[j].y + ev[j].y;
+      av[j].z = av[j].z * rstd * gv[j].z + ev[j].z;
+      av[j].w = av[j].w * rstd * gv[j].w + ev[j].w;
+    }
+  }
+  accv acc;
+#pragma unroll
+  for (int q = 0; q < NACC; ++q) acc[q] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    if constexpr (R == 32) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, bv[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, bv[j].w, acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NACC; ++q) s_acc[wave][q][lane] = acc[q];
+  __syncthreads();
+  // accumulator register q of lane l: 32x32 tile - row (q & 3) + 8 (q >> 2) + 4 (l >> 5), column l & 31;
+  //                                   16x16 tile - row 4 (l >> 4) + q, column l & 15
+  for (int o = threadIdx.x; o < R * R; o += WPB * 64) {
+    const int q = o >> 6, l = o & 63;
+    const int rw = R == 32 ? (q & 3) + 8 * (q >> 2) + 4 * (l >> 5) : 4 * (l >> 4) + q;
+    const int c = col0 + (l & (R - 1));
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) v += s_acc[w][q][l];
+    if (rw < a.N && c < a.Nout) {
+      if (a.bias) v += a.bias[c];
+      v = act_fwd(a.act, v);
+      if (a.res) v += a.res[(int64_t)rw * a.ldr + c];
+      a.out[(int64_t)rw * a.ldo + c] = v;
+    }
+  }
+}
+
+template <int R>
+static bool rowlin_launch(const RowLinArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)((a.Nout + R - 1) / R));
+  switch (a.K) {
+    case 64: hipLaunchKernelGGL((rowlin_kernel<R, 1, 64>), grid, dim3(64), 0, st, a); return true;
+    case 128: hipLaunchKernelGGL((rowlin_kernel<R, 2, 64>), grid, dim3(128), 0, st, a); return true;
+    case 256: hipLaunchKernelGGL((rowlin_kernel<R, 4, 64>), grid, dim3(256), 0, st, a); return true;
+    case 512: hipLaunchKernelGGL((rowlin_kernel<R, 8, 64>), grid, dim3(512), 0, st, a); return true;
+    case 1024: hipLaunchKernelGGL((rowlin_kernel<R, 16, 64>), grid, dim3(1024), 0, st, a); return true;
+    case 2048: hipLaunchKernelGGL((rowlin_kernel<R, 16, 128>), grid, dim3(1024), 0, st, a); return true;
+    default: return false;
+  }
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) y[i] = act_fwd(act, x[i]);
@@ -262,6 +421,27 @@ extern "C" int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, t
 }
 
 
+extern "C" int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, const float* gamma, const float* beta, float eps,
+                            const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr,
+                            float* out, int64_t ldo, int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && W && out, TAVSR_EINVAL, "rowlin: null pointer");
+  TAVSR_REQUIRE((gamma == nullptr) == (beta == nullptr), TAVSR_EINVAL, "rowlin: gamma and beta go together");
+  TAVSR_REQUIRE(N <= 32, TAVSR_EUNSUPPORTED, "rowlin: at most 32 rows (got %d): larger steps go through tavsr_gemm", N);
+  TAVSR_REQUIRE(K == 64 || K == 128 || K == 256 || K == 512 || K == 1024 || K == 2048, TAVSR_EUNSUPPORTED,
+                "rowlin: K in {64, 128, 256, 512, 1024, 2048} (got %d)", K);
+  TAVSR_REQUIRE(!gamma || K <= 1024, TAVSR_EUNSUPPORTED, "rowlin: LayerNorm prologue up to K = 1024");
+  TAVSR_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)x | (uintptr_t)W) & 15) == 0 &&
+                    (!gamma || (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
+                TAVSR_EALIGN, "rowlin: rows of x / W (and gamma / beta) must be 16-byte aligned");
+  TAVSR_REQUIRE(out != x, TAVSR_EINVAL, "rowlin: out must not alias x");
+  if (N <= 0 || Nout <= 0) return TAVSR_OK;
+  RowLinArgs a{x, ldx, gather, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act};
+  if (N <= 16) rowlin_launch<16>(a, (hipStream_t)stream);
+  else rowlin_launch<32>(a, (hipStream_t)stream);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
 extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                                     const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N,
                                     int32_t H, int32_t dk, float scale, const int32_t* step_dev, const float* k_new,
@@ -273,9 +453,15 @@ extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kp
   TAVSR_REQUIRE(dk % 4 == 0 && dk <= 128 && ldkv % 4 == 0 && ((uintptr_t)kpool & 15) == 0, TAVSR_EALIGN,
                 "tree_attn_step: dk %% 4, dk <= 128 and 16-byte aligned key rows are required");
   if (N <= 0) return TAVSR_OK;
-  hipLaunchKernelGGL(tree_attn_step_kernel, dim3((unsigned)((N * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, kpool,
-                     vpool, ldkv, anc, ld_anc, nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool),
-                     const_cast<float*>(vpool));
+  TAVSR_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)q | (uintptr_t)out | (uintptr_t)vpool | (uintptr_t)k_new | (uintptr_t)v_new) & 15) == 0,
+                TAVSR_EALIGN, "tree_attn_step: q / out / k_new / v_new rows must be 16-byte aligned");
+  const dim3 grid((unsigned)((N * H + 3) / 4));
+  if (dk <= 64)
+    hipLaunchKernelGGL(tree_attn_step_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
+                       nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool));
+  else
+    hipLaunchKernelGGL(tree_attn_step_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
+                       nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool));
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

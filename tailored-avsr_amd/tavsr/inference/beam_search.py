@@ -39,11 +39,30 @@ def _cat(ws):
 # One-token scorer steps are chains of small launches: the fused feed-forward block (LayerNorm + both GEMMs, csrc/ffn.hip)
 # and the fused source attention cut the chain.  TAVSR_DECODE_FUSED=0 keeps the GEMM launches (A/B switch).
 FUSED_STEP = os.environ.get("TAVSR_DECODE_FUSED", "1") == "1"
+SCORERS_PARALLEL = os.environ.get("TAVSR_DECODE_PARALLEL", "1") == "1"   # decoder || LM on two streams
 FUSED_FFN = os.environ.get("TAVSR_DECODE_FUSED_FFN", "0") == "1"      # measured: 153 vs 166 utt/s at batch 64 (in-call A/B): off
+
+
+def _ln_linear(x, norm, w, b, act=None):
+    """act(W LN(x) + b): one launch (ops.rowlin) when the shapes allow, else LayerNorm + GEMM launches."""
+    if ops.rowlin_ok(x, w):
+        return ops.rowlin(x, w, b, ln=(norm[0], norm[1], EPS), act=act)
+    n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
+    return ops.linear(n, w, b, act=act)
+
+
+def _linear_res(x, w, b, res):
+    """res + W x + b."""
+    if ops.rowlin_ok(x, w):
+        return ops.rowlin(x, w, b, res=res)
+    return ops.linear(x, w, b, res=res)
 
 
 def _ffn_step(x, norm, L):
     """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows."""
+    if ops.rowlin_ok(x, L["w1"]) and not FUSED_FFN:
+        t = ops.rowlin(x, L["w1"], L["b1"], ln=(norm[0], norm[1], EPS), act="relu")
+        return _linear_res(t, L["w2"], L["b2"], x)
     if FUSED_FFN and x.shape[1] in (256, 512) and L["w1"].shape[0] % 128 == 0:
         return ops.ffn_fwd(x, norm[0], norm[1], EPS, L["w1"], L["b1"], L["w2"], L["b2"], "relu", 1.0, save=False)[0]
     n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
@@ -92,14 +111,12 @@ class _DecoderStep:
         pe = self.pe[i:i + 1].contiguous() if dyn is None else dyn[1]
         x = ops.embed_pe(tok.view(N, 1), self.emb, pe, self.xscale).view(N, D)
         for li, L in enumerate(self.layers):
-            n1 = ops.layernorm_fwd(x, *L["n1"], EPS, save=False)[0]
-            qkv = ops.linear(n1, L["wqkv"], L["bqkv"])
+            qkv = _ln_linear(x, L["n1"], L["wqkv"], L["bqkv"])
             # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
             a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
                                    step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
-            x = ops.linear(a, L["wo"], L["bo"], res=x)
-            n2 = ops.layernorm_fwd(x, *L["n2"], EPS, save=False)[0]
-            q2 = ops.linear(n2, L["wq2"], L["bq2"])
+            x = _linear_res(a, L["wo"], L["bo"], x)
+            q2 = _ln_linear(x, L["n2"], L["wq2"], L["bq2"])
             # source attention: the K slots of an utterance are K query rows against that utterance's memory
             kv = self.memkv[li]
             if FUSED_STEP and dk == 64:      # scores, mask, softmax and context in one launch (csrc/attn_fused.hip)
@@ -113,10 +130,11 @@ class _DecoderStep:
                 c2 = ops.empty(N, D, like=x)
                 ops.gemm(K, dk, T, att, S, kv, 2 * D, c2, D, b_off=D, b_kmajor=True, nb1=U, nb2=H, sA=(K * S, U * K * S),
                          sB=(T * 2 * D, dk), sC=(K * D, dk))
-            x = ops.linear(c2, L["wo2"], L["bo2"], res=x)
+            x = _linear_res(c2, L["wo2"], L["bo2"], x)
             x = _ffn_step(x, L["n3"], L)
-        y = ops.layernorm_fwd(x, self.dec.after_norm.weight, self.dec.after_norm.bias, EPS, save=False)[0]
-        return ops.log_softmax_rows(ops.linear(y, self.dec.output_layer.weight, self.dec.output_layer.bias), **score)
+        z = _ln_linear(x, (self.dec.after_norm.weight, self.dec.after_norm.bias), self.dec.output_layer.weight,
+                       self.dec.output_layer.bias)
+        return ops.log_softmax_rows(z, **score)
 
 
 class _LMStep:
@@ -141,24 +159,25 @@ class _LMStep:
         self.kpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
         self.vpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
 
-    def step(self, i, tok, anc, dyn=None, **score):
+    def step(self, i, tok, anc, dyn=None, logits_only=False, **score):
         N, D, H, dk = self.N, self.D, self.H, self.dk
         lm = self.lm
-        e = lm.embed.weight[tok].contiguous()                        # row gather (index plumbing)
         emb = lm.encoder.embed
-        h = ops.linear(e, emb[0].weight, emb[0].bias)
+        if ops.rowlin_ok(lm.embed.weight, emb[0].weight, n_rows=N):            # embedding row gather inside the Linear's launch
+            h = ops.rowlin(lm.embed.weight, emb[0].weight, emb[0].bias, gather=tok)
+        else:
+            h = ops.linear(lm.embed.weight[tok].contiguous(), emb[0].weight, emb[0].bias)
         h = ops.layernorm_fwd(h, emb[1].weight, emb[1].bias, EPS, save=False)[0]
         ops.act_(h, "relu")
         for li, L in enumerate(self.layers):
-            n1 = ops.layernorm_fwd(h, *L["n1"], EPS, save=False)[0]
-            qkv = ops.linear(n1, L["wqkv"], L["bqkv"])
+            qkv = _ln_linear(h, L["n1"], L["wqkv"], L["bqkv"])
             # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
             a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
                                    step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
-            h = ops.linear(a, L["wo"], L["bo"], res=h)
+            h = _linear_res(a, L["wo"], L["bo"], h)
             h = _ffn_step(h, L["n2"], L)
-        y = ops.layernorm_fwd(h, lm.encoder.after_norm.weight, lm.encoder.after_norm.bias, EPS, save=False)[0]
-        return ops.log_softmax_rows(ops.linear(y, lm.decoder.weight, lm.decoder.bias), **score)
+        z = _ln_linear(h, (lm.encoder.after_norm.weight, lm.encoder.after_norm.bias), lm.decoder.weight, lm.decoder.bias)
+        return z if logits_only else ops.log_softmax_rows(z, **score)
 
 
 class BatchBeamSearch:
@@ -235,10 +254,15 @@ class BatchBeamSearch:
                 anc.index_copy_(1, dyn["step64"], (slot_ids + dyn["step"] * N).view(N, 1))
                 sdyn = (dyn["step"], self.dec_step.pe.index_select(0, dyn["step64"]))
             # full = w_dec * decoder + w_lm * lm + w_len (LengthBonus: 1 per token), summed by the scorers' last launches
+            # the two scorers are independent chains of small launches: the LM runs on the side stream next to the decoder
             has_lm = self.lm_step is not None
+            if has_lm:
+                with ops.BranchScope(enabled=SCORERS_PARALLEL) as br:
+                    z_lm = self.lm_step.step(i, tok, anc, sdyn, logits_only=True)
             full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
             if has_lm:
-                self.lm_step.step(i, tok, anc, sdyn, out=full, alpha=self.w_lm, add=self.w_len, accumulate=True)
+                br.join()
+                ops.log_softmax_rows(z_lm, out=full, alpha=self.w_lm, add=self.w_len, accumulate=True)
             cand = torch.topk(full, C, dim=-1)[1]                   # pre-beam on the weighted full scores
             r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, cand, K, i,
                                                                       step_dev=None if dyn is None else dyn["step"])

@@ -1210,6 +1210,34 @@ def bootstrap_rates(dist, reflen, iters, seed):
 
 
 # ---------------------------------------------------------------------------------------------- decode steps
+ROWLIN = os.environ.get("TAVSR_DECODE_ROWLIN", "1") == "1"
+
+
+def rowlin_ok(x, w, n_rows=None) -> bool:
+    """the one-launch small-step Linear (tavsr_rowlin) takes up to 32 rows and K in {64 .. 2048} powers of two."""
+    K = x.shape[1]
+    N = x.shape[0] if n_rows is None else n_rows
+    return (ROWLIN and N <= 32 and K in (64, 128, 256, 512, 1024, 2048) and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
+            and x.stride(1) == 1 and w.stride(1) == 1 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def rowlin(x, w, b=None, *, ln=None, act=None, res=None, out=None, gather=None):
+    """out = res + act(LN(x[gather]) @ w.T + b) in one launch (csrc/decode.hip:rowlin_kernel) - the Linear layers of a
+    one-token scorer step.  ln = (gamma, beta, eps) or None; gather: int64 row indices into x (embedding lookup)."""
+    N = x.shape[0] if gather is None else gather.numel()
+    K, Nout = x.shape[1], w.shape[0]
+    require_cuda(x, w)
+    assert w.shape[1] == K
+    if out is None:
+        out = empty(N, Nout, like=x)
+    assert out.data_ptr() != x.data_ptr()
+    g, be, eps = ln if ln is not None else (None, None, 0.0)
+    check(lib().tavsr_rowlin(ptr(x), C.c_int64(x.stride(0)), ptr(gather), ptr(g), ptr(be), C.c_float(eps), ptr(w),
+                             C.c_int64(w.stride(0)), ptr(b), ACT[act], ptr(res), C.c_int64(0 if res is None else res.stride(0)),
+                             ptr(out), C.c_int64(out.stride(0)), N, K, Nout, stream()), "tavsr_rowlin")
+    return out
+
+
 def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None, k_new=None, v_new=None):
     """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk].
     ``step_dev`` (int32 device scalar): use min(step + 1, nkeys) keys (graph replays).  ``k_new`` / ``v_new`` (row stride of
