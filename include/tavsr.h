@@ -485,6 +485,10 @@ int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, tavsr_stream
  * ------------------------------------------------------------------------------------------- */
 int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int64_t step, float grad_scale, tavsr_stream_t stream);
+/* torch.optim.AdamW (the `optimizer: adamw` recipes, src/utils/scheduler.py:22-23): p *= 1 - lr * weight_decay before the Adam
+ * update; weight_decay = 0 is tavsr_adam_step. */
+int tavsr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int64_t step, float grad_scale, tavsr_stream_t stream);
 
 /* Gradient buckets of the data-parallel exchange (tavsr/dp.py): tensor t = n[t] floats at ptrs[t], its slot in
  * the flat bucket starts at off[t].  to_flat != 0: flat <- tensors (pack before the all-reduce); else tensors <-

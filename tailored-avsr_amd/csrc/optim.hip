@@ -14,7 +14,7 @@ namespace tavsr {
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                         int64_t n, float beta1, float beta2, float eps, float step_size,
-                                                        float bc2_sqrt, float grad_scale) {
+                                                        float bc2_sqrt, float grad_scale, float decay) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n4) {
     float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
       mm[j] = mm[j] + (gr - mm[j]) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
       vv[j] = vv[j] * beta2 + (1.f - beta2) * gr * gr;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
       const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
-      pp[j] = pp[j] - step_size * (mm[j] / denom);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
+      pp[j] = pp[j] * decay - step_size * (mm[j] / denom);          // [param.mul_(1 - lr * weight_decay);] param.addcdiv_(exp_avg, denom, value=-step_size)
     }
     reinterpret_cast<float4*>(p)[i] = P;
     reinterpret_cast<float4*>(m)[i] = M;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
     const float gr = g[k] * grad_scale;
     m[k] = m[k] + (gr - m[k]) * (1.f - beta1);
     v[k] = v[k] * beta2 + (1.f - beta2) * gr * gr;
-    p[k] = p[k] - step_size * (m[k] / (sqrtf(v[k]) / bc2_sqrt + eps));
+    p[k] = p[k] * decay - step_size * (m[k] / (sqrtf(v[k]) / bc2_sqrt + eps));
   }
 }
 
@@ -147,8 +147,8 @@ extern "C" int tavsr_multi_add(float* const* dst, const float* const* src, const
   return TAVSR_OK;
 }
 
-extern "C" int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                               float eps, int64_t step, float grad_scale, tavsr_stream_t stream) {
+extern "C" int tavsr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int64_t step, float grad_scale, tavsr_stream_t stream) {
   TAVSR_REQUIRE((p && g && m && v) || n <= 0, TAVSR_EINVAL, "adam_step: null pointer");
   TAVSR_REQUIRE(step >= 1, TAVSR_EINVAL, "adam_step: step counts from 1");
   TAVSR_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
@@ -156,11 +156,17 @@ extern "C" int tavsr_adam_step(float* p, const float* g, float* m, float* v, int
   if (n <= 0) return TAVSR_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
   const int64_t n4 = n >> 2;
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)std::max<int64_t>(1, (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     p, g, m, v, n4, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+                     p, g, m, v, n4, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, decay);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
+}
+
+extern "C" int tavsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, int64_t step, float grad_scale, tavsr_stream_t stream) {
+  return tavsr_adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, 0.f, step, grad_scale, stream);
 }
 
 extern "C" int tavsr_bucket_copy(float* const* ptrs_dev, const int64_t* off_dev, const int64_t* n_dev, int32_t ntensors,

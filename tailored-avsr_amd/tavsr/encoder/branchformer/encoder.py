@@ -2,7 +2,7 @@
 
 Constructor keywords, ``forward(xs_pad, ilens, prev_states, ctc, max_layer)`` and state_dict keys
 follow the reference; supported option subset = what the shipped configs use (rel_pos "latest",
-``input_layer`` in {"conv2d", None}); anything else raises ``ValueError`` like the reference does
+``input_layer`` in {"conv2d", "linear", "conv1d" / "conv3dresnet18", None}); anything else raises ``ValueError`` like the reference does
 for unknown strings.
 """
 from __future__ import annotations
@@ -12,6 +12,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from ... import functional as F_
+from ... import functional_av as FA
+from ... import ops
 from ...layers import (Conv2dSubsampling, ConvolutionalGatingMLP, LayerNorm, PositionwiseFeedForward,
                        RelPositionalEncoding, RelPositionMultiHeadedAttention, TooShortUttError, check_short_utt,
                        make_pad_mask)
@@ -42,6 +44,12 @@ class MyBranchformerEncoder(torch.nn.Module):
         pos = lambda: RelPositionalEncoding(output_size, positional_dropout_rate, max_pos_emb_len)
         if input_layer == "conv2d":
             self.embed = Conv2dSubsampling(input_size, output_size, dropout_rate, pos())
+        elif input_layer == "linear":             # the VSR recipes: lip features [B, T, 512] (encoder.py:123-129)
+            self.embed = torch.nn.Sequential(torch.nn.Linear(input_size, output_size), torch.nn.LayerNorm(output_size),
+                                             torch.nn.Dropout(dropout_rate), pos())
+        elif input_layer in ("conv1d", "conv3dresnet18"):      # the constructor default (encoder.py:130-134)
+            self.embed = torch.nn.Sequential(torch.nn.Linear(512, output_size),
+                                             RelPositionalEncoding(output_size, positional_dropout_rate))
         elif input_layer is None:
             self.embed = None
         else:
@@ -78,6 +86,21 @@ class MyBranchformerEncoder(torch.nn.Module):
     def output_size(self) -> int:
         return self._output_size
 
+    def _linear_embed(self, x):
+        """Sequential(Linear[, torch LayerNorm(eps 1e-5), Dropout], RelPositionalEncoding) -> (x * sqrt(d), pos_emb)."""
+        lin, pe = self.embed[0], self.embed[-1]
+        x = F_.LinearFn.apply(x, lin.weight, lin.bias, 1.0)
+        if len(self.embed) == 4:
+            ln, drop = self.embed[1], self.embed[2]
+            x = F_.LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+            if self.training and drop.p > 0:
+                x = F_.DropoutFn.apply(x, drop.p)
+        x, pos = FA.ScaleFn.apply(x, pe.xscale), pe.pos_emb(x.size(1), x.device)
+        if self.training and pe.dropout_rate > 0:           # RelPositionalEncoding: dropout(x), dropout(pos_emb)
+            x = F_.DropoutFn.apply(x, pe.dropout_rate)
+            pos = ops.dropout(pos, pe.dropout_rate)[0]
+        return x, pos
+
     def forward(self, xs_pad: torch.Tensor, ilens: torch.Tensor, prev_states: torch.Tensor = None, ctc=None,
                 max_layer: int = None) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
         masks = (~make_pad_mask(ilens, xs_pad.size(1))[:, None, :]).to(xs_pad.device)
@@ -88,6 +111,8 @@ class MyBranchformerEncoder(torch.nn.Module):
                     f"has {xs_pad.size(1)} frames and is too short for subsampling "
                     + f"(it needs more than {limit_size} frames), return empty results", xs_pad.size(1), limit_size)
             xs_pad, masks = self.embed(xs_pad, masks)
+        elif isinstance(self.embed, torch.nn.Sequential):
+            xs_pad = self._linear_embed(xs_pad)
         elif not isinstance(xs_pad, tuple):
             raise ValueError("input_layer=None expects (x, pos_emb) from an external embedding (AV encoders)")
         lens = masks.squeeze(1).sum(1).to(torch.int64)

@@ -7,12 +7,13 @@ import argparse
 from ..ctc.ctc import CTC
 from ..decoder.transformer_decoder import TransformerDecoder
 from ..encoder.branchformer.encoder import MyBranchformerEncoder
+from ..frontend.conv3d_resnet18 import Conv3dResNet18
 from ..frontend.default import DefaultFrontend
 from ..models.espnet_model import ESPnetASRModel, UtteranceMVN
 from ..specaug.specaug import SpecAug
 from ..utils.tokens import load_token_list
 
-frontend_choices = {"default": DefaultFrontend}
+frontend_choices = {"default": DefaultFrontend, "conv3dresnet18": Conv3dResNet18}      # src/tasks/asr.py:93-103
 specaug_choices = {"specaug": SpecAug}
 encoder_choices = {"branchformer": MyBranchformerEncoder}
 decoder_choices = {"transformer": TransformerDecoder}

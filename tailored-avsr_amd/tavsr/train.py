@@ -22,10 +22,12 @@ from . import dp
 
 
 class FusedAdam:
-    """torch.optim.Adam(params, lr, betas, eps) semantics on flat buffers (no weight decay / amsgrad: the reference
-    uses neither).  ``param_groups`` is kept (one group) so that a learning-rate wrapper can set ``lr``."""
+    """torch.optim.Adam(params, lr, betas, eps) semantics on flat buffers; ``weight_decay`` > 0 gives torch.optim.AdamW's
+    decoupled decay (the ``optimizer: adamw`` recipes).  No amsgrad (the reference does not use it).  ``param_groups`` is
+    kept (one group) so that a learning-rate wrapper or scheduler can set ``lr`` / ``betas``."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.98), eps: float = 1e-9):
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.98), eps: float = 1e-9,
+                 weight_decay: float = 0.0):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")
@@ -46,7 +48,8 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.grad = torch.zeros_like(self.flat)
-        self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps)]
+        self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         self._step = 0
         self._steps = [0] * len(self.params)      # per-parameter step counts (torch.optim.Adam keeps one per parameter)
 
@@ -80,12 +83,13 @@ class FusedAdam:
         for ia, ib in runs:
             lo = self.offsets[ia]
             hi = self.offsets[ib + 1] if ib + 1 < len(self.params) else self.flat.numel()
-            L.check(L.lib().tavsr_adam_step(C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad.data_ptr() + 4 * lo),
-                                            C.c_void_p(self.exp_avg.data_ptr() + 4 * lo),
-                                            C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * lo), C.c_int64(hi - lo),
-                                            C.c_float(g["lr"]), C.c_float(g["betas"][0]), C.c_float(g["betas"][1]),
-                                            C.c_float(g["eps"]), C.c_int64(self._steps[ia]), C.c_float(grad_scale), L.stream()),
-                    "tavsr_adam_step")
+            L.check(L.lib().tavsr_adamw_step(C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad.data_ptr() + 4 * lo),
+                                             C.c_void_p(self.exp_avg.data_ptr() + 4 * lo),
+                                             C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * lo), C.c_int64(hi - lo),
+                                             C.c_float(g["lr"]), C.c_float(g["betas"][0]), C.c_float(g["betas"][1]),
+                                             C.c_float(g["eps"]), C.c_float(g.get("weight_decay", 0.0)),
+                                             C.c_int64(self._steps[ia]), C.c_float(grad_scale), L.stream()),
+                    "tavsr_adamw_step")
 
     def state_dict(self):
         return dict(step=self._step, steps=list(self._steps), exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, param_groups=[
@@ -147,12 +151,101 @@ def get_noam_scheduler(model_params, factor, d_model, warmup):
     return NoamScheduler(d_model, factor, warmup, FusedAdam(model_params, lr=0, betas=(0.9, 0.98), eps=1e-9))
 
 
+class OneCycleLR:
+    """torch.optim.lr_scheduler.OneCycleLR as src/utils/scheduler.py:36-41 builds it (two phases, ``anneal_strategy``
+    "linear" or "cos", pct_start 0.3, div_factor 25, final_div_factor 1e4, momentum cycled through the optimizer's beta1
+    between 0.85 and 0.95) for an optimizer that exposes ``param_groups`` - torch's class insists on a
+    ``torch.optim.Optimizer`` instance, which the flat-buffer optimizer is not.  Same values step for step
+    (tests/test_train_harness.py compares with torch's class)."""
+
+    def __init__(self, optimizer, max_lr, total_steps=None, epochs=None, steps_per_epoch=None, pct_start=0.3,
+                 anneal_strategy="cos", cycle_momentum=True, base_momentum=0.85, max_momentum=0.95, div_factor=25.0,
+                 final_div_factor=1e4):
+        if total_steps is None:
+            if epochs is None or steps_per_epoch is None or epochs <= 0 or steps_per_epoch <= 0:
+                raise ValueError("You must define either total_steps OR (epochs AND steps_per_epoch)")
+            total_steps = epochs * steps_per_epoch
+        if total_steps <= 0:
+            raise ValueError(f"Expected positive integer total_steps, but got {total_steps}")
+        if anneal_strategy not in ("cos", "linear"):
+            raise ValueError(f"anneal_strategy must be one of 'cos' or 'linear', instead got {anneal_strategy}")
+        self.optimizer, self.total_steps, self.anneal_strategy = optimizer, total_steps, anneal_strategy
+        self.cycle_momentum = cycle_momentum
+        self._phases = [dict(end_step=float(pct_start * total_steps) - 1, start_lr="initial_lr", end_lr="max_lr",
+                             start_momentum="max_momentum", end_momentum="base_momentum"),
+                        dict(end_step=total_steps - 1, start_lr="max_lr", end_lr="min_lr", start_momentum="base_momentum",
+                             end_momentum="max_momentum")]
+        for g in optimizer.param_groups:
+            g["initial_lr"] = max_lr / div_factor
+            g["max_lr"] = max_lr
+            g["min_lr"] = g["initial_lr"] / final_div_factor
+            if cycle_momentum:
+                g["max_momentum"], g["base_momentum"] = max_momentum, base_momentum
+                g["betas"] = (max_momentum, g["betas"][1])
+        self.last_epoch = -1
+        self._last_lr = []
+        self.step()                                    # LRScheduler._initial_step
+
+    def _anneal(self, start, end, pct):
+        if self.anneal_strategy == "linear":
+            return (end - start) * pct + start
+        import math
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1)
+
+    def step(self):
+        self.last_epoch += 1
+        n = self.last_epoch
+        if n > self.total_steps:
+            raise ValueError(f"Tried to step {n} times. The specified number of total steps is {self.total_steps}")
+        self._last_lr = []
+        for g in self.optimizer.param_groups:
+            start = 0.0
+            for i, ph in enumerate(self._phases):
+                end = ph["end_step"]
+                if n <= end or i == len(self._phases) - 1:
+                    pct = (n - start) / (end - start)
+                    lr = self._anneal(g[ph["start_lr"]], g[ph["end_lr"]], pct)
+                    mom = self._anneal(g[ph["start_momentum"]], g[ph["end_momentum"]], pct) if self.cycle_momentum else None
+                    break
+                start = end
+            g["lr"] = lr
+            if self.cycle_momentum:
+                g["betas"] = (mom, g["betas"][1])
+            self._last_lr.append(lr)
+
+    def get_last_lr(self):
+        return list(self._last_lr)
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)
+
+
 def set_optimizer(config, e2e, train_loader):
-    """src/utils/scheduler.py:6-45 for the ``scheduler: noam`` recipes (every shipped config)."""
+    """src/utils/scheduler.py:6-45: ``scheduler: noam`` -> Adam(0.9, 0.98, 1e-9) under the Noam rate, no scheduler object;
+    ``scheduler: onecycle`` -> ``optimizer: adamw`` (torch defaults: betas (0.9, 0.999), eps 1e-8, weight decay 0.01) or
+    ``adam`` (betas (0.9, 0.98), eps 10e-09) at ``learning_rate`` under a linear one-cycle schedule over
+    ``epochs x ceil(len(loader) / accum_grad)`` steps."""
+    import math
     ts = config.training_settings
+    steps_per_epoch = math.ceil(len(train_loader) / ts["accum_grad"]) if ts["accum_grad"] != 0 else len(train_loader)
+    optimizer = scheduler = None
     if ts["scheduler"] != "noam":
-        raise RuntimeError("The scheduler should be specified as 'noam' (onecycle is not used by any shipped config)")
-    return get_noam_scheduler(e2e.parameters(), ts["noam_factor"], config.encoder_conf["output_size"], ts["warmup_steps"]), None
+        params = [p for p in e2e.parameters() if p.requires_grad]
+        if ts["optimizer"] == "adamw":
+            optimizer = FusedAdam(params, ts["learning_rate"], betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+        elif ts["optimizer"] == "adam":
+            optimizer = FusedAdam(params, ts["learning_rate"], betas=(0.9, 0.98), eps=10e-09)
+    if ts["scheduler"] == "noam":
+        optimizer = get_noam_scheduler(e2e.parameters(), ts["noam_factor"], config.encoder_conf["output_size"], ts["warmup_steps"])
+    elif ts["scheduler"] == "onecycle":
+        scheduler = OneCycleLR(optimizer, max_lr=ts["learning_rate"], steps_per_epoch=steps_per_epoch, epochs=ts["epochs"],
+                               anneal_strategy="linear")
+    else:
+        raise RuntimeError("The scheduler should be specified as 'noam' or 'onecycle'")
+    return optimizer, scheduler
 
 
 def _to_device(batch, device):

@@ -106,3 +106,34 @@ def test_c_oracle_ctc_greedy_matches_python_oracle():
     # and on the reference's own config-1 ids
     ref_ids = torch.from_numpy(g["ids"][0])
     assert ctc_greedy_collapse(ref_ids) == g["hyp"].tolist()
+
+
+def test_every_recipe_yaml_builds_through_the_task_registries():
+    """the recipe files under tailored-avsr_amd/configs (values of the reference's configs/{ASR,VSR,AVSR}/*english*.yaml)
+    share one top-level key set per task and build on the host through the same registries the reference uses
+    (avsr_main.py:185: AVSRTask for ``task: avsr``, ASRTask for asr / vsr)."""
+    import copy
+    import glob
+
+    import yaml
+    from tavsr.tasks.asr import ASRTask
+    from tavsr.tasks.avsr import AVSRTask
+    files = sorted(glob.glob(os.path.join(ROOT, "tailored-avsr_amd", "configs", "*.yaml")))
+    assert len(files) >= 6
+    keys = {}
+    for f in files:
+        conf = yaml.safe_load(open(f))
+        keys.setdefault(conf["task"], []).append(set(conf))
+        conf["token_list"] = list(TOKENS_EN)
+        task = AVSRTask if conf["task"] == "avsr" else ASRTask
+        model = task.build_model(argparse.Namespace(**copy.deepcopy(conf)))
+        n = sum(p.numel() for p in model.parameters()) / 1e6
+        enc = conf["encoder_conf"]
+        if conf["task"] == "vsr":
+            assert type(model.frontend).__name__ == "Conv3dResNet18" and model.encoder.embed[0].in_features == 512
+            assert 50 < n < 70, (f, n)            # ResNet-18 front-end (11.2 M) + the 12-layer encoder / 6-layer decoder
+        if isinstance(enc.get("cgmlp_weight"), list):       # the *_tailored recipes: a dead branch is not built at all
+            for w, layer in zip(enc["cgmlp_weight"], model.encoder.encoders):
+                assert (layer.cgmlp is None) == (w == 0.0) and (layer.attn is None) == (w == 1.0)
+    for task, sets in keys.items():
+        assert all(s == sets[0] for s in sets), task

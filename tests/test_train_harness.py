@@ -161,3 +161,89 @@ def test_checkpoint_save_load_average_roundtrip(tmp_path):
     assert all(p.requires_grad for p in d.ctc.parameters())          # the reference's typo: the CTC head stays trainable
     MC.save_val_stats(str(tmp_path), [(pa, 12.5), (pb, 11.0)])
     assert open(tmp_path / "val_stats.csv").read().splitlines()[0] == ",model_check_path,cer"
+
+
+@pytest.mark.parametrize("anneal,total", [("linear", 40), ("cos", 37), ("linear", 7)])
+def test_one_cycle_schedule_equals_torch(anneal, total):
+    """tavsr.train.OneCycleLR (for optimizers that only expose param_groups) vs torch.optim.lr_scheduler.OneCycleLR on a
+    torch Adam: learning rate and cycled beta1 at every step, and the error after the last one."""
+    from tavsr.train import OneCycleLR
+
+    class Bare:           # what the flat-buffer optimizer exposes
+        def __init__(self):
+            self.param_groups = [dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)]
+
+    p = torch.nn.Parameter(torch.zeros(3))
+    to = torch.optim.AdamW([p], 5e-4)
+    ts = torch.optim.lr_scheduler.OneCycleLR(to, max_lr=5e-4, total_steps=total, anneal_strategy=anneal)
+    bo = Bare()
+    bs = OneCycleLR(bo, max_lr=5e-4, total_steps=total, anneal_strategy=anneal)
+    for step in range(total):
+        assert bo.param_groups[0]["lr"] == pytest.approx(to.param_groups[0]["lr"], rel=1e-12), step
+        assert bo.param_groups[0]["betas"][0] == pytest.approx(to.param_groups[0]["betas"][0], rel=1e-12), step
+        assert bs.get_last_lr() == pytest.approx(ts.get_last_lr(), rel=1e-12)
+        if step < total - 1:
+            to.step()
+            ts.step()
+            bs.step()
+    ts.step()
+    bs.step()                      # step number total_steps is still allowed, the next one is not
+    with pytest.raises(ValueError):
+        bs.step()
+
+
+def test_set_optimizer_follows_the_reference_factory():
+    """src/utils/scheduler.py:6-45 on a bare namespace: which optimizer / scheduler objects come back for the recipes'
+    (optimizer, scheduler) pairs, steps per epoch with gradient accumulation, and the error for an unknown scheduler."""
+    import argparse
+    from tavsr import train as T
+
+    made = {}
+
+    class FakeAdam:
+        def __init__(self, params, lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0):
+            made.update(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+            self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+
+    real = T.FusedAdam
+    T.FusedAdam = FakeAdam
+    try:
+        e2e = torch.nn.Linear(4, 4)
+        loader = list(range(50))
+        ts = dict(optimizer="adamw", scheduler="onecycle", learning_rate=5e-4, accum_grad=16, epochs=10)
+        opt, sch = T.set_optimizer(argparse.Namespace(training_settings=ts, encoder_conf=dict(output_size=256)), e2e, loader)
+        assert made == dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+        assert isinstance(sch, T.OneCycleLR) and sch.total_steps == 10 * 4 and sch.anneal_strategy == "linear"
+        ts = dict(optimizer="adam", scheduler="onecycle", learning_rate=1e-3, accum_grad=0, epochs=2)
+        opt, sch = T.set_optimizer(argparse.Namespace(training_settings=ts, encoder_conf=dict(output_size=256)), e2e, loader)
+        assert made == dict(lr=1e-3, betas=(0.9, 0.98), eps=10e-09, weight_decay=0.0) and sch.total_steps == 100
+        ts = dict(optimizer="adam", scheduler="noam", noam_factor=1.6, warmup_steps=10000, accum_grad=4, learning_rate=1e-3)
+        opt, sch = T.set_optimizer(argparse.Namespace(training_settings=ts, encoder_conf=dict(output_size=256)), e2e, loader)
+        assert isinstance(opt, T.NoamScheduler) and sch is None and made["lr"] == 0 and made["eps"] == 1e-9
+        ts = dict(optimizer="adam", scheduler="cosine", learning_rate=1e-3, accum_grad=1, epochs=1)
+        with pytest.raises(RuntimeError):
+            T.set_optimizer(argparse.Namespace(training_settings=ts, encoder_conf=dict(output_size=256)), e2e, loader)
+    finally:
+        T.FusedAdam = real
+
+
+@pytest.mark.gpu
+def test_fused_adamw_under_one_cycle_matches_torch():
+    """the ``optimizer: adamw`` + ``scheduler: onecycle`` recipes: decoupled weight decay, lr and beta1 moved every step."""
+    from tavsr.train import FusedAdam, OneCycleLR
+    ref = [torch.nn.Parameter(synth(s, seed=121 + i).cuda()) for i, s in enumerate(SHAPES)]
+    got = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    oa = torch.optim.AdamW(ref, 5e-3)
+    sa = torch.optim.lr_scheduler.OneCycleLR(oa, max_lr=5e-3, total_steps=12, anneal_strategy="linear")
+    ob = FusedAdam(got, 5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    sb = OneCycleLR(ob, max_lr=5e-3, total_steps=12, anneal_strategy="linear")
+    for step in range(11):
+        for i, (pa, pb) in enumerate(zip(ref, got)):
+            g = synth(tuple(pa.shape), seed=900 + 10 * step + i).cuda()
+            pa.grad, pb.grad = g.clone(), g
+        oa.step()
+        sa.step()
+        ob.step()
+        sb.step()
+    for i, (pa, pb) in enumerate(zip(ref, got)):
+        assert rel_err(pb.detach().cpu(), pa.detach().cpu()) < 2e-6, i
