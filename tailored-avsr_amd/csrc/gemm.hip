@@ -599,6 +599,11 @@ __device__ unsigned int g_trace_n;
 //      loader move by one scalar and out-of-image rows are pointed at a zero page.
 //   2: the k-major B operand is the image (weight gradient dW = dY^T patches): B(k = m, n = tap*C + c); a 64-wide n
 //      tile lies in one tap, validity is per k row.
+// Conv3d stem (1 -> 64 channels, kernel (5,7,7), stride (1,2,2), padding (2,3,3); conv3d_resnet18.py:48-57) over clips
+// x [clips][T = conv_C][H][W], single input channel, 245 taps padded to K / N = 256 - every operand element is its own
+// 4-byte LDS-DMA gather (a patch row is 35 runs of 7 floats), so no patch matrix is ever written:
+//   4: A(m = output pixel (clip, t, ho, wo), k = (kt*7 + kh)*7 + kw) = x[clip][t + kt - 2][2 ho - 3 + kh][2 wo - 3 + kw];
+//   5: the k-major B operand (weight gradient): B(k = pixel, n = tap), as 4 with the roles of rows and columns swapped.
 template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM, int KW = 1, int CONV = 0>
 __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid, bool vec_epi) {
   constexpr int BK = 32, NG = BK / 8;
@@ -608,7 +613,8 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
   using LA = GLoader<BM, AK, NT>;
   using LB = GLoader<BN, BKM, NT>;
   constexpr int ASZ = BM * BK, STAGE = (BM + BN) * BK;
-  constexpr int G = LA::NR + LB::NR;          // LDS-DMA instructions per wave per tile
+  constexpr int NR4A = BM * BK / NT, NR4B = BN * BK / NT;      // 4-byte gathers per thread per tile (CONV 4 / 5)
+  constexpr int G = (CONV == 4 ? NR4A : LA::NR) + (CONV == 5 ? NR4B : LB::NR);          // LDS-DMA instructions per wave per tile
   static_assert((S - 2) * G <= 63, "vmcnt field");
   __shared__ __attribute__((aligned(1024))) float smem[S * STAGE];
 
@@ -673,6 +679,54 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       cmask[i] = c9 ? mk : 1u;
     }
   }
+  // CONV 4: gather i of this thread fills LDS float (i NT + tid) of the k-contiguous image: row 8 i + (tid >> 5), physical
+  // column p = tid & 31, i.e. (XOR swizzle) k = 32 kt + kk with kk = (((p >> 2) ^ ((4 i + wave) & 7)) << 2) + (p & 3) - two
+  // values per thread (i even / odd), so a K-step decodes two taps, not eight.  Per gather stay: the pixel's offset in x and
+  // one validity mask (bit a: frame t + a - 2 exists; bit 8 + b: row 2 ho - 3 + b; bit 16 + c: column 2 wo - 3 + c).
+  static_assert(CONV != 4 || NT == 256, "the two-taps-per-thread decoding assumes 8 rows per gather instruction");
+  int s4_base[CONV == 4 ? NR4A : 1], s4_mask[CONV == 4 ? NR4A : 1];
+  const int sT = d.conv_C, sH = d.conv_H, sW = d.conv_W, sHo = (sH - 1) / 2 + 1, sWo = (sW - 1) / 2 + 1;
+  const int s4_p = tid & 31;
+  const int s4_kk0 = ((((s4_p >> 2) ^ (wave & 7))) << 2) + (s4_p & 3), s4_kk1 = ((((s4_p >> 2) ^ ((wave + 4) & 7))) << 2) + (s4_p & 3);
+  if (CONV == 4) {
+#pragma unroll
+    for (int i = 0; i < NR4A; ++i) {
+      const int row = i * 8 + (tid >> 5);
+      const int m = min(m0 + row, d.M - 1);
+      const int wo = m % sWo, ho = (m / sWo) % sHo, ft = m / (sWo * sHo);          // ft = clip * T + t
+      const int t = ft % sT, hy = 2 * ho - 3, wx = 2 * wo - 3;
+      s4_base[i] = (ft * sH + hy) * sW + wx;
+      int mk = 0;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) mk |= (int)((unsigned)(t + q - 2) < (unsigned)sT) << q;
+#pragma unroll
+      for (int q = 0; q < 7; ++q)
+        mk |= ((int)((unsigned)(hy + q) < (unsigned)sH) << (8 + q)) | ((int)((unsigned)(wx + q) < (unsigned)sW) << (16 + q));
+      s4_mask[i] = mk;
+    }
+  }
+  // CONV 5: gather (i, wave) of a tile is B(k = 32 kt + 4 i + wave, n = n0 + lane): the tap is fixed per lane, the pixel is
+  // the same for the whole wave and walks on by 4 per gather (tiles are issued in k order): its coordinates and its offset
+  // in x are carried (wave-uniform), not divided out.  Needs even H and W (host).
+  static_assert(CONV != 5 || (BN == 64 && NT == 256), "one k row per wave instruction");
+  int s5_wo = 0, s5_ho = 0, s5_t = 0, s5_off = 0, s5_tapoff = 0, s5_c3 = 0;
+  bool s5_th = false;           // frame t + a - 2 and row 2 ho - 3 + b exist (changes only when the pixel changes row)
+  int s5_a = 0, s5_b = 0;
+  bool s5_nok = false;
+  if (CONV == 5) {
+    const int nn = n0 + lane;
+    s5_a = nn / 49; s5_b = (nn % 49) / 7;
+    const int c = nn % 7;
+    s5_c3 = c - 3;
+    s5_nok = nn < 245;
+    s5_tapoff = ((s5_a - 2) * sH + s5_b - 3) * sW + c - 3;
+    const int m = kbeg + wave;
+    s5_wo = m % sWo; s5_ho = (m / sWo) % sHo;
+    const int ft = m / (sWo * sHo);
+    s5_t = ft % sT;
+    s5_off = (ft * sH + 2 * s5_ho) * sW + 2 * s5_wo;
+    s5_th = s5_nok && (unsigned)(s5_t + s5_a - 2) < (unsigned)sT && (unsigned)(2 * s5_ho - 3 + s5_b) < (unsigned)sH;
+  }
   // CONV 3 (K tail: K % 32 != 0): chunks whose first k lies at or past K are fetched from a zero page; a k-contiguous chunk
   // that straddles K (K % 4 != 0) is fetched whole and its k >= K elements are zeroed in LDS before the last K-step
   int kofsA[LA::NR], kofsB[LB::NR];
@@ -703,7 +757,23 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       }
       return;
     }
-    if (CONV == 1) {
+    if (CONV == 4) {
+      int tapoff[2], sh[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = kbeg + kt * BK + (q ? s4_kk1 : s4_kk0);
+        const int a = k / 49, r = k - 49 * a, b = r / 7, c = r - 7 * b;
+        tapoff[q] = ((a - 2) * sH + b) * sW + c;
+        sh[q] = k < 245 ? (a | ((8 + b) << 8) | ((16 + c) << 16)) : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < NR4A; ++i) {
+        const int q = i & 1, mk = s4_mask[i];
+        const bool ok = sh[q] >= 0 && (((mk >> (sh[q] & 31)) & (mk >> ((sh[q] >> 8) & 31)) & (mk >> ((sh[q] >> 16) & 31))) & 1);
+        const float* src = ok ? A + (s4_base[i] + tapoff[q]) : d.conv_zero;
+        __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + i * NT + wave * 64), 4, 0, 0);
+      }
+    } else if (CONV == 1) {
       const int kk = kbeg + kt * BK, tap = kk / d.conv_C;
       const int toff = c9 ? (tap / 3 - 1) * d.conv_W + (tap % 3 - 1) : 0;
       const int64_t delta = (int64_t)toff * d.conv_C + (kk - tap * d.conv_C);
@@ -715,7 +785,25 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
     } else {
       LA::issue(Ak + kt * kstepA, offA, smem + st * STAGE, wave);
     }
-    if (CONV == 2) {
+    if (CONV == 5) {
+#pragma unroll
+      for (int i = 0; i < NR4B; ++i) {
+        const bool ok = s5_th && (unsigned)(2 * s5_wo + s5_c3) < (unsigned)sW;
+        const float* src = ok ? B + (s5_off + s5_tapoff) : d.conv_zero;
+        __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + ASZ + i * NT + wave * 64), 4, 0, 0);
+        s5_wo += 4;
+        s5_off += 8;
+        if (s5_wo >= sWo) {                          // wave-uniform: next output row (W = 2 Wo, H = 2 Ho: the offset in x
+          s5_wo -= sWo;                              // moves on by one input row, also across frames and clips)
+          s5_off += sW;
+          if (++s5_ho == sHo) {
+            s5_ho = 0;
+            if (++s5_t == sT) s5_t = 0;
+          }
+          s5_th = s5_nok && (unsigned)(s5_t + s5_a - 2) < (unsigned)sT && (unsigned)(2 * s5_ho - 3 + s5_b) < (unsigned)sH;
+        }
+      }
+    } else if (CONV == 2) {
       const int tap = n0 / d.conv_C, cb = n0 - tap * d.conv_C, dy = c9 ? tap / 3 - 1 : 0, dx = c9 ? tap % 3 - 1 : 0;
 #pragma unroll
       for (int i = 0; i < LB::NR; ++i) {
@@ -968,6 +1056,16 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
   // TAVSR_CONV_TILE=0 / TAVSR_CONV_DW_TILE=0 keep 64x64 everywhere (A/B switches).
   static const int wide = [] { const char* e = getenv("TAVSR_CONV_TILE"); return e ? atoi(e) : 1; }();
   static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
+  if (d.conv_mode == 4 || d.conv_mode == 5) {      // Conv3d stem: 4-byte gathers, three stages
+    GemmArgs a4{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve};
+    const dim3 grid4(a4.tiles_m * a4.tiles_n, 1, nsplit);
+    if (d.conv_mode == 4)
+      hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, false, false, 1, 4>), grid4, dim3(256), 0, s, a4);
+    else
+      hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, true, true, 1, 5>), grid4, dim3(256), 0, s, a4);
+    TAVSR_LAUNCH_CHECK();
+    return launch_epilogue(a4, s);
+  }
   if (d.conv_mode == 1 && !d.b_kmajor && nsplit == 1 && wide && d.N % 128 == 0) {
     GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 128), (int)vec_epi_ok(d)};
     hipLaunchKernelGGL((gemm_glds_kernel<64, 128, 2, 2, 2, 3, false, false, 1, 1>), dim3(a2.tiles_m * a2.tiles_n, 1, 1), dim3(256), 0, s, a2);
@@ -1084,9 +1182,9 @@ static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
 // is split until all five block slots of every CU are filled (the slabs stay tiny); TAVSR_CONV_DW_BLOCKS tunes the target
 static Plan plan_conv(const tavsr_gemm_desc& d, bool can_split) {
   Plan pc = plan(d, can_split, true);
-  if (d.conv_mode == 2 && can_split) {
+  if ((d.conv_mode == 2 || d.conv_mode == 5) && can_split) {
     static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
-    const bool wide = dw_wide && d.M % 128 == 0;                 // 128x64 tiles (launch_conv): three block slots per CU
+    const bool wide = d.conv_mode == 2 && dw_wide && d.M % 128 == 0;     // 128x64 tiles (launch_conv): three block slots per CU
     const long tiles = (long)cdiv(d.M, wide ? 128 : 64) * cdiv(d.N, 64);
     static const long target64 = [] { const char* e = getenv("TAVSR_CONV_DW_BLOCKS"); return e ? atol(e) : 2560L; }();
     static const long target128 = [] { const char* e = getenv("TAVSR_CONV_DW_BLOCKS_WIDE"); return e ? atol(e) : 2304L; }();
@@ -1125,12 +1223,29 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
   const bool can_split = d.ws != nullptr;
   const bool fast = glds_ok(d, vec);
   if (d.conv_mode != 0) {       // implicit 3x3/s1/p1 convolution: only the LDS-DMA kernel reads images as patch operands
-    TAVSR_REQUIRE(d.conv_mode == 1 || d.conv_mode == 2, TAVSR_EINVAL, "tavsr_gemm: conv_mode must be 0, 1 or 2");
+    TAVSR_REQUIRE(d.conv_mode == 1 || d.conv_mode == 2 || d.conv_mode == 4 || d.conv_mode == 5, TAVSR_EINVAL,
+                  "tavsr_gemm: conv_mode must be 0, 1, 2, 4 or 5");
     TAVSR_REQUIRE(d.drop_p == 0.f, TAVSR_EUNSUPPORTED, "tavsr_gemm: no epilogue dropout on convolution operands");
     TAVSR_REQUIRE(d.conv_zero && aligned16(d.conv_zero) && d.conv_H > 0 && d.conv_W > 0 && d.conv_C > 0, TAVSR_EINVAL,
                   "tavsr_gemm: conv needs H, W, C and a 16-byte aligned zero page");
     TAVSR_REQUIRE(d.nb1 * d.nb2 == 1 && fast && force_cfg < 0, TAVSR_EUNSUPPORTED,
                   "tavsr_gemm: conv operands need an unbatched, aligned problem with K %% 32 == 0");
+    if (d.conv_mode >= 4) {       // Conv3d stem: conv_H x conv_W input frames, conv_C frames per clip, 245 taps padded to 256
+      const int64_t per_frame = (int64_t)((d.conv_H - 1) / 2 + 1) * ((d.conv_W - 1) / 2 + 1);
+      const int64_t pixels = d.conv_mode == 4 ? d.M : d.K;
+      TAVSR_REQUIRE(pixels % (per_frame * d.conv_C) == 0 && d.conv_C < 1024 && d.conv_H < 1000 && d.conv_W < 1000 &&
+                        pixels / per_frame * d.conv_H * d.conv_W < (1ll << 31),
+                    TAVSR_EINVAL, "tavsr_gemm: stem rows must be whole clips of conv_C frames (fewer than 2^31 input pixels)");
+      if (d.conv_mode == 4)
+        TAVSR_REQUIRE(!d.a_kmajor && !d.b_kmajor && d.K == 256 && d.ldb >= 256, TAVSR_EUNSUPPORTED,
+                      "tavsr_gemm: conv mode 4 needs the NT layout with K = 256 (245 taps + padding)");
+      else
+        TAVSR_REQUIRE(d.a_kmajor && d.b_kmajor && d.N == 256 && d.M % 4 == 0, TAVSR_EUNSUPPORTED,
+                      "tavsr_gemm: conv mode 5 needs the TN layout with N = 256 (245 taps + padding)");
+      Plan p4 = plan_conv(d, can_split);
+      if (p4.nsplit > 1 && d.ws_floats < ws_floats_for(d, p4.nsplit)) p4 = plan(d, false, true);
+      return launch_conv(d, p4.nsplit, p4.kchunk, s);
+    }
     const int cs = d.conv_stride > 1 ? d.conv_stride : 1, taps = d.conv_taps == 1 ? 1 : 9;
     TAVSR_REQUIRE(d.conv_taps == 0 || d.conv_taps == 1 || d.conv_taps == 9, TAVSR_EINVAL, "tavsr_gemm: conv_taps must be 1 or 9");
     const int64_t pixels = d.conv_mode == 1 ? d.M : d.K;       // output pixels

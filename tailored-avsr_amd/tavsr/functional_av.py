@@ -100,15 +100,19 @@ class VisualFrontendFn(torch.autograd.Function):
         x = x.contiguous()
         saved = {}
         # ---- stem: Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BN3d -> Swish -> MaxPool(1,3,3)/(1,2,2)
-        col0, H0, W0 = ops.im2col_stem(x)
         w0 = ops.fill_(ops.empty(64, 256, like=x), 0.0)
         ops.copy2d(p["frontend3D.0.weight"].reshape(64, 245), w0[:, :245])
-        z0 = ops.linear(col0, w0)
+        if ops.stem_implicit_ok(x):            # every patch element is gathered by the GEMM's own loader: no patch matrix
+            col0 = None
+            z0, H0, W0 = ops.stem_conv_fwd(x, w0)
+        else:
+            col0, H0, W0 = ops.im2col_stem(x)
+            z0 = ops.linear(col0, w0)
         m0, r0 = _BN.stats(z0, "frontend3D.1.", bufs, training)
         y0 = ops.bn_apply_fwd(z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
         cur, idx0, Hc, Wc = ops.maxpool3x3s2_fwd(y0, N, H0, W0, 64)
         del y0
-        saved["stem"] = (x, z0, m0, r0, idx0, H0, W0, w0, col0)     # 288 GB of HBM: the 6 GB patch matrix stays resident
+        saved["stem"] = (x, z0, m0, r0, idx0, H0, W0, w0, col0)     # fallback route: the 6 GB patch matrix stays resident
         # ---- trunk
         blocks = []
         cin = 64
@@ -200,7 +204,10 @@ class VisualFrontendFn(torch.autograd.Function):
         # max-pool backward inside the BatchNorm backward passes: the 1.6 GB gradient of the pool's input is never written
         dz0, G["frontend3D.1.weight"], G["frontend3D.1.bias"] = ops.bn_bwd_pooled(
             d.contiguous(), idx0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], N, H0, W0, "swish")
-        gw0 = ops.linear_dw(dz0, col0, force=STEM_DW_PLAN)            # [64, 256], columns >= 245 are padding
+        if col0 is None:
+            gw0 = ops.stem_conv_dw(dz0, x)                                # [64, 256], columns >= 245 are padding
+        else:
+            gw0 = ops.linear_dw(dz0, col0, force=STEM_DW_PLAN)
         del col0
         g0 = ops.empty(64, 245, like=gw0)
         ops.copy2d(gw0[:, :245], g0)

@@ -126,7 +126,9 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         key += f" M={M} N={N} K={K} nb={max(1, nb1) * max(1, nb2)}"
     nb = max(1, nb1) * max(1, nb2)
     a_el, b_el = M * K, K * N                 # each operand once; an implicit-conv operand is the image, not its 9 taps
-    if conv is not None:
+    if conv is not None and conv[0] >= 4:      # Conv3d stem: the clip tensor is the gathered operand
+        a_el, b_el = (A.numel(), b_el) if conv[0] == 4 else (a_el, B.numel())
+    elif conv is not None:
         a_el, b_el = (a_el // 9, b_el) if conv[0] == 1 else (a_el, b_el // 9)
     c_el = M * N * (1 + (R is not None) + (Z is not None) + (DZ is not None))
     PROFILE.records.append((key, 2.0 * M * N * K * nb, 4.0 * nb * (a_el + b_el + c_el), e0, e1))
@@ -928,6 +930,37 @@ def col2im2d(dcol, N, H, W, Cn, KH, KW, stride, pad, extra=None):
     check(lib().tavsr_col2im2d(ptr(dcol), ptr(dx), C.c_int64(N), H, W, Cn, KH, KW, stride, pad, ptr(extra), stream()),
           "tavsr_col2im2d")
     return dx
+
+
+# Conv3d stem as an implicit GEMM (tavsr_gemm_desc.conv_mode 4 / 5): no 6 GB patch matrix.  TAVSR_STEM_IMPLICIT=0 returns to
+# im2col_stem + plain GEMMs (A/B switch; also the route for shapes the gather loader does not take).
+STEM_IMPLICIT = os.environ.get("TAVSR_STEM_IMPLICIT", "1") == "1"
+
+
+def stem_implicit_ok(x) -> bool:
+    B, T, H, W = x.shape
+    Ho, Wo = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+    return (STEM_IMPLICIT and H % 2 == 0 and W % 2 == 0 and W >= 8 and (B * T * Ho * Wo) % 32 == 0 and T < 1024 and H < 1000 and W < 1000
+            and B * T * H * W < 2 ** 31 and x.data_ptr() % 16 == 0)
+
+
+def stem_conv_fwd(x, w0p):
+    """x [B,T,H,W] clips, w0p [64, 256] (245 taps of the (5,7,7) kernel + zero columns) -> z [B*T*Ho*Wo, 64]."""
+    B, T, H, W = x.shape
+    Ho, Wo = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+    M = B * T * Ho * Wo
+    z = empty(M, w0p.shape[0], like=x)
+    gemm(M, w0p.shape[0], 256, x, 4, w0p, 256, z, w0p.shape[0], conv=(4, H, W, T))
+    return z, Ho, Wo
+
+
+def stem_conv_dw(dz, x):
+    """dW0 [64, 256] = dz^T patches(x) (columns >= 245 are zero); dz [B*T*Ho*Wo, 64]."""
+    B, T, H, W = x.shape
+    M, cout = dz.shape
+    dw = empty(cout, 256, like=dz)
+    gemm(cout, 256, M, dz, cout, x, 4, dw, 256, a_kmajor=True, b_kmajor=True, conv=(5, H, W, T))
+    return dw
 
 
 def im2col_stem(x):
