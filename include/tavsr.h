@@ -428,6 +428,8 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
  *       so one captured hipGraph of the scorer step can be replayed for every step of the search.
  *       k_new / v_new (nullable, row stride ldq): this step's keys / values [N][H*dk].  They are key number nkeys-1 of every
  *       hypothesis (pool row (nkeys-1)*N + n, which anc must name): read from here and written to the pool by the same launch.
+ *       group (0 / 1: none): hypotheses n in [u*group, (u+1)*group) belong to one utterance (the beam): they are scheduled
+ *       next to each other per head, so that the rows their ancestor lists share are fetched once per CU.
  *   tavsr_kv_append      : kpool/vpool row (*step_dev * N + n) = k[n] / v[n] (the rows this step's anc column names).
  *   tavsr_ctc_prefix_step: espnet CTCPrefixScoreTH.__call__ (no attention window) for C candidate tokens per
  *       hypothesis.  logp [U][T][V] log-softmax of the CTC head, lens [U] frames, hypotheses n belong to utterance n / K.
@@ -450,7 +452,7 @@ int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, const float
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                          const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N, int32_t H,
                          int32_t dk, float scale, const int32_t* step_dev, const float* k_new, const float* v_new,
-                         tavsr_stream_t stream);
+                         int32_t group, tavsr_stream_t stream);
 int tavsr_kv_append(const float* k, const float* v, int64_t ld_src, float* kpool, float* vpool, int64_t ldkv, int32_t N,
                     int32_t D, int32_t max_steps, const int32_t* step_dev, tavsr_stream_t stream);
 int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,

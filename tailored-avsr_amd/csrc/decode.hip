@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
                                                              int nkeys, float* __restrict__ out, int64_t ldo, int N, int H,
                                                              int dk, float scale, const int32_t* __restrict__ step_dev,
                                                              const float* __restrict__ k_new, const float* __restrict__ v_new,
-                                                             float* __restrict__ kpool_w, float* __restrict__ vpool_w) {
+                                                             float* __restrict__ kpool_w, float* __restrict__ vpool_w, int group) {
   constexpr int KG = 64 / DL;
   __shared__ float s_p[4][kTreeMaxKeys];
   __shared__ int32_t s_a[4][kTreeMaxKeys];
@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool live = blockIdx.x * 4 + wave < N * H;       // surplus waves recompute the last item and store nothing
   const int item = min(blockIdx.x * 4 + wave, N * H - 1);
-  const int n = item / H, h = item % H;
+  // item order (utterance, head, beam slot): the waves of a block are hypotheses of ONE utterance on ONE head - their
+  // ancestor lists share most rows (a beam is a tree), so the block's gathers hit the same lines in the CU's cache
+  const int n = (item / (H * group)) * group + item % group, h = (item / group) % H;
   const float* qv = q + (int64_t)n * ldq + h * dk;
   const int32_t* a = anc + (int64_t)n * ld_anc;
   for (int d = lane; d < dk; d += 64) s_q[wave][d] = qv[d] * scale;
@@ -445,7 +447,7 @@ extern "C" int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, 
 extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                                     const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N,
                                     int32_t H, int32_t dk, float scale, const int32_t* step_dev, const float* k_new,
-                                    const float* v_new, tavsr_stream_t stream) {
+                                    const float* v_new, int32_t group, tavsr_stream_t stream) {
   TAVSR_REQUIRE(q && kpool && vpool && anc && out, TAVSR_EINVAL, "tree_attn_step: null pointer");
   TAVSR_REQUIRE((k_new == nullptr) == (v_new == nullptr), TAVSR_EINVAL, "tree_attn_step: k_new and v_new go together");
   TAVSR_REQUIRE(nkeys > 0 && nkeys <= kTreeMaxKeys, TAVSR_EUNSUPPORTED, "tree_attn_step: 1..%d keys supported (got %d)",
@@ -455,13 +457,14 @@ extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kp
   if (N <= 0) return TAVSR_OK;
   TAVSR_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)q | (uintptr_t)out | (uintptr_t)vpool | (uintptr_t)k_new | (uintptr_t)v_new) & 15) == 0,
                 TAVSR_EALIGN, "tree_attn_step: q / out / k_new / v_new rows must be 16-byte aligned");
+  if (group <= 0 || N % group != 0) group = 1;
   const dim3 grid((unsigned)((N * H + 3) / 4));
   if (dk <= 64)
     hipLaunchKernelGGL(tree_attn_step_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
-                       nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool));
+                       nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool), group);
   else
     hipLaunchKernelGGL(tree_attn_step_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
-                       nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool));
+                       nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool), group);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -40,6 +40,7 @@ def _cat(ws):
 # and the fused source attention cut the chain.  TAVSR_DECODE_FUSED=0 keeps the GEMM launches (A/B switch).
 FUSED_STEP = os.environ.get("TAVSR_DECODE_FUSED", "1") == "1"
 SCORERS_PARALLEL = os.environ.get("TAVSR_DECODE_PARALLEL", "1") == "1"   # decoder || LM on two streams
+TREE_GROUP = int(os.environ.get("TAVSR_DECODE_TREE_GROUP", "1"))     # beams of an utterance side by side in the tree attention
 FUSED_FFN = os.environ.get("TAVSR_DECODE_FUSED_FFN", "0") == "1"      # measured: 153 vs 166 utt/s at batch 64 (in-call A/B): off
 
 
@@ -114,7 +115,8 @@ class _DecoderStep:
             qkv = _ln_linear(x, L["n1"], L["wqkv"], L["bqkv"])
             # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
             a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
-                                   step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
+                                   step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:],
+                                   group=TREE_GROUP * self.K)
             x = _linear_res(a, L["wo"], L["bo"], x)
             q2 = _ln_linear(x, L["n2"], L["wq2"], L["bq2"])
             # source attention: the K slots of an utterance are K query rows against that utterance's memory
@@ -154,8 +156,8 @@ class _LMStep:
                 wo=a.linear_out.weight, bo=a.linear_out.bias,
                 w1=ff.w_1.weight, b1=ff.w_1.bias, w2=ff.w_2.weight, b2=ff.w_2.bias))
 
-    def start(self, like, N, max_steps):
-        self.N = N
+    def start(self, like, N, max_steps, K=1):
+        self.N, self.K = N, K
         self.kpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
         self.vpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
 
@@ -173,7 +175,8 @@ class _LMStep:
             qkv = _ln_linear(h, L["n1"], L["wqkv"], L["bqkv"])
             # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
             a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
-                                   step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
+                                   step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:],
+                                   group=TREE_GROUP * self.K)
             h = _linear_res(a, L["wo"], L["bo"], h)
             h = _ffn_step(h, L["n2"], L)
         z = _ln_linear(h, (lm.encoder.after_norm.weight, lm.encoder.after_norm.bias), lm.decoder.weight, lm.decoder.bias)
@@ -217,7 +220,7 @@ class BatchBeamSearch:
         logp_ctc = ops.log_softmax_rows(ops.linear(enc.reshape(U * T, D), ctc.ctc_lo.weight, ctc.ctc_lo.bias)).view(U, T, V)
         self.dec_step.start(enc, enc_lens, N, K, steps)
         if self.lm_step is not None:
-            self.lm_step.start(enc, N, steps)
+            self.lm_step.start(enc, N, steps, K)
         # running state
         tok = torch.full((N,), self.sos, dtype=torch.int64, device=dev)
         yseq = torch.full((N, steps + 2), self.eos, dtype=torch.int64, device=dev)

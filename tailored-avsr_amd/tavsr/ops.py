@@ -1271,7 +1271,7 @@ def rowlin(x, w, b=None, *, ln=None, act=None, res=None, out=None, gather=None):
     return out
 
 
-def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None, k_new=None, v_new=None):
+def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None, k_new=None, v_new=None, group=1):
     """q [N, H*dk] (row stride q.stride(0)); kpool/vpool [nodes, H*dk]; anc int32 [N, >= nkeys] -> [N, H*dk].
     ``step_dev`` (int32 device scalar): use min(step + 1, nkeys) keys (graph replays).  ``k_new`` / ``v_new`` (row stride of
     q): this step's keys / values - the last key of every hypothesis - appended to the pools by the same launch."""
@@ -1283,7 +1283,7 @@ def tree_attn_step(q, kpool, vpool, anc, nkeys, H, dk, out=None, step_dev=None, 
         out = empty(N, H * dk, like=q)
     check(lib().tavsr_tree_attn_step(ptr(q), C.c_int64(q.stride(0)), ptr(kpool), ptr(vpool), C.c_int64(kpool.stride(0)),
                                      ptr(anc), C.c_int64(anc.stride(0)), int(nkeys), ptr(out), C.c_int64(out.stride(0)), N, H, dk,
-                                     C.c_float(1.0 / (dk ** 0.5)), ptr(step_dev), ptr(k_new), ptr(v_new), stream()),
+                                     C.c_float(1.0 / (dk ** 0.5)), ptr(step_dev), ptr(k_new), ptr(v_new), int(group), stream()),
           "tavsr_tree_attn_step")
     return out
 
