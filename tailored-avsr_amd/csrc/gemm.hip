@@ -42,6 +42,7 @@ struct GemmArgs {
   int nsplit;
   int tiles_m, tiles_n;
   int vec_epi;    // LDS-DMA kernels: epilogue through LDS with 16-byte row accesses (finish_tile_vec)
+  int zmap;       // split-K convolution weight gradients: all tiles of a K slice on one XCD (see gemm_glds_kernel)
 };
 
 // Fixed-order sum of the split-K slabs + the fused epilogue (same math as the in-kernel one); one thread per
@@ -211,7 +212,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int row, 
 template <int TM, int TN>
 __device__ __forceinline__ void finish_tile(const tavsr_gemm_desc& d, int nsplit, f32x16 (&acc)[TM][TN],
                                             float (&asum)[TM], bool want_rowsum, int m0, int n0, int wm, int wn, int lr,
-                                            int lk, int z1, int z2, int64_t coff, const float* bias_pre = nullptr) {
+                                            int lk, int z1, int z2, int64_t coff, int zidx, const float* bias_pre = nullptr) {
   if (want_rowsum) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] += __shfl_xor(asum[i], 32, 64);
@@ -222,7 +223,7 @@ __device__ __forceinline__ void finish_tile(const tavsr_gemm_desc& d, int nsplit
   if (nsplit > 1) {
     const int64_t mn = (int64_t)d.M * d.N;
     const int nbatch = gridDim.y;
-    float* slab = d.ws + ((int64_t)blockIdx.z * nbatch + blockIdx.y) * mn;
+    float* slab = d.ws + ((int64_t)zidx * nbatch + blockIdx.y) * mn;
     float* rsum0 = d.ws + (int64_t)nsplit * nbatch * mn;       // [nsplit][M] (only when nbatch == 1)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -242,7 +243,7 @@ __device__ __forceinline__ void finish_tile(const tavsr_gemm_desc& d, int nsplit
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * TM * 32 + i * 32 + lr;
-        if (m < d.M) rsum0[(int64_t)blockIdx.z * d.M + m] = asum[i];
+        if (m < d.M) rsum0[(int64_t)zidx * d.M + m] = asum[i];
       }
     }
     return;
@@ -433,7 +434,7 @@ void gemm_kernel(const GemmArgs args) {
   if (fast) run_loop(std::true_type{});
   else run_loop(std::false_type{});
 
-  finish_tile<TM, TN>(d, args.nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff);
+  finish_tile<TM, TN>(d, args.nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff, (int)blockIdx.z);
 }
 
 // Epilogue through LDS (the staging ring is free once the K loop is over): the accumulators (lane = column, registers =
@@ -445,7 +446,7 @@ void gemm_kernel(const GemmArgs args) {
 template <int BM, int BN, int NT, int TM, int TN>
 __device__ __forceinline__ void finish_tile_vec(const tavsr_gemm_desc& d, int nsplit, f32x16 (&acc)[TM][TN], float* __restrict__ img,
                                                 int m0, int n0, int wm, int wn, int lr, int lk, int z1, int z2, int64_t coff,
-                                                int tid) {
+                                                int tid, int zidx) {
   __syncthreads();                                   // every wave has finished reading the staging ring
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -461,7 +462,7 @@ __device__ __forceinline__ void finish_tile_vec(const tavsr_gemm_desc& d, int ns
   float* base;
   int64_t ld;
   if (split) {
-    base = d.ws + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * ((int64_t)d.M * d.N);
+    base = d.ws + ((int64_t)zidx * gridDim.y + blockIdx.y) * ((int64_t)d.M * d.N);
     ld = d.N;
   } else {
     base = d.C + coff;
@@ -605,7 +606,8 @@ __device__ unsigned int g_trace_n;
 //   4: A(m = output pixel (clip, t, ho, wo), k = (kt*7 + kh)*7 + kw) = x[clip][t + kt - 2][2 ho - 3 + kh][2 wo - 3 + kw];
 //   5: the k-major B operand (weight gradient): B(k = pixel, n = tap), as 4 with the roles of rows and columns swapped.
 template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM, int KW = 1, int CONV = 0>
-__device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid, bool vec_epi) {
+__device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid, bool vec_epi,
+                                          int zidx) {
   constexpr int BK = 32, NG = BK / 8;
   static_assert(NG % KW == 0, "k-groups must divide over the wave sets");
   constexpr int NT = WM * WN * KW * 64;
@@ -651,7 +653,7 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
     bpre[j] = (d.bias && nsplit == 1 && n < d.N) ? d.bias[n] : 0.f;
   }
 
-  const int kbeg = blockIdx.z * kchunk;
+  const int kbeg = zidx * kchunk;
   const int kend = min(d.K, kbeg + kchunk);
   const int nk = CONV == 3 ? (kend - kbeg + BK - 1) / BK : (kend - kbeg) / BK;     // whole K-steps (host guarantees it); CONV 3: K tail
   const int64_t kstepA = AK ? (int64_t)BK * d.lda : BK;
@@ -931,15 +933,15 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
         for (int i = 0; i < TM; ++i) {
           const int m = m0 + wm * TM * 32 + i * 32 + lr;
           if (m < d.M) {
-            if (nsplit > 1) (d.ws + (int64_t)nsplit * gridDim.y * d.M * d.N)[(int64_t)blockIdx.z * d.M + m] = asum[i];
+            if (nsplit > 1) (d.ws + (int64_t)nsplit * gridDim.y * d.M * d.N)[(int64_t)zidx * d.M + m] = asum[i];
             else d.a_rowsum[m] = d.alpha * asum[i];
           }
         }
       }
     }
-    finish_tile_vec<BM, BN, NT, TM, TN>(d, nsplit, acc, smem, m0, n0, wm, wn, lr, lk, z1, z2, coff, tid);
+    finish_tile_vec<BM, BN, NT, TM, TN>(d, nsplit, acc, smem, m0, n0, wm, wn, lr, lk, z1, z2, coff, tid, zidx);
   } else {
-    finish_tile<TM, TN>(d, nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff, bpre);
+    finish_tile<TM, TN>(d, nsplit, acc, asum, want_rowsum, m0, n0, wm, wn, lr, lk, z1, z2, coff, zidx, bpre);
   }
 #ifdef TAVSR_GEMM_TRACE
   __builtin_amdgcn_s_waitcnt(0);
@@ -964,8 +966,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <int BM, int BN, int WM, int WN, int S, int MINW, bool AK, bool BKM, int KW = 1, int CONV = 0>
 __global__ __launch_bounds__(WM* WN * KW * 64, MINW)
 void gemm_glds_kernel(const GemmArgs args) {
-  glds_tile<BM, BN, WM, WN, S, AK, BKM, KW, CONV>(args.d, args.kchunk, args.nsplit, args.tiles_n,
-                                                  xcd_remap(blockIdx.x, gridDim.x), args.vec_epi != 0);
+  int bid = xcd_remap(blockIdx.x, gridDim.x), zidx = blockIdx.z;
+  if (args.zmap) {
+    // Workgroups go to the XCDs round-robin in launch order (x fastest, then z).  The tiles of one K slice of a convolution
+    // weight gradient read the same dY rows and overlapping image rows (one tile per tap / channel block): give ALL tiles
+    // of a slice to one XCD, back to back, so that the slice is fetched from HBM once and served from that XCD's L2 to the
+    // others.  Launch l = x + tiles * z runs on XCD l % 8 as that XCD's (l / 8)-th block: slice (l % 8) + 8 * ((l / 8) /
+    // tiles), tile (l / 8) % tiles - a bijection when the number of slices is a multiple of 8 (host).
+    const int tiles = gridDim.x, l = blockIdx.x + tiles * blockIdx.z, j = l >> 3;
+    zidx = (l & 7) + 8 * (j / tiles);
+    bid = j % tiles;
+  }
+  glds_tile<BM, BN, WM, WN, S, AK, BKM, KW, CONV>(args.d, args.kchunk, args.nsplit, args.tiles_n, bid, args.vec_epi != 0, zidx);
 }
 
 // Grouped launch: up to kMaxGroup independent problems of one layout share ONE grid (tile ranges by prefix sums).
@@ -988,7 +1000,7 @@ void gemm_glds_grouped_kernel(const GroupArgs g) {
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
     if (i < g.n && bid >= g.tile_start[i]) pi = i;
-  glds_tile<BM, BN, WM, WN, S, AK, BKM>(g.d[pi], g.d[pi].K, 1, g.tiles_n[pi], bid - g.tile_start[pi], g.vec_epi != 0);
+  glds_tile<BM, BN, WM, WN, S, AK, BKM>(g.d[pi], g.d[pi].K, 1, g.tiles_n[pi], bid - g.tile_start[pi], g.vec_epi != 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -1056,8 +1068,10 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
   // TAVSR_CONV_TILE=0 / TAVSR_CONV_DW_TILE=0 keep 64x64 everywhere (A/B switches).
   static const int wide = [] { const char* e = getenv("TAVSR_CONV_TILE"); return e ? atoi(e) : 1; }();
   static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
-  if (d.conv_mode == 4 || d.conv_mode == 5) {      // Conv3d stem: 4-byte gathers, three stages
-    GemmArgs a4{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve};
+  static const int zmap_on = [] { const char* e = getenv("TAVSR_CONV_ZMAP"); return e ? atoi(e) : 1; }();
+  const int zmap = zmap_on && (d.conv_mode == 2 || d.conv_mode == 5) && nsplit >= 8 && nsplit % 8 == 0;
+  if (d.conv_mode == 4 || d.conv_mode == 5) {      // Conv3d stem: 4-byte gathers
+    GemmArgs a4{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve, zmap};
     const dim3 grid4(a4.tiles_m * a4.tiles_n, 1, nsplit);
     if (d.conv_mode == 4)
       hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, false, false, 1, 4>), grid4, dim3(256), 0, s, a4);
@@ -1073,12 +1087,12 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
     return TAVSR_OK;
   }
   if (d.conv_mode == 2 && dw_wide && d.M % 128 == 0) {     // weight gradient: 128 output channels share one patch tile
-    GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 128), cdiv(d.N, 64), (int)vec_epi_ok(d)};
+    GemmArgs a2{d, kchunk, nsplit, cdiv(d.M, 128), cdiv(d.N, 64), (int)vec_epi_ok(d), zmap};
     hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, 3, true, true, 1, 2>), dim3(a2.tiles_m * a2.tiles_n, 1, nsplit), dim3(256), 0, s, a2);
     TAVSR_LAUNCH_CHECK();
     return launch_epilogue(a2, s);
   }
-  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve};
+  GemmArgs a{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve, zmap};
   dim3 grid(a.tiles_m * a.tiles_n, 1, nsplit);
   if (d.conv_mode == 1 && !d.b_kmajor)
     hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, false, false, 1, 1>), grid, dim3(256), 0, s, a);
@@ -1193,6 +1207,13 @@ static Plan plan_conv(const tavsr_gemm_desc& d, bool can_split) {
     if (want > pc.nsplit) {
       pc.kchunk = cdiv(cdiv(d.K, want), 32) * 32;
       pc.nsplit = cdiv(d.K, pc.kchunk);
+    }
+    if (pc.nsplit >= 16 && pc.nsplit % 8 != 0) {        // a multiple of 8 slices lets launch_conv keep each slice on one XCD
+      for (long w8 = pc.nsplit / 8 * 8; w8 >= 8; w8 -= 8) {
+        const int kc = cdiv(cdiv(d.K, w8), 32) * 32;
+        if (cdiv(d.K, kc) % 8 == 0) { pc.kchunk = kc; pc.nsplit = cdiv(d.K, kc); break; }
+        if (w8 < pc.nsplit / 2) break;
+      }
     }
   }
   return pc;
