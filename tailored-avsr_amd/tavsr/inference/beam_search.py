@@ -191,8 +191,9 @@ class BatchBeamSearch:
         if not (0.0 < ctc_weight < 1.0):
             raise NotImplementedError("ctc_weight in (0, 1): the shipped decode recipes (0.1); pure CTC / attention "
                                       "searches are not built")
-        if maxlenratio != 0.0 or minlenratio != 0.0:
-            raise NotImplementedError("maxlenratio = minlenratio = 0 (end detection), as the shipped decode recipes")
+        # espnet BeamSearch.forward: maxlenratio == 0 -> up to T tokens with end detection; > 0 -> max(1, int(ratio * T)) tokens,
+        # < 0 -> -int(ratio) tokens, both without end detection; minlenratio is accepted and (as in espnet 202402) only logged
+        self.maxlenratio, self.minlenratio = float(maxlenratio), float(minlenratio)
         self.model, self.lm = model, lm
         self.K = beam_size
         self.V = len(model.token_list)
@@ -214,8 +215,18 @@ class BatchBeamSearch:
         enc = enc.contiguous().float()
         enc_lens = enc_lens.to(dev).to(torch.int64)
         lens_h = [int(v) for v in enc_lens.cpu()]
-        maxlen = max(lens_h)
-        steps = maxlen                                             # maxlenratio == 0: at most T tokens per utterance
+        if self.maxlenratio == 0.0:                                # at most T tokens per utterance, end detection below
+            maxl_h = list(lens_h)
+        elif self.maxlenratio < 0:
+            maxl_h = [-1 * int(self.maxlenratio)] * U
+        else:
+            maxl_h = [max(1, int(self.maxlenratio * t)) for t in lens_h]
+        if any(m > t for m, t in zip(maxl_h, lens_h)):
+            # espnet's CTCPrefixScoreTH indexes its forward variables by output length: a hypothesis longer than the number
+            # of frames raises IndexError there; refused up front here
+            raise ValueError(f"maxlenratio {self.maxlenratio} asks for more tokens than encoder frames {lens_h}: "
+                             "the CTC prefix scorer cannot score a prefix longer than its input")
+        steps = max(maxl_h)
         ctc = self.model.ctc
         logp_ctc = ops.log_softmax_rows(ops.linear(enc.reshape(U * T, D), ctc.ctc_lo.weight, ctc.ctc_lo.bias)).view(U, T, V)
         self.dec_step.start(enc, enc_lens, N, K, steps)
@@ -234,7 +245,7 @@ class BatchBeamSearch:
         s_prev = torch.zeros(N, device=dev)
         utt_base = (torch.arange(U, device=dev) * K).view(U, 1)
         # host-side bookkeeping, vectorised over utterances ([U] / [N]-sized CPU tensors)
-        lens_c = torch.tensor(lens_h)
+        lens_c = torch.tensor(maxl_h)                               # per-utterance maxlen: the last iteration closes every hypothesis
         active = torch.ones(U, dtype=torch.bool)
         best = torch.full((U,), -float("inf"))                      # best ended score per utterance
         best_len = torch.full((U, steps + 4), -float("inf"))        # best ended score per (utterance, hypothesis length)
@@ -360,6 +371,8 @@ class BatchBeamSearch:
                 if i - m >= 0:
                     bl = best_len[:, i - m]
                     count += (torch.isfinite(bl) & (bl - best < D_end)).to(torch.int64)
+            if self.maxlenratio != 0.0:                            # end_detect runs only for maxlenratio == 0
+                count.zero_()
             stop = (count == 3) | (running == 0) | last.view(U)
             active = active & ~stop
             kill = (take | ~active.view(U, 1)).view(N)

@@ -99,6 +99,40 @@ def test_hip_beam_search_matches_oracle(beam, ctc_w, lm_w, pen):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ratio", [0.25, -9, 0.8])
+def test_hip_beam_search_length_ratio_matches_oracle(ratio):
+    """maxlenratio != 0 (espnet BeamSearch.forward: max(1, int(ratio * T)) tokens, or -ratio tokens, no end detection; the
+    last iteration closes every running hypothesis) - per utterance of the batch, against the oracle's one-by-one search."""
+    from tavsr.inference.beam_search import BatchBeamSearch
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.asr import ASRTask
+    m, lm = _oracle_models()
+    conf = asr_conf(num_blocks=2, dec_blocks=2)
+    conf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**conf)).eval()
+    fill_parameters_(pm, seed=5)
+    plm = TransformerLM(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(plm, seed=6)
+    pm, plm = pm.cuda(), plm.cuda()
+    x = synth((3, 100, 80), seed=17)
+    lens = torch.tensor([100, 72, 48])
+    with torch.no_grad():
+        enc, olens = m.encode(x, lens)
+        ref = [BS.build_beam_search(m, lm, 5, 0.3, 0.6, 0.5).forward(enc[u, : int(olens[u])], maxlenratio=ratio, minlenratio=0.1)
+               for u in range(3)]
+        hip = BatchBeamSearch(pm, plm, 5, 0.3, 0.6, 0.5, maxlenratio=ratio, minlenratio=0.1).decode(enc.cuda(), olens.cuda())
+    for u in range(3):
+        T = int(olens[u])
+        maxlen = -int(ratio) if ratio < 0 else max(1, int(ratio * T))
+        assert len(hip[u]) > 0 and len(ref[u]) > 0
+        assert max(len(h[0]) for h in hip[u]) <= maxlen + 2
+        assert hip[u][0][0] == ref[u][0].yseq.tolist(), (u, hip[u][0], ref[u][0].yseq.tolist())
+        assert abs(hip[u][0][1] - ref[u][0].score) < 2e-4 * abs(ref[u][0].score)
+    with pytest.raises(ValueError):            # more tokens than frames: espnet's CTC prefix scorer raises IndexError there
+        BatchBeamSearch(pm, plm, 5, 0.3, 0.6, 0.5, maxlenratio=1.5).decode(enc.cuda(), olens.cuda())
+
+
+@pytest.mark.gpu
 def test_graph_replayed_scorer_step_equals_eager_launches(monkeypatch):
     """The captured scorer step (device-side step counter, kv_append, in-place token / ancestor buffers) yields the
     same hypotheses, bit for bit in the scores, as the eager launches with host-side step arguments."""
