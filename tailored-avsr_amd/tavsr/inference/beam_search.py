@@ -188,9 +188,10 @@ class BatchBeamSearch:
                  penalty: float = 0.5, maxlenratio: float = 0.0, minlenratio: float = 0.0):
         if model.decoder is None or model.ctc is None:
             raise ValueError("the hybrid search needs both the attention decoder and the CTC head (0 < ctc_weight < 1)")
-        if not (0.0 < ctc_weight < 1.0):
-            raise NotImplementedError("ctc_weight in (0, 1): the shipped decode recipes (0.1); pure CTC / attention "
-                                      "searches are not built")
+        if not (0.0 <= ctc_weight <= 1.0):
+            raise ValueError(f"ctc_weight must lie in [0, 1]: {ctc_weight}")
+        # ctc_weight 0 / 1: espnet skips a scorer whose weight is 0; here its launches still run and enter the sums with
+        # weight 0 (finite log-probabilities), which selects the same hypotheses
         # espnet BeamSearch.forward: maxlenratio == 0 -> up to T tokens with end detection; > 0 -> max(1, int(ratio * T)) tokens,
         # < 0 -> -int(ratio) tokens, both without end detection; minlenratio is accepted and (as in espnet 202402) only logged
         self.maxlenratio, self.minlenratio = float(maxlenratio), float(minlenratio)
@@ -201,7 +202,8 @@ class BatchBeamSearch:
         self.w_dec, self.w_ctc = 1.0 - ctc_weight, ctc_weight
         self.w_lm = lm_weight if lm is not None else 0.0
         self.w_len = penalty
-        self.C = min(int(1.5 * beam_size), self.V)
+        # avsr_inference.py:298: pre_beam_score_key = None when ctc_weight == 1 -> the CTC prefix scorer sees every token
+        self.C = self.V if ctc_weight == 1.0 else min(int(1.5 * beam_size), self.V)
         self.dec_step = _DecoderStep(model.decoder)
         self.lm_step = _LMStep(lm) if (lm is not None and lm_weight != 0.0) else None
 

@@ -61,7 +61,8 @@ def test_oracle_beam_search_is_deterministic_and_sorted():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("beam,ctc_w,lm_w,pen", [(5, 0.3, 0.6, 0.5), (10, 0.1, 0.6, 0.5), (4, 0.5, 0.0, 0.0)])
+@pytest.mark.parametrize("beam,ctc_w,lm_w,pen", [(5, 0.3, 0.6, 0.5), (10, 0.1, 0.6, 0.5), (4, 0.5, 0.0, 0.0),
+                                                  (5, 0.0, 0.6, 0.5), (5, 1.0, 0.6, 0.5)])     # pure attention / pure CTC + LM
 def test_hip_beam_search_matches_oracle(beam, ctc_w, lm_w, pen):
     from tavsr.inference.beam_search import BatchBeamSearch
     from tavsr.lm.transformer_lm import TransformerLM
