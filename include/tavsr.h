@@ -476,7 +476,13 @@ int tavsr_beam_combine(const float* full, const int64_t* cand, const float* psi,
 int tavsr_beam_reorder(const int64_t* top_i, const float* top_s, const int64_t* cand, const float* r_new, const float* psi_abs,
                        const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out, int64_t* yseq_out, int32_t* anc_out,
                        int64_t* tok_out, float* score_out, int32_t N, int32_t K, int32_t V, int32_t C, int32_t T, int32_t ld_y,
-                       int32_t ld_a, const int32_t* step_dev, tavsr_stream_t stream);
+                       int32_t ld_a, const int32_t* step_dev, int32_t* hist, int32_t hist_steps, tavsr_stream_t stream);
+/* head of a captured search step: score[n] = -inf for the hypotheses that ended with the previous token (tok[n] == eos, or
+ * *step_dev >= maxlen[n / K]: the previous iteration was their utterance's last), anc[n][*step_dev] = n + *step_dev * N.
+ * tavsr_beam_reorder's hist (nullable) [hist_steps][3][N] int32 receives the token's record (token, extended slot, score
+ * bits) at row *step_dev: the host rebuilds ended hypotheses from these back-pointers without reading the state back. */
+int tavsr_beam_step_begin(float* score, const int64_t* tok, int32_t* anc, int32_t ld_a, const int32_t* maxlen, int32_t N, int32_t K,
+                          int32_t eos, const int32_t* step_dev, tavsr_stream_t stream);
 /* y = act(x) elementwise (the LM's Linear -> LayerNorm -> ReLU input layer); in place allowed */
 int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, tavsr_stream_t stream);
 

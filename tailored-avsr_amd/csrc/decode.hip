@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void beam_reorder_kernel(const int64_t* __rest
                                                            float* __restrict__ s_out, int64_t* __restrict__ yseq_out,
                                                            int32_t* __restrict__ anc_out, int64_t* __restrict__ tok_out,
                                                            float* __restrict__ score_out, int N, int K, int V, int C, int T,
-                                                           int ld_y, int ld_a, const int32_t* __restrict__ step_dev) {
+                                                           int ld_y, int ld_a, const int32_t* __restrict__ step_dev,
+                                                           int32_t* __restrict__ hist, int hist_steps) {
   const int n = blockIdx.x;
   const int u = n / K;
   const int64_t ti = top_i[n];
@@ -270,7 +271,26 @@ __global__ __launch_bounds__(256) void beam_reorder_kernel(const int64_t* __rest
     s_out[n] = psi_abs[(int64_t)prev * C + cidx];
     tok_out[n] = tk;
     score_out[n] = top_s[n];
+    if (hist && step < hist_steps) {          // back-pointer record of this token: (token, extended slot, score bits)
+      int32_t* h = hist + (int64_t)step * 3 * N;
+      h[n] = tk;
+      h[N + n] = prev;
+      h[2 * N + n] = __float_as_int(top_s[n]);
+    }
   }
+}
+
+// Head of a captured search step: the hypotheses that ended with the previous token - their last token is <eos>, or the
+// previous iteration was the last one of their utterance (step >= maxlen[u]) - leave the beam (score -inf), and column
+// `step` of every ancestor list names this step's own key / value row.  Replaces the host's per-token kill mask upload.
+__global__ __launch_bounds__(256) void beam_step_begin_kernel(float* __restrict__ score, const int64_t* __restrict__ tok,
+                                                              int32_t* __restrict__ anc, int ld_a, const int32_t* __restrict__ maxlen,
+                                                              int N, int K, int eos, const int32_t* __restrict__ step_dev) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int step = *step_dev;
+  if (step > 0 && ((int)tok[n] == eos || step >= maxlen[n / K])) score[n] = -INFINITY;
+  if (step < ld_a) anc[(int64_t)n * ld_a + step] = n + step * N;
 }
 
 // ---- one-token linear layers -----------------------------------------------------------------------------------------
@@ -522,14 +542,24 @@ extern "C" int tavsr_beam_reorder(const int64_t* top_i, const float* top_s, cons
                                   const float* psi_abs, const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out,
                                   int64_t* yseq_out, int32_t* anc_out, int64_t* tok_out, float* score_out, int32_t N, int32_t K,
                                   int32_t V, int32_t C, int32_t T, int32_t ld_y, int32_t ld_a, const int32_t* step_dev,
-                                  tavsr_stream_t stream) {
+                                  int32_t* hist, int32_t hist_steps, tavsr_stream_t stream) {
   TAVSR_REQUIRE(top_i && top_s && cand && r_new && psi_abs && yseq && anc && r_out && s_out && yseq_out && anc_out && tok_out &&
                     score_out && step_dev, TAVSR_EINVAL, "beam_reorder: null pointer");
   TAVSR_REQUIRE(r_out != r_new && (const int64_t*)yseq_out != yseq && (const int32_t*)anc_out != anc, TAVSR_EINVAL,
                 "beam_reorder: the state is re-ordered, outputs must not alias the inputs");
   TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0, TAVSR_EINVAL, "beam_reorder: bad sizes");
   hipLaunchKernelGGL(beam_reorder_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, top_i, top_s, cand, r_new, psi_abs, yseq,
-                     anc, r_out, s_out, yseq_out, anc_out, tok_out, score_out, N, K, V, C, T, ld_y, ld_a, step_dev);
+                     anc, r_out, s_out, yseq_out, anc_out, tok_out, score_out, N, K, V, C, T, ld_y, ld_a, step_dev, hist, hist_steps);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_beam_step_begin(float* score, const int64_t* tok, int32_t* anc, int32_t ld_a, const int32_t* maxlen, int32_t N,
+                                     int32_t K, int32_t eos, const int32_t* step_dev, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(score && tok && anc && maxlen && step_dev, TAVSR_EINVAL, "beam_step_begin: null pointer");
+  TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0, TAVSR_EINVAL, "beam_step_begin: bad sizes");
+  hipLaunchKernelGGL(beam_step_begin_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, score, tok, anc, ld_a,
+                     maxlen, N, K, eos, step_dev);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -204,6 +204,7 @@ class BatchBeamSearch:
         self.w_len = penalty
         # avsr_inference.py:298: pre_beam_score_key = None when ctc_weight == 1 -> the CTC prefix scorer sees every token
         self.C = self.V if ctc_weight == 1.0 else min(int(1.5 * beam_size), self.V)
+        self._pinned = {}
         self.dec_step = _DecoderStep(model.decoder)
         self.lm_step = _LMStep(lm) if (lm is not None and lm_weight != 0.0) else None
 
@@ -252,7 +253,6 @@ class BatchBeamSearch:
         best = torch.full((U,), -float("inf"))                      # best ended score per utterance
         best_len = torch.full((U, steps + 4), -float("inf"))        # best ended score per (utterance, hypothesis length)
         D_end = math.log(1 * math.exp(-10))
-        ended_rows, ended_meta = [], []                             # yseq rows (CPU) and (utterance, length, score)
         NEG_INF = -float("inf")
         state = dict(r_prev=r_prev, s_prev=s_prev, yseq=yseq, score=score)
 
@@ -266,8 +266,9 @@ class BatchBeamSearch:
                 anc[:, i] = slot_ids + i * N
                 sdyn = None
             else:
-                score.masked_fill_(dyn["kill"], NEG_INF)            # hypotheses the host ended after the previous token
-                anc.index_copy_(1, dyn["step64"], (slot_ids + dyn["step"] * N).view(N, 1))
+                # hypotheses that ended with the previous token (<eos>, or their utterance's last iteration) leave the beam
+                # and column `step` of the ancestor lists is filled: one launch, no host input
+                ops.beam_step_begin(score, tok, anc, dyn["maxl"], K, self.eos, dyn["step"])
                 sdyn = (dyn["step"], self.dec_step.pe.index_select(0, dyn["step64"]))
             # full = w_dec * decoder + w_lm * lm + w_len (LengthBonus: 1 per token), summed by the scorers' last launches
             # the two scorers are independent chains of small launches: the LM runs on the side stream next to the decoder
@@ -287,7 +288,7 @@ class BatchBeamSearch:
                 # shadow buffers + one multi-buffer commit (+ the counters); same arithmetic as the torch ops below
                 weighted = ops.beam_combine(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, self.eos, self.w_ctc)
                 top_s, top_i = torch.topk(weighted.view(U, K * V), K, dim=-1)
-                ops.beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, dyn["shadow"], K, V, dyn["step"])
+                ops.beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, dyn["shadow"], K, V, dyn["step"], hist=dyn["hist"])
                 ops.multi_copy_([r_prev, s_prev, yseq, anc, tok, score], list(dyn["shadow"]))
                 dyn["ctr"].add_(1)                                  # step, step64, stepp1 are views of this one tensor
                 return anc, tok
@@ -324,13 +325,16 @@ class BatchBeamSearch:
             # One token costs ~300 scorer launches plus ~90 small ones for the beam update, all on [N, d]-sized operands.
             # The whole device side of a step is captured once per decode() - the step index, the positional row, tokens,
             # ancestor lists, CTC state and scores live in fixed device buffers updated in place - and replayed per token;
-            # the host then only reads the new tokens / scores back (end detection) and uploads the kill mask.
+            # the device also retires ended hypotheses itself and records (token, back-pointer, score) per slot and token, so
+            # the host neither uploads anything nor sits on the critical path: it reads the records one token behind the
+            # device (end detection, collecting ended hypotheses by back-tracking) while the next step already runs.
             # The step is bound by its chain of dependent small kernels (5-6 us each), not by the host: what shortens it is
             # fewer launches - the K/V append rides in the attention launch, the scorer weights in the log-softmax
             # launches, the beam update is three launches (beam_combine, top-k, beam_reorder) plus one commit.
             ctr = torch.tensor([0, 1], dtype=torch.int64, device=dev)          # (i, i + 1); the kernels read i as int32
             dyn = dict(ctr=ctr, step64=ctr[0:1], stepp1=ctr[1:2], step=ctr.view(torch.int32)[0:1],     # (low word: little endian)
-                       kill=torch.zeros(N, dtype=torch.bool, device=dev),
+                       maxl=torch.tensor(maxl_h, dtype=torch.int32, device=dev),
+                       hist=torch.zeros(steps, 3, N, dtype=torch.int32, device=dev),
                        shadow=(torch.empty_like(r_prev), torch.empty_like(s_prev), torch.empty_like(yseq), torch.empty_like(anc),
                                torch.empty_like(tok), torch.empty_like(score)))
             side = torch.cuda.Stream()
@@ -343,27 +347,25 @@ class BatchBeamSearch:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 device_step(steps, dyn)
-        for i in range(steps):
-            if graph is not None:
-                graph.replay()
-            else:
-                anc, tok = device_step(i, None)
-            yseq, score = state["yseq"], state["score"]
-            # ended hypotheses, last iteration, end detection (espnet post_process / end_detect per utterance)
-            tok_h, score_h = tok.cpu(), score.cpu()
+        ended = [[] for _ in range(U)]
+
+        def host_step(i, tok_h, score_h, rows_of):
+            """espnet post_process / end_detect for token i of every utterance: collects the hypotheses that end here
+            (``rows_of(slot indices)`` -> their token lists incl. <sos>), returns the slots to retire."""
+            nonlocal active
             valid = torch.isfinite(score_h).view(U, K) & active.view(U, 1)
             last = (lens_c - 1 == i).view(U, 1)
             # espnet appends <eos> to EVERY hypothesis of the last iteration (also to the ones that just ended)
             take = valid & ((tok_h.view(U, K) == self.eos) | last)
             if bool(take.any()):
                 idx = take.view(N).nonzero().view(-1)
-                rows = yseq[idx.to(dev)].cpu()
                 us = idx // K
                 lns = torch.where(last.view(U)[us], torch.full_like(us, i + 3), torch.full_like(us, i + 2))
                 scs = score_h[idx]
-                for r, u_, ln, sc in zip(rows, us.tolist(), lns.tolist(), scs.tolist()):
-                    ended_rows.append(r)
-                    ended_meta.append((u_, ln, sc))
+                for ys, u_, ln, sc in zip(rows_of(idx), us.tolist(), lns.tolist(), scs.tolist()):
+                    ys = (ys + [self.eos] * 2)[:ln]
+                    ys[ln - 1] = self.eos
+                    ended[u_].append((ys, sc))
                 best.index_reduce_(0, us, scs, "amax")
                 flat = us * best_len.shape[1] + lns
                 best_len.view(-1).index_reduce_(0, flat, scs, "amax")
@@ -377,18 +379,54 @@ class BatchBeamSearch:
                 count.zero_()
             stop = (count == 3) | (running == 0) | last.view(U)
             active = active & ~stop
-            kill = (take | ~active.view(U, 1)).view(N)
-            if graph is not None:
-                dyn["kill"].copy_(kill)                             # applied at the head of the next replay
-            elif bool(kill.any()):
-                state["score"] = torch.where(kill.to(dev), torch.full_like(score, NEG_INF), score)
-            if not bool(active.any()):
-                break
-        ended = [[] for _ in range(U)]
-        for r, (u_, ln, sc) in zip(ended_rows, ended_meta):
-            ys = r[:ln].tolist()
-            ys[ln - 1] = self.eos
-            ended[u_].append((ys, sc))
+            return (take | ~active.view(U, 1)).view(N)
+
+        if graph is not None:
+            hist = dyn["hist"]
+            pin = self._pinned.get((steps, N))                      # page-locked landing zone of the records, kept per shape
+            if pin is None:
+                pin = self._pinned[(steps, N)] = torch.empty((steps, 3, N), dtype=torch.int32, pin_memory=True)
+            rec = pin.numpy()                                       # same memory: rec[token][0 / 1 / 2][slot]
+
+            def rows_from_records(i):
+                def rows_of(idx):
+                    out_rows = []
+                    for n in idx.tolist():
+                        toks, cur = [], n
+                        for t in range(i, -1, -1):                  # back-track: token of slot `cur`, then the slot it extended
+                            toks.append(int(rec[t, 0, cur]))
+                            cur = int(rec[t, 1, cur])
+                        out_rows.append([self.sos] + toks[::-1])
+                    return out_rows
+                return rows_of
+
+            events, done = [], 0
+            for i in range(steps):
+                graph.replay()
+                pin[i].copy_(hist[i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                events.append(ev)
+                while done < i and bool(active.any()):              # the host works one token behind the device
+                    events[done].synchronize()
+                    host_step(done, pin[done, 0].to(torch.int64), pin[done, 2].view(torch.float32), rows_from_records(done))
+                    done += 1
+                if not bool(active.any()):
+                    break
+            while done < len(events) and bool(active.any()):
+                events[done].synchronize()
+                host_step(done, pin[done, 0].to(torch.int64), pin[done, 2].view(torch.float32), rows_from_records(done))
+                done += 1
+            torch.cuda.current_stream().synchronize()               # a step the device ran ahead may still be in flight
+        else:
+            for i in range(steps):
+                anc, tok = device_step(i, None)
+                yseq, score = state["yseq"], state["score"]
+                kill = host_step(i, tok.cpu(), score.cpu(), lambda idx: yseq[idx.to(dev)].cpu().tolist())
+                if bool(kill.any()):
+                    state["score"] = torch.where(kill.to(dev), torch.full_like(score, NEG_INF), score)
+                if not bool(active.any()):
+                    break
         out = []
         for u in range(U):
             hyps = sorted(ended[u], key=lambda h: h[1], reverse=True)

@@ -1345,17 +1345,28 @@ def beam_combine(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, eos, w
     return weighted
 
 
-def beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, outs, K, V, step_dev):
+def beam_step_begin(score, tok, anc, maxlen, K, eos, step_dev):
+    """head of a captured search step (tavsr.h): ended hypotheses leave the beam, anc[:, step] names this step's rows."""
+    N = score.numel()
+    require_cuda(score, tok, anc, maxlen, step_dev)
+    assert anc.dtype == torch.int32 and maxlen.dtype == torch.int32 and tok.dtype == torch.int64 and step_dev.dtype == torch.int32
+    check(lib().tavsr_beam_step_begin(ptr(score), ptr(tok), ptr(anc), anc.stride(0), ptr(maxlen), N, K, int(eos), ptr(step_dev),
+                                      stream()), "tavsr_beam_step_begin")
+
+
+def beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, outs, K, V, step_dev, hist=None):
     """gathers the state of the extended slots into ``outs`` = (r, s, yseq, anc, tok, score) buffers (tavsr.h)."""
     N, Cn = cand.shape
     T = r_new.shape[1]
     r_out, s_out, y_out, a_out, t_out, sc_out = outs
-    require_cuda(top_i, top_s, cand, r_new, psi_abs, yseq, anc, *outs, step_dev)
+    require_cuda(top_i, top_s, cand, r_new, psi_abs, yseq, anc, *outs, step_dev, hist)
+    assert hist is None or (hist.dtype == torch.int32 and hist.is_contiguous() and hist.shape[1:] == (3, N))
     assert top_i.is_contiguous() and top_s.is_contiguous() and top_i.numel() == N and yseq.dtype == torch.int64
     assert anc.dtype == torch.int32 and y_out.shape == yseq.shape and a_out.shape == anc.shape and r_out.shape == (N, T, 2)
     check(lib().tavsr_beam_reorder(ptr(top_i), ptr(top_s), ptr(cand), ptr(r_new), ptr(psi_abs), ptr(yseq), ptr(anc), ptr(r_out),
                                    ptr(s_out), ptr(y_out), ptr(a_out), ptr(t_out), ptr(sc_out), N, K, V, Cn, T, yseq.stride(0),
-                                   anc.stride(0), ptr(step_dev), stream()), "tavsr_beam_reorder")
+                                   anc.stride(0), ptr(step_dev), ptr(hist), 0 if hist is None else hist.shape[0], stream()),
+          "tavsr_beam_reorder")
 
 
 # ---------------------------------------------------------------------------------------------- dropout
