@@ -10,8 +10,13 @@ timeout 600 python profiles/gemm_shapes.py --workload asr > gpurun_out/gemm_shap
 bash scripts/gpu_prof.sh | tail -3; cp gpurun_out/prof_stats.txt gpurun_out/kernel_stats_av.txt
 bash scripts/gpu_prof.sh --workload asr | tail -3; cp gpurun_out/prof_stats.txt gpurun_out/kernel_stats_asr.txt
 OUT=pmc_hbm_av bash scripts/gpu_pmc_hbm.sh | tail -4
+OUT=pmc_hbm_asr bash scripts/gpu_pmc_hbm.sh --workload asr | tail -4
 OUT=pmc_mfma_av bash scripts/gpu_pmc_mfma.sh | tail -4
 OUT=pmc_mfma_asr bash scripts/gpu_pmc_mfma.sh --workload asr | tail -4
 OUT=pmc_mfma_fwd_encoder bash scripts/gpu_pmc_mfma.sh --mode fwd-encoder | tail -4
 timeout 900 python bench_decode.py --utterances 256 --batch 64 > gpurun_out/decode_b64.json 2> gpurun_out/decode_b64.err; echo "decode rc=$?"; cut -c1-300 gpurun_out/decode_b64.json
 timeout 900 python bench_decode.py --utterances 16 --batch 1 --no-cpu-baseline > gpurun_out/decode_b1.json 2> gpurun_out/decode_b1.err; echo "decode1 rc=$?"; cut -c1-300 gpurun_out/decode_b1.json
+timeout 900 python bench_decode.py --utterances 512 --batch 256 --no-cpu-baseline > gpurun_out/decode_b256.json 2> gpurun_out/decode_b256.err; echo "decode256 rc=$?"; cut -c1-300 gpurun_out/decode_b256.json
+bash scripts/gpu_decode_prof.sh 1 | head -12
+bash scripts/gpu_decode_prof.sh 64 | head -12
+timeout 600 python scripts/fwd_breakdown.py > gpurun_out/fwd_breakdown.txt 2>&1; head -14 gpurun_out/fwd_breakdown.txt | cut -c1-150

@@ -446,6 +446,11 @@ class TailoredLayerFn(torch.autograd.Function):
         br = ops.BranchScope(dya.is_cuda)
         dyv = dyv.contiguous()
         br.keep(dyv)
+        # The video stream's saved state holds tensors of the MAIN stream's allocator pool (layer 0: the stream's input from
+        # the embedding).  Its backward drops that state while its launches are still queued on the forked stream; the block
+        # would return to the main pool and the audio stream's backward - issued next, on the main stream - could be handed
+        # it and overwrite it under the video stream's last readers (the macaron LayerNorm backward).  Hold until the join.
+        br.keep(dict(vars(ctx.cv)))
         with br:
             gv = TailoredStreamFn.backward(ctx.cv, dyv)
         ga = TailoredStreamFn.backward(ctx.ca, dya)
@@ -496,6 +501,7 @@ class FrontendPairFn(torch.autograd.Function):
         br = ops.BranchScope(dyv.is_cuda)
         dya = dya.contiguous()
         br.keep(dya)
+        br.keep(dict(vars(ctx.ca)))          # as in TailoredLayerFn.backward: saved main-pool tensors outlive the forked launches
         with br:
             ga = Conv2dSubsamplingFn.backward(ctx.ca, dya)
         gv = VisualFrontendFn.backward(ctx.cv, dyv)

@@ -287,10 +287,10 @@ class BranchScope:
         self.enabled = enabled and BRANCH_SIDE_STREAM
         self._keep = []
 
-    def keep(self, *tensors):
-        """Main-stream tensors whose last reader is in the body must stay allocated until the join (the main
-        stream's allocator would otherwise hand their memory out while the side stream still reads it)."""
-        self._keep.extend(tensors)
+    def keep(self, *objs):
+        """Main-stream tensors (or containers of them) whose last reader is in the body must stay allocated until the join
+        (the main stream's allocator would otherwise hand their memory out while the side stream still reads it)."""
+        self._keep.extend(objs)
 
     def __enter__(self):
         self.main = torch.cuda.current_stream()

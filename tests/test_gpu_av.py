@@ -532,3 +532,27 @@ def test_acoustic_branch_drop_matches_the_oracle():
             assert p.grad is None, n
         else:
             assert grad_ok(p.grad.cpu(), po[n].grad, GRAD_TOL), n
+
+
+def test_av_training_step_is_reproducible_across_fresh_models():
+    """Six freshly built AV models (same seed, allocator cache emptied in between) run one training step each on the
+    benchmark batch: every parameter gradient must equal the first model's bit for bit.  The two modality streams of a
+    tailored layer run on two HIP streams; a saved tensor of the main stream's pool that is dropped while the forked
+    stream's launches are still queued can be handed out again and overwritten under its readers (layer 0's macaron
+    LayerNorm backward read such a block: wrong dgamma in ~1 of 3 cold steps before the state was held until the join)."""
+    from tavsr.tasks.avsr import AVSRTask
+    batch = [t.cuda() for t in _bench_batch(32)]
+    ref = None
+    for it in range(6):
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6))).cuda().train()
+        loss = model(*batch)[0]
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        if ref is None:
+            ref = grads
+        else:
+            bad = [n for n, g in grads.items() if not torch.equal(g, ref[n])]
+            assert not bad, (it, bad[:8])
+        del model
