@@ -77,7 +77,15 @@ typedef struct tavsr_gemm_desc {
      conv_stride s (0 = 1) and conv_taps (0 = 9, or 1): the strided 3x3 / pad 1 and 1x1 / pad 0 convolutions of the blocks
      that halve the maps (resnet.py:68-87 downsample, :95-97 conv1).  conv_H x conv_W is always the INPUT image; the rows
      of the patch operand are the OUTPUT pixels (n, ho, wo), Ho = (H-1)/s + 1, centred on input pixel (s*ho, s*wo);
-     K (mode 1) / N (mode 2) = taps * C. */
+     K (mode 1) / N (mode 2) = taps * C.
+     Conv3d stem of the lip front-end (src/frontend/conv3d_resnet18/conv3d_resnet18.py:48-57: 1 -> Cout channels, kernel
+     (5,7,7), stride (1,2,2), padding (2,3,3), no bias) over clips X [clips][conv_C frames][conv_H][conv_W] (even H, W), the
+     245 taps padded to 256, every element gathered by the loader - no patch matrix:
+       conv_mode 4: A is X, M = output pixels (clip, t, ho, wo), K = 256: A(m, (kt*7 + kh)*7 + kw) = X[clip][t + kt - 2]
+                    [2 ho - 3 + kh][2 wo - 3 + kw] (0 outside the clip / frame, 0 for k >= 245); B = weights [Cout][256];
+       conv_mode 5: B is X (TN layout, a_kmajor and b_kmajor), N = 256, K = output pixels (a multiple of 32): weight gradient
+                    dW[co][tap] = sum_m dY[m][co] * patch(m, tap); columns >= 245 come out 0.
+     lda (mode 4) / ldb (mode 5) are ignored (pass a multiple of 4). */
   int32_t conv_mode, conv_H, conv_W, conv_C;
   const float* conv_zero;
   int32_t conv_stride, conv_taps;
