@@ -16,7 +16,14 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     from tavsr.tasks.avsr import AVSRTask
-    conf = avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)
+    kind = os.environ.get("REPRO_MODEL", "tailored")         # tailored | conventional | asr
+    if kind == "asr":
+        from helpers import asr_conf
+        from tavsr.tasks.asr import ASRTask as AVSRTask      # noqa: F811  (same build_model interface)
+        conf = asr_conf(num_blocks=12, dec_blocks=6)
+    else:
+        from helpers import AVSR_CONV_YAML
+        conf = avsr_conf(AVSR_YAML if kind == "tailored" else AVSR_CONV_YAML, num_blocks=12, dec_blocks=6)
     conf["token_list"] = list(TOKENS_EN)
     torch.manual_seed(0)
     model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf))).cuda().train()
@@ -39,7 +46,7 @@ def main():
             model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf))).cuda().train()
         for p in model.parameters():
             p.grad = None
-        loss = model(audio, alens, video, vlens, text, tlens)[0]
+        loss = model(audio, alens, text, tlens)[0] if kind == "asr" else model(audio, alens, video, vlens, text, tlens)[0]
         loss.backward()
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
         if ref is None:

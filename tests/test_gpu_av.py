@@ -556,3 +556,52 @@ def test_av_training_step_is_reproducible_across_fresh_models():
             bad = [n for n, g in grads.items() if not torch.equal(g, ref[n])]
             assert not bad, (it, bad[:8])
         del model
+
+
+@pytest.mark.parametrize("workload", ["avsr", "asr"])
+def test_graph_replayed_training_step_equals_eager_launches(workload):
+    """The whole fwd+bwd captured into one hipGraph (what bench.py times) gives, at every replay, the loss and gradients of
+    the eager launches bit for bit - a capture fixes the allocator's block assignment and the cross-stream edges once, so a
+    buffer shared by two branches without an edge between them would show here (dropout 0: same arithmetic both ways)."""
+    if workload == "avsr":
+        from tavsr.tasks.avsr import AVSRTask
+        model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(AVSR_YAML, num_blocks=3, dec_blocks=2)))
+        batch = [t.cuda() for t in _bench_batch(8)]
+    else:
+        from helpers import asr_conf
+        from oracle.model import synth
+        from tavsr.tasks.asr import ASRTask
+        model = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=3, dec_blocks=2)))
+        text = synth((8, 30), seed=2, kind="int", lo=1, hi=40)
+        batch = [synth((8, 400, 80), seed=1).cuda(), torch.full((8,), 400).cuda(), text.cuda(), torch.full((8,), 30).cuda()]
+    torch.manual_seed(0)
+    model = model.cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = model(*batch)[0]
+        loss.backward()
+        return loss
+
+    eager_loss = step().detach().clone()
+    eager = [p.grad.detach().clone() for p in params]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = model(*batch)[0]
+        static_loss.backward()
+    for replay in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_loss.detach(), eager_loss), replay
+        bad = [n for (n, p), g in zip(model.named_parameters(), eager) if not torch.equal(p.grad, g)]
+        assert not bad, (replay, bad[:8])
