@@ -467,6 +467,12 @@ int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, const float* r
                           const int64_t* last_tok, const int64_t* cand, float* r_new, float* psi, float* psi_abs, float* eos,
                           float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V, int32_t C, int32_t out_len,
                           int32_t blank, const int32_t* step_dev, tavsr_stream_t stream);
+/* as tavsr_ctc_prefix_step with the pre-beam in front: cand [N][C] is an OUTPUT - the C <= 64 best tokens of full[n][0..V)
+ * (descending, lower index first among equal scores; espnet's pre_beam on the weighted full scores), V <= 4096. */
+int tavsr_ctc_prefix_step_topk(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,
+                               const int64_t* last_tok, const float* full, int64_t* cand, float* r_new, float* psi, float* psi_abs,
+                               float* eos, float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V, int32_t C, int32_t out_len,
+                               int32_t blank, const int32_t* step_dev, tavsr_stream_t stream);
 int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t V, float alpha, float add,
                            int32_t accumulate, tavsr_stream_t stream);
 /* Beam update around the top-k (espnet BatchBeamSearch.search / batch_beam, avsr_inference.py:449-518):

@@ -122,26 +122,19 @@ __device__ __forceinline__ float logaddexp2(float a, float b) {
   return m + logf(expf(a - m) + expf(b - m));
 }
 
-// thread = (hypothesis n, candidate c).  logp [U][T][V] (log-softmax of the CTC head), lens [U].
-// r_prev [N][T][2] (nb, b) and s_prev [N] of the hypothesis (first == 1: the <sos> state is built here instead).
+// One (hypothesis n, candidate column c) of CTCPrefixScoreTH.__call__.  logp [U][T][V] (log-softmax of the CTC head),
+// lens [U].  r_prev [N][T][2] (nb, b) and s_prev [N] of the hypothesis (first == 1: the <sos> state is built here instead).
 // Writes r_new [N][T][2][C], psi [N][C] = log_psi(candidate) - s_prev  and  psi_abs [N][C] = log_psi(candidate);
-// thread c == 0 also writes eos [N] = r_sum[len-1] - s_prev and eos_abs.
-__global__ __launch_bounds__(256) void ctc_prefix_step_kernel(const float* __restrict__ logp, const int64_t* __restrict__ lens,
-                                                              const float* __restrict__ r_prev, const float* __restrict__ s_prev,
-                                                              const int64_t* __restrict__ last_tok,
-                                                              const int64_t* __restrict__ cand, float* __restrict__ r_new,
-                                                              float* __restrict__ psi, float* __restrict__ psi_abs,
-                                                              float* __restrict__ eos, float* __restrict__ eos_abs, int N,
-                                                              int K, int T, int V, int C, int out_len, int blank, int first,
-                                                              const int32_t* __restrict__ step_dev) {
+// column c == 0 also writes eos [N] = r_sum[len-1] - s_prev and eos_abs.
+__device__ __forceinline__ void ctc_prefix_one(const float* __restrict__ logp, const int64_t* __restrict__ lens,
+                                               const float* __restrict__ r_prev, const float* __restrict__ s_prev,
+                                               const int64_t* __restrict__ last_tok, int tok, float* __restrict__ r_new,
+                                               float* __restrict__ psi, float* __restrict__ psi_abs, float* __restrict__ eos,
+                                               float* __restrict__ eos_abs, int n, int c, int K, int T, int V, int C, int out_len,
+                                               int blank, int first) {
   const float logzero = -10000000000.0f;
-  if (step_dev) { out_len = *step_dev; first = out_len == 0; }     // replayed graphs: the step counter lives in device memory
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * C) return;
-  const int n = i / C, c = i % C;
   const int u = n / K;
   const int L = (int)lens[u];
-  const int tok = (int)cand[(int64_t)n * C + c];
   const float* lp = logp + (int64_t)u * T * V;
   const float* rp = r_prev + (int64_t)n * T * 2;
   const float sp = first ? 0.f : s_prev[n];
@@ -187,6 +180,78 @@ __global__ __launch_bounds__(256) void ctc_prefix_step_kernel(const float* __res
     const float e = logaddexp2(pn, pb);
     eos_abs[n] = e;
     eos[n] = e - sp;
+  }
+}
+
+// thread = (hypothesis n, candidate c), candidates given
+__global__ __launch_bounds__(256) void ctc_prefix_step_kernel(const float* __restrict__ logp, const int64_t* __restrict__ lens,
+                                                              const float* __restrict__ r_prev, const float* __restrict__ s_prev,
+                                                              const int64_t* __restrict__ last_tok,
+                                                              const int64_t* __restrict__ cand, float* __restrict__ r_new,
+                                                              float* __restrict__ psi, float* __restrict__ psi_abs,
+                                                              float* __restrict__ eos, float* __restrict__ eos_abs, int N,
+                                                              int K, int T, int V, int C, int out_len, int blank, int first,
+                                                              const int32_t* __restrict__ step_dev) {
+  if (step_dev) { out_len = *step_dev; first = out_len == 0; }     // replayed graphs: the step counter lives in device memory
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  ctc_prefix_one(logp, lens, r_prev, s_prev, last_tok, (int)cand[(int64_t)n * C + c], r_new, psi, psi_abs, eos, eos_abs, n, c, K, T, V,
+                 C, out_len, blank, first);
+}
+
+// wave = hypothesis n.  The pre-beam rides in front of the scorer: the C <= 64 best tokens of full[n][0..V) (espnet's
+// pre_beam on the weighted full scores; descending, the lower index first among equal scores, V <= 4096) are selected by the
+// wave, written to cand [N][C], and lane c runs the prefix recursion of candidate c - two torch.topk launches less per token.
+__global__ __launch_bounds__(256) void ctc_prefix_topk_kernel(const float* __restrict__ logp, const int64_t* __restrict__ lens,
+                                                              const float* __restrict__ r_prev, const float* __restrict__ s_prev,
+                                                              const int64_t* __restrict__ last_tok, const float* __restrict__ full,
+                                                              int64_t* __restrict__ cand, float* __restrict__ r_new,
+                                                              float* __restrict__ psi, float* __restrict__ psi_abs,
+                                                              float* __restrict__ eos, float* __restrict__ eos_abs, int N,
+                                                              int K, int T, int V, int C, int out_len, int blank, int first,
+                                                              const int32_t* __restrict__ step_dev) {
+  if (step_dev) { out_len = *step_dev; first = out_len == 0; }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  const float* f = full + (int64_t)n * V;
+  uint64_t taken = 0;                 // bit j: element lane + 64 j of this row is already a candidate
+  int mytok = 0;
+  constexpr int VR = 8;               // rows of up to 512 tokens live in registers: a selection round is shuffles only
+  float xv[VR];
+  const bool inreg = V <= 64 * VR;
+#pragma unroll
+  for (int j = 0; j < VR; ++j) xv[j] = (inreg && lane + 64 * j < V) ? f[lane + 64 * j] : -INFINITY;
+  for (int c = 0; c < C; ++c) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (inreg) {
+#pragma unroll
+      for (int j = 0; j < VR; ++j) {
+        const int v = lane + 64 * j;
+        if (v < V && !((taken >> j) & 1) && (xv[j] > best || (xv[j] == best && v < bi))) { best = xv[j]; bi = v; }
+      }
+    } else {
+      for (int j = 0, v = lane; v < V; ++j, v += 64) {
+        const float x = f[v];
+        if (!((taken >> j) & 1) && (x > best || (x == best && v < bi))) { best = x; bi = v; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (bi == 0x7fffffff) bi = 0;     // fewer than C finite-or-not elements cannot happen for C <= V; keeps indices valid
+    if ((bi & 63) == lane) taken |= 1ull << (bi >> 6);
+    if (lane == c) mytok = bi;
+  }
+  if (lane < C) {
+    cand[(int64_t)n * C + lane] = mytok;
+    ctc_prefix_one(logp, lens, r_prev, s_prev, last_tok, mytok, r_new, psi, psi_abs, eos, eos_abs, n, lane, K, T, V, C, out_len, blank,
+                   first);
   }
 }
 
@@ -511,6 +576,26 @@ extern "C" int tavsr_ctc_prefix_step(const float* logp, const int64_t* lens, con
   TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0 && C > 0, TAVSR_EINVAL, "ctc_prefix_step: bad sizes");
   hipLaunchKernelGGL(ctc_prefix_step_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logp,
                      lens, r_prev, s_prev, last_tok, cand, r_new, psi, psi_abs, eos, eos_abs, N, K, T, V, C, out_len, blank,
+                     out_len == 0 ? 1 : 0, step_dev);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_ctc_prefix_step_topk(const float* logp, const int64_t* lens, const float* r_prev, const float* s_prev,
+                                          const int64_t* last_tok, const float* full, int64_t* cand, float* r_new, float* psi,
+                                          float* psi_abs, float* eos, float* eos_abs, int32_t N, int32_t K, int32_t T, int32_t V,
+                                          int32_t C, int32_t out_len, int32_t blank, const int32_t* step_dev,
+                                          tavsr_stream_t stream) {
+  TAVSR_REQUIRE(logp && lens && full && cand && r_new && psi && psi_abs && eos && eos_abs, TAVSR_EINVAL,
+                "ctc_prefix_step_topk: null pointer");
+  TAVSR_REQUIRE((out_len == 0 && !step_dev) || (r_prev && s_prev && last_tok), TAVSR_EINVAL,
+                "ctc_prefix_step_topk: state needed after <sos>");
+  TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0 && C > 0, TAVSR_EINVAL, "ctc_prefix_step_topk: bad sizes");
+  TAVSR_REQUIRE(C <= 64 && C <= V && V <= 4096, TAVSR_EUNSUPPORTED,
+                "ctc_prefix_step_topk: up to 64 candidates of up to 4096 tokens (got C = %d, V = %d): select them first and call "
+                "tavsr_ctc_prefix_step", C, V);
+  hipLaunchKernelGGL(ctc_prefix_topk_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logp, lens, r_prev,
+                     s_prev, last_tok, full, cand, r_new, psi, psi_abs, eos, eos_abs, N, K, T, V, C, out_len, blank,
                      out_len == 0 ? 1 : 0, step_dev);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;

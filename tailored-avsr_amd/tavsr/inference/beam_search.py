@@ -41,6 +41,7 @@ def _cat(ws):
 FUSED_STEP = os.environ.get("TAVSR_DECODE_FUSED", "1") == "1"
 SCORERS_PARALLEL = os.environ.get("TAVSR_DECODE_PARALLEL", "1") == "1"   # decoder || LM on two streams
 TREE_GROUP = int(os.environ.get("TAVSR_DECODE_TREE_GROUP", "1"))     # beams of an utterance side by side in the tree attention
+PREBEAM_FUSED = os.environ.get("TAVSR_DECODE_PREBEAM", "1") == "1"   # pre-beam top-k inside the CTC prefix launch
 FUSED_FFN = os.environ.get("TAVSR_DECODE_FUSED_FFN", "0") == "1"      # measured: 153 vs 166 utt/s at batch 64 (in-call A/B): off
 
 
@@ -280,9 +281,13 @@ class BatchBeamSearch:
             if has_lm:
                 br.join()
                 ops.log_softmax_rows(z_lm, out=full, alpha=self.w_lm, add=self.w_len, accumulate=True)
-            cand = torch.topk(full, C, dim=-1)[1]                   # pre-beam on the weighted full scores
-            r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, cand, K, i,
-                                                                      step_dev=None if dyn is None else dyn["step"])
+            if PREBEAM_FUSED and C <= 64 and V <= 4096:            # pre-beam on the weighted full scores inside the CTC launch
+                cand, r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step_topk(
+                    logp_ctc, enc_lens, r_prev, s_prev, tok, full, C, K, i, step_dev=None if dyn is None else dyn["step"])
+            else:
+                cand = torch.topk(full, C, dim=-1)[1]
+                r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, cand, K, i,
+                                                                          step_dev=None if dyn is None else dyn["step"])
             if dyn is not None:
                 # beam update in three launches: weighted scores, top-k, gather of the extended slots' state into the
                 # shadow buffers + one multi-buffer commit (+ the counters); same arithmetic as the torch ops below
@@ -401,18 +406,31 @@ class BatchBeamSearch:
                 return rows_of
 
             events, done = [], 0
+            timing = os.environ.get("TAVSR_DECODE_TIMING") == "1"   # host-side cost of a token: replay call / record processing
+            t_replay = t_host = t_wait = 0.0
+            import time as _time
             for i in range(steps):
+                t0 = _time.perf_counter()
                 graph.replay()
                 pin[i].copy_(hist[i], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 events.append(ev)
+                t1 = _time.perf_counter()
                 while done < i and bool(active.any()):              # the host works one token behind the device
                     events[done].synchronize()
+                    t2 = _time.perf_counter()
                     host_step(done, pin[done, 0].to(torch.int64), pin[done, 2].view(torch.float32), rows_from_records(done))
                     done += 1
+                    t_wait += t2 - t1
+                    t_host += _time.perf_counter() - t2
+                t_replay += t1 - t0
                 if not bool(active.any()):
                     break
+            if timing:
+                n_ = max(1, len(events))
+                print(f"decode timing (host, per token, N = {N}): replay + copy + event {1e6 * t_replay / n_:.0f} us, waiting for the "
+                      f"device {1e6 * t_wait / n_:.0f} us, record processing {1e6 * t_host / n_:.0f} us", flush=True)
             while done < len(events) and bool(active.any()):
                 events[done].synchronize()
                 host_step(done, pin[done, 0].to(torch.int64), pin[done, 2].view(torch.float32), rows_from_records(done))

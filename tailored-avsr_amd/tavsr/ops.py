@@ -1313,6 +1313,23 @@ def ctc_prefix_step(logp, lens, r_prev, s_prev, last_tok, cand, K, out_len, blan
     return r_new, psi, psi_abs, eos, eos_abs
 
 
+def ctc_prefix_step_topk(logp, lens, r_prev, s_prev, last_tok, full, Cn, K, out_len, blank=0, step_dev=None):
+    """pre-beam + prefix scores in one launch: -> (cand [N,C] int64, r_new, psi, psi_abs, eos, eos_abs); see include/tavsr.h."""
+    U, T, V = logp.shape
+    N = full.shape[0]
+    require_cuda(logp, lens, r_prev, s_prev, last_tok, full)
+    assert full.is_contiguous() and full.shape[1] == V
+    cand = torch.empty(N, Cn, dtype=torch.int64, device=logp.device)
+    r_new = empty(N, T, 2, Cn, like=logp)
+    psi, psi_abs = empty(N, Cn, like=logp), empty(N, Cn, like=logp)
+    eos, eos_abs = empty(N, like=logp), empty(N, like=logp)
+    check(lib().tavsr_ctc_prefix_step_topk(ptr(logp), ptr(lens), ptr(r_prev), ptr(s_prev), ptr(last_tok), ptr(full), ptr(cand),
+                                           ptr(r_new), ptr(psi), ptr(psi_abs), ptr(eos), ptr(eos_abs), N, K, T, V, Cn,
+                                           0 if step_dev is not None else int(out_len), blank, ptr(step_dev), stream()),
+          "tavsr_ctc_prefix_step_topk")
+    return cand, r_new, psi, psi_abs, eos, eos_abs
+
+
 def act_(x, act):
     """x = act(x) in place."""
     require_cuda(x)

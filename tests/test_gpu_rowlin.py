@@ -97,3 +97,24 @@ def test_tree_attention_step_matches_fp64(N, H, dk, nkeys):
     sc = torch.einsum("nhd,njhd->nhj", q.double().reshape(N, H, dk), K) / dk ** 0.5
     ref = torch.einsum("nhj,njhd->nhd", torch.softmax(sc, -1), V).reshape(N, D)
     assert float((out.double() - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("U,K,V,Cn,step", [(3, 5, 41, 7, 0), (2, 10, 41, 15, 4), (1, 4, 300, 64, 2), (2, 3, 41, 41, 1)])
+def test_prebeam_inside_ctc_prefix_step_equals_topk_then_prefix_step(U, K, V, Cn, step):
+    """tavsr_ctc_prefix_step_topk = torch.topk(full, C) (descending; no ties in random scores) followed by
+    tavsr_ctc_prefix_step on those candidates: same candidate lists, bit-identical forward variables and scores."""
+    from tavsr import ops
+    g = torch.Generator(device="cuda").manual_seed(V + Cn)
+    N, T = U * K, 37
+    logp = torch.log_softmax(torch.randn(U, T, V, device="cuda", generator=g), -1)
+    lens = torch.tensor([T, T - 9, T - 20][:U], device="cuda")
+    full = torch.randn(N, V, device="cuda", generator=g)
+    r_prev = -torch.rand(N, T, 2, device="cuda", generator=g) * 5
+    s_prev = -torch.rand(N, device="cuda", generator=g) * 3
+    tok = torch.randint(1, V, (N,), device="cuda", generator=g)
+    cand0 = torch.topk(full, Cn, dim=-1)[1]
+    want = ops.ctc_prefix_step(logp, lens, r_prev, s_prev, tok, cand0, K, step)
+    got = ops.ctc_prefix_step_topk(logp, lens, r_prev, s_prev, tok, full, Cn, K, step)
+    assert torch.equal(got[0], cand0)
+    for a, b in zip(got[1:], want):
+        assert torch.equal(a, b)
