@@ -813,17 +813,20 @@ class LabelSmoothingLossFn(torch.autograd.Function):
     def forward(ctx, logits, target, ignore, smoothing, normalize_length):
         B, L, V = logits.shape
         row, g, correct = ops.lsm_loss(logits.reshape(B * L, V), target.reshape(-1).contiguous(), ignore, smoothing)
-        if normalize_length:
-            raise NotImplementedError("length_normalized_loss=true is not used by the shipped configs")
+        denom = B
+        if normalize_length:      # espnet LabelSmoothingLoss: sum / number of real target tokens (a host count, as espnet's .item())
+            if logits.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise NotImplementedError("length_normalized_loss=true reads the token count on the host: not capturable")
+            denom = max(1, int((target != ignore).sum()))
         ctx.save_for_backward(g)
-        ctx.B = B
+        ctx.B, ctx.denom = B, denom
         ctx.mark_non_differentiable(correct)
-        return ops.colsum(row.view(-1, 1), scale=1.0 / B).view(()), correct
+        return ops.colsum(row.view(-1, 1), scale=1.0 / denom).view(()), correct
 
     @staticmethod
     def backward(ctx, dl, _dc):
         (g,) = ctx.saved_tensors
-        return ops.scale_dev(g, dl.contiguous(), 1.0 / ctx.B).view(ctx.B, -1, g.shape[-1]), None, None, None, None
+        return ops.scale_dev(g, dl.contiguous(), 1.0 / ctx.denom).view(ctx.B, -1, g.shape[-1]), None, None, None, None
 
 
 class WeightedSumFn(torch.autograd.Function):

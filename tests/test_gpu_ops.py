@@ -251,6 +251,28 @@ def test_lsm_loss_and_embed():
     _close(dt, ref, 1e-5)
 
 
+@pytest.mark.parametrize("normalize_length", [False, True])
+def test_label_smoothing_loss_fn_matches_the_oracle_class(normalize_length):
+    """functional.LabelSmoothingLossFn vs the oracle's LabelSmoothingLoss (espnet: KL sum / batch, or / number of real target
+    tokens with length_normalized_loss): value and gradient on the logits."""
+    from oracle.leaves import LabelSmoothingLoss
+    from tavsr import functional as F_
+    torch.manual_seed(3)
+    B, L, V = 5, 9, 41
+    logits = torch.randn(B, L, V)
+    target = torch.randint(0, V, (B, L))
+    for b in range(B):
+        target[b, L - b:] = -1
+    lo = logits.clone().requires_grad_(True)
+    want = LabelSmoothingLoss(V, -1, 0.1, normalize_length)(lo, target)
+    want.backward()
+    lg = logits.cuda().requires_grad_(True)
+    got, _ = F_.LabelSmoothingLossFn.apply(lg, target.cuda(), -1, 0.1, normalize_length)
+    got.backward()
+    assert abs(float(got) - float(want)) < 1e-5 * abs(float(want))
+    _close(lg.grad.cpu(), lo.grad.double(), 1e-5)
+
+
 def test_grouped_helpers_match_the_plain_calls():
     """LNGroup (shared reduction, and its immediate path for an odd shape), linear_group (grouped launch and its
     per-projection fallback for K % 32 != 0) and add2_colsum against the single-call forms."""
