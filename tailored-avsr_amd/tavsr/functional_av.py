@@ -525,33 +525,44 @@ FUSION_PARAM_NAMES = ("acoustic_pooling_proj.weight", "visual_pooling_proj.weigh
 class FusionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, audio, video, alens, vlens, cfg, *P):
+        """cfg["mode"]: "learned" (P = 8 pooling / weight projections + FFN + norm), "const" (cfg["w"] = (w_audio, w_video):
+        merge_method fixed_ave, or the dropped acoustic branch of learned_ave) or "concat" (P = FFN over 2 D + norm)."""
         B, T, D = audio.shape
         a2, v2 = audio.contiguous().view(B * T, D), video.contiguous().view(B * T, D)
-        mp = list(P[:8])
-        w1, b1, w2, b2, lw, lb = P[8:14]
+        mode = cfg.get("mode", "learned")
         if cfg.get("drop_acoustic"):      # constant weights (0, 1): the fused stream is the video stream
-            score = pooled = wts = None
-            m = v2
+            mode, cfg = "const", dict(cfg, w=(0.0, 1.0))
+        nm = len(P) - 6                   # merge projections in front of (w1, b1, w2, b2, norm weight, norm bias)
+        mp = list(P[:nm])
+        w1, b1, w2, b2, lw, lb = P[nm:nm + 6]
+        score = pooled = wts = None
+        if mode == "const":
+            wa, wv = cfg["w"]
+            m = v2 if (wa == 0.0 and wv == 1.0) else ops.axpby(a2, v2, float(wa), float(wv))
+        elif mode == "concat":
+            m = ops.empty(B * T, 2 * D, like=a2)
+            ops.copy2d(a2, m[:, :D])
+            ops.copy2d(v2, m[:, D:])
         else:
-            score, pooled, wts = ops.merge_pool_fwd(a2, v2, alens, mp, B, T, lens2=vlens)
+            score, pooled, wts = ops.merge_pool_fwd(a2, v2, alens, mp[:8], B, T, lens2=vlens)
             m = ops.merge_combine(a2, v2, wts, B, T)
         h, z = ops.linear(m, w1, b1, act=cfg["act"], save_z=True)
         t_in = _drop_(h, cfg.get("p", 0.0))       # PositionwiseFeedForward's inner dropout (the fusion has no outer one)
         y2 = ops.linear(h, w2, b2)
         out, mean, rstd = ops.layernorm_fwd(y2, lw, lb, EPS_ESPNET)
         ctx.sv = (a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd, t_in)
-        ctx.P, ctx.cfg, ctx.lens, ctx.dims = P, cfg, (alens, vlens), (B, T, D)
+        ctx.P, ctx.cfg, ctx.lens, ctx.dims, ctx.mode, ctx.nm = P, cfg, (alens, vlens), (B, T, D), mode, nm
         cfg["_last_w"] = wts
         return out.view(B, T, -1)
 
     @staticmethod
     def backward(ctx, dy):
         a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd, t_in = ctx.sv
-        P, cfg = ctx.P, ctx.cfg
+        P, cfg, mode, nm = ctx.P, ctx.cfg, ctx.mode, ctx.nm
         B, T, D = ctx.dims
         alens, vlens = ctx.lens
-        mp = list(P[:8])
-        w1, b1, w2, b2, lw, lb = P[8:14]
+        mp = list(P[:nm])
+        w1, b1, w2, b2, lw, lb = P[nm:nm + 6]
         dy2, glw, glb = ops.layernorm_bwd(dy.contiguous().view(B * T, -1), y2, mean, rstd, lw)
         gw2, gb2 = ops.linear_dw(dy2, h, bias_grad=True)
         if t_in is None:
@@ -561,8 +572,15 @@ class FusionFn(torch.autograd.Function):
             dz = ops.dropout_act_bwd(dh, z, cfg["act"], t_in, out=dh)
         gw1, gb1 = ops.linear_dw(dz, m, bias_grad=True)
         dm = ops.linear_dx(dz, w1)
-        if wts is None:                   # acoustic branch dropped: d/d audio = 0, the merge projections took no part
-            da, dv, mg = torch.zeros_like(dm), dm, [None] * 8
+        mg = [None] * nm
+        if mode == "const":               # constant weights: the merge projections (if any) took no part
+            wa, wv = cfg["w"]
+            da = torch.zeros_like(dm) if wa == 0.0 else ops.axpby(dm, None, float(wa), 0.0)
+            dv = dm if wv == 1.0 else ops.axpby(dm, None, float(wv), 0.0)
+        elif mode == "concat":
+            da, dv = ops.empty(B * T, D, like=dm), ops.empty(B * T, D, like=dm)
+            ops.copy2d(dm[:, :D], da)
+            ops.copy2d(dm[:, D:], dv)
         else:
             da, dv, mg = ops.merge_bwd(dm, a2, v2, alens, mp, score, pooled, wts, B, T, lens2=vlens)
             mg = [g.view_as(q) for g, q in zip(mg, mp)]

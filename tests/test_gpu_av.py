@@ -605,3 +605,41 @@ def test_graph_replayed_training_step_equals_eager_launches(workload):
         assert torch.equal(static_loss.detach(), eager_loss), replay
         bad = [n for (n, p), g in zip(model.named_parameters(), eager) if not torch.equal(p.grad, g)]
         assert not bad, (replay, bad[:8])
+
+
+@pytest.mark.parametrize("merge,kw", [("concat", {}), ("fixed_ave", dict(acoustic_weight=0.3)), ("fixed_ave", dict(acoustic_weight=1.0))])
+def test_fusion_concat_and_fixed_ave_match_the_oracle(merge, kw):
+    """AdaptiveAudioVisualFusion merge_method "concat" (FFN over the concatenated streams) and "fixed_ave" (constant
+    weights) - adaptive_audiovisual_fusion.py:132-135,197-200 - vs the oracle class: output, lengths, every gradient."""
+    from oracle.av import AdaptiveFusionOracle
+    from oracle.model import fill_parameters_, synth
+    from tavsr.audiovisual_fusion.adaptive_audiovisual_fusion import AdaptiveAudioVisualFusion
+    # espnet's PositionwiseFeedForward maps idim -> hidden -> idim: with "concat" the fused stream is 2 x input_size wide,
+    # so the reference's norm_final only fits for output_size = 2 x input_size
+    conf = dict(output_size=512 if merge == "concat" else 256, hidden_units=512, merge_method=merge, activation_type="swish",
+                dropout_rate=0.0, **kw)
+    ora = AdaptiveFusionOracle(input_size=256, **conf)
+    fill_parameters_(ora, seed=31)
+    fus = AdaptiveAudioVisualFusion(input_size=256, **conf)
+    assert sorted(fus.state_dict().keys()) == sorted(ora.state_dict().keys())
+    fus.load_state_dict(ora.state_dict())
+    fus = fus.cuda().train()
+    ora.train()
+    B, T = 3, 21
+    a, v = synth((B, T, 256), seed=1), synth((B, T, 256), seed=2)
+    alens, vlens = torch.tensor([21, 15, 9]), torch.tensor([21, 17, 8])
+    am = (torch.arange(T)[None, :] < alens[:, None])[:, None, :]
+    vm = (torch.arange(T)[None, :] < vlens[:, None])[:, None, :]
+    ao, vo = a.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    yo, lo = ora(ao, am, vo, vm)
+    dy = synth(tuple(yo.shape), seed=3)
+    yo.backward(dy)
+    ag, vg = a.cuda().requires_grad_(True), v.cuda().requires_grad_(True)
+    yg, lg = fus(ag, am.cuda(), vg, vm.cuda())
+    yg.backward(dy.cuda())
+    assert torch.equal(lg.cpu(), lo)
+    assert max_rel(yg.detach().cpu(), yo.detach()) < ACT_TOL
+    assert grad_ok(ag.grad.cpu(), ao.grad, 1e-3) and grad_ok(vg.grad.cpu(), vo.grad, 1e-3)
+    po = dict(ora.named_parameters())
+    for n, p in fus.named_parameters():
+        assert grad_ok(p.grad.cpu(), po[n].grad, 1e-3), n
