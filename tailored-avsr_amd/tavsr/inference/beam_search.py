@@ -205,7 +205,7 @@ class BatchBeamSearch:
         self.w_len = penalty
         # avsr_inference.py:298: pre_beam_score_key = None when ctc_weight == 1 -> the CTC prefix scorer sees every token
         self.C = self.V if ctc_weight == 1.0 else min(int(1.5 * beam_size), self.V)
-        self._pinned = {}
+        self._pinned = None
         self.dec_step = _DecoderStep(model.decoder)
         self.lm_step = _LMStep(lm) if (lm is not None and lm_weight != 0.0) else None
 
@@ -388,9 +388,10 @@ class BatchBeamSearch:
 
         if graph is not None:
             hist = dyn["hist"]
-            pin = self._pinned.get((steps, N))                      # page-locked landing zone of the records, kept per shape
-            if pin is None:
-                pin = self._pinned[(steps, N)] = torch.empty((steps, 3, N), dtype=torch.int32, pin_memory=True)
+            need = steps * 3 * N                                    # page-locked landing zone of the records: ONE buffer that
+            if self._pinned is None or self._pinned.numel() < need:   # grows to the largest search seen
+                self._pinned = torch.empty(max(need, 1 << 16), dtype=torch.int32, pin_memory=True)
+            pin = self._pinned[:need].view(steps, 3, N)
             rec = pin.numpy()                                       # same memory: rec[token][0 / 1 / 2][slot]
 
             def rows_from_records(i):
