@@ -605,6 +605,12 @@ __device__ unsigned int g_trace_n;
 // 4-byte LDS-DMA gather (a patch row is 35 runs of 7 floats), so no patch matrix is ever written:
 //   4: A(m = output pixel (clip, t, ho, wo), k = (kt*7 + kh)*7 + kw) = x[clip][t + kt - 2][2 ho - 3 + kh][2 wo - 3 + kw];
 //   5: the k-major B operand (weight gradient): B(k = pixel, n = tap), as 4 with the roles of rows and columns swapped.
+// The same stem over ZERO-PADDED clips xp [clips][T + 5][H + 6][W + 8] (2 / 3 frames, 3 / 3 rows, 3 / 5 columns of zeros
+// around every clip, tavsr_stem_pad) with the taps laid out k = ((kt*7 + kh) * 8 + kw), K / N = 288 (kw = 7 and the last
+// 8 columns carry zero weights): every tap is inside the buffer and four consecutive k are four consecutive floats, so the
+// operand is fetched with the GEMM's ordinary 16-byte LDS-DMA (two per thread and K-step instead of eight 4-byte gathers; the
+// source is only 8-byte aligned, which gfx950's global_load_lds takes) and no validity test is left:
+//   6: A(m, k) = xp[clip][t + kt][2 ho + kh][2 wo + kw];   7: B(k = pixel, n = tap) likewise (weight gradient).
 template <int BM, int BN, int WM, int WN, int S, bool AK, bool BKM, int KW = 1, int CONV = 0>
 __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, int nsplit, int tiles_n, int bid, bool vec_epi,
                                           int zidx) {
@@ -729,6 +735,37 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
     s5_off = (ft * sH + 2 * s5_ho) * sW + 2 * s5_wo;
     s5_th = s5_nok && (unsigned)(s5_t + s5_a - 2) < (unsigned)sT && (unsigned)(2 * s5_ho - 3 + s5_b) < (unsigned)sH;
   }
+  // CONV 6 / 7: padded clips, 16-byte chunks.  Hp x Wp padded frame, Tp padded frames per clip (conv_H, conv_W, conv_C).
+  const int pHp = d.conv_H, pWp = d.conv_W, pTp = d.conv_C, pHo = (pHp - 6) / 2, pWo = (pWp - 8) / 2, pT = pTp - 5;
+  int s6_base[CONV == 6 ? LA::NR : 1], s6_cl[CONV == 6 ? LA::NR : 1];
+  if (CONV == 6) {
+#pragma unroll
+    for (int i = 0; i < LA::NR; ++i) {
+      const int q = i * NT + tid, row = q >> 3;
+      s6_cl[i] = (q & 7) ^ ((row >> 1) & 7);                 // logical 16-byte chunk of the K-step this DMA fetches
+      const int m = min(m0 + row, d.M - 1);
+      const int wo = m % pWo, ho = (m / pWo) % pHo, ft = m / (pWo * pHo);
+      s6_base[i] = (((ft / pT) * pTp + ft % pT) * pHp + 2 * ho) * pWp + 2 * wo;
+    }
+  }
+  // CONV 7: the chunk's tap is fixed per thread, its pixel walks on by NT / (BN / 4) per gather (tiles are issued in k order)
+  int s7_wo[CONV == 7 ? LB::NR : 1], s7_ho[CONV == 7 ? LB::NR : 1], s7_t[CONV == 7 ? LB::NR : 1], s7_off[CONV == 7 ? LB::NR : 1];
+  int s7_tapoff = 0;
+  if (CONV == 7) {
+    static_assert(CONV != 7 || BKM, "weight gradient: k-major patch operand");
+    constexpr int CPR = BN / 4;                               // chunks per k row
+    int c = (n0 >> 2) + (tid % CPR);
+    if (c >= 72) c = 0;                                       // columns >= 288 are never stored: any valid address
+    const int r = c >> 1, a = r / 7, b = r - 7 * a;
+    s7_tapoff = (a * pHp + b) * pWp + 4 * (c & 1);
+#pragma unroll
+    for (int i = 0; i < LB::NR; ++i) {
+      const int m = kbeg + (i * NT + tid) / CPR;
+      const int wo = m % pWo, ho = (m / pWo) % pHo, ft = m / (pWo * pHo);
+      s7_wo[i] = wo; s7_ho[i] = ho; s7_t[i] = ft % pT;
+      s7_off[i] = (((ft / pT) * pTp + ft % pT) * pHp + 2 * ho) * pWp + 2 * wo;
+    }
+  }
   // CONV 3 (K tail: K % 32 != 0): chunks whose first k lies at or past K are fetched from a zero page; a k-contiguous chunk
   // that straddles K (K % 4 != 0) is fetched whole and its k >= K elements are zeroed in LDS before the last K-step
   int kofsA[LA::NR], kofsB[LB::NR];
@@ -759,7 +796,14 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       }
       return;
     }
-    if (CONV == 4) {
+    if (CONV == 6) {
+#pragma unroll
+      for (int i = 0; i < LA::NR; ++i) {
+        const int c = (kbeg >> 2) + kt * 8 + s6_cl[i], r = c >> 1, a = r / 7, b = r - 7 * a;
+        const float* src = A + (s6_base[i] + (a * pHp + b) * pWp + 4 * (c & 1));
+        __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + (i * NT + wave * 64) * 4), 16, 0, 0);
+      }
+    } else if (CONV == 4) {
       int tapoff[2], sh[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -787,7 +831,25 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
     } else {
       LA::issue(Ak + kt * kstepA, offA, smem + st * STAGE, wave);
     }
-    if (CONV == 5) {
+    if (CONV == 7) {
+      constexpr int STEP = 32;                                // a thread's gather i of the next tile is 32 pixels further on
+#pragma unroll
+      for (int i = 0; i < LB::NR; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_float*)(B + (s7_off[i] + s7_tapoff)),
+                                         (lds_float*)(smem + st * STAGE + ASZ + (i * NT + wave * 64) * 4), 16, 0, 0);
+        s7_wo[i] += STEP;
+        s7_off[i] += 2 * STEP;
+        while (s7_wo[i] >= pWo) {                             // next output row: 2 rows of the padded frame further down
+          s7_wo[i] -= pWo;
+          s7_off[i] += 2 * pWp - 2 * pWo;
+          if (++s7_ho[i] == pHo) {                            // next frame, at the end of a clip over its padding frames
+            s7_ho[i] = 0;
+            s7_off[i] += (pHp - 2 * pHo) * pWp;
+            if (++s7_t[i] == pT) { s7_t[i] = 0; s7_off[i] += (pTp - pT) * pHp * pWp; }
+          }
+        }
+      }
+    } else if (CONV == 5) {
 #pragma unroll
       for (int i = 0; i < NR4B; ++i) {
         const bool ok = s5_th && (unsigned)(2 * s5_wo + s5_c3) < (unsigned)sW;
@@ -1069,7 +1131,17 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
   static const int wide = [] { const char* e = getenv("TAVSR_CONV_TILE"); return e ? atoi(e) : 1; }();
   static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
   static const int zmap_on = [] { const char* e = getenv("TAVSR_CONV_ZMAP"); return e ? atoi(e) : 1; }();
-  const int zmap = zmap_on && (d.conv_mode == 2 || d.conv_mode == 5) && nsplit >= 8 && nsplit % 8 == 0;
+  const int zmap = zmap_on && (d.conv_mode == 2 || d.conv_mode == 5 || d.conv_mode == 7) && nsplit >= 8 && nsplit % 8 == 0;
+  if (d.conv_mode == 6 || d.conv_mode == 7) {      // Conv3d stem over padded clips: ordinary 16-byte chunks
+    GemmArgs a6{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve, zmap};
+    const dim3 grid6(a6.tiles_m * a6.tiles_n, 1, nsplit);
+    if (d.conv_mode == 6)
+      hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, false, false, 1, 6>), grid6, dim3(256), 0, s, a6);
+    else
+      hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, true, true, 1, 7>), grid6, dim3(256), 0, s, a6);
+    TAVSR_LAUNCH_CHECK();
+    return launch_epilogue(a6, s);
+  }
   if (d.conv_mode == 4 || d.conv_mode == 5) {      // Conv3d stem: 4-byte gathers
     GemmArgs a4{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve, zmap};
     const dim3 grid4(a4.tiles_m * a4.tiles_n, 1, nsplit);
@@ -1196,7 +1268,7 @@ static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
 // is split until all five block slots of every CU are filled (the slabs stay tiny); TAVSR_CONV_DW_BLOCKS tunes the target
 static Plan plan_conv(const tavsr_gemm_desc& d, bool can_split) {
   Plan pc = plan(d, can_split, true);
-  if ((d.conv_mode == 2 || d.conv_mode == 5) && can_split) {
+  if ((d.conv_mode == 2 || d.conv_mode == 5 || d.conv_mode == 7) && can_split) {
     static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
     const bool wide = d.conv_mode == 2 && dw_wide && d.M % 128 == 0;     // 128x64 tiles (launch_conv): three block slots per CU
     const long tiles = (long)cdiv(d.M, wide ? 128 : 64) * cdiv(d.N, 64);
@@ -1244,13 +1316,30 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
   const bool can_split = d.ws != nullptr;
   const bool fast = glds_ok(d, vec);
   if (d.conv_mode != 0) {       // implicit 3x3/s1/p1 convolution: only the LDS-DMA kernel reads images as patch operands
-    TAVSR_REQUIRE(d.conv_mode == 1 || d.conv_mode == 2 || d.conv_mode == 4 || d.conv_mode == 5, TAVSR_EINVAL,
-                  "tavsr_gemm: conv_mode must be 0, 1, 2, 4 or 5");
+    TAVSR_REQUIRE(d.conv_mode == 1 || d.conv_mode == 2 || (d.conv_mode >= 4 && d.conv_mode <= 7), TAVSR_EINVAL,
+                  "tavsr_gemm: conv_mode must be 0, 1, 2 or 4..7");
     TAVSR_REQUIRE(d.drop_p == 0.f, TAVSR_EUNSUPPORTED, "tavsr_gemm: no epilogue dropout on convolution operands");
     TAVSR_REQUIRE(d.conv_zero && aligned16(d.conv_zero) && d.conv_H > 0 && d.conv_W > 0 && d.conv_C > 0, TAVSR_EINVAL,
                   "tavsr_gemm: conv needs H, W, C and a 16-byte aligned zero page");
     TAVSR_REQUIRE(d.nb1 * d.nb2 == 1 && fast && force_cfg < 0, TAVSR_EUNSUPPORTED,
                   "tavsr_gemm: conv operands need an unbatched, aligned problem with K %% 32 == 0");
+    if (d.conv_mode >= 6) {       // Conv3d stem over padded clips [clips][conv_C = T + 5][conv_H = H + 6][conv_W = W + 8], 288 tap columns
+      TAVSR_REQUIRE(d.conv_C > 5 && d.conv_H > 6 && d.conv_W > 8 && (d.conv_H - 6) % 2 == 0 && (d.conv_W - 8) % 2 == 0 &&
+                        d.conv_W % 4 == 0, TAVSR_EINVAL, "tavsr_gemm: padded stem clips are [T + 5][H + 6][W + 8], H and W even");
+      const int64_t per_clip = (int64_t)(d.conv_C - 5) * ((d.conv_H - 6) / 2) * ((d.conv_W - 8) / 2);
+      const int64_t pixels = d.conv_mode == 6 ? d.M : d.K;
+      TAVSR_REQUIRE(pixels % per_clip == 0 && pixels / per_clip * d.conv_C * d.conv_H * d.conv_W < (1ll << 31), TAVSR_EINVAL,
+                    "tavsr_gemm: stem rows must be whole clips (fewer than 2^31 padded input pixels)");
+      if (d.conv_mode == 6)
+        TAVSR_REQUIRE(!d.a_kmajor && !d.b_kmajor && d.K == 288 && d.ldb >= 288, TAVSR_EUNSUPPORTED,
+                      "tavsr_gemm: conv mode 6 needs the NT layout with K = 288 (35 x 8 tap columns + padding)");
+      else
+        TAVSR_REQUIRE(d.a_kmajor && d.b_kmajor && d.N == 288 && d.M % 4 == 0, TAVSR_EUNSUPPORTED,
+                      "tavsr_gemm: conv mode 7 needs the TN layout with N = 288 (35 x 8 tap columns + padding)");
+      Plan p6 = plan_conv(d, can_split);
+      if (p6.nsplit > 1 && d.ws_floats < ws_floats_for(d, p6.nsplit)) p6 = plan(d, false, true);
+      return launch_conv(d, p6.nsplit, p6.kchunk, s);
+    }
     if (d.conv_mode >= 4) {       // Conv3d stem: conv_H x conv_W input frames, conv_C frames per clip, 245 taps padded to 256
       const int64_t per_frame = (int64_t)((d.conv_H - 1) / 2 + 1) * ((d.conv_W - 1) / 2 + 1);
       const int64_t pixels = d.conv_mode == 4 ? d.M : d.K;

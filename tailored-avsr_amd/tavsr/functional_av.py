@@ -100,19 +100,24 @@ class VisualFrontendFn(torch.autograd.Function):
         x = x.contiguous()
         saved = {}
         # ---- stem: Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BN3d -> Swish -> MaxPool(1,3,3)/(1,2,2)
-        w0 = ops.fill_(ops.empty(64, 256, like=x), 0.0)
-        ops.copy2d(p["frontend3D.0.weight"].reshape(64, 245), w0[:, :245])
-        if ops.stem_implicit_ok(x):            # every patch element is gathered by the GEMM's own loader: no patch matrix
-            col0 = None
-            z0, H0, W0 = ops.stem_conv_fwd(x, w0)
+        xp = col0 = w0 = None
+        if ops.stem_pad16_ok(x):               # zero-padded clips, taps 35 x 8: the GEMM's ordinary 16-byte loader, no patch matrix
+            xp = ops.stem_pad(x)
+            w0 = ops.stem_weight_288(p["frontend3D.0.weight"])
+            z0, H0, W0 = ops.stem_conv_fwd_pad16(xp, w0, B, T, H, W)
         else:
-            col0, H0, W0 = ops.im2col_stem(x)
-            z0 = ops.linear(col0, w0)
+            w0 = ops.fill_(ops.empty(64, 256, like=x), 0.0)
+            ops.copy2d(p["frontend3D.0.weight"].reshape(64, 245), w0[:, :245])
+            if ops.stem_implicit_ok(x):        # every patch element is its own 4-byte gather: no padded copy either
+                z0, H0, W0 = ops.stem_conv_fwd(x, w0)
+            else:
+                col0, H0, W0 = ops.im2col_stem(x)
+                z0 = ops.linear(col0, w0)
         m0, r0 = _BN.stats(z0, "frontend3D.1.", bufs, training)
         y0 = ops.bn_apply_fwd(z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
         cur, idx0, Hc, Wc = ops.maxpool3x3s2_fwd(y0, N, H0, W0, 64)
         del y0
-        saved["stem"] = (x, z0, m0, r0, idx0, H0, W0, w0, col0)     # fallback route: the 6 GB patch matrix stays resident
+        saved["stem"] = (x if xp is None else xp, z0, m0, r0, idx0, H0, W0, w0, col0, xp is not None)
         # ---- trunk
         blocks = []
         cin = 64
@@ -200,18 +205,23 @@ class VisualFrontendFn(torch.autograd.Function):
             else:
                 d = ops.axpby(dX, dres, 1.0, 1.0)
         # ---- stem
-        x, z0, m0, r0, idx0, H0, W0, w0, col0 = ctx.saved["stem"]
+        x, z0, m0, r0, idx0, H0, W0, w0, col0, padded = ctx.saved["stem"]
         # max-pool backward inside the BatchNorm backward passes: the 1.6 GB gradient of the pool's input is never written
         dz0, G["frontend3D.1.weight"], G["frontend3D.1.bias"] = ops.bn_bwd_pooled(
             d.contiguous(), idx0, z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], N, H0, W0, "swish")
-        if col0 is None:
-            gw0 = ops.stem_conv_dw(dz0, x)                                # [64, 256], columns >= 245 are padding
+        if padded:
+            T_ = ctx.dims[1]
+            gw0 = ops.stem_conv_dw_pad16(dz0, x, T_, 2 * H0, 2 * W0)      # [64, 288] in the 35 x 8 tap layout
+            G["frontend3D.0.weight"] = ops.stem_weight_grad_from_288(gw0, p["frontend3D.0.weight"].shape)
         else:
-            gw0 = ops.linear_dw(dz0, col0, force=STEM_DW_PLAN)
+            if col0 is None:
+                gw0 = ops.stem_conv_dw(dz0, x)                            # [64, 256], columns >= 245 are padding
+            else:
+                gw0 = ops.linear_dw(dz0, col0, force=STEM_DW_PLAN)
+            g0 = ops.empty(64, 245, like=gw0)
+            ops.copy2d(gw0[:, :245], g0)
+            G["frontend3D.0.weight"] = g0.view(p["frontend3D.0.weight"].shape)
         del col0
-        g0 = ops.empty(64, 245, like=gw0)
-        ops.copy2d(gw0[:, :245], g0)
-        G["frontend3D.0.weight"] = g0.view(p["frontend3D.0.weight"].shape)
         ops.join_side()
         ctx.saved = ctx.blocks = None
         return (None, None, *[G[n] for n in ctx.names])

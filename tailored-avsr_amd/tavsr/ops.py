@@ -127,7 +127,7 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
     nb = max(1, nb1) * max(1, nb2)
     a_el, b_el = M * K, K * N                 # each operand once; an implicit-conv operand is the image, not its 9 taps
     if conv is not None and conv[0] >= 4:      # Conv3d stem: the clip tensor is the gathered operand
-        a_el, b_el = (A.numel(), b_el) if conv[0] == 4 else (a_el, B.numel())
+        a_el, b_el = (A.numel(), b_el) if conv[0] in (4, 6) else (a_el, B.numel())
     elif conv is not None:
         a_el, b_el = (a_el // 9, b_el) if conv[0] == 1 else (a_el, b_el // 9)
     c_el = M * N * (1 + (R is not None) + (Z is not None) + (DZ is not None))
@@ -942,6 +942,52 @@ def stem_implicit_ok(x) -> bool:
     Ho, Wo = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
     return (STEM_IMPLICIT and H % 2 == 0 and W % 2 == 0 and W >= 8 and (B * T * Ho * Wo) % 32 == 0 and T < 1024 and H < 1000 and W < 1000
             and B * T * H * W < 2 ** 31 and x.data_ptr() % 16 == 0)
+
+
+# Default stem route: zero-padded clips + taps laid out 35 x 8, fetched with the GEMM's ordinary 16-byte LDS-DMA (conv_mode 6 / 7).
+# TAVSR_STEM_PAD16=0: the 4-byte gather route (conv_mode 4 / 5, no padded copy of the clips).
+STEM_PAD16 = os.environ.get("TAVSR_STEM_PAD16", "1") == "1"
+
+
+def stem_pad16_ok(x) -> bool:
+    B, T, H, W = x.shape
+    Ho, Wo = H // 2, W // 2
+    return (STEM_IMPLICIT and STEM_PAD16 and H % 2 == 0 and W % 4 == 0 and (B * T * Ho * Wo) % 32 == 0
+            and B * (T + 5) * (H + 6) * (W + 8) < 2 ** 31)
+
+
+def stem_pad(x):
+    """x [B,T,H,W] -> zero-padded clips [B, T+5, H+6, W+8] (2/3 frames, 3/3 rows, 3/5 columns): every tap of the (5,7,7)
+    stride (1,2,2) stem is inside the buffer, also the zero-weight tap columns."""
+    return torch.nn.functional.pad(x, (3, 5, 3, 3, 2, 3)).contiguous()
+
+
+def stem_weight_288(w):
+    """Conv3d weight [Cout,1,5,7,7] -> [Cout, 288]: column ((kt*7 + kh)*8 + kw), zeros at kw = 7 and in the last 8 columns."""
+    co = w.shape[0]
+    return torch.nn.functional.pad(torch.nn.functional.pad(w.reshape(co, 35, 7), (0, 1)).reshape(co, 280), (0, 8)).contiguous()
+
+
+def stem_weight_grad_from_288(g, shape):
+    co = g.shape[0]
+    return g[:, :280].reshape(co, 35, 8)[:, :, :7].reshape(shape).contiguous()
+
+
+def stem_conv_fwd_pad16(xp, w288, B, T, H, W):
+    """padded clips xp (stem_pad), w288 [Cout, 288] -> z [B*T*Ho*Wo, Cout]."""
+    Ho, Wo = H // 2, W // 2
+    M = B * T * Ho * Wo
+    z = empty(M, w288.shape[0], like=xp)
+    gemm(M, w288.shape[0], 288, xp, 4, w288, 288, z, w288.shape[0], conv=(6, H + 6, W + 8, T + 5))
+    return z, Ho, Wo
+
+
+def stem_conv_dw_pad16(dz, xp, T, H, W):
+    """dW [Cout, 288] = dz^T patches(xp) in the 35 x 8 tap layout (the zero-weight columns receive values nobody reads)."""
+    M, cout = dz.shape
+    dw = empty(cout, 288, like=dz)
+    gemm(cout, 288, M, dz, cout, xp, 4, dw, 288, a_kmajor=True, b_kmajor=True, conv=(7, H + 6, W + 8, T + 5))
+    return dw
 
 
 def stem_conv_fwd(x, w0p):
