@@ -1135,8 +1135,13 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
   if (d.conv_mode == 6 || d.conv_mode == 7) {      // Conv3d stem over padded clips: ordinary 16-byte chunks
     GemmArgs a6{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve, zmap};
     const dim3 grid6(a6.tiles_m * a6.tiles_n, 1, nsplit);
-    if (d.conv_mode == 6)
+    static const int st3 = [] { const char* e = getenv("TAVSR_STEM_STAGES"); return e ? atoi(e) : 2; }();   // tuning aid
+    if (d.conv_mode == 6 && st3 == 3)
+      hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 3, 3, false, false, 1, 6>), grid6, dim3(256), 0, s, a6);
+    else if (d.conv_mode == 6)
       hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, false, false, 1, 6>), grid6, dim3(256), 0, s, a6);
+    else if (st3 == 3)
+      hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 3, 3, true, true, 1, 7>), grid6, dim3(256), 0, s, a6);
     else
       hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 2, 5, true, true, 1, 7>), grid6, dim3(256), 0, s, a6);
     TAVSR_LAUNCH_CHECK();
