@@ -389,6 +389,11 @@ int tavsr_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const float* x, 
 int tavsr_rsqrt_eps(const float* v, float eps, float* out, int64_t n, tavsr_stream_t stream);
 int tavsr_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int64_t N, int32_t H, int32_t W, int32_t C,
                            tavsr_stream_t stream);
+/* y = maxpool3x3/s2/p1(act(BatchNorm(x))) per frame with the statistics given (mean, rstd): tavsr_bn_apply_fwd fused into the
+ * pool's window loads - the stem's [frames*H*W, C] activation map (conv3d_resnet18.py:57-63) is never written */
+int tavsr_bn_act_maxpool3x3s2_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  int32_t act, float* y, uint8_t* idx, int64_t N, int32_t H, int32_t W, int32_t C,
+                                  tavsr_stream_t stream);
 int tavsr_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t N, int32_t H, int32_t W, int32_t C,
                            tavsr_stream_t stream);
 int tavsr_avgpool_fwd(const float* x, float* y, int64_t N, int32_t P, int32_t C, tavsr_stream_t stream);

@@ -269,12 +269,21 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
 // ---- pooling ------------------------------------------------------------------------------------------------
 // MaxPool 3x3 stride 2 pad 1 per frame, NHWC (the (1,3,3)/(1,2,2) MaxPool3d of the stem); idx = winning tap 0..8
 // thread = 4 channels of one output pixel (16-byte loads; C % 4 == 0)
+// mean != nullptr: the pooled map is act(BatchNorm(x)) - the normalisation and activation of bn_apply_fwd_kernel applied
+// to every window element on the fly (same arithmetic), so the [N*H*W, C] activation map is never written (stem: 1.6 GB).
 __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
-                                        int H, int W, int Ho, int Wo, int C, int64_t total4) {
+                                        int H, int W, int Ho, int Wo, int C, int64_t total4, const float* __restrict__ mean,
+                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, int act) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int C4 = C >> 2;
   const int c4 = (int)(i % C4);
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, g = mu, b = mu;
+  if (mean) {
+    mu = reinterpret_cast<const float4*>(mean)[c4]; rs = reinterpret_cast<const float4*>(rstd)[c4];
+    g = reinterpret_cast<const float4*>(gamma)[c4]; b = reinterpret_cast<const float4*>(beta)[c4];
+  }
   int64_t r = i / C4;
   const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho);
   const int64_t n = r / ((int64_t)Wo * Ho);
@@ -284,7 +293,10 @@ __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __re
   for (int k = 0; k < 9; ++k) {
     const int h = ho * 2 - 1 + k / 3, w = wo * 2 - 1 + k % 3;
     if (h < 0 || h >= H || w < 0 || w >= W) continue;
-    const float4 v4 = *reinterpret_cast<const float4*>(x + ((n * H + h) * W + w) * C + c4 * 4);
+    float4 v4 = *reinterpret_cast<const float4*>(x + ((n * H + h) * W + w) * C + c4 * 4);
+    if (mean)
+      v4 = make_float4(act_fwd(act, (v4.x - mu.x) * rs.x * g.x + b.x), act_fwd(act, (v4.y - mu.y) * rs.y * g.y + b.y),
+                       act_fwd(act, (v4.z - mu.z) * rs.z * g.z + b.z), act_fwd(act, (v4.w - mu.w) * rs.w * g.w + b.w));
     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -643,7 +655,23 @@ extern "C" int tavsr_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, in
                 "maxpool_fwd: C %% 4 == 0 and aligned tensors required");
   const int64_t total = N * Ho * Wo * (C / 4);
   if (total <= 0) return TAVSR_OK;
-  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo, C, total);
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo, C, total,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_bn_act_maxpool3x3s2_fwd(const float* x, const float* mean, const float* rstd, const float* gamma,
+                                             const float* beta, int32_t act, float* y, uint8_t* idx, int64_t N, int32_t H,
+                                             int32_t W, int32_t C, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && mean && rstd && gamma && beta && y && idx, TAVSR_EINVAL, "bn_act_maxpool_fwd: null pointer");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  TAVSR_REQUIRE(C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 &&
+                    ((uintptr_t)idx & 3) == 0, TAVSR_EUNSUPPORTED, "bn_act_maxpool_fwd: C %% 4 == 0 and aligned tensors required");
+  const int64_t total = N * Ho * Wo * (C / 4);
+  if (total <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo, C, total,
+                     mean, rstd, gamma, beta, act);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -69,6 +69,7 @@ def _plan_env(name, default):
 # 64x128 tiles read dz0 twice instead of four times (the launch is HBM-bound: 12.7 GB -> 9.5 GB); +0.35 % on the AV step
 # against the planner's 64x64 / 250 slices (in-call A/B).  TAVSR_STEM_DW_PLAN=0 returns to the planner.
 STEM_DW_PLAN = _plan_env("TAVSR_STEM_DW_PLAN", (3, 512))
+STEM_POOL_FUSED = os.environ.get("TAVSR_STEM_POOL_FUSED", "1") == "1"      # A/B switch
 
 
 class _BN:
@@ -114,9 +115,13 @@ class VisualFrontendFn(torch.autograd.Function):
                 col0, H0, W0 = ops.im2col_stem(x)
                 z0 = ops.linear(col0, w0)
         m0, r0 = _BN.stats(z0, "frontend3D.1.", bufs, training)
-        y0 = ops.bn_apply_fwd(z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
-        cur, idx0, Hc, Wc = ops.maxpool3x3s2_fwd(y0, N, H0, W0, 64)
-        del y0
+        if STEM_POOL_FUSED:      # BatchNorm + Swish inside the pool's window loads: the 1.6 GB activation map is never written
+            cur, idx0, Hc, Wc = ops.bn_act_maxpool3x3s2_fwd(z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], "swish",
+                                                            N, H0, W0, 64)
+        else:
+            y0 = ops.bn_apply_fwd(z0, m0, r0, p["frontend3D.1.weight"], p["frontend3D.1.bias"], None, "swish")
+            cur, idx0, Hc, Wc = ops.maxpool3x3s2_fwd(y0, N, H0, W0, 64)
+            del y0
         saved["stem"] = (x if xp is None else xp, z0, m0, r0, idx0, H0, W0, w0, col0, xp is not None)
         # ---- trunk
         blocks = []

@@ -1079,6 +1079,17 @@ def maxpool3x3s2_fwd(x, N, H, W, Cn):
     return y, idx, Ho, Wo
 
 
+def bn_act_maxpool3x3s2_fwd(z, mean, rstd, gamma, beta, act, N, H, W, Cn):
+    """maxpool(act(BatchNorm(z))) without writing the activation map: -> (pooled, idx, Ho, Wo)."""
+    Ho, Wo = conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1)
+    require_cuda(z, mean, rstd, gamma, beta)
+    y = empty(N * Ho * Wo, Cn, like=z)
+    idx = torch.empty((N * Ho * Wo, Cn), dtype=torch.uint8, device=z.device)
+    check(lib().tavsr_bn_act_maxpool3x3s2_fwd(ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(y), ptr(idx),
+                                              C.c_int64(N), H, W, Cn, stream()), "tavsr_bn_act_maxpool3x3s2_fwd")
+    return y, idx, Ho, Wo
+
+
 def maxpool3x3s2_bwd(dy, idx, N, H, W, Cn):
     dx = empty(N * H * W, Cn, like=dy)
     check(lib().tavsr_maxpool3x3s2_bwd(ptr(dy), ptr(idx), ptr(dx), C.c_int64(N), H, W, Cn, stream()), "tavsr_maxpool3x3s2_bwd")

@@ -643,3 +643,22 @@ def test_fusion_concat_and_fixed_ave_match_the_oracle(merge, kw):
     po = dict(ora.named_parameters())
     for n, p in fus.named_parameters():
         assert grad_ok(p.grad.cpu(), po[n].grad, 1e-3), n
+
+
+@pytest.mark.parametrize("N,H,W,C", [(3, 10, 12, 64), (2, 7, 9, 8), (1, 44, 44, 64)])
+def test_bn_act_maxpool_equals_the_two_launches(N, H, W, C):
+    """tavsr_bn_act_maxpool3x3s2_fwd == bn_apply_fwd followed by maxpool3x3s2_fwd: pooled values to rounding (the compiler
+    contracts the normalisation differently in the two kernels), the same winning tap wherever the window has a clear winner."""
+    from tavsr import ops
+    g_ = torch.Generator(device="cuda").manual_seed(H * W)
+    x = torch.randn(N * H * W, C, device="cuda", generator=g_)
+    mean, rstd = torch.randn(C, device="cuda", generator=g_) * 0.1, torch.rand(C, device="cuda", generator=g_) + 0.5
+    gam, bet = torch.randn(C, device="cuda", generator=g_), torch.randn(C, device="cuda", generator=g_)
+    y = ops.bn_apply_fwd(x, mean, rstd, gam, bet, None, "swish")
+    want = ops.maxpool3x3s2_fwd(y, N, H, W, C)
+    got = ops.bn_act_maxpool3x3s2_fwd(x, mean, rstd, gam, bet, "swish", N, H, W, C)
+    assert got[2:] == want[2:]
+    assert float((got[0] - want[0]).abs().max()) < 1e-6 * float(want[0].abs().max())
+    same = got[1] == want[1]
+    assert float(same.float().mean()) > 0.999
+    # where the taps differ the two candidates are a rounding apart: the pooled values agree (checked above)
