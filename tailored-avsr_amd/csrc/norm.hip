@@ -153,28 +153,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // out[c] (+)= scale * sum_p part[p*stride + c].  One block per 64 columns; the 4 waves take the partials
 // p = w, w+4, ... (four independent load streams per lane), then a fixed-order cross-wave sum: deterministic.
 // Columns c >= n1 go to out2[c - n1] (LayerNorm: dgamma and dbeta from one [blk][2][D] slab in one launch).
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int nparts, int64_t stride,
-                                                          float* __restrict__ out, float* __restrict__ out2, int n1,
-                                                          int n, int accumulate, float scale) {
-  __shared__ float red[4][64];
+constexpr int kSumWaves = 16;      // waves per block: the partial rows are dealt to them (a 1024-row slab is 64 rows per wave)
+__global__ __launch_bounds__(kSumWaves * 64) void sum_partials_kernel(const float* __restrict__ part, int nparts, int64_t stride,
+                                                                      float* __restrict__ out, float* __restrict__ out2, int n1,
+                                                                      int n, int accumulate, float scale) {
+  __shared__ float red[kSumWaves][64];
   const int cx = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < n) {
     const float* p = part + c;
     int q = w;
-    for (; q + 12 < nparts; q += 16) {
+    for (; q + 3 * kSumWaves < nparts; q += 4 * kSumWaves) {
       s0 += p[(int64_t)q * stride];
-      s1 += p[(int64_t)(q + 4) * stride];
-      s2 += p[(int64_t)(q + 8) * stride];
-      s3 += p[(int64_t)(q + 12) * stride];
+      s1 += p[(int64_t)(q + kSumWaves) * stride];
+      s2 += p[(int64_t)(q + 2 * kSumWaves) * stride];
+      s3 += p[(int64_t)(q + 3 * kSumWaves) * stride];
     }
-    for (; q < nparts; q += 4) s0 += p[(int64_t)q * stride];
+    for (; q < nparts; q += kSumWaves) s0 += p[(int64_t)q * stride];
   }
   red[w][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (w == 0 && c < n) {
-    const float s = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) * scale;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kSumWaves; ++j) s += red[j][cx];      // fixed order: deterministic
+    s *= scale;
     float* o = c < n1 ? out + c : out2 + (c - n1);
     *o = accumulate ? *o + s : s;
   }
@@ -284,7 +288,7 @@ extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x
   int rc = tavsr_layernorm_bwd_partial(dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx, lddx, ws, 2 * (int64_t)D, M, D,
                                        stream);
   if (rc || M <= 0) return rc;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, (hipStream_t)stream, ws, ln_blocks(M),
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(kSumWaves * 64), 0, (hipStream_t)stream, ws, ln_blocks(M),
                      (int64_t)2 * D, dgamma, dbeta, D, 2 * D, accumulate, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
@@ -301,7 +305,7 @@ extern "C" int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, f
   const int rpc = M > 0 ? cdiv(M, chunks) : 1;
   hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, s, x, ldx, M, N, rpc, ws);
   TAVSR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, ws, chunks, (int64_t)N, out, out, N, N,
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 64)), dim3(kSumWaves * 64), 0, s, ws, chunks, (int64_t)N, out, out, N, N,
                      accumulate, scale);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
@@ -316,7 +320,7 @@ extern "C" int tavsr_add2_colsum(const float* x, int64_t ldx, const float* y, in
   const int rpc = cdiv(M, chunks);
   hipLaunchKernelGGL(add2_colsum_part_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, s, x, ldx, y, ldy, out, ldo, M, N, rpc, ws);
   TAVSR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * N, 64)), dim3(256), 0, s, ws, chunks, (int64_t)2 * N, sum_x, sum_y, N,
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * N, 64)), dim3(kSumWaves * 64), 0, s, ws, chunks, (int64_t)2 * N, sum_x, sum_y, N,
                      2 * N, 0, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
@@ -327,7 +331,7 @@ extern "C" int tavsr_sum_partials(const float* part, int32_t nparts, int64_t str
                                   int32_t accumulate, tavsr_stream_t stream) {
   TAVSR_REQUIRE(part && out, TAVSR_EINVAL, "sum_partials: null pointer");
   if (n <= 0) return TAVSR_OK;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, part, nparts, stride,
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 64)), dim3(kSumWaves * 64), 0, (hipStream_t)stream, part, nparts, stride,
                      out, out, n, n, accumulate, 1.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;

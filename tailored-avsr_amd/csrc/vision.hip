@@ -481,6 +481,17 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restri
   const int64_t n = i / ((int64_t)C * P);
   dx[i] = dy[n * C + c] / (float)P;
 }
+// C % 4 == 0: one thread per (frame, 4 channels) writes its P rows (16-byte stores, no 64-bit divisions per element)
+__global__ void avgpool_bwd_vec_kernel(const float* __restrict__ dy, float* __restrict__ dx, int P, int C4, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = (int)(i % C4);
+  const int64_t n = i / C4;
+  float4 v = reinterpret_cast<const float4*>(dy)[i];
+  v = make_float4(v.x / (float)P, v.y / (float)P, v.z / (float)P, v.w / (float)P);      // the division of the scalar kernel
+  float4* o = reinterpret_cast<float4*>(dx) + n * P * C4 + c4;
+  for (int p = 0; p < P; ++p) o[(int64_t)p * C4] = v;
+}
 
 __global__ void rsqrt_eps_kernel(const float* __restrict__ v, float eps, float* __restrict__ out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,7 +713,10 @@ extern "C" int tavsr_avgpool_bwd(const float* dy, float* dx, int64_t N, int32_t 
   TAVSR_REQUIRE(dy && dx, TAVSR_EINVAL, "avgpool_bwd: null pointer");
   const int64_t total = N * P * C;
   if (total <= 0) return TAVSR_OK;
-  hipLaunchKernelGGL(avgpool_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, dy, dx, P, C, total);
+  if (C % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
+    hipLaunchKernelGGL(avgpool_bwd_vec_kernel, grid1d(N * (C / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, P, C / 4, N * (C / 4));
+  else
+    hipLaunchKernelGGL(avgpool_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, dy, dx, P, C, total);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
