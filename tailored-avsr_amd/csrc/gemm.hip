@@ -1136,6 +1136,13 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
     GemmArgs a6{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve, zmap};
     const dim3 grid6(a6.tiles_m * a6.tiles_n, 1, nsplit);
     static const int st3 = [] { const char* e = getenv("TAVSR_STEM_STAGES"); return e ? atoi(e) : 2; }();   // tuning aid
+    static const int tile128 = [] { const char* e = getenv("TAVSR_STEM_TILE"); return e ? atoi(e) == 128 : 0; }();   // tuning aid
+    if (d.conv_mode == 6 && tile128) {
+      GemmArgs a7{d, kchunk, nsplit, cdiv(d.M, 128), cdiv(d.N, 64), ve, 0};
+      hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, 3, false, false, 1, 6>), dim3(a7.tiles_m * a7.tiles_n, 1, 1), dim3(256), 0, s, a7);
+      TAVSR_LAUNCH_CHECK();
+      return TAVSR_OK;
+    }
     if (d.conv_mode == 6 && st3 == 3)
       hipLaunchKernelGGL((gemm_glds_kernel<64, 64, 2, 2, 3, 3, false, false, 1, 6>), grid6, dim3(256), 0, s, a6);
     else if (d.conv_mode == 6)
