@@ -49,7 +49,7 @@ def hbm_traffic(layout_key):
     """HBM bytes per launch of the dominant GEMM family, from the committed rocprofv3 PMC pass over this same step
     (scripts/gpu_pmc_hbm.sh -> profiles/summarize_pmc.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes).  PMC
     counters cannot be read from inside the process, so this is the profile's number, or None if it is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_av_v3.json" if WORKLOAD == "avsr" else "r02_pmc_hbm_asr_v3.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_av_v4.json" if WORKLOAD == "avsr" else "r02_pmc_hbm_asr_v4.json")
     if not os.path.exists(path):
         return None
     ak, bkm = {"NT": ("false", "false"), "NN": ("false", "true"), "TN": ("true", "true"), "TT": ("true", "false")}[layout_key[-3:-1]]
