@@ -77,7 +77,8 @@ typedef struct tavsr_gemm_desc {
      conv_stride s (0 = 1) and conv_taps (0 = 9, or 1): the strided 3x3 / pad 1 and 1x1 / pad 0 convolutions of the blocks
      that halve the maps (resnet.py:68-87 downsample, :95-97 conv1).  conv_H x conv_W is always the INPUT image; the rows
      of the patch operand are the OUTPUT pixels (n, ho, wo), Ho = (H-1)/s + 1, centred on input pixel (s*ho, s*wo);
-     K (mode 1) / N (mode 2) = taps * C.
+     K (mode 1) / N (mode 2) = taps * C.  conv_taps = 90: the 3x3 window WITHOUT padding (espnet Conv2dSubsampling's second
+     convolution, subsampling.py: Conv2d(odim, odim, 3, 2)): Ho = (H-3)/s + 1, output pixel centred on (s*ho + 1, s*wo + 1).
      Conv3d stem of the lip front-end (src/frontend/conv3d_resnet18/conv3d_resnet18.py:48-57: 1 -> Cout channels, kernel
      (5,7,7), stride (1,2,2), padding (2,3,3), no bias) over clips X [clips][conv_C frames][conv_H][conv_W] (even H, W), the
      245 taps padded to 256, every element gathered by the loader - no patch matrix:

@@ -672,14 +672,17 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
   uint32_t cmask[LA::NR];               // CONV 1: bit tap = the tap's neighbour of this thread's row is inside the image
   const int cs = d.conv_stride > 1 ? d.conv_stride : 1;         // CONV: stride; 9 taps (3x3, pad 1) or 1 (1x1, pad 0)
   const bool c9 = d.conv_taps != 1;
-  const int cHo = CONV ? (d.conv_H - 1) / cs + 1 : 1, cWo = CONV ? (d.conv_W - 1) / cs + 1 : 1;
+  // conv_taps 90: the 3x3 window without padding (espnet Conv2dSubsampling's second convolution): output pixel (ho, wo) is
+  // centred on input pixel (cs*ho + 1, cs*wo + 1) and every tap is inside the image
+  const int cp0 = (CONV == 1 || CONV == 2) && d.conv_taps == 90 ? 1 : 0;
+  const int cHo = CONV ? (d.conv_H - 1 - 2 * cp0) / cs + 1 : 1, cWo = CONV ? (d.conv_W - 1 - 2 * cp0) / cs + 1 : 1;
   if (CONV == 1) {
 #pragma unroll
     for (int i = 0; i < LA::NR; ++i) {
       const int m = min(m0 + ((i * NT + tid) >> 3), d.M - 1);
       // row m = output pixel (n, ho, wo), centred on input pixel (cs*ho, cs*wo)
-      const int x = (m % cWo) * cs, y = ((m / cWo) % cHo) * cs;
-      if (cs > 1) offA[i] += ((int64_t)((m / (cWo * cHo)) * d.conv_H + y) * d.conv_W + x - m) * d.conv_C;
+      const int x = (m % cWo) * cs + cp0, y = ((m / cWo) % cHo) * cs + cp0;
+      if (cs > 1 || cp0) offA[i] += ((int64_t)((m / (cWo * cHo)) * d.conv_H + y) * d.conv_W + x - m) * d.conv_C;
       uint32_t mk = 0;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap)
@@ -873,9 +876,9 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       for (int i = 0; i < LB::NR; ++i) {
         const int q = i * NT + tid;
         const int m = kbeg + kt * BK + q / (BN / 4), r = (q % (BN / 4)) * 4;
-        const int x = (m % cWo) * cs, y = ((m / cWo) % cHo) * cs;
+        const int x = (m % cWo) * cs + cp0, y = ((m / cWo) % cHo) * cs + cp0;
         const bool ok = (unsigned)(y + dy) < (unsigned)d.conv_H && (unsigned)(x + dx) < (unsigned)d.conv_W;
-        const int64_t pix = cs > 1 ? (int64_t)((m / (cWo * cHo)) * d.conv_H + y) * d.conv_W + x : m;
+        const int64_t pix = (cs > 1 || cp0) ? (int64_t)((m / (cWo * cHo)) * d.conv_H + y) * d.conv_W + x : m;
         const float* src = ok ? B + (pix + dy * d.conv_W + dx) * d.conv_C + cb + r : d.conv_zero;
         __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + ASZ + (i * NT + wave * 64) * 4), 16, 0, 0);
       }
@@ -1369,9 +1372,12 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
       return launch_conv(d, p4.nsplit, p4.kchunk, s);
     }
     const int cs = d.conv_stride > 1 ? d.conv_stride : 1, taps = d.conv_taps == 1 ? 1 : 9;
-    TAVSR_REQUIRE(d.conv_taps == 0 || d.conv_taps == 1 || d.conv_taps == 9, TAVSR_EINVAL, "tavsr_gemm: conv_taps must be 1 or 9");
+    TAVSR_REQUIRE(d.conv_taps == 0 || d.conv_taps == 1 || d.conv_taps == 9 || d.conv_taps == 90, TAVSR_EINVAL,
+                  "tavsr_gemm: conv_taps must be 1, 9 or 90 (3x3 without padding)");
+    const int p0 = d.conv_taps == 90 ? 1 : 0;
+    TAVSR_REQUIRE(!p0 || (d.conv_H >= 3 && d.conv_W >= 3), TAVSR_EINVAL, "tavsr_gemm: an unpadded 3x3 window needs a 3x3 image");
     const int64_t pixels = d.conv_mode == 1 ? d.M : d.K;       // output pixels
-    const int64_t per_image = (int64_t)((d.conv_H - 1) / cs + 1) * ((d.conv_W - 1) / cs + 1);
+    const int64_t per_image = (int64_t)((d.conv_H - 1 - 2 * p0) / cs + 1) * ((d.conv_W - 1 - 2 * p0) / cs + 1);
     TAVSR_REQUIRE(pixels % per_image == 0, TAVSR_EINVAL, "tavsr_gemm: conv rows are not whole images");
     if (d.conv_mode == 1)
       TAVSR_REQUIRE(!d.a_kmajor && d.K == taps * d.conv_C && d.conv_C % 32 == 0 && d.lda == d.conv_C, TAVSR_EUNSUPPORTED,

@@ -13,6 +13,7 @@ Reference semantics followed are cited per Function.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -577,20 +578,29 @@ class LinearFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # Conv2dSubsampling (espnet subsampling.py; encoder.py:149-155,364): conv-relu-conv-relu-linear, x sqrt(d)
 # ------------------------------------------------------------------------------------------------
+CONV2_IMPLICIT = os.environ.get("TAVSR_CONV2_IMPLICIT", "1") == "1"      # Conv2dSubsampling's second convolution without im2col
+
+
 class Conv2dSubsamplingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, wo, bo, xscale):
         B, T, F = x.shape
         Cn = w1.shape[0]
         y1 = ops.conv1_fwd(x.contiguous(), w1.reshape(Cn, 9), b1)              # [B,T1,F1,C] NHWC, relu
-        col, T2, F2 = ops.im2col3x3s2(y1)                                      # [B*T2*F2, 9C]
-        # torch (co, ci, kh, kw) -> (co, kh, kw, ci) to match the channels-last im2col
+        # torch (co, ci, kh, kw) -> (co, kh, kw, ci) to match the channels-last patch order
         w2r = ops.transpose_inner(w2, Cn, Cn, 9).view(Cn, 9 * Cn)
-        y2 = ops.linear(col, w2r, b2, act="relu")                              # [B*T2*F2, C] == (b,t,f,c)
+        T1, F1 = y1.shape[1], y1.shape[2]
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        if CONV2_IMPLICIT and Cn % 64 == 0 and (B * T2 * F2) % 32 == 0:        # image rows as the GEMM operand: no patch matrix
+            col = None
+            y2 = ops.conv3x3_fwd(y1.view(B * T1 * F1, Cn), w2r, T1, F1, stride=2, pad0=True, bias=b2, act="relu")
+        else:
+            col, T2, F2 = ops.im2col3x3s2(y1)                                  # [B*T2*F2, 9C]
+            y2 = ops.linear(col, w2r, b2, act="relu")                          # [B*T2*F2, C] == (b,t,f,c)
         # out Linear consumes (c*F2 + f); re-index its weight to (f*C + c) instead of transposing activations
         wor = ops.transpose_inner(wo, wo.shape[0], Cn, F2).view(wo.shape[0], F2 * Cn)
         out = ops.linear(y2.view(B * T2, F2 * Cn), wor, bo, alpha=xscale)
-        ctx.save_for_backward(x, y1, col, y2, w2r, wor)
+        ctx.save_for_backward(x, y1, col, y2, w2r, wor)      # col is None on the implicit route
         ctx.dims = (B, T, F, Cn, T2, F2, xscale, w1.shape, w2.shape, wo.shape)
         return out.view(B, T2, -1)
 
@@ -603,7 +613,10 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         gwor, gbo = ops.linear_dw(do, y2f, alpha=xscale, bias_grad=True)        # [odim, F2*C], [odim]
         # dz2 = (do @ wor) * xscale * relu'(y2)
         dz2 = ops.linear_dx(do, wor, alpha=xscale, DZ=y2f, dact="relu").view(B * T2 * F2, Cn)
-        gw2r, gb2 = ops.linear_dw(dz2, col, bias_grad=True)                     # [C, 9C], [C]
+        if col is None:
+            gw2r, gb2 = ops.conv3x3_dw(dz2, y1.view(-1, Cn), y1.shape[1], y1.shape[2], stride=2, pad0=True, bias_grad=True)
+        else:
+            gw2r, gb2 = ops.linear_dw(dz2, col, bias_grad=True)                 # [C, 9C], [C]
         dcol = ops.linear_dx(dz2, w2r)                                          # [B*T2*F2, 9C]
         dz1 = ops.col2im3x3s2_relu(dcol, y1)
         gw1, gb1 = ops.conv1_bwd(dz1, x.contiguous(), Cn)

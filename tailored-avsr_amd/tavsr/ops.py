@@ -1115,15 +1115,19 @@ def conv_wflip(w2d, cout, cin):
     return out
 
 
-def conv3x3_fwd(x, w2d, H, W, stride=1, taps=9):
+def conv3x3_fwd(x, w2d, H, W, stride=1, taps=9, pad0=False, bias=None, act=None):
     """implicit 3x3/p1 (taps 9) or 1x1/p0 (taps 1) convolution with stride: x [images*H*W, Cin] channels-last image rows,
-    w2d [Cout, taps*Cin] -> [images*Ho*Wo, Cout]."""
+    w2d [Cout, taps*Cin] -> [images*Ho*Wo, Cout].  ``pad0``: the 3x3 window without padding (Conv2dSubsampling)."""
     M, cin = x.shape
     cout = w2d.shape[0]
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if pad0:
+        assert taps == 9
+        Ho, Wo = (H - 3) // stride + 1, (W - 3) // stride + 1
+    else:
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     Mo = M // (H * W) * Ho * Wo
     z = empty(Mo, cout, like=x)
-    gemm(Mo, cout, taps * cin, x, cin, w2d, taps * cin, z, cout, conv=(1, H, W, cin, stride, taps))
+    gemm(Mo, cout, taps * cin, x, cin, w2d, taps * cin, z, cout, conv=(1, H, W, cin, stride, 90 if pad0 else taps), bias=bias, act=act)
     return z
 
 
@@ -1137,13 +1141,16 @@ def conv3x3_dx(dz, wflip, H, W, res=None):
     return dx
 
 
-def conv3x3_dw(dz, x, H, W, stride=1, taps=9):
-    """weight gradient: dz [output pixels, Cout], x [images*H*W, Cin] -> [Cout, taps*Cin]; needs output pixels % 32 == 0."""
+def conv3x3_dw(dz, x, H, W, stride=1, taps=9, pad0=False, bias_grad=False):
+    """weight gradient: dz [output pixels, Cout], x [images*H*W, Cin] -> [Cout, taps*Cin]; needs output pixels % 32 == 0.
+    ``bias_grad``: also the column sums of dz (the bias gradient) from the same launch."""
     M, cout = dz.shape
     cin = x.shape[1]
     dw = empty(cout, taps * cin, like=dz)
-    gemm(cout, taps * cin, M, dz, cout, x, cin, dw, taps * cin, a_kmajor=True, b_kmajor=True, conv=(2, H, W, cin, stride, taps))
-    return dw
+    gb = empty(cout, like=dz) if bias_grad else None
+    gemm(cout, taps * cin, M, dz, cout, x, cin, dw, taps * cin, a_kmajor=True, b_kmajor=True,
+         conv=(2, H, W, cin, stride, 90 if pad0 else taps), a_rowsum=gb)
+    return (dw, gb) if bias_grad else dw
 
 
 def fill_(t, value):

@@ -324,3 +324,27 @@ def test_multi_add_sums_lists_of_tensors_in_place():
     out = ops.multi_add_(dst, src)
     for o, d, w in zip(out, dst, want):
         assert o.data_ptr() == d.data_ptr() and torch.equal(d, w)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(4, 33, 19, 64), (2, 199, 39, 256)])
+def test_unpadded_strided_3x3_implicit_conv(B, H, W, C):
+    """conv_taps 90 of the implicit-GEMM loader (3x3 window, stride 2, NO padding: espnet Conv2dSubsampling's second
+    convolution) vs torch conv2d in fp64: forward with bias + ReLU, weight and bias gradient."""
+    from tavsr import ops
+    g = torch.Generator(device="cuda").manual_seed(H)
+    x = torch.randn(B, H, W, C, device="cuda", generator=g)
+    w = torch.randn(C, C, 3, 3, device="cuda", generator=g) / (3 * C ** 0.5)
+    b = torch.randn(C, device="cuda", generator=g)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    w2d = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()                 # (co, kh, kw, ci)
+    y = ops.conv3x3_fwd(x.view(-1, C), w2d, H, W, stride=2, pad0=True, bias=b, act="relu")
+    ref = torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=2))
+    _close(y.view(B, Ho, Wo, C), ref.permute(0, 2, 3, 1), 2e-6)
+    if (B * Ho * Wo) % 32 == 0:
+        dz = torch.randn(B * Ho * Wo, C, device="cuda", generator=g)
+        gw, gb = ops.conv3x3_dw(dz, x.view(-1, C), H, W, stride=2, pad0=True, bias_grad=True)
+        wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+        torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wr, br, stride=2).backward(
+            dz.double().view(B, Ho, Wo, C).permute(0, 3, 1, 2))
+        _close(gw.view(C, 3, 3, C), wr.grad.permute(0, 2, 3, 1), 1e-5)
+        _close(gb, br.grad, 1e-5)
