@@ -263,10 +263,28 @@ def main():
     ap.add_argument("--no-eager", action="store_true", help="skip the eager (no-graph) timing beside the graph number")
     ap.add_argument("--workload", choices=("asr", "avsr"), default="avsr",
                     help="asr: BASELINE configs[1] (headline); avsr: configs[2] tailored AV-Branchformer incl. the visual frontend")
+    ap.add_argument("--sustain-s", type=float, default=12.0,
+                    help="after the timed steps keep stepping for this many seconds more and report that rate as `sustained` "
+                         "(clocks settle within a few seconds of MFMA-dense load); 0 = off")
     args = ap.parse_args()
     global WORKLOAD, DROPOUT
     WORKLOAD = args.workload
     DROPOUT = not args.no_dropout
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under torch.distributed.run) as a
+        # CHILD process - nothing in this process has touched the GPU yet (no HIP call, the tavsr library is not loaded) - and
+        # leave with its exit code; rank 0's JSON line reaches our stdout through the inherited descriptor.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     from tavsr import dp, ops
 
@@ -323,6 +341,7 @@ def main():
         if graph is not None:
             graph.replay()
         else:
+            buckets.begin_step()       # the hooks enqueue buckets under the backward pass
             fwd_bwd()
         buckets.allreduce_mean()
 
@@ -331,6 +350,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t)
+        return x
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -338,11 +364,39 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    sustained = None
+    if args.sustain_s > 0:
+        # the same step, replayed for >= --sustain-s seconds more: the rate the chip holds once its clocks have settled
+        n_sus = max(args.steps, int(args.sustain_s / (elapsed / args.steps)) + 1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        barrier()
+        el_s = max_over_ranks(time.perf_counter() - t0)
+        sustained = {"value": round(B_PER_GPU * world * n_sus / el_s, 2), "unit": "utterances/s", "steps": n_sus,
+                     "ms_per_step": round(1e3 * el_s / n_sus, 3), "seconds": round(el_s, 2),
+                     "note": "same step, run back to back right after the timed region"}
+    exposed_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
+        # stream time of the exchange that nothing hides (pack + all-reduce + unpack behind the last gradient): a few steps
+        # with one event pair each, outside the timed region
+        pairs = []
+        for _ in range(5):
+            if graph is not None:
+                graph.replay()
+            else:
+                buckets.begin_step()
+                fwd_bwd()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            buckets.allreduce_mean()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        exposed_ms = max_over_ranks(sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2])
 
     utts = B_PER_GPU * world * args.steps
     value = utts / elapsed
@@ -369,24 +423,29 @@ def main():
         "frac_of_fp32_mfma_peak_whole_step": round(value * GFLOP_PER_UTT_STEP[WORKLOAD] / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
         "gflop_per_utt_step": round(GFLOP_PER_UTT_STEP[WORKLOAD], 2),
     }
+    if sustained is not None:
+        out["sustained"] = sustained
+    if exposed_ms is not None:
+        out["grad_exchange_exposed_ms_per_step"] = round(exposed_ms, 3)
 
     if graph is not None and not args.no_eager:
         # the same step as eager launches (what a ragged, un-captured training loop pays): reported beside the graph number
         n_eager = max(3, args.steps // 4)
         buckets.overlap = True
-        for _ in range(2):
+
+        def eager_step():
+            buckets.begin_step()
             fwd_bwd()
+            buckets.allreduce_mean()
+
+        for _ in range(2):
+            eager_step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(n_eager):
-            fwd_bwd()
-            buckets.allreduce_mean()
+            eager_step()
         barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            el = float(t)
+        el = max_over_ranks(time.perf_counter() - t0)
         out["eager"] = {"value": round(B_PER_GPU * world * n_eager / el, 2), "unit": "utterances/s",
                         "ms_per_step": round(1e3 * el / n_eager, 3), "steps": n_eager}
 

@@ -60,6 +60,6 @@ class TransformerDecoder(torch.nn.Module):
         cfg = dict(heads=self.heads, num_blocks=self.num_blocks)
         if self.training:    # (dropout_rate, positional, self-attention, source-attention) of the espnet2 decoder
             cfg.update(p=self._rates[0], p_pos=self._rates[1], p_self=self._rates[2], p_src=self._rates[3])
-        logits = F_.TransformerDecoderFn.apply(hs_pad, hlens.to(torch.int64), ys_in_pad.to(torch.int64),
+        logits = F_.grad_apply(F_.TransformerDecoderFn, hs_pad, hlens.to(torch.int64), ys_in_pad.to(torch.int64),
                                                ys_in_lens.to(torch.int64), pe, cfg, *self._params())
         return logits, ys_in_lens

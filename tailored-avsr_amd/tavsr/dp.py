@@ -25,12 +25,23 @@ def _rccl_init(rank: int, world: int, device: torch.device) -> bool:
     """communicator of the C ABI: rank 0 draws the id, torch.distributed ships it, every rank joins."""
     from ._lib import check, lib
     ident = torch.zeros(128, dtype=torch.uint8, device=device)
+    err = None
     if rank == 0:
-        buf = (C.c_char * 128)()
-        check(lib().tavsr_dp_unique_id(buf), "tavsr_dp_unique_id")
-        ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        # rank 0 ALWAYS takes part in the broadcast below: an all-zero id is the failure marker (RCCL ids are never all zero),
+        # so a rank 0 that cannot draw an id does not leave the others blocked in the collective
+        try:
+            buf = (C.c_char * 128)()
+            check(lib().tavsr_dp_unique_id(buf), "tavsr_dp_unique_id")
+            ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        except Exception as e:          # librccl absent, symbol missing, stale libtavsr_hip.so
+            err = e
+            ident.zero_()
     dist.broadcast(ident, 0)
+    if err is not None:
+        raise err
     raw = bytes(ident.cpu().tolist())
+    if not any(raw):
+        raise RuntimeError("rank 0 could not create the RCCL communicator id")
     check(lib().tavsr_dp_init(rank, world, C.c_char_p(raw)), "tavsr_dp_init")
     return True
 
@@ -62,9 +73,13 @@ def init_from_env(backend: str | None = None, seed: int | None = 0) -> tuple[int
             except Exception as e:          # both are GPU paths; say which one runs
                 warnings.warn(f"tavsr_dp_init failed ({e}); gradients go through torch.distributed's RCCL instead")
                 RCCL_ABI = False
+            mine = RCCL_ABI
             flag = torch.tensor([int(RCCL_ABI)], device=f"cuda:{local}")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # all ranks or none
             RCCL_ABI = bool(int(flag))
+            if mine and not RCCL_ABI:                         # joined here but not everywhere: give the communicator back
+                from ._lib import lib
+                lib().tavsr_dp_destroy()
     if seed is not None:
         torch.manual_seed(int(seed) + rank)
         if torch.cuda.is_available():
@@ -104,7 +119,38 @@ class GradBuckets:
         self._comm = None
         self._works = [None] * len(self.buckets)
         self._pending = [len(b) for b in self.buckets]
+        self._next = 0            # buckets 0 .. _next-1 have been enqueued in this window (ALWAYS in index order)
+        self._armed = False       # a window is open: begin_step() has been called and allreduce_mean() has not yet
         self._hooked, self.overlap = False, True
+        # flat sizes do not depend on the gradients: [HIP layout (16-byte aligned slots), torch.cat layout]
+        self._numel_hip = [sum((p.numel() + 3) // 4 * 4 for p in b[:-1]) + b[-1].numel() for b in self.buckets]
+        self._numel_cat = [sum(p.numel() for p in b) for b in self.buckets]
+
+    def begin_step(self) -> None:
+        """Open a backward window: from here to ``allreduce_mean()`` the gradient hooks may enqueue buckets (overlap with
+        the backward pass).  Every rank must call it at the same point of the program.  A window issues EXACTLY one
+        collective per bucket, in index order, on every rank - that is the invariant that keeps ranks paired.  If the
+        previous window was never closed (an exception, a skipped step, a stray backward), it is completed here: the
+        buckets it did not issue are issued now with whatever the flat buffers hold, all results are dropped.  Without
+        ``begin_step`` the hooks stay idle and ``allreduce_mean`` issues everything itself (no overlap, same result)."""
+        if self._armed:
+            cuda = bool(self.params) and self.params[0].is_cuda
+            for i in range(self._next, len(self.buckets)):
+                if cuda:
+                    self._issue_flat(i, self._flatbuf_for(i))
+                else:
+                    self._flat[i] = torch.zeros(self._numel_cat[i])
+                    self._works[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True)
+            for i, w in enumerate(self._works):
+                if w is not None and w != "rccl":
+                    w.wait()
+                self._works[i] = None
+                self._flat[i] = None
+            if self._comm is not None and RCCL_ABI:
+                torch.cuda.current_stream().wait_stream(self._comm)
+        self._pending = [len(b) for b in self.buckets]
+        self._next = 0
+        self._armed = dist.is_initialized() and dist.get_world_size() > 1
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -136,13 +182,11 @@ class GradBuckets:
                 p.grad = torch.zeros_like(p)
         if self.params and self.params[0].is_cuda:
             return self._allreduce_mean_hip(world)
-        works = []
+        for i in range(self._next, len(self.buckets)):      # what the gradient hooks did not enqueue, in index order
+            self._launch_bucket_cpu(i)
+        self._next = len(self.buckets)
         for i, bucket in enumerate(self.buckets):
-            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-            self._flat[i] = flat
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for i, bucket in enumerate(self.buckets):
-            works[i].wait()
+            self._works[i].wait()
             flat = self._flat[i]
             flat.mul_(1.0 / world)
             off = 0
@@ -150,6 +194,16 @@ class GradBuckets:
                 p.grad.copy_(flat[off: off + p.numel()].view_as(p))
                 off += p.numel()
             self._flat[i] = None
+            self._works[i] = None
+        self._pending = [len(b) for b in self.buckets]
+        self._next = 0
+        self._armed = False
+
+    def _launch_bucket_cpu(self, i):
+        """torch path (gloo, CPU tensors): the same fixed issue order as the GPU path."""
+        flat = torch.cat([p.grad.reshape(-1) for p in self.buckets[i]])
+        self._flat[i] = flat
+        self._works[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def _tables(self, i, bucket):
         """device pointer / offset / size tables of bucket i; rebuilt only when a gradient tensor moved (under hipGraph
@@ -163,14 +217,18 @@ class GradBuckets:
         offs = [0]
         for n in sizes[:-1]:
             offs.append(offs[-1] + (n + 3) // 4 * 4)                # 16-byte aligned slots
-        total = offs[-1] + sizes[-1]
+        assert offs[-1] + sizes[-1] == self._numel_hip[i]
         assert all(p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in bucket)
         t = tuple(torch.tensor(v, dtype=torch.int64).to(dev) for v in (ptrs, offs, sizes))
-        flat = self._flatbuf.get(i)
-        if flat is None or flat.numel() != total:
-            flat = self._flatbuf[i] = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat = self._flatbuf_for(i)
         self._tab[i] = (ptrs,) + t + (flat, max(sizes))
         return t + (flat, max(sizes))
+
+    def _flatbuf_for(self, i):
+        flat = self._flatbuf.get(i)
+        if flat is None:
+            flat = self._flatbuf[i] = torch.zeros(self._numel_hip[i], dtype=torch.float32, device=self.buckets[i][0].device)
+        return flat
 
     # ---- GPU path: pack (one launch per bucket) -> all-reduce on the communication stream -> unpack * 1/world
     def _comm_stream(self):
@@ -185,6 +243,10 @@ class GradBuckets:
         bucket = self.buckets[i]
         ptrs, offs, sizes, flat, mx = self._tables(i, bucket)
         ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0, True, mx)
+        self._issue_flat(i, flat)
+
+    def _issue_flat(self, i, flat):
+        from ._lib import check, lib
         if RCCL_ABI:
             comm = self._comm_stream()
             comm.wait_stream(torch.cuda.current_stream())
@@ -196,9 +258,9 @@ class GradBuckets:
 
     def _allreduce_mean_hip(self, world):
         from . import ops
-        for i in range(len(self.buckets)):
-            if self._works[i] is None:          # not already enqueued by the gradient hooks
-                self._launch_bucket(i)
+        for i in range(self._next, len(self.buckets)):      # what the gradient hooks did not enqueue, in index order
+            self._launch_bucket(i)
+        self._next = len(self.buckets)
         if RCCL_ABI:
             torch.cuda.current_stream().wait_stream(self._comm_stream())
         for i, bucket in enumerate(self.buckets):
@@ -208,24 +270,34 @@ class GradBuckets:
             ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0 / world, False, mx)
             self._works[i] = None
         self._pending = [len(b) for b in self.buckets]
+        self._next = 0
+        self._armed = False
 
     # ---- overlap with the backward pass (eager loops): a bucket leaves as soon as its last gradient exists
     def attach_overlap_hooks(self) -> None:
-        """``p.grad`` must be None at the start of every backward pass (``optimizer.zero_grad()`` does that): each
-        parameter's hook then fires exactly once per pass.  Not for captured (hipGraph) steps - set ``overlap = False``
-        around a capture; ``allreduce_mean`` enqueues whatever the hooks did not."""
+        """The hooks work inside a window opened by ``begin_step()`` (``tavsr.train.training`` opens one before the last
+        micro-batch's backward pass).  ``p.grad`` must be None at the start of that backward pass (``optimizer.zero_grad()``
+        does that) or hold the earlier micro-batches' sums: each parameter's hook then fires once in it.  Not for captured
+        (hipGraph) steps - no window is opened around a capture; ``allreduce_mean`` enqueues whatever the hooks did not.
+
+        Issue order is FIXED: collectives are paired across ranks by the order in which they are enqueued on the communicator,
+        and ranks do not complete their buckets in the same order (every rank draws its own stochastic-depth / branch-drop
+        coins, so a rank may never produce some layer's gradients at all).  A hook therefore only marks its bucket complete;
+        bucket i is enqueued when buckets 0 .. i-1 have been (as torch DDP does), and ``allreduce_mean`` enqueues the rest
+        in index order - every rank issues 0, 1, 2, ... whatever its gradients looked like."""
         if self._hooked or not (dist.is_initialized() and dist.get_world_size() > 1):
             return
         self._hooked = True
         index = {id(p): i for i, b in enumerate(self.buckets) for p in b}
 
         def hook(p):
-            if not self.overlap or not p.is_cuda:
+            if not (self.overlap and self._armed):
                 return
             i = index[id(p)]
-            self._pending[i] -= 1
-            if self._pending[i] == 0 and self._works[i] is None:
-                self._launch_bucket(i)
+            self._pending[i] -= 1               # (a second backward pass inside one window drives this below 0: no launch)
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                (self._launch_bucket if p.is_cuda else self._launch_bucket_cpu)(self._next)
+                self._next += 1
 
         for b in self.buckets:
             for p in b:

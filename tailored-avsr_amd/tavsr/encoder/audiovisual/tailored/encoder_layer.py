@@ -9,6 +9,7 @@ from typing import Optional
 
 import torch
 
+from .... import functional as F_
 from .... import functional_av as FA
 from ....layers import LayerNorm
 
@@ -95,5 +96,5 @@ class TailoredEncoderLayer(torch.nn.Module):
         ns = len(FA.TS_SHARED)
         pa, pv = self._stream_params("acoustic", ua), self._stream_params("visual", uv)
         # one node for both streams: the video stream runs on the forked stream beside the audio stream
-        audio, video = FA.TailoredLayerFn.apply(audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, *pa, *pv[ns:])
+        audio, video = F_.grad_apply(FA.TailoredLayerFn, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, *pa, *pv[ns:])
         return (audio, apos), audio_masks, (video, vpos), video_masks

@@ -115,7 +115,7 @@ class MyBranchformerEncoderLayer(torch.nn.Module):
                    # probabilities: attention_dropout_rate); masks come from the device-resident generator (ops.dropout)
                    p=self.dropout_rate if self.training else 0.0,
                    p_att=(self.attn.dropout_rate if (self.training and self.attn is not None) else 0.0))
-        y = F_.BranchformerLayerFn.apply(x, pos_emb, lens, cfg, *self._params())
+        y = F_.grad_apply(F_.BranchformerLayerFn, x, pos_emb, lens, cfg, *self._params())
         w = cfg.get("_last_w")
         if dropped:
             self.weight_global, self.weight_local = 0.0, 1.0

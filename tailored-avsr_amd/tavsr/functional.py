@@ -25,11 +25,25 @@ EPS_ESPNET = 1e-12  # espnet LayerNorm eps
 # Does the node being run have a backward pass?  Set by every Function.forward from ctx.needs_input_grad: a forward under
 # no_grad / in eval mode does not write the [M, 2048] pre-activations of its feed-forward and cgMLP blocks (26 MB each).
 _NEED_BWD = [True]
+_GRAD_MODE = [True]
+
+
+def grad_apply(fn, *args):
+    """``fn.apply(*args)`` that also tells the node whether autograd is recording: ``ctx.needs_input_grad`` only mirrors the
+    inputs' ``requires_grad`` and ignores ``torch.no_grad()``, and inside ``Function.forward`` grad mode reads disabled."""
+    _GRAD_MODE[0] = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _GRAD_MODE[0] = True
 
 
 def _note_ctx(ctx):
+    """does this node get a backward pass?  (returned, and passed on explicitly by the callers)"""
     nig = getattr(ctx, "needs_input_grad", None)
-    _NEED_BWD[0] = True if nig is None else any(nig)
+    need = (True if nig is None else any(nig)) and _GRAD_MODE[0]
+    _NEED_BWD[0] = need
+    return need
 
 
 # ------------------------------------------------------------------------------------------------
@@ -60,11 +74,12 @@ class _FFN:
 
     @staticmethod
     def fwd(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, eps=EPS_ESPNET, p=0.0, save=True):
+        """``save``: keep what the backward needs (the [M, hidden] pre-activations); False for passes without one."""
         if ops.ffn_fusable(x, w1, act):      # LayerNorm + both GEMMs in one launch (csrc/ffn.hip) + one finishing launch
             y, (n, mean, rstd, z, h, t_in, t_out) = ops.ffn_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=p, save=save)
             return y, ("fused", x, mean, rstd, n, z, h, t_in, t_out)
         n, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, eps)
-        if _NEED_BWD[0]:
+        if save:
             h, z, t_in = ops.linear_drop(n, w1, b1, p, act=act, save_z=True)     # both dropouts ride in the GEMM epilogues
         else:
             (h, t_in), z = ops.linear_drop(n, w1, b1, p, act=act), None
@@ -235,7 +250,7 @@ class BranchformerLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos_emb, lens, cfg, *P):
-        _note_ctx(ctx)
+        need = _note_ctx(ctx)
         B, T, D = x.shape
         M = B * T
         H = cfg["heads"]
@@ -251,7 +266,7 @@ class BranchformerLayerFn(torch.autograd.Function):
 
         x1, sv["ffm"] = _FFN.fwd(x2d, p("norm_ff_macaron.weight"), p("norm_ff_macaron.bias"),
                                  p("feed_forward_macaron.w_1.weight"), p("feed_forward_macaron.w_1.bias"),
-                                 p("feed_forward_macaron.w_2.weight"), p("feed_forward_macaron.w_2.bias"), act, 0.5, p=pd)
+                                 p("feed_forward_macaron.w_2.weight"), p("feed_forward_macaron.w_2.bias"), act, 0.5, p=pd, save=need)
         two = has_attn and has_mlp
         cat = ops.empty(M, 2 * D, like=x) if merge == "concat" else None
         xa = xm = None
@@ -282,7 +297,7 @@ class BranchformerLayerFn(torch.autograd.Function):
                 sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
         if has_mlp:
             n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mlp.weight"), p("norm_mlp.bias"), EPS_ESPNET)
-            if _NEED_BWD[0]:
+            if need:
                 g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu",
                                   save_z=True)
             else:
@@ -332,7 +347,7 @@ class BranchformerLayerFn(torch.autograd.Function):
         sv["drop"] = (t_cat, t_m)
         x3, sv["ff"] = _FFN.fwd(x2, p("norm_ff.weight"), p("norm_ff.bias"), p("feed_forward.w_1.weight"),
                                 p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
-                                act, 0.5, p=pd)
+                                act, 0.5, p=pd, save=need)
         y, fmean, frstd = ops.layernorm_fwd(x3, p("norm_final.weight"), p("norm_final.bias"), EPS_ESPNET)
         sv["final"] = (x3, fmean, frstd)
         sv["x1"], sv["xa"], sv["xm"] = x1, xa, xm
@@ -682,7 +697,7 @@ class TransformerDecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, memory, hlens, ys_in, ys_lens, pe, cfg, *P):
-        _note_ctx(ctx)
+        need = _note_ctx(ctx)
         B, T, D = memory.shape
         L = ys_in.shape[1]
         H = cfg["heads"]
@@ -729,7 +744,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             # --- position-wise FFN (ReLU, scale 1)
             x, s["ff"] = _FFN.fwd(x2, p("norm3.weight"), p("norm3.bias"), p("feed_forward.w_1.weight"),
                                   p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
-                                  "relu", 1.0, p=pd)
+                                  "relu", 1.0, p=pd, save=need)
             saved.append(s)
         an_w, an_b, out_w, out_b = P[1 + nb * _NL: 1 + nb * _NL + 4]
         xn, mf, rf = ops.layernorm_fwd(x, an_w, an_b, EPS_ESPNET)

@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
-from .functional import EPS_ESPNET, _FFN, _AttnFused, _SelfAttnCore, _drop_, _drop_bwd, _drop_bwd_, _NEED_BWD, _note_ctx
+from .functional import EPS_ESPNET, _FFN, _AttnFused, _SelfAttnCore, _drop_, _drop_bwd, _drop_bwd_, _note_ctx
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch.nn.BatchNorm defaults (conv3d_resnet18.py:57, resnet.py:39,68,84)
 
@@ -319,11 +319,13 @@ class TailoredStreamFn(torch.autograd.Function):
         dk = D // H
         act, coeff = cfg["ffn_act"], cfg.get("coeff", 1.0)
         pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)      # dropout rates (0 in eval)
+        need = cfg.get("need_bwd", True)                       # set by TailoredLayerFn: does the node get a backward pass?
         x2d = x.contiguous().view(M, D)
         sv = {}
         x1, sv["ffm"] = _FFN.fwd(x2d, p["norm_ff_macaron.weight"], p["norm_ff_macaron.bias"],
                                  p["feed_forward_macaron.w_1.weight"], p["feed_forward_macaron.w_1.bias"],
-                                 p["feed_forward_macaron.w_2.weight"], p["feed_forward_macaron.w_2.bias"], act, 0.5, p=pd)
+                                 p["feed_forward_macaron.w_2.weight"], p["feed_forward_macaron.w_2.bias"], act, 0.5, p=pd,
+                                 save=need)
         if cfg["use_attn"]:
             n, mean, rstd = ops.layernorm_fwd(x1, p["norm_mha.weight"], p["norm_mha.bias"], EPS_ESPNET)
             qkv = ops.empty(M, 3 * D, like=x2d)
@@ -344,7 +346,7 @@ class TailoredStreamFn(torch.autograd.Function):
             sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
         else:
             n, mean, rstd = ops.layernorm_fwd(x1, p["norm_cgmlp.weight"], p["norm_cgmlp.bias"], EPS_ESPNET)
-            if _NEED_BWD[0]:
+            if need:
                 g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
             else:
                 g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu"), None
@@ -357,7 +359,8 @@ class TailoredStreamFn(torch.autograd.Function):
             x2, t_br = ops.linear_drop(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], pd, alpha=coeff, res=x1)
             sv["br"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
         x3, sv["ff"] = _FFN.fwd(x2, p["norm_ff.weight"], p["norm_ff.bias"], p["feed_forward.w_1.weight"],
-                                p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"], p["feed_forward.w_2.bias"], act, 0.5, p=pd)
+                                p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"], p["feed_forward.w_2.bias"], act, 0.5, p=pd,
+                                save=need)
         y, fmean, frstd = ops.layernorm_fwd(x3, p["norm_final.weight"], p["norm_final.bias"], EPS_ESPNET)
         sv["final"] = (x3, fmean, frstd)
         sv["x1"] = x1
@@ -442,7 +445,8 @@ class TailoredLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, *P):
         import types
-        _note_ctx(ctx)
+        need = _note_ctx(ctx)
+        cfg_a, cfg_v = dict(cfg_a, need_bwd=need), dict(cfg_v, need_bwd=need)
         na, nv = len(tailored_stream_param_names(cfg_a["use_attn"])), len(tailored_stream_param_names(cfg_v["use_attn"]))
         ns = len(TS_SHARED)
         Pa, Pv = P[:na], P[:ns] + P[na: na + nv - ns]

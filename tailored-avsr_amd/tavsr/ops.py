@@ -131,7 +131,12 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
     elif conv is not None:
         a_el, b_el = (a_el // 9, b_el) if conv[0] == 1 else (a_el, b_el // 9)
     c_el = M * N * (1 + (R is not None) + (Z is not None) + (DZ is not None))
-    PROFILE.records.append((key, 2.0 * M * N * K * nb, 4.0 * nb * (a_el + b_el + c_el), e0, e1))
+    fl = 2.0 * M * N * K * nb
+    if conv is not None and conv[0] in (6, 7):    # padded-clip stem: 245 taps are algorithmic, the 288-wide layout is not
+        fl = fl * 245.0 / 288.0
+    elif conv is not None and conv[0] in (4, 5):  # 4-byte-gather stem: 245 taps padded to 256
+        fl = fl * 245.0 / 256.0
+    PROFILE.records.append((key, fl, 4.0 * nb * (a_el + b_el + c_el), e0, e1))
 
 
 def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None, force=None):

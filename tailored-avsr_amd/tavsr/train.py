@@ -62,7 +62,12 @@ class FusedAdam:
         """torch.optim.Adam semantics incl. its treatment of missing gradients: a parameter whose ``grad`` is None is
         skipped (no moment decay, no update) and keeps its own step count for the bias correction.  Gradients are packed
         by multi-tensor launches (24 tensors each); the update is one launch per maximal run of neighbouring parameters
-        that have a gradient and the same step count - ONE launch in the usual case where every parameter has one."""
+        that have a gradient and the same step count - ONE launch in the usual case where every parameter has one.
+
+        Under data parallelism ``GradBuckets.allreduce_mean`` replaces a missing gradient by zeros before the exchange (a
+        layer skipped by stochastic depth on this rank may have run on another), so there every parameter is stepped every
+        time - moment decay, decoupled weight decay and step count included - exactly as torch DDP + torch.optim.Adam
+        behave; a single-process run skips such a parameter.  The shipped recipes set the skip rates to 0."""
         from . import ops
         g = self.param_groups[0]
         live = [i for i, p in enumerate(self.params) if p.grad is not None]
@@ -97,7 +102,13 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         self._step = sd["step"]
-        self._steps = list(sd.get("steps", [sd["step"]] * len(self.params)))
+        steps = list(sd.get("steps", [sd["step"]] * len(self.params)))
+        if len(steps) != len(self.params):
+            raise ValueError(f"optimizer state holds {len(steps)} per-parameter step counts, the optimizer has "
+                             f"{len(self.params)} parameters")
+        if sd["exp_avg"].numel() != self.exp_avg.numel():
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        self._steps = steps
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.param_groups[0].update(sd["param_groups"][0])
@@ -267,6 +278,8 @@ def training(e2e, train_loader, optimizer, scheduler, accum_grad, device="cuda",
         stepping = ((batch_idx + 1) % accum_grad == 0) or (batch_idx + 1 == n)
         if buckets is not None:             # gradients are exchanged once per optimizer step: the hooks launch buckets
             buckets.overlap = stepping      # only during the window's LAST micro-batch (every hook fires once in it)
+            if stepping:
+                buckets.begin_step()        # nothing of an earlier, unfinished window survives into this one
         loss.backward()
         if stepping:
             if buckets is not None:

@@ -45,6 +45,67 @@ def test_dp_allreduce_mean_world2():
         assert torch.allclose(ga, (la + lb) / 2, atol=1e-6)
 
 
+def _hook_order_worker(rank, world, port, ret):
+    """overlap hooks with DIFFERENT gradient sets per rank: rank 1 skips the middle layer (a stochastic-depth coin that fell
+    differently), so its bucket never completes there.  Collectives must still be issued 0, 1, 2, ... on every rank."""
+    sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
+    from tavsr import dp
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dp.init_from_env("gloo")
+    torch.manual_seed(5)
+    layers = [torch.nn.Linear(16, 16) for _ in range(4)]       # equal-sized buckets: a mis-paired collective would NOT hang,
+    params = [p for l in layers for p in l.parameters()]       # it would silently sum the wrong tensors
+    buckets = dp.GradBuckets(params, bucket_bytes=16 * 16 * 4)
+    assert len(buckets.buckets) == 4
+    buckets.attach_overlap_hooks()
+    issued = []
+    launch = buckets._launch_bucket_cpu
+    buckets._launch_bucket_cpu = lambda i: (issued.append(i), launch(i))[1]
+    torch.manual_seed(11 + rank)
+    x = torch.randn(3, 16)
+    outs = []
+    for step in range(3):
+        for p in params:
+            p.grad = None
+        h = x * (step + 1)
+        for j, l in enumerate(layers):
+            if not (rank == 1 and j == 2 and step != 1):       # rank 1 drops layer 2 in steps 0 and 2
+                h = l(h)
+        del issued[:]
+        buckets.begin_step()
+        h.square().sum().backward()
+        if step == 2:                                          # a window that is never closed by allreduce_mean ...
+            for p in params:
+                p.grad = None
+            h = x
+            for l in layers:
+                h = l(h)
+            buckets.begin_step()                               # ... then a new one: the stale one is completed and dropped
+            h.square().sum().backward()
+        local = [None if p.grad is None else p.grad.clone() for p in params]
+        buckets.allreduce_mean()
+        outs.append(dict(local=local, avg=[p.grad.clone() for p in params], issued=list(issued)))
+    ret[rank] = outs
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_overlap_hooks_issue_buckets_in_fixed_order_world2():
+    world, port = 2, 29761
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hook_order_worker, args=(world, port, ret), nprocs=world, join=True)
+    for step in range(3):
+        a, b = ret[0][step], ret[1][step]
+        assert a["issued"][-4:] == [0, 1, 2, 3] and b["issued"][-4:] == [0, 1, 2, 3], (a["issued"], b["issued"])
+        for ga, gb, la, lb in zip(a["avg"], b["avg"], a["local"], b["local"]):
+            la = torch.zeros_like(ga) if la is None else la
+            lb = torch.zeros_like(ga) if lb is None else lb
+            assert torch.equal(ga, gb)
+            assert torch.allclose(ga, (la + lb) / 2, atol=1e-6)
+
+
 def _gpu_worker(rank, world, port, ret):
     """two ranks sharing cuda:0 over gloo (RCCL needs one device per rank): exercises the HIP pack/unpack path."""
     sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
@@ -123,6 +184,7 @@ def _real_model_worker(rank, world, port, ret):
     buckets.attach_overlap_hooks()
     for p in model.parameters():
         p.grad = None
+    buckets.begin_step()
     model(**{k: v.cuda() for k, v in mine.items()})[0].backward()      # hooks enqueue the buckets during this backward
     buckets.allreduce_mean()
     torch.cuda.synchronize()
