@@ -244,6 +244,49 @@ int tavsr_ffn_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w1
                      int32_t M, int32_t D, int32_t N1, float p_drop, const uint64_t* seed_dev, uint64_t offset_in, float* dz,
                      float* dn, float* ws, tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Feed-forward block, streaming form (csrc/ffn2.hip) - the same espnet PositionwiseFeedForward residual block
+ * (src/encoder/branchformer/encoder_layer.py:191-194,311-314; src/encoder/audiovisual/tailored/encoder_layer.py:173-175,
+ * 211-213) for d_model 256, hidden N1 % 32 == 0, weights in torch Linear layout (w1 [N1][256], w2 [256][N1]):
+ *     y = res + scale * dropout(w2 dropout(act(w1 LN(x) + b1)) + b2)          (res NULL: res = x)
+ *     ln2_out[k] = LayerNorm(y) * ln2_w[k] + ln2_b[k], k = 0, 1 (optional)    - the norms the consumers of y start with
+ *                                                                               (encoder_layer.py:197,215 after the macaron
+ *                                                                               block, :316 norm_final after the second)
+ * Two launches: the chain kernel (LayerNorm prologue; unit of work 32 rows x 32 hidden units, the K = 256 contraction of
+ * the first product split over the four waves of a workgroup, partial tiles exchanged through LDS, second product into
+ * accumulators that live as long as the row tile; weights streamed by LDS-DMA through per-wave rings; the flat unit list cut
+ * into equal contiguous ranges, one per workgroup) and the finishing kernel (fixed-order sum of a row tile's partials, bias,
+ * dropout, scale, residual, the optional LayerNorms).
+ * Saved for a backward pass (all optional): n_out = LN(x) [M][256], mean / rstd [M], z / h = pre-activations and dropped
+ * activations, buffers of roundup32(M) rows x N1 (whole 32-row tiles are stored); ln2_mean / ln2_rstd [M].
+ * Dropout: both sites use the tavsr_dropout mapping (element e of the contiguous [M][N1] / [M][256] result = word e & 3 of
+ * Philox counter offset/4 + e/4), i.e. the masks the GEMM-epilogue path draws from the same offsets.
+ * ws: tavsr_ffn2_ws(M, 256, N1) floats.  Unsupported shapes: TAVSR_EUNSUPPORTED (callers keep the GEMM launches).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tavsr_ffn_desc {
+  int32_t M, D, N1, act;
+  float scale, eps;
+  const float* x;            /* [M][ldx] */
+  int64_t ldx;
+  const float* res;          /* residual rows [M][ldr]; NULL: x */
+  int64_t ldr;
+  const float *ln_w, *ln_b, *w1, *b1, *w2, *b2;
+  float* y;                  /* [M][256] */
+  float p_drop;
+  const uint64_t* seed;      /* device */
+  uint64_t offset_in, offset_out;
+  float *n_out, *mean, *rstd, *z, *h;
+  const float* ln2_w[2];
+  const float* ln2_b[2];
+  float* ln2_out[2];
+  float *ln2_mean, *ln2_rstd;
+  float ln2_eps;
+  float* ws;
+  int64_t ws_floats;
+} tavsr_ffn_desc;
+int64_t tavsr_ffn2_ws(int32_t M, int32_t D, int32_t N1);
+int tavsr_ffn2_fwd(const tavsr_ffn_desc* d, tavsr_stream_t stream);
+
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);
 int tavsr_axpby2d(const float* x, int64_t ldx, const float* y, int64_t ldy, float a, float b, float* out,

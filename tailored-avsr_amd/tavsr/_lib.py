@@ -60,6 +60,27 @@ class AttnDesc(C.Structure):
     ]
 
 
+class FfnDesc(C.Structure):
+    """tavsr_ffn_desc (include/tavsr.h)"""
+    _fields_ = [
+        ("M", C.c_int32), ("D", C.c_int32), ("N1", C.c_int32), ("act", C.c_int32),
+        ("scale", C.c_float), ("eps", C.c_float),
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("res", C.c_void_p), ("ldr", C.c_int64),
+        ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
+        ("b2", C.c_void_p),
+        ("y", C.c_void_p),
+        ("p_drop", C.c_float),
+        ("seed", C.c_void_p),
+        ("offset_in", C.c_uint64), ("offset_out", C.c_uint64),
+        ("n_out", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("z", C.c_void_p), ("h", C.c_void_p),
+        ("ln2_w", C.c_void_p * 2), ("ln2_b", C.c_void_p * 2), ("ln2_out", C.c_void_p * 2),
+        ("ln2_mean", C.c_void_p), ("ln2_rstd", C.c_void_p),
+        ("ln2_eps", C.c_float),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+    ]
+
+
 _lib = None
 
 

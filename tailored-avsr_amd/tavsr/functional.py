@@ -75,6 +75,10 @@ class _FFN:
     @staticmethod
     def fwd(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, eps=EPS_ESPNET, p=0.0, save=True):
         """``save``: keep what the backward needs (the [M, hidden] pre-activations); False for passes without one."""
+        if ops.ffn2_usable(x, w1, act):      # streaming chain kernel (csrc/ffn2.hip) + finishing launch; GEMM-path masks
+            y, (n, mean, rstd, z, h, t_in, t_out), _, _ = ops.ffn2_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=p,
+                                                                       save=save)
+            return y, (x, mean, rstd, n, z, h, t_in, t_out)
         if ops.ffn_fusable(x, w1, act):      # LayerNorm + both GEMMs in one launch (csrc/ffn.hip) + one finishing launch
             y, (n, mean, rstd, z, h, t_in, t_out) = ops.ffn_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=p, save=save)
             return y, ("fused", x, mean, rstd, n, z, h, t_in, t_out)
@@ -85,6 +89,22 @@ class _FFN:
             (h, t_in), z = ops.linear_drop(n, w1, b1, p, act=act), None
         y, t_out = ops.linear_drop(h, w2, b2, p, alpha=scale, res=x)             # x + scale * dropout(.)
         return y, (x, mean, rstd, n, z, h, t_in, t_out)
+
+    @staticmethod
+    def fwd_ln(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, norms, eps=EPS_ESPNET, p=0.0, save=True):
+        """``fwd`` plus the LayerNorms (espnet eps) the consumers of y start with: ``norms`` = [(gamma, beta), ...] (at most
+        two) -> (y, saved, [n_k], mean, rstd).  On the streaming path they ride in the finishing launch (one statistics
+        pass for all of them); otherwise they are the usual LayerNorm launches."""
+        if ops.ffn2_usable(x, w1, act):
+            y, (n, mean, rstd, z, h, t_in, t_out), outs, (m2, r2) = ops.ffn2_fwd(
+                x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=p, save=save, ln2=norms, ln2_eps=EPS_ESPNET, ln2_stats=save)
+            return y, (x, mean, rstd, n, z, h, t_in, t_out), outs, m2, r2
+        y, saved = _FFN.fwd(x, ln_w, ln_b, w1, b1, w2, b2, act, scale, eps=eps, p=p, save=save)
+        outs, m2, r2 = [], None, None
+        for g, b in norms:
+            o, m2, r2 = ops.layernorm_fwd(y, g, b, EPS_ESPNET)
+            outs.append(o)
+        return y, saved, outs, m2, r2
 
     @staticmethod
     def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None, lng=None):
@@ -264,16 +284,20 @@ class BranchformerLayerFn(torch.autograd.Function):
         x2d = x.reshape(M, D)
         sv = {}
 
-        x1, sv["ffm"] = _FFN.fwd(x2d, p("norm_ff_macaron.weight"), p("norm_ff_macaron.bias"),
-                                 p("feed_forward_macaron.w_1.weight"), p("feed_forward_macaron.w_1.bias"),
-                                 p("feed_forward_macaron.w_2.weight"), p("feed_forward_macaron.w_2.bias"), act, 0.5, p=pd, save=need)
+        # the macaron block's finishing launch also normalises its output for the two branches (one statistics pass)
+        br_norms = ([(p("norm_mha.weight"), p("norm_mha.bias"))] if has_attn else []) + \
+                   ([(p("norm_mlp.weight"), p("norm_mlp.bias"))] if has_mlp else [])
+        x1, sv["ffm"], nbr, bmean, brstd = _FFN.fwd_ln(x2d, p("norm_ff_macaron.weight"), p("norm_ff_macaron.bias"),
+                                                       p("feed_forward_macaron.w_1.weight"), p("feed_forward_macaron.w_1.bias"),
+                                                       p("feed_forward_macaron.w_2.weight"), p("feed_forward_macaron.w_2.bias"),
+                                                       act, 0.5, br_norms, p=pd, save=need)
         two = has_attn and has_mlp
         cat = ops.empty(M, 2 * D, like=x) if merge == "concat" else None
         xa = xm = None
         br = ops.BranchScope(two)     # attention branch beside the cgMLP branch (joined before the merge)
         with br:
             if has_attn:
-                n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mha.weight"), p("norm_mha.bias"), EPS_ESPNET)
+                n, mean, rstd = nbr[0], bmean, brstd
                 qkv = ops.empty(M, 3 * D, like=x)
                 ops.linear_group(n, [(p(f"attn.linear_{c}.weight"), p(f"attn.linear_{c}.bias"), j * D)
                                      for j, c in enumerate("qkv")], qkv)
@@ -296,7 +320,7 @@ class BranchformerLayerFn(torch.autograd.Function):
                     xa, t_xa = ops.linear_drop(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), pd)   # x1 = dropout(x_att)  (encoder_layer.py:212)
                 sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
         if has_mlp:
-            n, mean, rstd = ops.layernorm_fwd(x1, p("norm_mlp.weight"), p("norm_mlp.bias"), EPS_ESPNET)
+            n, mean, rstd = nbr[-1], bmean, brstd
             if need:
                 g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu",
                                   save_z=True)
@@ -345,10 +369,10 @@ class BranchformerLayerFn(torch.autograd.Function):
         else:                                               # x + coeff * dropout(merge_proj(.))  (:232-300)
             x2, t_m = ops.linear_drop(m, p("merge_proj.weight"), p("merge_proj.bias"), pd, alpha=coeff, res=x1)
         sv["drop"] = (t_cat, t_m)
-        x3, sv["ff"] = _FFN.fwd(x2, p("norm_ff.weight"), p("norm_ff.bias"), p("feed_forward.w_1.weight"),
-                                p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
-                                act, 0.5, p=pd, save=need)
-        y, fmean, frstd = ops.layernorm_fwd(x3, p("norm_final.weight"), p("norm_final.bias"), EPS_ESPNET)
+        x3, sv["ff"], (y,), fmean, frstd = _FFN.fwd_ln(x2, p("norm_ff.weight"), p("norm_ff.bias"), p("feed_forward.w_1.weight"),
+                                                       p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"),
+                                                       p("feed_forward.w_2.bias"), act, 0.5,
+                                                       [(p("norm_final.weight"), p("norm_final.bias"))], p=pd, save=need)
         sv["final"] = (x3, fmean, frstd)
         sv["x1"], sv["xa"], sv["xm"] = x1, xa, xm
         ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = sv, cfg, P, lens, pos_emb

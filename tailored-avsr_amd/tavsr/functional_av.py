@@ -322,12 +322,12 @@ class TailoredStreamFn(torch.autograd.Function):
         need = cfg.get("need_bwd", True)                       # set by TailoredLayerFn: does the node get a backward pass?
         x2d = x.contiguous().view(M, D)
         sv = {}
-        x1, sv["ffm"] = _FFN.fwd(x2d, p["norm_ff_macaron.weight"], p["norm_ff_macaron.bias"],
-                                 p["feed_forward_macaron.w_1.weight"], p["feed_forward_macaron.w_1.bias"],
-                                 p["feed_forward_macaron.w_2.weight"], p["feed_forward_macaron.w_2.bias"], act, 0.5, p=pd,
-                                 save=need)
+        bn = "norm_mha" if cfg["use_attn"] else "norm_cgmlp"     # the branch's LayerNorm rides in the macaron block's finishing launch
+        x1, sv["ffm"], (n,), mean, rstd = _FFN.fwd_ln(x2d, p["norm_ff_macaron.weight"], p["norm_ff_macaron.bias"],
+                                                      p["feed_forward_macaron.w_1.weight"], p["feed_forward_macaron.w_1.bias"],
+                                                      p["feed_forward_macaron.w_2.weight"], p["feed_forward_macaron.w_2.bias"],
+                                                      act, 0.5, [(p[bn + ".weight"], p[bn + ".bias"])], p=pd, save=need)
         if cfg["use_attn"]:
-            n, mean, rstd = ops.layernorm_fwd(x1, p["norm_mha.weight"], p["norm_mha.bias"], EPS_ESPNET)
             qkv = ops.empty(M, 3 * D, like=x2d)
             ops.linear_group(n, [(p[f"attn.linear_{c}.weight"], p[f"attn.linear_{c}.bias"], j * D) for j, c in enumerate("qkv")],
                              qkv)
@@ -345,7 +345,6 @@ class TailoredStreamFn(torch.autograd.Function):
             x2, t_br = ops.linear_drop(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], pd, alpha=coeff, res=x1)
             sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
         else:
-            n, mean, rstd = ops.layernorm_fwd(x1, p["norm_cgmlp.weight"], p["norm_cgmlp.bias"], EPS_ESPNET)
             if need:
                 g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
             else:
@@ -358,10 +357,10 @@ class TailoredStreamFn(torch.autograd.Function):
             # residual + coeff * dropout(cgmlp)  (encoder_layer.py:208,256)
             x2, t_br = ops.linear_drop(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], pd, alpha=coeff, res=x1)
             sv["br"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
-        x3, sv["ff"] = _FFN.fwd(x2, p["norm_ff.weight"], p["norm_ff.bias"], p["feed_forward.w_1.weight"],
-                                p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"], p["feed_forward.w_2.bias"], act, 0.5, p=pd,
-                                save=need)
-        y, fmean, frstd = ops.layernorm_fwd(x3, p["norm_final.weight"], p["norm_final.bias"], EPS_ESPNET)
+        x3, sv["ff"], (y,), fmean, frstd = _FFN.fwd_ln(x2, p["norm_ff.weight"], p["norm_ff.bias"], p["feed_forward.w_1.weight"],
+                                                       p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"],
+                                                       p["feed_forward.w_2.bias"], act, 0.5,
+                                                       [(p["norm_final.weight"], p["norm_final.bias"])], p=pd, save=need)
         sv["final"] = (x3, fmean, frstd)
         sv["x1"] = x1
         ctx.sv, ctx.cfg, ctx.p, ctx.names, ctx.pos_emb, ctx.shape, ctx.lens = sv, cfg, p, names, pos_emb, (B, T, D), lens

@@ -713,6 +713,62 @@ def ffn_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
     return dz, dn
 
 
+# Streaming feed-forward block (csrc/ffn2.hip, round 3): LayerNorm prologue + both GEMMs in one launch whose weights stream
+# through per-wave LDS-DMA rings, + a finishing launch that can also emit the LayerNorms the consumers of y start with.
+# TAVSR_FFN2=0 keeps the LayerNorm + GEMM + GEMM launches.
+FFN2 = os.environ.get("TAVSR_FFN2", "1") == "1"
+
+
+def ffn2_usable(x, w1, act) -> bool:
+    return (FFN2 and x.dim() == 2 and x.shape[1] == 256 and w1.shape[0] >= 1024 and w1.shape[0] % 32 == 0
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w1.is_contiguous()
+            and act in ("relu", "swish"))
+
+
+def ffn2_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=0.0, save=True, ln2=(), ln2_eps=1e-12, ln2_stats=False):
+    """y = x + scale * dropout(w2 dropout(act(w1 LN(x) + b1)) + b2) and, for every (gamma, beta) in ``ln2`` (at most two),
+    LayerNorm(y) * gamma + beta.  Returns (y, saved, ln2_outs, (ln2_mean, ln2_rstd)) with saved = (n, mean, rstd, z, h,
+    tok_in, tok_out) as the GEMM path keeps it (None entries when ``save`` is false): the dropout masks are the ones the GEMM
+    epilogues would draw, so the GEMM-based backward pairs with this forward."""
+    from ._lib import FfnDesc
+    M, D = x.shape
+    N1 = w1.shape[0]
+    require_cuda(x, ln_w, ln_b, w1, b1, w2, b2)
+    assert w1.is_contiguous() and w2.is_contiguous() and w1.shape == (N1, D) and w2.shape == (D, N1) and len(ln2) <= 2
+    d = FfnDesc()
+    d.M, d.D, d.N1, d.act, d.scale, d.eps = M, D, N1, ACT[act], scale, eps
+    d.x, d.ldx = x.data_ptr(), x.stride(0)
+    d.ln_w, d.ln_b, d.w1, d.b1, d.w2, d.b2 = (t.data_ptr() for t in (ln_w, ln_b, w1, b1, w2, b2))
+    y = empty(M, D, like=x)
+    d.y = y.data_ptr()
+    n = mean = rstd = z = h = None
+    if save:
+        n, mean, rstd = empty(M, D, like=x), empty(M, like=x), empty(M, like=x)
+        Mp = (M + 31) // 32 * 32          # whole 32-row tiles are stored
+        z, h = empty(Mp, N1, like=x)[:M], empty(Mp, N1, like=x)[:M]
+        d.n_out, d.mean, d.rstd, d.z, d.h = (t.data_ptr() for t in (n, mean, rstd, z, h))
+    tok_in = tok_out = None
+    if p and p > 0.0:
+        tok_in = _new_token(p, M * N1, x.device)
+        tok_out = _new_token(p, M * D, x.device)
+        d.p_drop, d.seed, d.offset_in, d.offset_out = p, tok_in[2].data_ptr(), tok_in[1], tok_out[1]
+    outs = []
+    for k, (g, b) in enumerate(ln2):
+        o = empty(M, D, like=x)
+        outs.append(o)
+        d.ln2_w[k], d.ln2_b[k], d.ln2_out[k] = g.data_ptr(), b.data_ptr(), o.data_ptr()
+    m2 = r2 = None
+    if ln2 and ln2_stats:
+        m2, r2 = empty(M, like=x), empty(M, like=x)
+        d.ln2_mean, d.ln2_rstd = m2.data_ptr(), r2.data_ptr()
+    d.ln2_eps = ln2_eps
+    nws = lib_i64("tavsr_ffn2_ws", M, D, N1)
+    ws = empty(nws, like=x)
+    d.ws, d.ws_floats = ws.data_ptr(), nws
+    check(lib().tavsr_ffn2_fwd(C.byref(d), stream()), "tavsr_ffn2_fwd")
+    return y, (n, mean, rstd, z, h, tok_in, tok_out), outs, (m2, r2)
+
+
 def axpby(x, y=None, a=1.0, b=1.0, out=None):
     if out is None:
         out = torch.empty_like(x)

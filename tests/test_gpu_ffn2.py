@@ -1,0 +1,147 @@
+"""GPU: the streaming feed-forward block (csrc/ffn2.hip: tavsr_ffn2_fwd through the C ABI) against a plain torch fp64
+restatement of espnet's LayerNorm(eps 1e-12) -> PositionwiseFeedForward -> scaled residual
+(src/encoder/branchformer/encoder_layer.py:191-194,311-316): outputs, the LayerNorms of the output it can emit, everything
+it saves for the backward pass, the dropout contract it shares with the GEMM-epilogue path, and every plan of the unit
+split (workgroup counts that cut row tiles in different places, both ring depths)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _act(name, z):
+    return z * torch.sigmoid(z) if name == "swish" else torch.relu(z)
+
+
+def _close(a, b, tol):
+    a, b = a.double(), b.double()
+    assert a.shape == b.shape
+    err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert err < tol, err
+
+
+def _params(D, N1, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    return (1 + 0.1 * r(D), 0.1 * r(D), r(N1, D) / D ** 0.5, 0.1 * r(N1), r(D, N1) / N1 ** 0.5, 0.1 * r(D))
+
+
+def _ref(x, ln_w, ln_b, w1, b1, w2, b2, act, scale):
+    xd = x.double()
+    nr = F.layer_norm(xd, (x.shape[1],), ln_w.double(), ln_b.double(), 1e-12)
+    zr = nr @ w1.double().t() + b1.double()
+    hr = _act(act, zr)
+    return xd, nr, zr, hr, xd + scale * (hr @ w2.double().t() + b2.double())
+
+
+@pytest.fixture(autouse=True)
+def _default_plan():
+    os.environ.pop("TAVSR_FFN2_CFG", None)
+    yield
+    os.environ.pop("TAVSR_FFN2_CFG", None)
+
+
+@pytest.mark.parametrize("M,N1,act,cfg", [
+    (3168, 2048, "swish", None),         # the encoder's shape (99 row tiles x 64 hidden tiles on 512 workgroups)
+    (3168, 2048, "swish", "256,3"),      # one workgroup per CU, three ring stages
+    (3168, 2048, "swish", "256,2"),
+    (3168, 2048, "swish", "333,2"),      # cuts that fall anywhere inside the row tiles
+    (6400, 2048, "swish", None),         # both modality streams of a tailored AV layer in one call
+    (1312, 2048, "relu", None),          # decoder block
+    (100, 2048, "swish", None),          # M % 32 != 0: the last row tile is padded
+    (32, 1024, "relu", None),            # one row tile, fewer units than workgroups
+    (77, 1056, "swish", "7,2"),          # 33 hidden tiles, ranges of up to 15 units that span row tiles
+])
+def test_ffn2_forward_matches_fp64(M, N1, act, cfg):
+    from tavsr import ops
+    if cfg:
+        os.environ["TAVSR_FFN2_CFG"] = cfg
+    D = 256
+    ln_w, ln_b, w1, b1, w2, b2 = _params(D, N1, seed=M)
+    g2, c2, g3, c3 = (_params(D, N1, seed=M + 7)[i] for i in (0, 1, 0, 1))
+    g3 = g3 * 0.5 + 0.3
+    x = torch.randn(M, D, device="cuda")
+    y, (n, mean, rstd, z, h, t_in, t_out), outs, (m2, r2) = ops.ffn2_fwd(
+        x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, act, 0.5, save=True, ln2=((g2, c2), (g3, c3)), ln2_stats=True)
+    assert t_in is None and t_out is None
+    xd, nr, zr, hr, yr = _ref(x, ln_w, ln_b, w1, b1, w2, b2, act, 0.5)
+    _close(n, nr, 2e-6)
+    _close(mean, xd.mean(1), 2e-6)
+    _close(rstd, 1 / torch.sqrt(xd.var(1, unbiased=False) + 1e-12), 2e-6)
+    _close(z, zr, 5e-6)
+    _close(h, hr, 5e-6)
+    _close(y, yr, 5e-6)
+    _close(outs[0], F.layer_norm(yr, (D,), g2.double(), c2.double(), 1e-12), 1e-5)
+    _close(outs[1], F.layer_norm(yr, (D,), g3.double(), c3.double(), 1e-12), 1e-5)
+    _close(m2, yr.mean(1), 1e-5)
+    _close(r2, 1 / torch.sqrt(yr.var(1, unbiased=False) + 1e-12), 1e-5)
+    # eval form: nothing saved, no extra LayerNorm: bitwise the same output, and run-to-run reproducible
+    y2, saved, outs2, _ = ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, act, 0.5, save=False)
+    assert torch.equal(y, y2) and saved[0] is None and saved[3] is None and outs2 == []
+    y3 = ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, act, 0.5, save=False)[0]
+    assert torch.equal(y2, y3)
+
+
+def test_ffn2_strided_input_rows():
+    """x as a column window of a wider buffer (row stride != 256), as the layer's concat buffers hand it over."""
+    from tavsr import ops
+    M, D, N1 = 200, 256, 2048
+    ln_w, ln_b, w1, b1, w2, b2 = _params(D, N1, seed=3)
+    big = torch.randn(M, 3 * D, device="cuda")
+    x = big[:, D:2 * D]
+    y = ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, "swish", 0.5, save=False)[0]
+    _close(y, _ref(x, ln_w, ln_b, w1, b1, w2, b2, "swish", 0.5)[-1], 5e-6)
+
+
+@pytest.mark.parametrize("cfg", [None, "256,3"])
+def test_ffn2_dropout_is_the_gemm_path_dropout(cfg):
+    """Both dropout sites draw the tavsr_dropout mapping at the offsets of their tokens: the stand-alone dropout kernel
+    regenerates the masks from the tokens, i.e. the GEMM-based backward pairs with this forward."""
+    from tavsr import ops
+    if cfg:
+        os.environ["TAVSR_FFN2_CFG"] = cfg
+    M, D, N1, p = 515, 256, 2048, 0.2
+    ln_w, ln_b, w1, b1, w2, b2 = _params(D, N1, seed=1)
+    x = torch.randn(M, D, device="cuda")
+    ops.manual_seed(99)
+    y, (n, mean, rstd, z, h, t_in, t_out), _, _ = ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, "swish", 0.5, p=p)
+    xd, nr, zr, hr, _ = _ref(x, ln_w, ln_b, w1, b1, w2, b2, "swish", 0.5)
+    _close(z, zr, 5e-6)
+    ones = torch.ones(M, N1, device="cuda")
+    in_mask = ops.dropout(ones, p, token=t_in)[0] != 0
+    assert abs(float(in_mask.float().mean()) - (1 - p)) < 5e-3
+    _close(h, hr * in_mask / (1 - p), 5e-6)
+    assert torch.equal(h != 0, in_mask & (hr.float() != 0))
+    t = (hr * in_mask / (1 - p)) @ w2.double().t() + b2.double()
+    out_mask = ops.dropout(torch.ones(M, D, device="cuda"), p, token=t_out)[0] != 0
+    _close(y, xd + 0.5 * t * out_mask / (1 - p), 5e-6)
+    # eval-style call of the same pass without saving: same y (the masks do not depend on what is saved)
+    ops.manual_seed(99)
+    y2 = ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, "swish", 0.5, p=p, save=False)[0]
+    assert torch.equal(y, y2)
+
+
+def test_ffn_block_function_streaming_equals_gemm_launches():
+    """functional._FFN forward + backward with the streaming forward against the LayerNorm + GEMM + GEMM launches, with the
+    recipe's dropout on: same masks, so outputs and every gradient agree."""
+    from tavsr import functional as F_
+    from tavsr import ops
+    M, D, N1 = 999, 256, 2048
+    ln_w, ln_b, w1, b1, w2, b2 = _params(D, N1, seed=5)
+    x, dy = torch.randn(M, D, device="cuda"), torch.randn(M, D, device="cuda")
+    res = []
+    keep = ops.FFN2
+    for fused in (True, False):
+        ops.FFN2 = fused
+        ops.manual_seed(4242)
+        try:
+            y, saved = F_._FFN.fwd(x, ln_w, ln_b, w1, b1, w2, b2, "swish", 0.5, p=0.1)
+            dx, grads = F_._FFN.bwd(dy, saved, ln_w, w1, w2, "swish", 0.5)
+        finally:
+            ops.FFN2 = keep
+        res.append((y, dx) + tuple(grads))
+    for a, b in zip(*res):
+        _close(a, b, 2e-5)
