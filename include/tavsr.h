@@ -252,13 +252,14 @@ int tavsr_ffn_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w1
  *     ln2_out[k] = LayerNorm(y) * ln2_w[k] + ln2_b[k], k = 0, 1 (optional)    - the norms the consumers of y start with
  *                                                                               (encoder_layer.py:197,215 after the macaron
  *                                                                               block, :316 norm_final after the second)
- * Two launches: the chain kernel (LayerNorm prologue; unit of work 32 rows x 32 hidden units, the K = 256 contraction of
- * the first product split over the four waves of a workgroup, partial tiles exchanged through LDS, second product into
- * accumulators that live as long as the row tile; weights streamed by LDS-DMA through per-wave rings; the flat unit list cut
- * into equal contiguous ranges, one per workgroup) and the finishing kernel (fixed-order sum of a row tile's partials, bias,
- * dropout, scale, residual, the optional LayerNorms).
+ * Two launches: the chain kernel (a workgroup owns a block of 128 rows, wave w its 32-row tile, LayerNorm straight into the
+ * B-operand registers; unit of work 128 rows x 32 hidden units: z^T tile = w1[unit] x LN(x)^T, whose accumulators - hidden
+ * unit on the registers, row on the lane - are, after the activation, the A operand of the second product, so the hidden
+ * activations never leave the registers; weight tiles shared by the four waves through one LDS ring filled by LDS-DMA; the
+ * flat unit list cut into equal contiguous ranges, one per workgroup) and the finishing kernel (fixed-order sum of a row
+ * block's partials, bias, dropout, scale, residual, the optional LayerNorms).
  * Saved for a backward pass (all optional): n_out = LN(x) [M][256], mean / rstd [M], z / h = pre-activations and dropped
- * activations, buffers of roundup32(M) rows x N1 (whole 32-row tiles are stored); ln2_mean / ln2_rstd [M].
+ * activations, buffers of roundup128(M) rows x N1 (whole 128-row blocks are stored); ln2_mean / ln2_rstd [M].
  * Dropout: both sites use the tavsr_dropout mapping (element e of the contiguous [M][N1] / [M][256] result = word e & 3 of
  * Philox counter offset/4 + e/4), i.e. the masks the GEMM-epilogue path draws from the same offsets.
  * ws: tavsr_ffn2_ws(M, 256, N1) floats.  Unsupported shapes: TAVSR_EUNSUPPORTED (callers keep the GEMM launches).

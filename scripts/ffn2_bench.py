@@ -54,15 +54,18 @@ def main():
             us = timed(base)
             rows.append((f"{mode} LN+GEMM+GEMM(+LN)", us))
             ops.FFN2 = True
-            for cfg in ("512,2", "256,2", "256,3", "384,2", "768,2", "1024,2"):
-                os.environ["TAVSR_FFN2_CFG"] = cfg
+            for cfg in (None, "10,3", "10,5", "8,4"):
+                if cfg is None:
+                    os.environ.pop("TAVSR_FFN2_CFG", None)
+                else:
+                    os.environ["TAVSR_FFN2_CFG"] = cfg
                 def fused():
                     return ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, "swish", 0.5, p=p, save=save, ln2=((g2, c2),),
                                         ln2_stats=save)
-                rows.append((f"{mode} ffn2 G,NS={cfg}", timed(fused)))
+                rows.append((f"{mode} ffn2 wpb,NS={cfg}", timed(fused)))
             os.environ.pop("TAVSR_FFN2_CFG", None)
         for name, us in rows:
-            print(f"M={M} {name:34s} {us:8.1f} us  {gf / us * 1e-3 * 1e3:7.1f} TFLOP/s", flush=True)
+            print(f"M={M} {name:34s} {us:8.1f} us  {gf / us * 1e3:7.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":

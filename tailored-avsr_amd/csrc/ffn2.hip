@@ -3,23 +3,26 @@
 // src/encoder/audiovisual/tailored/encoder_layer.py:173-175,211-213; d_model 256):
 //     y = x + scale * dropout(W2 dropout(act(W1 LN(x) + b1)) + b2)       [+ LayerNorms of y for the consumers of y]
 //
-// Why a second design: the first chain kernel (ffn.hip) gathered its weight fragments row-per-lane from L2 and its
-// (row tile x hidden slice) workgroups filled 77 % of the chip.  Here
-//   * the unit of work is (32 rows) x (32 hidden units): phase 1 computes the 32x32 tile of LN(x) W1^T with the K = 256
-//     contraction SPLIT over the workgroup's four waves (each wave keeps its 64-wide slice of the LN'd rows in 32
-//     registers for the whole row tile), the four partial tiles meet in LDS (one barrier per unit, double buffered),
-//     every wave rebuilds the activated tile as its A operand and phase 2 adds tile x W2[:, unit]^T into the wave's 64
-//     output columns (2 accumulator tiles that live as long as the row tile);
-//   * the flat unit list (row tiles x hidden tiles, 6336 units at M = 3168, hidden 2048) is cut into EQUAL contiguous
-//     ranges, one per workgroup (two workgroups per CU): 12 or 13 units each, 95+ % balance instead of 77 %; a range that
-//     crosses a row-tile boundary writes two partial outputs, and the finishing kernel adds the (at most four) partials
-//     of a row tile in workgroup order - deterministic, no atomics;
-//   * weights never touch registers on their way in: every wave streams ITS slices (W1: 32 hidden x 64 k, W2: 64 out x
-//     32 hidden per unit, 16 KB) through a private LDS ring with 16-byte LDS-DMA (global_load_lds, full 128-byte lines,
-//     XOR swizzle on the source address), NS stages of 4 KB ahead, ordered by counted s_waitcnt vmcnt only - no barrier
-//     guards the weight stream;
-//   * the hidden activations make no HBM round trip (written once, coalesced, when a backward pass will need them).
-// v_mfma_f32_32x32x2_f32: exact fp32 (the 1e-4 parity bar).  One unit = 64 MFMAs per wave.
+// What bounds this block on MI355X (measured, profiles/r03_ffn_notes.md): not the fp32 MFMA pipe but the CU's vector-memory
+// path.  Any form that streams 16 KB of weights per 1 MFLOP - the 64x64-tile GEMM launches, the first chain kernel
+// (ffn.hip), a K-split chain with per-wave LDS-DMA rings - ran the 6.6 GFLOP in 104-108 us (63 TFLOP/s, MFMA pipe 48 % busy)
+// whatever the ring depth, the occupancy or the cache level the weights came from: a CU takes in 7-8 bytes per clock.
+// So this design buys REUSE: a workgroup owns a block of 128 rows, wave w its 32-row tile w, and the four waves share every
+// weight tile through one LDS ring - 4 bytes of weights per clock and CU at the full MFMA rate instead of 16.
+//   * unit of work = (128 rows) x (32 hidden units) = 256 MFMAs per wave:
+//       phase 1: z^T tile (32 hidden x 32 rows) = W1[unit] (A operand, from LDS) x LN(x)^T (B operand: the wave's row tile
+//                lives in 128 registers for the whole row block), bias as the initial accumulator;
+//       the accumulator tile - hidden unit on the registers, row on the lane - IS the A operand of phase 2 after the
+//       activation (the MFMA sums over k in any order as long as A and B agree, and W2's fragment is read with the
+//       accumulator's k permutation): the hidden activations never leave the registers, no exchange, no second barrier;
+//       phase 2: out tile (32 rows x 256) += act(z) x W2[:, unit]^T into 8 accumulator tiles that live as long as the row block.
+//   * the flat unit list (row blocks x hidden tiles) is cut into equal contiguous ranges, one workgroup per CU; a range that
+//     crosses a row-block boundary writes two partial outputs and the finishing kernel adds a row block's partials in
+//     workgroup order (deterministic, no atomics);
+//   * weights stream through a ring of NS stages of 16 KB (W1: 32 hidden x 128 k; W2: 128 out x 32 hidden) by 16-byte
+//     LDS-DMA, each wave bringing a quarter of every stage; one raw barrier per stage (64 MFMAs) publishes it, a counted
+//     s_waitcnt vmcnt keeps the younger stages in flight across it.
+// v_mfma_f32_32x32x2_f32: exact fp32 (the 1e-4 parity bar).  512 registers per lane (one wave per SIMD).
 //
 // The finishing kernel (one wave per row) adds the partials, bias, dropout, scale and residual, and can emit up to two
 // LayerNorms of the result (norm_mha / norm_mlp after the macaron block, norm_final after the second block): the layer's
@@ -38,275 +41,340 @@ typedef __attribute__((address_space(3))) float lds_f;
 typedef const __attribute__((address_space(1))) float glb_f;
 
 constexpr int kMaxU = 32;          // units per workgroup (bias slices staged in LDS)
+constexpr int kRB = 128;           // rows per row block (4 waves x 32)
 
 struct Ffn2Args {
   int dbg;                         // tuning runs only (TAVSR_FFN2_DBG): bit 0 = every unit streams hidden tile 0's weights
-  int M, N1, G, UPR, maxseg, act;  // rows, hidden units, workgroups, units per row tile (N1 / 32), slab slots per workgroup
-  long U;                          // units in all: row tiles * UPR
+  int M, N1, G, UPR, wpb, act;     // rows, hidden units, workgroups, units per row block (N1 / 32), workgroups per row block
   const float* x;                  // [M][ldx]
   long ldx;
   const float *ln_w, *ln_b, *W1, *b1, *W2;
   float eps;
-  float* slab;                     // [G][maxseg][32][256]
+  float* slab;                     // [G][128][256]
   float *n_out, *mean, *rstd;      // saved LayerNorm output / statistics (null: not kept)
-  float *Z, *H;                    // [roundup32(M)][N1] (SAVE)
+  float *Z, *H;                    // [roundup128(M)][N1] (SAVE)
   uint32_t thr;                    // inner dropout: element (m, c) = word c & 3 of counter offset4 + (m * N1 + c) / 4
   float inv_keep;
   const uint64_t* seed;
   uint64_t offset4;
 };
 
+// Tuning runs only (TAVSR_FFN2_DBG bit 1): per-workgroup time stamps (100 MHz wall clock) of the kernel's phases.
+constexpr int kTraceWG = 1024, kTraceN = 16;     // [0..7] 100 MHz wall clock, [8..15] shader clock (s_memtime)
+__device__ unsigned long long g_ffn2_trace[kTraceWG * kTraceN];
+__device__ __forceinline__ void stamp(const Ffn2Args& a, int i) {
+  if ((a.dbg & 2) && threadIdx.x == 0 && blockIdx.x < kTraceWG) {
+    g_ffn2_trace[blockIdx.x * kTraceN + i] = wall_clock64();
+    g_ffn2_trace[blockIdx.x * kTraceN + 8 + i] = __builtin_readcyclecounter();
+  }
+}
+
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+// Activation inside the chain: hardware exp2 / reciprocal (1 ulp each) instead of expf and an IEEE division - 6 instructions
+// per element instead of ~35, which matters for a wave that is alone on its SIMD: what it issues between two MFMAs beyond
+// ~64 cycles delays the second one.  |error| ~ 2e-7 relative, far inside the 1e-4 parity bar.
+template <int ACT>
+__device__ __forceinline__ float act_fast(float z) {
+  if (ACT == TAVSR_ACT_SWISH) return z * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+  return z > 0.f ? z : 0.f;
+}
 template <int N>
 __device__ __forceinline__ void vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void lgkwait0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wg_barrier() {      // LDS-only barrier: LDS-DMA stays in flight across it
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
 // Every LDS read of the steady-state loop goes through a function with a __restrict__ pointer: the alias scope this gives
 // the load is what keeps hipcc from waiting vmcnt(0) - draining the whole LDS-DMA weight stream - in front of it (without
 // scope information its waitcnt pass assumes that any LDS read may alias any LDS-DMA in flight).
 __device__ __forceinline__ float4 lds4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float lds1(const float* __restrict__ p) { return *p; }
-__device__ __forceinline__ uint32_t ldsu(const uint32_t* __restrict__ p) { return *p; }
-__device__ __forceinline__ uint32_t ldsb(const unsigned char* __restrict__ p) { return *p; }
 
-// NS: stages (4 KB) of a wave's weight ring.  SAVE: z / h (and the LayerNorm output) are written for the backward pass.
+// NS: stages (16 KB) of the weight ring.  SAVE: z / h (and the LayerNorm output) are written for the backward pass.
 template <int NS, bool SAVE, bool DROP, int ACT>
-__global__ __launch_bounds__(256, 2) void ffn2_fwd_kernel(const Ffn2Args a) {
-  constexpr int HPF = 2 * 4 * 1024;               // partial tiles [2 buffers][4 waves][32 x 32]; aliased by the LN'd row tile
-  constexpr int RINGF = 4 * NS * 1024;
-  constexpr int NVM = (NS - 1) * 4;               // LDS-DMA instructions that may stay in flight behind the awaited stage
-  __shared__ __attribute__((aligned(1024))) float smem[HPF + RINGF + kMaxU * 32 + 128];
+__global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
+  constexpr int STG = 4096;                       // floats per stage
+  constexpr int NVM = (NS - 2) * 4;               // a wave's LDS-DMA instructions that may stay in flight behind the awaited stage
+  static_assert(NS >= 3 && NS <= 5, "one stage being read, one about to be, at least one in flight; NS * 16 KB + 84 KB of LDS");
+  constexpr int XSF = 4 * 4096;                   // x staging: [4 waves][32 rows][128 floats] (half a row tile per wave)
+  __shared__ __attribute__((aligned(1024))) float smem[NS * STG + XSF + kMaxU * 32 + 512];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h2 = lane >> 5;
-  float* const Hp = smem;
-  float* const ring = smem + HPF + w * (NS * 1024);
-  float* const b1s = smem + HPF + RINGF;
-  unsigned char* const Mk = reinterpret_cast<unsigned char*>(b1s + kMaxU * 32);   // keep bits [2][32 rows][8 chunks]
+  float* const ring = smem;
+  float* const xs = smem + NS * STG + w * 4096;
+  float* const b1s = smem + NS * STG + XSF;
+  float* const gbs = b1s + kMaxU * 32;            // LayerNorm gamma | beta
 
+  // Workgroup g = row block g / wpb, part g % wpb of that block's hidden tiles: ranges never cross a row block, so a
+  // workgroup pays ONE LayerNorm prologue and writes ONE partial output.
   const int UPR = a.UPR;
-  const long ub = (long)blockIdx.x * a.U / a.G, ue = (long)(blockIdx.x + 1) * a.U / a.G;
-  const int nu = (int)(ue - ub);
+  const int rb = blockIdx.x / a.wpb, part = blockIdx.x - rb * a.wpb;
+  const int ht0 = part * UPR / a.wpb;
+  const int nu = (part + 1) * UPR / a.wpb - ht0;
   if (nu <= 0) return;
-  int rt = (int)(ub / UPR);
-  int ht = (int)(ub - (long)rt * UPR);            // hidden tile of the unit at hand
-  const int ht0 = ht;
+  stamp(a, 0);
+  const int m0 = rb * kRB + 32 * w;               // this wave's row tile
 
-  // ---- weight stream: stage k of unit i is W1[32 ih .. +32][64 w + 32 k .. +32] (k = 0, 1) or W2[64 w + 32 (k-2) .. +32][32 ih .. +32]
-  // as a k-contiguous [32 rows][32 floats] image; 16-byte chunk c of row r lands at chunk c ^ ((r >> 1) & 7)
+  // ---- x, first half of the wave's rows (k 0 .. 127): LDS-DMA of whole 512-byte half rows into the staging image
+  // [32 rows][128 floats] (16-byte chunk c of row r at chunk (c & ~15) | ((c ^ r) & 15)), ahead of everything else
+  // (ordinary loads first, so that nothing waits behind the LDS-DMA queue for them: bias slices of this workgroup's units
+  // and the LayerNorm weights go to LDS - an ordinary load inside the loop would drain the weight stream)
+  float bpre[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) bpre[it] = tid + 256 * it < nu * 32 ? a.b1[32 * ht0 + tid + 256 * it] : 0.f;
+  const float gpre = a.ln_w[tid], cpre = a.ln_b[tid];
+  auto issue_x = [&](int half) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = 2 * j + h2, pc = li;
+      const float* src = a.x + (long)min(m0 + row, a.M - 1) * a.ldx + 128 * half + (((pc & ~15) | ((pc ^ row) & 15)) << 2);
+      __builtin_amdgcn_global_load_lds((glb_f*)src, (lds_f*)(xs + j * 256), 16, 0, 0);
+    }
+  };
+  issue_x(0);
+
+  // ---- weight stream.  Stages of a unit: 0, 1 = W1[32 ih .. +32][128 s .. +128] as a [32 rows][128 floats] image (16-byte
+  // chunk c of row r at chunk (c & ~15) | ((c ^ r) & 15)); 2, 3 = W2[128 (s-2) .. +128][32 ih .. +32] as four [32 rows][32 floats]
+  // images (chunk c of row r at c ^ ((r >> 1) & 7)).  A wave brings a quarter of every stage: 4 LDS-DMA instructions of 1 KB.
   int offW1[4], offW2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int q = j * 64 + lane, row = q >> 3, cl = (q & 7) ^ ((row >> 1) & 7);
-    offW1[j] = row * 256 + cl * 4;
-    offW2[j] = row * a.N1 + cl * 4;
+    const int p = (4 * w + j) * 64 + lane, row = p >> 5, pc = p & 31;
+    offW1[j] = row * 256 + (((pc & ~15) | ((pc ^ row) & 15)) << 2);
+    const int q = j * 64 + lane, r2 = q >> 3;
+    offW2[j] = (32 * w + r2) * a.N1 + (((q & 7) ^ ((r2 >> 1) & 7)) << 2);
   }
-  // hidden tiles of the units iu, iu + 1, iu + 2 (clamped to the range's last unit: past the end the stream fetches valid
-  // addresses whose data is never used).  UPR >= 32 > units per workgroup: one conditional subtraction wraps.
+  // hidden tiles of the units iu, iu + 1, iu + 2 (clamped to the range's last unit: past the end the stream fetches valid addresses
+  // whose data is never used)
   int hta[3];
   auto set_hta = [&](int iu_) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const int v = ht0 + min(iu_ + d, nu - 1);
-      hta[d] = (a.dbg & 1) ? 0 : (v >= UPR ? v - UPR : v);
-    }
+    for (int d = 0; d < 3; ++d) hta[d] = (a.dbg & 1) ? 0 : ht0 + min(iu_ + d, nu - 1);
   };
-  // LDS-DMA instruction j of stage `sub` of unit iu + du -> ring slot (sub, du: compile-time at every call site)
+  // LDS-DMA instruction j of this wave's quarter of stage `sub` of unit iu + du -> ring slot (sub, du: compile-time at every
+  // call site)
   auto issue_one = [&](int du, int sub, int slot, int j) {
     const int ih = hta[du];
-    const float* src = sub < 2 ? a.W1 + ((long)(32 * ih) * 256 + 64 * w + 32 * sub) + offW1[j]
-                               : a.W2 + ((long)(64 * w + 32 * (sub - 2)) * a.N1 + 32 * ih) + offW2[j];
-    __builtin_amdgcn_global_load_lds((glb_f*)src, (lds_f*)(ring + slot * 1024 + j * 256), 16, 0, 0);
-  };
-  auto read16 = [&](int slot, float (&f)[16]) {
-    const float* s = ring + slot * 1024 + li * 32;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 v = lds4(s + (((2 * g + h2) ^ ((li >> 1) & 7)) << 2));
-      f[4 * g] = v.x; f[4 * g + 1] = v.y; f[4 * g + 2] = v.z; f[4 * g + 3] = v.w;
-    }
+    const float* src = sub < 2 ? a.W1 + ((long)(32 * ih) * 256 + 128 * sub) + offW1[j]
+                               : a.W2 + ((long)(128 * (sub - 2)) * a.N1 + 32 * ih) + offW2[j];
+    __builtin_amdgcn_global_load_lds((glb_f*)src, (lds_f*)(ring + slot * STG + w * 1024 + j * 256), 16, 0, 0);
   };
 
   set_hta(0);
 #pragma unroll
-  for (int s = 0; s < NS; ++s)                    // stages 0 .. NS-1 (all of unit 0: NS <= 3) on their way before anything else
+  for (int s = 0; s < NS; ++s)                    // stages 0 .. NS-1 fill the ring before anything else
 #pragma unroll
-    for (int j = 0; j < 4; ++j) issue_one(0, s, s, j);
-  // bias slices of this workgroup's units (LDS: an ordinary load inside the loop would drain the weight stream)
-  for (int i = tid; i < nu * 32; i += 256) {
-    int ih = ht0 + (i >> 5);
-    while (ih >= UPR) ih -= UPR;
-    b1s[i] = a.b1[32 * ih + (i & 31)];
-  }
+    for (int j = 0; j < 4; ++j) issue_one(s / 4, s % 4, s, j);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) b1s[tid + 256 * it] = bpre[it];       // kMaxU * 32 = 1024 floats
+  gbs[tid] = gpre;
+  gbs[256 + tid] = cpre;
 
   const uint64_t sd = DROP ? a.seed[0] : 0;
-  float fbC[16], fbN[16];
-  // fragments of the very first stage; its slot takes stage NS
-  vmwait<NVM>();
-  read16(0, fbC);
-  lgkwait0();
-  SB();
+  // ---- LayerNorm of the wave's 32 rows into the B-operand registers: lane (li, h2) holds row li,
+  // xr[4 g + j] = LN(x)[8 g + 4 h2 + j] (the k order of the weight fragments); statistics over the lane pair (li, 0), (li, 1)
+#define FFN2_A1(ST, G) ((ST) + li * 128 + ((((2 * (G) + h2) & ~15) | (((2 * (G) + h2) ^ li) & 15)) << 2))
+  float xr[128];
+  {
+    float s1 = 0.f;
+    vmwait<4 * NS>();                             // the first half has landed (the NS weight stages behind it may not have)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue_one(NS / 4, NS % 4, 0, j);
-  int cs = 1 % NS;                                // ring slot of the stage whose fragments are read next
-  int iu = 0, seg = 0;
-  while (iu < nu) {
-    const int m0 = rt * 32;
-    const int nsu = min(UPR - ht, nu - iu);       // units of this row tile
-    // ---- LayerNorm(x) of the row tile -> LDS (16-byte chunk c of row r at chunk (c & ~15) | ((c ^ r) & 15))
-    wg_barrier();                                 // everyone is done with the previous row tile's partials
-    {
-      const bool owner = SAVE && ht == 0;         // the workgroup that holds the row tile's first unit keeps the LN output
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int row = w * 8 + q, m = min(m0 + row, a.M - 1);
-        float4 v = *reinterpret_cast<const float4*>(a.x + (long)m * a.ldx + lane * 4);
-        const float mu = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
-        const float c0 = v.x - mu, c1 = v.y - mu, c2 = v.z - mu, c3 = v.w - mu;
-        const float rs = rsqrtf(wave_sum((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) * (1.f / 256.f) + a.eps);
-        const float4 gg = *reinterpret_cast<const float4*>(a.ln_w + lane * 4), bb = *reinterpret_cast<const float4*>(a.ln_b + lane * 4);
-        v = make_float4(c0 * rs * gg.x + bb.x, c1 * rs * gg.y + bb.y, c2 * rs * gg.z + bb.z, c3 * rs * gg.w + bb.w);
-        if (owner && m0 + row < a.M) {
-          if (a.n_out) *reinterpret_cast<float4*>(a.n_out + (long)m * 256 + lane * 4) = v;
-          if (a.mean && lane == 0) { a.mean[m] = mu; a.rstd[m] = rs; }
-        }
-        *reinterpret_cast<float4*>(Hp + row * 256 + (((lane & ~15) | ((lane ^ row) & 15)) << 2)) = v;
-      }
+    for (int g = 0; g < 16; ++g) {
+      const float4 v = lds4(FFN2_A1(xs, g));
+      xr[4 * g] = v.x; xr[4 * g + 1] = v.y; xr[4 * g + 2] = v.z; xr[4 * g + 3] = v.w;
+      s1 += (v.x + v.y) + (v.z + v.w);
     }
-    wg_barrier();
-    float xq[32];                                 // this wave's K slice of the row tile: k = 64 w + 8 g + 4 h2 + j
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    issue_x(1);                                   // second half (k 128 .. 255) over the first
+    vmwait<0>();
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int c = 16 * w + 2 * g + h2;
-      const float4 v = lds4(Hp + li * 256 + (((c & ~15) | ((c ^ li) & 15)) << 2));
-      xq[4 * g] = v.x; xq[4 * g + 1] = v.y; xq[4 * g + 2] = v.z; xq[4 * g + 3] = v.w;
+    for (int g = 0; g < 16; ++g) {
+      const float4 v = lds4(FFN2_A1(xs, g));
+      xr[64 + 4 * g] = v.x; xr[64 + 4 * g + 1] = v.y; xr[64 + 4 * g + 2] = v.z; xr[64 + 4 * g + 3] = v.w;
+      s1 += (v.x + v.y) + (v.z + v.w);
     }
-    wg_barrier();                                 // the row tile image may now be overwritten by partial tiles
-    f32x16 acc2[2];
+    const float mu = (s1 + __shfl_xor(s1, 32, 64)) * (1.f / 256.f);
+    float s2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int k = 0; k < 128; ++k) {
+      xr[k] -= mu;
+      s2 += xr[k] * xr[k];
+    }
+    const float rs = rsqrtf((s2 + __shfl_xor(s2, 32, 64)) * (1.f / 256.f) + a.eps);
+    wg_barrier();                                 // gamma / beta / bias slices are in LDS; barrier 0 of the ring: stage 0 has landed
+    const int m = min(m0 + li, a.M - 1);
+    const bool keepn = SAVE && part == 0 && m0 + li < a.M;    // the workgroup that holds the row block's first unit keeps LN(x)
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const float4 gg = lds4(gbs + 8 * g + 4 * h2), bb = lds4(gbs + 256 + 8 * g + 4 * h2);
+      xr[4 * g] = xr[4 * g] * rs * gg.x + bb.x;
+      xr[4 * g + 1] = xr[4 * g + 1] * rs * gg.y + bb.y;
+      xr[4 * g + 2] = xr[4 * g + 2] * rs * gg.z + bb.z;
+      xr[4 * g + 3] = xr[4 * g + 3] * rs * gg.w + bb.w;
+      if (keepn && a.n_out)
+        *reinterpret_cast<float4*>(a.n_out + (long)m * 256 + 8 * g + 4 * h2) = make_float4(xr[4 * g], xr[4 * g + 1], xr[4 * g + 2], xr[4 * g + 3]);
+    }
+    if (keepn && a.mean && h2 == 0) { a.mean[m] = mu; a.rstd[m] = rs; }
+  }
+  // Ring protocol.  Stage k lives in slot k % NS.  "Barrier k" = every wave has waited for its own quarter of stage k
+  // (counted vmcnt) and holds in registers everything it will still read of stage k - 1; behind it stage k may be read and
+  // slot (k - 1) % NS is refilled with stage k - 1 + NS.  Barrier k + 1 is passed two fragment groups BEFORE the end of stage
+  // k: the first fragment of stage k + 1 and the four LDS-DMA instructions are then issued in the shadow of the last eight
+  // MFMAs of stage k, and no MFMA waits at a stage boundary.  (Barrier 0 is the one above.)
+  int cs = 0;                                     // ring slot of the stage whose fragments are read
+  float4 fa, fb, ga, gb;                          // fragments of the pair of groups being multiplied / of the next pair
+  ga = lds4(FFN2_A1(ring, 0));
+  gb = lds4(FFN2_A1(ring, 1));
+  int iu = 0, ht = ht0;
+  stamp(a, 2);
+  {
+    f32x16 acc2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 
-    // One stage = 16 MFMAs with the fragments FC; the NEXT stage's fragments are read into FN after the 4th MFMA (the
-    // LDS-DMA that brings them was issued NS stages ago), and once those reads are back the freed ring slot is refilled,
-    // one LDS-DMA instruction per MFMA shadow.
-#define FFN2_STAGE(POS, AV, AO, FC, FN, ACC, NWAIT)                                                              \
-    {                                                                                                       \
-      _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                      \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[AO + s_], FC[s_], ACC, 0, 0, 0);                      \
-      SB();                                                                                                 \
-      vmwait<NWAIT>();                                                                                      \
-      read16(cs, FN);                                                                                       \
-      SB();                                                                                                 \
-      _Pragma("unroll") for (int s_ = 4; s_ < 10; ++s_)                                                     \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[AO + s_], FC[s_], ACC, 0, 0, 0);                      \
-      SB();                                                                                                 \
-      lgkwait0();                                                                                           \
-      SB();                                                                                                 \
-      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                    \
-        issue_one((POS + 1 + NS) / 4, (POS + 1 + NS) % 4, cs, j_);                                          \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[AO + 10 + j_], FC[10 + j_], ACC, 0, 0, 0);            \
-        SB();                                                                                               \
-      }                                                                                                     \
-      ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[AO + 14], FC[14], ACC, 0, 0, 0);                        \
-      ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[AO + 15], FC[15], ACC, 0, 0, 0);                        \
-      SB();                                                                                                 \
-      cs = cs + 1 == NS ? 0 : cs + 1;                                                                       \
-    }
+    // fragment addresses: W1 stage (group g: k = 8 g + 4 h2 ..), W2 stage (group i: q = i >> 2, output tile i & 3)
+#define FFN2_A2(ST, I) ((ST) + ((I) & 3) * 1024 + li * 32 + (((2 * ((I) >> 2) + h2) ^ ((li >> 1) & 7)) << 2))
+    // A stage = 8 pairs of fragment groups; the fragments of pair p + 1 are read while pair p multiplies (8 MFMAs).
+    // Consecutive MFMAs never share an accumulator (two chains side by side): a dependent f32 MFMA does not issue back to back.
+    // Tail of a stage (pair 7): barrier POS + 1, then - in the shadow of the pair's MFMAs - the first two fragments of the
+    // next stage and the refill of this stage's slot.  NEXTW1: the next stage is a W1 stage.
+#define FFN2_TAIL(POS, NWAIT, NEXTW1, MF7A, MF7B)                                                                       \
+        fa = ga; fb = gb;                                                                                               \
+        vmwait<NWAIT>();                                                                                                \
+        wg_barrier();                                                                                                   \
+        {                                                                                                               \
+          const int cn = cs + 1 == NS ? 0 : cs + 1;                                                                     \
+          const float* stn = ring + cn * STG;                                                                           \
+          SB();                                                                                                         \
+          MF7A                                                                                                          \
+          ga = NEXTW1 ? lds4(FFN2_A1(stn, 0)) : lds4(FFN2_A2(stn, 0));                                                  \
+          issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 0);                                                             \
+          issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 1);                                                             \
+          SB();                                                                                                         \
+          MF7B                                                                                                          \
+          gb = NEXTW1 ? lds4(FFN2_A1(stn, 1)) : lds4(FFN2_A2(stn, 1));                                                  \
+          issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 2);                                                             \
+          issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 3);                                                             \
+          SB();                                                                                                         \
+          cs = cn;                                                                                                      \
+        }
 
-    for (int t = 0; t < nsu; ++t, ++iu, ++ht) {
-      const int buf = iu & 1;
-      float* const P = Hp + buf * 4096;
+    for (; iu < nu; ++iu, ++ht) {
       set_hta(iu);
-      // ---- phase 1: partial tile of this wave's K slice (rows on the registers, hidden unit on the lane); bias rides on wave 0
-      const float bv = lds1(b1s + iu * 32 + li);
-      f32x16 acc1;
-      {
-        const float b0 = w == 0 ? bv : 0.f;
+      // ---- phase 1: z^T tile = W1[unit] x LN(x)^T, hidden unit on the registers (j = rho(r) + 4 h2), row on the lane
+      f32x16 acc1, acc1b;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = b0;
-      }
-      FFN2_STAGE(0, xq, 0, fbC, fbN, acc1, NVM)
-      FFN2_STAGE(1, xq, 16, fbN, fbC, acc1, NVM)
-      // ---- the four partial tiles meet in LDS: [wave][m][32 floats], 16-byte chunk c of row m at chunk c ^ ((m >> 1) & 7)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = rho(r) + 4 * h2;
-        P[w * 1024 + m * 32 + ((((li >> 2) ^ ((m >> 1) & 7))) << 2) + (li & 3)] = acc1[r];
-      }
-      if (DROP) {       // keep bits of chunk 2 w + h2 of row li (one Philox call covers 4 consecutive hidden units)
-        const uint64_t e = (uint64_t)(m0 + li) * (uint64_t)a.N1 + (uint64_t)(32 * ht + 8 * w + 4 * h2);
-        const uint64_t ctr = a.offset4 + (e >> 2);
-        uint32_t wv[4];
-        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), wv);
-        Mk[buf * 256 + li * 8 + h2 * 4 + w] =
-            (unsigned char)((wv[0] >= a.thr) | ((wv[1] >= a.thr) << 1) | ((wv[2] >= a.thr) << 2) | ((wv[3] >= a.thr) << 3));
-      }
-      wg_barrier();
-      // ---- every wave rebuilds the activated tile as its A operand: lane = row, 4 consecutive hidden units per read
-      float av[16];
+      for (int r = 0; r < 16; ++r) acc1b[r] = 0.f;
       {
-        uint32_t kb = 0xffffffffu;
-        if (DROP) kb = ldsu(reinterpret_cast<const uint32_t*>(Mk + buf * 256 + li * 8 + h2 * 4));
+        const float* bp = b1s + iu * 32 + 4 * h2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int off = li * 32 + (((2 * q + h2) ^ ((li >> 1) & 7)) << 2);
-          const float4 v0 = lds4(P + off), v1 = lds4(P + 1024 + off), v2 = lds4(P + 2048 + off), v3 = lds4(P + 3072 + off);
-          const float z0 = (v0.x + v1.x) + (v2.x + v3.x), z1 = (v0.y + v1.y) + (v2.y + v3.y);
-          const float z2 = (v0.z + v1.z) + (v2.z + v3.z), z3 = (v0.w + v1.w) + (v2.w + v3.w);
-          const uint32_t b = kb >> (8 * q);
-          av[4 * q] = act_fwd(ACT, z0) * ((b & 1u) ? a.inv_keep : 0.f);
-          av[4 * q + 1] = act_fwd(ACT, z1) * ((b & 2u) ? a.inv_keep : 0.f);
-          av[4 * q + 2] = act_fwd(ACT, z2) * ((b & 4u) ? a.inv_keep : 0.f);
-          av[4 * q + 3] = act_fwd(ACT, z3) * ((b & 8u) ? a.inv_keep : 0.f);
-          if (q & 1) SB();          // two chunks' loads (32 registers) in flight at a time, not all sixteen
+          const float4 b = lds4(bp + 8 * q);
+          acc1[4 * q] = b.x; acc1[4 * q + 1] = b.y; acc1[4 * q + 2] = b.z; acc1[4 * q + 3] = b.w;
         }
       }
-      if (SAVE) {       // rows 8 w .. 8 w + 7 of z and h, hidden unit on the lane: 128-byte row segments (8 stores per wave)
+#define FFN2_MF1(F, XO, G)                                                                                              \
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(F.x, xr[XO + 4 * (G)], acc1, 0, 0, 0);                            \
+          acc1b = __builtin_amdgcn_mfma_f32_32x32x2f32(F.y, xr[XO + 4 * (G) + 1], acc1b, 0, 0, 0);                      \
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(F.z, xr[XO + 4 * (G) + 2], acc1, 0, 0, 0);                        \
+          acc1b = __builtin_amdgcn_mfma_f32_32x32x2f32(F.w, xr[XO + 4 * (G) + 3], acc1b, 0, 0, 0);
+#define FFN2_P1_STAGE(POS, XO, NEXTW1)                                                                                  \
+      {                                                                                                                 \
+        const float* st = ring + cs * STG;                                                                              \
+        _Pragma("unroll") for (int p = 0; p < 7; ++p) {                                                                 \
+          fa = ga; fb = gb;                                                                                             \
+          ga = lds4(FFN2_A1(st, 2 * p + 2));                                                                            \
+          gb = lds4(FFN2_A1(st, 2 * p + 3));                                                                            \
+          FFN2_MF1(fa, XO, 2 * p)                                                                                       \
+          FFN2_MF1(fb, XO, 2 * p + 1)                                                                                   \
+          SB();                                                                                                         \
+        }                                                                                                               \
+        FFN2_TAIL(POS, NVM, NEXTW1, FFN2_MF1(fa, XO, 14), FFN2_MF1(fb, XO, 15))                                         \
+      }
+      FFN2_P1_STAGE(0, 0, true)
+      FFN2_P1_STAGE(1, 64, false)
+#undef FFN2_P1_STAGE
+#undef FFN2_MF1
+      // ---- activation (+ inner dropout) in place: av[4 q + e] = h[row li][hidden 8 q + 4 h2 + e] - the A operand of phase 2.
+      // Chunk 0 here; the elements of chunks 1 .. 3 one per fragment group, in the shadow of phase 2's MFMAs (q-major order).
+      float av[16];
+      uint32_t wv[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      auto activate = [&](int q, int e) {
+        const long e0 = (long)(m0 + li) * a.N1 + 32 * ht + 8 * q + 4 * h2;       // 4 consecutive hidden units of one row
+        if (DROP && e == 0) {
+          const uint64_t ctr = a.offset4 + ((uint64_t)e0 >> 2);
+          philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), wv);
+        }
+        av[4 * q + e] = act_fast<ACT>(acc1[4 * q + e]) * ((!DROP || wv[e] >= a.thr) ? a.inv_keep : 0.f);
+        if (SAVE && e == 3) {     // rows >= M exist in the buffers (roundup128(M) rows): unconditional 16-byte stores
+          *reinterpret_cast<float4*>(a.Z + e0) = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+          *reinterpret_cast<float4*>(a.H + e0) = make_float4(av[4 * q], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]);
+        }
+      };
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int m = 8 * w + e + 4 * h2;
-          const int off = m * 32 + ((((li >> 2) ^ ((m >> 1) & 7))) << 2) + (li & 3);
-          const float z = (lds1(P + off) + lds1(P + 1024 + off)) + (lds1(P + 2048 + off) + lds1(P + 3072 + off));
-          float keep = a.inv_keep;
-          if (DROP) keep = ((ldsb(Mk + buf * 256 + m * 8 + ((li >> 2) & 1) * 4 + (li >> 3)) >> (li & 3)) & 1) ? a.inv_keep : 0.f;
-          const long o = (long)(m0 + m) * a.N1 + 32 * ht + li;
-          a.Z[o] = z;
-          a.H[o] = act_fwd(ACT, z) * keep;
-        }
-        SB();
+      for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) activate(0, e);
+      // ---- phase 2: out tile += h x W2[:, unit]^T, 4 + 4 output tiles of 32 columns; q-major so that a chunk of h is used
+      // for 16 MFMAs in a row.  (SAVE: the 8 stores of a unit are all issued inside stage 2, before its tail barrier.)
+      // pair P = groups 2 P, 2 P + 1: the same chunk q = P >> 1 of h against output tiles nt, nt + 1 (nt = 2 (P & 1))
+#define FFN2_M2(AVI, X, Y, T0)                                                                                          \
+          acc2[T0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[AVI], X, acc2[T0], 0, 0, 0);                               \
+          acc2[(T0) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[AVI], Y, acc2[(T0) + 1], 0, 0, 0);
+#define FFN2_MF2A(FA, FB, NT0, P)                                                                                       \
+          FFN2_M2(4 * ((P) >> 1), FA.x, FB.x, NT0 + 2 * ((P) & 1))                                                      \
+          FFN2_M2(4 * ((P) >> 1) + 1, FA.y, FB.y, NT0 + 2 * ((P) & 1))
+#define FFN2_MF2B(FA, FB, NT0, P)                                                                                       \
+          FFN2_M2(4 * ((P) >> 1) + 2, FA.z, FB.z, NT0 + 2 * ((P) & 1))                                                  \
+          FFN2_M2(4 * ((P) >> 1) + 3, FA.w, FB.w, NT0 + 2 * ((P) & 1))
+#define FFN2_P2_STAGE(POS, NT0, ACTIVATE, NWAIT, NEXTW1)                                                                \
+      {                                                                                                                 \
+        const float* st = ring + cs * STG;                                                                              \
+        _Pragma("unroll") for (int p = 0; p < 7; ++p) {                                                                 \
+          fa = ga; fb = gb;                                                                                             \
+          ga = lds4(FFN2_A2(st, 2 * p + 2));                                                                            \
+          gb = lds4(FFN2_A2(st, 2 * p + 3));                                                                            \
+          FFN2_MF2A(fa, fb, NT0, p)                                                                                     \
+          FFN2_MF2B(fa, fb, NT0, p)                                                                                     \
+          if (ACTIVATE && p < 6) { activate((p >> 1) + 1, 2 * (p & 1)); activate((p >> 1) + 1, 2 * (p & 1) + 1); }      \
+          SB();                                                                                                         \
+        }                                                                                                               \
+        FFN2_TAIL(POS, NWAIT, NEXTW1, FFN2_MF2A(fa, fb, NT0, 7), FFN2_MF2B(fa, fb, NT0, 7))                             \
       }
-      // ---- phase 2: tile x W2[:, unit]^T into this wave's 64 output columns
-      FFN2_STAGE(2, av, 0, fbC, fbN, acc2[0], NVM + (SAVE ? 8 : 0))
-      FFN2_STAGE(3, av, 0, fbN, fbC, acc2[1], NVM + (SAVE ? 8 : 0))
+      FFN2_P2_STAGE(2, 0, true, NVM + (SAVE ? 8 : 0), false)
+      FFN2_P2_STAGE(3, 4, false, NVM + (SAVE ? 8 : 0), true)
+#undef FFN2_P2_STAGE
+#undef FFN2_MF2A
+#undef FFN2_MF2B
+#undef FFN2_M2
     }
-#undef FFN2_STAGE
-    // ---- partial output of this (row tile, unit range) -> slab slot
+#undef FFN2_TAIL
+#undef FFN2_A1
+#undef FFN2_A2
+    stamp(a, 3);
+    if (threadIdx.x == 0 && (a.dbg & 2) && blockIdx.x < kTraceWG) g_ffn2_trace[blockIdx.x * kTraceN + 7] = nu;
+    // ---- partial output of this (row block, unit range) -> slab slot
     {
-      float* out = a.slab + ((long)blockIdx.x * a.maxseg + seg) * (32 * 256);
+      float* out = a.slab + ((long)blockIdx.x * kRB + 32 * w) * 256;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(rho(r) + 4 * h2) * 256 + 64 * w + 32 * t + li] = acc2[t][r];
+        for (int r = 0; r < 16; ++r) out[(rho(r) + 4 * h2) * 256 + 32 * t + li] = acc2[t][r];
     }
-    ++seg;
-    ++rt;
-    ht = 0;
+    stamp(a, 4);      // epilogue's stores issued
   }
-  vmwait<0>();          // the stream ran ahead of the last unit: nothing may land in LDS after this workgroup has left
+  stamp(a, 5);
+  vmwait<0>();
+  stamp(a, 6);          // the stream ran ahead of the last unit: nothing may land in LDS after this workgroup has left
 }
 
-// Where the flat unit list is cut: workgroup g owns units [g U / G, (g + 1) U / G).
-__device__ __forceinline__ int wg_of_unit(long u, long U, int G) { return (int)(((u + 1) * G + U - 1) / U) - 1; }
-
-// y = res + scale * dropout(sum of the row tile's partials + bias); optional LayerNorms of y.  One wave per row.
-__global__ __launch_bounds__(256) void ffn2_finish_kernel(const float* __restrict__ slab, int G, int maxseg, int UPR, long U,
+// y = res + scale * dropout(sum of the row block's partials + bias); optional LayerNorms of y.  One wave per row.
+__global__ __launch_bounds__(256) void ffn2_finish_kernel(const float* __restrict__ slab, int wpb,
                                                           const float* __restrict__ bias, const float* __restrict__ res, long ldr,
                                                           float* __restrict__ y, int M, float scale, uint32_t thr, float inv_keep,
                                                           const uint64_t* __restrict__ seed, uint64_t offset4,
@@ -316,14 +384,16 @@ __global__ __launch_bounds__(256) void ffn2_finish_kernel(const float* __restric
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
-  const int rt = m >> 5, rr = m & 31;
-  const long u0 = (long)rt * UPR;
-  const int ga = wg_of_unit(u0, U, G), gb = wg_of_unit(u0 + UPR - 1, U, G);
+  const int rb = m / kRB, rr = m % kRB;       // row block, row inside it
+  const float* p = slab + (((long)rb * wpb) * kRB + rr) * 256 + lane * 4;     // partial j of the block: + j * kRB * 256
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int g = ga; g <= gb; ++g) {
-    const int sg = rt - (int)(((long)g * U / G) / UPR);       // which of the workgroup's row tiles this one is
-    const float4 t = *reinterpret_cast<const float4*>(slab + (((long)g * maxseg + sg) * 32 + rr) * 256 + lane * 4);
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  for (int j0 = 0; j0 < wpb; j0 += 4) {         // four independent loads in flight, added in workgroup order
+    float4 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const float4*>(p + (long)min(j0 + j, wpb - 1) * (kRB * 256));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j0 + j < wpb) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
   }
   if (bias) {
     const float4 b = *reinterpret_cast<const float4*>(bias + lane * 4);
@@ -361,24 +431,24 @@ __global__ __launch_bounds__(256) void ffn2_finish_kernel(const float* __restric
 }
 
 struct Plan {
-  int G, NS, maxseg, UPR;
-  long U;
+  int G, NS, wpb, UPR;
 };
 
-// TAVSR_FFN2_CFG="G,NS" overrides the plan (tuning runs).
+// Row blocks of 128 rows; every block's hidden tiles are dealt to wpb workgroups (about one workgroup per CU in all).
+// TAVSR_FFN2_CFG="wpb,NS" overrides the plan (tuning runs).
 Plan ffn2_plan(int M, int N1) {
   Plan p;
   p.UPR = N1 / 32;
-  p.U = (long)cdiv(M, 32) * p.UPR;
-  p.NS = 2;
-  p.G = 512;
+  const int nrb = cdiv(M, kRB);
+  p.NS = 4;
+  p.wpb = std::max(1, 256 / nrb);
   if (const char* e = getenv("TAVSR_FFN2_CFG")) {
     int g = 0, ns = 0;
-    if (sscanf(e, "%d,%d", &g, &ns) == 2 && g > 0 && (ns == 2 || ns == 3)) { p.G = g; p.NS = ns; }
+    if (sscanf(e, "%d,%d", &g, &ns) == 2 && g > 0 && ns >= 3 && ns <= 5) { p.wpb = g; p.NS = ns; }
   }
-  if (p.G > p.U) p.G = (int)p.U;
-  while (cdiv(p.U, p.G) > kMaxU - 1) p.G *= 2;        // bias slices of at most kMaxU units fit in LDS
-  p.maxseg = 2 + (cdiv(p.U, p.G) + 1) / p.UPR;
+  p.wpb = std::min(p.wpb, p.UPR);                              // at least one unit per workgroup
+  p.wpb = std::max(p.wpb, cdiv(p.UPR, kMaxU - 1));             // bias slices of at most kMaxU - 1 units fit in LDS
+  p.G = nrb * p.wpb;
   return p;
 }
 
@@ -398,10 +468,15 @@ void launch_fwd(const Ffn2Args& a, bool save, bool drop, hipStream_t s) {
 
 using namespace tavsr;
 
+extern "C" int tavsr_ffn2_trace_read(unsigned long long* dst_host, int32_t n) {      // tuning aid, not part of the product ABI
+  if (n > kTraceWG * kTraceN) n = kTraceWG * kTraceN;
+  return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_ffn2_trace), sizeof(unsigned long long) * n);
+}
+
 extern "C" int64_t tavsr_ffn2_ws(int32_t M, int32_t D, int32_t N1) {
   if (M <= 0 || D != 256 || N1 < 1024 || N1 % 32 != 0) return 0;
   const Plan p = ffn2_plan(M, N1);
-  return (int64_t)p.G * p.maxseg * 32 * 256;
+  return (int64_t)p.G * kRB * 256;
 }
 
 extern "C" int tavsr_ffn2_fwd(const tavsr_ffn_desc* d, tavsr_stream_t stream) {
@@ -422,9 +497,9 @@ extern "C" int tavsr_ffn2_fwd(const tavsr_ffn_desc* d, tavsr_stream_t stream) {
     TAVSR_REQUIRE(!d->ln2_out[k] || (d->ln2_w[k] && d->ln2_b[k] && al16(d->ln2_w[k]) && al16(d->ln2_b[k]) && al16(d->ln2_out[k])),
                   TAVSR_EINVAL, "ffn2_fwd: LayerNorm %d of the output lacks weights", k);
   const Plan p = ffn2_plan(d->M, d->N1);
-  TAVSR_REQUIRE(d->ws_floats >= (int64_t)p.G * p.maxseg * 32 * 256, TAVSR_EINVAL, "ffn2_fwd: workspace too small (tavsr_ffn2_ws)");
+  TAVSR_REQUIRE(d->ws_floats >= (int64_t)p.G * kRB * 256, TAVSR_EINVAL, "ffn2_fwd: workspace too small (tavsr_ffn2_ws)");
   Ffn2Args a{};
-  a.M = d->M; a.N1 = d->N1; a.G = p.G; a.UPR = p.UPR; a.maxseg = p.maxseg; a.act = d->act; a.U = p.U;
+  a.M = d->M; a.N1 = d->N1; a.G = p.G; a.UPR = p.UPR; a.wpb = p.wpb; a.act = d->act;
   a.x = d->x; a.ldx = d->ldx; a.ln_w = d->ln_w; a.ln_b = d->ln_b; a.W1 = d->w1; a.b1 = d->b1; a.W2 = d->w2; a.eps = d->eps;
   a.slab = d->ws; a.n_out = d->n_out; a.mean = d->mean; a.rstd = d->rstd; a.Z = d->z; a.H = d->h;
   a.thr = d->p_drop > 0.f ? (uint32_t)((double)d->p_drop * 4294967296.0) : 0u;
@@ -433,17 +508,20 @@ extern "C" int tavsr_ffn2_fwd(const tavsr_ffn_desc* d, tavsr_stream_t stream) {
   if (const char* e = getenv("TAVSR_FFN2_DBG")) a.dbg = atoi(e);
   hipStream_t s = (hipStream_t)stream;
   const bool save = d->z != nullptr, drop = a.thr != 0;
-  if (p.NS == 3) {
+  if (p.NS == 5) {
+    if (d->act == TAVSR_ACT_RELU) launch_fwd<5, TAVSR_ACT_RELU>(a, save, drop, s);
+    else launch_fwd<5, TAVSR_ACT_SWISH>(a, save, drop, s);
+  } else if (p.NS == 4) {
+    if (d->act == TAVSR_ACT_RELU) launch_fwd<4, TAVSR_ACT_RELU>(a, save, drop, s);
+    else launch_fwd<4, TAVSR_ACT_SWISH>(a, save, drop, s);
+  } else {
     if (d->act == TAVSR_ACT_RELU) launch_fwd<3, TAVSR_ACT_RELU>(a, save, drop, s);
     else launch_fwd<3, TAVSR_ACT_SWISH>(a, save, drop, s);
-  } else {
-    if (d->act == TAVSR_ACT_RELU) launch_fwd<2, TAVSR_ACT_RELU>(a, save, drop, s);
-    else launch_fwd<2, TAVSR_ACT_SWISH>(a, save, drop, s);
   }
   TAVSR_LAUNCH_CHECK();
   const float* res = d->res ? d->res : d->x;
   const int64_t ldr = d->res ? d->ldr : d->ldx;
-  hipLaunchKernelGGL(ffn2_finish_kernel, dim3(cdiv(d->M, 4)), dim3(256), 0, s, d->ws, p.G, p.maxseg, p.UPR, p.U, d->b2, res, (long)ldr,
+  hipLaunchKernelGGL(ffn2_finish_kernel, dim3(cdiv(d->M, 4)), dim3(256), 0, s, d->ws, p.wpb, d->b2, res, (long)ldr,
                      d->y, d->M, d->scale, a.thr, a.inv_keep, d->seed, d->offset_out / 4, d->ln2_w[0], d->ln2_b[0], d->ln2_out[0],
                      d->ln2_w[1], d->ln2_b[1], d->ln2_out[1], d->ln2_mean, d->ln2_rstd, d->ln2_eps);
   TAVSR_LAUNCH_CHECK();

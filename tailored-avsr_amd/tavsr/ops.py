@@ -744,7 +744,7 @@ def ffn2_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=0.0, save=True, l
     n = mean = rstd = z = h = None
     if save:
         n, mean, rstd = empty(M, D, like=x), empty(M, like=x), empty(M, like=x)
-        Mp = (M + 31) // 32 * 32          # whole 32-row tiles are stored
+        Mp = (M + 127) // 128 * 128       # whole 128-row blocks are stored
         z, h = empty(Mp, N1, like=x)[:M], empty(Mp, N1, like=x)[:M]
         d.n_out, d.mean, d.rstd, d.z, d.h = (t.data_ptr() for t in (n, mean, rstd, z, h))
     tok_in = tok_out = None

@@ -45,15 +45,15 @@ def _default_plan():
 
 
 @pytest.mark.parametrize("M,N1,act,cfg", [
-    (3168, 2048, "swish", None),         # the encoder's shape (99 row tiles x 64 hidden tiles on 512 workgroups)
-    (3168, 2048, "swish", "256,3"),      # one workgroup per CU, three ring stages
-    (3168, 2048, "swish", "256,2"),
-    (3168, 2048, "swish", "333,2"),      # cuts that fall anywhere inside the row tiles
+    (3168, 2048, "swish", None),         # the encoder's shape (25 row blocks x 64 hidden tiles, 10 workgroups per block)
+    (3168, 2048, "swish", "10,3"),       # three ring stages
+    (3168, 2048, "swish", "8,5"),        # five; 8 units per workgroup
+    (3168, 2048, "swish", "13,4"),       # uneven parts (4 or 5 units), more workgroups than CUs
     (6400, 2048, "swish", None),         # both modality streams of a tailored AV layer in one call
     (1312, 2048, "relu", None),          # decoder block
-    (100, 2048, "swish", None),          # M % 32 != 0: the last row tile is padded
+    (100, 2048, "swish", None),          # M % 128 != 0: the last row block is padded
     (32, 1024, "relu", None),            # one row tile, fewer units than workgroups
-    (77, 1056, "swish", "7,2"),          # 33 hidden tiles, ranges of up to 15 units that span row tiles
+    (300, 1056, "swish", "2,3"),         # 33 hidden tiles in parts of 16 and 17 units
 ])
 def test_ffn2_forward_matches_fp64(M, N1, act, cfg):
     from tavsr import ops
@@ -80,7 +80,8 @@ def test_ffn2_forward_matches_fp64(M, N1, act, cfg):
     _close(r2, 1 / torch.sqrt(yr.var(1, unbiased=False) + 1e-12), 1e-5)
     # eval form: nothing saved, no extra LayerNorm: bitwise the same output, and run-to-run reproducible
     y2, saved, outs2, _ = ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, act, 0.5, save=False)
-    assert torch.equal(y, y2) and saved[0] is None and saved[3] is None and outs2 == []
+    _close(y2, y, 2e-6)          # (another template instantiation: same arithmetic, not necessarily the same contractions)
+    assert saved[0] is None and saved[3] is None and outs2 == []
     y3 = ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, act, 0.5, save=False)[0]
     assert torch.equal(y2, y3)
 
@@ -96,7 +97,7 @@ def test_ffn2_strided_input_rows():
     _close(y, _ref(x, ln_w, ln_b, w1, b1, w2, b2, "swish", 0.5)[-1], 5e-6)
 
 
-@pytest.mark.parametrize("cfg", [None, "256,3"])
+@pytest.mark.parametrize("cfg", [None, "3,5"])
 def test_ffn2_dropout_is_the_gemm_path_dropout(cfg):
     """Both dropout sites draw the tavsr_dropout mapping at the offsets of their tokens: the stand-alone dropout kernel
     regenerates the masks from the tokens, i.e. the GEMM-based backward pairs with this forward."""
@@ -121,7 +122,8 @@ def test_ffn2_dropout_is_the_gemm_path_dropout(cfg):
     # eval-style call of the same pass without saving: same y (the masks do not depend on what is saved)
     ops.manual_seed(99)
     y2 = ops.ffn2_fwd(x, ln_w, ln_b, 1e-12, w1, b1, w2, b2, "swish", 0.5, p=p, save=False)[0]
-    assert torch.equal(y, y2)
+    _close(y2, y, 2e-6)
+    assert torch.equal(y2 == x, y == x)               # the same elements were dropped
 
 
 def test_ffn_block_function_streaming_equals_gemm_launches():
