@@ -308,6 +308,97 @@ def tailored_stream_param_names(use_attn: bool):
     return TS_SHARED + (TS_ATTN if use_attn else TS_MLP)
 
 
+def _ts_branch_fwd(p, cfg, x1, n, mean, rstd, pos_emb, lens, B, T, need):
+    """the stream's attention OR cgMLP branch with its residual (src/encoder/audiovisual/tailored/encoder_layer.py:185-208,
+    232-256) on the already normalised rows ``n``: returns (x2, saved)."""
+    M, D = x1.shape
+    H = cfg["heads"]
+    dk = D // H
+    coeff = cfg.get("coeff", 1.0)
+    pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)      # dropout rates (0 in eval)
+    if cfg["use_attn"]:
+        qkv = ops.empty(M, 3 * D, like=x1)
+        ops.linear_group(n, [(p[f"attn.linear_{c}.weight"], p[f"attn.linear_{c}.bias"], j * D) for j, c in enumerate("qkv")],
+                         qkv)
+        pp = ops.linear(pos_emb.reshape(-1, D), p["attn.linear_pos.weight"])
+        if ops.ATTN_FUSED and dk == 64:
+            qu = qv = t_att = None
+            cx, attn = _AttnFused.fwd(qkv, 0, qkv, D, qkv, 2 * D, B, T, T, H, dk, lens, False, pos=pp,
+                                      bias_u=p["attn.pos_bias_u"].reshape(-1), bias_v=p["attn.pos_bias_v"].reshape(-1),
+                                      p_att=pa)
+        else:
+            qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
+            cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
+                                                qv=qv, p=pp, p_att=pa)
+        # residual + coeff * dropout(att)  (encoder_layer.py:196,243): the dropout rides in the GEMM epilogue
+        x2, t_br = ops.linear_drop(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], pd, alpha=coeff, res=x1)
+        return x2, (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
+    if need:
+        g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
+    else:
+        g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu"), None
+    Cn = g.shape[1] // 2
+    gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET)
+    cw = p["cgmlp.csgu.conv.weight"]
+    u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T)
+    t_u = _drop_(u, pd)                # csgu: dropout(x_r * x_g)
+    # residual + coeff * dropout(cgmlp)  (encoder_layer.py:208,256)
+    x2, t_br = ops.linear_drop(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], pd, alpha=coeff, res=x1)
+    return x2, (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
+
+
+def _ts_branch_bwd(p, cfg, saved, dx2, x1, pos_emb, lens, B, T, grp, lng, G):
+    """backward of _ts_branch_fwd: returns dx1 (the residual path included) and fills ``G`` with the branch's gradients."""
+    M, D = x1.shape
+    H = cfg["heads"]
+    dk = D // H
+    coeff = cfg.get("coeff", 1.0)
+    if cfg["use_attn"]:
+        mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br = saved
+        dbr = _drop_bwd(dx2, t_br)
+        G["attn.linear_out.weight"], G["attn.linear_out.bias"] = grp.add(dbr, cx, alpha=coeff, bias_grad=True)
+        dcx = ops.linear_dx(dbr, p["attn.linear_out.weight"], alpha=coeff)
+        dqkv = torch.empty_like(qkv)
+        dqu = ops.empty(M, D, like=dx2)
+        if qu is None:           # fused attention core
+            dqv, dp = _AttnFused.bwd(dcx, cx, attn, qkv, 0, qkv, D, qkv, 2 * D, dqu, 0, dqkv, D, dqkv, 2 * D, B, T, T, H, dk,
+                                     lens, False, pos=pp, bias_u=p["attn.pos_bias_u"].reshape(-1),
+                                     bias_v=p["attn.pos_bias_v"].reshape(-1))
+        else:
+            dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
+                                        dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
+        gu_, gv_ = ops.add2_colsum(dqu, dqv, dqkv[:, :D])
+        G["attn.pos_bias_u"], G["attn.pos_bias_v"] = gu_.view_as(p["attn.pos_bias_u"]), gv_.view_as(p["attn.pos_bias_v"])
+        G["attn.linear_pos.weight"] = ops.linear_dw(dp, pos_emb.reshape(-1, D))
+        for j, nm in enumerate(("q", "k", "v")):
+            G[f"attn.linear_{nm}.weight"], G[f"attn.linear_{nm}.bias"] = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
+        dn = ops.linear_dx_cat(dqkv, [p[f"attn.linear_{c}.weight"] for c in "qkv"])      # one K = 3D GEMM
+        dx1, G["norm_mha.weight"], G["norm_mha.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2)
+        return dx1
+    mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br = saved
+    Cn = g.shape[1] // 2
+    dbr = _drop_bwd(dx2, t_br)
+    G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = grp.add(dbr, u, alpha=coeff, bias_grad=True)
+    du = ops.linear_dx_drop(dbr, p["cgmlp.channel_proj2.weight"], t_u, alpha=coeff)
+    dg = torch.empty_like(g)
+    cw = p["cgmlp.csgu.conv.weight"]
+    dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
+    G["cgmlp.csgu.conv.weight"], G["cgmlp.csgu.conv.bias"] = gcw.view_as(cw), gcb
+    _, G["cgmlp.csgu.norm.weight"], G["cgmlp.csgu.norm.bias"] = ops.layernorm_bwd(
+        dgn, g[:, Cn:], gmean, grstd, p["cgmlp.csgu.norm.weight"], dx=dg[:, Cn:])
+    ops.act_bwd_(dg, z, "gelu")
+    G["cgmlp.channel_proj1.0.weight"], G["cgmlp.channel_proj1.0.bias"] = grp.add(dg, n, bias_grad=True)
+    dn = ops.linear_dx(dg, p["cgmlp.channel_proj1.0.weight"])
+    dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2)
+    return dx1
+
+
+_FFM = ("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight", "feed_forward_macaron.w_1.bias",
+        "feed_forward_macaron.w_2.weight", "feed_forward_macaron.w_2.bias")
+_FF = ("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias", "feed_forward.w_2.weight",
+       "feed_forward.w_2.bias")
+
+
 class TailoredStreamFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos_emb, lens, cfg, *P):
@@ -315,51 +406,16 @@ class TailoredStreamFn(torch.autograd.Function):
         p = dict(zip(names, P))
         B, T, D = x.shape
         M = B * T
-        H = cfg["heads"]
-        dk = D // H
-        act, coeff = cfg["ffn_act"], cfg.get("coeff", 1.0)
-        pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)      # dropout rates (0 in eval)
+        act = cfg["ffn_act"]
+        pd = cfg.get("p", 0.0)
         need = cfg.get("need_bwd", True)                       # set by TailoredLayerFn: does the node get a backward pass?
         x2d = x.contiguous().view(M, D)
         sv = {}
         bn = "norm_mha" if cfg["use_attn"] else "norm_cgmlp"     # the branch's LayerNorm rides in the macaron block's finishing launch
-        x1, sv["ffm"], (n,), mean, rstd = _FFN.fwd_ln(x2d, p["norm_ff_macaron.weight"], p["norm_ff_macaron.bias"],
-                                                      p["feed_forward_macaron.w_1.weight"], p["feed_forward_macaron.w_1.bias"],
-                                                      p["feed_forward_macaron.w_2.weight"], p["feed_forward_macaron.w_2.bias"],
-                                                      act, 0.5, [(p[bn + ".weight"], p[bn + ".bias"])], p=pd, save=need)
-        if cfg["use_attn"]:
-            qkv = ops.empty(M, 3 * D, like=x2d)
-            ops.linear_group(n, [(p[f"attn.linear_{c}.weight"], p[f"attn.linear_{c}.bias"], j * D) for j, c in enumerate("qkv")],
-                             qkv)
-            pp = ops.linear(pos_emb.reshape(-1, D), p["attn.linear_pos.weight"])
-            if ops.ATTN_FUSED and dk == 64:
-                qu = qv = t_att = None
-                cx, attn = _AttnFused.fwd(qkv, 0, qkv, D, qkv, 2 * D, B, T, T, H, dk, lens, False, pos=pp,
-                                          bias_u=p["attn.pos_bias_u"].reshape(-1), bias_v=p["attn.pos_bias_v"].reshape(-1),
-                                          p_att=pa)
-            else:
-                qu, qv = ops.add_head_bias(qkv[:, :D], p["attn.pos_bias_u"].reshape(-1), p["attn.pos_bias_v"].reshape(-1))
-                cx, attn, t_att = _SelfAttnCore.fwd(qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, B, T, T, H, dk, lens, False,
-                                                    qv=qv, p=pp, p_att=pa)
-            # residual + coeff * dropout(att)  (encoder_layer.py:196,243): the dropout rides in the GEMM epilogue
-            x2, t_br = ops.linear_drop(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], pd, alpha=coeff, res=x1)
-            sv["br"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
-        else:
-            if need:
-                g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
-            else:
-                g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu"), None
-            Cn = g.shape[1] // 2
-            gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET)
-            cw = p["cgmlp.csgu.conv.weight"]
-            u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T)
-            t_u = _drop_(u, pd)                # csgu: dropout(x_r * x_g)
-            # residual + coeff * dropout(cgmlp)  (encoder_layer.py:208,256)
-            x2, t_br = ops.linear_drop(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], pd, alpha=coeff, res=x1)
-            sv["br"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
-        x3, sv["ff"], (y,), fmean, frstd = _FFN.fwd_ln(x2, p["norm_ff.weight"], p["norm_ff.bias"], p["feed_forward.w_1.weight"],
-                                                       p["feed_forward.w_1.bias"], p["feed_forward.w_2.weight"],
-                                                       p["feed_forward.w_2.bias"], act, 0.5,
+        x1, sv["ffm"], (n,), mean, rstd = _FFN.fwd_ln(x2d, *[p[k] for k in _FFM], act, 0.5, [(p[bn + ".weight"], p[bn + ".bias"])],
+                                                      p=pd, save=need)
+        x2, sv["br"] = _ts_branch_fwd(p, cfg, x1, n, mean, rstd, pos_emb, lens, B, T, need)
+        x3, sv["ff"], (y,), fmean, frstd = _FFN.fwd_ln(x2, *[p[k] for k in _FF], act, 0.5,
                                                        [(p["norm_final.weight"], p["norm_final.bias"])], p=pd, save=need)
         sv["final"] = (x3, fmean, frstd)
         sv["x1"] = x1
@@ -371,9 +427,7 @@ class TailoredStreamFn(torch.autograd.Function):
         sv, cfg, p = ctx.sv, ctx.cfg, ctx.p
         B, T, D = ctx.shape
         M = B * T
-        H = cfg["heads"]
-        dk = D // H
-        act, coeff = cfg["ffn_act"], cfg.get("coeff", 1.0)
+        act = cfg["ffn_act"]
         G = {}
         grp = ops.WgradGroup()
         lng = ops.LNGroup()        # the stream's four d-wide LayerNorms: one (dgamma, dbeta) reduction
@@ -382,57 +436,24 @@ class TailoredStreamFn(torch.autograd.Function):
                                                                    p["norm_final.weight"])
         dx2, gs = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act, 0.5,
                            grp=grp, lng=lng)
-        for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
-                          "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
-            G[n_] = g
-        x1 = sv["x1"]
-        if cfg["use_attn"]:
-            mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br = sv["br"]
-            dbr = _drop_bwd(dx2, t_br)
-            G["attn.linear_out.weight"], G["attn.linear_out.bias"] = grp.add(dbr, cx, alpha=coeff, bias_grad=True)
-            dcx = ops.linear_dx(dbr, p["attn.linear_out.weight"], alpha=coeff)
-            dqkv = torch.empty_like(qkv)
-            dqu = ops.empty(M, D, like=dx2)
-            if qu is None:           # fused attention core
-                dqv, dp = _AttnFused.bwd(dcx, cx, attn, qkv, 0, qkv, D, qkv, 2 * D, dqu, 0, dqkv, D, dqkv, 2 * D, B, T, T, H, dk,
-                                         ctx.lens, False, pos=pp, bias_u=p["attn.pos_bias_u"].reshape(-1),
-                                         bias_v=p["attn.pos_bias_v"].reshape(-1))
-            else:
-                dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
-                                            dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
-            gu_, gv_ = ops.add2_colsum(dqu, dqv, dqkv[:, :D])
-            G["attn.pos_bias_u"], G["attn.pos_bias_v"] = gu_.view_as(p["attn.pos_bias_u"]), gv_.view_as(p["attn.pos_bias_v"])
-            G["attn.linear_pos.weight"] = ops.linear_dw(dp, ctx.pos_emb.reshape(-1, D))
-            for j, nm in enumerate(("q", "k", "v")):
-                G[f"attn.linear_{nm}.weight"], G[f"attn.linear_{nm}.bias"] = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
-            dn = ops.linear_dx_cat(dqkv, [p[f"attn.linear_{c}.weight"] for c in "qkv"])      # one K = 3D GEMM
-            dx1, G["norm_mha.weight"], G["norm_mha.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2)
-        else:
-            mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br = sv["br"]
-            Cn = g.shape[1] // 2
-            dbr = _drop_bwd(dx2, t_br)
-            G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = grp.add(dbr, u, alpha=coeff, bias_grad=True)
-            du = ops.linear_dx_drop(dbr, p["cgmlp.channel_proj2.weight"], t_u, alpha=coeff)
-            dg = torch.empty_like(g)
-            cw = p["cgmlp.csgu.conv.weight"]
-            dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
-            G["cgmlp.csgu.conv.weight"], G["cgmlp.csgu.conv.bias"] = gcw.view_as(cw), gcb
-            _, G["cgmlp.csgu.norm.weight"], G["cgmlp.csgu.norm.bias"] = ops.layernorm_bwd(
-                dgn, g[:, Cn:], gmean, grstd, p["cgmlp.csgu.norm.weight"], dx=dg[:, Cn:])
-            ops.act_bwd_(dg, z, "gelu")
-            G["cgmlp.channel_proj1.0.weight"], G["cgmlp.channel_proj1.0.bias"] = grp.add(dg, n, bias_grad=True)
-            dn = ops.linear_dx(dg, p["cgmlp.channel_proj1.0.weight"])
-            dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2)
+        G.update(zip(_FF, gs))
+        dx1 = _ts_branch_bwd(p, cfg, sv["br"], dx2, sv["x1"], ctx.pos_emb, ctx.lens, B, T, grp, lng, G)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p["norm_ff_macaron.weight"], p["feed_forward_macaron.w_1.weight"],
                           p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng)
-        for n_, g in zip(("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight",
-                          "feed_forward_macaron.w_1.bias", "feed_forward_macaron.w_2.weight", "feed_forward_macaron.w_2.bias"), gs):
-            G[n_] = g
+        G.update(zip(_FFM, gs))
         grp.flush()
         lng.flush()
         ctx.sv = None
         ops.join_side()
         return (dx.view(B, T, D), None, None, None, *[G[n] for n in ctx.names])
+
+
+# One feed-forward call for BOTH modality streams: the tailored layer's FFNs and three of its norms are shared by the streams
+# (src/encoder/audiovisual/tailored/encoder_layer.py:84-111, 171-175, 211-216, 220-222, 259-264), so the audio and the video
+# rows go through them as ONE [Ma + Mv, 256] problem ("one GEMM with M = 2 B T") - the streaming feed-forward kernel
+# then streams every weight once for both streams, and in the backward pass the shared parameters' gradients come out of
+# K = Ma + Mv contractions directly instead of as two partial results that are added.  TAVSR_AV_JOINT_FFN=0: per stream.
+AV_JOINT_FFN = os.environ.get("TAVSR_AV_JOINT_FFN", "1") == "1"
 
 
 class TailoredLayerFn(torch.autograd.Function):
@@ -446,20 +467,103 @@ class TailoredLayerFn(torch.autograd.Function):
         import types
         need = _note_ctx(ctx)
         cfg_a, cfg_v = dict(cfg_a, need_bwd=need), dict(cfg_v, need_bwd=need)
-        na, nv = len(tailored_stream_param_names(cfg_a["use_attn"])), len(tailored_stream_param_names(cfg_v["use_attn"]))
+        names_a, names_v = tailored_stream_param_names(cfg_a["use_attn"]), tailored_stream_param_names(cfg_v["use_attn"])
+        na, nv = len(names_a), len(names_v)
         ns = len(TS_SHARED)
         Pa, Pv = P[:na], P[:ns] + P[na: na + nv - ns]
+        D = audio.shape[-1]
+        if (AV_JOINT_FFN and audio.is_cuda and cfg_a.get("p", 0.0) == cfg_v.get("p", 0.0)
+                and ops.ffn2_usable(audio.reshape(-1, D), Pa[names_a.index("feed_forward.w_1.weight")], cfg_a["ffn_act"])):
+            return TailoredLayerFn._forward_joint(ctx, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, dict(zip(names_a, Pa)),
+                                                  dict(zip(names_v, Pv)), names_a, names_v, need)
         ca, cv = types.SimpleNamespace(), types.SimpleNamespace()
         br = ops.BranchScope(audio.is_cuda)
         with br:
             yv = TailoredStreamFn.forward(cv, video, vpos, vlens, cfg_v, *Pv)
         ya = TailoredStreamFn.forward(ca, audio, apos, alens, cfg_a, *Pa)
         br.join()
+        ctx.joint = None
         ctx.ca, ctx.cv, ctx.n = ca, cv, (ns, na, nv)
         return ya, yv
 
     @staticmethod
+    def _forward_joint(ctx, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, pa, pv, names_a, names_v, need):
+        (Ba, Ta, D), (Bv, Tv, _) = audio.shape, video.shape
+        Ma, Mv = Ba * Ta, Bv * Tv
+        act, pd = cfg_a["ffn_act"], cfg_a.get("p", 0.0)
+        xcat = ops.empty(Ma + Mv, D, like=audio)
+        ops.multi_copy_([xcat[:Ma], xcat[Ma:]], [audio.contiguous().view(Ma, D), video.contiguous().view(Mv, D)])
+        bna = "norm_mha" if cfg_a["use_attn"] else "norm_cgmlp"
+        bnv = "norm_mha" if cfg_v["use_attn"] else "norm_cgmlp"
+        # the macaron block for all rows; its finishing launch normalises them with BOTH streams' branch norms (each stream
+        # then reads its rows of its own output)
+        x1, sv_ffm, (n_a, n_v), mean, rstd = _FFN.fwd_ln(xcat, *[pa[k] for k in _FFM], act, 0.5,
+                                                         [(pa[bna + ".weight"], pa[bna + ".bias"]),
+                                                          (pv[bnv + ".weight"], pv[bnv + ".bias"])], p=pd, save=need)
+        sl = lambda t, lo, hi: None if t is None else t[lo:hi]
+        br = ops.BranchScope(True)
+        with br:
+            x2v, sv_brv = _ts_branch_fwd(pv, cfg_v, x1[Ma:], n_v[Ma:], sl(mean, Ma, Ma + Mv), sl(rstd, Ma, Ma + Mv), vpos, vlens,
+                                         Bv, Tv, need)
+        x2a, sv_bra = _ts_branch_fwd(pa, cfg_a, x1[:Ma], n_a[:Ma], sl(mean, 0, Ma), sl(rstd, 0, Ma), apos, alens, Ba, Ta, need)
+        br.join()
+        x2cat = ops.empty(Ma + Mv, D, like=audio)
+        ops.multi_copy_([x2cat[:Ma], x2cat[Ma:]], [x2a, x2v])
+        del x2a, x2v
+        x3, sv_ff, (ycat,), fmean, frstd = _FFN.fwd_ln(x2cat, *[pa[k] for k in _FF], act, 0.5,
+                                                       [(pa["norm_final.weight"], pa["norm_final.bias"])], p=pd, save=need)
+        ctx.joint = dict(pa=pa, pv=pv, names_a=names_a, names_v=names_v, cfg_a=cfg_a, cfg_v=cfg_v, ffm=sv_ffm, ff=sv_ff, bra=sv_bra,
+                         brv=sv_brv, x1=x1, final=(x3, fmean, frstd), apos=apos, vpos=vpos, alens=alens, vlens=vlens,
+                         shapes=((Ba, Ta, D), (Bv, Tv, D)))
+        return ycat[:Ma].view(Ba, Ta, D), ycat[Ma:].view(Bv, Tv, D)
+
+    @staticmethod
+    def _backward_joint(ctx, dya, dyv):
+        J = ctx.joint
+        pa, pv, cfg_a, cfg_v = J["pa"], J["pv"], J["cfg_a"], J["cfg_v"]
+        (Ba, Ta, D), (Bv, Tv, _) = J["shapes"]
+        Ma, Mv = Ba * Ta, Bv * Tv
+        act = cfg_a["ffn_act"]
+        G, Ga, Gv = {}, {}, {}
+        grp, lng = ops.WgradGroup(), ops.LNGroup()          # the shared parameters: K = Ma + Mv contractions
+        dycat = ops.empty(Ma + Mv, D, like=dya)
+        ops.multi_copy_([dycat[:Ma], dycat[Ma:]], [dya.contiguous().view(Ma, D), dyv.contiguous().view(Mv, D)])
+        x3, fmean, frstd = J["final"]
+        dx3, G["norm_final.weight"], G["norm_final.bias"] = lng.bwd(dycat, x3, fmean, frstd, pa["norm_final.weight"])
+        dx2, gs = _FFN.bwd(dx3, J["ff"], pa["norm_ff.weight"], pa["feed_forward.w_1.weight"], pa["feed_forward.w_2.weight"], act,
+                           0.5, grp=grp, lng=lng)
+        G.update(zip(_FF, gs))
+        x1 = J["x1"]
+        br = ops.BranchScope(True)
+        br.keep(J["brv"], x1, dx2)        # main-stream tensors whose last reader is on the forked stream: held until the join
+        with br:
+            grp_v, lng_v = ops.WgradGroup(), ops.LNGroup()
+            dx1v = _ts_branch_bwd(pv, cfg_v, J["brv"], dx2[Ma:], x1[Ma:], J["vpos"], J["vlens"], Bv, Tv, grp_v, lng_v, Gv)
+            grp_v.flush()
+            lng_v.flush()
+        grp_a, lng_a = ops.WgradGroup(), ops.LNGroup()
+        dx1a = _ts_branch_bwd(pa, cfg_a, J["bra"], dx2[:Ma], x1[:Ma], J["apos"], J["alens"], Ba, Ta, grp_a, lng_a, Ga)
+        grp_a.flush()
+        lng_a.flush()
+        br.join()
+        dx1cat = ops.empty(Ma + Mv, D, like=dya)
+        ops.multi_copy_([dx1cat[:Ma], dx1cat[Ma:]], [dx1a.contiguous(), dx1v.contiguous()])
+        del dx1a, dx1v
+        dx, gs = _FFN.bwd(dx1cat, J["ffm"], pa["norm_ff_macaron.weight"], pa["feed_forward_macaron.w_1.weight"],
+                          pa["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng)
+        G.update(zip(_FFM, gs))
+        grp.flush()
+        lng.flush()
+        ops.join_side()
+        ns = len(TS_SHARED)
+        ctx.joint = None
+        return (dx[:Ma].view(Ba, Ta, D), None, None, None, dx[Ma:].view(Bv, Tv, D), None, None, None, *[G[n] for n in TS_SHARED],
+                *[Ga[n] for n in J["names_a"][ns:]], *[Gv[n] for n in J["names_v"][ns:]])
+
+    @staticmethod
     def backward(ctx, dya, dyv):
+        if ctx.joint is not None:
+            return TailoredLayerFn._backward_joint(ctx, dya, dyv)
         ns, na, nv = ctx.n
         br = ops.BranchScope(dya.is_cuda)
         dyv = dyv.contiguous()
