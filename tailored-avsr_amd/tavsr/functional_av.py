@@ -452,8 +452,12 @@ class TailoredStreamFn(torch.autograd.Function):
 # (src/encoder/audiovisual/tailored/encoder_layer.py:84-111, 171-175, 211-216, 220-222, 259-264), so the audio and the video
 # rows go through them as ONE [Ma + Mv, 256] problem ("one GEMM with M = 2 B T") - the streaming feed-forward kernel
 # then streams every weight once for both streams, and in the backward pass the shared parameters' gradients come out of
-# K = Ma + Mv contractions directly instead of as two partial results that are added.  TAVSR_AV_JOINT_FFN=0: per stream.
-AV_JOINT_FFN = os.environ.get("TAVSR_AV_JOINT_FFN", "1") == "1"
+# K = Ma + Mv contractions directly instead of as two partial results that are added.
+# Measured (profiles/r03_notes.md, in-call A/B on the batch-32 AV step): 363.5-364.3 utt/s joint against 367.2-367.5 per stream -
+# the per-stream form keeps two independent launch queues (the audio stream's blocks fill the LayerNorm-prologue and
+# finishing phases of the video stream's and vice versa), which is worth more than the shared weight stream.  So the joint
+# form is built, parity-tested (tests/test_gpu_av.py) and OFF by default; TAVSR_AV_JOINT_FFN=1 selects it.
+AV_JOINT_FFN = os.environ.get("TAVSR_AV_JOINT_FFN", "0") == "1"
 
 
 class TailoredLayerFn(torch.autograd.Function):
