@@ -109,11 +109,12 @@ def test_dwconv_gate(B, T):
     _close(db, br.grad, 1e-4)
 
 
-def test_merge_learned_ave():
+@pytest.mark.parametrize("T", [23, 99, 128, 150])     # <= 128: the single-read kernel; beyond: the two-pass one
+def test_merge_learned_ave(T):
     from tavsr import ops
     torch.manual_seed(4)
-    B, T, D = 3, 23, 256
-    lens = torch.tensor([23, 17, 9], device="cuda")
+    B, D = 3, 256
+    lens = torch.tensor([T, (3 * T) // 4, max(1, T // 3)], device="cuda")
     x1, x2 = torch.randn(B, T, D, device="cuda"), torch.randn(B, T, D, device="cuda")
     prm = [torch.randn(1, D, device="cuda") / 4, torch.randn(1, D, device="cuda") / 4, torch.randn(1, device="cuda"),
            torch.randn(1, device="cuda"), torch.randn(1, D, device="cuda") / 4, torch.randn(1, D, device="cuda") / 4,
