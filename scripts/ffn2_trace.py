@@ -30,6 +30,12 @@ for cfg in sys.argv[1:] or ["10,4"]:
     names = ["start", "-", "prologue (x, LN, ring)", "units", "epilogue", "-", "drain"]
     print(f"cfg {cfg}: kernel span {(t[:, 6].max() - t0) / 100:.1f} us; per-workgroup phases in us (median / max), 100 MHz clock")
     print(f"  start skew       {np.median(t[:, 0] - t0) / 100:7.2f} / {(t[:, 0] - t0).max() / 100:7.2f}")
+    d = (t[:, 1] - t[:, 0]) / 100.0
+    print(f"    setup + issue of 36 LDS-DMA {np.median(d):7.2f} / {d.max():7.2f}")
+    d = (t[:, 5] - t[:, 1]) / 100.0
+    print(f"    wait for the rows           {np.median(d):7.2f} / {d.max():7.2f}")
+    d = (t[:, 2] - t[:, 5]) / 100.0
+    print(f"    LayerNorm, barriers, ring   {np.median(d):7.2f} / {d.max():7.2f}")
     for i, j in ((2, 0), (3, 2), (4, 3), (6, 4)):
         d = (t[:, i] - t[:, j]) / 100.0
         print(f"  {names[i]:24s} {np.median(d):7.2f} / {d.max():7.2f}")

@@ -99,13 +99,16 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
   constexpr int STG = 4096;                       // floats per stage
   constexpr int NVM = (NS - 2) * 4;               // a wave's LDS-DMA instructions that may stay in flight behind the awaited stage
   static_assert(NS >= 3 && NS <= 5, "one stage being read, one about to be, at least one in flight; NS * 16 KB + 84 KB of LDS");
-  constexpr int XSF = 4 * 4096;                   // x staging: [4 waves][32 rows][128 floats] (half a row tile per wave)
-  __shared__ __attribute__((aligned(1024))) float smem[NS * STG + XSF + kMaxU * 32 + 512];
+  // LDS: ring slot 0 | x staging [2 halves][4 waves][32 rows][128 floats] = 128 KB, which ring slots 1 .. NS-1 overlay once the
+  // rows are in registers | bias slices | LayerNorm weights
+  constexpr int XSF = 2 * 4 * 4096;
+  static_assert((NS - 1) * STG <= XSF, "ring slots 1.. live in the x staging area");
+  __shared__ __attribute__((aligned(1024))) float smem[STG + XSF + kMaxU * 32 + 512];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h2 = lane >> 5;
   float* const ring = smem;
-  float* const xs = smem + NS * STG + w * 4096;
-  float* const b1s = smem + NS * STG + XSF;
+  float* const xs = smem + STG + w * 4096;           // + half * 4 * 4096
+  float* const b1s = smem + STG + XSF;
   float* const gbs = b1s + kMaxU * 32;            // LayerNorm gamma | beta
 
   // Workgroup g = row block g / wpb, part g % wpb of that block's hidden tiles: ranges never cross a row block, so a
@@ -131,10 +134,11 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
     for (int j = 0; j < 16; ++j) {
       const int row = 2 * j + h2, pc = li;
       const float* src = a.x + (long)min(m0 + row, a.M - 1) * a.ldx + 128 * half + (((pc & ~15) | ((pc ^ row) & 15)) << 2);
-      __builtin_amdgcn_global_load_lds((glb_f*)src, (lds_f*)(xs + j * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_f*)src, (lds_f*)(xs + half * (4 * 4096) + j * 256), 16, 0, 0);
     }
   };
   issue_x(0);
+  issue_x(1);
 
   // ---- weight stream.  Stages of a unit: 0, 1 = W1[32 ih .. +32][128 s .. +128] as a [32 rows][128 floats] image (16-byte
   // chunk c of row r at chunk (c & ~15) | ((c ^ r) & 15)); 2, 3 = W2[128 (s-2) .. +128][32 ih .. +32] as four [32 rows][32 floats]
@@ -165,9 +169,7 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
 
   set_hta(0);
 #pragma unroll
-  for (int s = 0; s < NS; ++s)                    // stages 0 .. NS-1 fill the ring before anything else
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue_one(s / 4, s % 4, s, j);
+  for (int j = 0; j < 4; ++j) issue_one(0, 0, 0, j);            // stage 0 behind the rows; stages 1 .. NS-1 once the staging area is free
 #pragma unroll
   for (int it = 0; it < 4; ++it) b1s[tid + 256 * it] = bpre[it];       // kMaxU * 32 = 1024 floats
   gbs[tid] = gpre;
@@ -179,44 +181,51 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
 #define FFN2_A1(ST, G) ((ST) + li * 128 + ((((2 * (G) + h2) & ~15) | (((2 * (G) + h2) ^ li) & 15)) << 2))
   float xr[128];
   {
+    // three passes over the staged rows (sum; squared deviations; normalise): the values are read from LDS each time instead of
+    // being kept - 128 live VALU registers in the middle of the prologue push the loop's invariants out to scratch
+    stamp(a, 1);           // everything issued
+    vmwait<0>();                                  // both halves of the rows (and this wave's quarter of stage 0) have landed
+    stamp(a, 5);           // rows landed
     float s1 = 0.f;
-    vmwait<4 * NS>();                             // the first half has landed (the NS weight stages behind it may not have)
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const float4 v = lds4(FFN2_A1(xs, g));
-      xr[4 * g] = v.x; xr[4 * g + 1] = v.y; xr[4 * g + 2] = v.z; xr[4 * g + 3] = v.w;
-      s1 += (v.x + v.y) + (v.z + v.w);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    issue_x(1);                                   // second half (k 128 .. 255) over the first
-    vmwait<0>();
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float4 v = lds4(FFN2_A1(xs, g));
-      xr[64 + 4 * g] = v.x; xr[64 + 4 * g + 1] = v.y; xr[64 + 4 * g + 2] = v.z; xr[64 + 4 * g + 3] = v.w;
-      s1 += (v.x + v.y) + (v.z + v.w);
+      const float4 v = lds4(FFN2_A1(xs, g)), u = lds4(FFN2_A1(xs + 4 * 4096, g));
+      s1 += ((v.x + v.y) + (v.z + v.w)) + ((u.x + u.y) + (u.z + u.w));
     }
     const float mu = (s1 + __shfl_xor(s1, 32, 64)) * (1.f / 256.f);
     float s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 128; ++k) {
-      xr[k] -= mu;
-      s2 += xr[k] * xr[k];
+    for (int g = 0; g < 16; ++g) {
+      const float4 v = lds4(FFN2_A1(xs, g)), u = lds4(FFN2_A1(xs + 4 * 4096, g));
+      const float a0 = v.x - mu, a1 = v.y - mu, a2 = v.z - mu, a3 = v.w - mu, c0 = u.x - mu, c1 = u.y - mu, c2 = u.z - mu, c3 = u.w - mu;
+      s2 += ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3));
     }
     const float rs = rsqrtf((s2 + __shfl_xor(s2, 32, 64)) * (1.f / 256.f) + a.eps);
-    wg_barrier();                                 // gamma / beta / bias slices are in LDS; barrier 0 of the ring: stage 0 has landed
     const int m = min(m0 + li, a.M - 1);
-    const bool keepn = SAVE && part == 0 && m0 + li < a.M;    // the workgroup that holds the row block's first unit keeps LN(x)
+    // the workgroup that holds the row block's first unit keeps LN(x) (a run-time test in every variant: with the store
+    // compiled out hipcc allocates the whole kernel differently and spills 40 loop invariants)
+    const bool keepn = a.n_out != nullptr && part == 0 && m0 + li < a.M;
+    // (gamma / beta were written to LDS by all threads before this point only in program order: make them visible)
+    wg_barrier();
 #pragma unroll
     for (int g = 0; g < 32; ++g) {
+      const float4 v = lds4(FFN2_A1(xs + (g >> 4) * (4 * 4096), g & 15));
       const float4 gg = lds4(gbs + 8 * g + 4 * h2), bb = lds4(gbs + 256 + 8 * g + 4 * h2);
-      xr[4 * g] = xr[4 * g] * rs * gg.x + bb.x;
-      xr[4 * g + 1] = xr[4 * g + 1] * rs * gg.y + bb.y;
-      xr[4 * g + 2] = xr[4 * g + 2] * rs * gg.z + bb.z;
-      xr[4 * g + 3] = xr[4 * g + 3] * rs * gg.w + bb.w;
-      if (keepn && a.n_out)
+      xr[4 * g] = (v.x - mu) * rs * gg.x + bb.x;
+      xr[4 * g + 1] = (v.y - mu) * rs * gg.y + bb.y;
+      xr[4 * g + 2] = (v.z - mu) * rs * gg.z + bb.z;
+      xr[4 * g + 3] = (v.w - mu) * rs * gg.w + bb.w;
+      if (keepn)
         *reinterpret_cast<float4*>(a.n_out + (long)m * 256 + 8 * g + 4 * h2) = make_float4(xr[4 * g], xr[4 * g + 1], xr[4 * g + 2], xr[4 * g + 3]);
+      if ((g & 3) == 3) SB();       // a few loads in flight at a time: hoisting all 96 of them costs 384 registers
     }
+    // everybody holds its rows in registers and has waited for its quarter of stage 0 (barrier 0 of the ring); the staging
+    // area is free: stages 1 .. NS-1 go out over it
+    wg_barrier();
+#pragma unroll
+    for (int s_ = 1; s_ < NS; ++s_)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) issue_one(s_ / 4, s_ % 4, s_, j);
     if (keepn && a.mean && h2 == 0) { a.mean[m] = mu; a.rstd[m] = rs; }
   }
   // Ring protocol.  Stage k lives in slot k % NS.  "Barrier k" = every wave has waited for its own quarter of stage k
@@ -238,7 +247,8 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
       for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 
     // fragment addresses: W1 stage (group g: k = 8 g + 4 h2 ..), W2 stage (group i: q = i >> 2, output tile i & 3)
-#define FFN2_A2(ST, I) ((ST) + ((I) & 3) * 1024 + li * 32 + (((2 * ((I) >> 2) + h2) ^ ((li >> 1) & 7)) << 2))
+#define FFN2_A2(ST, I) ((ST) + ((I) & 3) * 1024 + lq * 32 + (((2 * ((I) >> 2) + hq) ^ ((lq >> 1) & 7)) << 2))
+#define FFN2_A1L(ST, G) ((ST) + lq * 128 + ((((2 * (G) + hq) & ~15) | (((2 * (G) + hq) ^ lq) & 15)) << 2))
     // A stage = 8 pairs of fragment groups; the fragments of pair p + 1 are read while pair p multiplies (8 MFMAs).
     // Consecutive MFMAs never share an accumulator (two chains side by side): a dependent f32 MFMA does not issue back to back.
     // Tail of a stage (pair 7): barrier POS + 1, then - in the shadow of the pair's MFMAs - the first two fragments of the
@@ -252,12 +262,12 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
           const float* stn = ring + cn * STG;                                                                           \
           SB();                                                                                                         \
           MF7A                                                                                                          \
-          ga = NEXTW1 ? lds4(FFN2_A1(stn, 0)) : lds4(FFN2_A2(stn, 0));                                                  \
+          ga = NEXTW1 ? lds4(FFN2_A1L(stn, 0)) : lds4(FFN2_A2(stn, 0));                                                  \
           issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 0);                                                             \
           issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 1);                                                             \
           SB();                                                                                                         \
           MF7B                                                                                                          \
-          gb = NEXTW1 ? lds4(FFN2_A1(stn, 1)) : lds4(FFN2_A2(stn, 1));                                                  \
+          gb = NEXTW1 ? lds4(FFN2_A1L(stn, 1)) : lds4(FFN2_A2(stn, 1));                                                  \
           issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 2);                                                             \
           issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 3);                                                             \
           SB();                                                                                                         \
@@ -266,6 +276,11 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
 
     for (; iu < nu; ++iu, ++ht) {
       set_hta(iu);
+      // lane coordinates the compiler cannot see through: the ~40 fragment addresses of a unit are then recomputed in the
+      // MFMAs' shadow instead of being hoisted out of the loop, where they cost 40 registers and - the LayerNorm prologue
+      // peaks at 128 + registers - a spill round trip each (6 us of serial scratch reloads per workgroup)
+      int lq = li, hq = h2;
+      asm volatile("" : "+v"(lq), "+v"(hq));
       // ---- phase 1: z^T tile = W1[unit] x LN(x)^T, hidden unit on the registers (j = rho(r) + 4 h2), row on the lane
       f32x16 acc1, acc1b;
 #pragma unroll
@@ -288,8 +303,8 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
         const float* st = ring + cs * STG;                                                                              \
         _Pragma("unroll") for (int p = 0; p < 7; ++p) {                                                                 \
           fa = ga; fb = gb;                                                                                             \
-          ga = lds4(FFN2_A1(st, 2 * p + 2));                                                                            \
-          gb = lds4(FFN2_A1(st, 2 * p + 3));                                                                            \
+          ga = lds4(FFN2_A1L(st, 2 * p + 2));                                                                            \
+          gb = lds4(FFN2_A1L(st, 2 * p + 3));                                                                            \
           FFN2_MF1(fa, XO, 2 * p)                                                                                       \
           FFN2_MF1(fb, XO, 2 * p + 1)                                                                                   \
           SB();                                                                                                         \
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
 #undef FFN2_TAIL
 #undef FFN2_A1
 #undef FFN2_A2
+#undef FFN2_A1L
     stamp(a, 3);
     if (threadIdx.x == 0 && (a.dbg & 2) && blockIdx.x < kTraceWG) g_ffn2_trace[blockIdx.x * kTraceN + 7] = nu;
     // ---- partial output of this (row block, unit range) -> slab slot
@@ -368,7 +384,6 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
     }
     stamp(a, 4);      // epilogue's stores issued
   }
-  stamp(a, 5);
   vmwait<0>();
   stamp(a, 6);          // the stream ran ahead of the last unit: nothing may land in LDS after this workgroup has left
 }
