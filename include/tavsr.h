@@ -287,6 +287,15 @@ typedef struct tavsr_ffn_desc {
 } tavsr_ffn_desc;
 int64_t tavsr_ffn2_ws(int32_t M, int32_t D, int32_t N1);
 int tavsr_ffn2_fwd(const tavsr_ffn_desc* d, tavsr_stream_t stream);
+/* Backward of the block w.r.t. its activations, same streaming structure: dz = ((alpha * dy) w2) * mask / keep * act'(z)
+ * [roundup128(M)][N1] (operand of w1's weight gradient; rows >= M are scratch) and dn = dz w1 [M][256] (gradient w.r.t.
+ * LN(x)).  Weights in torch Linear layout, untransposed (w1 [N1][256], w2 [256][N1]); z [>= M rows][N1] as saved by the
+ * forward; the inner mask is regenerated from (p_drop, seed_dev, offset_in).  dy is the block's output gradient with the
+ * outer mask already applied.  ws: tavsr_ffn2_ws(M, 256, N1) floats.  Replaces the two dgrad GEMMs of espnet's autograd
+ * for PositionwiseFeedForward (src/encoder/branchformer/encoder_layer.py:191-194). */
+int tavsr_ffn2_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w1, const float* w2, const float* z, int32_t act,
+                      int32_t M, int32_t D, int32_t N1, float p_drop, const uint64_t* seed_dev, uint64_t offset_in, float* dz,
+                      float* dn, float* ws, int64_t ws_floats, tavsr_stream_t stream);
 
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);

@@ -49,7 +49,7 @@ struct Ffn2Args {
   const float* x;                  // [M][ldx]
   long ldx;
   const float *ln_w, *ln_b, *W1, *b1, *W2;
-  float eps;
+  float eps, alpha;              // alpha: backward only (scale of dyd)
   float* slab;                     // [G][128][256]
   float *n_out, *mean, *rstd;      // saved LayerNorm output / statistics (null: not kept)
   float *Z, *H;                    // [roundup128(M)][N1] (SAVE)
@@ -388,6 +388,251 @@ __global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(const Ffn2Args a) {
   stamp(a, 6);          // the stream ran ahead of the last unit: nothing may land in LDS after this workgroup has left
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the block w.r.t. its activations, same structure (espnet's autograd of the block above):
+//     dz = ((alpha * dyd) W2) * mask / keep * act'(z)   [M][N1]   (operand of W1's weight gradient)
+//     dn = dz W1                                        [M][256]  (gradient w.r.t. LN(x))
+// A workgroup holds alpha * dyd of its 128 rows in registers; unit = 32 hidden units:
+//   phase 1: dh^T tile (32 hidden x 32 rows) = W2[:, unit]^T x dyd^T.  W2 is [256][N1]: a stage is the k-major image
+//            [128 k][32 hidden], a fragment value is one float per lane (lanes = hidden units, consecutive banks);
+//   the tile times act'(z) and the inner mask (z tile: 4 LDS-DMA instructions per wave and unit into a private double
+//   buffer, one unit ahead) is dz - written out once - and the A operand of
+//   phase 2: dn tile (32 rows x 256) += dz x W1[unit, :].  W1 is [N1][256]: a stage is [32 hidden][128 columns], again one
+//            float per lane (lanes = output columns).
+// No transposed weight copies (the first chain kernel, ffn.hip, needs two per call).  Four ring stages.
+// vmcnt bookkeeping (per wave, program order of one unit i; D(k) = this wave's 4 LDS-DMA instructions of stage k):
+//   tail 0: D(4i+4) | tail 1: D(4i+5), z(i+1) | 4 dz stores (during stage 2) | tail 2: D(4i+6) | tail 3: D(4i+7);
+//   prologue: z(0), D(1), D(2), D(3).  Tail p waits for D(4i+p+1) before its own issues; the operations younger than it are at
+//   least 8, 8, 16, 16 (first unit included) - the counts below.  z(i) is older than everything tail 1 of unit i leaves in flight.
+template <int S>
+__device__ __forceinline__ float4 lds4s(const float* __restrict__ p) { return make_float4(p[0], p[S], p[2 * S], p[3 * S]); }
+template <int ACT>
+__device__ __forceinline__ float dact_fast(float z) {
+  if (ACT == TAVSR_ACT_SWISH) {
+    const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+    return s * (1.f + z * (1.f - s));
+  }
+  return z > 0.f ? 1.f : 0.f;
+}
+
+template <bool DROP, int ACT>
+__global__ __launch_bounds__(256, 1) void ffn2_bwd_kernel(const Ffn2Args a) {
+  constexpr int NS = 4, STG = 4096, XSF = 2 * 4 * 4096;
+  // LDS: ring slot 0 | dyd staging (128 KB), overlaid after the prologue by ring slots 1 .. 3 and the waves' z double buffers
+  __shared__ __attribute__((aligned(1024))) float smem[STG + XSF];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h2 = lane >> 5;
+  float* const ring = smem;
+  float* const xs = smem + STG + w * 4096;           // + half * 4 * 4096
+  float* const zb = smem + STG + (NS - 1) * STG + w * 2048;       // [2][32 rows][32 floats]
+  static_assert((NS - 1) * STG + 4 * 2048 <= XSF, "ring slots 1.. and the z buffers live in the staging area");
+
+  const int UPR = a.UPR;
+  const int rb = blockIdx.x / a.wpb, part = blockIdx.x - rb * a.wpb;
+  const int ht0 = part * UPR / a.wpb;
+  const int nu = (part + 1) * UPR / a.wpb - ht0;
+  if (nu <= 0) return;
+  const int m0 = rb * kRB + 32 * w;               // this wave's row tile
+
+  auto issue_x = [&](int half) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = 2 * j + h2, pc = li;
+      const float* src = a.x + (long)min(m0 + row, a.M - 1) * a.ldx + 128 * half + (((pc & ~15) | ((pc ^ row) & 15)) << 2);
+      __builtin_amdgcn_global_load_lds((glb_f*)src, (lds_f*)(xs + half * (4 * 4096) + j * 256), 16, 0, 0);
+    }
+  };
+  issue_x(0);
+  issue_x(1);
+
+  // stages of a unit: 0, 1 = W2[128 s .. +128][32 ih .. +32] as [128 rows][32 floats]; 2, 3 = W1[32 ih .. +32][128 (s-2) .. +128]
+  // as [32 rows][128 floats]; unswizzled (every fragment read is 32 consecutive floats per half wave).  z tile of the wave:
+  // [32 rows][32 floats], 16-byte chunk c of row r at c ^ ((r >> 1) & 7).
+  int offA[4], offB[4], offZ[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    offA[j] = (32 * w + 8 * j + (lane >> 3)) * a.N1 + ((lane & 7) << 2);
+    offB[j] = (8 * w + 2 * j + (lane >> 5)) * 256 + ((lane & 31) << 2);
+    const int r = 8 * j + (lane >> 3);
+    offZ[j] = min(m0 + r, a.M - 1) * a.N1 + (((lane & 7) ^ ((r >> 1) & 7)) << 2);
+  }
+  int hta[3];
+  auto set_hta = [&](int iu_) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) hta[d] = (a.dbg & 1) ? 0 : ht0 + min(iu_ + d, nu - 1);
+  };
+  auto issue_one = [&](int du, int sub, int slot, int j) {
+    const int ih = hta[du];
+    const float* src = sub < 2 ? a.W2 + ((long)(128 * sub) * a.N1 + 32 * ih) + offA[j]
+                               : a.W1 + ((long)(32 * ih) * 256 + 128 * (sub - 2)) + offB[j];
+    __builtin_amdgcn_global_load_lds((glb_f*)src, (lds_f*)(ring + slot * STG + w * 1024 + j * 256), 16, 0, 0);
+  };
+  auto issue_z = [&](int ih, int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((glb_f*)(a.Z + 32 * ih + offZ[j]), (lds_f*)(zb + buf * 1024 + j * 256), 16, 0, 0);
+  };
+
+  set_hta(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue_one(0, 0, 0, j);
+  const uint64_t sd = DROP ? a.seed[0] : 0;
+  // ---- alpha * dyd of the wave's 32 rows into the B-operand registers: xr[4 g + j] = row li, column 8 g + 4 h2 + j
+#define FFN2_A1(ST, G) ((ST) + li * 128 + ((((2 * (G) + h2) & ~15) | (((2 * (G) + h2) ^ li) & 15)) << 2))
+  float xr[128];
+  {
+    vmwait<0>();
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const float4 v = lds4(FFN2_A1(xs + (g >> 4) * (4 * 4096), g & 15));
+      xr[4 * g] = v.x * a.alpha; xr[4 * g + 1] = v.y * a.alpha; xr[4 * g + 2] = v.z * a.alpha; xr[4 * g + 3] = v.w * a.alpha;
+      if ((g & 3) == 3) SB();
+    }
+    wg_barrier();           // rows in registers everywhere, own quarter of stage 0 landed: the staging area is free
+    issue_z(hta[0], 0);
+#pragma unroll
+    for (int s_ = 1; s_ < NS; ++s_)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) issue_one(0, s_, s_, j);
+  }
+#undef FFN2_A1
+  int cs = 0;
+  float4 fa, fb, ga, gb;
+#define FFN2_B1(ST, G) ((ST) + (8 * (G) + 4 * hq) * 32 + lq)
+#define FFN2_B2(ST, I) ((ST) + (8 * ((I) >> 2) + 4 * hq) * 128 + 32 * ((I) & 3) + lq)
+  {
+    int lq = li, hq = h2;
+    ga = lds4s<32>(FFN2_B1(ring, 0));
+    gb = lds4s<32>(FFN2_B1(ring, 1));
+  }
+  int iu = 0, ht = ht0;
+  {
+    f32x16 acc2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+
+#define FFN2_BTAIL(POS, NWAIT, NEXTP1, MF7A, MF7B)                                                                      \
+        fa = ga; fb = gb;                                                                                               \
+        vmwait<NWAIT>();                                                                                                \
+        wg_barrier();                                                                                                   \
+        {                                                                                                               \
+          const int cn = cs + 1 == NS ? 0 : cs + 1;                                                                     \
+          const float* stn = ring + cn * STG;                                                                           \
+          SB();                                                                                                         \
+          MF7A                                                                                                          \
+          ga = NEXTP1 ? lds4s<32>(FFN2_B1(stn, 0)) : lds4s<128>(FFN2_B2(stn, 0));                                       \
+          issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 0);                                                             \
+          issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 1);                                                             \
+          SB();                                                                                                         \
+          MF7B                                                                                                          \
+          gb = NEXTP1 ? lds4s<32>(FFN2_B1(stn, 1)) : lds4s<128>(FFN2_B2(stn, 1));                                       \
+          issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 2);                                                             \
+          issue_one((POS + NS) / 4, (POS + NS) % 4, cs, 3);                                                             \
+          SB();                                                                                                         \
+          cs = cn;                                                                                                      \
+        }
+
+    for (; iu < nu; ++iu, ++ht) {
+      set_hta(iu);
+      int lq = li, hq = h2;
+      asm volatile("" : "+v"(lq), "+v"(hq));
+      // ---- phase 1: dh^T tile, hidden unit on the registers (j = rho(r) + 4 h2), row on the lane
+      f32x16 acc1, acc1b;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc1b[r] = 0.f; }
+#define FFN2_MF1(F, XO, G)                                                                                              \
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(F.x, xr[XO + 4 * (G)], acc1, 0, 0, 0);                            \
+          acc1b = __builtin_amdgcn_mfma_f32_32x32x2f32(F.y, xr[XO + 4 * (G) + 1], acc1b, 0, 0, 0);                      \
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(F.z, xr[XO + 4 * (G) + 2], acc1, 0, 0, 0);                        \
+          acc1b = __builtin_amdgcn_mfma_f32_32x32x2f32(F.w, xr[XO + 4 * (G) + 3], acc1b, 0, 0, 0);
+#define FFN2_P1_STAGE(POS, XO, NEXTP1)                                                                                  \
+      {                                                                                                                 \
+        const float* st = ring + cs * STG;                                                                              \
+        _Pragma("unroll") for (int p = 0; p < 7; ++p) {                                                                 \
+          fa = ga; fb = gb;                                                                                             \
+          ga = lds4s<32>(FFN2_B1(st, 2 * p + 2));                                                                       \
+          gb = lds4s<32>(FFN2_B1(st, 2 * p + 3));                                                                       \
+          FFN2_MF1(fa, XO, 2 * p)                                                                                       \
+          FFN2_MF1(fb, XO, 2 * p + 1)                                                                                   \
+          SB();                                                                                                         \
+        }                                                                                                               \
+        FFN2_BTAIL(POS, 8, NEXTP1, FFN2_MF1(fa, XO, 14), FFN2_MF1(fb, XO, 15))                                          \
+      }
+      FFN2_P1_STAGE(0, 0, true)
+      FFN2_P1_STAGE(1, 64, false)
+#undef FFN2_P1_STAGE
+#undef FFN2_MF1
+      issue_z(hta[1], (iu + 1) & 1);              // next unit's z tile, right behind D(4 iu + 5)
+      // ---- dz = dh * act'(z) * mask / keep in place: av[4 q + e] = dz[row li][hidden 8 q + 4 h2 + e] - the A operand of phase 2
+      float av[16];
+      uint32_t wv[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      float4 zq;
+      const float* zt = zb + (iu & 1) * 1024 + li * 32;
+      auto activate = [&](int q, int e) {
+        const long e0 = (long)(m0 + li) * a.N1 + 32 * ht + 8 * q + 4 * h2;
+        if (e == 0) {
+          zq = lds4(zt + (((2 * q + h2) ^ ((li >> 1) & 7)) << 2));
+          if (DROP) {
+            const uint64_t ctr = a.offset4 + ((uint64_t)e0 >> 2);
+            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), wv);
+          }
+        }
+        const float zv = e == 0 ? zq.x : e == 1 ? zq.y : e == 2 ? zq.z : zq.w;
+        av[4 * q + e] = acc1[4 * q + e] * dact_fast<ACT>(zv) * ((!DROP || wv[e] >= a.thr) ? a.inv_keep : 0.f);
+        if (e == 3)       // rows >= M exist in the buffer (roundup128(M) rows): unconditional 16-byte stores
+          *reinterpret_cast<float4*>(a.H + e0) = make_float4(av[4 * q], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]);
+      };
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) activate(0, e);
+      // ---- phase 2: dn tile += dz x W1[unit, :], 4 + 4 output tiles of 32 columns
+#define FFN2_M2(AVI, X, Y, T0)                                                                                          \
+          acc2[T0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[AVI], X, acc2[T0], 0, 0, 0);                               \
+          acc2[(T0) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[AVI], Y, acc2[(T0) + 1], 0, 0, 0);
+#define FFN2_MF2A(FA, FB, NT0, P)                                                                                       \
+          FFN2_M2(4 * ((P) >> 1), FA.x, FB.x, NT0 + 2 * ((P) & 1))                                                      \
+          FFN2_M2(4 * ((P) >> 1) + 1, FA.y, FB.y, NT0 + 2 * ((P) & 1))
+#define FFN2_MF2B(FA, FB, NT0, P)                                                                                       \
+          FFN2_M2(4 * ((P) >> 1) + 2, FA.z, FB.z, NT0 + 2 * ((P) & 1))                                                  \
+          FFN2_M2(4 * ((P) >> 1) + 3, FA.w, FB.w, NT0 + 2 * ((P) & 1))
+#define FFN2_P2_STAGE(POS, NT0, ACTIVATE, NEXTP1)                                                                       \
+      {                                                                                                                 \
+        const float* st = ring + cs * STG;                                                                              \
+        _Pragma("unroll") for (int p = 0; p < 7; ++p) {                                                                 \
+          fa = ga; fb = gb;                                                                                             \
+          ga = lds4s<128>(FFN2_B2(st, 2 * p + 2));                                                                      \
+          gb = lds4s<128>(FFN2_B2(st, 2 * p + 3));                                                                      \
+          FFN2_MF2A(fa, fb, NT0, p)                                                                                     \
+          FFN2_MF2B(fa, fb, NT0, p)                                                                                     \
+          if (ACTIVATE && p < 6) { activate((p >> 1) + 1, 2 * (p & 1)); activate((p >> 1) + 1, 2 * (p & 1) + 1); }      \
+          SB();                                                                                                         \
+        }                                                                                                               \
+        FFN2_BTAIL(POS, 16, NEXTP1, FFN2_MF2A(fa, fb, NT0, 7), FFN2_MF2B(fa, fb, NT0, 7))                               \
+      }
+      FFN2_P2_STAGE(2, 0, true, false)
+      FFN2_P2_STAGE(3, 4, false, true)
+#undef FFN2_P2_STAGE
+#undef FFN2_MF2A
+#undef FFN2_MF2B
+#undef FFN2_M2
+    }
+#undef FFN2_BTAIL
+#undef FFN2_B1
+#undef FFN2_B2
+    {
+      float* out = a.slab + ((long)blockIdx.x * kRB + 32 * w) * 256;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(rho(r) + 4 * h2) * 256 + 32 * t + li] = acc2[t][r];
+    }
+  }
+  vmwait<0>();
+}
+
 // y = res + scale * dropout(sum of the row block's partials + bias); optional LayerNorms of y.  One wave per row.
 __global__ __launch_bounds__(256) void ffn2_finish_kernel(const float* __restrict__ slab, int wpb,
                                                           const float* __restrict__ bias, const float* __restrict__ res, long ldr,
@@ -539,6 +784,44 @@ extern "C" int tavsr_ffn2_fwd(const tavsr_ffn_desc* d, tavsr_stream_t stream) {
   hipLaunchKernelGGL(ffn2_finish_kernel, dim3(cdiv(d->M, 4)), dim3(256), 0, s, d->ws, p.wpb, d->b2, res, (long)ldr,
                      d->y, d->M, d->scale, a.thr, a.inv_keep, d->seed, d->offset_out / 4, d->ln2_w[0], d->ln2_b[0], d->ln2_out[0],
                      d->ln2_w[1], d->ln2_b[1], d->ln2_out[1], d->ln2_mean, d->ln2_rstd, d->ln2_eps);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_ffn2_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w1, const float* w2, const float* z,
+                                 int32_t act, int32_t M, int32_t D, int32_t N1, float p_drop, const uint64_t* seed_dev,
+                                 uint64_t offset_in, float* dz, float* dn, float* ws, int64_t ws_floats, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(M > 0 && D == 256 && N1 >= 1024 && N1 % 32 == 0, TAVSR_EUNSUPPORTED,
+                "ffn2_bwd_dx: d_model 256 and a hidden size >= 1024 that is a multiple of 32 (got %d, %d)", D, N1);
+  TAVSR_REQUIRE(act == TAVSR_ACT_RELU || act == TAVSR_ACT_SWISH, TAVSR_EUNSUPPORTED, "ffn2_bwd_dx: ReLU or Swish only");
+  TAVSR_REQUIRE(dy && w1 && w2 && z && dz && dn && ws, TAVSR_EINVAL, "ffn2_bwd_dx: null operand");
+  TAVSR_REQUIRE(al16(dy) && al16(w1) && al16(w2) && al16(z) && al16(dz) && al16(dn) && al16(ws) && lddy % 4 == 0, TAVSR_EINVAL,
+                "ffn2_bwd_dx: operands must be 16-byte aligned");
+  TAVSR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_dev) && offset_in % 4 == 0, TAVSR_EINVAL,
+                "ffn2_bwd_dx: dropout needs p in [0, 1), a device seed and an offset %% 4 == 0");
+  Plan p = ffn2_plan(M, N1);
+  TAVSR_REQUIRE(ws_floats >= (int64_t)p.G * kRB * 256, TAVSR_EINVAL, "ffn2_bwd_dx: workspace too small (tavsr_ffn2_ws)");
+  Ffn2Args a{};
+  a.M = M; a.N1 = N1; a.G = p.G; a.UPR = p.UPR; a.wpb = p.wpb; a.act = act;
+  a.x = dy; a.ldx = lddy; a.alpha = alpha; a.W1 = w1; a.W2 = w2; a.slab = ws; a.Z = const_cast<float*>(z); a.H = dz;
+  a.thr = p_drop > 0.f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  a.inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  a.seed = seed_dev; a.offset4 = offset_in / 4;
+  if (const char* e = getenv("TAVSR_FFN2_DBG")) a.dbg = atoi(e) & 1;
+  hipStream_t s = (hipStream_t)stream;
+  const bool drop = a.thr != 0;
+  dim3 grid(a.G);
+  if (act == TAVSR_ACT_RELU) {
+    if (drop) hipLaunchKernelGGL((ffn2_bwd_kernel<true, TAVSR_ACT_RELU>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ffn2_bwd_kernel<false, TAVSR_ACT_RELU>), grid, dim3(256), 0, s, a);
+  } else {
+    if (drop) hipLaunchKernelGGL((ffn2_bwd_kernel<true, TAVSR_ACT_SWISH>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ffn2_bwd_kernel<false, TAVSR_ACT_SWISH>), grid, dim3(256), 0, s, a);
+  }
+  TAVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ffn2_finish_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, ws, p.wpb, (const float*)nullptr, (const float*)nullptr,
+                     0L, dn, M, 1.f, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0, (const float*)nullptr, (const float*)nullptr,
+                     (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -107,9 +107,11 @@ class _FFN:
         return y, saved, outs, m2, r2
 
     @staticmethod
-    def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None, lng=None):
+    def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None, lng=None, chain=True):
         """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2).  ``grp`` (ops.WgradGroup)
-        defers the two weight gradients to the caller's grouped launch."""
+        defers the two weight gradients to the caller's grouped launch.  ``chain``: the two activation gradients as one
+        streaming launch (ops.ffn2_bwd_dx) instead of two dgrad GEMMs - callers that run two of these blocks side by side
+        on two launch queues pass False (a chain kernel owns every CU; two of them serialise, two GEMM sequences overlap)."""
         fused = saved[0] == "fused" if isinstance(saved[0], str) else False
         if fused:
             saved = saved[1:]
@@ -117,12 +119,15 @@ class _FFN:
         wgrad = ops.linear_dw if grp is None else grp.add
         dyd = _drop_bwd(dy, t_out)
         gw2, gb2 = wgrad(dyd, h, alpha=scale, bias_grad=True)
+        stream2 = chain and not fused and ops.FFN2_BWD and ops.ffn2_shape_ok(dyd, w1, act) and z.is_contiguous()
         if fused:
             dz, dn = ops.ffn_bwd_dx(dyd, scale, w1, w2, z, act, t_in)
+        elif stream2:
+            dz, dn = ops.ffn2_bwd_dx(dyd, scale, w1, w2, z, act, t_in)
         else:
             dz = ops.linear_dx_drop(dyd, w2, t_in, alpha=scale, DZ=z, dact=act)    # inner mask and act'(z) in the epilogue
         gw1, gb1 = wgrad(dz, n, bias_grad=True)
-        if not fused:
+        if not fused and not stream2:
             dn = ops.linear_dx(dz, w1)
         ln_bwd = ops.layernorm_bwd if lng is None else lng.bwd      # lng: the node's shared (dgamma, dbeta) reduction
         dx, gln_w, gln_b = ln_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)

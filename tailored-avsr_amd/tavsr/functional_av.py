@@ -434,12 +434,14 @@ class TailoredStreamFn(torch.autograd.Function):
         x3, fmean, frstd = sv["final"]
         dx3, G["norm_final.weight"], G["norm_final.bias"] = lng.bwd(dy.contiguous().view(M, D), x3, fmean, frstd,
                                                                    p["norm_final.weight"])
+        # chain=False: the two modality streams run side by side (measured on the AV step: 367.9 utt/s with the dgrad GEMMs,
+        # 365.3 with the streaming launch, which cannot share the chip with the other stream's kernels)
         dx2, gs = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act, 0.5,
-                           grp=grp, lng=lng)
+                           grp=grp, lng=lng, chain=False)
         G.update(zip(_FF, gs))
         dx1 = _ts_branch_bwd(p, cfg, sv["br"], dx2, sv["x1"], ctx.pos_emb, ctx.lens, B, T, grp, lng, G)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p["norm_ff_macaron.weight"], p["feed_forward_macaron.w_1.weight"],
-                          p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng)
+                          p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng, chain=False)
         G.update(zip(_FFM, gs))
         grp.flush()
         lng.flush()

@@ -717,10 +717,15 @@ def ffn_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
 # through per-wave LDS-DMA rings, + a finishing launch that can also emit the LayerNorms the consumers of y start with.
 # TAVSR_FFN2=0 keeps the LayerNorm + GEMM + GEMM launches.
 FFN2 = os.environ.get("TAVSR_FFN2", "1") == "1"
+FFN2_BWD = os.environ.get("TAVSR_FFN2_BWD", "1") == "1"      # the dgrad pair of the block as the streaming kernel too
 
 
 def ffn2_usable(x, w1, act) -> bool:
-    return (FFN2 and x.dim() == 2 and x.shape[1] == 256 and w1.shape[0] >= 1024 and w1.shape[0] % 32 == 0
+    return FFN2 and ffn2_shape_ok(x, w1, act)
+
+
+def ffn2_shape_ok(x, w1, act) -> bool:
+    return (x.dim() == 2 and x.shape[1] == 256 and w1.shape[0] >= 1024 and w1.shape[0] % 32 == 0
             and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w1.is_contiguous()
             and act in ("relu", "swish"))
 
@@ -767,6 +772,23 @@ def ffn2_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=0.0, save=True, l
     d.ws, d.ws_floats = ws.data_ptr(), nws
     check(lib().tavsr_ffn2_fwd(C.byref(d), stream()), "tavsr_ffn2_fwd")
     return y, (n, mean, rstd, z, h, tok_in, tok_out), outs, (m2, r2)
+
+
+def ffn2_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
+    """(dz [M, N1], dn [M, 256]) of the block: dz = ((alpha * dyd) w2) * mask / keep * act'(z), dn = dz w1 - the streaming
+    counterpart of linear_dx_drop + linear_dx (weights untransposed)."""
+    M, D = dyd.shape
+    N1 = w1.shape[0]
+    require_cuda(dyd, w1, w2, z)
+    assert w1.is_contiguous() and w2.is_contiguous() and z.is_contiguous() and z.shape == (M, N1)
+    dz, dn = empty((M + 127) // 128 * 128, N1, like=dyd)[:M], empty(M, D, like=dyd)
+    nws = lib_i64("tavsr_ffn2_ws", M, D, N1)
+    ws = empty(nws, like=dyd)
+    check(lib().tavsr_ffn2_bwd_dx(ptr(dyd), C.c_int64(dyd.stride(0)), C.c_float(alpha), ptr(w1), ptr(w2), ptr(z), ACT[act], M, D,
+                                  N1, C.c_float(tok_in[0] if tok_in else 0.0), ptr(tok_in[2] if tok_in else None),
+                                  C.c_uint64(tok_in[1] if tok_in else 0), ptr(dz), ptr(dn), ptr(ws), C.c_int64(nws), stream()),
+          "tavsr_ffn2_bwd_dx")
+    return dz, dn
 
 
 def axpby(x, y=None, a=1.0, b=1.0, out=None):

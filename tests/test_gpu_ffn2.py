@@ -126,6 +126,39 @@ def test_ffn2_dropout_is_the_gemm_path_dropout(cfg):
     assert torch.equal(y2 == x, y == x)               # the same elements were dropped
 
 
+@pytest.mark.parametrize("M,N1,act,p,cfg", [
+    (3168, 2048, "swish", 0.0, None),
+    (3168, 2048, "swish", 0.1, "13,4"),
+    (1312, 2048, "relu", 0.1, None),
+    (100, 2048, "swish", 0.0, None),       # padded last row block; z handed over with exactly M rows
+    (300, 1056, "relu", 0.2, "2,4"),
+])
+def test_ffn2_backward_dx_matches_fp64(M, N1, act, p, cfg):
+    """tavsr_ffn2_bwd_dx: dz = ((alpha dyd) w2) * mask / keep * act'(z), dn = dz w1 against fp64 autograd of the same
+    expression (the mask regenerated from the token by the stand-alone dropout kernel)."""
+    from tavsr import ops
+    if cfg:
+        os.environ["TAVSR_FFN2_CFG"] = cfg
+    D = 256
+    _, _, w1, _, w2, _ = _params(D, N1, seed=M + 1)
+    z = torch.randn(M, N1, device="cuda") * 1.5
+    dyd = torch.randn(M, D, device="cuda")
+    ops.manual_seed(5)
+    tok = ops._new_token(p, M * N1, z.device) if p else None
+    dz, dn = ops.ffn2_bwd_dx(dyd, 0.5, w1, w2, z, act, tok)
+    zd = z.double().requires_grad_(True)
+    _act(act, zd).backward(torch.ones_like(zd))
+    dact = zd.grad
+    mask = torch.ones(M, N1, device="cuda", dtype=torch.double)
+    if p:
+        mask = (ops.dropout(torch.ones(M, N1, device="cuda"), p, token=tok)[0] != 0).double() / (1 - p)
+    dzr = (0.5 * dyd.double()) @ w2.double() * mask * dact
+    _close(dz, dzr, 5e-6)
+    _close(dn, dzr @ w1.double(), 5e-6)
+    dz2, dn2 = ops.ffn2_bwd_dx(dyd, 0.5, w1, w2, z, act, tok)
+    assert torch.equal(dz, dz2) and torch.equal(dn, dn2)
+
+
 def test_ffn_block_function_streaming_equals_gemm_launches():
     """functional._FFN forward + backward with the streaming forward against the LayerNorm + GEMM + GEMM launches, with the
     recipe's dropout on: same masks, so outputs and every gradient agree."""
@@ -135,15 +168,16 @@ def test_ffn_block_function_streaming_equals_gemm_launches():
     ln_w, ln_b, w1, b1, w2, b2 = _params(D, N1, seed=5)
     x, dy = torch.randn(M, D, device="cuda"), torch.randn(M, D, device="cuda")
     res = []
-    keep = ops.FFN2
-    for fused in (True, False):
-        ops.FFN2 = fused
+    keep = ops.FFN2, ops.FFN2_BWD
+    for fused, fused_bwd in ((True, True), (False, False), (True, False), (False, True)):
+        ops.FFN2, ops.FFN2_BWD = fused, fused_bwd
         ops.manual_seed(4242)
         try:
             y, saved = F_._FFN.fwd(x, ln_w, ln_b, w1, b1, w2, b2, "swish", 0.5, p=0.1)
             dx, grads = F_._FFN.bwd(dy, saved, ln_w, w1, w2, "swish", 0.5)
         finally:
-            ops.FFN2 = keep
+            ops.FFN2, ops.FFN2_BWD = keep
         res.append((y, dx) + tuple(grads))
-    for a, b in zip(*res):
-        _close(a, b, 2e-5)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            _close(a, b, 2e-5)
