@@ -49,7 +49,7 @@ def hbm_traffic(layout_key):
     """HBM bytes per launch of the dominant GEMM family, from the committed rocprofv3 PMC pass over this same step
     (scripts/gpu_pmc_hbm.sh -> profiles/summarize_pmc.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes).  PMC
     counters cannot be read from inside the process, so this is the profile's number, or None if it is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_av_v4.json" if WORKLOAD == "avsr" else "r02_pmc_hbm_asr_v4.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_hbm_av.json" if WORKLOAD == "avsr" else "r03_pmc_hbm_asr.json")
     if not os.path.exists(path):
         return None
     ak, bkm = {"NT": ("false", "false"), "NN": ("false", "true"), "TN": ("true", "true"), "TT": ("true", "false")}[layout_key[-3:-1]]
@@ -318,6 +318,42 @@ def main():
         loss.backward()
         return loss
 
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t)
+        return x
+
+    eager_out = None
+    if not args.no_graph and not args.no_eager:
+        # the same step as eager launches (what a ragged, un-captured training loop pays): reported beside the graph number.
+        # Taken BEFORE the capture, in the allocator / interpreter state a training loop would run in.
+        n_eager = max(3, args.steps // 4)
+        buckets.overlap = True
+
+        def eager_step():
+            buckets.begin_step()
+            fwd_bwd()
+            buckets.allreduce_mean()
+
+        for _ in range(3):
+            eager_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_eager):
+            eager_step()
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        eager_out = {"value": round(B_PER_GPU * world * n_eager / el, 2), "unit": "utterances/s",
+                     "ms_per_step": round(1e3 * el / n_eager, 3), "steps": n_eager}
+        buckets.overlap = args.no_graph
+
     graph = None
     static_loss = None
     if not args.no_graph:
@@ -344,18 +380,6 @@ def main():
             buckets.begin_step()       # the hooks enqueue buckets under the backward pass
             fwd_bwd()
         buckets.allreduce_mean()
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        if world > 1:
-            t = torch.tensor([x], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            return float(t)
-        return x
 
     for _ in range(args.warmup):
         step()
@@ -429,26 +453,8 @@ def main():
     if exposed_ms is not None:
         out["grad_exchange_exposed_ms_per_step"] = round(exposed_ms, 3)
 
-    if graph is not None and not args.no_eager:
-        # the same step as eager launches (what a ragged, un-captured training loop pays): reported beside the graph number
-        n_eager = max(3, args.steps // 4)
-        buckets.overlap = True
-
-        def eager_step():
-            buckets.begin_step()
-            fwd_bwd()
-            buckets.allreduce_mean()
-
-        for _ in range(2):
-            eager_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n_eager):
-            eager_step()
-        barrier()
-        el = max_over_ranks(time.perf_counter() - t0)
-        out["eager"] = {"value": round(B_PER_GPU * world * n_eager / el, 2), "unit": "utterances/s",
-                        "ms_per_step": round(1e3 * el / n_eager, 3), "steps": n_eager}
+    if eager_out is not None:
+        out["eager"] = eager_out
 
     buckets.overlap = False       # the legs below run on rank 0 alone: no collective may leave from a hook
     if rank == 0 and not args.no_roofline:

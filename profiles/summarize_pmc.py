@@ -13,7 +13,7 @@ path = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 agg = {}
 for row in csv.DictReader(open(path)):
-    name = re.sub(r"\(.*$", "", row["Kernel_Name"])
+    name = re.sub(r"\(.*$", "", row["Kernel_Name"].replace("(anonymous namespace)::", ""))
     a = agg.setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "disp": set()})
     if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
         a[row["Counter_Name"]] += float(row["Counter_Value"])

@@ -18,7 +18,7 @@ csv.field_size_limit(1 << 30)
 PEAK = 157.3e12
 agg, dur = {}, {}
 for row in csv.DictReader(open(sys.argv[1])):
-    name = re.sub(r"\(.*$", "", row["Kernel_Name"])
+    name = re.sub(r"\(.*$", "", row["Kernel_Name"].replace("(anonymous namespace)::", ""))
     a = agg.setdefault(name, {"disp": set()})
     a[row["Counter_Name"]] = a.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
     a["disp"].add(row["Dispatch_Id"])
@@ -27,7 +27,7 @@ for row in csv.DictReader(open(sys.argv[1])):
 if len(sys.argv) > 2:
     try:
         for row in csv.DictReader(open(sys.argv[2])):
-            name = re.sub(r"\(.*$", "", row["Kernel_Name"])
+            name = re.sub(r"\(.*$", "", row["Kernel_Name"].replace("(anonymous namespace)::", ""))
             dur.setdefault(name, {})[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
     except FileNotFoundError:
         pass

@@ -9,7 +9,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = db.execute("select name, start, end from kernels").fetchall()
 agg = {}
 for name, s, e in rows:
-    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", ""))
     a = agg.setdefault(name, [0, 0, 1 << 62, 0])
     d = e - s
     a[0] += 1

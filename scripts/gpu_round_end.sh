@@ -20,3 +20,8 @@ timeout 900 python bench_decode.py --utterances 512 --batch 256 --no-cpu-baselin
 bash scripts/gpu_decode_prof.sh 1 | head -12
 bash scripts/gpu_decode_prof.sh 64 | head -12
 timeout 600 python scripts/fwd_breakdown.py > gpurun_out/fwd_breakdown.txt 2>&1; head -14 gpurun_out/fwd_breakdown.txt | cut -c1-150
+timeout 300 python scripts/ffn2_bench.py > gpurun_out/ffn2_bench.txt 2>&1; tail -12 gpurun_out/ffn2_bench.txt
+timeout 300 python scripts/ffn2_bwd_bench.py > gpurun_out/ffn2_bwd_bench.txt 2>&1; tail -8 gpurun_out/ffn2_bwd_bench.txt
+timeout 300 python scripts/attn_bench.py > gpurun_out/attn_bench.txt 2>&1; tail -6 gpurun_out/attn_bench.txt
+timeout 300 python scripts/eager_host_profile.py > gpurun_out/eager_host_profile.txt 2>&1; head -5 gpurun_out/eager_host_profile.txt
+du -sh gpurun_out
