@@ -338,6 +338,9 @@ int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int64_t* lens, 
                          const float* const* params,
                          float* score, float* pooled, float* w, int32_t B, int32_t T, int32_t D,
                          tavsr_stream_t stream);
+/* pool_fwd + combine (one launch for T <= 128, D = 256: the rows are read once) */
+int tavsr_merge_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2, const float* const* params,
+                    float* score, float* pooled, float* w, float* out, int32_t B, int32_t T, int32_t D, tavsr_stream_t stream);
 int tavsr_merge_combine(const float* x1, const float* x2, const float* w, float* out, int32_t B, int32_t T,
                         int32_t D, tavsr_stream_t stream);
 int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D);

@@ -455,8 +455,10 @@ __global__ __launch_bounds__(1024) void merge_pool_fwd_t128_kernel(const float* 
                                                                    const int64_t* __restrict__ lens,
                                                                    const int64_t* __restrict__ lens2, MergeParams p,
                                                                    float* __restrict__ score, float* __restrict__ pooled,
-                                                                   float* __restrict__ wout, int B, int T) {
+                                                                   float* __restrict__ wout, float* __restrict__ mix, int B, int T) {
   constexpr int D = 256, R = 16;
+  // mix != null: the weighted sum of the two branches (merge_combine) from the same registers - no second pass over the rows
+  __shared__ __attribute__((aligned(16))) float s_x2[128 * D];
   __shared__ float s_sc[2][128];
   __shared__ float s_red[2][8];
   __shared__ float s_w[2];
@@ -471,7 +473,8 @@ __global__ __launch_bounds__(1024) void merge_pool_fwd_t128_kernel(const float* 
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int t = wv + 8 * i;
-    xv[i] = t < len ? *reinterpret_cast<const float4*>(x + (int64_t)t * D + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (rows len <= t < T take no part in the statistics - every use below tests t < len - but the combination covers them)
+    xv[i] = t < T ? *reinterpret_cast<const float4*>(x + (int64_t)t * D + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float4 wp = *reinterpret_cast<const float4*>(p.wp[k] + 4 * lane);
   const float bias = p.bp[k][0], inv_sqrt_d = 1.f / 16.f;
@@ -517,11 +520,34 @@ __global__ __launch_bounds__(1024) void merge_pool_fwd_t128_kernel(const float* 
     s_w[k] = t + p.bw[k][0];
   }
   __syncthreads();
+  const float m = fmaxf(s_w[0], s_w[1]);
+  const float e0 = expf(s_w[0] - m), e1 = expf(s_w[1] - m);
+  const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
   if (threadIdx.x == 0) {
-    const float m = fmaxf(s_w[0], s_w[1]);
-    const float e0 = expf(s_w[0] - m), e1 = expf(s_w[1] - m);
-    wout[b * 2 + 0] = e0 / (e0 + e1);
-    wout[b * 2 + 1] = e1 / (e0 + e1);
+    wout[b * 2 + 0] = w0;
+    wout[b * 2 + 1] = w1;
+  }
+  if (mix) {        // the second branch's waves park w1 * x2 in LDS, the first branch's waves add w0 * x1 and store
+    if (k == 1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int t = wv + 8 * i;
+        if (t < T) *reinterpret_cast<float4*>(&s_x2[t * D + 4 * lane]) = make_float4(w1 * xv[i].x, w1 * xv[i].y, w1 * xv[i].z, w1 * xv[i].w);
+      }
+    }
+    __syncthreads();
+    if (k == 0) {
+      float* o = mix + (int64_t)b * T * D;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int t = wv + 8 * i;
+        if (t < T) {
+          const float4 c = *reinterpret_cast<const float4*>(&s_x2[t * D + 4 * lane]);
+          *reinterpret_cast<float4*>(o + (int64_t)t * D + 4 * lane) =
+              make_float4(w0 * xv[i].x + c.x, w0 * xv[i].y + c.y, w0 * xv[i].z + c.z, w0 * xv[i].w + c.w);
+        }
+      }
+    }
   }
 }
 
@@ -722,7 +748,7 @@ extern "C" int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int6
                 "merge_pool_fwd: D %% 4 == 0 and 16-byte aligned rows required");
   if (T <= 128 && D == 256) {       // rows read once, held in registers through both passes
     hipLaunchKernelGGL(merge_pool_fwd_t128_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x1, x2, lens, lens2, mk(params),
-                       score, pooled, w, B, T);
+                       score, pooled, w, (float*)nullptr, B, T);
     TAVSR_LAUNCH_CHECK();
     return TAVSR_OK;
   }
@@ -744,6 +770,25 @@ extern "C" int tavsr_merge_combine(const float* x1, const float* x2, const float
                      total4, (int)((int64_t)T * D / 4));
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
+}
+
+// pool + combine; one launch when the rows fit the single-read kernel (T <= 128, D = 256), else the two launches above
+extern "C" int tavsr_merge_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
+                               const float* const* params, float* score, float* pooled, float* w, float* out, int32_t B,
+                               int32_t T, int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(out, TAVSR_EINVAL, "merge_fwd: null output");
+  if (B > 0 && T <= 128 && D == 256) {
+    TAVSR_REQUIRE(x1 && x2 && params && score && pooled && w, TAVSR_EINVAL, "merge_fwd: null pointer");
+    for (int i = 0; i < 8; ++i) TAVSR_REQUIRE(params[i], TAVSR_EINVAL, "merge_fwd: null parameter %d", i);
+    TAVSR_REQUIRE(((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0) && ((uintptr_t)out % 16 == 0), TAVSR_EALIGN,
+                  "merge_fwd: 16-byte aligned rows required");
+    hipLaunchKernelGGL(merge_pool_fwd_t128_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x1, x2, lens, lens2, mk(params),
+                       score, pooled, w, out, B, T);
+    TAVSR_LAUNCH_CHECK();
+    return TAVSR_OK;
+  }
+  int rc = tavsr_merge_pool_fwd(x1, x2, lens, lens2, params, score, pooled, w, B, T, D, stream);
+  return rc ? rc : tavsr_merge_combine(x1, x2, w, out, B, T, D, stream);
 }
 
 extern "C" int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D) { return (int64_t)(B + 1) * (4 * D + 4); }

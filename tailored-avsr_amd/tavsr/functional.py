@@ -352,8 +352,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             mp = [p(k) for k in ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias",
                                  "pooling_proj2.bias", "weight_proj1.weight", "weight_proj2.weight",
                                  "weight_proj1.bias", "weight_proj2.bias")]
-            score, pooled, wts = ops.merge_pool_fwd(xa, xm, lens, mp, B, T)
-            m = ops.merge_combine(xa, xm, wts, B, T)
+            score, pooled, wts, m = ops.merge_fwd(xa, xm, lens, mp, B, T)       # pooling + weighted sum: one launch for T <= 128
             sv["merge"] = (score, pooled, wts, m)
         elif two and merge == "fixed_ave":
             cw_ = cfg["cgmlp_weight"]

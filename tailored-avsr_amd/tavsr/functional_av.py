@@ -672,8 +672,7 @@ class FusionFn(torch.autograd.Function):
             ops.copy2d(a2, m[:, :D])
             ops.copy2d(v2, m[:, D:])
         else:
-            score, pooled, wts = ops.merge_pool_fwd(a2, v2, alens, mp[:8], B, T, lens2=vlens)
-            m = ops.merge_combine(a2, v2, wts, B, T)
+            score, pooled, wts, m = ops.merge_fwd(a2, v2, alens, mp[:8], B, T, lens2=vlens)
         h, z = ops.linear(m, w1, b1, act=cfg["act"], save_z=True)
         t_in = _drop_(h, cfg.get("p", 0.0))       # PositionwiseFeedForward's inner dropout (the fusion has no outer one)
         y2 = ops.linear(h, w2, b2)

@@ -863,6 +863,18 @@ def merge_pool_fwd(x1, x2, lens, params, B, T, lens2=None):
     return score, pooled, w
 
 
+def merge_fwd(x1, x2, lens, params, B, T, lens2=None):
+    """merge_pool_fwd + merge_combine: (score, pooled, w, w[:, 0] * x1 + w[:, 1] * x2)."""
+    D = x1.shape[-1]
+    score, pooled, w = empty(2, B, T, like=x1), empty(2, B, D, like=x1), empty(B, 2, like=x1)
+    out = torch.empty_like(x1)
+    require_cuda(x1, x2, lens, lens2)
+    assert x1.is_contiguous() and x2.is_contiguous()
+    check(lib().tavsr_merge_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(score), ptr(pooled), ptr(w),
+                                ptr(out), B, T, D, stream()), "tavsr_merge_fwd")
+    return score, pooled, w, out
+
+
 def merge_combine(x1, x2, w, B, T):
     D = x1.shape[-1]
     out = torch.empty_like(x1)

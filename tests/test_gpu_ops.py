@@ -134,6 +134,10 @@ def test_merge_learned_ave(T):
     ref = mw[:, 0, None, None] * X[0] + mw[:, 1, None, None] * X[1]
     _close(w, mw, 1e-5)
     _close(m.view(B, T, D), ref, 1e-5)
+    # pooling + combination in one call (one launch for T <= 128): the same four results
+    score2, pooled2, w2, m2 = ops.merge_fwd(x1.view(-1, D), x2.view(-1, D), lens, prm, B, T)
+    assert torch.equal(score2, score) and torch.equal(pooled2, pooled) and torch.equal(w2, w)
+    _close(m2.view(B, T, D), ref, 1e-5)
     dm = torch.randn(B * T, D, device="cuda")
     ref.backward(dm.view(B, T, D).double())
     dx1, dx2, grads = ops.merge_bwd(dm, x1.view(-1, D), x2.view(-1, D), lens, prm, score, pooled, w, B, T)
