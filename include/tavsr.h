@@ -315,6 +315,15 @@ int tavsr_scale_dev(const float* x, const float* s, float c, float* out, int64_t
 int tavsr_dwconv_gate_fwd(const float* gn, const float* r, int64_t ldr, const float* w, const float* bias,
                           float* out, float* conv, int32_t B, int32_t T, int32_t C, int32_t K,
                           tavsr_stream_t stream);
+/* The whole ConvolutionalSpatialGatingUnit between the channel projections (espnet cgmlp.py, called at
+ * src/encoder/branchformer/encoder_layer.py:213-222): out = dropout(g[:, :C] * dwconv_K(LayerNorm(g[:, C:2C]))) over B utterances
+ * of T rows, g [B*T][ldg] (ldg >= 2C).  Two launches: LayerNorm statistics of the gate rows (mean / rstd [B*T], always written),
+ * then normalise + convolve + gate (+ dropout: the tavsr_dropout mapping at `offset` over the [B*T][C] result).  gn / conv
+ * (optional, [B*T][C]): the normalised gate and the convolution output the backward pass needs.  K = 31, C % 64 == 0; other
+ * shapes: TAVSR_EUNSUPPORTED (callers keep tavsr_layernorm_fwd + tavsr_dwconv_gate_fwd). */
+int tavsr_csgu_fwd(const float* g, int64_t ldg, const float* ln_w, const float* ln_b, float eps, const float* conv_w,
+                   const float* conv_b, float* out, float* gn, float* conv, float* mean, float* rstd, float p_drop,
+                   const uint64_t* seed_dev, uint64_t offset, int32_t B, int32_t T, int32_t C, int32_t K, tavsr_stream_t stream);
 int64_t tavsr_dwconv_gate_bwd_ws(int32_t B, int32_t T, int32_t C, int32_t K);
 int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv,
                           const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,

@@ -117,6 +117,115 @@ __global__ __launch_bounds__(256) void dwconv_gate_fwd_kfix_kernel(const float* 
   }
 }
 
+// The whole CSGU between the two channel projections in one launch (espnet ConvolutionalSpatialGatingUnit.forward: x_r, x_g =
+// chunk(2); x_g = norm(x_g); x_g = depthwise conv over time; out = dropout(x_r * x_g)), given the LayerNorm statistics of the
+// gate rows: block (64 channels, utterance) normalises its [T x 64] gate tile on the way into LDS (16-byte loads, all in flight
+// together), convolves along time with the taps in registers and multiplies by x_r - the normalised gate never makes a round
+// trip through HBM in eval, and is written once (with the convolution output) when the backward pass needs it.
+template <int K>
+__global__ __launch_bounds__(256, 2) void csgu_fwd_kernel(const float* __restrict__ g, int64_t ldg, int C,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ out, float* __restrict__ conv, float* __restrict__ gn_out,
+                                                       int B, int T, uint32_t thr, float inv_keep,
+                                                       const uint64_t* __restrict__ seed, uint64_t offset4) {
+  constexpr int pad = (K - 1) / 2, rows = CG_TT + K - 1;
+  __shared__ __attribute__((aligned(16))) float s_x[rows * CG_CH];
+  __shared__ float s_w[CG_CH * K];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * CG_CH, b = blockIdx.y;
+  for (int i = tid; i < CG_CH * K; i += 256) s_w[i] = w[(int64_t)c0 * K + i];      // the 64 x K tap block is contiguous
+  // a thread = 4 consecutive channels (16-byte accesses everywhere) x, per pass, one of 16 rows
+  const float4 gam = *reinterpret_cast<const float4*>(ln_w + c0 + 4 * (tid & 15));
+  const float4 bet = *reinterpret_cast<const float4*>(ln_b + c0 + 4 * (tid & 15));
+  const uint64_t sd = thr ? seed[0] : 0;
+  // compute phase: a thread = 2 consecutive channels (taps in registers: 2 K of them) x CG_TT / 8 consecutive rows
+  constexpr int RP = CG_TT / 8;
+  const float2 bv = *reinterpret_cast<const float2*>(bias + c0 + 2 * (tid & 31));
+  const int tid_ = tid;
+  for (int t0 = 0; t0 < T; t0 += CG_TT) {
+    if (t0) __syncthreads();                           // the previous tile has been read
+    // lane coordinates the compiler cannot see through: otherwise every tile-invariant address of the body (~150 of them) is
+    // hoisted out of this loop and spilled
+    int tq_ = tid_;
+    asm volatile("" : "+v"(tq_));
+    const int l4 = tq_ & 15, rr = tq_ >> 4, cc = c0 + 4 * l4, l2 = tq_ & 31, rg = tq_ >> 5, c2 = c0 + 2 * l2;
+    constexpr int NP = (rows + 15) / 16;
+    float4 xv[NP];
+    float mu[NP], rs[NP];
+    // unconditional loads at clamped rows (straight-line code: all of them in flight together); uniform bases, 32-bit offsets
+    const float* gb = g + (int64_t)b * T * ldg;
+    const float* mb = mean + (int64_t)b * T;
+    const float* sb = rstd + (int64_t)b * T;
+    const int ldg32 = (int)ldg;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int tc = min(max(t0 + rr + 16 * q - pad, 0), T - 1);
+      xv[q] = *reinterpret_cast<const float4*>(gb + (tc * ldg32 + C + cc));
+      mu[q] = mb[tc];
+      rs[q] = sb[tc];
+    }
+    // x_r of the thread's output rows (rows tb .. tb + RP - 1 of the tile), fetched together with the gate tile
+    const int tb = rg * RP;
+    float2 rv[RP];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) rv[q] = *reinterpret_cast<const float2*>(gb + (min(t0 + tb + q, T - 1) * ldg32 + c2));
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int i = rr + 16 * q, t = t0 + i - pad;
+      if (i < rows) {
+        const bool ok = t >= 0 && t < T;                // outside the utterance the convolution sees zeros, not beta
+        const float4 v = ok ? make_float4((xv[q].x - mu[q]) * rs[q] * gam.x + bet.x, (xv[q].y - mu[q]) * rs[q] * gam.y + bet.y,
+                                          (xv[q].z - mu[q]) * rs[q] * gam.z + bet.z, (xv[q].w - mu[q]) * rs[q] * gam.w + bet.w)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&s_x[i * CG_CH + 4 * l4]) = v;
+        if (gn_out && ok && i >= pad && i < pad + CG_TT)
+          *reinterpret_cast<float4*>(gn_out + ((int64_t)b * T + t) * C + cc) = v;
+      }
+    }
+    __syncthreads();
+    float2 wv[K];                                       // (per tile: not live across the load phase)
+#pragma unroll
+    for (int k = 0; k < K; ++k) wv[k] = make_float2(s_w[(2 * l2) * K + k], s_w[(2 * l2 + 1) * K + k]);
+#pragma unroll
+    for (int gi = 0; gi < RP / 4; ++gi) {               // 4 outputs share one sliding window of K + 3 LDS rows
+      const int tq = tb + 4 * gi;
+      if (t0 + tq >= T) break;
+      float2 o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = bv;
+#pragma unroll
+      for (int u = 0; u < K + 3; ++u) {
+        const float2 v = *reinterpret_cast<const float2*>(&s_x[(tq + u) * CG_CH + 2 * l2]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (u - q >= 0 && u - q < K) { o[q].x += wv[u - q].x * v.x; o[q].y += wv[u - q].y * v.y; }
+        if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // a few window rows in flight at a time, not all of them
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = t0 + tq + q;
+        if (t < T) {
+          const int64_t e = ((int64_t)b * T + t) * C + c2;
+          if (conv) *reinterpret_cast<float2*>(conv + e) = o[q];
+          float2 y = make_float2(rv[4 * gi + q].x * o[q].x, rv[4 * gi + q].y * o[q].y);
+          if (thr) {                                    // tavsr_dropout's mapping: element e = word e & 3 of counter offset4 + e / 4
+            const uint64_t ctr = offset4 + ((uint64_t)e >> 2);
+            uint32_t r4[4];
+            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), r4);
+            const uint32_t ra = (e & 2) ? r4[2] : r4[0], rb = (e & 2) ? r4[3] : r4[1];
+            y.x = ra >= thr ? y.x * inv_keep : 0.f;
+            y.y = rb >= thr ? y.y * inv_keep : 0.f;
+          }
+          *reinterpret_cast<float2*>(out + e) = y;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // du -> dr = du*conv ; dconv = du*r ; dgn[t] = sum_k w[c,k]*dconv[t-k+pad] ;
 // dw[c,k] = sum_{b,t} dconv[t]*gn[t+k-pad], dbias[c] = sum_{b,t} dconv[t].
 // One block per (64 channels, utterance): it walks the utterance in time tiles of CG_TB steps (dconv and gn tiles
@@ -691,6 +800,30 @@ extern "C" int tavsr_dwconv_gate_fwd(const float* gn, const float* r, int64_t ld
   else
     hipLaunchKernelGGL(dwconv_gate_fwd_kernel, dim3(cdiv(C, CG_CH), cdiv(T, CG_TT), B), dim3(256), lds,
                        (hipStream_t)stream, gn, r, ldr, w, bias, out, conv, B, T, C, K);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y,
+                                   int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D, tavsr_stream_t stream);
+
+extern "C" int tavsr_csgu_fwd(const float* g, int64_t ldg, const float* ln_w, const float* ln_b, float eps, const float* conv_w,
+                              const float* conv_b, float* out, float* gn, float* conv, float* mean, float* rstd, float p_drop,
+                              const uint64_t* seed_dev, uint64_t offset, int32_t B, int32_t T, int32_t C, int32_t K,
+                              tavsr_stream_t stream) {
+  TAVSR_REQUIRE(g && ln_w && ln_b && conv_w && conv_b && out && mean && rstd, TAVSR_EINVAL, "csgu_fwd: null pointer");
+  TAVSR_REQUIRE(K == 31 && C > 0 && C % CG_CH == 0, TAVSR_EUNSUPPORTED, "csgu_fwd: kernel size 31 and C %% 64 == 0 (got %d, %d)", K, C);
+  TAVSR_REQUIRE(ldg % 4 == 0 && ldg >= 2 * (int64_t)C && ((uintptr_t)g % 16 == 0) && ((uintptr_t)ln_w % 16 == 0) &&
+                    ((uintptr_t)ln_b % 16 == 0) && (!gn || (uintptr_t)gn % 16 == 0), TAVSR_EALIGN, "csgu_fwd: rows must be 16-byte aligned");
+  TAVSR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_dev) && offset % 4 == 0, TAVSR_EINVAL,
+                "csgu_fwd: dropout needs p in [0, 1), a device seed and an offset %% 4 == 0");
+  if (B <= 0 || T <= 0) return TAVSR_OK;
+  // statistics of the gate rows (columns C .. 2C-1 of g), then the fused pass
+  int rc = tavsr_layernorm_fwd(g + C, ldg, nullptr, nullptr, eps, nullptr, 0, mean, rstd, B * T, C, stream);
+  if (rc) return rc;
+  const uint32_t thr = p_drop > 0.f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  hipLaunchKernelGGL(csgu_fwd_kernel<31>, dim3(C / CG_CH, B), dim3(256), 0, (hipStream_t)stream, g, ldg, C, mean, rstd, ln_w, ln_b,
+                     conv_w, conv_b, out, conv, gn, B, T, thr, p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_dev, offset / 4);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

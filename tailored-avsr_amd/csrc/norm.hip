@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (mean) mean[row] = mu;
     if (rstd) rstd[row] = rs;
   }
+  if (!y) return;                   // statistics only
   float* yr = y + (int64_t)row * ldy;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
@@ -236,7 +237,8 @@ using namespace tavsr;
 extern "C" int tavsr_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                    float* y, int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D,
                                    tavsr_stream_t stream) {
-  TAVSR_REQUIRE(x && gamma && beta && y, TAVSR_EINVAL, "layernorm_fwd: null pointer");
+  TAVSR_REQUIRE(x && ((gamma && beta && y) || (!y && mean && rstd)), TAVSR_EINVAL,
+                "layernorm_fwd: null pointer (y may be null only for a statistics-only call with mean and rstd)");
   TAVSR_REQUIRE(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, TAVSR_EUNSUPPORTED,
                 "layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, LN_MAXV * 256);
   TAVSR_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&

@@ -332,11 +332,15 @@ class BranchformerLayerFn(torch.autograd.Function):
             else:
                 g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu"), None
             Cn = g.shape[1] // 2
-            gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p("cgmlp.csgu.norm.weight"), p("cgmlp.csgu.norm.bias"),
-                                                 EPS_ESPNET)
             cw = p("cgmlp.csgu.conv.weight")
-            u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p("cgmlp.csgu.conv.bias"), B, T)
-            t_u = _drop_(u, pd)                             # csgu: dropout(x_r * x_g)
+            if ops.csgu_usable(g, cw):       # LayerNorm + depthwise convolution + gate + dropout: one pass over g
+                u, conv, gn, gmean, grstd, t_u = ops.csgu_fwd(g, p("cgmlp.csgu.norm.weight"), p("cgmlp.csgu.norm.bias"), EPS_ESPNET,
+                                                              cw.reshape(Cn, -1), p("cgmlp.csgu.conv.bias"), B, T, p=pd, save=need)
+            else:
+                gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p("cgmlp.csgu.norm.weight"), p("cgmlp.csgu.norm.bias"),
+                                                     EPS_ESPNET)
+                u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p("cgmlp.csgu.conv.bias"), B, T)
+                t_u = _drop_(u, pd)                             # csgu: dropout(x_r * x_g)
             t_xm = None
             if merge == "concat":
                 ops.linear(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"), out=cat, out_off=D,

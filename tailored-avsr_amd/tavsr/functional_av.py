@@ -338,10 +338,14 @@ def _ts_branch_fwd(p, cfg, x1, n, mean, rstd, pos_emb, lens, B, T, need):
     else:
         g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu"), None
     Cn = g.shape[1] // 2
-    gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET)
     cw = p["cgmlp.csgu.conv.weight"]
-    u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T)
-    t_u = _drop_(u, pd)                # csgu: dropout(x_r * x_g)
+    if ops.csgu_usable(g, cw):         # LayerNorm + depthwise convolution + gate + dropout: one pass over g
+        u, conv, gn, gmean, grstd, t_u = ops.csgu_fwd(g, p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET,
+                                                      cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T, p=pd, save=need)
+    else:
+        gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET)
+        u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T)
+        t_u = _drop_(u, pd)            # csgu: dropout(x_r * x_g)
     # residual + coeff * dropout(cgmlp)  (encoder_layer.py:208,256)
     x2, t_br = ops.linear_drop(u, p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], pd, alpha=coeff, res=x1)
     return x2, (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)

@@ -837,6 +837,30 @@ def dwconv_gate_fwd(gn, r, w, bias, B, T):
     return out, conv
 
 
+CSGU_FUSED = os.environ.get("TAVSR_CSGU_FUSED", "1") == "1"
+
+
+def csgu_usable(g, w) -> bool:
+    return (CSGU_FUSED and w.shape[-1] == 31 and g.shape[1] % 128 == 0 and g.is_contiguous() and g.data_ptr() % 16 == 0)
+
+
+def csgu_fwd(g, ln_w, ln_b, eps, w, bias, B, T, p=0.0, save=True):
+    """dropout(g[:, :C] * dwconv(LayerNorm(g[:, C:]))) in one pass over g (+ the statistics launch).  Returns
+    (u, conv, gn, mean, rstd, token); conv / gn only when ``save``."""
+    M, C2 = g.shape
+    Cn = C2 // 2
+    require_cuda(g, ln_w, ln_b, w, bias)
+    out = empty(M, Cn, like=g)
+    conv, gn = (empty(M, Cn, like=g), empty(M, Cn, like=g)) if save else (None, None)
+    mean, rstd = empty(M, like=g), empty(M, like=g)
+    tok = _new_token(p, M * Cn, g.device) if p and p > 0.0 else None
+    check(lib().tavsr_csgu_fwd(ptr(g), C.c_int64(g.stride(0)), ptr(ln_w), ptr(ln_b), C.c_float(eps), ptr(w), ptr(bias), ptr(out),
+                               ptr(gn), ptr(conv), ptr(mean), ptr(rstd), C.c_float(tok[0] if tok else 0.0),
+                               ptr(tok[2] if tok else None), C.c_uint64(tok[1] if tok else 0), B, T, Cn, w.shape[-1], stream()),
+          "tavsr_csgu_fwd")
+    return out, conv, gn, mean, rstd, tok
+
+
 def dwconv_gate_bwd(du, gn, r, conv, w, dr, B, T):
     M, Cn = gn.shape
     K = w.shape[-1]

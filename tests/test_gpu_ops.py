@@ -109,6 +109,40 @@ def test_dwconv_gate(B, T):
     _close(db, br.grad, 1e-4)
 
 
+@pytest.mark.parametrize("B,T,p", [(3, 23, 0.0), (32, 99, 0.0), (2, 99, 0.1), (1, 300, 0.2), (2, 128, 0.0)])
+def test_csgu_fused_forward(B, T, p):
+    """tavsr_csgu_fwd (LayerNorm statistics + normalise / 31-tap depthwise convolution / gate / dropout in one pass over g)
+    against fp64 torch of espnet's ConvolutionalSpatialGatingUnit, and against the LayerNorm + dwconv_gate + dropout launches
+    (same mask: the dropout follows tavsr_dropout's mapping)."""
+    from tavsr import ops
+    torch.manual_seed(31)
+    Cn, K = 1024, 31
+    g = torch.randn(B * T, 2 * Cn, device="cuda") * 1.3 + 0.2
+    lw, lb = 1 + 0.1 * torch.randn(Cn, device="cuda"), 0.1 * torch.randn(Cn, device="cuda")
+    w, bias = torch.randn(Cn, 1, K, device="cuda") / 5, torch.randn(Cn, device="cuda")
+    ops.manual_seed(77)
+    u, conv, gn, mean, rstd, tok = ops.csgu_fwd(g, lw, lb, 1e-12, w.view(Cn, K), bias, B, T, p=p, save=True)
+    gd = g.double()
+    gnr = F.layer_norm(gd[:, Cn:], (Cn,), lw.double(), lb.double(), 1e-12)
+    cr = F.conv1d(gnr.view(B, T, Cn).transpose(1, 2), w.double(), bias.double(), 1, 15, 1, Cn).transpose(1, 2).reshape(B * T, Cn)
+    _close(gn, gnr, 1e-5)
+    _close(conv, cr, 1e-5)
+    _close(mean, gd[:, Cn:].mean(1), 1e-5)
+    _close(rstd, 1 / torch.sqrt(gd[:, Cn:].var(1, unbiased=False) + 1e-12), 1e-5)
+    ref = gd[:, :Cn] * cr
+    if p:
+        keep = ops.dropout(torch.ones(B * T, Cn, device="cuda"), p, token=tok)[0] != 0
+        assert abs(float(keep.float().mean()) - (1 - p)) < 1e-2
+        ref = ref * keep / (1 - p)
+    else:
+        assert tok is None
+    _close(u, ref, 1e-5)
+    # eval form: nothing saved, same output
+    ops.manual_seed(77)
+    u2, conv2, gn2, _, _, _ = ops.csgu_fwd(g, lw, lb, 1e-12, w.view(Cn, K), bias, B, T, p=p, save=False)
+    assert conv2 is None and gn2 is None and torch.equal(u2, u)
+
+
 @pytest.mark.parametrize("T", [23, 99, 128, 150])     # <= 128: the single-read kernel; beyond: the two-pass one
 def test_merge_learned_ave(T):
     from tavsr import ops
