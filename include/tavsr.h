@@ -297,6 +297,22 @@ int tavsr_ffn2_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w
                       int32_t M, int32_t D, int32_t N1, float p_drop, const uint64_t* seed_dev, uint64_t offset_in, float* dz,
                       float* dn, float* ws, int64_t ws_floats, tavsr_stream_t stream);
 
+/* Linear layers of ONE d_model = 256 input as one streaming launch (csrc/lin2.hip): out_s = act(x w_s^T + b_s) for up to four
+ * weight matrices w_s [n_s][256] (n_s % 32 == 0) - espnet's linear_q / linear_k / linear_v of one attention input, cgMLP's
+ * channel_proj1 + GELU (src/encoder/branchformer/encoder_layer.py:196-222).  out_s [M][ldo] (a column window of a wider buffer
+ * is fine), z_s (optional, all or none): the pre-activations.  K != 256: TAVSR_EUNSUPPORTED (callers keep tavsr_gemm). */
+typedef struct tavsr_lin2_seg {
+  const float* w;
+  const float* b;            /* [n] or NULL */
+  float* out;
+  int64_t ldo;
+  float* z;
+  int64_t ldz;
+  int32_t n;
+} tavsr_lin2_seg;
+int tavsr_lin2_fwd(const float* x, int64_t ldx, int32_t M, int32_t K, const tavsr_lin2_seg* segs, int32_t nseg, int32_t act,
+                   tavsr_stream_t stream);
+
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);
 int tavsr_axpby2d(const float* x, int64_t ldx, const float* y, int64_t ldy, float a, float b, float* out,

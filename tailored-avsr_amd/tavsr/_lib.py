@@ -60,6 +60,12 @@ class AttnDesc(C.Structure):
     ]
 
 
+class Lin2Seg(C.Structure):
+    """tavsr_lin2_seg (include/tavsr.h)"""
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64), ("z", C.c_void_p),
+                ("ldz", C.c_int64), ("n", C.c_int32)]
+
+
 class FfnDesc(C.Structure):
     """tavsr_ffn_desc (include/tavsr.h)"""
     _fields_ = [

@@ -148,6 +148,9 @@ def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=Non
         ldc = N
     z = empty(M, N, like=x) if save_z else None
     assert not save_z or (out_off == 0 and ldc == N)
+    if (res is None and alpha == 1.0 and force is None and N >= LIN2_MIN_N and ldc == out.stride(0) and lin2_usable(x, [w])):
+        lin2_fwd(x, [(w, b, out, out_off, z)], act=act)
+        return (out, z) if save_z else out
     gemm(M, N, K, x, x.stride(0), w, w.stride(0), out, ldc, c_off=out_off, bias=b, act=act, alpha=alpha, Z=z,
          R=res, ldr=0 if res is None else res.stride(0), force=force)
     return (out, z) if save_z else out
@@ -425,6 +428,9 @@ def linear_group(x, wbs, out, ldc=None):
     list of (w_j, b_j, column offset of y_j in ``out``); out rows have stride ``ldc``.  Falls back to one GEMM per
     projection when the grouped kernel cannot take the problems (alignment / K % 32) - same results."""
     M, K = x.shape
+    if (ldc is None or ldc == out.stride(0)) and lin2_usable(x, [w for w, _, _ in wbs]):
+        lin2_fwd(x, [(w, b, out, off, None) for w, b, off in wbs])
+        return out
     ldc = out.stride(0) if ldc is None else ldc
     require_cuda(x, out)
     arr = (GemmDesc * len(wbs))()
@@ -444,6 +450,34 @@ def linear_group(x, wbs, out, ldc=None):
         return out
     check(rc, "tavsr_gemm_grouped")
     return out
+
+
+# Linear layers of a d_model = 256 input as one streaming launch (csrc/lin2.hip): the rows stay in registers, the weights stream
+# through an LDS ring shared by a workgroup's four waves.  OFF by default (TAVSR_LIN2=1 routes linear_group and the wide
+# linear() calls to it): alone on the chip it is as fast as the tiled GEMM or a little faster (query / key / value projections
+# 22.4 -> 20.6 us), but the layer runs its attention branch BESIDE its cgMLP branch, and a kernel that owns every CU's LDS does
+# not share the chip: 12-layer forward 3.72 -> 3.84 ms (profiles/r03_notes.md).
+LIN2 = os.environ.get("TAVSR_LIN2", "0") == "1"
+LIN2_MIN_N = int(os.environ.get("TAVSR_LIN2_MIN_N", "512"))     # a single matrix narrower than this stays on the GEMM
+
+
+def lin2_usable(x, ws) -> bool:
+    return (LIN2 and PROFILE is None and x.dim() == 2 and x.shape[1] == 256 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and len(ws) <= 4 and all(w.shape[0] % 32 == 0 and w.is_contiguous() for w in ws))
+
+
+def lin2_fwd(x, segs, act=None):
+    """out_j[:, off_j : off_j + n_j] = act(x @ w_j.T + b_j) for every (w_j, b_j, out_j, off_j, z_j) of ``segs`` (z_j: tensor
+    [M, n_j] that receives the pre-activations, or None - for all or for none)."""
+    from ._lib import Lin2Seg
+    M, K = x.shape
+    arr = (Lin2Seg * len(segs))()
+    for d, (w, b, out, off, z) in zip(arr, segs):
+        require_cuda(x, w, b, out, z)
+        d.w, d.b, d.n = w.data_ptr(), (None if b is None else b.data_ptr()), w.shape[0]
+        d.out, d.ldo = _addr(out, off), out.stride(0)
+        d.z, d.ldz = (None, 0) if z is None else (z.data_ptr(), z.stride(0))
+    check(lib().tavsr_lin2_fwd(ptr(x), C.c_int64(x.stride(0)), M, K, arr, len(segs), ACT[act], stream()), "tavsr_lin2_fwd")
 
 
 def colsum(x, *, scale=1.0, out=None, accumulate=False):
