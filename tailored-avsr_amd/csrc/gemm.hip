@@ -769,6 +769,30 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
       s7_off[i] = (((ft / pT) * pTp + ft % pT) * pHp + 2 * ho) * pWp + 2 * wo;
     }
   }
+  // CONV 2: the output pixel (image, oy, ox) of every chunk of this thread is CARRIED from K-step to K-step (tiles are issued in
+  // k order; a step moves on by BK pixels = (sa_hi * cHo + sa_lo) rows + sb pixels, at most one wrap each): the three divisions
+  // per chunk that recomputed it were ~170 integer instructions per K-step beside 32 MFMAs per wave
+  int c2_ox[CONV == 2 ? LB::NR : 1], c2_oy[CONV == 2 ? LB::NR : 1], c2_img[CONV == 2 ? LB::NR : 1];
+  int c2_sb = 0, c2_salo = 0, c2_sahi = 0, c2_tapoff = 0, c2_cb = 0, c2_dy = 0, c2_dx = 0;
+  if (CONV == 2) {
+    const int sa = BK / cWo;
+    c2_sb = BK - sa * cWo;
+    c2_sahi = sa / cHo;
+    c2_salo = sa - c2_sahi * cHo;
+    const int tap = n0 / d.conv_C;
+    c2_cb = n0 - tap * d.conv_C;
+    c2_dy = c9 ? tap / 3 - 1 : 0;
+    c2_dx = c9 ? tap % 3 - 1 : 0;
+    c2_tapoff = c2_dy * d.conv_W + c2_dx;
+#pragma unroll
+    for (int i = 0; i < LB::NR; ++i) {
+      const int m = kbeg + (i * NT + tid) / (BN / 4);
+      const int t = m / cWo;
+      c2_ox[i] = m - t * cWo;
+      c2_img[i] = t / cHo;
+      c2_oy[i] = t - c2_img[i] * cHo;
+    }
+  }
   // CONV 3 (K tail: K % 32 != 0): chunks whose first k lies at or past K are fetched from a zero page; a k-contiguous chunk
   // that straddles K (K % 4 != 0) is fetched whole and its k >= K elements are zeroed in LDS before the last K-step
   int kofsA[LA::NR], kofsB[LB::NR];
@@ -871,16 +895,22 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
         }
       }
     } else if (CONV == 2) {
-      const int tap = n0 / d.conv_C, cb = n0 - tap * d.conv_C, dy = c9 ? tap / 3 - 1 : 0, dx = c9 ? tap % 3 - 1 : 0;
 #pragma unroll
       for (int i = 0; i < LB::NR; ++i) {
-        const int q = i * NT + tid;
-        const int m = kbeg + kt * BK + q / (BN / 4), r = (q % (BN / 4)) * 4;
-        const int x = (m % cWo) * cs + cp0, y = ((m / cWo) % cHo) * cs + cp0;
-        const bool ok = (unsigned)(y + dy) < (unsigned)d.conv_H && (unsigned)(x + dx) < (unsigned)d.conv_W;
-        const int64_t pix = (cs > 1 || cp0) ? (int64_t)((m / (cWo * cHo)) * d.conv_H + y) * d.conv_W + x : m;
-        const float* src = ok ? B + (pix + dy * d.conv_W + dx) * d.conv_C + cb + r : d.conv_zero;
+        const int r = (((i * NT + tid) % (BN / 4)) * 4);
+        const int x = c2_ox[i] * cs + cp0, y = c2_oy[i] * cs + cp0;
+        const bool ok = (unsigned)(y + c2_dy) < (unsigned)d.conv_H && (unsigned)(x + c2_dx) < (unsigned)d.conv_W;
+        const int64_t pix = (int64_t)(c2_img[i] * d.conv_H + y) * d.conv_W + x;
+        const float* src = ok ? B + (pix + c2_tapoff) * d.conv_C + c2_cb + r : d.conv_zero;
         __builtin_amdgcn_global_load_lds((glb_float*)src, (lds_float*)(smem + st * STAGE + ASZ + (i * NT + wave * 64) * 4), 16, 0, 0);
+        // the next K-step's pixel
+        int ox = c2_ox[i] + c2_sb;
+        const int w1 = ox >= cWo ? 1 : 0;
+        ox -= w1 ? cWo : 0;
+        int oy = c2_oy[i] + c2_salo + w1;
+        const int w2 = oy >= cHo ? 1 : 0;
+        oy -= w2 ? cHo : 0;
+        c2_ox[i] = ox; c2_oy[i] = oy; c2_img[i] += c2_sahi + w2;
       }
     } else {
       LB::issue(Bk + kt * kstepB, offB, smem + st * STAGE + ASZ, wave);
