@@ -559,6 +559,15 @@ struct GLoader {
   }
 };
 
+#ifndef TAVSR_GEMM_SB
+#define TAVSR_GEMM_SB 1
+#endif
+#if TAVSR_GEMM_SB
+#define GEMM_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GEMM_SB()
+#endif
+
 template <int ROWS, bool KMAJOR>
 __device__ __forceinline__ void read_frag_g(const float* __restrict__ s, int row, int g, int lk, float (&f)[4]) {
   if (KMAJOR) {
@@ -934,6 +943,10 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
 #pragma unroll
         for (int j = 0; j < TN; ++j) read_frag_g<BN, BKM>(b_s, brow + j * 32, kw + (q + 1) * KW, lk, bf[c ^ 1][j]);
       }
+      // keep the order "next group's fragment reads, then this group's MFMAs": left alone, hipcc sinks the reads to just in
+      // front of their first use and waits lgkmcnt(0) there - one exposed LDS latency per k-group (TAVSR_GEMM_SB=0 at build
+      // time restores that)
+      GEMM_SB();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -943,6 +956,7 @@ __device__ __forceinline__ void glds_tile(const tavsr_gemm_desc& d, int kchunk, 
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i][kk], bf[c][j][kk], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < TM; ++i) asum[i] += (af[c][i][0] + af[c][i][1]) + (af[c][i][2] + af[c][i][3]);
+      GEMM_SB();
     }
   };
 
