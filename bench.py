@@ -331,7 +331,10 @@ def main():
         return x
 
     eager_out = None
-    if not args.no_graph and not args.no_eager:
+    # (1 GPU only: with N ranks the un-captured loop is measured by --no-graph; running hook-driven exchanges in front of the
+    # capture made the gloo rehearsal's captured steps slower from step to step - 0.2 s, 1.7 s, 5.5 s of host time in the
+    # exchange - so the N > 1 line keeps the order that was rehearsed: capture first, nothing before it)
+    if not args.no_graph and not args.no_eager and world == 1:
         # the same step as eager launches (what a ragged, un-captured training loop pays): reported beside the graph number.
         # Taken BEFORE the capture, in the allocator / interpreter state a training loop would run in.
         n_eager = max(3, args.steps // 4)
@@ -373,13 +376,25 @@ def main():
             static_loss = model(*batch)[0]
             static_loss.backward()
 
+    trace = os.environ.get("TAVSR_BENCH_TRACE") == "1"     # diagnostic: synchronous per-phase times of every step on stderr
+
     def step():
+        t0 = time.perf_counter()
         if graph is not None:
             graph.replay()
         else:
             buckets.begin_step()       # the hooks enqueue buckets under the backward pass
             fwd_bwd()
+        if trace:
+            if os.environ.get("TAVSR_BENCH_TRACE_SYNC", "1") == "1":
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
         buckets.allreduce_mean()
+        if trace:
+            t2 = time.perf_counter()
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] step: compute {1e3 * (t1 - t0):.1f} ms, exchange {1e3 * (t2 - t1):.1f} ms, "
+                  f"drain {1e3 * (time.perf_counter() - t2):.1f} ms", file=sys.stderr, flush=True)
 
     for _ in range(args.warmup):
         step()
