@@ -313,6 +313,48 @@ typedef struct tavsr_lin2_seg {
 int tavsr_lin2_fwd(const float* x, int64_t ldx, int32_t M, int32_t K, const tavsr_lin2_seg* segs, int32_t nseg, int32_t act,
                    tavsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * One Branchformer encoder layer forward as ONE call (csrc/layer.hip): MyBranchformerEncoderLayer.forward
+ * (src/encoder/branchformer/encoder_layer.py:153-321) in its recipe form - macaron FFN, rel-pos attention branch beside the
+ * cgMLP branch, learned-average merge + merge_proj, FFN, norm_final - sequenced in C over the entry points above (14 launches;
+ * the attention branch is enqueued on `stream2` between two events, as the Python sequencing does with a side stream).
+ * All buffers are the caller's: the outputs / saved tensors below are exactly what the backward pass reads; `save` = 0 (eval)
+ * leaves z / h / gn / conv untouched (may be NULL).  Dropout: rate p_drop (p_att inside the attention core) with the counter
+ * offsets drop_off[] in the order {ffm inner, ffm outer, attention, attention out-proj, csgu, channel_proj2, merge_proj,
+ * ff inner, ff outer}; p_drop = 0 in eval.  ws: tavsr_branchformer_layer_ws(desc) floats.
+ * Shapes outside the streaming kernels' range (D != 256, d_k != 64, conv kernel != 31, ...): TAVSR_EUNSUPPORTED, nothing is
+ * launched, the caller keeps its own sequencing.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tavsr_bf_layer_desc {
+  int32_t B, T, D, H, ffn_units, cg_units /* 2 C */, cg_kernel, ffn_act, save;
+  float p_drop, p_att, coeff;
+  const float* x;                  /* [B*T][D] */
+  const float* pos_emb;            /* [2T-1][D] */
+  const int64_t* lens;             /* [B] */
+  /* parameters (torch layouts) */
+  const float *ffm_ln_w, *ffm_ln_b, *ffm_w1, *ffm_b1, *ffm_w2, *ffm_b2;
+  const float *mha_ln_w, *mha_ln_b, *wq, *bq, *wk, *bk, *wv, *bv, *wpos, *pos_u, *pos_v, *wo, *bo;
+  const float *mlp_ln_w, *mlp_ln_b, *cg_w1, *cg_b1, *csgu_ln_w, *csgu_ln_b, *csgu_cw, *csgu_cb, *cg_w2, *cg_b2;
+  const float* merge_p[8];         /* pooling_proj{1,2}.weight, pooling_proj{1,2}.bias, weight_proj{1,2}.weight, weight_proj{1,2}.bias */
+  const float *merge_w, *merge_b;
+  const float *ff_ln_w, *ff_ln_b, *ff_w1, *ff_b1, *ff_w2, *ff_b2, *final_ln_w, *final_ln_b;
+  const uint64_t* seed;            /* device; NULL when p_drop == p_att == 0 */
+  uint64_t drop_off[9];
+  /* results and what the backward pass keeps */
+  float *x1, *ffm_n, *ffm_mean, *ffm_rstd, *ffm_z, *ffm_h;      /* ffm_z / ffm_h: [roundup128(B*T)][ffn_units] */
+  float *n_mha, *n_mlp, *br_mean, *br_rstd;
+  float *qkv, *pp, *cx, *lse, *xa;
+  float *g, *g_z, *gn, *g_mean, *g_rstd, *u, *conv, *xm;
+  float *score, *pooled, *wts, *m;
+  float *x2, *ff_n, *ff_mean, *ff_rstd, *ff_z, *ff_h, *x3, *y, *fin_mean, *fin_rstd;
+  tavsr_stream_t stream2;          /* the attention branch's queue */
+  void *ev_fork, *ev_join;         /* hipEvent_t */
+  float* ws;
+  int64_t ws_floats;
+} tavsr_bf_layer_desc;
+int64_t tavsr_branchformer_layer_ws(const tavsr_bf_layer_desc* d);
+int tavsr_branchformer_layer_fwd(const tavsr_bf_layer_desc* d, tavsr_stream_t stream);
+
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);
 int tavsr_axpby2d(const float* x, int64_t ldx, const float* y, int64_t ldy, float a, float b, float* out,

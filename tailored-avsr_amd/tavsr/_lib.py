@@ -66,6 +66,33 @@ class Lin2Seg(C.Structure):
                 ("ldz", C.c_int64), ("n", C.c_int32)]
 
 
+class BfLayerDesc(C.Structure):
+    """tavsr_bf_layer_desc (include/tavsr.h): field order is the header's"""
+    _P = C.c_void_p
+    _fields_ = (
+        [(n, C.c_int32) for n in ("B", "T", "D", "H", "ffn_units", "cg_units", "cg_kernel", "ffn_act", "save")]
+        + [(n, C.c_float) for n in ("p_drop", "p_att", "coeff")]
+        + [(n, C.c_void_p) for n in (
+            "x", "pos_emb", "lens",
+            "ffm_ln_w", "ffm_ln_b", "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2",
+            "mha_ln_w", "mha_ln_b", "wq", "bq", "wk", "bk", "wv", "bv", "wpos", "pos_u", "pos_v", "wo", "bo",
+            "mlp_ln_w", "mlp_ln_b", "cg_w1", "cg_b1", "csgu_ln_w", "csgu_ln_b", "csgu_cw", "csgu_cb", "cg_w2", "cg_b2")]
+        + [("merge_p", C.c_void_p * 8)]
+        + [(n, C.c_void_p) for n in (
+            "merge_w", "merge_b", "ff_ln_w", "ff_ln_b", "ff_w1", "ff_b1", "ff_w2", "ff_b2", "final_ln_w", "final_ln_b", "seed")]
+        + [("drop_off", C.c_uint64 * 9)]
+        + [(n, C.c_void_p) for n in (
+            "x1", "ffm_n", "ffm_mean", "ffm_rstd", "ffm_z", "ffm_h",
+            "n_mha", "n_mlp", "br_mean", "br_rstd",
+            "qkv", "pp", "cx", "lse", "xa",
+            "g", "g_z", "gn", "g_mean", "g_rstd", "u", "conv", "xm",
+            "score", "pooled", "wts", "m",
+            "x2", "ff_n", "ff_mean", "ff_rstd", "ff_z", "ff_h", "x3", "y", "fin_mean", "fin_rstd",
+            "stream2", "ev_fork", "ev_join", "ws")]
+        + [("ws_floats", C.c_int64)]
+    )
+
+
 class FfnDesc(C.Structure):
     """tavsr_ffn_desc (include/tavsr.h)"""
     _fields_ = [

@@ -269,6 +269,115 @@ BF_PARAM_NAMES = (
 _I = {n: i for i, n in enumerate(BF_PARAM_NAMES)}
 
 
+_LAYER_WS = {}
+
+
+def _layer_c_ok(x, cfg, P, pd, pos_emb=None) -> bool:
+    """the recipe form that csrc/layer.hip sequences: both branches, learned-average merge + merge_proj, fused attention,
+    streaming FFN, one-pass CSGU, dropout in the GEMM epilogues"""
+    B, T, D = x.shape
+    cw = P[_I["cgmlp.csgu.conv.weight"]]
+    return (ops.LAYER_C and cfg["has_attn"] and cfg["has_mlp"] and cfg["merge"] == "learned_ave" and not cfg["merge_identity"]
+            and ops.ATTN_FUSED and ops.FFN2 and ops.CSGU_FUSED and ops.BRANCH_SIDE_STREAM and not ops.LIN2 and ops.PROFILE is None
+            and D == 256 and D // cfg["heads"] == 64 and cw is not None and cw.shape[-1] == 31 and (2 * cw.shape[0]) % 128 == 0
+            and P[_I["feed_forward.w_1.weight"]].shape[0] >= 1024 and P[_I["feed_forward.w_1.weight"]].shape[0] % 32 == 0
+            and P[_I["feed_forward_macaron.w_1.weight"]].shape == P[_I["feed_forward.w_1.weight"]].shape
+            and x.is_contiguous() and (pos_emb is None or pos_emb.is_contiguous())
+            and (pd == 0.0 or ops._drop_fusable(x.view(-1, D), D, D)))
+
+
+def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
+    """BranchformerLayerFn.forward as one C call (tavsr_branchformer_layer_fwd): allocates what the backward pass reads,
+    fills the descriptor, leaves ``ctx`` exactly as the Python sequencing does."""
+    from ._lib import BfLayerDesc, check, lib
+    import ctypes as C
+    B, T, D = x.shape
+    M, H = B * T, cfg["heads"]
+    W = 2 * T - 1
+    p = lambda n: P[_I[n]]
+    N1 = p("feed_forward.w_1.weight").shape[0]
+    C2 = p("cgmlp.channel_proj1.0.weight").shape[0]
+    Cn = C2 // 2
+    pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)
+    E = lambda *s: ops.empty(*s, like=x)
+    Mp = (M + 127) // 128 * 128
+    x2d = x.view(M, D)
+    d = BfLayerDesc()
+    d.B, d.T, d.D, d.H, d.ffn_units, d.cg_units, d.cg_kernel = B, T, D, H, N1, C2, 31
+    d.ffn_act, d.save = ops.ACT[cfg["ffn_act"]], int(need)
+    d.p_drop, d.p_att, d.coeff = pd, pa, cfg.get("coeff", 1.0)
+    d.x, d.pos_emb, d.lens = x2d.data_ptr(), pos_emb.data_ptr(), (None if lens is None else lens.data_ptr())
+    for f, n in (("ffm_ln_w", "norm_ff_macaron.weight"), ("ffm_ln_b", "norm_ff_macaron.bias"),
+                 ("ffm_w1", "feed_forward_macaron.w_1.weight"), ("ffm_b1", "feed_forward_macaron.w_1.bias"),
+                 ("ffm_w2", "feed_forward_macaron.w_2.weight"), ("ffm_b2", "feed_forward_macaron.w_2.bias"),
+                 ("mha_ln_w", "norm_mha.weight"), ("mha_ln_b", "norm_mha.bias"),
+                 ("wq", "attn.linear_q.weight"), ("bq", "attn.linear_q.bias"), ("wk", "attn.linear_k.weight"),
+                 ("bk", "attn.linear_k.bias"), ("wv", "attn.linear_v.weight"), ("bv", "attn.linear_v.bias"),
+                 ("wpos", "attn.linear_pos.weight"), ("pos_u", "attn.pos_bias_u"), ("pos_v", "attn.pos_bias_v"),
+                 ("wo", "attn.linear_out.weight"), ("bo", "attn.linear_out.bias"),
+                 ("mlp_ln_w", "norm_mlp.weight"), ("mlp_ln_b", "norm_mlp.bias"),
+                 ("cg_w1", "cgmlp.channel_proj1.0.weight"), ("cg_b1", "cgmlp.channel_proj1.0.bias"),
+                 ("csgu_ln_w", "cgmlp.csgu.norm.weight"), ("csgu_ln_b", "cgmlp.csgu.norm.bias"),
+                 ("csgu_cw", "cgmlp.csgu.conv.weight"), ("csgu_cb", "cgmlp.csgu.conv.bias"),
+                 ("cg_w2", "cgmlp.channel_proj2.weight"), ("cg_b2", "cgmlp.channel_proj2.bias"),
+                 ("merge_w", "merge_proj.weight"), ("merge_b", "merge_proj.bias"),
+                 ("ff_ln_w", "norm_ff.weight"), ("ff_ln_b", "norm_ff.bias"),
+                 ("ff_w1", "feed_forward.w_1.weight"), ("ff_b1", "feed_forward.w_1.bias"),
+                 ("ff_w2", "feed_forward.w_2.weight"), ("ff_b2", "feed_forward.w_2.bias"),
+                 ("final_ln_w", "norm_final.weight"), ("final_ln_b", "norm_final.bias")):
+        setattr(d, f, p(n).data_ptr())
+    for j, n in enumerate(("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias", "pooling_proj2.bias",
+                           "weight_proj1.weight", "weight_proj2.weight", "weight_proj1.bias", "weight_proj2.bias")):
+        d.merge_p[j] = p(n).data_ptr()
+    # dropout tokens in the order the Python sequencing draws them (same masks either way)
+    T4 = ops.pad4(T)
+    sizes = (M * N1, M * D, B * H * T * T4, M * D, M * Cn, M * D, M * D, M * N1, M * D)
+    rates = (pd, pd, pa, pd, pd, pd, pd, pd, pd)
+    toks = [ops._new_token(r, n, x.device) if r and r > 0.0 else None for r, n in zip(rates, sizes)]
+    for j, t in enumerate(toks):
+        if t is not None:
+            d.drop_off[j] = t[1]
+            d.seed = t[2].data_ptr()
+    # buffers
+    b = {k: E(M, D) for k in ("x1", "n_mha", "n_mlp", "cx", "xa", "xm", "m", "x2", "x3", "y")}
+    b.update(qkv=E(M, 3 * D), pp=E(W, D), lse=E(B * H, T), g=E(M, C2), u=E(M, Cn), g_mean=E(M), g_rstd=E(M),
+             score=E(2, B, T), pooled=E(2, B, D), wts=E(B, 2))
+    if need:
+        b.update(ffm_n=E(M, D), ff_n=E(M, D), ffm_z=E(Mp, N1)[:M], ffm_h=E(Mp, N1)[:M], ff_z=E(Mp, N1)[:M], ff_h=E(Mp, N1)[:M],
+                 g_z=E(M, C2), gn=E(M, Cn), conv=E(M, Cn))
+        b.update({k: E(M) for k in ("ffm_mean", "ffm_rstd", "br_mean", "br_rstd", "ff_mean", "ff_rstd", "fin_mean", "fin_rstd")})
+    for k, t in b.items():
+        setattr(d, k, t.data_ptr())
+    main = torch.cuda.current_stream()
+    side = ops.branch_stream(main)
+    ev = ops.branch_events(main)
+    d.stream2, d.ev_fork, d.ev_join = side.cuda_stream, ev[0].cuda_event, ev[1].cuda_event
+    key = (B, T, N1, C2)
+    nws = _LAYER_WS.get(key)
+    if nws is None:
+        fn = lib().tavsr_branchformer_layer_ws
+        fn.restype = C.c_int64
+        nws = _LAYER_WS[key] = int(fn(C.byref(d)))
+    ws = ops.empty(max(nws, 4), like=x)
+    d.ws, d.ws_floats = ws.data_ptr(), nws
+    check(lib().tavsr_branchformer_layer_fwd(C.byref(d), C.c_void_p(main.cuda_stream)), "tavsr_branchformer_layer_fwd")
+    g = b.get
+    sv = {"ffm": (x2d, g("ffm_mean"), g("ffm_rstd"), g("ffm_n"), g("ffm_z"), g("ffm_h"), toks[0], toks[1]),
+          "attn": (g("br_mean"), g("br_rstd"), b["n_mha"], b["qkv"], b["pp"], None, None, b["cx"], (b["lse"], toks[2]), None, toks[3]),
+          "mlp": (g("br_mean"), g("br_rstd"), b["n_mlp"], b["g"], g("g_z"), g("gn"), b["g_mean"], b["g_rstd"], b["u"], g("conv"),
+                  toks[4], toks[5]),
+          "merge": (b["score"], b["pooled"], b["wts"], b["m"]),
+          "drop": (None, toks[6]),
+          "ff": (b["x2"], g("ff_mean"), g("ff_rstd"), g("ff_n"), g("ff_z"), g("ff_h"), toks[7], toks[8]),
+          "final": (b["x3"], g("fin_mean"), g("fin_rstd")),
+          "x1": b["x1"], "xa": b["xa"], "xm": b["xm"]}
+    ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = sv, cfg, P, lens, pos_emb
+    ctx.shape = (B, T, D)
+    ctx._ws = ws                      # (freed with the node: every launch that reads it is already enqueued)
+    cfg["_last_w"] = b["wts"]
+    return b["y"].view(B, T, D)
+
+
 class BranchformerLayerFn(torch.autograd.Function):
     """``MyBranchformerEncoderLayer.forward`` (src/encoder/branchformer/encoder_layer.py:153-321) with
     dropout / stochastic depth disabled (rate 0 or eval); ``coeff`` is the stochastic-depth scale."""
@@ -286,6 +395,8 @@ class BranchformerLayerFn(torch.autograd.Function):
         coeff = cfg.get("coeff", 1.0)
         pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)     # dropout rates (0 in eval)
         p = lambda n: P[_I[n]]
+        if _layer_c_ok(x, cfg, P, pd, pos_emb):
+            return _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need)
         x2d = x.reshape(M, D)
         sv = {}
 

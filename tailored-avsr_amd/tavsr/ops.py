@@ -825,6 +825,24 @@ def ffn2_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
     return dz, dn
 
 
+# One Branchformer layer forward as ONE C call (csrc/layer.hip): the same launches, sequenced in C.  For un-captured loops
+# (the host is what limits an eager step); a captured step replays the same kernels either way.  TAVSR_LAYER_C=0: Python sequencing.
+LAYER_C = os.environ.get("TAVSR_LAYER_C", "1") == "1"
+_BR_EVENTS = {}
+
+
+def branch_events(main: torch.cuda.Stream):
+    """(fork, join) events of the side stream that belongs to ``main`` (created once; recorded once so that the handles exist)."""
+    key = (main.device.index, main.cuda_stream)
+    ev = _BR_EVENTS.get(key)
+    if ev is None:
+        ev = (torch.cuda.Event(), torch.cuda.Event())
+        for e in ev:
+            e.record(main)
+        _BR_EVENTS[key] = ev
+    return ev
+
+
 def axpby(x, y=None, a=1.0, b=1.0, out=None):
     if out is None:
         out = torch.empty_like(x)
