@@ -99,6 +99,11 @@ typedef struct tavsr_gemm_desc {
   float drop_p;
   const uint64_t* drop_seed;
   uint64_t drop_offset;
+  /* optional [M][ceil(N / 64)][2]: per row and 64-column tile, sum and sum of squares of the stored C values (after bias /
+     activation / alpha / residual) - LayerNorm statistics of the result without another pass over it (cgMLP: the gate half of
+     channel_proj1's output, consumed by tavsr_csgu_fwd).  Unbatched problems on the 16-byte path, no K split; otherwise
+     TAVSR_EUNSUPPORTED and nothing is launched. */
+  float* rowstat;
 } tavsr_gemm_desc;
 
 int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);
@@ -381,7 +386,10 @@ int tavsr_dwconv_gate_fwd(const float* gn, const float* r, int64_t ldr, const fl
  * shapes: TAVSR_EUNSUPPORTED (callers keep tavsr_layernorm_fwd + tavsr_dwconv_gate_fwd). */
 int tavsr_csgu_fwd(const float* g, int64_t ldg, const float* ln_w, const float* ln_b, float eps, const float* conv_w,
                    const float* conv_b, float* out, float* gn, float* conv, float* mean, float* rstd, float p_drop,
-                   const uint64_t* seed_dev, uint64_t offset, int32_t B, int32_t T, int32_t C, int32_t K, tavsr_stream_t stream);
+                   const uint64_t* seed_dev, uint64_t offset, int32_t B, int32_t T, int32_t C, int32_t K,
+                   const float* rowstat, tavsr_stream_t stream);
+/* rowstat (optional): the tavsr_gemm_desc.rowstat output of the GEMM that produced g ([B*T][ldg / 64][2]): the statistics launch is
+ * skipped, the gate rows' mean / rstd come from the C / 64 gate tiles' partial sums (C <= 1024) and are still written out. */
 int64_t tavsr_dwconv_gate_bwd_ws(int32_t B, int32_t T, int32_t C, int32_t K);
 int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv,
                           const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,

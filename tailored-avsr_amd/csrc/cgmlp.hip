@@ -129,7 +129,12 @@ __global__ __launch_bounds__(256, 2) void csgu_fwd_kernel(const float* __restric
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        float* __restrict__ out, float* __restrict__ conv, float* __restrict__ gn_out,
                                                        int B, int T, uint32_t thr, float inv_keep,
-                                                       const uint64_t* __restrict__ seed, uint64_t offset4) {
+                                                       const uint64_t* __restrict__ seed, uint64_t offset4,
+                                                       const float* __restrict__ rowstat, int stat_ld, float eps,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  // rowstat != null: the statistics come as per-row partial (sum, sum of squares) pairs of the 64-column tiles of the GEMM
+  // that produced g ([rows][stat_ld][2]; the gate half is tiles C / 64 ..): the 16 lanes that load a row fetch one pair each
+  // and reduce; block 0 writes mean / rstd out for the backward pass.
   constexpr int pad = (K - 1) / 2, rows = CG_TT + K - 1;
   __shared__ __attribute__((aligned(16))) float s_x[rows * CG_CH];
   __shared__ float s_w[CG_CH * K];
@@ -159,12 +164,35 @@ __global__ __launch_bounds__(256, 2) void csgu_fwd_kernel(const float* __restric
     const float* mb = mean + (int64_t)b * T;
     const float* sb = rstd + (int64_t)b * T;
     const int ldg32 = (int)ldg;
+    float2 sp[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const int tc = min(max(t0 + rr + 16 * q - pad, 0), T - 1);
       xv[q] = *reinterpret_cast<const float4*>(gb + (tc * ldg32 + C + cc));
-      mu[q] = mb[tc];
-      rs[q] = sb[tc];
+      if (rowstat) {
+        const int nt = C >> 6;                           // gate tiles (<= 16: one per lane of the row's 16)
+        sp[q] = l4 < nt ? *reinterpret_cast<const float2*>(rowstat + ((int64_t)(b * T + tc) * stat_ld + nt + l4) * 2)
+                        : make_float2(0.f, 0.f);
+      } else {
+        mu[q] = mb[tc];
+        rs[q] = sb[tc];
+      }
+    }
+    if (rowstat) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        float s1 = sp[q].x, s2 = sp[q].y;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const float m_ = s1 / (float)C;
+        mu[q] = m_;
+        rs[q] = rsqrtf(fmaxf(s2 / (float)C - m_ * m_, 0.f) + eps);
+        const int i = rr + 16 * q, t = t0 + i - pad;
+        if (mean_out && blockIdx.x == 0 && l4 == 0 && i >= pad && i < pad + CG_TT && t < T) {
+          mean_out[(int64_t)b * T + t] = mu[q];
+          rstd_out[(int64_t)b * T + t] = rs[q];
+        }
+      }
     }
     // x_r of the thread's output rows (rows tb .. tb + RP - 1 of the tile), fetched together with the gate tile
     const int tb = rg * RP;
@@ -810,7 +838,7 @@ extern "C" int tavsr_layernorm_fwd(const float* x, int64_t ldx, const float* gam
 extern "C" int tavsr_csgu_fwd(const float* g, int64_t ldg, const float* ln_w, const float* ln_b, float eps, const float* conv_w,
                               const float* conv_b, float* out, float* gn, float* conv, float* mean, float* rstd, float p_drop,
                               const uint64_t* seed_dev, uint64_t offset, int32_t B, int32_t T, int32_t C, int32_t K,
-                              tavsr_stream_t stream) {
+                              const float* rowstat, tavsr_stream_t stream) {
   TAVSR_REQUIRE(g && ln_w && ln_b && conv_w && conv_b && out && mean && rstd, TAVSR_EINVAL, "csgu_fwd: null pointer");
   TAVSR_REQUIRE(K == 31 && C > 0 && C % CG_CH == 0, TAVSR_EUNSUPPORTED, "csgu_fwd: kernel size 31 and C %% 64 == 0 (got %d, %d)", K, C);
   TAVSR_REQUIRE(ldg % 4 == 0 && ldg >= 2 * (int64_t)C && ((uintptr_t)g % 16 == 0) && ((uintptr_t)ln_w % 16 == 0) &&
@@ -818,12 +846,19 @@ extern "C" int tavsr_csgu_fwd(const float* g, int64_t ldg, const float* ln_w, co
   TAVSR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_dev) && offset % 4 == 0, TAVSR_EINVAL,
                 "csgu_fwd: dropout needs p in [0, 1), a device seed and an offset %% 4 == 0");
   if (B <= 0 || T <= 0) return TAVSR_OK;
-  // statistics of the gate rows (columns C .. 2C-1 of g), then the fused pass
-  int rc = tavsr_layernorm_fwd(g + C, ldg, nullptr, nullptr, eps, nullptr, 0, mean, rstd, B * T, C, stream);
-  if (rc) return rc;
+  // statistics of the gate rows (columns C .. 2C-1 of g) - a launch of their own, or the producing GEMM's row statistics -
+  // then the fused pass
+  if (rowstat) {
+    TAVSR_REQUIRE(C <= 1024 && ldg % 64 == 0 && ((uintptr_t)rowstat % 8 == 0), TAVSR_EUNSUPPORTED,
+                  "csgu_fwd: GEMM row statistics need C <= 1024 and a row stride %% 64 == 0");
+  } else {
+    int rc = tavsr_layernorm_fwd(g + C, ldg, nullptr, nullptr, eps, nullptr, 0, mean, rstd, B * T, C, stream);
+    if (rc) return rc;
+  }
   const uint32_t thr = p_drop > 0.f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
   hipLaunchKernelGGL(csgu_fwd_kernel<31>, dim3(C / CG_CH, B), dim3(256), 0, (hipStream_t)stream, g, ldg, C, mean, rstd, ln_w, ln_b,
-                     conv_w, conv_b, out, conv, gn, B, T, thr, p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_dev, offset / 4);
+                     conv_w, conv_b, out, conv, gn, B, T, thr, p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_dev, offset / 4,
+                     rowstat, (int)(ldg / 64), eps, mean, rstd);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -471,12 +471,15 @@ __device__ __forceinline__ void finish_tile_vec(const tavsr_gemm_desc& d, int ns
   const float* R = (!split && d.R) ? d.R + z1 * d.sR1 + z2 * d.sR2 : nullptr;
   float* Z = (!split && d.Z) ? d.Z + coff : nullptr;
   const float* DZ = (!split && d.DZ) ? d.DZ + coff : nullptr;
+  const bool rowstat = BN == 64 && !split && d.rowstat != nullptr;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const int idx = q * NT + tid, row = idx / V4R, c4 = idx % V4R;
     const int m = m0 + row, n = n0 + 4 * c4;
-    if (m >= d.M || n >= d.N) continue;
-    float4 v = *reinterpret_cast<const float4*>(img + row * BN + 4 * c4);
+    const bool ok = m < d.M && n < d.N;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+    v = *reinterpret_cast<const float4*>(img + row * BN + 4 * c4);
     const int64_t o = (int64_t)m * ld + n;
     if (!split) {
       if (d.bias) {
@@ -505,6 +508,14 @@ __device__ __forceinline__ void finish_tile_vec(const tavsr_gemm_desc& d, int ns
       }
     }
     *reinterpret_cast<float4*>(base + o) = v;
+    }
+    if (rowstat) {       // the 16 lanes that share a row of a 64-wide tile: sum and sum of squares of what was stored
+      float s1 = ok ? (v.x + v.y) + (v.z + v.w) : 0.f, s2 = ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+#pragma unroll
+      for (int o2 = 8; o2 > 0; o2 >>= 1) { s1 += __shfl_xor(s1, o2, 64); s2 += __shfl_xor(s2, o2, 64); }
+      if (c4 == 0 && m < d.M)
+        *reinterpret_cast<float2*>(d.rowstat + ((int64_t)m * ((d.N + 63) / 64) + n0 / 64) * 2) = make_float2(s1, s2);
+    }
   }
 }
 
@@ -1439,6 +1450,11 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
                   "tavsr_gemm: dropout needs p in (0, 1), a device seed and an offset %% 4 == 0");
     TAVSR_REQUIRE((fast || tail) && force_cfg < 0 && d.nb1 * d.nb2 == 1 && vec_epi_ok(d), TAVSR_EUNSUPPORTED,
                   "tavsr_gemm: epilogue dropout needs an unbatched problem on the 16-byte path");
+  }
+  if (d.rowstat) {
+    TAVSR_REQUIRE(fast && force_cfg < 0 && d.nb1 * d.nb2 == 1 && vec_epi_ok(d) && aligned16(d.rowstat), TAVSR_EUNSUPPORTED,
+                  "tavsr_gemm: row statistics need an unbatched problem on the 16-byte path");
+    return launch(8, d, vec, 1, d.K, s);             // 64-wide tiles, no K split: the statistics are taken where the tile is stored
   }
   Plan p = plan(d, can_split, fast || tail);
   if (tail) {

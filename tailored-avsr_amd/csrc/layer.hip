@@ -115,10 +115,13 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
     tavsr_gemm_desc g1 = lin(M, C2, D, d->n_mlp, D, d->cg_w1, d->cg_b1, d->g, C2);
     g1.act = TAVSR_ACT_GELU;
     if (d->save) g1.Z = d->g_z;
+    // the GEMM's epilogue leaves per-row partial sums of its 64-column tiles: the CSGU's LayerNorm statistics without a launch
+    float* rowstat = Cn <= 1024 ? ws.take((int64_t)M * (C2 / 64) * 2) : nullptr;
+    g1.rowstat = rowstat;
     if ((rc = run_gemm(g1, ws, s))) return rc;
     if (!dry && (rc = tavsr_csgu_fwd(d->g, C2, d->csgu_ln_w, d->csgu_ln_b, 1e-12f, d->csgu_cw, d->csgu_cb, d->u, d->save ? d->gn : nullptr,
                                      d->save ? d->conv : nullptr, d->g_mean, d->g_rstd, d->p_drop, d->seed, d->drop_off[4], d->B,
-                                     d->T, Cn, d->cg_kernel, (tavsr_stream_t)s)))
+                                     d->T, Cn, d->cg_kernel, rowstat, (tavsr_stream_t)s)))
       return rc;
     tavsr_gemm_desc g2 = lin(M, D, Cn, d->u, Cn, d->cg_w2, d->cg_b2, d->xm, D);
     g2.drop_p = d->p_drop; g2.drop_seed = d->seed; g2.drop_offset = d->drop_off[5];

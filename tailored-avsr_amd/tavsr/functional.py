@@ -277,6 +277,10 @@ def _layer_c_ok(x, cfg, P, pd, pos_emb=None) -> bool:
     streaming FFN, one-pass CSGU, dropout in the GEMM epilogues"""
     B, T, D = x.shape
     cw = P[_I["cgmlp.csgu.conv.weight"]]
+    # (un-captured loops only: a captured step replays the same kernels either way, and the capture of the Python sequencing
+    # measured 1 % faster on the train-mode forward - allocation order - so it keeps that)
+    if ops.LAYER_C_EAGER_ONLY and torch.cuda.is_current_stream_capturing():
+        return False
     return (ops.LAYER_C and cfg["has_attn"] and cfg["has_mlp"] and cfg["merge"] == "learned_ave" and not cfg["merge_identity"]
             and ops.ATTN_FUSED and ops.FFN2 and ops.CSGU_FUSED and ops.BRANCH_SIDE_STREAM and not ops.LIN2 and ops.PROFILE is None
             and D == 256 and D // cfg["heads"] == 64 and cw is not None and cw.shape[-1] == 31 and (2 * cw.shape[0]) % 128 == 0
@@ -437,16 +441,20 @@ class BranchformerLayerFn(torch.autograd.Function):
                 sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
         if has_mlp:
             n, mean, rstd = nbr[-1], bmean, brstd
-            if need:
-                g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu",
-                                  save_z=True)
-            else:
-                g, z = ops.linear(n, p("cgmlp.channel_proj1.0.weight"), p("cgmlp.channel_proj1.0.bias"), act="gelu"), None
-            Cn = g.shape[1] // 2
+            w1c = p("cgmlp.channel_proj1.0.weight")
             cw = p("cgmlp.csgu.conv.weight")
+            # channel_proj1's epilogue leaves the CSGU's LayerNorm statistics as per-tile row sums (no statistics launch)
+            rst = (ops.empty(M, w1c.shape[0] // 64, 2, like=x)
+                   if (ops.CSGU_FUSED and cw.shape[-1] == 31 and ops.csgu_rowstat_ok(n, w1c)) else None)
+            if need:
+                g, z = ops.linear(n, w1c, p("cgmlp.channel_proj1.0.bias"), act="gelu", save_z=True, rowstat=rst)
+            else:
+                g, z = ops.linear(n, w1c, p("cgmlp.channel_proj1.0.bias"), act="gelu", rowstat=rst), None
+            Cn = g.shape[1] // 2
             if ops.csgu_usable(g, cw):       # LayerNorm + depthwise convolution + gate + dropout: one pass over g
                 u, conv, gn, gmean, grstd, t_u = ops.csgu_fwd(g, p("cgmlp.csgu.norm.weight"), p("cgmlp.csgu.norm.bias"), EPS_ESPNET,
-                                                              cw.reshape(Cn, -1), p("cgmlp.csgu.conv.bias"), B, T, p=pd, save=need)
+                                                              cw.reshape(Cn, -1), p("cgmlp.csgu.conv.bias"), B, T, p=pd, save=need,
+                                                              rowstat=rst)
             else:
                 gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p("cgmlp.csgu.norm.weight"), p("cgmlp.csgu.norm.bias"),
                                                      EPS_ESPNET)

@@ -333,15 +333,20 @@ def _ts_branch_fwd(p, cfg, x1, n, mean, rstd, pos_emb, lens, B, T, need):
         # residual + coeff * dropout(att)  (encoder_layer.py:196,243): the dropout rides in the GEMM epilogue
         x2, t_br = ops.linear_drop(cx, p["attn.linear_out.weight"], p["attn.linear_out.bias"], pd, alpha=coeff, res=x1)
         return x2, (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
-    if need:
-        g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True)
-    else:
-        g, z = ops.linear(n, p["cgmlp.channel_proj1.0.weight"], p["cgmlp.channel_proj1.0.bias"], act="gelu"), None
-    Cn = g.shape[1] // 2
+    w1c = p["cgmlp.channel_proj1.0.weight"]
     cw = p["cgmlp.csgu.conv.weight"]
+    # channel_proj1's epilogue leaves the CSGU's LayerNorm statistics as per-tile row sums (no statistics launch)
+    rst = (ops.empty(n.shape[0], w1c.shape[0] // 64, 2, like=n)
+           if (ops.CSGU_FUSED and cw.shape[-1] == 31 and ops.csgu_rowstat_ok(n, w1c)) else None)
+    if need:
+        g, z = ops.linear(n, w1c, p["cgmlp.channel_proj1.0.bias"], act="gelu", save_z=True, rowstat=rst)
+    else:
+        g, z = ops.linear(n, w1c, p["cgmlp.channel_proj1.0.bias"], act="gelu", rowstat=rst), None
+    Cn = g.shape[1] // 2
     if ops.csgu_usable(g, cw):         # LayerNorm + depthwise convolution + gate + dropout: one pass over g
         u, conv, gn, gmean, grstd, t_u = ops.csgu_fwd(g, p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET,
-                                                      cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T, p=pd, save=need)
+                                                      cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T, p=pd, save=need,
+                                                      rowstat=rst)
     else:
         gn, gmean, grstd = ops.layernorm_fwd(g[:, Cn:], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], EPS_ESPNET)
         u, conv = ops.dwconv_gate_fwd(gn, g[:, :Cn], cw.reshape(Cn, -1), p["cgmlp.csgu.conv.bias"], B, T)

@@ -67,7 +67,7 @@ def _zero_page(device) -> torch.Tensor:
 def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
          R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, conv=None, force=None, ws_cap=None,
-         drop=None):
+         drop=None, rowstat=None):
     """Raw descriptor call; offsets are in elements into the given tensors.  ``force=(cfg, nsplit)`` bypasses
     the planner (tuning / tests); ``ws_cap`` caps the split-K workspace handed to the library (tests of its fallback)."""
     require_cuda(A, B, Cc, bias, Z, R, DZ, a_rowsum)
@@ -93,6 +93,8 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.a_rowsum = a_rowsum.data_ptr()
     if drop is not None:        # dropout token (p, offset, seed tensor): the mask rides in the epilogue
         d.drop_p, d.drop_offset, d.drop_seed = drop[0], drop[1], drop[2].data_ptr()
+    if rowstat is not None:     # [M, ceil(N / 64), 2]: per-row (sum, sum of squares) of every 64-column tile of the result
+        d.rowstat = rowstat.data_ptr()
     if conv is not None:       # (mode, H, W, C[, stride, taps]): implicit convolution operand (include/tavsr.h)
         d.conv_mode, d.conv_H, d.conv_W, d.conv_C = conv[:4]
         if len(conv) > 4:
@@ -139,8 +141,10 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
     PROFILE.records.append((key, fl, 4.0 * nb * (a_el + b_el + c_el), e0, e1))
 
 
-def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None, force=None):
-    """y = res + alpha*act(x @ w.T + b); x [M,K] (row stride x.stride(0)), w [N,K] torch layout."""
+def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None, force=None,
+           rowstat=None):
+    """y = res + alpha*act(x @ w.T + b); x [M,K] (row stride x.stride(0)), w [N,K] torch layout.  ``rowstat`` (tensor
+    [M, ceil(N / 64), 2]): receives the per-row (sum, sum of squares) of every 64-column tile of y (tavsr_gemm_desc.rowstat)."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
@@ -148,11 +152,12 @@ def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=Non
         ldc = N
     z = empty(M, N, like=x) if save_z else None
     assert not save_z or (out_off == 0 and ldc == N)
-    if (res is None and alpha == 1.0 and force is None and N >= LIN2_MIN_N and ldc == out.stride(0) and lin2_usable(x, [w])):
+    if (rowstat is None and res is None and alpha == 1.0 and force is None and N >= LIN2_MIN_N and ldc == out.stride(0)
+            and lin2_usable(x, [w])):
         lin2_fwd(x, [(w, b, out, out_off, z)], act=act)
         return (out, z) if save_z else out
     gemm(M, N, K, x, x.stride(0), w, w.stride(0), out, ldc, c_off=out_off, bias=b, act=act, alpha=alpha, Z=z,
-         R=res, ldr=0 if res is None else res.stride(0), force=force)
+         R=res, ldr=0 if res is None else res.stride(0), force=force, rowstat=rowstat)
     return (out, z) if save_z else out
 
 
@@ -828,6 +833,7 @@ def ffn2_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
 # One Branchformer layer forward as ONE C call (csrc/layer.hip): the same launches, sequenced in C.  For un-captured loops
 # (the host is what limits an eager step); a captured step replays the same kernels either way.  TAVSR_LAYER_C=0: Python sequencing.
 LAYER_C = os.environ.get("TAVSR_LAYER_C", "1") == "1"
+LAYER_C_EAGER_ONLY = os.environ.get("TAVSR_LAYER_C_CAPTURE", "0") != "1"     # 1: also while a hipGraph is being captured
 _BR_EVENTS = {}
 
 
@@ -890,14 +896,24 @@ def dwconv_gate_fwd(gn, r, w, bias, B, T):
 
 
 CSGU_FUSED = os.environ.get("TAVSR_CSGU_FUSED", "1") == "1"
+CSGU_STATS_IN_GEMM = os.environ.get("TAVSR_CSGU_STATS_IN_GEMM", "1") == "1"     # A/B switch
 
 
 def csgu_usable(g, w) -> bool:
     return (CSGU_FUSED and w.shape[-1] == 31 and g.shape[1] % 128 == 0 and g.is_contiguous() and g.data_ptr() % 16 == 0)
 
 
-def csgu_fwd(g, ln_w, ln_b, eps, w, bias, B, T, p=0.0, save=True):
-    """dropout(g[:, :C] * dwconv(LayerNorm(g[:, C:]))) in one pass over g (+ the statistics launch).  Returns
+def csgu_rowstat_ok(x, w1) -> bool:
+    """can channel_proj1's GEMM leave the CSGU's LayerNorm statistics (tavsr_gemm_desc.rowstat)?  (16-byte path, gate half of
+    at most 1024 channels in whole 64-column tiles)"""
+    return (CSGU_STATS_IN_GEMM and PROFILE is None and not LIN2 and os.environ.get("TAVSR_GEMM_VEC_EPI", "1") == "1"
+            and w1.is_contiguous() and w1.shape[0] % 128 == 0 and w1.shape[0] <= 2048
+            and x.shape[1] % 32 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def csgu_fwd(g, ln_w, ln_b, eps, w, bias, B, T, p=0.0, save=True, rowstat=None):
+    """dropout(g[:, :C] * dwconv(LayerNorm(g[:, C:]))) in one pass over g (+ the statistics launch, unless ``rowstat`` - the
+    row statistics the GEMM that produced g left, ops.linear(..., rowstat=) - is given).  Returns
     (u, conv, gn, mean, rstd, token); conv / gn only when ``save``."""
     M, C2 = g.shape
     Cn = C2 // 2
@@ -908,7 +924,8 @@ def csgu_fwd(g, ln_w, ln_b, eps, w, bias, B, T, p=0.0, save=True):
     tok = _new_token(p, M * Cn, g.device) if p and p > 0.0 else None
     check(lib().tavsr_csgu_fwd(ptr(g), C.c_int64(g.stride(0)), ptr(ln_w), ptr(ln_b), C.c_float(eps), ptr(w), ptr(bias), ptr(out),
                                ptr(gn), ptr(conv), ptr(mean), ptr(rstd), C.c_float(tok[0] if tok else 0.0),
-                               ptr(tok[2] if tok else None), C.c_uint64(tok[1] if tok else 0), B, T, Cn, w.shape[-1], stream()),
+                               ptr(tok[2] if tok else None), C.c_uint64(tok[1] if tok else 0), B, T, Cn, w.shape[-1], ptr(rowstat),
+                               stream()),
           "tavsr_csgu_fwd")
     return out, conv, gn, mean, rstd, tok
 

@@ -141,6 +141,23 @@ def test_csgu_fused_forward(B, T, p):
     ops.manual_seed(77)
     u2, conv2, gn2, _, _, _ = ops.csgu_fwd(g, lw, lb, 1e-12, w.view(Cn, K), bias, B, T, p=p, save=False)
     assert conv2 is None and gn2 is None and torch.equal(u2, u)
+    # statistics from the producing GEMM's epilogue (tavsr_gemm_desc.rowstat) instead of the statistics launch
+    x = torch.randn(B * T, 256, device="cuda")
+    w1, b1 = torch.randn(2 * Cn, 256, device="cuda") / 16, 0.1 * torch.randn(2 * Cn, device="cuda")
+    rst = torch.empty(B * T, 2 * Cn // 64, 2, device="cuda")
+    g2 = ops.linear(x, w1, b1, act="gelu", rowstat=rst)
+    g2d = g2.double().view(B * T, 2 * Cn // 64, 64)
+    _close(rst[..., 0], g2d.sum(-1), 1e-5)
+    _close(rst[..., 1], (g2d * g2d).sum(-1), 1e-5)
+    assert torch.equal(g2, ops.linear(x, w1, b1, act="gelu"))
+    ops.manual_seed(78)
+    ua, ca, gna, ma, ra, _ = ops.csgu_fwd(g2, lw, lb, 1e-12, w.view(Cn, K), bias, B, T, p=p, save=True, rowstat=rst)
+    ops.manual_seed(78)
+    ub, cb, gnb, mb_, rb, _ = ops.csgu_fwd(g2, lw, lb, 1e-12, w.view(Cn, K), bias, B, T, p=p, save=True)
+    _close(ma, mb_, 1e-5)
+    _close(ra, rb, 1e-5)
+    _close(gna, gnb, 1e-5)
+    _close(ua, ub, 1e-5)
 
 
 @pytest.mark.parametrize("T", [23, 99, 128, 150])     # <= 128: the single-read kernel; beyond: the two-pass one
