@@ -6,6 +6,7 @@ tensor manipulation such as add_sos_eos); every floating-point op runs in libtav
 """
 from __future__ import annotations
 
+import os
 from itertools import groupby
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -80,6 +81,9 @@ class ErrorCalculator:
             d = sum(_levenshtein(h.split(), r.split()) for h, r in zip(hyps, refs))
             wer = d / sum(len(r.split()) for r in refs)
         return cer, wer
+
+
+LOSS_BRANCH = os.environ.get("TAVSR_LOSS_BRANCH", "1") == "1"      # A/B switch: CTC branch beside the attention decoder
 
 
 def cut_to_longest(x: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
@@ -171,28 +175,32 @@ class ESPnetASRModel(torch.nn.Module):
             encoder_out, intermediate_outs = encoder_out
         stats: Dict[str, Optional[torch.Tensor]] = dict()
         loss_ctc = loss_att = None
-        if self.ctc_weight != 0.0:
-            loss_ctc = self.ctc(encoder_out, encoder_out_lens, text, text_lengths)
-            cer_ctc = None
-            if not self.training and self.error_calculator is not None:
-                ys_hat = self.ctc.argmax(encoder_out).data
-                cer_ctc = self.error_calculator(ys_hat.cpu(), text.cpu(), is_ctc=True)
-            stats["loss_ctc"], stats["cer_ctc"] = loss_ctc.detach(), cer_ctc
-        if self.interctc_weight != 0.0 and intermediate_outs is not None:      # espnet_model.py:260-304
-            if self.aux_ctc is not None:
-                raise NotImplementedError("aux_ctc tasks are not used by any shipped recipe")
-            loss_interctc = None
-            for layer_idx, intermediate_out in intermediate_outs:
-                loss_ic = self.ctc(intermediate_out, encoder_out_lens, text, text_lengths)
-                cer_ic = None
+        # training: the CTC branch (projection, loss, their backward) is independent of the attention decoder - it is enqueued on
+        # the side queue and runs beside the decoder, forward and (autograd replays a node on its forward queue) backward
+        br = ops.BranchScope(LOSS_BRANCH and self.training and encoder_out.is_cuda and self.ctc_weight not in (0.0, 1.0))
+        with br:
+            if self.ctc_weight != 0.0:
+                loss_ctc = self.ctc(encoder_out, encoder_out_lens, text, text_lengths)
+                cer_ctc = None
                 if not self.training and self.error_calculator is not None:
-                    ys_hat = self.ctc.argmax(intermediate_out).data
-                    cer_ic = self.error_calculator(ys_hat.cpu(), text.cpu(), is_ctc=True)
-                loss_interctc = loss_ic if loss_interctc is None else F_.WeightedSumFn.apply(loss_interctc, loss_ic, 1.0, 1.0)
-                stats[f"loss_interctc_layer{layer_idx}"] = loss_ic.detach()
-                stats[f"cer_interctc_layer{layer_idx}"] = cer_ic
-            n_ic = len(intermediate_outs)
-            loss_ctc = F_.WeightedSumFn.apply(loss_ctc, loss_interctc, 1 - self.interctc_weight, self.interctc_weight / n_ic)
+                    ys_hat = self.ctc.argmax(encoder_out).data
+                    cer_ctc = self.error_calculator(ys_hat.cpu(), text.cpu(), is_ctc=True)
+                stats["loss_ctc"], stats["cer_ctc"] = loss_ctc.detach(), cer_ctc
+            if self.interctc_weight != 0.0 and intermediate_outs is not None:      # espnet_model.py:260-304
+                if self.aux_ctc is not None:
+                    raise NotImplementedError("aux_ctc tasks are not used by any shipped recipe")
+                loss_interctc = None
+                for layer_idx, intermediate_out in intermediate_outs:
+                    loss_ic = self.ctc(intermediate_out, encoder_out_lens, text, text_lengths)
+                    cer_ic = None
+                    if not self.training and self.error_calculator is not None:
+                        ys_hat = self.ctc.argmax(intermediate_out).data
+                        cer_ic = self.error_calculator(ys_hat.cpu(), text.cpu(), is_ctc=True)
+                    loss_interctc = loss_ic if loss_interctc is None else F_.WeightedSumFn.apply(loss_interctc, loss_ic, 1.0, 1.0)
+                    stats[f"loss_interctc_layer{layer_idx}"] = loss_ic.detach()
+                    stats[f"cer_interctc_layer{layer_idx}"] = cer_ic
+                n_ic = len(intermediate_outs)
+                loss_ctc = F_.WeightedSumFn.apply(loss_ctc, loss_interctc, 1 - self.interctc_weight, self.interctc_weight / n_ic)
         acc_att = cer_att = wer_att = None
         if self.ctc_weight != 1.0:
             ys_in, ys_out = add_sos_eos(text, text_lengths, self.sos, self.eos, self.ignore_id)
@@ -203,6 +211,7 @@ class ESPnetASRModel(torch.nn.Module):
             if not self.training and self.error_calculator is not None:
                 ids, _, _ = ops.ctc_greedy(decoder_out.detach().contiguous(), None, -1, collapse=False)  # argmax(-1)
                 cer_att, wer_att = self.error_calculator(ids.cpu(), text.cpu())
+        br.join()
         if self.ctc_weight == 0.0:
             loss = loss_att
         elif self.ctc_weight == 1.0:
