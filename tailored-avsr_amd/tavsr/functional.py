@@ -377,7 +377,8 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
           "x1": b["x1"], "xa": b["xa"], "xm": b["xm"]}
     ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = sv, cfg, P, lens, pos_emb
     ctx.shape = (B, T, D)
-    ctx._ws = ws                      # (freed with the node: every launch that reads it is already enqueued)
+    # (ws goes back to the allocator here: every launch that reads it is enqueued, the side queue has been joined into the calling
+    # one inside the call, and the block can only be handed to later work of the calling queue)
     cfg["_last_w"] = b["wts"]
     return b["y"].view(B, T, D)
 
