@@ -131,6 +131,7 @@ def test_ffn2_dropout_is_the_gemm_path_dropout(cfg):
     (3168, 2048, "swish", 0.1, "13,4"),
     (1312, 2048, "relu", 0.1, None),
     (100, 2048, "swish", 0.0, None),       # padded last row block; z handed over with exactly M rows
+    (1, 2048, "swish", 0.1, None),         # a single row
     (300, 1056, "relu", 0.2, "2,4"),
 ])
 def test_ffn2_backward_dx_matches_fp64(M, N1, act, p, cfg):

@@ -46,7 +46,7 @@ def _run(layer_c, train, B, T, lens):
         ops.LAYER_C = keep
 
 
-@pytest.mark.parametrize("B,T", [(4, 99), (3, 40), (2, 150)])
+@pytest.mark.parametrize("B,T", [(4, 99), (3, 40), (2, 150), (1, 5)])
 @pytest.mark.parametrize("train", [False, True])
 def test_layer_forward_in_c_equals_python_sequencing(B, T, train):
     lens = torch.tensor([T, max(1, (2 * T) // 3), max(1, T // 2), T][:B], device="cuda")

@@ -109,6 +109,30 @@ def test_dwconv_gate(B, T):
     _close(db, br.grad, 1e-4)
 
 
+@pytest.mark.parametrize("B,T,Cn", [(2, 1, 1024), (1, 129, 1024), (3, 16, 512), (1, 257, 256)])
+def test_csgu_fused_forward_edge_shapes(B, T, Cn):
+    """one-row utterances (the window is almost all padding), a second time tile of one row, gate halves of 8 / 4 tiles
+    (fewer partial pairs than the 16 lanes that reduce them) - with the statistics from the GEMM epilogue and from the launch"""
+    from tavsr import ops
+    torch.manual_seed(B * 1000 + T)
+    K = 31
+    x = torch.randn(B * T, 256, device="cuda")
+    w1, b1 = torch.randn(2 * Cn, 256, device="cuda") / 16, 0.1 * torch.randn(2 * Cn, device="cuda")
+    lw, lb = 1 + 0.1 * torch.randn(Cn, device="cuda"), 0.1 * torch.randn(Cn, device="cuda")
+    w, bias = torch.randn(Cn, 1, K, device="cuda") / 5, torch.randn(Cn, device="cuda")
+    rst = torch.empty(B * T, 2 * Cn // 64, 2, device="cuda")
+    g = ops.linear(x, w1, b1, act="gelu", rowstat=rst)
+    gd = g.double()
+    gnr = F.layer_norm(gd[:, Cn:], (Cn,), lw.double(), lb.double(), 1e-12)
+    cr = F.conv1d(gnr.view(B, T, Cn).transpose(1, 2), w.double(), bias.double(), 1, 15, 1, Cn).transpose(1, 2).reshape(B * T, Cn)
+    for stats in (rst, None):
+        u, conv, gn, mean, rstd, _ = ops.csgu_fwd(g, lw, lb, 1e-12, w.view(Cn, K), bias, B, T, save=True, rowstat=stats)
+        _close(gn, gnr, 2e-5)
+        _close(conv, cr, 2e-5)
+        _close(u, gd[:, :Cn] * cr, 2e-5)
+        _close(mean, gd[:, Cn:].mean(1), 2e-5)
+
+
 @pytest.mark.parametrize("B,T,p", [(3, 23, 0.0), (32, 99, 0.0), (2, 99, 0.1), (1, 300, 0.2), (2, 128, 0.0)])
 def test_csgu_fused_forward(B, T, p):
     """tavsr_csgu_fwd (LayerNorm statistics + normalise / 31-tap depthwise convolution / gate / dropout in one pass over g)
