@@ -298,6 +298,7 @@ class BranchScope:
 
     def __init__(self, enabled=True):
         self.enabled = enabled and BRANCH_SIDE_STREAM
+        self.on = False               # (join() of a scope that was never entered is a no-op)
         self._keep = []
 
     def keep(self, *objs):
