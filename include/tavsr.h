@@ -321,7 +321,7 @@ int tavsr_lin2_fwd(const float* x, int64_t ldx, int32_t M, int32_t K, const tavs
 /* ---------------------------------------------------------------------------------------------
  * One Branchformer encoder layer forward as ONE call (csrc/layer.hip): MyBranchformerEncoderLayer.forward
  * (src/encoder/branchformer/encoder_layer.py:153-321) in its recipe form - macaron FFN, rel-pos attention branch beside the
- * cgMLP branch, learned-average merge + merge_proj, FFN, norm_final - sequenced in C over the entry points above (14 launches;
+ * cgMLP branch, learned-average merge + merge_proj, FFN, norm_final - sequenced in C over the entry points above (13 launches;
  * the attention branch is enqueued on `stream2` between two events, as the Python sequencing does with a side stream).
  * All buffers are the caller's: the outputs / saved tensors below are exactly what the backward pass reads; `save` = 0 (eval)
  * leaves z / h / gn / conv untouched (may be NULL).  Dropout: rate p_drop (p_att inside the attention core) with the counter
