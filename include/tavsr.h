@@ -143,6 +143,13 @@ int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t l
 int tavsr_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                                 const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd, float* dx,
                                 int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D, tavsr_stream_t stream);
+/* ... and with a second output dx_drop [M][D] = dx * mask / keep under the tavsr_dropout mask of a contiguous [M][D] tensor at
+ * `offset`: the masked gradient that the backward of the next residual block's branch starts from
+ * (x + s * dropout(f(x)), encoder_layer.py:194,309,314) - saves that block's stand-alone mask launch. */
+int tavsr_layernorm_bwd_partial_drop(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                     const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd, float* dx,
+                                     int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D, float* dx_drop, float p_drop,
+                                     const uint64_t* seed_dev, uint64_t offset, tavsr_stream_t stream);
 int64_t tavsr_colsum_ws(int32_t M, int32_t N);
 /* out = x + y, sum_x[n] = sum_m x[m][n], sum_y[n] = sum_m y[m][n] in two launches (dQ = dQu + dQv with the pos_bias_u/v
  * gradients of RelPositionMultiHeadedAttention); ws >= 2 * tavsr_colsum_ws(M, N) floats */

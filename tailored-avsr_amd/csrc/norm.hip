@@ -73,7 +73,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ dx_add, int64_t ldadd,
                                                             float* __restrict__ dx, int64_t lddx,
-                                                            float* __restrict__ part, int64_t ld_part, int M, int D) {
+                                                            float* __restrict__ part, int64_t ld_part, int M, int D,
+                                                            float* __restrict__ dx_drop, uint32_t thr, float inv_keep,
+                                                            const uint64_t* __restrict__ seed, uint64_t offset4) {
+  // dx_drop != null: a second output [M][D] = dropout_backward(dx) under the tavsr_dropout mask at offset4 - the consumer of dx
+  // is a residual block whose branch starts with that mask (x + s * dropout(f(x))): saves its stand-alone mask launch
   __shared__ float red[4][2][NV * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float4 ag[NV], ab[NV], g[NV];
@@ -132,6 +136,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.z = rs[q] * (gd[i].z - s1 - xh[i].z * s2) + av[q][i].z;
           o.w = rs[q] * (gd[i].w - s1 - xh[i].w * s2) + av[q][i].w;
           *reinterpret_cast<float4*>(or_ + c) = o;
+          if (dx_drop) {
+            const uint64_t sd = seed[0], ctr = offset4 + (((uint64_t)(row0 + q) * (uint64_t)D + (uint64_t)c) >> 2);
+            uint32_t w4[4];
+            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), w4);
+            *reinterpret_cast<float4*>(dx_drop + (int64_t)(row0 + q) * D + c) =
+                make_float4(w4[0] >= thr ? o.x * inv_keep : 0.f, w4[1] >= thr ? o.y * inv_keep : 0.f,
+                            w4[2] >= thr ? o.z * inv_keep : 0.f, w4[3] >= thr ? o.w * inv_keep : 0.f);
+          }
         }
       }
     }
@@ -271,13 +283,46 @@ extern "C" int tavsr_layernorm_bwd_partial(const float* dy, int64_t lddy, const 
   hipStream_t s = (hipStream_t)stream;
   if (D <= 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, ws_ld, M, D);
+                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0);
   else if (D <= 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, ws_ld, M, D);
+                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, ws_ld, M, D);
+                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// tavsr_layernorm_bwd_partial that also writes dx_drop [M][D] = dx * mask / keep (the tavsr_dropout mask of a contiguous [M][D]
+// tensor at `offset`): the masked gradient the next residual block's branch starts from
+extern "C" int tavsr_layernorm_bwd_partial_drop(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                                const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd,
+                                                float* dx, int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D,
+                                                float* dx_drop, float p_drop, const uint64_t* seed_dev, uint64_t offset,
+                                                tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dy && x && mean && rstd && gamma && dx && ws && dx_drop && seed_dev, TAVSR_EINVAL, "layernorm_bwd_drop: null pointer");
+  TAVSR_REQUIRE(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, TAVSR_EUNSUPPORTED, "layernorm_bwd_drop: unsupported D=%d", D);
+  TAVSR_REQUIRE(ws_ld >= 2 * (int64_t)D, TAVSR_EINVAL, "layernorm_bwd_drop: partial slab rows too short");
+  TAVSR_REQUIRE(p_drop > 0.f && p_drop < 1.f && offset % 4 == 0, TAVSR_EINVAL, "layernorm_bwd_drop: p in (0, 1), offset %% 4 == 0");
+  TAVSR_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldadd % 4 == 0 && ((uintptr_t)x % 16 == 0) &&
+                    ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) && ((uintptr_t)dx_add % 16 == 0) &&
+                    ((uintptr_t)dx_drop % 16 == 0),
+                TAVSR_EALIGN, "layernorm_bwd_drop: rows must be 16-byte aligned");
+  if (M <= 0) return TAVSR_OK;
+  const int nb = ln_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+  const float ik = 1.f / (1.f - p_drop);
+  if (D <= 256)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx,
+                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4);
+  else if (D <= 512)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx,
+                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx,
+                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

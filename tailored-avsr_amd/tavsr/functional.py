@@ -107,7 +107,7 @@ class _FFN:
         return y, saved, outs, m2, r2
 
     @staticmethod
-    def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None, lng=None, chain=True):
+    def bwd(dy, saved, ln_w, w1, w2, act, scale, grp=None, lng=None, chain=True, dyd=None, out_drop=None):
         """returns dx (includes the residual path) and grads (ln_w, ln_b, w1, b1, w2, b2).  ``grp`` (ops.WgradGroup)
         defers the two weight gradients to the caller's grouped launch.  ``chain``: the two activation gradients as one
         streaming launch (ops.ffn2_bwd_dx) instead of two dgrad GEMMs - callers that run two of these blocks side by side
@@ -117,7 +117,8 @@ class _FFN:
             saved = saved[1:]
         x, mean, rstd, n, z, h, t_in, t_out = saved
         wgrad = ops.linear_dw if grp is None else grp.add
-        dyd = _drop_bwd(dy, t_out)
+        if dyd is None:              # (callers whose producer of dy is a LayerNorm backward get the masked copy from that launch)
+            dyd = _drop_bwd(dy, t_out)
         gw2, gb2 = wgrad(dyd, h, alpha=scale, bias_grad=True)
         stream2 = chain and not fused and ops.FFN2_BWD and ops.ffn2_shape_ok(dyd, w1, act) and z.is_contiguous()
         if fused:
@@ -129,6 +130,9 @@ class _FFN:
         gw1, gb1 = wgrad(dz, n, bias_grad=True)
         if not fused and not stream2:
             dn = ops.linear_dx(dz, w1)
+        if out_drop is not None and lng is not None:       # + dx under the NEXT block's outer mask, from the same launch
+            dx, gln_w, gln_b, dxd = lng.bwd(dn, x, mean, rstd, ln_w, dx_add=dy, drop=out_drop)
+            return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2), dxd
         ln_bwd = ops.layernorm_bwd if lng is None else lng.bwd      # lng: the node's shared (dgamma, dbeta) reduction
         dx, gln_w, gln_b = ln_bwd(dn, x, mean, rstd, ln_w, dx_add=dy)
         return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2)
@@ -529,21 +533,25 @@ class BranchformerLayerFn(torch.autograd.Function):
         lng = ops.LNGroup()        # ... and the five d=256 LayerNorms' (dgamma, dbeta) partials in one reduction
         dy2 = dy.contiguous().view(M, D)
         x3, fmean, frstd = sv["final"]
-        dx3, g1, g2 = lng.bwd(dy2, x3, fmean, frstd, p("norm_final.weight"))
+        # each LayerNorm backward whose dx the next block's dropout mask is applied to also writes the masked copy
+        t_m = sv["drop"][1]
+        t_ff, t_ffm = sv["ff"][-1], sv["ffm"][-1]
+        dx3, g1, g2, *dyd = lng.bwd(dy2, x3, fmean, frstd, p("norm_final.weight"), drop=t_ff)
         put("norm_final.weight", g1); put("norm_final.bias", g2)
-        dx2, gs = _FFN.bwd(dx3, sv["ff"], p("norm_ff.weight"), p("feed_forward.w_1.weight"),
-                           p("feed_forward.w_2.weight"), act, 0.5, grp=grp, lng=lng)
+        dx2, gs, *dxd = _FFN.bwd(dx3, sv["ff"], p("norm_ff.weight"), p("feed_forward.w_1.weight"),
+                                 p("feed_forward.w_2.weight"), act, 0.5, grp=grp, lng=lng, dyd=dyd[0] if dyd else None,
+                                 out_drop=None if cfg["merge_identity"] else t_m)
         for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                           "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
             put(n_, g)
         # merge projection: x2 = x1 + coeff * (m Wm^T + bm)
         m = sv["merge"][-1]
-        t_cat, t_m = sv["drop"]
+        t_cat = sv["drop"][0]
         if cfg["merge_identity"]:
             dm = ops.axpby(dx2, None, coeff, 0.0) if (coeff != 1.0 or t_m is not None) else dx2
             _drop_bwd_(dm, t_m) if t_m is not None else None
         else:
-            dxd = _drop_bwd(dx2, t_m)
+            dxd = dxd[0] if dxd else _drop_bwd(dx2, t_m)
             gw_, gb_ = grp.add(dxd, m, alpha=coeff, bias_grad=True)
             put("merge_proj.weight", gw_); put("merge_proj.bias", gb_)
             dm = ops.linear_dx(dxd, p("merge_proj.weight"), alpha=coeff)
@@ -617,14 +625,14 @@ class BranchformerLayerFn(torch.autograd.Function):
             gw_, gb_ = grp.add(dg, n, bias_grad=True)
             put("cgmlp.channel_proj1.0.weight", gw_); put("cgmlp.channel_proj1.0.bias", gb_)
             dn = ops.linear_dx(dg, p("cgmlp.channel_proj1.0.weight"))
-            dx1, g1, g2 = lng.bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1)
+            dx1, g1, g2, *dyd = lng.bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1, drop=None if has_attn else t_ffm)
             put("norm_mlp.weight", g1); put("norm_mlp.bias", g2)
         br.join()
         if has_attn:     # same accumulation order into dx1 as a single stream: cgMLP branch first, then attention
-            dx1, g1, g2 = lng.bwd(dn_a, x1, a_mean, a_rstd, p("norm_mha.weight"), dx_add=dx1)
+            dx1, g1, g2, *dyd = lng.bwd(dn_a, x1, a_mean, a_rstd, p("norm_mha.weight"), dx_add=dx1, drop=t_ffm)
             put("norm_mha.weight", g1); put("norm_mha.bias", g2)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p("norm_ff_macaron.weight"), p("feed_forward_macaron.w_1.weight"),
-                          p("feed_forward_macaron.w_2.weight"), act, 0.5, grp=grp, lng=lng)
+                          p("feed_forward_macaron.w_2.weight"), act, 0.5, grp=grp, lng=lng, dyd=dyd[0] if dyd else None)
         for n_, g in zip(("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight",
                           "feed_forward_macaron.w_1.bias", "feed_forward_macaron.w_2.weight",
                           "feed_forward_macaron.w_2.bias"), gs):
@@ -919,7 +927,8 @@ class TransformerDecoderFn(torch.autograd.Function):
         G[an_i + 2], G[an_i + 3] = ops.linear_dw(dl, xn, bias_grad=True)
         dxn = ops.linear_dx(dl, out_w)
         lng = ops.LNGroup(cap=3 * nb + 1)     # all LayerNorms of the decoder: one (dgamma, dbeta) reduction at the end
-        dx, G[an_i], G[an_i + 1] = lng.bwd(dxn, x, mf, rf, an_w)
+        # (every LayerNorm backward also writes its dx under the mask of the residual block below it: no dropout launches)
+        dx, G[an_i], G[an_i + 1], *dyd = lng.bwd(dxn, x, mf, rf, an_w, drop=ctx.saved[nb - 1]["ff"][-1])
         dmem = None
         mem2 = ctx.mem2
         for li in reversed(range(nb)):
@@ -931,14 +940,14 @@ class TransformerDecoderFn(torch.autograd.Function):
 
             s = ctx.saved[li]
             grp = ops.WgradGroup()
-            dx2, gs = _FFN.bwd(dx, s["ff"], p("norm3.weight"), p("feed_forward.w_1.weight"), p("feed_forward.w_2.weight"),
-                               "relu", 1.0, grp=grp, lng=lng)
+            dx2, gs, *dt2 = _FFN.bwd(dx, s["ff"], p("norm3.weight"), p("feed_forward.w_1.weight"), p("feed_forward.w_2.weight"),
+                                     "relu", 1.0, grp=grp, lng=lng, dyd=dyd[0] if dyd else None, out_drop=s["src"][-1])
             for n_, g in zip(("norm3.weight", "norm3.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                               "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
                 put(n_, g)
             # --- source attention
             x1, m2, r2, n2, q2, kv, cx2, attn2, tk_a2, tk_r2 = s["src"]
-            dt2 = _drop_bwd(dx2, tk_r2)
+            dt2 = dt2[0] if dt2 else _drop_bwd(dx2, tk_r2)
             gw_, gb_ = grp.add(dt2, cx2, bias_grad=True)
             put("src_attn.linear_out.weight", gw_); put("src_attn.linear_out.bias", gb_)
             dcx2 = ops.linear_dx(dt2, p("src_attn.linear_out.weight"))
@@ -956,11 +965,11 @@ class TransformerDecoderFn(torch.autograd.Function):
                 put(f"src_attn.linear_{nm}.weight", gw_); put(f"src_attn.linear_{nm}.bias", gb_)
             dmem = ops.linear_dx_cat(dkv, [p("src_attn.linear_k.weight"), p("src_attn.linear_v.weight")], res=dmem, out=dmem)
             dn2 = ops.linear_dx(dq2, p("src_attn.linear_q.weight"))
-            dx1, g1, g2 = lng.bwd(dn2, x1, m2, r2, p("norm2.weight"), dx_add=dx2)
+            dx1, g1, g2, *dt1 = lng.bwd(dn2, x1, m2, r2, p("norm2.weight"), dx_add=dx2, drop=s["self"][-1])
             put("norm2.weight", g1); put("norm2.bias", g2)
             # --- self attention
             x0, m1, r1, n1, qkv, cx, attn, tk_a, tk_r = s["self"]
-            dt1 = _drop_bwd(dx1, tk_r)
+            dt1 = dt1[0] if dt1 else _drop_bwd(dx1, tk_r)
             gw_, gb_ = grp.add(dt1, cx, bias_grad=True)
             put("self_attn.linear_out.weight", gw_); put("self_attn.linear_out.bias", gb_)
             dcx = ops.linear_dx(dt1, p("self_attn.linear_out.weight"))
@@ -975,7 +984,8 @@ class TransformerDecoderFn(torch.autograd.Function):
                 gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n1, bias_grad=True)
                 put(f"self_attn.linear_{nm}.weight", gw_); put(f"self_attn.linear_{nm}.bias", gb_)
             dn1 = ops.linear_dx_cat(dqkv, [p(f"self_attn.linear_{c}.weight") for c in "qkv"])
-            dx, g1, g2 = lng.bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1)
+            dx, g1, g2, *dyd = lng.bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1,
+                                       drop=ctx.saved[li - 1]["ff"][-1] if li else None)
             put("norm1.weight", g1); put("norm1.bias", g2)
             grp.flush()
         lng.flush()

@@ -356,15 +356,17 @@ def _ts_branch_fwd(p, cfg, x1, n, mean, rstd, pos_emb, lens, B, T, need):
     return x2, (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
 
 
-def _ts_branch_bwd(p, cfg, saved, dx2, x1, pos_emb, lens, B, T, grp, lng, G):
-    """backward of _ts_branch_fwd: returns dx1 (the residual path included) and fills ``G`` with the branch's gradients."""
+def _ts_branch_bwd(p, cfg, saved, dx2, x1, pos_emb, lens, B, T, grp, lng, G, dbr=None, out_drop=None):
+    """backward of _ts_branch_fwd: returns dx1 (the residual path included) and fills ``G`` with the branch's gradients.
+    ``dbr``: dx2 under the branch's outer mask when the caller's LayerNorm backward already produced it; ``out_drop``: the
+    token of the block below - the branch's own LayerNorm backward then also returns dx1 under that mask (dx1, dx1_masked)."""
     M, D = x1.shape
     H = cfg["heads"]
     dk = D // H
     coeff = cfg.get("coeff", 1.0)
     if cfg["use_attn"]:
         mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br = saved
-        dbr = _drop_bwd(dx2, t_br)
+        dbr = _drop_bwd(dx2, t_br) if dbr is None else dbr
         G["attn.linear_out.weight"], G["attn.linear_out.bias"] = grp.add(dbr, cx, alpha=coeff, bias_grad=True)
         dcx = ops.linear_dx(dbr, p["attn.linear_out.weight"], alpha=coeff)
         dqkv = torch.empty_like(qkv)
@@ -382,11 +384,12 @@ def _ts_branch_bwd(p, cfg, saved, dx2, x1, pos_emb, lens, B, T, grp, lng, G):
         for j, nm in enumerate(("q", "k", "v")):
             G[f"attn.linear_{nm}.weight"], G[f"attn.linear_{nm}.bias"] = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
         dn = ops.linear_dx_cat(dqkv, [p[f"attn.linear_{c}.weight"] for c in "qkv"])      # one K = 3D GEMM
-        dx1, G["norm_mha.weight"], G["norm_mha.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2)
-        return dx1
+        dx1, G["norm_mha.weight"], G["norm_mha.bias"], *dxd = lng.bwd(dn, x1, mean, rstd, p["norm_mha.weight"], dx_add=dx2,
+                                                                      drop=out_drop)
+        return (dx1, dxd[0]) if dxd else dx1
     mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br = saved
     Cn = g.shape[1] // 2
-    dbr = _drop_bwd(dx2, t_br)
+    dbr = _drop_bwd(dx2, t_br) if dbr is None else dbr
     G["cgmlp.channel_proj2.weight"], G["cgmlp.channel_proj2.bias"] = grp.add(dbr, u, alpha=coeff, bias_grad=True)
     du = ops.linear_dx_drop(dbr, p["cgmlp.channel_proj2.weight"], t_u, alpha=coeff)
     dg = torch.empty_like(g)
@@ -398,8 +401,9 @@ def _ts_branch_bwd(p, cfg, saved, dx2, x1, pos_emb, lens, B, T, grp, lng, G):
     ops.act_bwd_(dg, z, "gelu")
     G["cgmlp.channel_proj1.0.weight"], G["cgmlp.channel_proj1.0.bias"] = grp.add(dg, n, bias_grad=True)
     dn = ops.linear_dx(dg, p["cgmlp.channel_proj1.0.weight"])
-    dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"] = lng.bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2)
-    return dx1
+    dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"], *dxd = lng.bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2,
+                                                                      drop=out_drop)
+    return (dx1, dxd[0]) if dxd else dx1
 
 
 _FFM = ("norm_ff_macaron.weight", "norm_ff_macaron.bias", "feed_forward_macaron.w_1.weight", "feed_forward_macaron.w_1.bias",
@@ -441,16 +445,20 @@ class TailoredStreamFn(torch.autograd.Function):
         grp = ops.WgradGroup()
         lng = ops.LNGroup()        # the stream's four d-wide LayerNorms: one (dgamma, dbeta) reduction
         x3, fmean, frstd = sv["final"]
-        dx3, G["norm_final.weight"], G["norm_final.bias"] = lng.bwd(dy.contiguous().view(M, D), x3, fmean, frstd,
-                                                                   p["norm_final.weight"])
+        # (each LayerNorm backward also writes its dx under the outer mask of the block below: no stand-alone mask launches)
+        t_ff, t_br, t_ffm = sv["ff"][-1], sv["br"][-1], sv["ffm"][-1]
+        dx3, G["norm_final.weight"], G["norm_final.bias"], *dyd = lng.bwd(dy.contiguous().view(M, D), x3, fmean, frstd,
+                                                                         p["norm_final.weight"], drop=t_ff)
         # chain=False: the two modality streams run side by side (measured on the AV step: 367.9 utt/s with the dgrad GEMMs,
         # 365.3 with the streaming launch, which cannot share the chip with the other stream's kernels)
-        dx2, gs = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act, 0.5,
-                           grp=grp, lng=lng, chain=False)
+        dx2, gs, *dbr = _FFN.bwd(dx3, sv["ff"], p["norm_ff.weight"], p["feed_forward.w_1.weight"], p["feed_forward.w_2.weight"], act,
+                                 0.5, grp=grp, lng=lng, chain=False, dyd=dyd[0] if dyd else None, out_drop=t_br)
         G.update(zip(_FF, gs))
-        dx1 = _ts_branch_bwd(p, cfg, sv["br"], dx2, sv["x1"], ctx.pos_emb, ctx.lens, B, T, grp, lng, G)
+        dx1 = _ts_branch_bwd(p, cfg, sv["br"], dx2, sv["x1"], ctx.pos_emb, ctx.lens, B, T, grp, lng, G,
+                             dbr=dbr[0] if dbr else None, out_drop=t_ffm)
+        dx1, dyd = dx1 if isinstance(dx1, tuple) else (dx1, None)
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p["norm_ff_macaron.weight"], p["feed_forward_macaron.w_1.weight"],
-                          p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng, chain=False)
+                          p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng, chain=False, dyd=dyd)
         G.update(zip(_FFM, gs))
         grp.flush()
         lng.flush()

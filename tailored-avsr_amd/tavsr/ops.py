@@ -542,6 +542,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dx_add=None, dx=None):
     return dx, dg, db
 
 
+LN_BWD_DROP = os.environ.get("TAVSR_LN_BWD_DROP", "1") == "1"      # A/B switch: masked gradient copy from the LayerNorm backward
+
+
 class LNGroup:
     """LayerNorm backward passes of one backward node whose (dgamma, dbeta) partials share ONE reduction launch:
     ``bwd`` runs the main pass (dx is ready when it returns) and parks the per-block partials in a common slab,
@@ -552,19 +555,37 @@ class LNGroup:
         self.CAP = cap
         self.key, self.slab, self.out, self.k = None, None, None, 0
 
-    def bwd(self, dy, x, mean, rstd, gamma, *, dx_add=None, dx=None):
+    def bwd(self, dy, x, mean, rstd, gamma, *, dx_add=None, dx=None, drop=None):
+        """``drop`` (a dropout token): also returns dx * mask / keep as a fourth result (the masked gradient the next residual
+        block's branch starts from) - from the same launch when the group takes the call, else from a dropout launch."""
         M, D = x.shape
+        if drop is not None and not LN_BWD_DROP:
+            r = self.bwd(dy, x, mean, rstd, gamma, dx_add=dx_add, dx=dx)
+            return r + (dropout(r[0], drop[0], token=drop)[0],)
         if self.key is None:
             self.key = (M, D)
             self.nb = lib_i64("tavsr_layernorm_bwd_ws", M, D) // (2 * D)
             self.slab = empty(self.nb, self.CAP * 2 * D, like=x)
             self.out = empty(self.CAP * 2 * D, like=x)
         if (M, D) != self.key or self.k >= self.CAP:
-            return layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=dx_add, dx=dx)
+            r = layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=dx_add, dx=dx)
+            return r if drop is None else r + (dropout(r[0], drop[0], token=drop)[0],)
         require_cuda(dy, x, mean, rstd, gamma, dx_add)
         if dx is None:
             dx = empty(M, D, like=x)
         off = self.k * 2 * D
+        if drop is not None:
+            assert dx.is_contiguous()
+            dxd = empty(M, D, like=x)
+            check(lib().tavsr_layernorm_bwd_partial_drop(ptr(dy), C.c_int64(dy.stride(0)), ptr(x), C.c_int64(x.stride(0)), ptr(mean),
+                                                         ptr(rstd), ptr(gamma), ptr(dx_add),
+                                                         C.c_int64(0 if dx_add is None else dx_add.stride(0)), ptr(dx),
+                                                         C.c_int64(dx.stride(0)), C.c_void_p(self.slab.data_ptr() + 4 * off),
+                                                         C.c_int64(self.slab.stride(0)), M, D, ptr(dxd), C.c_float(drop[0]),
+                                                         ptr(drop[2]), C.c_uint64(drop[1]), stream()),
+                  "tavsr_layernorm_bwd_partial_drop")
+            self.k += 1
+            return dx, self.out[off: off + D], self.out[off + D: off + 2 * D], dxd
         check(lib().tavsr_layernorm_bwd_partial(ptr(dy), C.c_int64(dy.stride(0)), ptr(x), C.c_int64(x.stride(0)), ptr(mean),
                                                 ptr(rstd), ptr(gamma), ptr(dx_add),
                                                 C.c_int64(0 if dx_add is None else dx_add.stride(0)), ptr(dx),

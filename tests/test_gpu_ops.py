@@ -390,6 +390,36 @@ def test_grouped_helpers_match_the_plain_calls():
     assert torch.equal(sa, ops.colsum(a)) and torch.equal(sb, ops.colsum(b))
 
 
+@pytest.mark.parametrize("M,D", [(3168, 256), (777, 256), (50, 1024), (1, 256)])
+def test_layernorm_backward_masked_copy_is_the_dropout_kernels(M, D):
+    """tavsr_layernorm_bwd_partial_drop: same dx / dgamma / dbeta as the plain pass, and its second output equals the
+    stand-alone dropout kernel applied to dx with the same token (bitwise); both the in-launch route and the A/B-off and
+    slab-overflow routes of LNGroup.bwd."""
+    from tavsr import ops
+    torch.manual_seed(M)
+    x, dy, add = (torch.randn(M, D, device="cuda") for _ in range(3))
+    gam = torch.randn(D, device="cuda")
+    mean, rstd = ops.layernorm_fwd(x, gam, gam, 1e-12)[1:]
+    ops.manual_seed(11)
+    tok = ops._new_token(0.1, M * D, x.device)
+    ref = ops.layernorm_bwd(dy, x, mean, rstd, gam, dx_add=add)
+    want = ops.dropout(ref[0], 0.1, token=tok)[0]
+    assert 0.05 < float((want == 0).float().mean()) < 0.15 or M * D < 1000
+    keep = ops.LN_BWD_DROP
+    try:
+        for on, cap in ((True, 8), (False, 8), (True, 0)):
+            ops.LN_BWD_DROP = on
+            lng = ops.LNGroup(cap=cap)
+            dx, g1, g2, dxd = lng.bwd(dy, x, mean, rstd, gam, dx_add=add, drop=tok)
+            lng.flush()
+            assert torch.equal(dx, ref[0]) and torch.equal(g1, ref[1]) and torch.equal(g2, ref[2])
+            assert torch.equal(dxd, want)
+            assert len(lng.bwd(dy, x, mean, rstd, gam)) == 3            # no token: the three-result form
+            lng.flush()
+    finally:
+        ops.LN_BWD_DROP = keep
+
+
 def test_multi_add_sums_lists_of_tensors_in_place():
     from tavsr import ops
     torch.manual_seed(4)
