@@ -328,7 +328,7 @@ int tavsr_lin2_fwd(const float* x, int64_t ldx, int32_t M, int32_t K, const tavs
 /* ---------------------------------------------------------------------------------------------
  * One Branchformer encoder layer forward as ONE call (csrc/layer.hip): MyBranchformerEncoderLayer.forward
  * (src/encoder/branchformer/encoder_layer.py:153-321) in its recipe form - macaron FFN, rel-pos attention branch beside the
- * cgMLP branch, learned-average merge + merge_proj, FFN, norm_final - sequenced in C over the entry points above (13 launches;
+ * cgMLP branch, learned-average merge + merge_proj, FFN, norm_final - sequenced in C over the entry points above (14 launches;
  * the attention branch is enqueued on `stream2` between two events, as the Python sequencing does with a side stream).
  * All buffers are the caller's: the outputs / saved tensors below are exactly what the backward pass reads; `save` = 0 (eval)
  * leaves z / h / gn / conv untouched (may be NULL).  Dropout: rate p_drop (p_att inside the attention core) with the counter
@@ -357,7 +357,7 @@ typedef struct tavsr_bf_layer_desc {
   float *n_mha, *n_mlp, *br_mean, *br_rstd;
   float *qkv, *pp, *cx, *lse, *xa;
   float *g, *g_z, *gn, *g_mean, *g_rstd, *u, *conv, *xm;
-  float *score, *pooled, *wts, *m;
+  float *score, *pooled /* the merge's row dots [4][B*T] (tavsr_merge_rows_fwd) */, *wts, *m;
   float *x2, *ff_n, *ff_mean, *ff_rstd, *ff_z, *ff_h, *x3, *y, *fin_mean, *fin_rstd;
   tavsr_stream_t stream2;          /* the attention branch's queue */
   void *ev_fork, *ev_join;         /* hipEvent_t */
@@ -425,6 +425,22 @@ int tavsr_merge_fwd(const float* x1, const float* x2, const int64_t* lens, const
                     float* score, float* pooled, float* w, float* out, int32_t B, int32_t T, int32_t D, tavsr_stream_t stream);
 int tavsr_merge_combine(const float* x1, const float* x2, const float* w, float* out, int32_t B, int32_t T,
                         int32_t D, tavsr_stream_t stream);
+/* The row-parallel form of the same merge (D = 256, T <= 2048: tavsr_merge_rows_ok): the launches above run one workgroup
+ * per utterance (B of the 256 CUs); these split every utterance into 16-row blocks.  Pass 1 writes four dot products per row
+ * (dots [4][B*T] = <wp_1,x_1>, <wp_2,x_2>, <ww_1,x_1>, <ww_2,x_2>; weight_k = sum_t score_k[t] <ww_k, x_k[t]> + bw_k, so
+ * no pooled vector is needed), pass 2 redoes the utterance's softmaxes from them in every block and combines the block's
+ * rows.  The backward pass reads `dots` back (it replaces `pooled` as the saved tensor), writes dx1 / dx2 - optionally
+ * already under the dropout masks of the two branch outputs (encoder_layer.py:212,224) - and the eight parameter
+ * gradients; ws >= tavsr_merge_rows_bwd_ws(B, T, D) floats. */
+int tavsr_merge_rows_ok(int32_t T, int32_t D);
+int tavsr_merge_rows_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2, const float* const* params,
+                         float* dots, float* score, float* w, float* out, int32_t B, int32_t T, int32_t D, tavsr_stream_t stream);
+int64_t tavsr_merge_rows_bwd_ws(int32_t B, int32_t T, int32_t D);
+int tavsr_merge_rows_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
+                         const float* const* params, const float* score, const float* w, const float* dots, float* dx1,
+                         float* dx2, float* const* dparams, int32_t accumulate, float* ws, float p_drop1, uint64_t offset1,
+                         float p_drop2, uint64_t offset2, const uint64_t* seed_dev, int32_t B, int32_t T, int32_t D,
+                         tavsr_stream_t stream);
 int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D);
 int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
                     const float* const* params, const float* score, const float* pooled, const float* w,

@@ -811,6 +811,256 @@ __global__ void merge_scatter_kernel(const float* __restrict__ sum, MergeGradPtr
   *dst = accumulate ? *dst + sum[i] : sum[i];
 }
 
+
+// ------------------------------- learned_ave merge, row-parallel form (D = 256) -----------------
+// The one-block-per-utterance kernels above run on B (= 32) of the 256 CUs and are bound by what ONE CU can stream
+// (~12 GB/s each: 16 us forward, 32 us backward at B = 32, T = 99).  Everything the merge needs from a row is four dot
+// products, because  weight_k = <ww_k, sum_t p_k[t] x_k[t,:]> + bw_k = sum_t p_k[t] <ww_k, x_k[t,:]> + bw_k :
+//   pass 1 (all rows in parallel)  dots[0..3][row] = <wp_1,x_1>, <wp_2,x_2>, <ww_1,x_1>, <ww_2,x_2>
+//   pass 2 (blocks of MR_RPB rows) every block redoes the utterance's two softmaxes over time and the softmax over the
+//                                  branches from the dots (4 T floats), then combines its own rows.
+// The backward pass has the same shape: pass 1 the row dots <dm, x_k>, pass 2 the per-utterance scalars from the dots, then
+// dx_k for the block's rows (optionally already under the branch's dropout mask) and the block's partial parameter gradients.
+constexpr int MR_RPB = 16;      // rows per block of the second passes (8 waves x 2 rows)
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+// dots[j][row], j < 4 (dm == null) or adots[k][row] = <dm[row], x_k[row]>, k < 2 (dm != null); one wave per two rows
+__global__ __launch_bounds__(256) void merge_rowdots_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                            const float* __restrict__ dm, MergeParams p,
+                                                            float* __restrict__ dots, int M) {
+  constexpr int D = 256;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r0 = (blockIdx.x * 4 + wv) * 2;
+  float4 a[2], c[2], g[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t o = (int64_t)min(r0 + i, M - 1) * D + 4 * lane;
+    a[i] = *reinterpret_cast<const float4*>(x1 + o);
+    c[i] = *reinterpret_cast<const float4*>(x2 + o);
+    if (dm) g[i] = *reinterpret_cast<const float4*>(dm + o);
+  }
+  if (dm) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float a1 = wave_sum(dot4(g[i], a[i])), a2 = wave_sum(dot4(g[i], c[i]));
+      if (lane == 0 && r0 + i < M) { dots[r0 + i] = a1; dots[(int64_t)M + r0 + i] = a2; }
+    }
+    return;
+  }
+  const float4 wp1 = *reinterpret_cast<const float4*>(p.wp[0] + 4 * lane), wp2 = *reinterpret_cast<const float4*>(p.wp[1] + 4 * lane);
+  const float4 ww1 = *reinterpret_cast<const float4*>(p.ww[0] + 4 * lane), ww2 = *reinterpret_cast<const float4*>(p.ww[1] + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float s1 = wave_sum(dot4(a[i], wp1)), s2 = wave_sum(dot4(c[i], wp2));
+    const float q1 = wave_sum(dot4(a[i], ww1)), q2 = wave_sum(dot4(c[i], ww2));
+    if (lane == 0 && r0 + i < M) {
+      const int64_t r = r0 + i;
+      dots[r] = s1; dots[M + r] = s2; dots[2 * (int64_t)M + r] = q1; dots[3 * (int64_t)M + r] = q2;
+    }
+  }
+}
+
+// grid (cdiv(T, MR_RPB), B), 512 threads, dynamic LDS 4 T floats
+__global__ __launch_bounds__(512) void merge_rows_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                             const int64_t* __restrict__ lens, const int64_t* __restrict__ lens2,
+                                                             MergeParams p, const float* __restrict__ dots,
+                                                             float* __restrict__ score, float* __restrict__ wout,
+                                                             float* __restrict__ mix, int B, int T) {
+  constexpr int D = 256;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_s = sm;            // [2][T] scores, then the softmax over time
+  float* s_q = sm + 2 * T;    // [2][T] <ww_k, x_k[t]>
+  __shared__ float s_w[2];
+  const int b = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t M = (int64_t)B * T, r0 = (int64_t)b * T;
+  const float inv_sqrt_d = 1.f / 16.f;
+  for (int i = threadIdx.x; i < 2 * T; i += 512) {
+    const int k = i >= T, t = i - k * T;
+    s_s[i] = (dots[k * M + r0 + t] + p.bp[k][0]) * inv_sqrt_d;
+    s_q[i] = dots[(2 + k) * M + r0 + t];
+  }
+  __syncthreads();
+  if (wv < 2) {
+    const int k = wv;
+    const int64_t* lk = (k == 1 && lens2) ? lens2 : lens;
+    const int len = lk ? (int)min((int64_t)T, lk[b]) : T;
+    float* sc = s_s + k * T;
+    float mx = -FLT_MAX;
+    for (int t = lane; t < len; t += 64) mx = fmaxf(mx, sc[t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < len; t += 64) sum += expf(sc[t] - mx);
+    sum = wave_sum(sum);
+    const float inv = len > 0 ? 1.f / sum : 0.f;
+    float lg = 0.f;
+    for (int t = lane; t < T; t += 64) {      // (each lane rewrites only the entries it read)
+      const float pv = t < len ? expf(sc[t] - mx) * inv : 0.f;
+      sc[t] = pv;
+      lg += pv * s_q[k * T + t];
+    }
+    lg = wave_sum(lg);
+    if (lane == 0) s_w[k] = lg + p.bw[k][0];
+  }
+  __syncthreads();
+  const float m = fmaxf(s_w[0], s_w[1]);
+  const float e0 = expf(s_w[0] - m), e1 = expf(s_w[1] - m);
+  const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
+  if (ch == 0 && threadIdx.x == 0) { wout[b * 2 + 0] = w0; wout[b * 2 + 1] = w1; }
+  if (threadIdx.x < 2 * MR_RPB) {
+    const int k = threadIdx.x / MR_RPB, t = ch * MR_RPB + threadIdx.x % MR_RPB;
+    if (t < T) score[((int64_t)k * B + b) * T + t] = s_s[k * T + t];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int t = ch * MR_RPB + wv * 2 + i;
+    if (t < T) {
+      const int64_t o = (r0 + t) * D + 4 * lane;
+      const float4 a = *reinterpret_cast<const float4*>(x1 + o), c = *reinterpret_cast<const float4*>(x2 + o);
+      *reinterpret_cast<float4*>(mix + o) = make_float4(w0 * a.x + w1 * c.x, w0 * a.y + w1 * c.y, w0 * a.z + w1 * c.z, w0 * a.w + w1 * c.w);
+    }
+  }
+}
+
+struct MergeDrop { uint32_t thr[2]; float inv_keep[2]; uint64_t offset4[2]; const uint64_t* seed; };
+
+// grid (cdiv(T, MR_RPB), B), 512 threads, dynamic LDS 6 T floats; part[(b * chunks + ch)] = { dwp1[D], dwp2[D], dww1[D],
+// dww2[D], dbp1, dbp2, dbw1, dbw2 } (the four scalars from chunk 0 only)
+__global__ __launch_bounds__(512) void merge_rows_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ x1,
+                                                             const float* __restrict__ x2, const int64_t* __restrict__ lens,
+                                                             const int64_t* __restrict__ lens2, MergeParams p,
+                                                             const float* __restrict__ score, const float* __restrict__ w,
+                                                             const float* __restrict__ dots, const float* __restrict__ adots,
+                                                             float* __restrict__ dx1, float* __restrict__ dx2,
+                                                             float* __restrict__ part, MergeDrop dr, int B, int T) {
+  constexpr int D = 256;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_a = sm;             // [2][T] <dm, x_k[t]>, then ds_pre_k[t]
+  float* s_q = sm + 2 * T;     // [2][T] <ww_k, x_k[t]>
+  float* s_c = sm + 4 * T;     // [2][T] softmax over time
+  __shared__ float s_red[4];
+  __shared__ __attribute__((aligned(16))) float s_part[8][4][D];
+  const int b = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t M = (int64_t)B * T, r0 = (int64_t)b * T;
+  for (int i = threadIdx.x; i < 2 * T; i += 512) {
+    const int k = i >= T, t = i - k * T;
+    s_a[i] = adots[k * M + r0 + t];
+    s_q[i] = dots[(2 + k) * M + r0 + t];
+    s_c[i] = score[((int64_t)k * B + b) * T + t];
+  }
+  __syncthreads();
+  if (wv < 2) {
+    float a = 0.f;
+    for (int t = lane; t < T; t += 64) a += s_a[wv * T + t];
+    a = wave_sum(a);
+    if (lane == 0) s_red[wv] = a;
+  }
+  __syncthreads();
+  const float w1 = w[b * 2], w2 = w[b * 2 + 1];
+  const float dotw = w1 * s_red[0] + w2 * s_red[1];
+  const float dwt[2] = {w1 * (s_red[0] - dotw), w2 * (s_red[1] - dotw)};       // d(weight_k), the branch softmax backward
+  int len[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int64_t* lk = (k == 1 && lens2) ? lens2 : lens;
+    len[k] = lk ? (int)min((int64_t)T, lk[b]) : T;
+  }
+  __syncthreads();      // (s_red[0..1] are read by every thread above; the ds_pre writes below reuse s_a)
+  if (wv < 2) {
+    const int k = wv;
+    const float dw = k == 0 ? dwt[0] : dwt[1];
+    const int ln = k == 0 ? len[0] : len[1];
+    float dot = 0.f;
+    for (int t = lane; t < ln; t += 64) dot += s_c[k * T + t] * (dw * s_q[k * T + t]);
+    dot = wave_sum(dot);
+    float sb = 0.f;
+    for (int t = lane; t < T; t += 64) {
+      const float v = t < ln ? s_c[k * T + t] * (dw * s_q[k * T + t] - dot) * (1.f / 16.f) : 0.f;
+      s_a[k * T + t] = v;      // ds_pre_k[t]
+      sb += v;
+    }
+    sb = wave_sum(sb);
+    if (lane == 0) s_red[2 + k] = sb;
+  }
+  __syncthreads();
+  float4 acc[4];      // dwp1, dwp2, pooled1, pooled2 partials over this wave's rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 wp1 = *reinterpret_cast<const float4*>(p.wp[0] + 4 * lane), wp2 = *reinterpret_cast<const float4*>(p.wp[1] + 4 * lane);
+  const float4 ww1 = *reinterpret_cast<const float4*>(p.ww[0] + 4 * lane), ww2 = *reinterpret_cast<const float4*>(p.ww[1] + 4 * lane);
+  const uint64_t sd = dr.seed ? dr.seed[0] : 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int t = ch * MR_RPB + wv * 2 + i;
+    if (t < T) {
+      const int64_t row = r0 + t, o = row * D + 4 * lane;
+      const float4 g = *reinterpret_cast<const float4*>(dm + o);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float4 xv = *reinterpret_cast<const float4*>((k == 0 ? x1 : x2) + o);
+        const float4 wp = k == 0 ? wp1 : wp2, ww = k == 0 ? ww1 : ww2;
+        const float wk = k == 0 ? w1 : w2;
+        const float sv = s_c[k * T + t], dsv = s_a[k * T + t], sd_ = sv * dwt[k];
+        float4 v = make_float4(wk * g.x + sd_ * ww.x + dsv * wp.x, wk * g.y + sd_ * ww.y + dsv * wp.y,
+                               wk * g.z + sd_ * ww.z + dsv * wp.z, wk * g.w + sd_ * ww.w + dsv * wp.w);
+        if (dr.seed && dr.thr[k]) {       // the branch's outer dropout (x_k = dropout(branch output)): tavsr_dropout's mapping
+          const uint64_t ctr = dr.offset4[k] + (uint64_t)row * (D / 4) + (uint64_t)lane;
+          uint32_t r4[4];
+          philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), r4);
+          const float ik = dr.inv_keep[k];
+          v = make_float4(r4[0] >= dr.thr[k] ? v.x * ik : 0.f, r4[1] >= dr.thr[k] ? v.y * ik : 0.f,
+                          r4[2] >= dr.thr[k] ? v.z * ik : 0.f, r4[3] >= dr.thr[k] ? v.w * ik : 0.f);
+        }
+        *reinterpret_cast<float4*>((k == 0 ? dx1 : dx2) + o) = v;
+        acc[k].x += dsv * xv.x; acc[k].y += dsv * xv.y; acc[k].z += dsv * xv.z; acc[k].w += dsv * xv.w;
+        acc[2 + k].x += sv * xv.x; acc[2 + k].y += sv * xv.y; acc[2 + k].z += sv * xv.z; acc[2 + k].w += sv * xv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&s_part[wv][j][4 * lane]) = acc[j];
+  __syncthreads();
+  float* pb = part + ((int64_t)b * gridDim.x + ch) * (4 * D + 4);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int idx = threadIdx.x + h * 512, j = idx >> 8, c = idx & 255;
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += s_part[u][j][c];
+    pb[j * D + c] = j < 2 ? a : a * dwt[j - 2];      // dwp_k ; dww_k = d(weight_k) * pooled_k
+  }
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x & 1;
+    pb[4 * D + threadIdx.x] = ch != 0 ? 0.f : (threadIdx.x < 2 ? s_red[2 + k] : dwt[k]);     // dbp_k, dbw_k
+  }
+}
+
+// sum[i] = sum_r part[r][i] over nparts rows in a fixed order, written (or added) straight to the eight parameter gradients;
+// one block per 64 slab columns, the four waves take rows wv, wv + 4, ...
+__global__ __launch_bounds__(256) void merge_reduce_scatter_kernel(const float* __restrict__ part, int nparts, MergeGradPtrs o,
+                                                                   int D, int accumulate) {
+  __shared__ float s[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = 4 * D + 4, i = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < n) {
+    int r = wv;
+    for (; r + 12 < nparts; r += 16) {
+      a0 += part[(int64_t)r * n + i];
+      a1 += part[(int64_t)(r + 4) * n + i];
+      a2 += part[(int64_t)(r + 8) * n + i];
+      a3 += part[(int64_t)(r + 12) * n + i];
+    }
+    for (; r < nparts; r += 4) a0 += part[(int64_t)r * n + i];
+  }
+  s[wv][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wv == 0 && i < n) {
+    const float v = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+    float* dst = i < 4 * D ? o.g[i / D] + (i % D) : o.g[4 + (i - 4 * D)];
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
 }  // namespace tavsr
 
 using namespace tavsr;
@@ -990,3 +1240,79 @@ extern "C" int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
+
+// ---- the row-parallel form (D = 256, T <= MR_TMAX): see the kernels' header comment
+static constexpr int MR_TMAX = 2048;
+
+extern "C" int tavsr_merge_rows_ok(int32_t T, int32_t D) { return D == 256 && T >= 1 && T <= MR_TMAX; }
+
+extern "C" int tavsr_merge_rows_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
+                                    const float* const* params, float* dots, float* score, float* w, float* out, int32_t B,
+                                    int32_t T, int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x1 && x2 && params && dots && score && w && out, TAVSR_EINVAL, "merge_rows_fwd: null pointer");
+  for (int i = 0; i < 8; ++i) TAVSR_REQUIRE(params[i], TAVSR_EINVAL, "merge_rows_fwd: null parameter %d", i);
+  TAVSR_REQUIRE(tavsr_merge_rows_ok(T, D), TAVSR_EUNSUPPORTED, "merge_rows_fwd: D == 256 and T <= %d required (T=%d D=%d)", MR_TMAX, T, D);
+  TAVSR_REQUIRE(((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                    ((uintptr_t)params[0] % 16 == 0) && ((uintptr_t)params[1] % 16 == 0) && ((uintptr_t)params[4] % 16 == 0) &&
+                    ((uintptr_t)params[5] % 16 == 0),
+                TAVSR_EALIGN, "merge_rows_fwd: 16-byte aligned rows and weight vectors required");
+  if (B <= 0) return TAVSR_OK;
+  const int M = B * T;
+  hipLaunchKernelGGL(merge_rowdots_kernel, dim3(cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, x1, x2, (const float*)nullptr,
+                     mk(params), dots, M);
+  TAVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(merge_rows_fwd_kernel, dim3(cdiv(T, MR_RPB), B), dim3(512), 4 * T * sizeof(float), (hipStream_t)stream, x1, x2,
+                     lens, lens2, mk(params), dots, score, w, out, B, T);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int64_t tavsr_merge_rows_bwd_ws(int32_t B, int32_t T, int32_t D) {
+  return 2 * (int64_t)B * T + (int64_t)B * cdiv(T, MR_RPB) * (4 * D + 4);
+}
+
+// p_drop1 / p_drop2 > 0: dx1 / dx2 are written under the tavsr_dropout mask of a contiguous [B*T][D] tensor at offset1 /
+// offset2 (the branch outputs' outer dropouts, encoder_layer.py:212,224): dx_k = merge'(dm) * mask_k / keep_k
+extern "C" int tavsr_merge_rows_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
+                                    const float* const* params, const float* score, const float* w, const float* dots, float* dx1,
+                                    float* dx2, float* const* dparams, int32_t accumulate, float* ws, float p_drop1,
+                                    uint64_t offset1, float p_drop2, uint64_t offset2, const uint64_t* seed_dev, int32_t B,
+                                    int32_t T, int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dm && x1 && x2 && params && score && w && dots && dx1 && dx2 && dparams && ws, TAVSR_EINVAL,
+                "merge_rows_bwd: null pointer");
+  TAVSR_REQUIRE(tavsr_merge_rows_ok(T, D), TAVSR_EUNSUPPORTED, "merge_rows_bwd: D == 256 and T <= %d required (T=%d D=%d)", MR_TMAX, T, D);
+  TAVSR_REQUIRE(((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0) && ((uintptr_t)dm % 16 == 0) && ((uintptr_t)dx1 % 16 == 0) &&
+                    ((uintptr_t)dx2 % 16 == 0),
+                TAVSR_EALIGN, "merge_rows_bwd: 16-byte aligned rows required");
+  TAVSR_REQUIRE(p_drop1 >= 0.f && p_drop1 < 1.f && p_drop2 >= 0.f && p_drop2 < 1.f && offset1 % 4 == 0 && offset2 % 4 == 0 &&
+                    (seed_dev || (p_drop1 == 0.f && p_drop2 == 0.f)),
+                TAVSR_EINVAL, "merge_rows_bwd: dropout rates in [0, 1), offsets %% 4 == 0, a seed when a rate is set");
+  MergeGradPtrs o;
+  for (int i = 0; i < 8; ++i) {
+    TAVSR_REQUIRE(dparams[i] && params[i], TAVSR_EINVAL, "merge_rows_bwd: null parameter or gradient pointer %d", i);
+    o.g[i] = dparams[i];
+  }
+  if (B <= 0) return TAVSR_OK;
+  const int M = B * T, chunks = cdiv(T, MR_RPB), n = 4 * D + 4;
+  float* adots = ws;
+  float* part = ws + 2 * (int64_t)M;
+  MergeDrop dr;
+  const float pd[2] = {p_drop1, p_drop2};
+  const uint64_t off[2] = {offset1, offset2};
+  for (int k = 0; k < 2; ++k) {
+    dr.thr[k] = (uint32_t)((double)pd[k] * 4294967296.0);
+    dr.inv_keep[k] = 1.f / (1.f - pd[k]);
+    dr.offset4[k] = off[k] / 4;
+  }
+  dr.seed = (p_drop1 > 0.f || p_drop2 > 0.f) ? seed_dev : nullptr;
+  hipLaunchKernelGGL(merge_rowdots_kernel, dim3(cdiv(M, 8)), dim3(256), 0, (hipStream_t)stream, x1, x2, dm, mk(params), adots, M);
+  TAVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(merge_rows_bwd_kernel, dim3(chunks, B), dim3(512), 6 * T * sizeof(float), (hipStream_t)stream, dm, x1, x2, lens,
+                     lens2, mk(params), score, w, dots, adots, dx1, dx2, part, dr, B, T);
+  TAVSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(merge_reduce_scatter_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, part, B * chunks, o, D,
+                     accumulate);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+

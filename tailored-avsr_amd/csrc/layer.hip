@@ -130,9 +130,9 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
   if (!dry) {
     TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_join, s2));
     TAVSR_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)d->ev_join, 0));
-    // ---- learned-average merge: two poolings + weighted sum (one launch for T <= 128)
-    if ((rc = tavsr_merge_fwd(d->xa, d->xm, d->lens, nullptr, d->merge_p, d->score, d->pooled, d->wts, d->m, d->B, d->T, D,
-                              (tavsr_stream_t)s)))
+    // ---- learned-average merge, row-parallel form: d->pooled receives the row dots [4][B*T] (what its backward reads)
+    if ((rc = tavsr_merge_rows_fwd(d->xa, d->xm, d->lens, nullptr, d->merge_p, d->pooled, d->score, d->wts, d->m, d->B, d->T, D,
+                                   (tavsr_stream_t)s)))
       return rc;
   }
   {
@@ -157,8 +157,8 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
 int supported(const tavsr_bf_layer_desc* d, const char* who) {
   TAVSR_REQUIRE(d, TAVSR_EINVAL, "%s: null descriptor", who);
   TAVSR_REQUIRE(d->B > 0 && d->T > 0 && d->D == 256 && d->H > 0 && d->D / d->H == 64 && d->ffn_units >= 1024 &&
-                    d->ffn_units % 32 == 0 && d->cg_units % 128 == 0 && d->cg_kernel == 31,
-                TAVSR_EUNSUPPORTED, "%s: d_model 256, 64-wide heads, hidden >= 1024, cgMLP kernel 31 only", who);
+                    d->ffn_units % 32 == 0 && d->cg_units % 128 == 0 && d->cg_kernel == 31 && tavsr_merge_rows_ok(d->T, d->D),
+                TAVSR_EUNSUPPORTED, "%s: d_model 256, 64-wide heads, hidden >= 1024, cgMLP kernel 31, T <= 2048 only", who);
   return TAVSR_OK;
 }
 

@@ -286,7 +286,7 @@ def _layer_c_ok(x, cfg, P, pd, pos_emb=None) -> bool:
     if ops.LAYER_C_EAGER_ONLY and torch.cuda.is_current_stream_capturing():
         return False
     return (ops.LAYER_C and cfg["has_attn"] and cfg["has_mlp"] and cfg["merge"] == "learned_ave" and not cfg["merge_identity"]
-            and ops.ATTN_FUSED and ops.FFN2 and ops.CSGU_FUSED and ops.BRANCH_SIDE_STREAM and not ops.LIN2 and ops.PROFILE is None
+            and ops.ATTN_FUSED and ops.FFN2 and ops.CSGU_FUSED and ops.merge_rows_ok(T, D) and ops.BRANCH_SIDE_STREAM and not ops.LIN2 and ops.PROFILE is None
             and D == 256 and D // cfg["heads"] == 64 and cw is not None and cw.shape[-1] == 31 and (2 * cw.shape[0]) % 128 == 0
             and P[_I["feed_forward.w_1.weight"]].shape[0] >= 1024 and P[_I["feed_forward.w_1.weight"]].shape[0] % 32 == 0
             and P[_I["feed_forward_macaron.w_1.weight"]].shape == P[_I["feed_forward.w_1.weight"]].shape
@@ -349,7 +349,7 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
     # buffers
     b = {k: E(M, D) for k in ("x1", "n_mha", "n_mlp", "cx", "xa", "xm", "m", "x2", "x3", "y")}
     b.update(qkv=E(M, 3 * D), pp=E(W, D), lse=E(B * H, T), g=E(M, C2), u=E(M, Cn), g_mean=E(M), g_rstd=E(M),
-             score=E(2, B, T), pooled=E(2, B, D), wts=E(B, 2))
+             score=E(2, B, T), pooled=E(4, M), wts=E(B, 2))
     if need:
         b.update(ffm_n=E(M, D), ff_n=E(M, D), ffm_z=E(Mp, N1)[:M], ffm_h=E(Mp, N1)[:M], ff_z=E(Mp, N1)[:M], ff_h=E(Mp, N1)[:M],
                  g_z=E(M, C2), gn=E(M, Cn), conv=E(M, Cn))
@@ -556,12 +556,16 @@ class BranchformerLayerFn(torch.autograd.Function):
             put("merge_proj.weight", gw_); put("merge_proj.bias", gb_)
             dm = ops.linear_dx(dxd, p("merge_proj.weight"), alpha=coeff)
         xa, xm = sv["xa"], sv["xm"]
+        masked = False
         if two and merge == "learned_ave":
             score, pooled, wts, _ = sv["merge"]
             mp = [p(k) for k in ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias",
                                  "pooling_proj2.bias", "weight_proj1.weight", "weight_proj2.weight",
                                  "weight_proj1.bias", "weight_proj2.bias")]
-            dxa, dxm, mg = ops.merge_bwd(dm, xa, xm, ctx.lens, mp, score, pooled, wts, B, T)
+            # (dxa / dxm come back under the branch outputs' dropout masks: no mask launches at the head of the branches)
+            dxa, dxm, mg = ops.merge_bwd(dm, xa, xm, ctx.lens, mp, score, pooled, wts, B, T, drop1=sv["attn"][-1],
+                                         drop2=sv["mlp"][-1])
+            masked = True
             for k, g in zip(("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias", "pooling_proj2.bias",
                              "weight_proj1.weight", "weight_proj2.weight", "weight_proj1.bias", "weight_proj2.bias"), mg):
                 put(k, g, like=p(k))
@@ -584,7 +588,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             if has_attn:
                 a_mean, a_rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa = sv["attn"]
                 br.keep(dxa)
-                if t_xa is not None:
+                if t_xa is not None and not masked:
                     dxa = _drop_bwd(dxa.contiguous(), t_xa)
                 gw_, gb_ = grp.add(dxa, cx, bias_grad=True)
                 put("attn.linear_out.weight", gw_); put("attn.linear_out.bias", gb_)
@@ -610,7 +614,7 @@ class BranchformerLayerFn(torch.autograd.Function):
         if has_mlp:
             mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_xm = sv["mlp"]
             Cn = g.shape[1] // 2
-            if t_xm is not None:
+            if t_xm is not None and not masked:
                 dxm = _drop_bwd(dxm.contiguous(), t_xm)
             gw_, gb_ = grp.add(dxm, u, bias_grad=True)
             put("cgmlp.channel_proj2.weight", gw_); put("cgmlp.channel_proj2.bias", gb_)

@@ -978,13 +978,28 @@ def merge_pool_fwd(x1, x2, lens, params, B, T, lens2=None):
     return score, pooled, w
 
 
+MERGE_ROWS = os.environ.get("TAVSR_MERGE_ROWS", "1") == "1"      # A/B switch: the row-parallel learned_ave merge launches
+
+
+def merge_rows_ok(T, D) -> bool:
+    return MERGE_ROWS and bool(lib().tavsr_merge_rows_ok(T, D))
+
+
 def merge_fwd(x1, x2, lens, params, B, T, lens2=None):
-    """merge_pool_fwd + merge_combine: (score, pooled, w, w[:, 0] * x1 + w[:, 1] * x2)."""
+    """merge_pool_fwd + merge_combine: (score, aux, w, w[:, 0] * x1 + w[:, 1] * x2); ``aux`` is what ``merge_bwd`` wants back
+    with the other two: the pooled vectors [2, B, D] of the one-workgroup-per-utterance launches, or the row dot products
+    [4, B*T] of the row-parallel ones (D = 256)."""
     D = x1.shape[-1]
-    score, pooled, w = empty(2, B, T, like=x1), empty(2, B, D, like=x1), empty(B, 2, like=x1)
+    score, w = empty(2, B, T, like=x1), empty(B, 2, like=x1)
     out = torch.empty_like(x1)
     require_cuda(x1, x2, lens, lens2)
     assert x1.is_contiguous() and x2.is_contiguous()
+    if merge_rows_ok(T, D):
+        dots = empty(4, B * T, like=x1)
+        check(lib().tavsr_merge_rows_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(dots), ptr(score), ptr(w),
+                                         ptr(out), B, T, D, stream()), "tavsr_merge_rows_fwd")
+        return score, dots, w, out
+    pooled = empty(2, B, D, like=x1)
     check(lib().tavsr_merge_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(score), ptr(pooled), ptr(w),
                                 ptr(out), B, T, D, stream()), "tavsr_merge_fwd")
     return score, pooled, w, out
@@ -997,12 +1012,30 @@ def merge_combine(x1, x2, w, B, T):
     return out
 
 
-def merge_bwd(dm, x1, x2, lens, params, score, pooled, w, B, T, lens2=None):
+def merge_bwd(dm, x1, x2, lens, params, score, pooled, w, B, T, lens2=None, drop1=None, drop2=None):
+    """``pooled``: the ``aux`` of merge_fwd.  ``drop1`` / ``drop2`` (dropout tokens of the two branch outputs): dx1 / dx2 come
+    back under those masks - from the same launch on the row-parallel route, by a dropout launch each otherwise."""
     D = x1.shape[-1]
     dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
     # gradient order: weight{pool1,pool2,w1,w2} then bias{pool1,pool2,w1,w2}
     order = [0, 1, 4, 5, 2, 3, 6, 7]
     dparams = [torch.empty_like(params[i]) for i in order]
+    if pooled.dim() == 2:          # row dots: the row-parallel launches
+        require_cuda(dm, x1, x2, lens, lens2, score, pooled, w)
+        assert dm.is_contiguous() and x1.is_contiguous() and x2.is_contiguous()
+        ws = empty(lib_i64("tavsr_merge_rows_bwd_ws", B, T, D), like=x1)
+        seed = (drop1 or drop2 or (0.0, 0, None))[2]
+        assert drop1 is None or drop2 is None or drop1[2] is drop2[2] or drop1[2].data_ptr() == drop2[2].data_ptr()
+        p1, o1 = (drop1[0], drop1[1]) if drop1 is not None else (0.0, 0)
+        p2, o2 = (drop2[0], drop2[1]) if drop2 is not None else (0.0, 0)
+        check(lib().tavsr_merge_rows_bwd(ptr(dm), ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(score), ptr(w),
+                                         ptr(pooled), ptr(dx1), ptr(dx2), _ptr_array(dparams), 0, ptr(ws), C.c_float(p1),
+                                         C.c_uint64(o1), C.c_float(p2), C.c_uint64(o2), ptr(seed), B, T, D, stream()),
+              "tavsr_merge_rows_bwd")
+        grads = [None] * 8
+        for g, i in zip(dparams, order):
+            grads[i] = g
+        return dx1, dx2, grads
     ws = empty(lib_i64("tavsr_merge_bwd_ws", B, D), like=x1)
     check(lib().tavsr_merge_bwd(ptr(dm), ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(score), ptr(pooled),
                                 ptr(w), ptr(dx1), ptr(dx2), _ptr_array(dparams), 0, ptr(ws), B, T, D, stream()),
@@ -1010,6 +1043,10 @@ def merge_bwd(dm, x1, x2, lens, params, score, pooled, w, B, T, lens2=None):
     grads = [None] * 8
     for g, i in zip(dparams, order):
         grads[i] = g
+    if drop1 is not None:
+        dropout(dx1, drop1[0], out=dx1, token=drop1)
+    if drop2 is not None:
+        dropout(dx2, drop2[0], out=dx2, token=drop2)
     return dx1, dx2, grads
 
 

@@ -209,19 +209,66 @@ def test_merge_learned_ave(T):
     ref = mw[:, 0, None, None] * X[0] + mw[:, 1, None, None] * X[1]
     _close(w, mw, 1e-5)
     _close(m.view(B, T, D), ref, 1e-5)
-    # pooling + combination in one call (one launch for T <= 128): the same four results
-    score2, pooled2, w2, m2 = ops.merge_fwd(x1.view(-1, D), x2.view(-1, D), lens, prm, B, T)
-    assert torch.equal(score2, score) and torch.equal(pooled2, pooled) and torch.equal(w2, w)
-    _close(m2.view(B, T, D), ref, 1e-5)
     dm = torch.randn(B * T, D, device="cuda")
     ref.backward(dm.view(B, T, D).double())
-    dx1, dx2, grads = ops.merge_bwd(dm, x1.view(-1, D), x2.view(-1, D), lens, prm, score, pooled, w, B, T)
-    _close(dx1.view(B, T, D), X[0].grad, 1e-4)
-    _close(dx2.view(B, T, D), X[1].grad, 1e-4)
-    for i in (0, 1, 4, 5, 6, 7):
-        _close(grads[i].view(-1), P[i].grad.view(-1), 2e-4)
-    for i in (2, 3):  # d/d(pooling bias) is analytically 0 (softmax shift invariance)
-        assert grads[i].abs().max() < 1e-5
+    # pooling + combination in one call, both routes: one workgroup per utterance (one launch for T <= 128; the same four
+    # results as the two calls above) and the row-parallel launches (row dots instead of the pooled vectors)
+    keep = ops.MERGE_ROWS
+    try:
+        for rows in (False, True):
+            ops.MERGE_ROWS = rows
+            score2, aux, w2, m2 = ops.merge_fwd(x1.view(-1, D), x2.view(-1, D), lens, prm, B, T)
+            if rows:
+                assert aux.shape == (4, B * T)
+                _close(aux[2].view(B, T), (X[0] @ P[4].t()).squeeze(-1), 1e-5)
+                _close(score2, score, 1e-5)
+                _close(w2, w, 1e-5)
+            else:
+                assert torch.equal(score2, score) and torch.equal(aux, pooled) and torch.equal(w2, w)
+            _close(m2.view(B, T, D), ref, 1e-5)
+            dx1, dx2, grads = ops.merge_bwd(dm, x1.view(-1, D), x2.view(-1, D), lens, prm, score2, aux, w2, B, T)
+            _close(dx1.view(B, T, D), X[0].grad, 1e-4)
+            _close(dx2.view(B, T, D), X[1].grad, 1e-4)
+            for i in (0, 1, 4, 5, 6, 7):
+                _close(grads[i].view(-1), P[i].grad.view(-1), 2e-4)
+            for i in (2, 3):  # d/d(pooling bias) is analytically 0 (softmax shift invariance)
+                assert grads[i].abs().max() < 1e-5
+            # the branch outputs' dropout masks applied by the backward itself == the stand-alone dropout kernel on dx1 / dx2
+            ops.manual_seed(3)
+            t1, t2 = ops._new_token(0.1, B * T * D, dm.device), ops._new_token(0.25, B * T * D, dm.device)
+            for d1, d2 in ((t1, t2), (t1, None), (None, t2)):
+                e1, e2, g2 = ops.merge_bwd(dm, x1.view(-1, D), x2.view(-1, D), lens, prm, score2, aux, w2, B, T, drop1=d1, drop2=d2)
+                assert torch.equal(e1, dx1 if d1 is None else ops.dropout(dx1, d1[0], token=d1)[0])
+                assert torch.equal(e2, dx2 if d2 is None else ops.dropout(dx2, d2[0], token=d2)[0])
+                assert all(torch.equal(a, b) for a, b in zip(g2, grads))
+    finally:
+        ops.MERGE_ROWS = keep
+
+
+def test_merge_rows_second_length_vector_and_batch_32():
+    """the row-parallel merge with per-stream lengths (the AV fusion's use, adaptive_audiovisual_fusion.py:146-179) at the
+    encoder's batch, against the one-workgroup-per-utterance launches."""
+    from tavsr import ops
+    torch.manual_seed(9)
+    B, T, D = 32, 99, 256
+    lens = torch.randint(1, T + 1, (B,), device="cuda")
+    lens2 = torch.randint(1, T + 1, (B,), device="cuda")
+    x1, x2, dm = (torch.randn(B * T, D, device="cuda") for _ in range(3))
+    prm = [torch.randn(1, D, device="cuda") / 4, torch.randn(1, D, device="cuda") / 4, torch.randn(1, device="cuda"),
+           torch.randn(1, device="cuda"), torch.randn(1, D, device="cuda") / 4, torch.randn(1, D, device="cuda") / 4,
+           torch.randn(1, device="cuda"), torch.randn(1, device="cuda")]
+    keep = ops.MERGE_ROWS
+    res = []
+    try:
+        for rows in (False, True):
+            ops.MERGE_ROWS = rows
+            score, aux, w, m = ops.merge_fwd(x1, x2, lens, prm, B, T, lens2=lens2)
+            dx1, dx2, grads = ops.merge_bwd(dm, x1, x2, lens, prm, score, aux, w, B, T, lens2=lens2)
+            res.append((score, w, m, dx1, dx2, *[grads[i] for i in (0, 1, 4, 5, 6, 7)]))
+    finally:
+        ops.MERGE_ROWS = keep
+    for a, b in zip(*res):
+        _close(a, b, 2e-5)
 
 
 def test_conv2d_subsampling_pieces():
