@@ -253,6 +253,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
+    ap.add_argument("--split-backward", action="store_true",
+                    help="replay the step as two hipGraphs around the model's dp.cut also with one rank (the N > 1 default)")
+    ap.add_argument("--no-split-backward", action="store_true", help="N > 1: one hipGraph per step, all buckets leave after it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="all dropout rates 0 (the parity configuration)")
@@ -358,23 +361,57 @@ def main():
         buckets.overlap = args.no_graph
 
     graph = None
+    graph_b = None          # N > 1: the backward pass below the model's dp.cut as a second hipGraph
+    n_ready = 0             # ... and the number of gradient buckets the first graph completes
     static_loss = None
     if not args.no_graph:
         # Capture the whole forward+backward (≈2.5k kernel launches) into one hipGraph: the step is
         # launch-bound in eager mode.  Gradients land in graph-owned buffers that are stable across replays.
+        # With N > 1 ranks the step is TWO graphs (tavsr.dp.TwoPhaseBackward): forward + the backward pass above the model's cut
+        # (AV: everything but the front-ends), then the rest.  The buckets complete after the first are packed and their
+        # all-reduces enqueued on the communication stream before the second graph is replayed, so they run under it.
+        two = dp.TwoPhaseBackward() if (world > 1 or args.split_backward) and not args.no_split_backward else None
+
+        def fwd_bwd_capture():
+            for p in params:
+                p.grad = None
+            if two is None:
+                loss = model(*batch)[0]
+                loss.backward()
+                return loss, []
+            with two.forward():
+                loss = model(*batch)[0]
+            late = two.late_params(params)
+            two.phase_a(loss)
+            two.phase_b()
+            return loss, late
+
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                fwd_bwd()
+                _, late = fwd_bwd_capture()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         for p in params:
             p.grad = None
-        with torch.cuda.graph(graph):
-            static_loss = model(*batch)[0]
-            static_loss.backward()
+        if two is not None and late:
+            with torch.cuda.graph(graph):
+                with two.forward():
+                    static_loss = model(*batch)[0]
+                two.phase_a(static_loss)
+            graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_b, pool=graph.pool()):
+                two.phase_b()
+            n_ready = buckets.replan(late)      # the parameters below the cut: buckets of their own at the end of the issue order
+            if rank == 0:
+                print(f"[bench] two-graph step: {len(late)} of {len(params)} parameters below the cut, "
+                      f"{n_ready} of {len(buckets.buckets)} buckets leave under the second graph", file=sys.stderr, flush=True)
+        else:
+            with torch.cuda.graph(graph):
+                static_loss = model(*batch)[0]
+                static_loss.backward()
 
     trace = os.environ.get("TAVSR_BENCH_TRACE") == "1"     # diagnostic: synchronous per-phase times of every step on stderr
 
@@ -382,6 +419,9 @@ def main():
         t0 = time.perf_counter()
         if graph is not None:
             graph.replay()
+            if graph_b is not None:
+                buckets.launch_prefix(n_ready)     # their all-reduces run on the communication stream under the second graph
+                graph_b.replay()
         else:
             buckets.begin_step()       # the hooks enqueue buckets under the backward pass
             fwd_bwd()
@@ -426,6 +466,9 @@ def main():
         for _ in range(5):
             if graph is not None:
                 graph.replay()
+                if graph_b is not None:
+                    buckets.launch_prefix(n_ready)
+                    graph_b.replay()
             else:
                 buckets.begin_step()
                 fwd_bwd()
@@ -453,7 +496,9 @@ def main():
                    "6L Transformer decoder, batch 32 x 400 mel frames x 80 per GPU, text length 40, fwd+bwd",
                    "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
                    "dropout": 0.1 if DROPOUT else 0.0,
-                   "launch": "eager" if graph is None else "hipGraph replay (whole fwd+bwd)",
+                   "launch": "eager" if graph is None else ("hipGraph replay (whole fwd+bwd)" if graph_b is None else
+                                                            f"two hipGraphs (fwd + upper bwd | lower bwd), {n_ready} of "
+                                                            f"{len(buckets.buckets)} buckets exchanged under the second"),
                    "grad_exchange": ("none (1 GPU)" if world == 1 else
                                      ("tavsr_dp_allreduce (RCCL, C ABI)" if dp.RCCL_ABI else
                                       f"torch.distributed all_reduce ({'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()})")
@@ -498,7 +543,7 @@ def main():
                               "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)} for k, v in summ.items()},
         }
     if rank == 0 and world == 1 and not args.no_fwd_encoder:
-        del graph, static_loss
+        del graph, graph_b, static_loss
         for p in params:
             p.grad = None
         model = None

@@ -99,21 +99,51 @@ def shutdown():
         dist.destroy_process_group()
 
 
+GLOO_HOST_STAGED = os.environ.get("TAVSR_DP_GLOO_HOST_STAGED", "1") == "1"
+
+
 class GradBuckets:
     """Static bucket plan over a model's parameters (built once; parameters never change identity)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.bucket_bytes = bucket_bytes
+        self._hooked, self.overlap = False, True
+        self._plan(list(reversed(self.params)), [])  # backward produces the last layers' gradients first
+
+    def replan(self, late_params) -> int:
+        """Rebuild the plan for a step whose backward pass runs in two phases (TwoPhaseBackward): the parameters of the second
+        phase go to the end of the issue order, in buckets of their own, so that every bucket before them is complete when the
+        first phase has run.  Every rank must call it with the same partition (same model: same partition), outside a window.
+        Returns the number of buckets that hold no late parameter."""
+        assert not self._armed and self._next == 0, "replan() inside an exchange window"
+        late = {id(p) for p in late_params}
+        order = list(reversed(self.params))
+        n_early = self._plan([p for p in order if id(p) not in late], [p for p in order if id(p) in late])
+        if self._hooked:
+            self._index.clear()
+            self._index.update({id(p): i for i, b in enumerate(self.buckets) for p in b})
+        return n_early
+
+    def _plan(self, first, second) -> int:
         self.buckets: List[List[torch.nn.Parameter]] = []
-        cur, size = [], 0
-        for p in reversed(self.params):  # backward produces the last layers' gradients first
-            cur.append(p)
-            size += p.numel() * 4
-            if size >= bucket_bytes:
+        n_first = 0
+        for group in (first, second):
+            cur, size = [], 0
+            for p in group:
+                cur.append(p)
+                size += p.numel() * 4
+                if size >= self.bucket_bytes:
+                    self.buckets.append(cur)
+                    cur, size = [], 0
+            if cur:
                 self.buckets.append(cur)
-                cur, size = [], 0
-        if cur:
-            self.buckets.append(cur)
+            if group is first:
+                n_first = len(self.buckets)
+        self._reset_plan_state()
+        return n_first
+
+    def _reset_plan_state(self):
         self._flat = [None] * len(self.buckets)
         self._tab, self._flatbuf = {}, {}
         self._comm = None
@@ -121,7 +151,6 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._next = 0            # buckets 0 .. _next-1 have been enqueued in this window (ALWAYS in index order)
         self._armed = False       # a window is open: begin_step() has been called and allreduce_mean() has not yet
-        self._hooked, self.overlap = False, True
         # flat sizes do not depend on the gradients: [HIP layout (16-byte aligned slots), torch.cat layout]
         self._numel_hip = [sum((p.numel() + 3) // 4 * 4 for p in b[:-1]) + b[-1].numel() for b in self.buckets]
         self._numel_cat = [sum(p.numel() for p in b) for b in self.buckets]
@@ -253,8 +282,46 @@ class GradBuckets:
             check(lib().tavsr_dp_allreduce(C.c_void_p(flat.data_ptr()), C.c_int64(flat.numel()), C.c_void_p(comm.cuda_stream)),
                   "tavsr_dp_allreduce")
             self._works[i] = "rccl"
+        elif dist.get_backend() == "gloo" and GLOO_HOST_STAGED:
+            self._works[i] = self._issue_host_staged(i, flat)
         else:
             self._works[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _issue_host_staged(self, i, flat):
+        """gloo with GPU gradients (the one-GPU rehearsal rig): the flat buffer goes to a PERSISTENT pinned host buffer on the
+        communication stream, one helper thread all-reduces it over gloo's host path and sends it back on the same stream.
+        (gloo's own device path allocates its pinned staging per call; next to a replaying hipGraph those calls took seconds.)
+        The helper issues the collectives in submission order - the same on every rank."""
+        import concurrent.futures
+        if getattr(self, "_pool", None) is None:
+            self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            self._hostbuf = {}
+        host = self._hostbuf.get(i)
+        if host is None:
+            host = self._hostbuf[i] = torch.empty(flat.numel(), dtype=flat.dtype, pin_memory=True)
+        comm = self._comm_stream()
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            host.copy_(flat, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(comm)
+        dev = flat.device
+
+        def job():
+            torch.cuda.set_device(dev)
+            done.synchronize()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            with torch.cuda.stream(comm):
+                flat.copy_(host, non_blocking=True)
+
+        fut = self._pool.submit(job)
+
+        class _Work:
+            def wait(self_inner):
+                fut.result()
+                torch.cuda.current_stream().wait_stream(comm)
+
+        return _Work()
 
     def _allreduce_mean_hip(self, world):
         from . import ops
@@ -273,6 +340,29 @@ class GradBuckets:
         self._next = 0
         self._armed = False
 
+    # ---- overlap for captured steps: the backward pass as two hipGraphs around a cut (TwoPhaseBackward below)
+    def ready_prefix(self, late_params) -> int:
+        """number of leading buckets (issue order) that hold none of ``late_params``: complete once the first phase has run"""
+        late = {id(p) for p in late_params}
+        n = 0
+        while n < len(self.buckets) and not any(id(p) in late for p in self.buckets[n]):
+            n += 1
+        return n
+
+    def launch_prefix(self, n: int) -> None:
+        """pack buckets ``_next .. n-1`` and enqueue their all-reduces now (GPU tensors; their gradients must exist): what follows
+        on the compute stream runs beside them, ``allreduce_mean`` issues the rest and completes all.  Every rank must call it
+        with the same ``n`` - the issue order stays 0, 1, 2, ..."""
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        for p in self.params:                                  # (as allreduce_mean: a rank that skipped a layer sends zeros)
+            if p.grad is None and any(p is q for b in self.buckets[self._next: n] for q in b):
+                p.grad = torch.zeros_like(p)
+        cuda = bool(self.params) and self.params[0].is_cuda
+        for i in range(self._next, min(n, len(self.buckets))):
+            (self._launch_bucket if cuda else self._launch_bucket_cpu)(i)
+        self._next = max(self._next, min(n, len(self.buckets)))
+
     # ---- overlap with the backward pass (eager loops): a bucket leaves as soon as its last gradient exists
     def attach_overlap_hooks(self) -> None:
         """The hooks work inside a window opened by ``begin_step()`` (``tavsr.train.training`` opens one before the last
@@ -288,7 +378,7 @@ class GradBuckets:
         if self._hooked or not (dist.is_initialized() and dist.get_world_size() > 1):
             return
         self._hooked = True
-        index = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        index = self._index = {id(p): i for i, b in enumerate(self.buckets) for p in b}
 
         def hook(p):
             if not (self.overlap and self._armed):
@@ -302,3 +392,89 @@ class GradBuckets:
         for b in self.buckets:
             for p in b:
                 p.register_post_accumulate_grad_hook(hook)
+
+
+
+def _params_below(tensors) -> set:
+    """ids of the leaf tensors whose AccumulateGrad nodes the autograd graph under ``tensors`` reaches"""
+    seen, out = set(), set()
+    stack = [t.grad_fn for t in tensors if t.grad_fn is not None]
+    while stack:
+        fn = stack.pop()
+        if fn in seen:
+            continue
+        seen.add(fn)
+        if hasattr(fn, "variable"):
+            out.add(id(fn.variable))
+        stack.extend(n for n, _ in fn.next_functions if n is not None)
+    return out
+
+
+_ACTIVE_CUT = [None]
+
+
+def cut(*tensors):
+    """A model marks where its backward pass may be split: ``a, v = dp.cut(a, v)``.  Outside ``TwoPhaseBackward.forward()`` this
+    returns its arguments unchanged.  Inside, each tensor that requires a gradient is replaced by a detached leaf for the rest of
+    the forward pass and the pair is recorded: ``phase_a`` then ends at the leaves, ``phase_b`` continues from the originals with
+    the leaves' gradients.  Only the first ``cut`` call of a forward pass is honoured (one cut = two phases)."""
+    plan = _ACTIVE_CUT[0]
+    if plan is None or plan.pairs or not torch.is_grad_enabled():
+        return tensors if len(tensors) != 1 else tensors[0]
+    out = []
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.requires_grad and t.grad_fn is not None:
+            leaf = t.detach().requires_grad_(True)
+            plan.pairs.append((t, leaf))
+            out.append(leaf)
+        else:
+            out.append(t)
+    return tuple(out) if len(out) != 1 else out[0]
+
+
+class TwoPhaseBackward:
+    """The backward pass of one step as two calls around a cut of the autograd graph, so that a captured step is TWO hipGraphs
+    and the gradient buckets that the first one completes are exchanged while the second one replays:
+
+        with two.forward(): loss = model(batch)     the model's ``dp.cut(...)`` call detaches the graph there
+        two.phase_a(loss)                           loss.backward(): everything above the cut (ends at the detached leaves)
+        two.phase_b()                               continues below the cut from the leaves' gradients
+
+    Same gradients as one ``loss.backward()``: every node runs once, in one of the two calls; a parameter used on both sides of
+    the cut accumulates both contributions in ``.grad`` (and counts as late).  ``late_params(params)`` after a forward pass:
+    the parameters the graph below the cut reaches - the buckets that hold none of them are complete after ``phase_a``."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def forward(self):
+        two = self
+
+        class _Scope:
+            def __enter__(self):
+                two.pairs = []
+                _ACTIVE_CUT[0] = two
+                return two
+
+            def __exit__(self, *exc):
+                _ACTIVE_CUT[0] = None
+                return False
+
+        return _Scope()
+
+    @property
+    def split(self) -> bool:
+        return bool(self.pairs)
+
+    def late_params(self, params):
+        below = _params_below([t for t, _ in self.pairs])
+        return [p for p in params if id(p) in below]
+
+    def phase_a(self, loss) -> None:
+        loss.backward()
+
+    def phase_b(self) -> None:
+        pairs = [(t, leaf) for t, leaf in self.pairs if leaf.grad is not None]
+        if pairs:
+            torch.autograd.backward([t for t, _ in pairs], [leaf.grad for _, leaf in pairs])
+        self.pairs = []

@@ -13,7 +13,7 @@ import torch
 
 from ... import functional as F_
 from ... import functional_av as FA
-from ... import ops
+from ... import dp, ops
 from ...layers import (Conv2dSubsampling, ConvolutionalGatingMLP, LayerNorm, PositionwiseFeedForward,
                        RelPositionalEncoding, RelPositionMultiHeadedAttention, TooShortUttError, check_short_utt,
                        make_pad_mask)
@@ -119,6 +119,9 @@ class MyBranchformerEncoder(torch.nn.Module):
         intermediate_outs = []
         for layer_idx, encoder_layer in enumerate(self.encoders):
             xs_pad, masks = encoder_layer(xs_pad, masks, lens=lens)
+            if layer_idx + 1 == len(self.encoders) // 2 and isinstance(xs_pad, tuple):
+                # where a data-parallel step may split its backward pass (tavsr.dp.TwoPhaseBackward; identity otherwise)
+                xs_pad = (dp.cut(xs_pad[0]),) + tuple(xs_pad[1:])
             if (len(self.interctc_layer_idx) == 0 and max_layer is not None
                     and 0 <= max_layer < len(self.encoders) and layer_idx >= max_layer):
                 break

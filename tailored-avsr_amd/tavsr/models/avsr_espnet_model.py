@@ -11,7 +11,7 @@ from typing import List, Tuple, Union
 import torch
 
 from .. import functional_av as FA
-from .. import ops
+from .. import dp, ops
 from ..ctc.ctc import CTC
 from .espnet_model import ESPnetASRModel, cut_to_longest
 
@@ -97,6 +97,10 @@ class ESPnetAVSRModel(ESPnetASRModel):
             else:
                 video_feats, video_feats_lengths = video, video_lengths
             audio_feats, audio_masks = self.acoustic_embed.apply_embed_layer(audio_feats, audio_feats_lengths)
+        # where a data-parallel step may split its backward pass (tavsr.dp.TwoPhaseBackward; identity otherwise): everything below
+        # these two tensors is the front-ends' backward pass, the longest stretch of the step that completes no encoder / decoder
+        # gradient bucket
+        video_feats, audio_feats = dp.cut(video_feats, audio_feats)
         video_feats, video_masks = self.visual_embed.apply_embed_layer(video_feats, video_feats_lengths)
         audio_feats, audio_masks, video_feats, video_masks = self.audiovisual_alignment(audio_feats, audio_masks,
                                                                                         video_feats, video_masks)

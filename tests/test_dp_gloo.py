@@ -45,6 +45,77 @@ def test_dp_allreduce_mean_world2():
         assert torch.allclose(ga, (la + lb) / 2, atol=1e-6)
 
 
+def _two_phase_worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
+    from tavsr import dp
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dp.init_from_env("gloo")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = torch.nn.Linear(30, 7)              # registered first, used last: the plain plan puts it last
+            self.stem = torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.Tanh(), torch.nn.Linear(300, 30))
+            self.both = torch.nn.Parameter(torch.ones(30))   # used below AND above the cut
+
+        def forward(self, x):
+            h = self.stem(x) * self.both
+            h = dp.cut(h)
+            return (self.head(h * self.both)).square().sum()
+
+    torch.manual_seed(3)
+    model = Net()
+    params = list(model.parameters())
+    buckets = dp.GradBuckets(params, bucket_bytes=5_000)
+    buckets.broadcast_parameters(0)
+    torch.manual_seed(7 + rank)
+    x = torch.randn(5, 64)
+    model(x).backward()                                      # no plan active: dp.cut is the identity
+    local = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    two = dp.TwoPhaseBackward()
+    with two.forward():
+        loss = model(x)
+    late = two.late_params(params)
+    n_ready = buckets.replan(late)
+    assert 0 < n_ready < len(buckets.buckets)
+    assert {id(p) for b in buckets.buckets[n_ready:] for p in b} == {id(p) for p in late}
+    two.phase_a(loss)
+    early_done = all(p.grad is not None for b in buckets.buckets[:n_ready] for p in b)
+    stem_untouched = all(p.grad is None for p in model.stem.parameters())
+    buckets.launch_prefix(n_ready)                           # the head's buckets leave before the second phase runs
+    issued = buckets._next
+    two.phase_b()
+    split = [p.grad.clone() for p in params]
+    buckets.allreduce_mean()
+    ret[rank] = dict(local=local, split=split, avg=[p.grad.clone() for p in params], n_ready=n_ready, issued=issued,
+                     late=[n for n, p in model.named_parameters() if any(p is q for q in late)],
+                     early_done=early_done, stem_untouched=stem_untouched)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_two_phase_backward_buckets_world2():
+    """TwoPhaseBackward + GradBuckets.replan/launch_prefix (bench.py's N > 1 step, here without graphs): the split backward
+    gives the gradients of one backward pass, the parameters below the cut (and the one used on both sides) form the late
+    buckets, the early buckets are issued before the second phase, and the reduced gradients are the rank mean."""
+    world, port = 2, 29771
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_phase_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert sorted(a["late"]) == ["both", "stem.0.bias", "stem.0.weight", "stem.2.bias", "stem.2.weight"]
+    for r in (a, b):
+        assert r["early_done"] and r["stem_untouched"] and r["issued"] == r["n_ready"]
+        for g, s in zip(r["local"], r["split"]):
+            assert torch.allclose(g, s, rtol=1e-6, atol=1e-6)
+    for ga, gb, la, lb in zip(a["avg"], b["avg"], a["local"], b["local"]):
+        assert torch.equal(ga, gb)
+        assert torch.allclose(ga, (la + lb) / 2, rtol=1e-5, atol=1e-6)
+
+
 def _hook_order_worker(rank, world, port, ret):
     """overlap hooks with DIFFERENT gradient sets per rank: rank 1 skips the middle layer (a stochastic-depth coin that fell
     differently), so its bucket never completes there.  Collectives must still be issued 0, 1, 2, ... on every rank."""

@@ -618,6 +618,76 @@ def test_graph_replayed_training_step_equals_eager_launches(workload):
         assert not bad, (replay, bad[:8])
 
 
+@pytest.mark.parametrize("workload", ["avsr", "asr"])
+def test_training_step_as_two_graphs_around_the_cut_equals_eager_launches(workload):
+    """tavsr.dp.TwoPhaseBackward (what bench.py replays with N > 1 ranks so that the first graph's gradient buckets are exchanged
+    under the second): forward + upper backward as one hipGraph, the backward below the model's ``dp.cut`` as a second one
+    on the same pool - loss and every gradient equal one eager ``loss.backward()`` bit for bit; the parameters below the cut
+    are exactly the ones without a gradient after the first graph."""
+    from tavsr import dp
+    if workload == "avsr":
+        from tavsr.tasks.avsr import AVSRTask
+        model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(AVSR_YAML, num_blocks=3, dec_blocks=2)))
+        batch = [t.cuda() for t in _bench_batch(8)]
+    else:
+        from helpers import asr_conf
+        from oracle.model import synth
+        from tavsr.tasks.asr import ASRTask
+        model = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=4, dec_blocks=2)))
+        text = synth((8, 30), seed=2, kind="int", lo=1, hi=40)
+        batch = [synth((8, 400, 80), seed=1).cuda(), torch.full((8,), 400).cuda(), text.cuda(), torch.full((8,), 30).cuda()]
+    torch.manual_seed(0)
+    model = model.cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    for p in params:
+        p.grad = None
+    eager_loss = model(*batch)[0]
+    eager_loss.backward()
+    eager_loss = eager_loss.detach().clone()
+    eager = [p.grad.detach().clone() for p in params]
+    two = dp.TwoPhaseBackward()
+
+    def split_step():
+        for p in params:
+            p.grad = None
+        with two.forward():
+            loss = model(*batch)[0]
+        assert two.split
+        late = two.late_params(params)
+        two.phase_a(loss)
+        missing = [p for p in params if p.grad is None]
+        two.phase_b()
+        return loss, late, missing
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        loss, late, missing = split_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert late and len(late) < len(params)
+    assert {id(p) for p in late} == {id(p) for p in missing}
+    assert torch.equal(loss.detach(), eager_loss)
+    bad = [n for (n, p), g in zip(model.named_parameters(), eager) if not torch.equal(p.grad, g)]
+    assert not bad, bad[:8]
+    for p in params:
+        p.grad = None
+    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ga):
+        with two.forward():
+            static_loss = model(*batch)[0]
+        two.phase_a(static_loss)
+    with torch.cuda.graph(gb, pool=ga.pool()):
+        two.phase_b()
+    for replay in range(3):
+        ga.replay()
+        gb.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_loss.detach(), eager_loss), replay
+        bad = [n for (n, p), g in zip(model.named_parameters(), eager) if not torch.equal(p.grad, g)]
+        assert not bad, (replay, bad[:8])
+
+
 @pytest.mark.parametrize("merge,kw", [("concat", {}), ("fixed_ave", dict(acoustic_weight=0.3)), ("fixed_ave", dict(acoustic_weight=1.0))])
 def test_fusion_concat_and_fixed_ave_match_the_oracle(merge, kw):
     """AdaptiveAudioVisualFusion merge_method "concat" (FFN over the concatenated streams) and "fixed_ave" (constant
