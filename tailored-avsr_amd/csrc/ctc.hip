@@ -325,15 +325,43 @@ __global__ void embed_pe_kernel(const int64_t* __restrict__ ids, const float* __
   reinterpret_cast<float4*>(out)[i] = make_float4(e.x * scale + p.x, e.y * scale + p.y, e.z * scale + p.z, e.w * scale + p.w);
 }
 
-// dtable[v,:] = scale * sum_{n: ids[n]==v} dout[n,:]   (one block per vocabulary row: deterministic)
+// dtable[v,:] = scale * sum_{n: ids[n]==v} dout[n,:]   (one block per vocabulary row: deterministic, n ascending)
+// The block finds its row's occurrences together: thread t scans the ids of its contiguous chunk, an exclusive scan of the
+// counts gives every thread its place in the list (so the list is in ascending n), then the columns sum over the list.
+// (Every thread walking all N ids by itself took 110 us at N = 1312, V = 5000.)  Dynamic LDS: N ints.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
                                                         float scale, float* __restrict__ dtable, int64_t N, int D,
                                                         int accumulate) {
-  const int v = blockIdx.x;
-  for (int c = threadIdx.x; c < D; c += 256) {
+  extern __shared__ int s_list[];
+  __shared__ int s_cnt[257];
+  const int v = blockIdx.x, t = threadIdx.x;
+  const int per = (int)((N + 255) / 256);
+  const int64_t n0 = (int64_t)t * per, n1 = min(N, n0 + per);
+  int cnt = 0;
+  for (int64_t n = n0; n < n1; ++n) cnt += ids[n] == v;
+  s_cnt[t + 1] = cnt;
+  if (t == 0) s_cnt[0] = 0;
+  __syncthreads();
+  if (t < 64) {      // inclusive scan of 256 counts by one wave: four per lane, then a wave scan of the lane sums
+    int a0 = s_cnt[4 * t + 1], a1 = a0 + s_cnt[4 * t + 2], a2 = a1 + s_cnt[4 * t + 3], a3 = a2 + s_cnt[4 * t + 4];
+    int run = a3;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(run, o, 64);
+      if (t >= o) run += up;
+    }
+    const int base = run - a3;
+    s_cnt[4 * t + 1] = base + a0; s_cnt[4 * t + 2] = base + a1; s_cnt[4 * t + 3] = base + a2; s_cnt[4 * t + 4] = base + a3;
+  }
+  __syncthreads();
+  int pos = s_cnt[t];
+  for (int64_t n = n0; n < n1; ++n)
+    if (ids[n] == v) s_list[pos++] = (int)n;
+  __syncthreads();
+  const int total = s_cnt[256];
+  for (int c = t; c < D; c += 256) {
     float acc = 0.f;
-    for (int64_t n = 0; n < N; ++n)
-      if (ids[n] == v) acc += dout[n * D + c];
+    for (int i = 0; i < total; ++i) acc += dout[(int64_t)s_list[i] * D + c];
     acc *= scale;
     dtable[(int64_t)v * D + c] = accumulate ? dtable[(int64_t)v * D + c] + acc : acc;
   }
@@ -413,8 +441,9 @@ extern "C" int tavsr_embed_bwd(const int64_t* ids, const float* dout, float scal
                                int32_t D, int32_t accumulate, tavsr_stream_t stream) {
   TAVSR_REQUIRE(ids && dout && dtable, TAVSR_EINVAL, "embed_bwd: null pointer");
   if (V <= 0) return TAVSR_OK;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dout, scale, dtable, N, D,
-                     accumulate);
+  TAVSR_REQUIRE(N >= 0 && N <= 15000, TAVSR_EUNSUPPORTED, "embed_bwd: at most 15000 tokens per call (N=%lld)", (long long)N);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), (size_t)(N > 0 ? N : 1) * sizeof(int), (hipStream_t)stream, ids, dout, scale,
+                     dtable, N, D, accumulate);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
