@@ -355,9 +355,10 @@ class GradBuckets:
         with the same ``n`` - the issue order stays 0, 1, 2, ..."""
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return
-        for p in self.params:                                  # (as allreduce_mean: a rank that skipped a layer sends zeros)
-            if p.grad is None and any(p is q for b in self.buckets[self._next: n] for q in b):
-                p.grad = torch.zeros_like(p)
+        for b in self.buckets[self._next: n]:                  # (as allreduce_mean: a rank that skipped a layer sends zeros)
+            for p in b:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
         cuda = bool(self.params) and self.params[0].is_cuda
         for i in range(self._next, min(n, len(self.buckets))):
             (self._launch_bucket if cuda else self._launch_bucket_cpu)(i)
