@@ -502,6 +502,8 @@ def main():
                    "grad_exchange": ("none (1 GPU)" if world == 1 else
                                      ("tavsr_dp_allreduce (RCCL, C ABI)" if dp.RCCL_ABI else
                                       f"torch.distributed all_reduce ({'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()})")
+                                     + (", staged through pinned host buffers" if torch.distributed.get_backend() == "gloo"
+                                        and dp.GLOO_HOST_STAGED and not dp.RCCL_ABI else "")
                                      + ", 64 MB flat buckets")},
         "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
         "model_tflops_per_s": round(value * GFLOP_PER_UTT_STEP[WORKLOAD] / 1e3, 2),
