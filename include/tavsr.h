@@ -150,6 +150,11 @@ int tavsr_layernorm_bwd_partial_drop(const float* dy, int64_t lddy, const float*
                                      const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd, float* dx,
                                      int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D, float* dx_drop, float p_drop,
                                      const uint64_t* seed_dev, uint64_t offset, tavsr_stream_t stream);
+/* tavsr_layernorm_bwd for x = act(z): dx is written as the gradient w.r.t. z (the LayerNorm's dx times act'(z)): cgMLP's gate half
+ * LayerNorm(gelu(channel_proj1(x))[..., C:]) (espnet cgmlp.py ConvolutionalSpatialGatingUnit.norm; encoder_layer.py:220) */
+int tavsr_layernorm_bwd_act(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd,
+                            const float* gamma, float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate, float* ws,
+                            int32_t M, int32_t D, const float* z, int64_t ldz, int32_t act, tavsr_stream_t stream);
 int64_t tavsr_colsum_ws(int32_t M, int32_t N);
 /* out = x + y, sum_x[n] = sum_m x[m][n], sum_y[n] = sum_m y[m][n] in two launches (dQ = dQu + dQv with the pos_bias_u/v
  * gradients of RelPositionMultiHeadedAttention); ws >= 2 * tavsr_colsum_ws(M, N) floats */
@@ -402,6 +407,12 @@ int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int6
                           const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,
                           int32_t accumulate, float* ws, int32_t B, int32_t T, int32_t C, int32_t K,
                           tavsr_stream_t stream);
+/* ... for r = act(zr) (cgMLP: the left half of gelu(channel_proj1(x))): dr is written as the gradient w.r.t. zr, dr * act'(zr);
+ * kernel size 31 only.  With tavsr_layernorm_bwd_act on the gate half no activation-backward pass over the projection remains. */
+int tavsr_dwconv_gate_bwd_act(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv, const float* w,
+                              float* dr, int64_t lddr, float* dgn, float* dw, float* dbias, int32_t accumulate, float* ws,
+                              int32_t B, int32_t T, int32_t C, int32_t K, const float* zr, int64_t ldz, int32_t act,
+                              tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * learned_ave branch merge (encoder_layer.py:232-293) and the same pooling used by

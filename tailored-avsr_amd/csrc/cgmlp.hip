@@ -358,7 +358,10 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kfix_kernel(const float* 
                                                                    const float* __restrict__ conv,
                                                                    const float* __restrict__ w, float* __restrict__ dr,
                                                                    int64_t lddr, float* __restrict__ dgn,
-                                                                   float* __restrict__ part, int B, int T, int C) {
+                                                                   float* __restrict__ part, int B, int T, int C,
+                                                                   const float* __restrict__ zr, int64_t ldz, int act) {
+  // zr != null: r = act(zr) is the left half of cgMLP's activated projection; dr is written as the gradient w.r.t. zr
+  // (dr * act'(zr)): no activation-backward pass over that half afterwards
   extern __shared__ float sm[];
   constexpr int pad = (K - 1) / 2, rows = CG_TB + K - 1;
   constexpr int NTAP = (K + 1 + 3) / 4;        // taps per thread (tap K is the bias)
@@ -378,17 +381,20 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kfix_kernel(const float* 
   for (int t0 = 0; t0 < T; t0 += CG_TB) {
     __syncthreads();
     for (int ib = ty * 4; ib < rows; ib += 16) {
-      float duv[4], rv[4], gv[4], cv[4];
+      float duv[4], rv[4], gv[4], cv[4], zv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = ib + q, t = t0 + i - pad;
-        duv[q] = rv[q] = gv[q] = cv[q] = 0.f;
+        duv[q] = rv[q] = gv[q] = cv[q] = zv[q] = 0.f;
         if (i < rows && t >= 0 && t < T && cok) {
           const int64_t m = (int64_t)b * T + t;
           duv[q] = du[m * C + c];
           rv[q] = r[m * ldr + c];
           gv[q] = gn[m * C + c];
-          if (i >= pad && i < pad + CG_TB) cv[q] = conv[m * C + c];
+          if (i >= pad && i < pad + CG_TB) {
+            cv[q] = conv[m * C + c];
+            if (zr) zv[q] = zr[m * ldz + c];
+          }
         }
       }
 #pragma unroll
@@ -397,7 +403,11 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kfix_kernel(const float* 
         if (i < rows) {
           s_d[i * CG_CH + cx] = duv[q] * rv[q];
           s_g[i * CG_CH + cx] = gv[q];
-          if (i >= pad && i < pad + CG_TB && t < T && cok) dr[((int64_t)b * T + t) * lddr + c] = duv[q] * cv[q];
+          if (i >= pad && i < pad + CG_TB && t < T && cok) {
+            float v = duv[q] * cv[q];
+            if (zr) v *= act_bwd(act, zv[q]);
+            dr[((int64_t)b * T + t) * lddr + c] = v;
+          }
         }
       }
     }
@@ -1118,10 +1128,9 @@ extern "C" int64_t tavsr_dwconv_gate_bwd_ws(int32_t B, int32_t T, int32_t C, int
   return ((int64_t)B + 1) * C * (K + 1);
 }
 
-extern "C" int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv,
-                                     const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,
-                                     int32_t accumulate, float* ws, int32_t B, int32_t T, int32_t C, int32_t K,
-                                     tavsr_stream_t stream) {
+static int dwconv_gate_bwd_impl(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv, const float* w,
+                               float* dr, int64_t lddr, float* dgn, float* dw, float* dbias, int32_t accumulate, float* ws, int32_t B,
+                               int32_t T, int32_t C, int32_t K, const float* zr, int64_t ldz, int32_t act, tavsr_stream_t stream) {
   TAVSR_REQUIRE(du && gn && r && conv && w && dr && dgn && dw && dbias && ws, TAVSR_EINVAL,
                 "dwconv_gate_bwd: null pointer");
   TAVSR_REQUIRE(K >= 1 && K <= CG_KMAX && (K & 1), TAVSR_EUNSUPPORTED, "dwconv_gate_bwd: odd K <= %d required", CG_KMAX);
@@ -1130,7 +1139,7 @@ extern "C" int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const flo
   size_t lds = (2 * (CG_TB + K - 1) * CG_CH + K * CG_CH) * sizeof(float);
   if (K == 31)
     hipLaunchKernelGGL(dwconv_gate_bwd_kfix_kernel<31>, dim3(cdiv(C, CG_CH), B), dim3(256),
-                       2 * (CG_TB + 30) * CG_CH * sizeof(float), s, du, gn, r, ldr, conv, w, dr, lddr, dgn, ws, B, T, C);
+                       2 * (CG_TB + 30) * CG_CH * sizeof(float), s, du, gn, r, ldr, conv, w, dr, lddr, dgn, ws, B, T, C, zr, ldz, (int)act);
   else
     hipLaunchKernelGGL(dwconv_gate_bwd_kernel, dim3(cdiv(C, CG_CH), B), dim3(256), lds, s, du, gn, r, ldr, conv, w, dr,
                        lddr, dgn, ws, B, T, C, K);
@@ -1143,6 +1152,23 @@ extern "C" int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const flo
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
+
+extern "C" int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv,
+                                     const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,
+                                     int32_t accumulate, float* ws, int32_t B, int32_t T, int32_t C, int32_t K,
+                                     tavsr_stream_t stream) {
+  return dwconv_gate_bwd_impl(du, gn, r, ldr, conv, w, dr, lddr, dgn, dw, dbias, accumulate, ws, B, T, C, K, nullptr, 0, 0, stream);
+}
+
+// ... with r = act(zr): dr comes back as the gradient w.r.t. the pre-activation zr (kernel size 31 only)
+extern "C" int tavsr_dwconv_gate_bwd_act(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv,
+                                         const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,
+                                         int32_t accumulate, float* ws, int32_t B, int32_t T, int32_t C, int32_t K,
+                                         const float* zr, int64_t ldz, int32_t act, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(zr && K == 31, TAVSR_EUNSUPPORTED, "dwconv_gate_bwd_act: needs zr and kernel size 31 (K=%d)", K);
+  return dwconv_gate_bwd_impl(du, gn, r, ldr, conv, w, dr, lddr, dgn, dw, dbias, accumulate, ws, B, T, C, K, zr, ldz, act, stream);
+}
+
 
 static MergeParams mk(const float* const* prm) {
   MergeParams p;

@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx, int64_t lddx,
                                                             float* __restrict__ part, int64_t ld_part, int M, int D,
                                                             float* __restrict__ dx_drop, uint32_t thr, float inv_keep,
-                                                            const uint64_t* __restrict__ seed, uint64_t offset4) {
+                                                            const uint64_t* __restrict__ seed, uint64_t offset4,
+                                                            const float* __restrict__ az, int64_t ldaz, int act) {
+  // az != null: the normalised tensor was x = act(az) - dx is written as the gradient w.r.t. az (dx * act'(az)); cgMLP's gate
+  // half: LayerNorm(gelu(z)[:, C:]), no activation-backward pass over that half afterwards
   // dx_drop != null: a second output [M][D] = dropout_backward(dx) under the tavsr_dropout mask at offset4 - the consumer of dx
   // is a residual block whose branch starts with that mask (x + s * dropout(f(x))): saves its stand-alone mask launch
   __shared__ float red[4][2][NV * 256];
@@ -135,6 +138,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.y = rs[q] * (gd[i].y - s1 - xh[i].y * s2) + av[q][i].y;
           o.z = rs[q] * (gd[i].z - s1 - xh[i].z * s2) + av[q][i].z;
           o.w = rs[q] * (gd[i].w - s1 - xh[i].w * s2) + av[q][i].w;
+          if (az) {
+            const float4 zz = *reinterpret_cast<const float4*>(az + (int64_t)(row0 + q) * ldaz + c);
+            o.x *= act_bwd(act, zz.x); o.y *= act_bwd(act, zz.y); o.z *= act_bwd(act, zz.z); o.w *= act_bwd(act, zz.w);
+          }
           *reinterpret_cast<float4*>(or_ + c) = o;
           if (dx_drop) {
             const uint64_t sd = seed[0], ctr = offset4 + (((uint64_t)(row0 + q) * (uint64_t)D + (uint64_t)c) >> 2);
@@ -268,11 +275,12 @@ extern "C" int64_t tavsr_layernorm_bwd_ws(int32_t M, int32_t D) { return (int64_
 // main pass only: dx and the per-block partials of (dgamma | dbeta) at ws[blk * ws_ld + (0..2D)); the caller reduces them
 // (tavsr_sum_partials over `tavsr_layernorm_bwd_ws(M, D) / (2 D)` blocks) - lets several LayerNorms of one backward node
 // share ONE reduction launch (ws_ld = total columns of the shared slab).
-extern "C" int tavsr_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
-                                           const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd,
-                                           float* dx, int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D,
-                                           tavsr_stream_t stream) {
+static int layernorm_bwd_partial_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                      const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd, float* dx,
+                                      int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D, const float* az, int64_t ldaz,
+                                      int32_t act, tavsr_stream_t stream) {
   TAVSR_REQUIRE(dy && x && mean && rstd && gamma && dx && ws, TAVSR_EINVAL, "layernorm_bwd: null pointer");
+  TAVSR_REQUIRE(!az || (ldaz % 4 == 0 && (uintptr_t)az % 16 == 0), TAVSR_EALIGN, "layernorm_bwd: pre-activation rows must be 16-byte aligned");
   TAVSR_REQUIRE(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, TAVSR_EUNSUPPORTED, "layernorm_bwd: unsupported D=%d", D);
   TAVSR_REQUIRE(ws_ld >= 2 * (int64_t)D, TAVSR_EINVAL, "layernorm_bwd: partial slab rows too short");
   TAVSR_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldadd % 4 == 0 && ((uintptr_t)x % 16 == 0) &&
@@ -283,15 +291,22 @@ extern "C" int tavsr_layernorm_bwd_partial(const float* dy, int64_t lddy, const 
   hipStream_t s = (hipStream_t)stream;
   if (D <= 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0);
+                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0, az, ldaz, (int)act);
   else if (D <= 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0);
+                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0, az, ldaz, (int)act);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add,
-                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0);
+                       ldadd, dx, lddx, ws, ws_ld, M, D, (float*)nullptr, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0, az, ldaz, (int)act);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
+}
+
+extern "C" int tavsr_layernorm_bwd_partial(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                           const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd,
+                                           float* dx, int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D,
+                                           tavsr_stream_t stream) {
+  return layernorm_bwd_partial_impl(dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx, lddx, ws, ws_ld, M, D, nullptr, 0, 0, stream);
 }
 
 // tavsr_layernorm_bwd_partial that also writes dx_drop [M][D] = dx * mask / keep (the tavsr_dropout mask of a contiguous [M][D]
@@ -316,13 +331,13 @@ extern "C" int tavsr_layernorm_bwd_partial_drop(const float* dy, int64_t lddy, c
   const float ik = 1.f / (1.f - p_drop);
   if (D <= 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx,
-                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4);
+                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4, (const float*)nullptr, (int64_t)0, 0);
   else if (D <= 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx,
-                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4);
+                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4, (const float*)nullptr, (int64_t)0, 0);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx,
-                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4);
+                       lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4, (const float*)nullptr, (int64_t)0, 0);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
@@ -334,6 +349,22 @@ extern "C" int tavsr_layernorm_bwd(const float* dy, int64_t lddy, const float* x
   TAVSR_REQUIRE(dgamma && dbeta, TAVSR_EINVAL, "layernorm_bwd: null pointer");
   int rc = tavsr_layernorm_bwd_partial(dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx, lddx, ws, 2 * (int64_t)D, M, D,
                                        stream);
+  if (rc || M <= 0) return rc;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(kSumWaves * 64), 0, (hipStream_t)stream, ws, ln_blocks(M),
+                     (int64_t)2 * D, dgamma, dbeta, D, 2 * D, accumulate, 1.f);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// tavsr_layernorm_bwd for x = act(z): dx is the gradient w.r.t. z (dx_ln * act'(z)) - the LayerNorm of cgMLP's gate half
+// (espnet ConvolutionalSpatialGatingUnit.norm on gelu(channel_proj1(x))[..., C:]) without an activation-backward pass afterwards
+extern "C" int tavsr_layernorm_bwd_act(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                       const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                       int32_t accumulate, float* ws, int32_t M, int32_t D, const float* z, int64_t ldz, int32_t act,
+                                       tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dgamma && dbeta && z, TAVSR_EINVAL, "layernorm_bwd_act: null pointer");
+  int rc = layernorm_bwd_partial_impl(dy, lddy, x, ldx, mean, rstd, gamma, nullptr, 0, dx, lddx, ws, 2 * (int64_t)D, M, D, z, ldz, act,
+                                      stream);
   if (rc || M <= 0) return rc;
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * D, 64)), dim3(kSumWaves * 64), 0, (hipStream_t)stream, ws, ln_blocks(M),
                      (int64_t)2 * D, dgamma, dbeta, D, 2 * D, accumulate, 1.f);

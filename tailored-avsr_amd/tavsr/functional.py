@@ -621,11 +621,18 @@ class BranchformerLayerFn(torch.autograd.Function):
             du = ops.linear_dx_drop(dxm, p("cgmlp.channel_proj2.weight"), t_u)
             dg = torch.empty_like(g)
             cw = p("cgmlp.csgu.conv.weight")
-            dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
+            fused = ops.CGMLP_ACT_BWD_FUSED and cw.shape[-1] == 31      # gelu'(z) applied by the two kernels that write dg's halves
+            dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T,
+                                                zr=z[:, :Cn] if fused else None)
             put("cgmlp.csgu.conv.weight", gcw, like=cw); put("cgmlp.csgu.conv.bias", gcb)
-            _, g1, g2 = ops.layernorm_bwd(dgn, g[:, Cn:], gmean, grstd, p("cgmlp.csgu.norm.weight"), dx=dg[:, Cn:])
+            if fused:
+                _, g1, g2 = ops.layernorm_bwd_act(dgn, g[:, Cn:], gmean, grstd, p("cgmlp.csgu.norm.weight"), z[:, Cn:], "gelu",
+                                                  dx=dg[:, Cn:])
+            else:
+                _, g1, g2 = ops.layernorm_bwd(dgn, g[:, Cn:], gmean, grstd, p("cgmlp.csgu.norm.weight"), dx=dg[:, Cn:])
             put("cgmlp.csgu.norm.weight", g1); put("cgmlp.csgu.norm.bias", g2)
-            ops.act_bwd_(dg, z, "gelu")
+            if not fused:
+                ops.act_bwd_(dg, z, "gelu")
             gw_, gb_ = grp.add(dg, n, bias_grad=True)
             put("cgmlp.channel_proj1.0.weight", gw_); put("cgmlp.channel_proj1.0.bias", gb_)
             dn = ops.linear_dx(dg, p("cgmlp.channel_proj1.0.weight"))

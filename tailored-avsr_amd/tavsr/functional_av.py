@@ -394,11 +394,17 @@ def _ts_branch_bwd(p, cfg, saved, dx2, x1, pos_emb, lens, B, T, grp, lng, G, dbr
     du = ops.linear_dx_drop(dbr, p["cgmlp.channel_proj2.weight"], t_u, alpha=coeff)
     dg = torch.empty_like(g)
     cw = p["cgmlp.csgu.conv.weight"]
-    dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T)
+    fused = ops.CGMLP_ACT_BWD_FUSED and cw.shape[-1] == 31      # gelu'(z) applied by the two kernels that write dg's halves
+    dgn, gcw, gcb = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, cw.reshape(Cn, -1), dg[:, :Cn], B, T,
+                                        zr=z[:, :Cn] if fused else None)
     G["cgmlp.csgu.conv.weight"], G["cgmlp.csgu.conv.bias"] = gcw.view_as(cw), gcb
-    _, G["cgmlp.csgu.norm.weight"], G["cgmlp.csgu.norm.bias"] = ops.layernorm_bwd(
-        dgn, g[:, Cn:], gmean, grstd, p["cgmlp.csgu.norm.weight"], dx=dg[:, Cn:])
-    ops.act_bwd_(dg, z, "gelu")
+    if fused:
+        _, G["cgmlp.csgu.norm.weight"], G["cgmlp.csgu.norm.bias"] = ops.layernorm_bwd_act(
+            dgn, g[:, Cn:], gmean, grstd, p["cgmlp.csgu.norm.weight"], z[:, Cn:], "gelu", dx=dg[:, Cn:])
+    else:
+        _, G["cgmlp.csgu.norm.weight"], G["cgmlp.csgu.norm.bias"] = ops.layernorm_bwd(
+            dgn, g[:, Cn:], gmean, grstd, p["cgmlp.csgu.norm.weight"], dx=dg[:, Cn:])
+        ops.act_bwd_(dg, z, "gelu")
     G["cgmlp.channel_proj1.0.weight"], G["cgmlp.channel_proj1.0.bias"] = grp.add(dg, n, bias_grad=True)
     dn = ops.linear_dx(dg, p["cgmlp.channel_proj1.0.weight"])
     dx1, G["norm_cgmlp.weight"], G["norm_cgmlp.bias"], *dxd = lng.bwd(dn, x1, mean, rstd, p["norm_cgmlp.weight"], dx_add=dx2,

@@ -542,6 +542,20 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dx_add=None, dx=None):
     return dx, dg, db
 
 
+def layernorm_bwd_act(dy, x, mean, rstd, gamma, z, act, *, dx=None):
+    """layernorm_bwd for x = act(z): dx is the gradient w.r.t. z; returns dx, dgamma, dbeta."""
+    M, D = x.shape
+    require_cuda(dy, x, mean, rstd, gamma, z)
+    if dx is None:
+        dx = empty(M, D, like=x)
+    dg, db = empty(D, like=x), empty(D, like=x)
+    ws = empty(lib_i64("tavsr_layernorm_bwd_ws", M, D), like=x)
+    check(lib().tavsr_layernorm_bwd_act(ptr(dy), C.c_int64(dy.stride(0)), ptr(x), C.c_int64(x.stride(0)), ptr(mean), ptr(rstd),
+                                        ptr(gamma), ptr(dx), C.c_int64(dx.stride(0)), ptr(dg), ptr(db), 0, ptr(ws), M, D, ptr(z),
+                                        C.c_int64(z.stride(0)), ACT[act], stream()), "tavsr_layernorm_bwd_act")
+    return dx, dg, db
+
+
 LN_BWD_DROP = os.environ.get("TAVSR_LN_BWD_DROP", "1") == "1"      # A/B switch: masked gradient copy from the LayerNorm backward
 
 
@@ -952,12 +966,22 @@ def csgu_fwd(g, ln_w, ln_b, eps, w, bias, B, T, p=0.0, save=True, rowstat=None):
     return out, conv, gn, mean, rstd, tok
 
 
-def dwconv_gate_bwd(du, gn, r, conv, w, dr, B, T):
+CGMLP_ACT_BWD_FUSED = os.environ.get("TAVSR_CGMLP_ACT_BWD_FUSED", "1") == "1"   # A/B switch: gelu' in the CSGU's two backward kernels
+
+
+def dwconv_gate_bwd(du, gn, r, conv, w, dr, B, T, zr=None, act="gelu"):
+    """``zr`` (kernel size 31): r = act(zr); dr comes back as the gradient w.r.t. zr."""
     M, Cn = gn.shape
     K = w.shape[-1]
     dgn = empty(M, Cn, like=gn)
     dw, db = torch.empty_like(w), empty(Cn, like=gn)
     ws = empty(lib_i64("tavsr_dwconv_gate_bwd_ws", B, T, Cn, K), like=gn)
+    if zr is not None:
+        require_cuda(du, gn, r, conv, w, dr, zr)
+        check(lib().tavsr_dwconv_gate_bwd_act(ptr(du), ptr(gn), ptr(r), C.c_int64(r.stride(0)), ptr(conv), ptr(w), ptr(dr),
+                                              C.c_int64(dr.stride(0)), ptr(dgn), ptr(dw), ptr(db), 0, ptr(ws), B, T, Cn, K,
+                                              ptr(zr), C.c_int64(zr.stride(0)), ACT[act], stream()), "tavsr_dwconv_gate_bwd_act")
+        return dgn, dw, db
     check(lib().tavsr_dwconv_gate_bwd(ptr(du), ptr(gn), ptr(r), C.c_int64(r.stride(0)), ptr(conv), ptr(w), ptr(dr),
                                       C.c_int64(dr.stride(0)), ptr(dgn), ptr(dw), ptr(db), 0, ptr(ws), B, T, Cn, K,
                                       stream()), "tavsr_dwconv_gate_bwd")

@@ -107,6 +107,20 @@ def test_dwconv_gate(B, T):
     _close(dgn, gnr.grad, 1e-4)
     _close(dw.view(Cn, 1, K), wr.grad, 1e-4)
     _close(db, br.grad, 1e-4)
+    # g = gelu(z): both halves' gradients w.r.t. z written by the two backward kernels themselves (tavsr_dwconv_gate_bwd_act,
+    # tavsr_layernorm_bwd_act) == the activation-backward pass applied afterwards, bit for bit (same products, same order)
+    z = torch.randn(B * T, 2 * Cn, device="cuda")
+    lw = 1 + 0.1 * torch.randn(Cn, device="cuda")
+    m_, r_ = ops.layernorm_fwd(g[:, Cn:], lw, lw, 1e-12)[1:]
+    want = dg.clone()
+    _, gw_, gb_ = ops.layernorm_bwd(dgn, g[:, Cn:], m_, r_, lw, dx=want[:, Cn:])
+    ops.act_bwd_(want, z, "gelu")
+    got = torch.empty_like(dg)
+    dgn2, dw2, db2 = ops.dwconv_gate_bwd(du, gn, g[:, :Cn], conv, w.view(Cn, K), got[:, :Cn], B, T, zr=z[:, :Cn])
+    _, gw2, gb2 = ops.layernorm_bwd_act(dgn2, g[:, Cn:], m_, r_, lw, z[:, Cn:], "gelu", dx=got[:, Cn:])
+    assert torch.equal(dgn2, dgn) and torch.equal(dw2, dw) and torch.equal(db2, db)
+    assert torch.equal(gw2, gw_) and torch.equal(gb2, gb_)
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("B,T,Cn", [(2, 1, 1024), (1, 129, 1024), (3, 16, 512), (1, 257, 256)])
