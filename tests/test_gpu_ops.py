@@ -317,14 +317,19 @@ def test_conv2d_subsampling_pieces():
     _close(db, b1r.grad, 1e-4)
 
 
-def test_utterance_mvn():
+@pytest.mark.parametrize("B,T,F_", [(3, 50, 80), (32, 400, 80), (2, 3, 256), (2, 33, 4), (2, 50, 81), (3, 7, 30)])
+def test_utterance_mvn(B, T, F_):
+    """the 16-byte-column launch (F % 4 == 0: bench batch, one-float4 rows, 64 float4 columns, fewer rows than row groups) and
+    the scalar one (other F)"""
     from tavsr import ops
-    x = torch.randn(3, 50, 80, device="cuda")
-    lens = torch.tensor([50, 31, 7], device="cuda")
+    torch.manual_seed(T)
+    x = torch.randn(B, T, F_, device="cuda") + 3.0
+    lens = torch.tensor(([T, max(1, (2 * T) // 3), 1] + [T] * B)[:B], device="cuda")
     y = ops.utterance_mvn(x, lens)
     for b, l in enumerate(lens.tolist()):
         _close(y[b, :l], x[b, :l].double() - x[b, :l].double().mean(0, keepdim=True), 1e-5)
         assert (y[b, l:] == 0).all()
+    assert torch.equal(y, ops.utterance_mvn(x, lens))
 
 
 def test_ctc_loss_vs_torch():
