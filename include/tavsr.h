@@ -165,6 +165,9 @@ int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, float scale,
 /* out[i] (+)= sum_{p < nparts} part[p*stride + i], i < n */
 int tavsr_sum_partials(const float* part, int32_t nparts, int64_t stride, float* out, int32_t n,
                        int32_t accumulate, tavsr_stream_t stream);
+/* columns [0, n1) of the slab to out1, [n1, n1 + n2) to out2, one launch */
+int tavsr_sum_partials2(const float* part, int32_t nparts, int64_t stride, float* out1, int32_t n1, float* out2, int32_t n2,
+                        int32_t accumulate, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention glue (espnet attention.py: RelPositionMultiHeadedAttention.forward / rel_shift /

@@ -404,6 +404,17 @@ extern "C" int tavsr_add2_colsum(const float* x, int64_t ldx, const float* y, in
   return TAVSR_OK;
 }
 
+// ... a slab of n1 + n2 columns summed into two outputs by one launch (BatchNorm backward: dbeta | dgamma)
+extern "C" int tavsr_sum_partials2(const float* part, int32_t nparts, int64_t stride, float* out1, int32_t n1, float* out2,
+                                   int32_t n2, int32_t accumulate, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(part && out1 && out2 && n1 >= 0 && n2 >= 0, TAVSR_EINVAL, "sum_partials2: null pointer");
+  if (n1 + n2 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n1 + n2, 64)), dim3(kSumWaves * 64), 0, (hipStream_t)stream, part, nparts, stride,
+                     out1, out2, n1, n1 + n2, accumulate, 1.f);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
 // Generic "sum nparts slabs of n floats" (used by the host for per-block parameter-gradient partials).
 extern "C" int tavsr_sum_partials(const float* part, int32_t nparts, int64_t stride, float* out, int32_t n,
                                   int32_t accumulate, tavsr_stream_t stream) {

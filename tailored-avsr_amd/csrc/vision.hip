@@ -140,11 +140,21 @@ __global__ __launch_bounds__(1024) void bn_finalize2_kernel(const float* __restr
   const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int p = g; p < nparts; p += 16) {
+  if (c < C) {
+    int p = g;
+    for (; p + 48 < nparts; p += 64) {      // four loads of each stream in flight; the sums stay in partial order
+      const float a0 = part[((int64_t)p * 2 + 0) * C + c], a1 = part[((int64_t)(p + 16) * 2 + 0) * C + c];
+      const float a2 = part[((int64_t)(p + 32) * 2 + 0) * C + c], a3 = part[((int64_t)(p + 48) * 2 + 0) * C + c];
+      const float b0 = part[((int64_t)p * 2 + 1) * C + c], b1 = part[((int64_t)(p + 16) * 2 + 1) * C + c];
+      const float b2 = part[((int64_t)(p + 32) * 2 + 1) * C + c], b3 = part[((int64_t)(p + 48) * 2 + 1) * C + c];
+      a += (double)a0; a += (double)a1; a += (double)a2; a += (double)a3;
+      b += (double)b0; b += (double)b1; b += (double)b2; b += (double)b3;
+    }
+    for (; p < nparts; p += 16) {
       a += (double)part[((int64_t)p * 2 + 0) * C + c];
       b += (double)part[((int64_t)p * 2 + 1) * C + c];
     }
+  }
   red[g][0][cx] = a;
   red[g][1][cx] = b;
   __syncthreads();
@@ -618,9 +628,7 @@ extern "C" int tavsr_bn_bwd(const float* dy, const float* x, const float* mean, 
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), chunks), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta, res, dz, M,
                      C, rpb, act, ws);
   TAVSR_LAUNCH_CHECK();
-  int rc = tavsr_sum_partials(ws, chunks, (int64_t)2 * C, dbeta, C, 0, stream);
-  if (rc) return rc;
-  rc = tavsr_sum_partials(ws + C, chunks, (int64_t)2 * C, dgamma, C, 0, stream);
+  int rc = tavsr_sum_partials2(ws, chunks, (int64_t)2 * C, dbeta, C, dgamma, C, 0, stream);      // (dbeta | dgamma) slab, one launch
   if (rc) return rc;
   const int64_t total4 = M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1d(total4), dim3(256), 0, s, dz, x, mean, rstd, gamma, dgamma, dbeta, dx, C / 4,
@@ -647,9 +655,7 @@ extern "C" int tavsr_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const
   hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(cdiv(C, 64), chunks), dim3(256), 0, s, dpool, idx, x, mean, rstd, gamma, beta,
                      nblocks, H, W, Ho, Wo, C, bpw, act, ws);
   TAVSR_LAUNCH_CHECK();
-  int rc = tavsr_sum_partials(ws, chunks, (int64_t)2 * C, dbeta, C, 0, stream);
-  if (rc) return rc;
-  rc = tavsr_sum_partials(ws + C, chunks, (int64_t)2 * C, dgamma, C, 0, stream);
+  int rc = tavsr_sum_partials2(ws, chunks, (int64_t)2 * C, dbeta, C, dgamma, C, 0, stream);      // (dbeta | dgamma) slab, one launch
   if (rc) return rc;
   const int64_t total4 = nblocks * (C / 4);
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, grid1d(total4), dim3(256), 0, s, dpool, idx, x, mean, rstd, gamma, beta, dgamma, dbeta,
