@@ -410,7 +410,8 @@ int tavsr_dwconv_gate_bwd(const float* du, const float* gn, const float* r, int6
                           const float* w, float* dr, int64_t lddr, float* dgn, float* dw, float* dbias,
                           int32_t accumulate, float* ws, int32_t B, int32_t T, int32_t C, int32_t K,
                           tavsr_stream_t stream);
-/* ... for r = act(zr) (cgMLP: the left half of gelu(channel_proj1(x))): dr is written as the gradient w.r.t. zr, dr * act'(zr);
+/* ... for r = act(zr) (cgMLP: the left half of gelu(channel_proj1(x)), espnet cgmlp.py ConvolutionalGatingMLP.forward as called at
+ * src/encoder/branchformer/encoder_layer.py:220): dr is written as the gradient w.r.t. zr, dr * act'(zr);
  * kernel size 31 only.  With tavsr_layernorm_bwd_act on the gate half no activation-backward pass over the projection remains. */
 int tavsr_dwconv_gate_bwd_act(const float* du, const float* gn, const float* r, int64_t ldr, const float* conv, const float* w,
                               float* dr, int64_t lddr, float* dgn, float* dw, float* dbias, int32_t accumulate, float* ws,
