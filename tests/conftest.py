@@ -17,3 +17,26 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def _poison_device_memory(gib: float, value: float) -> None:
+    """Fill ``gib`` GiB of device memory with ``value`` and hand it back to torch's caching allocator: later ``torch.empty``
+    blocks then start out holding it, as they would on a box whose memory still holds another job's data."""
+    import torch
+    if not torch.cuda.is_available():
+        return
+    blocks = [torch.full((int(256 * 2**20 / 4),), value, device="cuda") for _ in range(int(gib * 4))]
+    blocks += [torch.full((n,), value, device="cuda") for n in (2**22, 2**20, 2**18, 2**16, 2**14, 2**12, 2**10, 256) for _ in range(64)]
+    torch.cuda.synchronize()
+    del blocks
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_allocator():
+    """TAVSR_POISON=nan|big: every GPU test starts with the allocator's cached blocks holding NaN / 3e38 - a kernel that reads
+    memory it (or its producer) never wrote, and uses the value, shows up as a parity failure instead of passing on zero-filled
+    fresh memory."""
+    mode = os.environ.get("TAVSR_POISON")
+    if mode:
+        _poison_device_memory(float(os.environ.get("TAVSR_POISON_GIB", "6")), float("nan") if mode == "nan" else 3.0e38)
+    yield
