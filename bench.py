@@ -10,7 +10,10 @@ its own batch of 32; ranks exchange gradients once per step (RCCL all-reduce, ta
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  box          - in-process calibration of THIS device before the model is built (fp32 MFMA microbench, HBM copy);
+  asr          - BASELINE configs[1] (the audio-only step) under the same protocol, so the driver's record holds it too;
+  fwd_encoder  - north_star's forward target (12-layer Branchformer forward, batch 32);
   roofline     - the dominant kernel (fp32 MFMA GEMM instantiation with the largest total time): algorithmic
                  FLOPs / HIP-event launch durations, measured in a separate instrumented replay of the same step;
   cpu_baseline - the oracle (CPU restatement, eager torch fp32) timed on this box's host cores on a bounded sample.
@@ -247,6 +250,109 @@ def bench_fwd_encoder(dev, steps=20, warmup=5):
     return res
 
 
+def box_calibration(dev):
+    """What THIS box delivers, measured in-process before any model exists (boxes of one pool differ by ~5 %, which is more
+    than a round's gain: without this a slower box cannot be told from a regression): (a) the fp32 matrix rate - every CU
+    issuing nothing but independent v_mfma_f32_32x32x2_f32 (tavsr_mfma_peak_f32, csrc/probe.hip), ~200 ms; (b) an HBM copy
+    (tavsr_axpby with a = 1: 1 GiB read + 1 GiB written per launch).  HIP events on the launch stream."""
+    import ctypes as C
+    from tavsr import ops
+    from tavsr._lib import check, lib, ptr, stream
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    sink = torch.zeros(1, device=dev)
+    blocks, iters = 2 * cus, 200000          # 8 waves per CU, ~50 ms per launch at the nominal peak
+
+    def mfma():
+        check(lib().tavsr_mfma_peak_f32(iters, blocks, ptr(sink), stream()), "tavsr_mfma_peak_f32")
+
+    def timed(fn, n):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / n
+
+    t_m = timed(mfma, 4)
+    tf = blocks * 4 * iters * 4 * 4096.0 / t_m / 1e12
+    n = 1 << 28
+    x, y = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    ops.fill_(x, 1.0)
+    t_c = timed(lambda: ops.axpby(x, None, 1.0, 0.0, out=y), 20)
+    del x, y
+    torch.cuda.empty_cache()
+    return {"device": torch.cuda.get_device_name(dev), "cus": cus,
+            "fp32_mfma_tflops": round(tf, 1), "fp32_mfma_frac_of_nominal": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+            "mfma_ms_per_launch": round(1e3 * t_m, 2),
+            "hbm_copy_gb_per_s": round(2 * 4 * n / t_c / 1e9, 1),
+            "note": "in-process calibration before the model is built: back-to-back v_mfma_f32_32x32x2_f32 on every CU "
+                    "(8 waves/CU, 4 independent accumulator tiles per wave, ~0.2 s) and a 1 GiB -> 1 GiB copy kernel"}
+
+
+def bench_asr_step(dev, steps=20, warmup=5):
+    """BASELINE configs[1] (audio-only 12-layer Branchformer + Conv2dSubsampling + CTC + 6L decoder, batch 32 x 4 s, fwd+bwd,
+    recipe dropout) under the headline's protocol - whole step captured as one hipGraph, W warm-up replays, K timed ones
+    bracketed by synchronisation - so that the driver's record carries the audio-only step too; plus a few eager steps."""
+    global WORKLOAD
+    from tavsr import ops
+    saved, WORKLOAD = WORKLOAD, "asr"
+    try:
+        torch.manual_seed(0)
+        model = build_product_model().to(dev).train()
+        batch = make_batch(B_PER_GPU, 1234, dev)
+    finally:
+        WORKLOAD = saved
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        loss = model(*batch)[0]
+        loss.backward()
+        return loss
+
+    def run(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    for _ in range(3):
+        fwd_bwd()
+    t_eager = run(fwd_bwd, 5)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = fwd_bwd()      # noqa: F841
+    run(graph.replay, warmup)
+    t = run(graph.replay, steps)
+    t_sus = run(graph.replay, max(steps, int(2.0 / t)))       # ~2 s more, back to back
+    gf = GFLOP_PER_UTT_STEP["asr"]
+    out = {"workload": "BASELINE configs[1]: audio-only 12-layer Branchformer d=256 + Conv2dSubsampling + CTC + 6L Transformer "
+                       "decoder, batch 32 x 400 mel frames x 80, text length 40, fwd+bwd, dropout 0.1, hipGraph replay",
+           "value": round(B_PER_GPU / t, 2), "unit": "utterances/s", "ms_per_step": round(1e3 * t, 3), "steps": steps, "warmup": warmup,
+           "sustained": round(B_PER_GPU / t_sus, 2),
+           "eager": {"value": round(B_PER_GPU / t_eager, 2), "ms_per_step": round(1e3 * t_eager, 3), "steps": 5},
+           "gflop_per_utt_step": round(gf, 2),
+           "frac_of_fp32_mfma_peak_whole_step": round(B_PER_GPU / t * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    del graph, static_loss, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +370,8 @@ def main():
                          "measurement (north_star's >= 50 %% MFMA target), printed as its own JSON line (profiling runs)")
     ap.add_argument("--no-fwd-encoder", action="store_true", help="skip the fwd_encoder object of the default run")
     ap.add_argument("--no-eager", action="store_true", help="skip the eager (no-graph) timing beside the graph number")
+    ap.add_argument("--no-asr", action="store_true", help="skip the `asr` object (BASELINE configs[1] step) of the default AV run")
+    ap.add_argument("--no-box", action="store_true", help="skip the `box` calibration object (fp32 MFMA microbench, HBM copy)")
     ap.add_argument("--workload", choices=("asr", "avsr"), default="avsr",
                     help="asr: BASELINE configs[1] (headline); avsr: configs[2] tailored AV-Branchformer incl. the visual frontend")
     ap.add_argument("--sustain-s", type=float, default=12.0,
@@ -305,6 +413,9 @@ def main():
                               "fwd_encoder": bench_fwd_encoder(dev, args.steps, args.warmup)}), flush=True)
         return
 
+    box = box_calibration(dev) if (rank == 0 and not args.no_box) else None      # before the model exists: the box, not the code
+    if world > 1:
+        torch.distributed.barrier()
     torch.manual_seed(0)
     model = build_product_model().to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
@@ -551,6 +662,10 @@ def main():
         model = None
         torch.cuda.empty_cache()
         out["fwd_encoder"] = bench_fwd_encoder(dev)
+        if WORKLOAD == "avsr" and not args.no_asr:
+            out["asr"] = bench_asr_step(dev)
+    if box is not None:
+        out["box"] = box
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

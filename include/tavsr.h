@@ -33,6 +33,18 @@ enum { TAVSR_ACT_NONE = 0, TAVSR_ACT_RELU = 1, TAVSR_ACT_SWISH = 2, TAVSR_ACT_GE
 int tavsr_version(void);                     /* ABI version, bumped on any signature change */
 const char* tavsr_last_error_string(void);   /* host string, thread-local */
 
+/* Stream-plumbing test hooks (csrc/probe.hip).  The reference runs its whole step on ONE queue
+ * (src/models/espnet_model.py:258-356 on torch's current stream); this library's callers spread a step over forked queues,
+ * and results must not depend on that.  tavsr_spin occupies `stream` for `us` microseconds (one idle wave), tavsr_race_probe
+ * arms the same delay inside the entry points that fork a second queue themselves (tavsr_branchformer_layer_fwd):
+ * mode 0 = head of the forked section, 1 = behind the join on the calling queue, 2 = alternately per call; us = 0 disarms. */
+int tavsr_spin(float us, tavsr_stream_t stream);
+int tavsr_race_probe(float us, int mode);
+/* Box calibration for bench.py's `box` object: `blocks` workgroups of 4 waves, each wave issuing 4 * iters independent
+ * v_mfma_f32_32x32x2_f32 (4096 FLOP each) and nothing else - the fp32 matrix rate this device holds, against which a 5 %
+ * difference between two boxes of a pool can be told from a regression.  `sink`: one device word (never written). */
+int tavsr_mfma_peak_f32(int32_t iters, int32_t blocks, float* sink, tavsr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GEMM (fp32 MFMA, v_mfma_f32_32x32x2_f32).  Replaces torch.nn.Linear / torch.matmul wherever the
  * reference's leaves call them: PositionwiseFeedForward.w_1/w_2 (encoder_layer.py:193-194,313-314),
@@ -456,6 +468,19 @@ int tavsr_merge_rows_bwd(const float* dm, const float* x1, const float* x2, cons
                          float* dx2, float* const* dparams, int32_t accumulate, float* ws, float p_drop1, uint64_t offset1,
                          float p_drop2, uint64_t offset2, const uint64_t* seed_dev, int32_t B, int32_t T, int32_t D,
                          tavsr_stream_t stream);
+/* The whole tail of a Branchformer layer behind the branch join in ONE launch (csrc/mergeproj.hip, D = 256, T <= 2048:
+ * tavsr_merge_proj_ok): the learned_ave merge above AND  out = res + alpha * dropout(mix W^T + bias)  with mix the merged
+ * rows (encoder_layer.py:232-300: pooling, weight softmax, weighted sum, merge_proj, dropout, residual).  One workgroup per 16
+ * frames of an utterance: it recomputes the utterance's row dots itself (no dots launch to wait for), forms its mixed rows and
+ * multiplies them by W [256][256] (torch layout) on v_mfma_f32_16x16x4_f32.  dots [4][B*T], score [2][B][T] and w [B][2] are what
+ * tavsr_merge_rows_bwd reads back; mix [B*T][256] (may be NULL: passes without a backward) is merge_proj's saved input.  The
+ * dropout mask is the one tavsr_gemm draws for a [B*T][256] result at drop_offset (drop_offset % 4 == 0), so the
+ * backward pass regenerates it from the same token. */
+int tavsr_merge_proj_ok(int32_t T, int32_t D);
+int tavsr_merge_proj_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2, const float* const* params,
+                         const float* w, const float* bias, const float* res, float alpha, float p_drop, const uint64_t* seed_dev,
+                         uint64_t drop_offset, float* dots, float* score, float* wout, float* mix, float* out, int32_t B, int32_t T,
+                         int32_t D, tavsr_stream_t stream);
 int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D);
 int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
                     const float* const* params, const float* score, const float* pooled, const float* w,

@@ -79,6 +79,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+int probe_fork(hipStream_t forked, hipStream_t caller, bool at_join);   // probe.hip: race amplifier at C-side forks / joins
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace tavsr

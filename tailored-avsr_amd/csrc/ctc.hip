@@ -441,9 +441,17 @@ extern "C" int tavsr_embed_bwd(const int64_t* ids, const float* dout, float scal
                                int32_t D, int32_t accumulate, tavsr_stream_t stream) {
   TAVSR_REQUIRE(ids && dout && dtable, TAVSR_EINVAL, "embed_bwd: null pointer");
   if (V <= 0) return TAVSR_OK;
-  TAVSR_REQUIRE(N >= 0 && N <= 15000, TAVSR_EUNSUPPORTED, "embed_bwd: at most 15000 tokens per call (N=%lld)", (long long)N);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), (size_t)(N > 0 ? N : 1) * sizeof(int), (hipStream_t)stream, ids, dout, scale,
-                     dtable, N, D, accumulate);
-  TAVSR_LAUNCH_CHECK();
+  TAVSR_REQUIRE(N >= 0, TAVSR_EINVAL, "embed_bwd: N < 0");
+  // the kernel keeps a launch's token ids in LDS: longer batches go through in chunks of 15000 tokens that accumulate
+  // into dtable (chunk by chunk in token order: deterministic; one rounding per chunk instead of one per call)
+  constexpr int64_t kChunk = 15000;
+  int64_t done = 0;
+  do {
+    const int64_t n = N - done < kChunk ? N - done : kChunk;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), (size_t)(n > 0 ? n : 1) * sizeof(int), (hipStream_t)stream, ids + done,
+                       dout + done * D, scale, dtable, n, D, (done > 0 || accumulate) ? 1 : 0);
+    TAVSR_LAUNCH_CHECK();
+    done += n;
+  } while (done < N);
   return TAVSR_OK;
 }

@@ -24,9 +24,13 @@ struct Bump {           // workspace carving (two queues run side by side: every
   float* base;
   int64_t cap, used;
   bool dry;
+  bool overflow = false;
+  // dry run: sizes only, but a non-null sentinel so that descriptors which switch on "is this pointer given" (rowstat)
+  // plan the same launches as the real pass; real pass: never past the caller's capacity
   float* take(int64_t n) {
     n = (n + 63) / 64 * 64;
-    float* p = dry ? nullptr : base + used;
+    float* p = dry ? reinterpret_cast<float*>(uintptr_t(64)) : base + used;
+    if (!dry && used + n > cap) { overflow = true; p = nullptr; }
     used += n;
     return p;
   }
@@ -46,7 +50,9 @@ tavsr_gemm_desc lin(int M, int N, int K, const float* x, int64_t ldx, const floa
 int run_gemm(tavsr_gemm_desc& g, Bump& ws, hipStream_t s) {
   const int64_t need = tavsr_gemm_ws(&g);
   if (need > 0) { g.ws = ws.take(need); g.ws_floats = need; }
-  return ws.dry ? TAVSR_OK : tavsr_gemm(&g, (tavsr_stream_t)s);
+  if (ws.dry) return TAVSR_OK;
+  TAVSR_REQUIRE(!ws.overflow, TAVSR_EINVAL, "branchformer_layer_fwd: workspace too small for a GEMM's split-K slabs");
+  return tavsr_gemm(&g, (tavsr_stream_t)s);
 }
 
 tavsr_ffn_desc ffn(const tavsr_bf_layer_desc* d, const float* x, const float* ln_w, const float* ln_b, const float* w1,
@@ -79,12 +85,14 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
     if (d->save) { f.ln2_mean = d->br_mean; f.ln2_rstd = d->br_rstd; }
     f.ws_floats = tavsr_ffn2_ws(M, D, d->ffn_units);
     f.ws = ws.take(f.ws_floats);
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_fwd: workspace too small");
     if (!dry && (rc = tavsr_ffn2_fwd(&f, (tavsr_stream_t)s))) return rc;
   }
-  // ---- attention branch on the second queue
+  // ---- attention branch on the second queue (stream2 == stream: one queue, the events order nothing new)
   if (!dry) {
     TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_fork, s));
     TAVSR_HIP_CHECK(hipStreamWaitEvent(s2, (hipEvent_t)d->ev_fork, 0));
+    if ((rc = probe_fork(s2, s, false))) return rc;
     tavsr_gemm_desc q3[3] = {lin(M, D, D, d->n_mha, D, d->wq, d->bq, d->qkv, 3 * D),
                              lin(M, D, D, d->n_mha, D, d->wk, d->bk, d->qkv + D, 3 * D),
                              lin(M, D, D, d->n_mha, D, d->wv, d->bv, d->qkv + 2 * D, 3 * D)};
@@ -117,6 +125,7 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
     if (d->save) g1.Z = d->g_z;
     // the GEMM's epilogue leaves per-row partial sums of its 64-column tiles: the CSGU's LayerNorm statistics without a launch
     float* rowstat = Cn <= 1024 ? ws.take((int64_t)M * (C2 / 64) * 2) : nullptr;
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_fwd: workspace too small");
     g1.rowstat = rowstat;
     if ((rc = run_gemm(g1, ws, s))) return rc;
     if (!dry && (rc = tavsr_csgu_fwd(d->g, C2, d->csgu_ln_w, d->csgu_ln_b, 1e-12f, d->csgu_cw, d->csgu_cb, d->u, d->save ? d->gn : nullptr,
@@ -130,16 +139,13 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
   if (!dry) {
     TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_join, s2));
     TAVSR_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)d->ev_join, 0));
-    // ---- learned-average merge, row-parallel form: d->pooled receives the row dots [4][B*T] (what its backward reads)
-    if ((rc = tavsr_merge_rows_fwd(d->xa, d->xm, d->lens, nullptr, d->merge_p, d->pooled, d->score, d->wts, d->m, d->B, d->T, D,
-                                   (tavsr_stream_t)s)))
+    if ((rc = probe_fork(s2, s, true))) return rc;
+    // ---- the tail behind the join as one launch: learned-average merge (d->pooled receives the row dots [4][B*T] its backward
+    //      reads), x2 = x1 + coeff dropout(merge_proj(m))
+    if ((rc = tavsr_merge_proj_fwd(d->xa, d->xm, d->lens, nullptr, d->merge_p, d->merge_w, d->merge_b, d->x1, d->coeff, d->p_drop,
+                                   d->seed, d->drop_off[6], d->pooled, d->score, d->wts, d->save ? d->m : nullptr, d->x2, d->B, d->T,
+                                   D, (tavsr_stream_t)s)))
       return rc;
-  }
-  {
-    tavsr_gemm_desc gm = lin(M, D, D, d->m, D, d->merge_w, d->merge_b, d->x2, D);       // x2 = x1 + coeff dropout(merge_proj(m))
-    gm.alpha = d->coeff; gm.R = d->x1; gm.ldr = D;
-    gm.drop_p = d->p_drop; gm.drop_seed = d->seed; gm.drop_offset = d->drop_off[6];
-    if ((rc = run_gemm(gm, ws, s))) return rc;
   }
   // ---- x3 = x2 + 0.5 dropout(ffn(norm_ff(x2))); y = norm_final(x3)
   {
@@ -149,6 +155,7 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
     if (d->save) { f.ln2_mean = d->fin_mean; f.ln2_rstd = d->fin_rstd; }
     f.ws_floats = tavsr_ffn2_ws(M, D, d->ffn_units);
     f.ws = ws.take(f.ws_floats);
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_fwd: workspace too small");
     if (!dry && (rc = tavsr_ffn2_fwd(&f, (tavsr_stream_t)s))) return rc;
   }
   return TAVSR_OK;
@@ -157,7 +164,7 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
 int supported(const tavsr_bf_layer_desc* d, const char* who) {
   TAVSR_REQUIRE(d, TAVSR_EINVAL, "%s: null descriptor", who);
   TAVSR_REQUIRE(d->B > 0 && d->T > 0 && d->D == 256 && d->H > 0 && d->D / d->H == 64 && d->ffn_units >= 1024 &&
-                    d->ffn_units % 32 == 0 && d->cg_units % 128 == 0 && d->cg_kernel == 31 && tavsr_merge_rows_ok(d->T, d->D),
+                    d->ffn_units % 32 == 0 && d->cg_units % 128 == 0 && d->cg_kernel == 31 && tavsr_merge_proj_ok(d->T, d->D),
                 TAVSR_EUNSUPPORTED, "%s: d_model 256, 64-wide heads, hidden >= 1024, cgMLP kernel 31, T <= 2048 only", who);
   return TAVSR_OK;
 }
@@ -166,7 +173,7 @@ int supported(const tavsr_bf_layer_desc* d, const char* who) {
 
 extern "C" int64_t tavsr_branchformer_layer_ws(const tavsr_bf_layer_desc* d) {
   if (supported(d, "branchformer_layer_ws")) return 0;
-  Bump ws{nullptr, 0, 0, true};
+  Bump ws{nullptr, 0, 0, true, false};
   if (sequence(d, nullptr, ws)) return 0;
   return ws.used;
 }
@@ -176,15 +183,15 @@ extern "C" int tavsr_branchformer_layer_fwd(const tavsr_bf_layer_desc* d, tavsr_
   if (rc) return rc;
   TAVSR_REQUIRE(d->x && d->pos_emb && d->x1 && d->n_mha && d->n_mlp && d->qkv && d->pp && d->cx && d->lse && d->xa && d->g && d->u &&
                     d->xm && d->g_mean && d->g_rstd && d->score && d->pooled && d->wts && d->m && d->x2 && d->x3 && d->y && d->ws &&
-                    d->stream2 && d->ev_fork && d->ev_join,
+                    d->ev_fork && d->ev_join,      // (stream2 may be the null stream: a caller that runs one queue)
                 TAVSR_EINVAL, "branchformer_layer_fwd: null buffer");
   TAVSR_REQUIRE(!d->save || (d->ffm_n && d->ffm_mean && d->ffm_rstd && d->ffm_z && d->ffm_h && d->br_mean && d->br_rstd && d->g_z && d->gn &&
                              d->conv && d->ff_n && d->ff_mean && d->ff_rstd && d->ff_z && d->ff_h && d->fin_mean && d->fin_rstd),
                 TAVSR_EINVAL, "branchformer_layer_fwd: save = 1 needs every saved buffer");
   TAVSR_REQUIRE((d->p_drop == 0.f && d->p_att == 0.f) || d->seed, TAVSR_EINVAL, "branchformer_layer_fwd: dropout needs a device seed");
-  Bump ws{d->ws, d->ws_floats, 0, false};
+  Bump ws{d->ws, d->ws_floats, 0, false, false};
   {
-    Bump dryrun{nullptr, 0, 0, true};
+    Bump dryrun{nullptr, 0, 0, true, false};
     if ((rc = sequence(d, nullptr, dryrun))) return rc;
     TAVSR_REQUIRE(dryrun.used <= d->ws_floats, TAVSR_EINVAL, "branchformer_layer_fwd: workspace too small (tavsr_branchformer_layer_ws)");
   }

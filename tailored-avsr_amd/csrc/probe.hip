@@ -1,0 +1,72 @@
+// Test instrumentation of the stream plumbing (no product path calls these with a non-zero time):
+//   tavsr_spin(us, stream)      one wave that polls the 100 MHz wall clock for `us` microseconds - a launch that does nothing but
+//                               occupy its queue, so that a missing dependency between two queues becomes deterministic;
+//   tavsr_race_probe(us, mode)  arms the same delay inside the C-side sequencers that fork a second queue themselves
+//                               (tavsr_branchformer_layer_fwd): mode 0 = head of the forked section, 1 = behind the join on the
+//                               calling queue, 2 = alternately per call.  tavsr/ops.py (TAVSR_RACE_PROBE) drives both.
+// The reference is single-queue (src/models/espnet_model.py:258-356 runs on torch's current stream): results must not depend on
+// how the launches of one step are spread over queues; tests/test_gpu_streams.py holds that.
+#include "common.h"
+
+namespace tavsr {
+
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+static float g_probe_us = 0.f;
+static int g_probe_mode = 2;
+static unsigned g_probe_tick = 0;
+
+int probe_fork(hipStream_t forked, hipStream_t caller, bool at_join) {
+  if (g_probe_us <= 0.f) return TAVSR_OK;
+  if (!at_join) ++g_probe_tick;
+  const int mode = g_probe_mode == 2 ? (int)(g_probe_tick & 1u) : g_probe_mode;
+  if (mode == (at_join ? 1 : 0)) return tavsr_spin(g_probe_us, (tavsr_stream_t)(at_join ? caller : forked));
+  return TAVSR_OK;
+}
+
+}  // namespace tavsr
+
+extern "C" int tavsr_spin(float us, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(us >= 0.f && us <= 1e6f, TAVSR_EINVAL, "spin: 0 .. 1e6 microseconds");
+  if (us == 0.f) return TAVSR_OK;
+  hipLaunchKernelGGL(tavsr::spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(us * 100.0));
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_race_probe(float us, int mode) {
+  TAVSR_REQUIRE(us >= 0.f && us <= 1e6f && mode >= 0 && mode <= 2, TAVSR_EINVAL, "race_probe: us in 0 .. 1e6, mode 0 / 1 / 2");
+  tavsr::g_probe_us = us;
+  tavsr::g_probe_mode = mode;
+  return TAVSR_OK;
+}
+
+// Box calibration (bench.py `box` object): what THIS device delivers on the one fp32 matrix instruction every GEMM of the
+// path issues, with nothing else in the way - 4 independent accumulator tiles per wave, 8 waves per CU, no memory traffic.
+// FLOPs = blocks x 4 waves x iters x 4 MFMAs x 4096.
+namespace tavsr {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) {
+  f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+  float x = 1.0f + 1e-9f * threadIdx.x, y = 1.0f - 1e-9f * threadIdx.x;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+  }
+  const float s = a0[0] + a1[1] + a2[2] + a3[3];
+  if (s == 12345.678f) sink[0] = s;      // (never true: keeps the loop alive)
+}
+}  // namespace tavsr
+
+extern "C" int tavsr_mfma_peak_f32(int32_t iters, int32_t blocks, float* sink, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(iters > 0 && blocks > 0 && blocks <= 65536 && sink, TAVSR_EINVAL, "mfma_peak_f32: iters, blocks > 0 and a sink word");
+  hipLaunchKernelGGL(tavsr::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}

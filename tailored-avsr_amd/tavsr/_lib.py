@@ -130,6 +130,9 @@ def lib() -> C.CDLL:
         _lib.tavsr_last_error_string.restype = C.c_char_p
         _lib.tavsr_version.restype = C.c_int
         _lib.tavsr_gemm_ws.restype = C.c_int64
+        us = float(os.environ.get("TAVSR_RACE_PROBE", "0") or 0)
+        if us > 0:      # race amplifier of the C-side sequencers (tests; ops.py arms the Python-side scopes from the same variables)
+            _lib.tavsr_race_probe(C.c_float(us), {"body": 0, "join": 1, "alt": 2}[os.environ.get("TAVSR_RACE_PROBE_MODE", "alt")])
     return _lib
 
 
@@ -150,8 +153,96 @@ def stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---------------------------------------------------------------------------------------------- stream safety
+# The package runs independent sections on forked HIP streams (ops.BranchScope; autograd replays a node on the stream its
+# forward ran on).  Two rules make that safe against torch's per-stream caching allocator, and both are enforced HERE, at the
+# one place where a tensor becomes a raw pointer, instead of by hand at the fork sites:
+#   1. a tensor handed to a launch on a forked stream is ``record_stream``-ed on it (a no-op for tensors of that stream's own
+#      pool): the allocator will not hand its block to anybody before the forked stream has passed the point of the free;
+#   2. a forked stream never starts work without first waiting for the stream that owns it (``BranchScope.__enter__``,
+#      ``enter_node`` at the head of every autograd backward): blocks of the forked stream's pool are only re-used behind
+#      every reader the owning stream had enqueued when they were freed.
+# ``tests/test_host_api.py`` checks that no module takes ``.data_ptr()`` behind this file's back.
+_FORKED = {}          # raw handle -> (torch.cuda.Stream forked, torch.cuda.Stream owner)
+_CUR_FORK = None      # the forked stream launches currently go to (None: an owning / main stream), kept by the scopes below
+_CUR_SEEN = None      # addresses already recorded in the innermost scope (a scope re-reads its operands many times)
+SINGLE_STREAM = os.environ.get("TAVSR_SINGLE_STREAM", "0") == "1"      # every fork disabled: one queue, as the reference
+
+
+def register_fork(forked: "torch.cuda.Stream", owner: "torch.cuda.Stream") -> None:
+    _FORKED[forked.cuda_stream] = (forked, owner)
+
+
+def _note(t) -> None:
+    """rule 1 for one tensor (parameters and other step-persistent tensors are never freed inside a step: skipped)"""
+    if isinstance(t, torch.nn.Parameter):
+        return
+    a = t.data_ptr()
+    if _CUR_SEEN is not None:
+        if a in _CUR_SEEN:
+            return
+        _CUR_SEEN.add(a)
+    t.record_stream(_CUR_FORK)
+
+
+def push_fork(forked) -> tuple:
+    """launches go to ``forked`` from here (ops.BranchScope); returns the state ``pop_fork`` restores"""
+    global _CUR_FORK, _CUR_SEEN
+    prev = (_CUR_FORK, _CUR_SEEN)
+    _CUR_FORK, _CUR_SEEN = forked, set()
+    return prev
+
+
+def pop_fork(prev: tuple) -> None:
+    global _CUR_FORK, _CUR_SEEN
+    _CUR_FORK, _CUR_SEEN = prev
+
+
+def enter_node() -> tuple:
+    """head of an autograd node's backward: autograd runs the node on the stream its forward ran on.  If that is a forked
+    stream and no scope put us there, apply rule 2 (wait for the owner) and switch rule 1 on for the node's launches."""
+    global _CUR_FORK, _CUR_SEEN
+    prev = (_CUR_FORK, _CUR_SEEN)
+    if _FORKED:
+        ent = _FORKED.get(_raw_stream(torch.cuda.current_device()) if _raw_stream is not None
+                          else torch.cuda.current_stream().cuda_stream)
+        if ent is None:
+            _CUR_FORK = _CUR_SEEN = None
+        elif _CUR_FORK is not ent[0]:
+            ent[0].wait_stream(ent[1])
+            _CUR_FORK, _CUR_SEEN = ent[0], set()
+    return prev
+
+
+def guarded(fn):
+    """decorator of every ``torch.autograd.Function.backward`` of the package (see enter_node)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args):
+        prev = enter_node()
+        try:
+            return fn(*args)
+        finally:
+            pop_fork(prev)
+    return wrapper
+
+
 def ptr(t) -> C.c_void_p:
-    return C.c_void_p(0 if t is None else t.data_ptr())
+    if t is None:
+        return C.c_void_p(0)
+    if _CUR_FORK is not None:
+        _note(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def addr(t, off: int = 0):
+    """``ptr`` as a plain integer (descriptor fields), ``off`` in 4-byte elements; None stays None"""
+    if t is None:
+        return None
+    if _CUR_FORK is not None:
+        _note(t)
+    return t.data_ptr() + 4 * off
 
 
 def cached_params(module, names):

@@ -18,6 +18,8 @@ from typing import Iterable, List
 import torch
 import torch.distributed as dist
 
+from ._lib import addr as L_addr, ptr as L_ptr
+
 RCCL_ABI = False          # set by init_from_env once tavsr_dp_init has succeeded on this rank
 
 
@@ -146,7 +148,9 @@ class GradBuckets:
     def _reset_plan_state(self):
         self._flat = [None] * len(self.buckets)
         self._tab, self._flatbuf = {}, {}
-        self._comm = None
+        self._hostbuf = {}                      # (pinned staging of the gloo rehearsal rig: sized per bucket of the OLD plan)
+        self._hook_streams = {}
+        self._comm = getattr(self, "_comm", None)      # the communication stream outlives a re-plan
         self._works = [None] * len(self.buckets)
         self._pending = [len(b) for b in self.buckets]
         self._next = 0            # buckets 0 .. _next-1 have been enqueued in this window (ALWAYS in index order)
@@ -179,6 +183,7 @@ class GradBuckets:
                 torch.cuda.current_stream().wait_stream(self._comm)
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
+        self._hook_streams = {}
         self._armed = dist.is_initialized() and dist.get_world_size() > 1
 
     def broadcast_parameters(self, src: int = 0) -> None:
@@ -188,7 +193,7 @@ class GradBuckets:
             flat = torch.cat([p.data.reshape(-1) for p in bucket])
             if RCCL_ABI and flat.is_cuda:
                 from ._lib import check, lib
-                check(lib().tavsr_dp_broadcast(C.c_void_p(flat.data_ptr()), C.c_int64(flat.numel()), src,
+                check(lib().tavsr_dp_broadcast(L_ptr(flat), C.c_int64(flat.numel()), src,
                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tavsr_dp_broadcast")
             else:
                 dist.broadcast(flat, src)
@@ -237,7 +242,7 @@ class GradBuckets:
     def _tables(self, i, bucket):
         """device pointer / offset / size tables of bucket i; rebuilt only when a gradient tensor moved (under hipGraph
         replay the gradients are graph-owned buffers: the tables are built once)."""
-        ptrs = [p.grad.data_ptr() for p in bucket]
+        ptrs = [L_addr(p.grad) for p in bucket]
         cached = self._tab.get(i)
         if cached is not None and cached[0] == ptrs:
             return cached[1:]
@@ -261,6 +266,9 @@ class GradBuckets:
 
     # ---- GPU path: pack (one launch per bucket) -> all-reduce on the communication stream -> unpack * 1/world
     def _comm_stream(self):
+        from . import _lib
+        if _lib.SINGLE_STREAM:                  # one queue: the exchange follows the backward pass on the calling stream
+            return torch.cuda.current_stream()
         if self._comm is None:
             self._comm = torch.cuda.Stream()
         return self._comm
@@ -271,6 +279,13 @@ class GradBuckets:
         from ._lib import check, lib
         bucket = self.buckets[i]
         ptrs, offs, sizes, flat, mx = self._tables(i, bucket)
+        # gradients are accumulated on the stream of their node (autograd replays a node on its forward stream: the CTC branch's
+        # ctc_lo lives on a forked one), and the hook that completes a bucket may itself run there: the pack is enqueued on the
+        # current stream behind EVERY stream a hook of this window has fired on
+        cur = torch.cuda.current_stream()
+        for h, st in self._hook_streams.items():
+            if h != cur.cuda_stream:
+                cur.wait_stream(st)
         ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0, True, mx)
         self._issue_flat(i, flat)
 
@@ -279,7 +294,7 @@ class GradBuckets:
         if RCCL_ABI:
             comm = self._comm_stream()
             comm.wait_stream(torch.cuda.current_stream())
-            check(lib().tavsr_dp_allreduce(C.c_void_p(flat.data_ptr()), C.c_int64(flat.numel()), C.c_void_p(comm.cuda_stream)),
+            check(lib().tavsr_dp_allreduce(L_ptr(flat), C.c_int64(flat.numel()), C.c_void_p(comm.cuda_stream)),
                   "tavsr_dp_allreduce")
             self._works[i] = "rccl"
         elif dist.get_backend() == "gloo" and GLOO_HOST_STAGED:
@@ -295,7 +310,6 @@ class GradBuckets:
         import concurrent.futures
         if getattr(self, "_pool", None) is None:
             self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
-            self._hostbuf = {}
         host = self._hostbuf.get(i)
         if host is None:
             host = self._hostbuf[i] = torch.empty(flat.numel(), dtype=flat.dtype, pin_memory=True)
@@ -385,6 +399,9 @@ class GradBuckets:
             if not (self.overlap and self._armed):
                 return
             i = index[id(p)]
+            if p.is_cuda:
+                st = torch.cuda.current_stream()
+                self._hook_streams.setdefault(st.cuda_stream, st)
             self._pending[i] -= 1               # (a second backward pass inside one window drives this below 0: no launch)
             while self._next < len(self.buckets) and self._pending[self._next] == 0:
                 (self._launch_bucket if p.is_cuda else self._launch_bucket_cpu)(self._next)
@@ -441,8 +458,10 @@ class TwoPhaseBackward:
         two.phase_a(loss)                           loss.backward(): everything above the cut (ends at the detached leaves)
         two.phase_b()                               continues below the cut from the leaves' gradients
 
-    Same gradients as one ``loss.backward()``: every node runs once, in one of the two calls; a parameter used on both sides of
-    the cut accumulates both contributions in ``.grad`` (and counts as late).  ``late_params(params)`` after a forward pass:
+    Same gradients as one ``loss.backward()`` PROVIDED the cut tensors are the only connection between the two halves: every node
+    then runs once, in one of the two calls (``phase_a`` refuses a loss that reaches the lower half some other way, e.g. through an
+    intermediate-CTC tap below the cut); a parameter used on both sides of the cut accumulates both contributions in ``.grad``
+    and counts as late (its hook fires once per phase: ``late_params`` puts it in a late bucket, which no hook completes early).  ``late_params(params)`` after a forward pass:
     the parameters the graph below the cut reaches - the buckets that hold none of them are complete after ``phase_a``."""
 
     def __init__(self):
@@ -471,7 +490,26 @@ class TwoPhaseBackward:
         below = _params_below([t for t, _ in self.pairs])
         return [p for p in params if id(p) in below]
 
+    def bypassed(self, loss) -> bool:
+        """does the graph under ``loss`` reach a node below the cut WITHOUT passing a detached leaf (an intermediate-CTC tap of
+        a layer below the cut, a parameter-sharing path)?  Then ``phase_a`` would already walk - and free - part of the lower
+        graph and ``phase_b`` would run those nodes a second time: such a step must not be split."""
+        below = {t.grad_fn for t, _ in self.pairs if t.grad_fn is not None}
+        seen, stack = set(), [loss.grad_fn] if loss.grad_fn is not None else []
+        while stack:
+            fn = stack.pop()
+            if fn in seen:
+                continue
+            if fn in below:
+                return True
+            seen.add(fn)
+            stack.extend(n for n, _ in fn.next_functions if n is not None)
+        return False
+
     def phase_a(self, loss) -> None:
+        if self.pairs and self.bypassed(loss):
+            raise RuntimeError("TwoPhaseBackward: the loss reaches the graph below dp.cut() without passing the cut (an intermediate "
+                               "CTC layer below it?): run this step as one backward pass (bench.py --no-split-backward)")
         loss.backward()
 
     def phase_b(self) -> None:

@@ -19,6 +19,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
+from ._lib import guarded
 
 EPS_ESPNET = 1e-12  # espnet LayerNorm eps
 
@@ -286,7 +287,7 @@ def _layer_c_ok(x, cfg, P, pd, pos_emb=None) -> bool:
     if ops.LAYER_C_EAGER_ONLY and torch.cuda.is_current_stream_capturing():
         return False
     return (ops.LAYER_C and cfg["has_attn"] and cfg["has_mlp"] and cfg["merge"] == "learned_ave" and not cfg["merge_identity"]
-            and ops.ATTN_FUSED and ops.FFN2 and ops.CSGU_FUSED and ops.merge_rows_ok(T, D) and ops.BRANCH_SIDE_STREAM and not ops.LIN2 and ops.PROFILE is None
+            and ops.ATTN_FUSED and ops.FFN2 and ops.CSGU_FUSED and ops.merge_rows_ok(T, D) and ops.MERGE_PROJ and not ops.LIN2 and ops.PROFILE is None
             and D == 256 and D // cfg["heads"] == 64 and cw is not None and cw.shape[-1] == 31 and (2 * cw.shape[0]) % 128 == 0
             and P[_I["feed_forward.w_1.weight"]].shape[0] >= 1024 and P[_I["feed_forward.w_1.weight"]].shape[0] % 32 == 0
             and P[_I["feed_forward_macaron.w_1.weight"]].shape == P[_I["feed_forward.w_1.weight"]].shape
@@ -314,7 +315,7 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
     d.B, d.T, d.D, d.H, d.ffn_units, d.cg_units, d.cg_kernel = B, T, D, H, N1, C2, 31
     d.ffn_act, d.save = ops.ACT[cfg["ffn_act"]], int(need)
     d.p_drop, d.p_att, d.coeff = pd, pa, cfg.get("coeff", 1.0)
-    d.x, d.pos_emb, d.lens = x2d.data_ptr(), pos_emb.data_ptr(), (None if lens is None else lens.data_ptr())
+    d.x, d.pos_emb, d.lens = ops._addr(x2d), ops._addr(pos_emb), ops._addr(lens)
     for f, n in (("ffm_ln_w", "norm_ff_macaron.weight"), ("ffm_ln_b", "norm_ff_macaron.bias"),
                  ("ffm_w1", "feed_forward_macaron.w_1.weight"), ("ffm_b1", "feed_forward_macaron.w_1.bias"),
                  ("ffm_w2", "feed_forward_macaron.w_2.weight"), ("ffm_b2", "feed_forward_macaron.w_2.bias"),
@@ -333,10 +334,10 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
                  ("ff_w1", "feed_forward.w_1.weight"), ("ff_b1", "feed_forward.w_1.bias"),
                  ("ff_w2", "feed_forward.w_2.weight"), ("ff_b2", "feed_forward.w_2.bias"),
                  ("final_ln_w", "norm_final.weight"), ("final_ln_b", "norm_final.bias")):
-        setattr(d, f, p(n).data_ptr())
+        setattr(d, f, ops._addr(p(n)))
     for j, n in enumerate(("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias", "pooling_proj2.bias",
                            "weight_proj1.weight", "weight_proj2.weight", "weight_proj1.bias", "weight_proj2.bias")):
-        d.merge_p[j] = p(n).data_ptr()
+        d.merge_p[j] = ops._addr(p(n))
     # dropout tokens in the order the Python sequencing draws them (same masks either way)
     T4 = ops.pad4(T)
     sizes = (M * N1, M * D, B * H * T * T4, M * D, M * Cn, M * D, M * D, M * N1, M * D)
@@ -345,7 +346,7 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
     for j, t in enumerate(toks):
         if t is not None:
             d.drop_off[j] = t[1]
-            d.seed = t[2].data_ptr()
+            d.seed = ops._addr(t[2])
     # buffers
     b = {k: E(M, D) for k in ("x1", "n_mha", "n_mlp", "cx", "xa", "xm", "m", "x2", "x3", "y")}
     b.update(qkv=E(M, 3 * D), pp=E(W, D), lse=E(B * H, T), g=E(M, C2), u=E(M, Cn), g_mean=E(M), g_rstd=E(M),
@@ -355,19 +356,19 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
                  g_z=E(M, C2), gn=E(M, Cn), conv=E(M, Cn))
         b.update({k: E(M) for k in ("ffm_mean", "ffm_rstd", "br_mean", "br_rstd", "ff_mean", "ff_rstd", "fin_mean", "fin_rstd")})
     for k, t in b.items():
-        setattr(d, k, t.data_ptr())
+        setattr(d, k, ops._addr(t))
     main = torch.cuda.current_stream()
-    side = ops.branch_stream(main)
+    side = ops.branch_stream(main) if ops.forks_enabled() else main      # (one queue: the fork / join events order nothing new)
     ev = ops.branch_events(main)
     d.stream2, d.ev_fork, d.ev_join = side.cuda_stream, ev[0].cuda_event, ev[1].cuda_event
-    key = (B, T, N1, C2)
+    key = (B, T, D, H, N1, C2, int(need), pd > 0.0, pa > 0.0)
     nws = _LAYER_WS.get(key)
     if nws is None:
         fn = lib().tavsr_branchformer_layer_ws
         fn.restype = C.c_int64
         nws = _LAYER_WS[key] = int(fn(C.byref(d)))
     ws = ops.empty(max(nws, 4), like=x)
-    d.ws, d.ws_floats = ws.data_ptr(), nws
+    d.ws, d.ws_floats = ops._addr(ws), nws
     check(lib().tavsr_branchformer_layer_fwd(C.byref(d), C.c_void_p(main.cuda_stream)), "tavsr_branchformer_layer_fwd")
     g = b.get
     sv = {"ffm": (x2d, g("ffm_mean"), g("ffm_rstd"), g("ffm_n"), g("ffm_z"), g("ffm_h"), toks[0], toks[1]),
@@ -476,11 +477,17 @@ class BranchformerLayerFn(torch.autograd.Function):
         br.join()
         t_cat = _drop_(cat, pd) if (merge == "concat" and cat is not None) else None   # both halves in one call (iid)
         wts = None
+        x2 = None
         if two and merge == "learned_ave":
             mp = [p(k) for k in ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias",
                                  "pooling_proj2.bias", "weight_proj1.weight", "weight_proj2.weight",
                                  "weight_proj1.bias", "weight_proj2.bias")]
-            score, pooled, wts, m = ops.merge_fwd(xa, xm, lens, mp, B, T)       # pooling + weighted sum: one launch for T <= 128
+            if not cfg["merge_identity"] and ops.merge_proj_ok(xa, xm, p("merge_proj.weight"), T, D, res=x1):
+                # merge + merge_proj + dropout + residual: the whole tail behind the join as ONE launch
+                score, pooled, wts, m, x2, t_m = ops.merge_proj_fwd(xa, xm, lens, mp, p("merge_proj.weight"), p("merge_proj.bias"),
+                                                                    x1, coeff, pd, B, T, save=need)
+            else:
+                score, pooled, wts, m = ops.merge_fwd(xa, xm, lens, mp, B, T)       # pooling + weighted sum: one launch for T <= 128
             sv["merge"] = (score, pooled, wts, m)
         elif two and merge == "fixed_ave":
             cw_ = cfg["cgmlp_weight"]
@@ -492,8 +499,10 @@ class BranchformerLayerFn(torch.autograd.Function):
         else:
             m = xa if has_attn else xm
             sv["merge"] = (m,)
-        t_m = None
-        if cfg["merge_identity"]:
+        if x2 is not None:
+            pass                                            # (the fused tail above)
+        elif cfg["merge_identity"]:
+            t_m = None
             md = m
             if pd > 0.0:                                    # x + coeff * dropout(x1 | x2)  (encoder_layer.py:302-309)
                 md, t_m = ops.dropout(m.contiguous(), pd)
@@ -513,6 +522,7 @@ class BranchformerLayerFn(torch.autograd.Function):
         return y.view(B, T, D)
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         sv, cfg, P = ctx.sv, ctx.cfg, ctx.P
         B, T, D = ctx.shape
@@ -587,7 +597,6 @@ class BranchformerLayerFn(torch.autograd.Function):
         with br:
             if has_attn:
                 a_mean, a_rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa = sv["attn"]
-                br.keep(dxa)
                 if t_xa is not None and not masked:
                     dxa = _drop_bwd(dxa.contiguous(), t_xa)
                 gw_, gb_ = grp.add(dxa, cx, bias_grad=True)
@@ -654,7 +663,6 @@ class BranchformerLayerFn(torch.autograd.Function):
         grp.flush()
         lng.flush()
         ctx.sv = None
-        ops.join_side()
         return (dx.view(B, T, D), None, None, None, *G)
 
 
@@ -671,6 +679,7 @@ class LayerNormFn(torch.autograd.Function):
         return y.view(shp)
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         x2, mean, rstd, w = ctx.saved_tensors
         dx, gw, gb = ops.layernorm_bwd(dy.contiguous().view(x2.shape), x2, mean, rstd, w)
@@ -700,6 +709,7 @@ class InterCTCConditionFn(torch.autograd.Function):
         return y.view(shp)
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         h2, prob, ctc_w, cond_w = ctx.saved_tensors
         shp, M, V, S, D = ctx.dims
@@ -732,6 +742,7 @@ class DropoutFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         return ops.dropout(dy.contiguous(), ctx.tok[0], token=ctx.tok)[0], None
 
@@ -749,6 +760,7 @@ class LinearFn(torch.autograd.Function):
         return y.view(*shp[:-1], w.shape[0])
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         dy2 = dy.contiguous().view(x2.shape[0], w.shape[0])
@@ -757,7 +769,6 @@ class LinearFn(torch.autograd.Function):
             gw, gb = ops.linear_dw(dy2, x2, alpha=ctx.alpha, bias_grad=True)
         else:
             gw, gb = ops.linear_dw(dy2, x2, alpha=ctx.alpha), None
-        ops.join_side()
         return (None if dx is None else dx.view(*dy.shape[:-1], w.shape[1])), gw, gb, None
 
 
@@ -791,6 +802,7 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         return out.view(B, T2, -1)
 
     @staticmethod
+    @guarded
     def backward(ctx, dout):
         x, y1, col, y2, w2r, wor = ctx.saved_tensors
         B, T, F, Cn, T2, F2, xscale, w1s, w2s, wos = ctx.dims
@@ -806,7 +818,6 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         dcol = ops.linear_dx(dz2, w2r)                                          # [B*T2*F2, 9C]
         dz1 = ops.col2im3x3s2_relu(dcol, y1)
         gw1, gb1 = ops.conv1_bwd(dz1, x.contiguous(), Cn)
-        ops.join_side()   # the weight gradients ran on the side stream: re-index them to torch order after the join
         gwo = ops.transpose_inner(gwor, wos[0], F2, Cn).view(wos)
         gw2 = ops.transpose_inner(gw2r, Cn, 9, Cn).view(w2s)
         return None, gw1.view(w1s), gb1, gw2, gb2, gwo, gbo, None
@@ -829,6 +840,7 @@ class CTCLossFn(torch.autograd.Function):
         return ops.axpby(nll, None, 1.0 / B, 0.0)
 
     @staticmethod
+    @guarded
     def backward(ctx, dl):
         x2, w, g = ctx.saved_tensors
         B = ctx.B
@@ -839,7 +851,6 @@ class CTCLossFn(torch.autograd.Function):
         gs = ops.scale_dev(g2, dl.contiguous(), 1.0 / B)   # dlogits = g * dl / B, dl stays on the device
         dx = ops.linear_dx(gs, w)
         gw, gb = ops.linear_dw(gs, x2, bias_grad=True)
-        ops.join_side()
         return dx.view(B, -1, x2.shape[1]), gw, gb, None, None, None, None, None
 
 
@@ -926,6 +937,7 @@ class TransformerDecoderFn(torch.autograd.Function):
         return logits.view(B, L, -1)
 
     @staticmethod
+    @guarded
     def backward(ctx, dlogits):
         P = ctx.P
         B, T, L, D, H, dk, nb = ctx.dims
@@ -1003,7 +1015,6 @@ class TransformerDecoderFn(torch.autograd.Function):
         _drop_bwd_(dx, ctx.t_pos)
         G[0] = ops.embed_bwd(ctx.ys_in.contiguous(), dx, math.sqrt(D), P[0].shape[0])
         ctx.saved = None
-        ops.join_side()
         return (dmem.view(B, T, D), None, None, None, None, None, *G)
 
 
@@ -1025,6 +1036,7 @@ class LabelSmoothingLossFn(torch.autograd.Function):
         return ops.colsum(row.view(-1, 1), scale=1.0 / denom).view(()), correct
 
     @staticmethod
+    @guarded
     def backward(ctx, dl, _dc):
         (g,) = ctx.saved_tensors
         return ops.scale_dev(g, dl.contiguous(), 1.0 / ctx.denom).view(ctx.B, -1, g.shape[-1]), None, None, None, None
@@ -1039,6 +1051,7 @@ class WeightedSumFn(torch.autograd.Function):
         return ops.axpby(l1.reshape(1).contiguous(), l2.reshape(1).contiguous(), a, b).view(())
 
     @staticmethod
+    @guarded
     def backward(ctx, dl):
         a, b = ctx.ab
         d = dl.reshape(1).contiguous()

@@ -11,6 +11,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
+from ._lib import guarded
 from .functional import EPS_ESPNET, _FFN, _AttnFused, _SelfAttnCore, _drop_, _drop_bwd, _drop_bwd_, _note_ctx
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch.nn.BatchNorm defaults (conv3d_resnet18.py:57, resnet.py:39,68,84)
@@ -160,6 +161,7 @@ class VisualFrontendFn(torch.autograd.Function):
         return feat.view(B, T, cin)
 
     @staticmethod
+    @guarded
     def backward(ctx, dfeat):
         if not ctx.training:
             _bn_eval_bwd(None, None, None, None, None, None, None, None)
@@ -227,7 +229,6 @@ class VisualFrontendFn(torch.autograd.Function):
             ops.copy2d(gw0[:, :245], g0)
             G["frontend3D.0.weight"] = g0.view(p["frontend3D.0.weight"].shape)
         del col0
-        ops.join_side()
         ctx.saved = ctx.blocks = None
         return (None, None, *[G[n] for n in ctx.names])
 
@@ -244,6 +245,7 @@ class ScaleFn(torch.autograd.Function):
         return ops.axpby(x.contiguous(), None, s, 0.0)
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         return ops.axpby(dy.contiguous(), None, ctx.s, 0.0), None
 
@@ -262,6 +264,7 @@ class PadTimeFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         B, T, D = ctx.dims
         dy = dy.contiguous()
@@ -281,6 +284,7 @@ class AddRowFn(torch.autograd.Function):
         return y.view(shp)
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         d2 = dy.contiguous().view(-1, dy.shape[-1])
         return dy, ops.colsum(d2)
@@ -442,6 +446,7 @@ class TailoredStreamFn(torch.autograd.Function):
         return y.view(B, T, D)
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         sv, cfg, p = ctx.sv, ctx.cfg, ctx.p
         B, T, D = ctx.shape
@@ -469,7 +474,6 @@ class TailoredStreamFn(torch.autograd.Function):
         grp.flush()
         lng.flush()
         ctx.sv = None
-        ops.join_side()
         return (dx.view(B, T, D), None, None, None, *[G[n] for n in ctx.names])
 
 
@@ -564,7 +568,6 @@ class TailoredLayerFn(torch.autograd.Function):
         G.update(zip(_FF, gs))
         x1 = J["x1"]
         br = ops.BranchScope(True)
-        br.keep(J["brv"], x1, dx2)        # main-stream tensors whose last reader is on the forked stream: held until the join
         with br:
             grp_v, lng_v = ops.WgradGroup(), ops.LNGroup()
             dx1v = _ts_branch_bwd(pv, cfg_v, J["brv"], dx2[Ma:], x1[Ma:], J["vpos"], J["vlens"], Bv, Tv, grp_v, lng_v, Gv)
@@ -583,25 +586,22 @@ class TailoredLayerFn(torch.autograd.Function):
         G.update(zip(_FFM, gs))
         grp.flush()
         lng.flush()
-        ops.join_side()
         ns = len(TS_SHARED)
         ctx.joint = None
         return (dx[:Ma].view(Ba, Ta, D), None, None, None, dx[Ma:].view(Bv, Tv, D), None, None, None, *[G[n] for n in TS_SHARED],
                 *[Ga[n] for n in J["names_a"][ns:]], *[Gv[n] for n in J["names_v"][ns:]])
 
     @staticmethod
+    @guarded
     def backward(ctx, dya, dyv):
         if ctx.joint is not None:
             return TailoredLayerFn._backward_joint(ctx, dya, dyv)
         ns, na, nv = ctx.n
         br = ops.BranchScope(dya.is_cuda)
         dyv = dyv.contiguous()
-        br.keep(dyv)
-        # The video stream's saved state holds tensors of the MAIN stream's allocator pool (layer 0: the stream's input from
-        # the embedding).  Its backward drops that state while its launches are still queued on the forked stream; the block
-        # would return to the main pool and the audio stream's backward - issued next, on the main stream - could be handed
-        # it and overwrite it under the video stream's last readers (the macaron LayerNorm backward).  Hold until the join.
-        br.keep(dict(vars(ctx.cv)))
+        # (the video stream's saved state holds tensors of the MAIN stream's allocator pool - layer 0: the stream's input from
+        # the embedding - and its backward drops that state while its launches are still queued on the forked stream: every
+        # such tensor was record_stream-ed when a launch of the body took its address, _lib.py rule 1)
         with br:
             gv = TailoredStreamFn.backward(ctx.cv, dyv)
         ga = TailoredStreamFn.backward(ctx.ca, dya)
@@ -647,12 +647,11 @@ class FrontendPairFn(torch.autograd.Function):
         return yv, ya
 
     @staticmethod
+    @guarded
     def backward(ctx, dyv, dya):
         from .functional import Conv2dSubsamplingFn
         br = ops.BranchScope(dyv.is_cuda)
         dya = dya.contiguous()
-        br.keep(dya)
-        br.keep(dict(vars(ctx.ca)))          # as in TailoredLayerFn.backward: saved main-pool tensors outlive the forked launches
         with br:
             ga = Conv2dSubsamplingFn.backward(ctx.ca, dya)
         gv = VisualFrontendFn.backward(ctx.cv, dyv)
@@ -706,6 +705,7 @@ class FusionFn(torch.autograd.Function):
         return out.view(B, T, -1)
 
     @staticmethod
+    @guarded
     def backward(ctx, dy):
         a2, v2, score, pooled, wts, m, h, z, y2, mean, rstd, t_in = ctx.sv
         P, cfg, mode, nm = ctx.P, ctx.cfg, ctx.mode, ctx.nm
@@ -734,6 +734,5 @@ class FusionFn(torch.autograd.Function):
         else:
             da, dv, mg = ops.merge_bwd(dm, a2, v2, alens, mp, score, pooled, wts, B, T, lens2=vlens)
             mg = [g.view_as(q) for g, q in zip(mg, mp)]
-        ops.join_side()
         ctx.sv = None
         return (da.view(B, T, D), dv.view(B, T, D), None, None, None, *mg, gw1, gb1, gw2, gb2, glw, glb)

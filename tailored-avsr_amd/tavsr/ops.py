@@ -21,8 +21,7 @@ def empty(*shape, like: Optional[torch.Tensor] = None, dtype=f32, device=None):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
-def _addr(t: torch.Tensor, off: int = 0) -> int:
-    return t.data_ptr() + 4 * off
+_addr = L.addr      # tensor (+ element offset) -> integer address; the stream-safety hook lives there (_lib.py)
 
 
 class GemmProfile:
@@ -81,7 +80,7 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
     d.sA1, d.sA2 = sA
     d.sB1, d.sB2 = sB
     d.sC1, d.sC2 = sC
-    d.bias = None if bias is None else bias.data_ptr()
+    d.bias = _addr(bias)
     d.act, d.alpha = ACT[act], alpha
     d.Z = None if Z is None else _addr(Z, c_off)
     if R is not None:
@@ -90,16 +89,16 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
     if DZ is not None:
         d.DZ, d.dact = _addr(DZ, c_off), ACT[dact]
     if a_rowsum is not None:
-        d.a_rowsum = a_rowsum.data_ptr()
+        d.a_rowsum = _addr(a_rowsum)
     if drop is not None:        # dropout token (p, offset, seed tensor): the mask rides in the epilogue
-        d.drop_p, d.drop_offset, d.drop_seed = drop[0], drop[1], drop[2].data_ptr()
+        d.drop_p, d.drop_offset, d.drop_seed = drop[0], drop[1], _addr(drop[2])
     if rowstat is not None:     # [M, ceil(N / 64), 2]: per-row (sum, sum of squares) of every 64-column tile of the result
-        d.rowstat = rowstat.data_ptr()
+        d.rowstat = _addr(rowstat)
     if conv is not None:       # (mode, H, W, C[, stride, taps]): implicit convolution operand (include/tavsr.h)
         d.conv_mode, d.conv_H, d.conv_W, d.conv_C = conv[:4]
         if len(conv) > 4:
             d.conv_stride, d.conv_taps = conv[4], conv[5]
-        d.conv_zero = _zero_page(Cc.device).data_ptr()
+        d.conv_zero = _addr(_zero_page(Cc.device))
     if force is not None and force[1] > 1:
         need = force[1] * max(1, nb1) * max(1, nb2) * M * N + force[1] * M
     else:
@@ -108,7 +107,7 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         need = min(need, int(ws_cap))
     if need > 0:
         ws = torch.empty(need, dtype=f32, device=Cc.device)
-        d.ws, d.ws_floats = ws.data_ptr(), need
+        d.ws, d.ws_floats = _addr(ws), need
 
     def call():
         if force is None:
@@ -238,45 +237,18 @@ def linear_dx_cat(dy_cat, ws, *, res=None, out=None):
     return linear_dx(dy_cat, wcat, res=res, out=out)
 
 
-# Weight-gradient GEMMs have few output tiles and a long K (= B*T rows): alone they fill a fraction of the 256 CUs.
-# They are leaves of the backward graph, so they are issued on a side stream and run beside the data-gradient chain
-# of the main stream (inside a captured hipGraph this is simply a parallel branch).  Every backward Function calls
-# ``join_side()`` before it returns, which orders the side stream before anything that consumes or frees its operands.
-WGRAD_SIDE_STREAM = os.environ.get("TAVSR_WGRAD_STREAM", "0") == "1"   # measured: no gain under hipGraph replay
-_SIDE = {}
-
-
-def side_stream() -> torch.cuda.Stream:
-    dev = torch.cuda.current_device()
-    s = _SIDE.get(dev)
-    if s is None:
-        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return s
-
-
-class _SideScope:
-    def __enter__(self):
-        self.main = torch.cuda.current_stream()
-        self.side = side_stream()
-        self.on = WGRAD_SIDE_STREAM and self.main != self.side
-        if self.on:
-            self.side.wait_stream(self.main)
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.ctx.__exit__(*exc)
-        return False
-
-
 # The two Branchformer branches (attention | cgMLP) are independent between the fork after the macaron FFN and the
 # merge: the attention branch is a chain of small latency-bound launches that fits beside the cgMLP GEMMs.
 BRANCH_SIDE_STREAM = os.environ.get("TAVSR_BRANCH_STREAM", "1") == "1"
 
 
 _BRANCH = {}
+
+
+def forks_enabled() -> bool:
+    """TAVSR_SINGLE_STREAM=1 (or ``_lib.SINGLE_STREAM = True`` at run time) puts every launch of the package on the calling
+    stream - the reference's queueing; results must not depend on it (tests/test_gpu_streams.py)."""
+    return BRANCH_SIDE_STREAM and not L.SINGLE_STREAM
 
 
 def branch_stream(main: torch.cuda.Stream) -> torch.cuda.Stream:
@@ -286,25 +258,53 @@ def branch_stream(main: torch.cuda.Stream) -> torch.cuda.Stream:
     s = _BRANCH.get(key)
     if s is None:
         s = _BRANCH[key] = torch.cuda.Stream(device=main.device)
+        L.register_fork(s, main)
     return s
+
+
+# Race amplifier (tests only): TAVSR_RACE_PROBE=<microseconds> enqueues a spin kernel at the head of every forked body
+# ("body": the forked stream falls behind its owner - a main-pool block freed too early is overwritten under its readers),
+# right after every join on the owning stream ("join": the owner falls behind - a forked-pool block handed out again too early
+# is overwritten under the owner's readers), or alternately per scope ("alt", the default).  TAVSR_RACE_PROBE_MODE picks.
+RACE_PROBE_US = float(os.environ.get("TAVSR_RACE_PROBE", "0") or 0)
+RACE_PROBE_MODE = os.environ.get("TAVSR_RACE_PROBE_MODE", "alt")
+_PROBE_TICK = [0]
+
+
+def spin(us: float) -> None:
+    """occupies the current stream for ``us`` microseconds (one wave polling the wall clock)"""
+    check(lib().tavsr_spin(C.c_float(us), stream()), "tavsr_spin")
+
+
+def arm_race_probe(us: float, mode: str = "alt") -> None:
+    """(tests) set the amplifier at run time, for the Python-side scopes and the C-side sequencers alike"""
+    global RACE_PROBE_US, RACE_PROBE_MODE
+    RACE_PROBE_US, RACE_PROBE_MODE = float(us), mode
+    check(lib().tavsr_race_probe(C.c_float(us), {"body": 0, "join": 1, "alt": 2}[mode]), "tavsr_race_probe")
+
+
+def _probe(where: str, tick: int) -> None:
+    if RACE_PROBE_US <= 0:
+        return
+    mode = RACE_PROBE_MODE
+    if mode == "alt":
+        mode = "body" if tick % 2 == 0 else "join"
+    if mode == where:
+        spin(RACE_PROBE_US)
 
 
 class BranchScope:
     """``with BranchScope() as br: <launches>`` enqueues the body on the side stream (ordered after everything
-    already on the main stream); ``br.join()`` orders the main stream after the body.  Tensors allocated in the
-    body live in the side stream's allocator pool: they are only handed out again to a later body, which starts
-    with a wait on the main stream, so main-stream readers enqueued before that are always finished.
-    Capturable (fork/join inside one hipGraph capture)."""
+    already on the main stream); ``br.join()`` orders the main stream after the body.
+    Allocator safety (the two rules of _lib.py): tensors of the main stream's pool that the body hands to a launch are
+    ``record_stream``-ed on the side stream as their pointers are taken (``_lib.ptr`` / ``_lib.addr``) - the main stream can
+    free them whenever it likes; tensors allocated in the body live in the side stream's pool and are only handed out again
+    to a later body, which starts with a wait on the main stream, so main-stream readers enqueued before that are always
+    finished.  Capturable (fork/join inside one hipGraph capture)."""
 
     def __init__(self, enabled=True):
-        self.enabled = enabled and BRANCH_SIDE_STREAM
+        self.enabled = enabled and forks_enabled()
         self.on = False               # (join() of a scope that was never entered is a no-op)
-        self._keep = []
-
-    def keep(self, *objs):
-        """Main-stream tensors (or containers of them) whose last reader is in the body must stay allocated until the join
-        (the main stream's allocator would otherwise hand their memory out while the side stream still reads it)."""
-        self._keep.extend(objs)
 
     def __enter__(self):
         self.main = torch.cuda.current_stream()
@@ -314,23 +314,22 @@ class BranchScope:
             self.side.wait_stream(self.main)
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
+            self._prev = L.push_fork(self.side)
+            self._tick = _PROBE_TICK[0]
+            _PROBE_TICK[0] += 1
+            _probe("body", self._tick)
         return self
 
     def __exit__(self, *exc):
         if self.on:
+            L.pop_fork(self._prev)
             self.ctx.__exit__(*exc)
         return False
 
     def join(self):
         if self.on:
             self.main.wait_stream(self.side)
-        self._keep.clear()
-
-
-def join_side():
-    """main stream waits for every weight-gradient launch issued so far on the side stream."""
-    if WGRAD_SIDE_STREAM and torch.cuda.current_device() in _SIDE:
-        torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
+            _probe("join", self._tick)
 
 
 def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False, force=None):
@@ -338,12 +337,11 @@ def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False, force=None):
     db = alpha * dy.sum(0), computed by the same launch from the A fragments (tavsr_gemm a_rowsum)."""
     M, N = dy.shape
     K = x.shape[1]
-    with _SideScope():
-        if out is None:
-            out = empty(N, K, like=dy)
-        gb = empty(N, like=dy) if bias_grad else None
-        gemm(N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), a_kmajor=True, b_kmajor=True, alpha=alpha,
-             a_rowsum=gb, force=force)
+    if out is None:
+        out = empty(N, K, like=dy)
+    gb = empty(N, like=dy) if bias_grad else None
+    gemm(N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), a_kmajor=True, b_kmajor=True, alpha=alpha,
+         a_rowsum=gb, force=force)
     return (out, gb) if bias_grad else out
 
 
@@ -373,12 +371,12 @@ class WgradGroup:
         K = x.shape[1]
         d.M, d.N, d.K = N, K, M
         d.a_kmajor, d.b_kmajor = 1, 1
-        d.A, d.lda = dy.data_ptr(), dy.stride(0)
-        d.B, d.ldb = x.data_ptr(), x.stride(0)
-        d.C, d.ldc = out.data_ptr(), out.stride(0)
+        d.A, d.lda = _addr(dy), dy.stride(0)
+        d.B, d.ldb = _addr(x), x.stride(0)
+        d.C, d.ldc = _addr(out), out.stride(0)
         d.nb1 = d.nb2 = 1
         d.alpha = alpha
-        d.a_rowsum = None if gb is None else gb.data_ptr()
+        d.a_rowsum = _addr(gb)
 
     @staticmethod
     def _tiles(it):
@@ -443,11 +441,11 @@ def linear_group(x, wbs, out, ldc=None):
     for d, (w, b, off) in zip(arr, wbs):
         d.M, d.N, d.K = M, w.shape[0], K
         d.a_kmajor, d.b_kmajor = 0, 0
-        d.A, d.lda = x.data_ptr(), x.stride(0)
-        d.B, d.ldb = w.data_ptr(), w.stride(0)
+        d.A, d.lda = _addr(x), x.stride(0)
+        d.B, d.ldb = _addr(w), w.stride(0)
         d.C, d.ldc = _addr(out, off), ldc
         d.nb1 = d.nb2 = 1
-        d.bias = None if b is None else b.data_ptr()
+        d.bias = _addr(b)
         d.alpha = 1.0
     rc = lib().tavsr_gemm_grouped(arr, len(wbs), stream()) if (len(wbs) > 1 and PROFILE is None) else -3
     if rc == -3:
@@ -480,9 +478,9 @@ def lin2_fwd(x, segs, act=None):
     arr = (Lin2Seg * len(segs))()
     for d, (w, b, out, off, z) in zip(arr, segs):
         require_cuda(x, w, b, out, z)
-        d.w, d.b, d.n = w.data_ptr(), (None if b is None else b.data_ptr()), w.shape[0]
+        d.w, d.b, d.n = _addr(w), (_addr(b)), w.shape[0]
         d.out, d.ldo = _addr(out, off), out.stride(0)
-        d.z, d.ldz = (None, 0) if z is None else (z.data_ptr(), z.stride(0))
+        d.z, d.ldz = (None, 0) if z is None else (_addr(z), z.stride(0))
     check(lib().tavsr_lin2_fwd(ptr(x), C.c_int64(x.stride(0)), M, K, arr, len(segs), ACT[act], stream()), "tavsr_lin2_fwd")
 
 
@@ -594,7 +592,7 @@ class LNGroup:
             check(lib().tavsr_layernorm_bwd_partial_drop(ptr(dy), C.c_int64(dy.stride(0)), ptr(x), C.c_int64(x.stride(0)), ptr(mean),
                                                          ptr(rstd), ptr(gamma), ptr(dx_add),
                                                          C.c_int64(0 if dx_add is None else dx_add.stride(0)), ptr(dx),
-                                                         C.c_int64(dx.stride(0)), C.c_void_p(self.slab.data_ptr() + 4 * off),
+                                                         C.c_int64(dx.stride(0)), C.c_void_p(_addr(self.slab) + 4 * off),
                                                          C.c_int64(self.slab.stride(0)), M, D, ptr(dxd), C.c_float(drop[0]),
                                                          ptr(drop[2]), C.c_uint64(drop[1]), stream()),
                   "tavsr_layernorm_bwd_partial_drop")
@@ -603,7 +601,7 @@ class LNGroup:
         check(lib().tavsr_layernorm_bwd_partial(ptr(dy), C.c_int64(dy.stride(0)), ptr(x), C.c_int64(x.stride(0)), ptr(mean),
                                                 ptr(rstd), ptr(gamma), ptr(dx_add),
                                                 C.c_int64(0 if dx_add is None else dx_add.stride(0)), ptr(dx),
-                                                C.c_int64(dx.stride(0)), C.c_void_p(self.slab.data_ptr() + 4 * off),
+                                                C.c_int64(dx.stride(0)), C.c_void_p(_addr(self.slab) + 4 * off),
                                                 C.c_int64(self.slab.stride(0)), M, D, stream()),
               "tavsr_layernorm_bwd_partial")
         self.k += 1
@@ -688,14 +686,14 @@ def _attn_desc(q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk, klens, causal, po
     d.q, d.k, d.v = _addr(q, q_off), _addr(k, k_off), _addr(v, v_off)
     d.ldq, d.ldk, d.ldv = q.stride(0), k.stride(0), v.stride(0)
     if pos is not None:
-        d.pos, d.ldp = pos.data_ptr(), pos.stride(0)
-    d.bias_u = None if bias_u is None else bias_u.data_ptr()
-    d.bias_v = None if bias_v is None else bias_v.data_ptr()
-    d.klens = None if klens is None else klens.data_ptr()
+        d.pos, d.ldp = _addr(pos), pos.stride(0)
+    d.bias_u = _addr(bias_u)
+    d.bias_v = _addr(bias_v)
+    d.klens = _addr(klens)
     d.B, d.H, d.T1, d.T2, d.dk = B, H, T1, T2, dk
     d.scale, d.causal = 1.0 / (dk ** 0.5), int(bool(causal))
     if token is not None:
-        d.p_drop, d.drop_offset, d.seed_dev = token[0], token[1], token[2].data_ptr()
+        d.p_drop, d.drop_offset, d.seed_dev = token[0], token[1], _addr(token[2])
     return d
 
 
@@ -817,34 +815,34 @@ def ffn2_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=0.0, save=True, l
     assert w1.is_contiguous() and w2.is_contiguous() and w1.shape == (N1, D) and w2.shape == (D, N1) and len(ln2) <= 2
     d = FfnDesc()
     d.M, d.D, d.N1, d.act, d.scale, d.eps = M, D, N1, ACT[act], scale, eps
-    d.x, d.ldx = x.data_ptr(), x.stride(0)
-    d.ln_w, d.ln_b, d.w1, d.b1, d.w2, d.b2 = (t.data_ptr() for t in (ln_w, ln_b, w1, b1, w2, b2))
+    d.x, d.ldx = _addr(x), x.stride(0)
+    d.ln_w, d.ln_b, d.w1, d.b1, d.w2, d.b2 = (_addr(t) for t in (ln_w, ln_b, w1, b1, w2, b2))
     y = empty(M, D, like=x)
-    d.y = y.data_ptr()
+    d.y = _addr(y)
     n = mean = rstd = z = h = None
     if save:
         n, mean, rstd = empty(M, D, like=x), empty(M, like=x), empty(M, like=x)
         Mp = (M + 127) // 128 * 128       # whole 128-row blocks are stored
         z, h = empty(Mp, N1, like=x)[:M], empty(Mp, N1, like=x)[:M]
-        d.n_out, d.mean, d.rstd, d.z, d.h = (t.data_ptr() for t in (n, mean, rstd, z, h))
+        d.n_out, d.mean, d.rstd, d.z, d.h = (_addr(t) for t in (n, mean, rstd, z, h))
     tok_in = tok_out = None
     if p and p > 0.0:
         tok_in = _new_token(p, M * N1, x.device)
         tok_out = _new_token(p, M * D, x.device)
-        d.p_drop, d.seed, d.offset_in, d.offset_out = p, tok_in[2].data_ptr(), tok_in[1], tok_out[1]
+        d.p_drop, d.seed, d.offset_in, d.offset_out = p, _addr(tok_in[2]), tok_in[1], tok_out[1]
     outs = []
     for k, (g, b) in enumerate(ln2):
         o = empty(M, D, like=x)
         outs.append(o)
-        d.ln2_w[k], d.ln2_b[k], d.ln2_out[k] = g.data_ptr(), b.data_ptr(), o.data_ptr()
+        d.ln2_w[k], d.ln2_b[k], d.ln2_out[k] = _addr(g), _addr(b), _addr(o)
     m2 = r2 = None
     if ln2 and ln2_stats:
         m2, r2 = empty(M, like=x), empty(M, like=x)
-        d.ln2_mean, d.ln2_rstd = m2.data_ptr(), r2.data_ptr()
+        d.ln2_mean, d.ln2_rstd = _addr(m2), _addr(r2)
     d.ln2_eps = ln2_eps
     nws = lib_i64("tavsr_ffn2_ws", M, D, N1)
     ws = empty(nws, like=x)
-    d.ws, d.ws_floats = ws.data_ptr(), nws
+    d.ws, d.ws_floats = _addr(ws), nws
     check(lib().tavsr_ffn2_fwd(C.byref(d), stream()), "tavsr_ffn2_fwd")
     return y, (n, mean, rstd, z, h, tok_in, tok_out), outs, (m2, r2)
 
@@ -990,7 +988,7 @@ def dwconv_gate_bwd(du, gn, r, conv, w, dr, B, T, zr=None, act="gelu"):
 
 def _ptr_array(ts: Sequence[torch.Tensor]):
     require_cuda(*ts)
-    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    return (C.c_void_p * len(ts))(*[_addr(t) for t in ts])
 
 
 def merge_pool_fwd(x1, x2, lens, params, B, T, lens2=None):
@@ -1027,6 +1025,32 @@ def merge_fwd(x1, x2, lens, params, B, T, lens2=None):
     check(lib().tavsr_merge_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(score), ptr(pooled), ptr(w),
                                 ptr(out), B, T, D, stream()), "tavsr_merge_fwd")
     return score, pooled, w, out
+
+
+MERGE_PROJ = os.environ.get("TAVSR_MERGE_PROJ", "1") == "1"      # A/B switch: merge + merge_proj + residual as one launch
+
+
+def merge_proj_ok(x1, x2, w, T, D, res=None) -> bool:
+    return (MERGE_PROJ and MERGE_ROWS and w.shape == (D, D) and w.is_contiguous() and x1.is_contiguous() and x2.is_contiguous()
+            and (res is None or res.is_contiguous()) and bool(lib().tavsr_merge_proj_ok(T, D)))
+
+
+def merge_proj_fwd(x1, x2, lens, params, w, b, res, alpha, p, B, T, lens2=None, save=True):
+    """the layer's tail behind the branch join in one launch (csrc/mergeproj.hip): learned_ave merge of x1 / x2 and
+    ``res + alpha * dropout(merge_proj(mix), p)`` -> (score, dots, wts, mix | None, out, token).  ``dots`` / ``score`` / ``wts`` are
+    what ``merge_bwd`` wants back (the row-parallel route's saved tensors), ``mix`` merge_proj's saved input (``save``)."""
+    D = x1.shape[-1]
+    M = B * T
+    require_cuda(x1, x2, lens, lens2, w, b, res)
+    score, wts, dots = empty(2, B, T, like=x1), empty(B, 2, like=x1), empty(4, M, like=x1)
+    mix = torch.empty_like(x1) if save else None
+    out = torch.empty_like(x1)
+    tok = _new_token(p, M * D, x1.device) if p and p > 0.0 else None
+    check(lib().tavsr_merge_proj_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(w), ptr(b), ptr(res),
+                                     C.c_float(alpha), C.c_float(p if tok is not None else 0.0), ptr(None if tok is None else tok[2]),
+                                     C.c_uint64(0 if tok is None else tok[1]), ptr(dots), ptr(score), ptr(wts), ptr(mix), ptr(out),
+                                     B, T, D, stream()), "tavsr_merge_proj_fwd")
+    return score, dots, wts, mix, out, tok
 
 
 def merge_combine(x1, x2, w, B, T):
@@ -1505,8 +1529,8 @@ def multi_add_(dst, src):
     n = len(dst)
     for a, b in zip(dst, src):
         assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() and a.dtype == f32 and b.dtype == f32
-    dp = (C.c_void_p * n)(*[t.data_ptr() for t in dst])
-    sp = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+    dp = (C.c_void_p * n)(*[_addr(t) for t in dst])
+    sp = (C.c_void_p * n)(*[_addr(t) for t in src])
     cnt = (C.c_int64 * n)(*[t.numel() for t in dst])
     check(lib().tavsr_multi_add(dp, sp, cnt, n, stream()), "tavsr_multi_add")
     return dst
@@ -1519,8 +1543,8 @@ def multi_copy_(dst, src):
     n = len(dst)
     for a, b in zip(dst, src):
         assert a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.numel() == b.numel()
-    dp = (C.c_void_p * n)(*[t.data_ptr() for t in dst])
-    sp = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+    dp = (C.c_void_p * n)(*[_addr(t) for t in dst])
+    sp = (C.c_void_p * n)(*[_addr(t) for t in src])
     cnt = (C.c_int64 * n)(*[t.numel() * t.element_size() for t in dst])
     check(lib().tavsr_multi_copy(dp, sp, cnt, n, stream()), "tavsr_multi_copy")
     return dst

@@ -88,9 +88,9 @@ class FusedAdam:
         for ia, ib in runs:
             lo = self.offsets[ia]
             hi = self.offsets[ib + 1] if ib + 1 < len(self.params) else self.flat.numel()
-            L.check(L.lib().tavsr_adamw_step(C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad.data_ptr() + 4 * lo),
-                                             C.c_void_p(self.exp_avg.data_ptr() + 4 * lo),
-                                             C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * lo), C.c_int64(hi - lo),
+            L.check(L.lib().tavsr_adamw_step(C.c_void_p(L.addr(self.flat, lo)), C.c_void_p(L.addr(self.grad, lo)),
+                                             C.c_void_p(L.addr(self.exp_avg, lo)),
+                                             C.c_void_p(L.addr(self.exp_avg_sq, lo)), C.c_int64(hi - lo),
                                              C.c_float(g["lr"]), C.c_float(g["betas"][0]), C.c_float(g["betas"][1]),
                                              C.c_float(g["eps"]), C.c_float(g.get("weight_decay", 0.0)),
                                              C.c_int64(self._steps[ia]), C.c_float(grad_scale), L.stream()),

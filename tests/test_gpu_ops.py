@@ -285,6 +285,68 @@ def test_merge_rows_second_length_vector_and_batch_32():
         _close(a, b, 2e-5)
 
 
+@pytest.mark.parametrize("B,T,p", [(3, 99, 0.0), (32, 99, 0.1), (2, 100, 0.1), (4, 37, 0.0), (2, 300, 0.1), (1, 1, 0.0)])
+def test_merge_proj_fused_tail_matches_fp64_and_the_launches_it_replaces(B, T, p):
+    """tavsr_merge_proj_fwd (csrc/mergeproj.hip): learned_ave merge + merge_proj + dropout + coeff + residual in one launch
+    (src/encoder/branchformer/encoder_layer.py:232-300) vs torch fp64, and - with dropout - vs the row-parallel merge followed by
+    the GEMM launch under the SAME mask token; the saved tensors feed the existing backward."""
+    from tavsr import ops
+    torch.manual_seed(11)
+    D = 256
+    lens = torch.randint(1, T + 1, (B,), device="cuda")
+    lens[0] = T
+    x1, x2, res = (torch.randn(B * T, D, device="cuda") for _ in range(3))
+    prm = [torch.randn(1, D, device="cuda") / 4, torch.randn(1, D, device="cuda") / 4, torch.randn(1, device="cuda"),
+           torch.randn(1, device="cuda"), torch.randn(1, D, device="cuda") / 4, torch.randn(1, D, device="cuda") / 4,
+           torch.randn(1, device="cuda"), torch.randn(1, device="cuda")]
+    W, bias = torch.randn(D, D, device="cuda") / 16, torch.randn(D, device="cuda")
+    coeff = 0.7
+    assert ops.merge_proj_ok(x1, x2, W, T, D, res=res)
+    ops.manual_seed(77)
+    ops.rng_step_begin(x1.device)
+    score, dots, wts, mix, out, tok = ops.merge_proj_fwd(x1, x2, lens, prm, W, bias, res, coeff, p, B, T)
+    # the launches it replaces
+    score_r, dots_r, wts_r, mix_r = ops.merge_fwd(x1, x2, lens, prm, B, T)
+    _close(score, score_r, 1e-5)
+    _close(dots, dots_r, 1e-5)
+    _close(wts, wts_r, 1e-5)
+    _close(mix, mix_r, 1e-5)
+    # fp64
+    X = [x1.view(B, T, D).double(), x2.view(B, T, D).double()]
+    P = [q.double() for q in prm]
+    mask = (torch.arange(T).cuda()[None, :] < lens[:, None])[:, None, :]
+    ws = []
+    for k in range(2):
+        s = (X[k] @ P[k].t() + P[2 + k]).transpose(1, 2) / D ** 0.5
+        s = torch.softmax(s.masked_fill(~mask, -1e300), -1).masked_fill(~mask, 0.0)
+        ws.append(torch.matmul(s, X[k]).squeeze(1) @ P[4 + k].t() + P[6 + k])
+    mw = torch.softmax(torch.cat(ws, -1), -1)
+    m64 = (mw[:, 0, None, None] * X[0] + mw[:, 1, None, None] * X[1]).view(B * T, D)
+    _close(wts, mw, 1e-5)
+    _close(mix, m64, 1e-5)
+    y64 = m64 @ W.double().t() + bias.double()
+    if p == 0.0:
+        assert tok is None
+        _close(out, res.double() + coeff * y64, 2e-5)
+    else:
+        # same mask as a dropout launch with the fused call's token on a [B*T][256] tensor
+        yd, _ = ops.dropout(y64.float().contiguous(), p, token=tok)
+        keep = yd != 0
+        assert 0.85 < float(keep.float().mean()) < 0.95
+        _close(out, res.double() + coeff * torch.where(keep, y64 / (1 - p), torch.zeros_like(y64)), 2e-5)
+    # without the saved mix (a forward without a backward): same result
+    ops.manual_seed(77)
+    ops.rng_step_begin(x1.device)
+    _, _, _, none_mix, out2, _ = ops.merge_proj_fwd(x1, x2, lens, prm, W, bias, res, coeff, p, B, T, save=False)
+    assert none_mix is None and torch.equal(out2, out)
+    # the saved tensors drive the existing backward
+    dm = torch.randn(B * T, D, device="cuda")
+    a = ops.merge_bwd(dm, x1, x2, lens, prm, score, dots, wts, B, T)
+    b = ops.merge_bwd(dm, x1, x2, lens, prm, score_r, dots_r, wts_r, B, T)
+    _close(a[0], b[0], 2e-5)
+    _close(a[1], b[1], 2e-5)
+
+
 def test_conv2d_subsampling_pieces():
     from tavsr import ops
     torch.manual_seed(5)

@@ -137,3 +137,27 @@ def test_every_recipe_yaml_builds_through_the_task_registries():
                 assert (layer.cgmlp is None) == (w == 0.0) and (layer.attn is None) == (w == 1.0)
     for task, sets in keys.items():
         assert all(s == sets[0] for s in sets), task
+
+
+def test_stream_safety_rules_are_not_bypassed():
+    """_lib.py's two allocator rules live at the one place where a tensor becomes a raw pointer (``ptr`` / ``addr``) and at
+    the head of every autograd backward (``guarded``): no module takes ``.data_ptr()`` behind their back (alignment tests and
+    identity asserts aside), every ``Function.backward`` of the package is guarded, and no hand-kept ``keep()`` list is left."""
+    pkg = os.path.join(ROOT, "tailored-avsr_amd", "tavsr")
+    offenders, unguarded, keeps = [], [], []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, f)
+            lines = open(path).read().split("\n")
+            for i, ln in enumerate(lines):
+                if ".data_ptr()" in ln and f != "_lib.py" and "% 16" not in ln and "assert" not in ln:
+                    offenders.append(f"{path}:{i + 1}")
+                if re.match(r"\s+def backward\(", ln) and "@guarded" not in lines[i - 1]:
+                    unguarded.append(f"{path}:{i + 1}")
+                if re.search(r"\bbr\.keep\(", ln):
+                    keeps.append(f"{path}:{i + 1}")
+    assert not offenders, offenders
+    assert not unguarded, unguarded
+    assert not keeps, keeps
