@@ -251,32 +251,6 @@ int tavsr_attn_bwd(const tavsr_attn_desc* d, const float* dctx, const float* ctx
                    tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Fused position-wise feed-forward block (csrc/ffn.hip) - espnet PositionwiseFeedForward inside its residual block
- * (src/encoder/branchformer/encoder_layer.py:191-194,311-314; tailored AV layer; decoder FFN), d_model D in {256, 512},
- * hidden N1 % 128 == 0, weights in torch Linear layout (w1 [N1][D], w2 [D][N1]):
- *   tavsr_ffn_fwd   : y = x + scale * dropout(w2 dropout(act(w1 LN(x) + b1)) + b2)  - LayerNorm prologue, both GEMMs in
- *                     one launch (the hidden activations go from the first product's accumulators through LDS into the
- *                     second product), then a finishing launch (fixed-order sum of the hidden-split partials, bias,
- *                     dropout, residual).  n_out / mean / rstd / z / h (all optional, NULL in eval): what the backward
- *                     needs - LN(x) [M][D], its statistics [M], pre-activations and dropped activations [M][N1].
- *   tavsr_ffn_bwd_dx: dz = ((alpha * dy) w2) * mask / keep * act'(z)  [M][N1] (operand of the w1 weight gradient) and
- *                     dn = dz w1 [M][D] (the gradient w.r.t. LN(x)), same structure; takes the weights TRANSPOSED
- *                     (w1t = w1^T [D][N1], w2t = w2^T [N1][D]) so that both products read k-contiguous rows.
- * z, h and dz are buffers of roundup32(M) rows (whole 32-row tiles are stored; rows >= M are scratch).
- * Inner dropout (between the GEMMs): element (m, c) keeps iff word (m & 3) of Philox counter offset_in/4 + (m >> 2)*N1 + c
- * is >= p * 2^32 (the layout the accumulators have); a call consumes roundup4(M) * N1 counter elements.  Outer dropout
- * (on the block output): the tavsr_dropout mapping at offset_out.  ws: tavsr_ffn_ws(M, D, N1) floats.
- * ------------------------------------------------------------------------------------------- */
-int64_t tavsr_ffn_ws(int32_t M, int32_t D, int32_t N1);
-int tavsr_ffn_fwd(const float* x, int64_t ldx, const float* ln_w, const float* ln_b, float eps, const float* w1, const float* b1,
-                  const float* w2, const float* b2, int32_t act, float scale, int32_t M, int32_t D, int32_t N1, float p_drop,
-                  const uint64_t* seed_dev, uint64_t offset_in, uint64_t offset_out, float* n_out, float* mean, float* rstd,
-                  float* z, float* h, float* y, float* ws, tavsr_stream_t stream);
-int tavsr_ffn_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w1t, const float* w2t, const float* z, int32_t act,
-                     int32_t M, int32_t D, int32_t N1, float p_drop, const uint64_t* seed_dev, uint64_t offset_in, float* dz,
-                     float* dn, float* ws, tavsr_stream_t stream);
-
-/* ---------------------------------------------------------------------------------------------
  * Feed-forward block, streaming form (csrc/ffn2.hip) - the same espnet PositionwiseFeedForward residual block
  * (src/encoder/branchformer/encoder_layer.py:191-194,311-314; src/encoder/audiovisual/tailored/encoder_layer.py:173-175,
  * 211-213) for d_model 256, hidden N1 % 32 == 0, weights in torch Linear layout (w1 [N1][256], w2 [256][N1]):
@@ -329,22 +303,6 @@ int tavsr_ffn2_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w
                       int32_t M, int32_t D, int32_t N1, float p_drop, const uint64_t* seed_dev, uint64_t offset_in, float* dz,
                       float* dn, float* ws, int64_t ws_floats, tavsr_stream_t stream);
 
-/* Linear layers of ONE d_model = 256 input as one streaming launch (csrc/lin2.hip): out_s = act(x w_s^T + b_s) for up to four
- * weight matrices w_s [n_s][256] (n_s % 32 == 0) - espnet's linear_q / linear_k / linear_v of one attention input, cgMLP's
- * channel_proj1 + GELU (src/encoder/branchformer/encoder_layer.py:196-222).  out_s [M][ldo] (a column window of a wider buffer
- * is fine), z_s (optional, all or none): the pre-activations.  K != 256: TAVSR_EUNSUPPORTED (callers keep tavsr_gemm). */
-typedef struct tavsr_lin2_seg {
-  const float* w;
-  const float* b;            /* [n] or NULL */
-  float* out;
-  int64_t ldo;
-  float* z;
-  int64_t ldz;
-  int32_t n;
-} tavsr_lin2_seg;
-int tavsr_lin2_fwd(const float* x, int64_t ldx, int32_t M, int32_t K, const tavsr_lin2_seg* segs, int32_t nseg, int32_t act,
-                   tavsr_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------
  * One Branchformer encoder layer forward as ONE call (csrc/layer.hip): MyBranchformerEncoderLayer.forward
  * (src/encoder/branchformer/encoder_layer.py:153-321) in its recipe form - macaron FFN, rel-pos attention branch beside the
@@ -384,6 +342,8 @@ typedef struct tavsr_bf_layer_desc {
   float* ws;
   int64_t ws_floats;
 } tavsr_bf_layer_desc;
+/* the shapes the sequencer takes (1) or not (0: the caller keeps its own sequencing of the primitive entry points) */
+int tavsr_branchformer_layer_ok(int32_t B, int32_t T, int32_t D, int32_t H, int32_t ffn_units, int32_t cg_units, int32_t cg_kernel);
 int64_t tavsr_branchformer_layer_ws(const tavsr_bf_layer_desc* d);
 int tavsr_branchformer_layer_fwd(const tavsr_bf_layer_desc* d, tavsr_stream_t stream);
 
@@ -447,9 +407,6 @@ int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int64_t* lens, 
                          const float* const* params,
                          float* score, float* pooled, float* w, int32_t B, int32_t T, int32_t D,
                          tavsr_stream_t stream);
-/* pool_fwd + combine (one launch for T <= 128, D = 256: the rows are read once) */
-int tavsr_merge_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2, const float* const* params,
-                    float* score, float* pooled, float* w, float* out, int32_t B, int32_t T, int32_t D, tavsr_stream_t stream);
 int tavsr_merge_combine(const float* x1, const float* x2, const float* w, float* out, int32_t B, int32_t T,
                         int32_t D, tavsr_stream_t stream);
 /* The row-parallel form of the same merge (D = 256, T <= 2048: tavsr_merge_rows_ok): the launches above run one workgroup

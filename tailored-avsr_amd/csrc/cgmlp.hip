@@ -594,109 +594,6 @@ __global__ __launch_bounds__(512) void merge_pool_fwd_kernel(const float* __rest
   }
 }
 
-// Same result for T <= 128, D = 256 (the encoder's shapes) with every row read ONCE: 1024 threads, 8 waves per branch, a wave
-// holds its rows t = wave, wave + 8, ... (<= 16 of them, one 16-byte load per lane and row, all issued together) in registers
-// through both passes - the score dots and, after the softmax over time, the pooled sum.  The 512-thread kernel above walks
-// 25 rows per wave twice, the second time one dependent load per row: 23 us at T = 99 against ~6 here.
-__global__ __launch_bounds__(1024) void merge_pool_fwd_t128_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                                                   const int64_t* __restrict__ lens,
-                                                                   const int64_t* __restrict__ lens2, MergeParams p,
-                                                                   float* __restrict__ score, float* __restrict__ pooled,
-                                                                   float* __restrict__ wout, float* __restrict__ mix, int B, int T) {
-  constexpr int D = 256, R = 16;
-  // mix != null: the weighted sum of the two branches (merge_combine) from the same registers - no second pass over the rows
-  __shared__ __attribute__((aligned(16))) float s_x2[128 * D];
-  __shared__ float s_sc[2][128];
-  __shared__ float s_red[2][8];
-  __shared__ float s_w[2];
-  __shared__ __attribute__((aligned(16))) float s_part[2][8][D];
-  const int k = threadIdx.x >> 9;                          // branch
-  const int ht = threadIdx.x & 511, lane = threadIdx.x & 63, wv = ht >> 6;
-  const int b = blockIdx.x;
-  const int64_t* lk = (k == 1 && lens2) ? lens2 : lens;
-  const int len = lk ? (int)min((int64_t)T, lk[b]) : T;
-  const float* x = (k == 0 ? x1 : x2) + (int64_t)b * T * D;
-  float4 xv[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int t = wv + 8 * i;
-    // (rows len <= t < T take no part in the statistics - every use below tests t < len - but the combination covers them)
-    xv[i] = t < T ? *reinterpret_cast<const float4*>(x + (int64_t)t * D + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const float4 wp = *reinterpret_cast<const float4*>(p.wp[k] + 4 * lane);
-  const float bias = p.bp[k][0], inv_sqrt_d = 1.f / 16.f;
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const float r = wave_sum((xv[i].x * wp.x + xv[i].y * wp.y) + (xv[i].z * wp.z + xv[i].w * wp.w));
-    if (lane == 0 && wv + 8 * i < T) s_sc[k][wv + 8 * i] = (r + bias) * inv_sqrt_d;
-  }
-  __syncthreads();
-  // softmax over t < len (every wave of the branch computes the same statistics from LDS: no second reduction tree)
-  float mx = -FLT_MAX;
-  for (int t = lane; t < len; t += 64) mx = fmaxf(mx, s_sc[k][t]);
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int t = lane; t < len; t += 64) sum += expf(s_sc[k][t] - mx);
-  sum = wave_sum(sum);
-  const float inv = len > 0 ? 1.f / sum : 0.f;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int t = wv + 8 * i;
-    const float sv = t < len ? expf(s_sc[k][t] - mx) * inv : 0.f;
-    if (lane == 0 && t < T) score[((int64_t)k * B + b) * T + t] = sv;
-    acc.x += sv * xv[i].x; acc.y += sv * xv[i].y; acc.z += sv * xv[i].z; acc.w += sv * xv[i].w;
-  }
-  *reinterpret_cast<float4*>(&s_part[k][wv][4 * lane]) = acc;
-  __syncthreads();
-  float wacc = 0.f;
-  if (ht < D) {
-    float a = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a += s_part[k][j][ht];
-    pooled[((int64_t)k * B + b) * D + ht] = a;
-    wacc = a * p.ww[k][ht];
-  }
-  wacc = wave_sum(wacc);
-  if (lane == 0) s_red[k][wv] = wacc;
-  __syncthreads();
-  if (ht == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t += s_red[k][j];
-    s_w[k] = t + p.bw[k][0];
-  }
-  __syncthreads();
-  const float m = fmaxf(s_w[0], s_w[1]);
-  const float e0 = expf(s_w[0] - m), e1 = expf(s_w[1] - m);
-  const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
-  if (threadIdx.x == 0) {
-    wout[b * 2 + 0] = w0;
-    wout[b * 2 + 1] = w1;
-  }
-  if (mix) {        // the second branch's waves park w1 * x2 in LDS, the first branch's waves add w0 * x1 and store
-    if (k == 1) {
-#pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const int t = wv + 8 * i;
-        if (t < T) *reinterpret_cast<float4*>(&s_x2[t * D + 4 * lane]) = make_float4(w1 * xv[i].x, w1 * xv[i].y, w1 * xv[i].z, w1 * xv[i].w);
-      }
-    }
-    __syncthreads();
-    if (k == 0) {
-      float* o = mix + (int64_t)b * T * D;
-#pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const int t = wv + 8 * i;
-        if (t < T) {
-          const float4 c = *reinterpret_cast<const float4*>(&s_x2[t * D + 4 * lane]);
-          *reinterpret_cast<float4*>(o + (int64_t)t * D + 4 * lane) =
-              make_float4(w0 * xv[i].x + c.x, w0 * xv[i].y + c.y, w0 * xv[i].z + c.z, w0 * xv[i].w + c.w);
-        }
-      }
-    }
-  }
-}
 
 // out[b,t,:] = w[b,0]*x1[b,t,:] + w[b,1]*x2[b,t,:]
 __global__ void merge_combine_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
@@ -1190,12 +1087,6 @@ extern "C" int tavsr_merge_pool_fwd(const float* x1, const float* x2, const int6
   if (B <= 0) return TAVSR_OK;
   TAVSR_REQUIRE(D % 4 == 0 && ((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0), TAVSR_EALIGN,
                 "merge_pool_fwd: D %% 4 == 0 and 16-byte aligned rows required");
-  if (T <= 128 && D == 256) {       // rows read once, held in registers through both passes
-    hipLaunchKernelGGL(merge_pool_fwd_t128_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x1, x2, lens, lens2, mk(params),
-                       score, pooled, w, (float*)nullptr, B, T);
-    TAVSR_LAUNCH_CHECK();
-    return TAVSR_OK;
-  }
   size_t lds = (2 * T + 4 + 16 + 8 * D) * sizeof(float);
   TAVSR_REQUIRE(lds <= 60000, TAVSR_EUNSUPPORTED, "merge_pool_fwd: T=%d too long", T);
   hipLaunchKernelGGL(merge_pool_fwd_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, x1, x2, lens, lens2, mk(params),
@@ -1214,25 +1105,6 @@ extern "C" int tavsr_merge_combine(const float* x1, const float* x2, const float
                      total4, (int)((int64_t)T * D / 4));
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
-}
-
-// pool + combine; one launch when the rows fit the single-read kernel (T <= 128, D = 256), else the two launches above
-extern "C" int tavsr_merge_fwd(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
-                               const float* const* params, float* score, float* pooled, float* w, float* out, int32_t B,
-                               int32_t T, int32_t D, tavsr_stream_t stream) {
-  TAVSR_REQUIRE(out, TAVSR_EINVAL, "merge_fwd: null output");
-  if (B > 0 && T <= 128 && D == 256) {
-    TAVSR_REQUIRE(x1 && x2 && params && score && pooled && w, TAVSR_EINVAL, "merge_fwd: null pointer");
-    for (int i = 0; i < 8; ++i) TAVSR_REQUIRE(params[i], TAVSR_EINVAL, "merge_fwd: null parameter %d", i);
-    TAVSR_REQUIRE(((uintptr_t)x1 % 16 == 0) && ((uintptr_t)x2 % 16 == 0) && ((uintptr_t)out % 16 == 0), TAVSR_EALIGN,
-                  "merge_fwd: 16-byte aligned rows required");
-    hipLaunchKernelGGL(merge_pool_fwd_t128_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x1, x2, lens, lens2, mk(params),
-                       score, pooled, w, out, B, T);
-    TAVSR_LAUNCH_CHECK();
-    return TAVSR_OK;
-  }
-  int rc = tavsr_merge_pool_fwd(x1, x2, lens, lens2, params, score, pooled, w, B, T, D, stream);
-  return rc ? rc : tavsr_merge_combine(x1, x2, w, out, B, T, D, stream);
 }
 
 extern "C" int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D) { return (int64_t)(B + 1) * (4 * D + 4); }

@@ -519,9 +519,9 @@ __device__ __forceinline__ void finish_tile_vec(const tavsr_gemm_desc& d, int ns
   }
 }
 
-// host-side test of the vectorised epilogue's requirements (TAVSR_GEMM_VEC_EPI=0 switches it off: A/B aid)
+// host-side test of the vectorised epilogue's requirements
 static bool vec_epi_ok(const tavsr_gemm_desc& d) {
-  static const int on = [] { const char* e = getenv("TAVSR_GEMM_VEC_EPI"); return e ? atoi(e) : 1; }();
+  constexpr int on = 1;
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   return on && d.N % 4 == 0 && d.ldc % 4 == 0 && d.sC1 % 4 == 0 && d.sC2 % 4 == 0 && al(d.C) && (!d.bias || al(d.bias)) &&
          (!d.Z || al(d.Z)) && (!d.DZ || al(d.DZ)) && (!d.R || (al(d.R) && d.ldr % 4 == 0 && d.sR1 % 4 == 0 && d.sR2 % 4 == 0)) &&
@@ -1185,16 +1185,16 @@ static int launch_conv(const tavsr_gemm_desc& d, int nsplit, int kchunk, hipStre
   //     +0.6 % on the AV step (128x64 and 128x128 tiles: nothing / worse);
   //   weight gradient: a 128x64 tile (Cout % 128 == 0) shares one patch tile between 128 output channels: +1.6 %, and
   //     another +0.7 % with the K split re-fitted to its three block slots per CU (2304 blocks).
-  // TAVSR_CONV_TILE=0 / TAVSR_CONV_DW_TILE=0 keep 64x64 everywhere (A/B switches).
-  static const int wide = [] { const char* e = getenv("TAVSR_CONV_TILE"); return e ? atoi(e) : 1; }();
-  static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
-  static const int zmap_on = [] { const char* e = getenv("TAVSR_CONV_ZMAP"); return e ? atoi(e) : 1; }();
+  // (in-call A/B of rounds 1-2; the run-time switches are gone, the constants below record the winners)
+  constexpr int wide = 1;
+  constexpr int dw_wide = 1;
+  constexpr int zmap_on = 1;
   const int zmap = zmap_on && (d.conv_mode == 2 || d.conv_mode == 5 || d.conv_mode == 7) && nsplit >= 8 && nsplit % 8 == 0;
   if (d.conv_mode == 6 || d.conv_mode == 7) {      // Conv3d stem over padded clips: ordinary 16-byte chunks
     GemmArgs a6{d, kchunk, nsplit, cdiv(d.M, 64), cdiv(d.N, 64), ve, zmap};
     const dim3 grid6(a6.tiles_m * a6.tiles_n, 1, nsplit);
-    static const int st3 = [] { const char* e = getenv("TAVSR_STEM_STAGES"); return e ? atoi(e) : 2; }();   // tuning aid
-    static const int tile128 = [] { const char* e = getenv("TAVSR_STEM_TILE"); return e ? atoi(e) == 128 : 0; }();   // tuning aid
+    constexpr int st3 = 2;   // tuning aid
+    constexpr int tile128 = 0;   // tuning aid
     if (d.conv_mode == 6 && tile128) {
       GemmArgs a7{d, kchunk, nsplit, cdiv(d.M, 128), cdiv(d.N, 64), ve, 0};
       hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, 3, false, false, 1, 6>), dim3(a7.tiles_m * a7.tiles_n, 1, 1), dim3(256), 0, s, a7);
@@ -1301,7 +1301,7 @@ static bool glds_ok(const tavsr_gemm_desc& d, bool vec) {
 // K % 32 != 0 on the LDS-DMA kernel (tail variant): 16-byte chunks past K come from a zero page; a k-contiguous operand
 // must hold the (up to 3) elements between K and the next multiple of 4 inside its rows (ld >= roundup4(K))
 static bool tail_ok(const tavsr_gemm_desc& d, bool vec) {
-  static const int on = [] { const char* e = getenv("TAVSR_GEMM_TAIL"); return e ? atoi(e) : 1; }();
+  constexpr int on = 1;
   const int64_t k4 = (d.K + 3) / 4 * 4;
   return on && vec && d.K % 32 != 0 && d.K >= 32 && (!d.a_kmajor || d.M % 4 == 0) && (!d.b_kmajor || d.N % 4 == 0) &&
          (d.a_kmajor || d.lda >= k4) && (d.b_kmajor || d.ldb >= k4) && d.conv_mode == 0;
@@ -1318,13 +1318,13 @@ static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
   const long tiles = (long)cdiv(d.M, 64) * cdiv(d.N, 64) * nbatch;
   // tile variant: two LDS stages (32 KB, five blocks per CU cover each other's epilogues).  The K-step-split variant
   // (cfg 7) wins isolated one-block-per-CU launches by 5-8 % but loses inside the two-stream step (end-to-end A/B).
-  // TAVSR_GEMM_CFG=<id> overrides the choice (tuning aid).
-  static const int forced = [] { const char* e = getenv("TAVSR_GEMM_CFG"); return e ? atoi(e) : -1; }();
+  // (tavsr_gemm_tune forces a variant for tests / sweeps)
+  constexpr int forced = -1;
   auto variant = [&](long blocks) { (void)blocks; return !fast ? kFallbackCfg : forced >= 0 ? forced : 8; };
   p.cfg = variant(tiles);
   if (!allow_split || tiles >= 384 || d.K < 512) return p;
   if (d.K <= 1024 && tiles >= 150) return p;
-  static const long target = [] { const char* e = getenv("TAVSR_SPLIT_TARGET"); return e ? atol(e) : 1000L; }();   // tuning aid
+  constexpr long target = 1000L;   // tuning aid
   long want = std::min<long>((target + tiles / 2) / tiles, d.K / 256);
   if (want < 2) return p;
   p.kchunk = cdiv(cdiv(d.K, want), 32) * 32;
@@ -1335,15 +1335,15 @@ static Plan plan(const tavsr_gemm_desc& d, bool allow_split, bool fast) {
 }
 
 // plan of an implicit-convolution launch: the weight gradient (mode 2) has an enormous K = frames*H*W and few tiles, so K
-// is split until all five block slots of every CU are filled (the slabs stay tiny); TAVSR_CONV_DW_BLOCKS tunes the target
+// is split until all five block slots of every CU are filled (the slabs stay tiny)
 static Plan plan_conv(const tavsr_gemm_desc& d, bool can_split) {
   Plan pc = plan(d, can_split, true);
   if ((d.conv_mode == 2 || d.conv_mode == 5 || d.conv_mode == 7) && can_split) {
-    static const int dw_wide = [] { const char* e = getenv("TAVSR_CONV_DW_TILE"); return e ? atoi(e) : 1; }();
+    constexpr int dw_wide = 1;
     const bool wide = d.conv_mode == 2 && dw_wide && d.M % 128 == 0;     // 128x64 tiles (launch_conv): three block slots per CU
     const long tiles = (long)cdiv(d.M, wide ? 128 : 64) * cdiv(d.N, 64);
-    static const long target64 = [] { const char* e = getenv("TAVSR_CONV_DW_BLOCKS"); return e ? atol(e) : 2560L; }();
-    static const long target128 = [] { const char* e = getenv("TAVSR_CONV_DW_BLOCKS_WIDE"); return e ? atol(e) : 2304L; }();
+    constexpr long target64 = 2560L;
+    constexpr long target128 = 2304L;
     const long target = wide ? target128 : target64;
     const long want = std::min<long>(std::max<long>(1, target / tiles), d.K / 512);
     if (want > pc.nsplit) {

@@ -163,13 +163,18 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
 
 int supported(const tavsr_bf_layer_desc* d, const char* who) {
   TAVSR_REQUIRE(d, TAVSR_EINVAL, "%s: null descriptor", who);
-  TAVSR_REQUIRE(d->B > 0 && d->T > 0 && d->D == 256 && d->H > 0 && d->D / d->H == 64 && d->ffn_units >= 1024 &&
-                    d->ffn_units % 32 == 0 && d->cg_units % 128 == 0 && d->cg_kernel == 31 && tavsr_merge_proj_ok(d->T, d->D),
-                TAVSR_EUNSUPPORTED, "%s: d_model 256, 64-wide heads, hidden >= 1024, cgMLP kernel 31, T <= 2048 only", who);
+  TAVSR_REQUIRE(tavsr_branchformer_layer_ok(d->B, d->T, d->D, d->H, d->ffn_units, d->cg_units, d->cg_kernel), TAVSR_EUNSUPPORTED,
+                "%s: d_model 256, 64-wide heads, hidden >= 1024, cgMLP kernel 31, T <= 2048 only", who);
   return TAVSR_OK;
 }
 
 }  // namespace
+
+extern "C" int tavsr_branchformer_layer_ok(int32_t B, int32_t T, int32_t D, int32_t H, int32_t ffn_units, int32_t cg_units,
+                                          int32_t cg_kernel) {
+  return B > 0 && T > 0 && D == 256 && H > 0 && D / H == 64 && D % H == 0 && ffn_units >= 1024 && ffn_units % 32 == 0 &&
+         cg_units > 0 && cg_units % 128 == 0 && cg_kernel == 31 && tavsr_merge_proj_ok(T, D);
+}
 
 extern "C" int64_t tavsr_branchformer_layer_ws(const tavsr_bf_layer_desc* d) {
   if (supported(d, "branchformer_layer_ws")) return 0;

@@ -4,7 +4,8 @@
 // Before: row dots (5.6 us) -> softmaxes + weighted sum per 16-row block (6.1 us) -> a 3168 x 256 x 256 GEMM launch at 0.15 of
 // the fp32 MFMA peak (17-29 us), three dependent launches at the one point of the layer where nothing else can run.
 //
-// One workgroup = 16 consecutive frames of one utterance (grid: ceil(T / 16) x B; 224 workgroups at B = 32, T = 99):
+// One workgroup = 16 consecutive frames of one utterance (8 ceil(T / 16) ceil(B / 8) workgroups, 224 at B = 32, T = 99;
+// the workgroups of an utterance share an XCD):
 //   phase 0  the four dot products per frame of the WHOLE utterance (<wp_k, x_k[t]>, <ww_k, x_k[t]>; 16 lanes per row, four
 //            rows per wave instruction, every load of a batch in flight before the first reduction) - every workgroup of an
 //            utterance recomputes them (the rows come from L2: 200 KB per utterance) instead of waiting for a launch that does;
@@ -59,8 +60,32 @@ __global__ __launch_bounds__(256) void merge_proj_fwd_kernel(const MpArgs a) {
   __shared__ float s_w[2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l16 = lane & 15, q = lane >> 4;
-  const int b = blockIdx.y, ch = blockIdx.x;
+  // consecutive workgroup ids go to consecutive XCDs: the ceil(T / 16) workgroups of an utterance - which all read its rows in
+  // phase 0 - are dealt to ONE XCD (utterance b lives on XCD b % 8), so the rows cross the fabric once and come from that L2 after
+  const int nch = (T + MP_R - 1) / MP_R;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = xcd + 8 * (slot / nch), ch = slot % nch;
+  if (b >= a.B) return;
   const int64_t M = (int64_t)a.B * T, r0 = (int64_t)b * T;
+  const int row = tid >> 4, t_row = ch * MP_R + row;
+  const bool row_ok = t_row < T;
+  const int64_t orow = (r0 + min(t_row, T - 1)) * MP_D + 4 * l16;
+
+  // ---- everything that depends on nothing is in flight before the first wait: the first quarter of this wave's weight rows
+  //      (B operand of phase 3), the thread's share of the block's own rows (phase 2) and of the residual rows (phase 4)
+  const float* wbase = a.w + (int64_t)(64 * wv + l16) * MP_D + 4 * q;
+  float4 bfr[2][4][4];                     // [buffer][n tile][g within the quarter]
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bfr[0][nt][g] = *reinterpret_cast<const float4*>(wbase + (int64_t)nt * 16 * MP_D + 16 * g);
+  float4 own1[4], own2[4], resv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    own1[j] = *reinterpret_cast<const float4*>(a.x1 + orow + 64 * j);
+    own2[j] = *reinterpret_cast<const float4*>(a.x2 + orow + 64 * j);
+    resv[j] = a.res ? *reinterpret_cast<const float4*>(a.res + orow + 64 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   // ---- phase 0: dots of every frame of the utterance
   {
@@ -72,7 +97,7 @@ __global__ __launch_bounds__(256) void merge_proj_fwd_kernel(const MpArgs a) {
       ww1[j] = *reinterpret_cast<const float4*>(a.ww[0] + c); ww2[j] = *reinterpret_cast<const float4*>(a.ww[1] + c);
     }
     const int nq = (T + 3) >> 2;                       // row quads; wave wv takes quads wv, wv + 4, ...
-    constexpr int NB = 4;                              // quads per batch (8 NB 16-byte loads in flight per lane)
+    constexpr int NB = 7;                              // quads per batch (8 NB 16-byte loads in flight per lane: T <= 112 is one batch)
     for (int q0 = wv; q0 < nq; q0 += 4 * NB) {
       float4 xa[NB][4], xc[NB][4];
 #pragma unroll
@@ -141,45 +166,46 @@ __global__ __launch_bounds__(256) void merge_proj_fwd_kernel(const MpArgs a) {
     const int k = tid / MP_R, t = ch * MP_R + tid % MP_R;
     if (t < T) a.score[((int64_t)k * a.B + b) * T + t] = s_s[k * T + t];
   }
-  // ---- phase 2: the block's mixed rows
-  const int row = tid >> 4, t_row = ch * MP_R + row;
-  {
-    const bool ok = t_row < T;
-    const int64_t o = (r0 + min(t_row, T - 1)) * MP_D + 4 * l16;
+  // ---- phase 2: the block's mixed rows (from the registers loaded at the top)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 xa = *reinterpret_cast<const float4*>(a.x1 + o + 64 * j), xc = *reinterpret_cast<const float4*>(a.x2 + o + 64 * j);
-      float4 m = make_float4(w0 * xa.x + w1 * xc.x, w0 * xa.y + w1 * xc.y, w0 * xa.z + w1 * xc.z, w0 * xa.w + w1 * xc.w);
-      if (!ok) m = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(s_m + row * MP_LD + 4 * l16 + 64 * j) = m;
-      if (ok && a.mix) *reinterpret_cast<float4*>(a.mix + o + 64 * j) = m;
-    }
+  for (int j = 0; j < 4; ++j) {
+    float4 m = make_float4(w0 * own1[j].x + w1 * own2[j].x, w0 * own1[j].y + w1 * own2[j].y, w0 * own1[j].z + w1 * own2[j].z,
+                           w0 * own1[j].w + w1 * own2[j].w);
+    if (!row_ok) m = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(s_m + row * MP_LD + 4 * l16 + 64 * j) = m;
+    if (row_ok && a.mix) *reinterpret_cast<float4*>(a.mix + orow + 64 * j) = m;
   }
   __syncthreads();
-  // ---- phase 3: [16 x 256] x W^T, wave wv -> columns 64 wv ..
+  // ---- phase 3: [16 x 256] x W^T, wave wv -> columns 64 wv ..; the weight rows arrive a quarter of K ahead of their MFMAs
   f32x4 acc[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* wbase = a.w + (int64_t)(64 * wv + l16) * MP_D + 4 * q;
+  {
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    float4 bf[4][8], af[8];
+    for (int qt = 0; qt < 4; ++qt) {
+      const int cur = qt & 1;
+      if (qt + 1 < 4) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int g = 0; g < 8; ++g) bf[nt][g] = *reinterpret_cast<const float4*>(wbase + (int64_t)nt * 16 * MP_D + 16 * (8 * hf + g));
+          for (int g = 0; g < 4; ++g)
+            bfr[cur ^ 1][nt][g] = *reinterpret_cast<const float4*>(wbase + (int64_t)nt * 16 * MP_D + 16 * (4 * (qt + 1) + g));
+      }
+      float4 af[4];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) af[g] = *reinterpret_cast<const float4*>(s_m + l16 * MP_LD + 16 * (8 * hf + g) + 4 * q);
+      for (int g = 0; g < 4; ++g) af[g] = *reinterpret_cast<const float4*>(s_m + l16 * MP_LD + 16 * (4 * qt + g) + 4 * q);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const float av[4] = {af[g].x, af[g].y, af[g].z, af[g].w};
+      for (int g = 0; g < 4; ++g) {
+        const float av[4] = {af[g].x, af[g].y, af[g].z, af[g].w};
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const float bv = jj == 0 ? bf[nt][g].x : jj == 1 ? bf[nt][g].y : jj == 2 ? bf[nt][g].z : bf[nt][g].w;
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv, acc[nt], 0, 0, 0);
-        }
+          for (int nt = 0; nt < 4; ++nt) {
+            const float4 bw = bfr[cur][nt][g];
+            const float bv = jj == 0 ? bw.x : jj == 1 ? bw.y : jj == 2 ? bw.z : bw.w;
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv, acc[nt], 0, 0, 0);
+          }
+      }
     }
   }
   // ---- phase 4: image, epilogue
@@ -188,7 +214,7 @@ __global__ __launch_bounds__(256) void merge_proj_fwd_kernel(const MpArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_o[(4 * q + r) * MP_LD + 64 * wv + 16 * nt + l16] = acc[nt][r];
   __syncthreads();
-  if (t_row < T) {
+  if (row_ok) {
     const int64_t mrow = r0 + t_row;
     const uint64_t sd = a.thr ? a.seed[0] : 0;
 #pragma unroll
@@ -204,11 +230,7 @@ __global__ __launch_bounds__(256) void merge_proj_fwd_kernel(const MpArgs a) {
         v.x = wd[0] >= a.thr ? v.x * a.inv_keep : 0.f; v.y = wd[1] >= a.thr ? v.y * a.inv_keep : 0.f;
         v.z = wd[2] >= a.thr ? v.z * a.inv_keep : 0.f; v.w = wd[3] >= a.thr ? v.w * a.inv_keep : 0.f;
       }
-      v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
-      if (a.res) {
-        const float4 rr = *reinterpret_cast<const float4*>(a.res + mrow * MP_D + n);
-        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-      }
+      v.x = v.x * a.alpha + resv[j].x; v.y = v.y * a.alpha + resv[j].y; v.z = v.z * a.alpha + resv[j].z; v.w = v.w * a.alpha + resv[j].w;
       *reinterpret_cast<float4*>(a.out + mrow * MP_D + n) = v;
     }
   }
@@ -247,7 +269,7 @@ extern "C" int tavsr_merge_proj_fwd(const float* x1, const float* x2, const int6
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_proj_fwd_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);     // T = 2048: 66 KB
   TAVSR_REQUIRE(attr == hipSuccess || lds <= 64 * 1024, TAVSR_EUNSUPPORTED, "merge_proj_fwd: %zu bytes of LDS not available", lds);
-  hipLaunchKernelGGL(merge_proj_fwd_kernel, dim3(cdiv(T, MP_R), B), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(merge_proj_fwd_kernel, dim3(8 * cdiv(T, MP_R) * cdiv(B, 8)), dim3(256), lds, (hipStream_t)stream, a);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -61,12 +61,6 @@ class AttnDesc(C.Structure):
     ]
 
 
-class Lin2Seg(C.Structure):
-    """tavsr_lin2_seg (include/tavsr.h)"""
-    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64), ("z", C.c_void_p),
-                ("ldz", C.c_int64), ("n", C.c_int32)]
-
-
 class BfLayerDesc(C.Structure):
     """tavsr_bf_layer_desc (include/tavsr.h): field order is the header's"""
     _P = C.c_void_p

@@ -70,7 +70,7 @@ def _plan_env(name, default):
 # 64x128 tiles read dz0 twice instead of four times (the launch is HBM-bound: 12.7 GB -> 9.5 GB); +0.35 % on the AV step
 # against the planner's 64x64 / 250 slices (in-call A/B).  TAVSR_STEM_DW_PLAN=0 returns to the planner.
 STEM_DW_PLAN = _plan_env("TAVSR_STEM_DW_PLAN", (3, 512))
-STEM_POOL_FUSED = os.environ.get("TAVSR_STEM_POOL_FUSED", "1") == "1"      # A/B switch
+STEM_POOL_FUSED = True
 
 
 class _BN:
@@ -477,16 +477,9 @@ class TailoredStreamFn(torch.autograd.Function):
         return (dx.view(B, T, D), None, None, None, *[G[n] for n in ctx.names])
 
 
-# One feed-forward call for BOTH modality streams: the tailored layer's FFNs and three of its norms are shared by the streams
-# (src/encoder/audiovisual/tailored/encoder_layer.py:84-111, 171-175, 211-216, 220-222, 259-264), so the audio and the video
-# rows go through them as ONE [Ma + Mv, 256] problem ("one GEMM with M = 2 B T") - the streaming feed-forward kernel
-# then streams every weight once for both streams, and in the backward pass the shared parameters' gradients come out of
-# K = Ma + Mv contractions directly instead of as two partial results that are added.
-# Measured (profiles/r03_notes.md, in-call A/B on the batch-32 AV step): 363.5-364.3 utt/s joint against 367.2-367.5 per stream -
-# the per-stream form keeps two independent launch queues (the audio stream's blocks fill the LayerNorm-prologue and
-# finishing phases of the video stream's and vice versa), which is worth more than the shared weight stream.  So the joint
-# form is built, parity-tested (tests/test_gpu_av.py) and OFF by default; TAVSR_AV_JOINT_FFN=1 selects it.
-AV_JOINT_FFN = os.environ.get("TAVSR_AV_JOINT_FFN", "0") == "1"
+# (One feed-forward call for BOTH modality streams - the shared FFNs as one [Ma + Mv, 256] problem, SURVEY a9 - was built and
+# measured in round 3: 363.5-364.3 utt/s against 367.2-367.5 per stream on the batch-32 AV step, profiles/r03_notes.md section 3;
+# the per-stream form keeps two launch queues whose kernels fill each other's prologue / finishing phases.  Removed in round 4.)
 
 
 class TailoredLayerFn(torch.autograd.Function):
@@ -504,98 +497,18 @@ class TailoredLayerFn(torch.autograd.Function):
         na, nv = len(names_a), len(names_v)
         ns = len(TS_SHARED)
         Pa, Pv = P[:na], P[:ns] + P[na: na + nv - ns]
-        D = audio.shape[-1]
-        if (AV_JOINT_FFN and audio.is_cuda and cfg_a.get("p", 0.0) == cfg_v.get("p", 0.0)
-                and ops.ffn2_usable(audio.reshape(-1, D), Pa[names_a.index("feed_forward.w_1.weight")], cfg_a["ffn_act"])):
-            return TailoredLayerFn._forward_joint(ctx, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, dict(zip(names_a, Pa)),
-                                                  dict(zip(names_v, Pv)), names_a, names_v, need)
         ca, cv = types.SimpleNamespace(), types.SimpleNamespace()
         br = ops.BranchScope(audio.is_cuda)
         with br:
             yv = TailoredStreamFn.forward(cv, video, vpos, vlens, cfg_v, *Pv)
         ya = TailoredStreamFn.forward(ca, audio, apos, alens, cfg_a, *Pa)
         br.join()
-        ctx.joint = None
         ctx.ca, ctx.cv, ctx.n = ca, cv, (ns, na, nv)
         return ya, yv
 
     @staticmethod
-    def _forward_joint(ctx, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, pa, pv, names_a, names_v, need):
-        (Ba, Ta, D), (Bv, Tv, _) = audio.shape, video.shape
-        Ma, Mv = Ba * Ta, Bv * Tv
-        act, pd = cfg_a["ffn_act"], cfg_a.get("p", 0.0)
-        xcat = ops.empty(Ma + Mv, D, like=audio)
-        ops.multi_copy_([xcat[:Ma], xcat[Ma:]], [audio.contiguous().view(Ma, D), video.contiguous().view(Mv, D)])
-        bna = "norm_mha" if cfg_a["use_attn"] else "norm_cgmlp"
-        bnv = "norm_mha" if cfg_v["use_attn"] else "norm_cgmlp"
-        # the macaron block for all rows; its finishing launch normalises them with BOTH streams' branch norms (each stream
-        # then reads its rows of its own output)
-        x1, sv_ffm, (n_a, n_v), mean, rstd = _FFN.fwd_ln(xcat, *[pa[k] for k in _FFM], act, 0.5,
-                                                         [(pa[bna + ".weight"], pa[bna + ".bias"]),
-                                                          (pv[bnv + ".weight"], pv[bnv + ".bias"])], p=pd, save=need)
-        sl = lambda t, lo, hi: None if t is None else t[lo:hi]
-        br = ops.BranchScope(True)
-        with br:
-            x2v, sv_brv = _ts_branch_fwd(pv, cfg_v, x1[Ma:], n_v[Ma:], sl(mean, Ma, Ma + Mv), sl(rstd, Ma, Ma + Mv), vpos, vlens,
-                                         Bv, Tv, need)
-        x2a, sv_bra = _ts_branch_fwd(pa, cfg_a, x1[:Ma], n_a[:Ma], sl(mean, 0, Ma), sl(rstd, 0, Ma), apos, alens, Ba, Ta, need)
-        br.join()
-        x2cat = ops.empty(Ma + Mv, D, like=audio)
-        ops.multi_copy_([x2cat[:Ma], x2cat[Ma:]], [x2a, x2v])
-        del x2a, x2v
-        x3, sv_ff, (ycat,), fmean, frstd = _FFN.fwd_ln(x2cat, *[pa[k] for k in _FF], act, 0.5,
-                                                       [(pa["norm_final.weight"], pa["norm_final.bias"])], p=pd, save=need)
-        ctx.joint = dict(pa=pa, pv=pv, names_a=names_a, names_v=names_v, cfg_a=cfg_a, cfg_v=cfg_v, ffm=sv_ffm, ff=sv_ff, bra=sv_bra,
-                         brv=sv_brv, x1=x1, final=(x3, fmean, frstd), apos=apos, vpos=vpos, alens=alens, vlens=vlens,
-                         shapes=((Ba, Ta, D), (Bv, Tv, D)))
-        return ycat[:Ma].view(Ba, Ta, D), ycat[Ma:].view(Bv, Tv, D)
-
-    @staticmethod
-    def _backward_joint(ctx, dya, dyv):
-        J = ctx.joint
-        pa, pv, cfg_a, cfg_v = J["pa"], J["pv"], J["cfg_a"], J["cfg_v"]
-        (Ba, Ta, D), (Bv, Tv, _) = J["shapes"]
-        Ma, Mv = Ba * Ta, Bv * Tv
-        act = cfg_a["ffn_act"]
-        G, Ga, Gv = {}, {}, {}
-        grp, lng = ops.WgradGroup(), ops.LNGroup()          # the shared parameters: K = Ma + Mv contractions
-        dycat = ops.empty(Ma + Mv, D, like=dya)
-        ops.multi_copy_([dycat[:Ma], dycat[Ma:]], [dya.contiguous().view(Ma, D), dyv.contiguous().view(Mv, D)])
-        x3, fmean, frstd = J["final"]
-        dx3, G["norm_final.weight"], G["norm_final.bias"] = lng.bwd(dycat, x3, fmean, frstd, pa["norm_final.weight"])
-        dx2, gs = _FFN.bwd(dx3, J["ff"], pa["norm_ff.weight"], pa["feed_forward.w_1.weight"], pa["feed_forward.w_2.weight"], act,
-                           0.5, grp=grp, lng=lng)
-        G.update(zip(_FF, gs))
-        x1 = J["x1"]
-        br = ops.BranchScope(True)
-        with br:
-            grp_v, lng_v = ops.WgradGroup(), ops.LNGroup()
-            dx1v = _ts_branch_bwd(pv, cfg_v, J["brv"], dx2[Ma:], x1[Ma:], J["vpos"], J["vlens"], Bv, Tv, grp_v, lng_v, Gv)
-            grp_v.flush()
-            lng_v.flush()
-        grp_a, lng_a = ops.WgradGroup(), ops.LNGroup()
-        dx1a = _ts_branch_bwd(pa, cfg_a, J["bra"], dx2[:Ma], x1[:Ma], J["apos"], J["alens"], Ba, Ta, grp_a, lng_a, Ga)
-        grp_a.flush()
-        lng_a.flush()
-        br.join()
-        dx1cat = ops.empty(Ma + Mv, D, like=dya)
-        ops.multi_copy_([dx1cat[:Ma], dx1cat[Ma:]], [dx1a.contiguous(), dx1v.contiguous()])
-        del dx1a, dx1v
-        dx, gs = _FFN.bwd(dx1cat, J["ffm"], pa["norm_ff_macaron.weight"], pa["feed_forward_macaron.w_1.weight"],
-                          pa["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng)
-        G.update(zip(_FFM, gs))
-        grp.flush()
-        lng.flush()
-        ns = len(TS_SHARED)
-        ctx.joint = None
-        return (dx[:Ma].view(Ba, Ta, D), None, None, None, dx[Ma:].view(Bv, Tv, D), None, None, None, *[G[n] for n in TS_SHARED],
-                *[Ga[n] for n in J["names_a"][ns:]], *[Gv[n] for n in J["names_v"][ns:]])
-
-    @staticmethod
     @guarded
     def backward(ctx, dya, dyv):
-        if ctx.joint is not None:
-            return TailoredLayerFn._backward_joint(ctx, dya, dyv)
         ns, na, nv = ctx.n
         br = ops.BranchScope(dya.is_cuda)
         dyv = dyv.contiguous()
@@ -622,7 +535,7 @@ class _Ctx:
 
 # Run two independent nodes side by side?  TAVSR_FRONT_PAIR=0 keeps them as two nodes on one stream (A/B switch).
 import os as _os
-FRONT_PAIR = _os.environ.get("TAVSR_FRONT_PAIR", "1") == "1"
+FRONT_PAIR = True
 
 
 class FrontendPairFn(torch.autograd.Function):

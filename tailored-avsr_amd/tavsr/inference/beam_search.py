@@ -38,11 +38,10 @@ def _cat(ws):
 
 # One-token scorer steps are chains of small launches: the fused feed-forward block (LayerNorm + both GEMMs, csrc/ffn.hip)
 # and the fused source attention cut the chain.  TAVSR_DECODE_FUSED=0 keeps the GEMM launches (A/B switch).
-FUSED_STEP = os.environ.get("TAVSR_DECODE_FUSED", "1") == "1"
-SCORERS_PARALLEL = os.environ.get("TAVSR_DECODE_PARALLEL", "1") == "1"   # decoder || LM on two streams
-TREE_GROUP = int(os.environ.get("TAVSR_DECODE_TREE_GROUP", "1"))     # beams of an utterance side by side in the tree attention
-PREBEAM_FUSED = os.environ.get("TAVSR_DECODE_PREBEAM", "1") == "1"   # pre-beam top-k inside the CTC prefix launch
-FUSED_FFN = os.environ.get("TAVSR_DECODE_FUSED_FFN", "0") == "1"      # measured: 153 vs 166 utt/s at batch 64 (in-call A/B): off
+FUSED_STEP = True
+SCORERS_PARALLEL = True   # decoder || LM on two streams (TAVSR_SINGLE_STREAM=1 disables every fork)
+TREE_GROUP = 1     # beams of an utterance side by side in the tree attention
+PREBEAM_FUSED = True   # pre-beam top-k inside the CTC prefix launch
 
 
 def _ln_linear(x, norm, w, b, act=None):
@@ -62,11 +61,9 @@ def _linear_res(x, w, b, res):
 
 def _ffn_step(x, norm, L):
     """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows."""
-    if ops.rowlin_ok(x, L["w1"]) and not FUSED_FFN:
+    if ops.rowlin_ok(x, L["w1"]):
         t = ops.rowlin(x, L["w1"], L["b1"], ln=(norm[0], norm[1], EPS), act="relu")
         return _linear_res(t, L["w2"], L["b2"], x)
-    if FUSED_FFN and x.shape[1] in (256, 512) and L["w1"].shape[0] % 128 == 0:
-        return ops.ffn_fwd(x, norm[0], norm[1], EPS, L["w1"], L["b1"], L["w2"], L["b2"], "relu", 1.0, save=False)[0]
     n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
     t = ops.linear(n, L["w1"], L["b1"], act="relu")
     return ops.linear(t, L["w2"], L["b2"], res=x)

@@ -83,7 +83,7 @@ class ErrorCalculator:
         return cer, wer
 
 
-LOSS_BRANCH = os.environ.get("TAVSR_LOSS_BRANCH", "1") == "1"      # A/B switch: CTC branch beside the attention decoder
+LOSS_BRANCH = True      # CTC branch beside the attention decoder (TAVSR_SINGLE_STREAM=1 disables every fork)
 
 
 def cut_to_longest(x: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:

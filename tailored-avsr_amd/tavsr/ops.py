@@ -151,10 +151,6 @@ def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=Non
         ldc = N
     z = empty(M, N, like=x) if save_z else None
     assert not save_z or (out_off == 0 and ldc == N)
-    if (rowstat is None and res is None and alpha == 1.0 and force is None and N >= LIN2_MIN_N and ldc == out.stride(0)
-            and lin2_usable(x, [w])):
-        lin2_fwd(x, [(w, b, out, out_off, z)], act=act)
-        return (out, z) if save_z else out
     gemm(M, N, K, x, x.stride(0), w, w.stride(0), out, ldc, c_off=out_off, bias=b, act=act, alpha=alpha, Z=z,
          R=res, ldr=0 if res is None else res.stride(0), force=force, rowstat=rowstat)
     return (out, z) if save_z else out
@@ -173,12 +169,10 @@ def linear_dx(dy, w, *, alpha=1.0, DZ=None, dact=None, res=None, out=None, force
 
 # Dropout fused into GEMM epilogues (tavsr_gemm_desc.drop_*): same mask as the stand-alone kernels draw for the contiguous
 # [M, N] result, so a fused forward pairs with a stand-alone backward and vice versa.  TAVSR_GEMM_DROP=0: separate launches.
-GEMM_DROP = os.environ.get("TAVSR_GEMM_DROP", "1") == "1"
 
 
 def _drop_fusable(x, N, K) -> bool:
-    return (GEMM_DROP and N % 4 == 0 and K % 32 == 0 and K >= 32 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
-            and os.environ.get("TAVSR_GEMM_VEC_EPI", "1") == "1")
+    return N % 4 == 0 and K % 32 == 0 and K >= 32 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
 
 
 def linear_drop(x, w, b, p, *, act=None, alpha=1.0, res=None, save_z=False):
@@ -239,7 +233,6 @@ def linear_dx_cat(dy_cat, ws, *, res=None, out=None):
 
 # The two Branchformer branches (attention | cgMLP) are independent between the fork after the macaron FFN and the
 # merge: the attention branch is a chain of small latency-bound launches that fits beside the cgMLP GEMMs.
-BRANCH_SIDE_STREAM = os.environ.get("TAVSR_BRANCH_STREAM", "1") == "1"
 
 
 _BRANCH = {}
@@ -248,7 +241,7 @@ _BRANCH = {}
 def forks_enabled() -> bool:
     """TAVSR_SINGLE_STREAM=1 (or ``_lib.SINGLE_STREAM = True`` at run time) puts every launch of the package on the calling
     stream - the reference's queueing; results must not depend on it (tests/test_gpu_streams.py)."""
-    return BRANCH_SIDE_STREAM and not L.SINGLE_STREAM
+    return not L.SINGLE_STREAM
 
 
 def branch_stream(main: torch.cuda.Stream) -> torch.cuda.Stream:
@@ -432,9 +425,6 @@ def linear_group(x, wbs, out, ldc=None):
     list of (w_j, b_j, column offset of y_j in ``out``); out rows have stride ``ldc``.  Falls back to one GEMM per
     projection when the grouped kernel cannot take the problems (alignment / K % 32) - same results."""
     M, K = x.shape
-    if (ldc is None or ldc == out.stride(0)) and lin2_usable(x, [w for w, _, _ in wbs]):
-        lin2_fwd(x, [(w, b, out, off, None) for w, b, off in wbs])
-        return out
     ldc = out.stride(0) if ldc is None else ldc
     require_cuda(x, out)
     arr = (GemmDesc * len(wbs))()
@@ -454,34 +444,6 @@ def linear_group(x, wbs, out, ldc=None):
         return out
     check(rc, "tavsr_gemm_grouped")
     return out
-
-
-# Linear layers of a d_model = 256 input as one streaming launch (csrc/lin2.hip): the rows stay in registers, the weights stream
-# through an LDS ring shared by a workgroup's four waves.  OFF by default (TAVSR_LIN2=1 routes linear_group and the wide
-# linear() calls to it): alone on the chip it is as fast as the tiled GEMM or a little faster (query / key / value projections
-# 22.4 -> 20.6 us), but the layer runs its attention branch BESIDE its cgMLP branch, and a kernel that owns every CU's LDS does
-# not share the chip: 12-layer forward 3.72 -> 3.84 ms (profiles/r03_notes.md).
-LIN2 = os.environ.get("TAVSR_LIN2", "0") == "1"
-LIN2_MIN_N = int(os.environ.get("TAVSR_LIN2_MIN_N", "512"))     # a single matrix narrower than this stays on the GEMM
-
-
-def lin2_usable(x, ws) -> bool:
-    return (LIN2 and PROFILE is None and x.dim() == 2 and x.shape[1] == 256 and x.stride(1) == 1 and x.stride(0) % 4 == 0
-            and x.data_ptr() % 16 == 0 and len(ws) <= 4 and all(w.shape[0] % 32 == 0 and w.is_contiguous() for w in ws))
-
-
-def lin2_fwd(x, segs, act=None):
-    """out_j[:, off_j : off_j + n_j] = act(x @ w_j.T + b_j) for every (w_j, b_j, out_j, off_j, z_j) of ``segs`` (z_j: tensor
-    [M, n_j] that receives the pre-activations, or None - for all or for none)."""
-    from ._lib import Lin2Seg
-    M, K = x.shape
-    arr = (Lin2Seg * len(segs))()
-    for d, (w, b, out, off, z) in zip(arr, segs):
-        require_cuda(x, w, b, out, z)
-        d.w, d.b, d.n = _addr(w), (_addr(b)), w.shape[0]
-        d.out, d.ldo = _addr(out, off), out.stride(0)
-        d.z, d.ldz = (None, 0) if z is None else (_addr(z), z.stride(0))
-    check(lib().tavsr_lin2_fwd(ptr(x), C.c_int64(x.stride(0)), M, K, arr, len(segs), ACT[act], stream()), "tavsr_lin2_fwd")
 
 
 def colsum(x, *, scale=1.0, out=None, accumulate=False):
@@ -554,7 +516,7 @@ def layernorm_bwd_act(dy, x, mean, rstd, gamma, z, act, *, dx=None):
     return dx, dg, db
 
 
-LN_BWD_DROP = os.environ.get("TAVSR_LN_BWD_DROP", "1") == "1"      # A/B switch: masked gradient copy from the LayerNorm backward
+LN_BWD_DROP = True      # masked gradient copy from the LayerNorm backward (tests flip it in-process to compare with the dropout launch)
 
 
 class LNGroup:
@@ -677,7 +639,7 @@ def softmax_bwd(attn, dattn, scale, skew=False, T2=None, token=None):
 
 # Fused attention core (csrc/attn_fused.hip): scores, rel_shift, mask, softmax, dropout and the context product in one
 # launch per direction.  TAVSR_ATTN_FUSED=0 keeps the GEMM + softmax chain (A/B switch; also the path for head sizes != 64).
-ATTN_FUSED = os.environ.get("TAVSR_ATTN_FUSED", "1") == "1"
+ATTN_FUSED = True
 
 
 def _attn_desc(q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk, klens, causal, pos, bias_u, bias_v, token):
@@ -731,66 +693,11 @@ def attn_bwd(dctx, ctx, lse, tok, q, q_off, k, k_off, v, v_off, B, T1, T2, H, dk
     return dqv, sk
 
 
-# Fused feed-forward block (csrc/ffn.hip): LayerNorm + both GEMMs of a direction in one launch.  Correct and tested
-# (tests/test_gpu_ffn.py) but OFF by default: at M = 3168 it measures 101 us forward / 122 us backward per block against
-# ~105 / ~112 us for the LayerNorm + GEMM + GEMM + dropout launches it replaces, and the audio-only step 1430 vs 1507 utt/s
-# (in-call A/B, profiles/r02_ffn_fusion_notes.md) - fp32 MFMA bound either way, and 99 row tiles x 4 hidden splits fill
-# the 512 workgroup slots to 77 % only.  TAVSR_FFN_FUSED=1 selects it.
-FFN_FUSED = os.environ.get("TAVSR_FFN_FUSED", "0") == "1"
-
-
-def ffn_fusable(x, w1, act) -> bool:
-    return (FFN_FUSED and x.shape[1] in (256, 512) and w1.shape[0] % 128 == 0 and x.is_contiguous()
-            and act in ("relu", "swish"))
-
-
-def ffn_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=0.0, save=True):
-    """y = x + scale * dropout(w2 dropout(act(w1 LN(x) + b1)) + b2) -> (y, saved) with saved = (n, mean, rstd, z, h, tok_in,
-    tok_out) (tensors None when ``save`` is false)."""
-    M, D = x.shape
-    N1 = w1.shape[0]
-    require_cuda(x, ln_w, ln_b, w1, b1, w2, b2)
-    assert w1.is_contiguous() and w2.is_contiguous() and w1.shape == (N1, D) and w2.shape == (D, N1)
-    y = empty(M, D, like=x)
-    n = mean = rstd = z = h = None
-    if save:
-        n, mean, rstd = empty(M, D, like=x), empty(M, like=x), empty(M, like=x)
-        Mp = (M + 31) // 32 * 32          # whole 32-row tiles are stored
-        z, h = empty(Mp, N1, like=x)[:M], empty(Mp, N1, like=x)[:M]
-    tok_in = tok_out = None
-    if p and p > 0.0:
-        tok_in = _new_token(p, (M + 3) // 4 * 4 * N1, x.device)
-        tok_out = _new_token(p, M * D, x.device)
-    ws = empty(lib_i64("tavsr_ffn_ws", M, D, N1), like=x)
-    check(lib().tavsr_ffn_fwd(ptr(x), C.c_int64(x.stride(0)), ptr(ln_w), ptr(ln_b), C.c_float(eps), ptr(w1), ptr(b1), ptr(w2),
-                              ptr(b2), ACT[act], C.c_float(scale), M, D, N1, C.c_float(p or 0.0),
-                              ptr(tok_in[2] if tok_in else None), C.c_uint64(tok_in[1] if tok_in else 0),
-                              C.c_uint64(tok_out[1] if tok_out else 0), ptr(n), ptr(mean), ptr(rstd), ptr(z), ptr(h), ptr(y),
-                              ptr(ws), stream()), "tavsr_ffn_fwd")
-    return y, (n, mean, rstd, z, h, tok_in, tok_out)
-
-
-def ffn_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
-    """(dz [M, N1], dn [M, D]) of the fused block: dz = ((alpha * dyd) w2) * mask / keep * act'(z), dn = dz w1."""
-    M, D = dyd.shape
-    N1 = w1.shape[0]
-    require_cuda(dyd, w1, w2, z)
-    dz, dn = empty((M + 31) // 32 * 32, N1, like=dyd)[:M], empty(M, D, like=dyd)
-    ws = empty(lib_i64("tavsr_ffn_ws", M, D, N1), like=dyd)
-    w1t = transpose_inner(w1, 1, N1, D)          # [D, N1]: both products of the chain read k-contiguous weight rows
-    w2t = transpose_inner(w2, 1, D, N1)          # [N1, D]
-    check(lib().tavsr_ffn_bwd_dx(ptr(dyd), C.c_int64(dyd.stride(0)), C.c_float(alpha), ptr(w1t), ptr(w2t), ptr(z), ACT[act], M, D,
-                                 N1, C.c_float(tok_in[0] if tok_in else 0.0), ptr(tok_in[2] if tok_in else None),
-                                 C.c_uint64(tok_in[1] if tok_in else 0), ptr(dz), ptr(dn), ptr(ws), stream()),
-          "tavsr_ffn_bwd_dx")
-    return dz, dn
-
-
 # Streaming feed-forward block (csrc/ffn2.hip, round 3): LayerNorm prologue + both GEMMs in one launch whose weights stream
 # through per-wave LDS-DMA rings, + a finishing launch that can also emit the LayerNorms the consumers of y start with.
-# TAVSR_FFN2=0 keeps the LayerNorm + GEMM + GEMM launches.
-FFN2 = os.environ.get("TAVSR_FFN2", "1") == "1"
-FFN2_BWD = os.environ.get("TAVSR_FFN2_BWD", "1") == "1"      # the dgrad pair of the block as the streaming kernel too
+# Shapes it does not take keep the LayerNorm + GEMM + GEMM launches; tests flip these two in-process to compare the routes.
+FFN2 = True
+FFN2_BWD = True      # the dgrad pair of the block as the streaming kernel too
 
 
 def ffn2_usable(x, w1, act) -> bool:
@@ -866,8 +773,8 @@ def ffn2_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
 
 # One Branchformer layer forward as ONE C call (csrc/layer.hip): the same launches, sequenced in C.  For un-captured loops
 # (the host is what limits an eager step); a captured step replays the same kernels either way.  TAVSR_LAYER_C=0: Python sequencing.
-LAYER_C = os.environ.get("TAVSR_LAYER_C", "1") == "1"
-LAYER_C_EAGER_ONLY = os.environ.get("TAVSR_LAYER_C_CAPTURE", "0") != "1"     # 1: also while a hipGraph is being captured
+LAYER_C = os.environ.get("TAVSR_LAYER_C", "1") != "0"
+LAYER_C_EAGER_ONLY = os.environ.get("TAVSR_LAYER_C", "1") != "capture"     # TAVSR_LAYER_C=capture: also while a hipGraph is being captured
 _BR_EVENTS = {}
 
 
@@ -929,8 +836,8 @@ def dwconv_gate_fwd(gn, r, w, bias, B, T):
     return out, conv
 
 
-CSGU_FUSED = os.environ.get("TAVSR_CSGU_FUSED", "1") == "1"
-CSGU_STATS_IN_GEMM = os.environ.get("TAVSR_CSGU_STATS_IN_GEMM", "1") == "1"     # A/B switch
+CSGU_FUSED = True
+CSGU_STATS_IN_GEMM = True
 
 
 def csgu_usable(g, w) -> bool:
@@ -940,7 +847,7 @@ def csgu_usable(g, w) -> bool:
 def csgu_rowstat_ok(x, w1) -> bool:
     """can channel_proj1's GEMM leave the CSGU's LayerNorm statistics (tavsr_gemm_desc.rowstat)?  (16-byte path, gate half of
     at most 1024 channels in whole 64-column tiles)"""
-    return (CSGU_STATS_IN_GEMM and PROFILE is None and not LIN2 and os.environ.get("TAVSR_GEMM_VEC_EPI", "1") == "1"
+    return (CSGU_STATS_IN_GEMM and PROFILE is None 
             and w1.is_contiguous() and w1.shape[0] % 128 == 0 and w1.shape[0] <= 2048
             and x.shape[1] % 32 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
@@ -964,7 +871,7 @@ def csgu_fwd(g, ln_w, ln_b, eps, w, bias, B, T, p=0.0, save=True, rowstat=None):
     return out, conv, gn, mean, rstd, tok
 
 
-CGMLP_ACT_BWD_FUSED = os.environ.get("TAVSR_CGMLP_ACT_BWD_FUSED", "1") == "1"   # A/B switch: gelu' in the CSGU's two backward kernels
+CGMLP_ACT_BWD_FUSED = True   # gelu' in the CSGU's two backward kernels
 
 
 def dwconv_gate_bwd(du, gn, r, conv, w, dr, B, T, zr=None, act="gelu"):
@@ -1000,7 +907,7 @@ def merge_pool_fwd(x1, x2, lens, params, B, T, lens2=None):
     return score, pooled, w
 
 
-MERGE_ROWS = os.environ.get("TAVSR_MERGE_ROWS", "1") == "1"      # A/B switch: the row-parallel learned_ave merge launches
+MERGE_ROWS = True      # the row-parallel learned_ave merge launches (D = 256; tests flip it in-process to compare the routes)
 
 
 def merge_rows_ok(T, D) -> bool:
@@ -1021,10 +928,8 @@ def merge_fwd(x1, x2, lens, params, B, T, lens2=None):
         check(lib().tavsr_merge_rows_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(dots), ptr(score), ptr(w),
                                          ptr(out), B, T, D, stream()), "tavsr_merge_rows_fwd")
         return score, dots, w, out
-    pooled = empty(2, B, D, like=x1)
-    check(lib().tavsr_merge_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(score), ptr(pooled), ptr(w),
-                                ptr(out), B, T, D, stream()), "tavsr_merge_fwd")
-    return score, pooled, w, out
+    score, pooled, w = merge_pool_fwd(x1, x2, lens, params, B, T, lens2=lens2)     # other widths: one workgroup per utterance
+    return score, pooled, w, merge_combine(x1, x2, w, B, T)
 
 
 MERGE_PROJ = os.environ.get("TAVSR_MERGE_PROJ", "1") == "1"      # A/B switch: merge + merge_proj + residual as one launch
@@ -1229,7 +1134,7 @@ def col2im2d(dcol, N, H, W, Cn, KH, KW, stride, pad, extra=None):
 
 # Conv3d stem as an implicit GEMM (tavsr_gemm_desc.conv_mode 4 / 5): no 6 GB patch matrix.  TAVSR_STEM_IMPLICIT=0 returns to
 # im2col_stem + plain GEMMs (A/B switch; also the route for shapes the gather loader does not take).
-STEM_IMPLICIT = os.environ.get("TAVSR_STEM_IMPLICIT", "1") == "1"
+STEM_IMPLICIT = True
 
 
 def stem_implicit_ok(x) -> bool:
@@ -1241,7 +1146,7 @@ def stem_implicit_ok(x) -> bool:
 
 # Default stem route: zero-padded clips + taps laid out 35 x 8, fetched with the GEMM's ordinary 16-byte LDS-DMA (conv_mode 6 / 7).
 # TAVSR_STEM_PAD16=0: the 4-byte gather route (conv_mode 4 / 5, no padded copy of the clips).
-STEM_PAD16 = os.environ.get("TAVSR_STEM_PAD16", "1") == "1"
+STEM_PAD16 = True
 
 
 def stem_pad16_ok(x) -> bool:
@@ -1602,7 +1507,7 @@ def bootstrap_rates(dist, reflen, iters, seed):
 
 
 # ---------------------------------------------------------------------------------------------- decode steps
-ROWLIN = os.environ.get("TAVSR_DECODE_ROWLIN", "1") == "1"
+ROWLIN = True
 
 
 def rowlin_ok(x, w, n_rows=None) -> bool:

@@ -170,23 +170,12 @@ def _masks(g, T):
     return (ar < alens[:, None])[:, None, :], (ar < vlens[:, None])[:, None, :]
 
 
-@pytest.fixture
-def _restore_joint():
-    from tavsr import functional_av as FA
-    keep = FA.AV_JOINT_FFN
-    yield
-    FA.AV_JOINT_FFN = keep
-
-
-@pytest.mark.parametrize("joint", [True, False])      # both streams' rows through the shared FFNs in one call / per stream
 @pytest.mark.parametrize("tag,ua,uv", [("aa", [True], [True]), ("ac", [True], [False]), ("ca", [False], [True]),
                                        ("cc", [False], [False])])
-def test_tailored_layer_vs_reference_golden(tag, ua, uv, joint, _restore_joint):
+def test_tailored_layer_vs_reference_golden(tag, ua, uv):
     from oracle.model import compact, synth
-    from tavsr import functional_av as FA
     from tavsr.encoder.audiovisual.tailored.encoder import TailoredEncoder
     from tavsr.layers import RelPositionalEncoding
-    FA.AV_JOINT_FFN = joint
     g = golden(f"av_tailored_layer_{tag}")
     B, T, D = int(g["B"]), int(g["T"]), int(g["D"])
     enc = TailoredEncoder("rel_pos", "latest", num_blocks=1, dropout_rate=0.0, positional_dropout_rate=0.0,
