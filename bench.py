@@ -362,6 +362,10 @@ def main():
     ap.add_argument("--split-backward", action="store_true",
                     help="replay the step as two hipGraphs around the model's dp.cut also with one rank (the N > 1 default)")
     ap.add_argument("--no-split-backward", action="store_true", help="N > 1: one hipGraph per step, all buckets leave after it")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="--gpus 1 only: drive a ONE-rank RCCL communicator through the whole exchange path (tavsr_dp_allreduce on the "
+                         "communication stream, bucket pack / unpack, with --split-backward between the two graph replays) - a rehearsal "
+                         "of the N > 1 step's plumbing on one GPU; the line says so in config.grad_exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="all dropout rates 0 (the parity configuration)")
@@ -399,7 +403,7 @@ def main():
 
     from tavsr import dp, ops
 
-    rank, local, world = dp.init_from_env()
+    rank, local, world = dp.init_from_env(force_rccl=args.force_rccl)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", local)
@@ -570,7 +574,7 @@ def main():
                      "ms_per_step": round(1e3 * el_s / n_sus, 3), "seconds": round(el_s, 2),
                      "note": "same step, run back to back right after the timed region"}
     exposed_ms = None
-    if world > 1:
+    if world > 1 or dp.FORCE_WORLD1:
         # stream time of the exchange that nothing hides (pack + all-reduce + unpack behind the last gradient): a few steps
         # with one event pair each, outside the timed region
         pairs = []
@@ -610,7 +614,8 @@ def main():
                    "launch": "eager" if graph is None else ("hipGraph replay (whole fwd+bwd)" if graph_b is None else
                                                             f"two hipGraphs (fwd + upper bwd | lower bwd), {n_ready} of "
                                                             f"{len(buckets.buckets)} buckets exchanged under the second"),
-                   "grad_exchange": ("none (1 GPU)" if world == 1 else
+                   "grad_exchange": ("tavsr_dp_allreduce (RCCL, world 1: one-GPU rehearsal of the exchange path), 64 MB flat buckets"
+                                     if dp.FORCE_WORLD1 else "none (1 GPU)" if world == 1 else
                                      ("tavsr_dp_allreduce (RCCL, C ABI)" if dp.RCCL_ABI else
                                       f"torch.distributed all_reduce ({'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()})")
                                      + (", staged through pinned host buffers" if torch.distributed.get_backend() == "gloo"
@@ -672,6 +677,9 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
+        dp.shutdown()
+    elif dp.FORCE_WORLD1:
+        torch.cuda.synchronize()
         dp.shutdown()
 
 

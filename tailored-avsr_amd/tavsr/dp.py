@@ -21,6 +21,16 @@ import torch.distributed as dist
 from ._lib import addr as L_addr, ptr as L_ptr
 
 RCCL_ABI = False          # set by init_from_env once tavsr_dp_init has succeeded on this rank
+FORCE_WORLD1 = False      # rehearsal: a ONE-rank RCCL communicator driven through the whole exchange path (init_from_env(force_rccl=True))
+
+
+def _world() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def _exchange_on() -> bool:
+    """is there a gradient exchange to run?  (N > 1 ranks, or the one-rank RCCL rehearsal)"""
+    return FORCE_WORLD1 or (dist.is_initialized() and dist.get_world_size() > 1)
 
 
 def _rccl_init(rank: int, world: int, device: torch.device) -> bool:
@@ -48,7 +58,19 @@ def _rccl_init(rank: int, world: int, device: torch.device) -> bool:
     return True
 
 
-def init_from_env(backend: str | None = None, seed: int | None = 0) -> tuple[int, int, int]:
+def _rccl_init_world1(device: torch.device) -> None:
+    """a communicator with ONE rank through the C ABI (no torch.distributed involved): every call of the exchange path then
+    runs for real - id, init, all-reduce kernels on the communication stream - without a second GPU."""
+    global RCCL_ABI, FORCE_WORLD1
+    from ._lib import check, lib
+    torch.cuda.set_device(device)
+    buf = (C.c_char * 128)()
+    check(lib().tavsr_dp_unique_id(buf), "tavsr_dp_unique_id")
+    check(lib().tavsr_dp_init(0, 1, C.c_char_p(buf.raw)), "tavsr_dp_init")
+    RCCL_ABI = FORCE_WORLD1 = True
+
+
+def init_from_env(backend: str | None = None, seed: int | None = 0, force_rccl: bool = False) -> tuple[int, int, int]:
     """(rank, local_rank, world) from the torch.distributed.run environment; initialises the group.
 
     ``seed`` (None: leave the generators alone): every rank seeds its generators with ``seed + rank`` - the device
@@ -82,6 +104,8 @@ def init_from_env(backend: str | None = None, seed: int | None = 0) -> tuple[int
             if mine and not RCCL_ABI:                         # joined here but not everywhere: give the communicator back
                 from ._lib import lib
                 lib().tavsr_dp_destroy()
+    if world == 1 and force_rccl and torch.cuda.is_available() and not RCCL_ABI:
+        _rccl_init_world1(torch.device("cuda", local))
     if seed is not None:
         torch.manual_seed(int(seed) + rank)
         if torch.cuda.is_available():
@@ -92,11 +116,11 @@ def init_from_env(backend: str | None = None, seed: int | None = 0) -> tuple[int
 
 def shutdown():
     """frees the C ABI's communicator and the process group."""
-    global RCCL_ABI
+    global RCCL_ABI, FORCE_WORLD1
     if RCCL_ABI:
         from ._lib import check, lib
         check(lib().tavsr_dp_destroy(), "tavsr_dp_destroy")
-        RCCL_ABI = False
+        RCCL_ABI = FORCE_WORLD1 = False
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -184,7 +208,7 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
         self._hook_streams = {}
-        self._armed = dist.is_initialized() and dist.get_world_size() > 1
+        self._armed = _exchange_on()
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -208,9 +232,9 @@ class GradBuckets:
         On the GPU a bucket is packed and unpacked by ONE launch each (``tavsr_bucket_copy`` over a pointer table; the
         1/world average rides on the unpack) and the flat buffers persist across steps; all buckets are packed and their
         all-reduces issued before the first wait.  CPU tensors (gloo tests) take the torch path."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not _exchange_on():
             return
-        world = dist.get_world_size()
+        world = _world()
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -367,7 +391,7 @@ class GradBuckets:
         """pack buckets ``_next .. n-1`` and enqueue their all-reduces now (GPU tensors; their gradients must exist): what follows
         on the compute stream runs beside them, ``allreduce_mean`` issues the rest and completes all.  Every rank must call it
         with the same ``n`` - the issue order stays 0, 1, 2, ..."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not _exchange_on():
             return
         for b in self.buckets[self._next: n]:                  # (as allreduce_mean: a rank that skipped a layer sends zeros)
             for p in b:
@@ -390,7 +414,7 @@ class GradBuckets:
         coins, so a rank may never produce some layer's gradients at all).  A hook therefore only marks its bucket complete;
         bucket i is enqueued when buckets 0 .. i-1 have been (as torch DDP does), and ``allreduce_mean`` enqueues the rest
         in index order - every rank issues 0, 1, 2, ... whatever its gradients looked like."""
-        if self._hooked or not (dist.is_initialized() and dist.get_world_size() > 1):
+        if self._hooked or not _exchange_on():
             return
         self._hooked = True
         index = self._index = {id(p): i for i, b in enumerate(self.buckets) for p in b}

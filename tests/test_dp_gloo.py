@@ -318,3 +318,96 @@ def test_rccl_c_abi_single_rank_roundtrip():
     assert torch.equal(x, want)
     check(lib().tavsr_dp_destroy(), "tavsr_dp_destroy")
     assert lib().tavsr_dp_world() == 0
+
+
+@pytest.mark.gpu
+def test_two_graph_step_with_the_real_collective_between_the_replays_world1():
+    """The N > 1 step's flow on one GPU, with RCCL itself (a one-rank communicator, tavsr.dp.init_from_env(force_rccl=True)):
+    graph A (forward + backward above the cut) -> pack + tavsr_dp_allreduce of the early buckets on the communication stream
+    -> graph B (backward below the cut) -> the late buckets -> unpack.  Three replays; loss and every gradient stay bit-equal
+    to one eager loss.backward() (a one-rank sum is the identity, 1 / world = 1), the eager hook-driven exchange too."""
+    import argparse
+    sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import asr_conf
+    from oracle.model import synth
+    from tavsr import dp, ops
+    from tavsr.tasks.asr import ASRTask
+    torch.cuda.set_device(0)
+    model = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=4, dec_blocks=2, dropout=0.1)))
+    torch.manual_seed(0)
+    model = model.cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    text = synth((8, 30), seed=2, kind="int", lo=1, hi=40)
+    batch = [synth((8, 400, 80), seed=1).cuda(), torch.full((8,), 400).cuda(), text.cuda(), torch.full((8,), 30).cuda()]
+
+    def eager():
+        ops.manual_seed(99)
+        for p in params:
+            p.grad = None
+        loss = model(*batch)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.grad.detach().clone() for p in params]
+
+    ref_loss, ref = eager()
+    assert not dp.FORCE_WORLD1
+    dp.init_from_env(seed=None, force_rccl=True)
+    try:
+        assert dp.RCCL_ABI and dp.FORCE_WORLD1 and dp._exchange_on()
+        buckets = dp.GradBuckets(params, bucket_bytes=8 << 20)
+        buckets.attach_overlap_hooks()
+        # eager loop: the hooks enqueue the collectives under the backward pass
+        ops.manual_seed(99)
+        for p in params:
+            p.grad = None
+        buckets.begin_step()
+        loss = model(*batch)[0]
+        loss.backward()
+        buckets.allreduce_mean()
+        torch.cuda.synchronize()
+        assert torch.equal(loss.detach(), ref_loss)
+        assert all(torch.equal(p.grad, g) for p, g in zip(params, ref))
+        # (the eager pass's graph must be gone before a capture: its AccumulateGrad nodes belong to the default stream, and
+        # autograd re-uses a parameter's node for as long as anything keeps it alive)
+        del loss
+        # captured loop: two graphs around the cut, the exchange between and behind them
+        buckets.overlap = False
+        two = dp.TwoPhaseBackward()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for p in params:
+                p.grad = None
+            with two.forward():
+                warm = model(*batch)[0]
+            late = two.late_params(params)
+            two.phase_a(warm)
+            two.phase_b()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert late and len(late) < len(params)
+        for p in params:
+            p.grad = None
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            with two.forward():
+                static_loss = model(*batch)[0]
+            two.phase_a(static_loss)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            two.phase_b()
+        n_ready = buckets.replan(late)
+        assert 0 < n_ready < len(buckets.buckets)
+        for rep in range(3):
+            ops.manual_seed(99)
+            ga.replay()
+            buckets.launch_prefix(n_ready)
+            gb.replay()
+            buckets.allreduce_mean()
+            torch.cuda.synchronize()
+            assert torch.equal(static_loss.detach(), ref_loss), rep
+            bad = [n for (n, p), g in zip(model.named_parameters(), ref) if not torch.equal(p.grad, g)]
+            assert not bad, (rep, bad[:6])
+    finally:
+        dp.shutdown()
+    assert not dp.RCCL_ABI and not dp.FORCE_WORLD1
