@@ -58,6 +58,30 @@ def _rccl_init(rank: int, world: int, device: torch.device) -> bool:
     return True
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    """RCCL prints a version banner to the C library's stdout when a communicator is created; programs whose stdout is a
+    protocol (bench.py: ONE JSON line) must not carry it.  Inside this scope file descriptor 1 is descriptor 2, and the C
+    library's buffer is flushed before the descriptor comes back."""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def _rccl_init_world1(device: torch.device) -> None:
     """a communicator with ONE rank through the C ABI (no torch.distributed involved): every call of the exchange path then
     runs for real - id, init, all-reduce kernels on the communication stream - without a second GPU."""
@@ -71,6 +95,17 @@ def _rccl_init_world1(device: torch.device) -> None:
 
 
 def init_from_env(backend: str | None = None, seed: int | None = 0, force_rccl: bool = False) -> tuple[int, int, int]:
+    """(see _init_from_env; communicator creation runs with the C library's stdout pointed at stderr)"""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or force_rccl:
+        with _c_stdout_to_stderr():
+            out = _init_from_env(backend, seed, force_rccl)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            return out
+    return _init_from_env(backend, seed, force_rccl)
+
+
+def _init_from_env(backend: str | None = None, seed: int | None = 0, force_rccl: bool = False) -> tuple[int, int, int]:
     """(rank, local_rank, world) from the torch.distributed.run environment; initialises the group.
 
     ``seed`` (None: leave the generators alone): every rank seeds its generators with ``seed + rank`` - the device
