@@ -347,6 +347,31 @@ int tavsr_branchformer_layer_ok(int32_t B, int32_t T, int32_t D, int32_t H, int3
 int64_t tavsr_branchformer_layer_ws(const tavsr_bf_layer_desc* d);
 int tavsr_branchformer_layer_fwd(const tavsr_bf_layer_desc* d, tavsr_stream_t stream);
 
+/* The backward pass of the same layer as ONE call (autograd of MyBranchformerEncoderLayer.forward,
+ * src/encoder/branchformer/encoder_layer.py:153-321): `fwd` is the descriptor of a tavsr_branchformer_layer_fwd call made with
+ * save = 1 (its parameters, dropout offsets and kept buffers), dy the gradient of its output y.  Writes dx and every parameter
+ * gradient (torch layouts, overwritten, not accumulated); the five d_model LayerNorms' gradients come as g_ln [5][2][D] =
+ * (dgamma | dbeta) of norm_final, norm_ff, norm_mlp, norm_mha, norm_ff_macaron.  Same launches, same order and the same grouping
+ * (all eleven weight gradients in one grouped launch, one reduction for the five LayerNorms) as the caller-side sequencing of
+ * the primitive entry points: bit-identical results.  ws >= tavsr_branchformer_layer_bwd_ws(b) floats; fwd->stream2 /
+ * ev_fork / ev_join are used as in the forward call (attention-branch backward beside the cgMLP-branch backward). */
+typedef struct tavsr_bf_layer_bwd_desc {
+  const tavsr_bf_layer_desc* fwd;
+  const float* dy;                 /* [B*T][D] */
+  float* dx;                       /* [B*T][D] */
+  float *g_ffm_w1, *g_ffm_b1, *g_ffm_w2, *g_ffm_b2;
+  float *g_wq, *g_bq, *g_wk, *g_bk, *g_wv, *g_bv, *g_wo, *g_bo, *g_wpos, *g_pos_u, *g_pos_v;
+  float *g_cg_w1, *g_cg_b1, *g_csgu_ln_w, *g_csgu_ln_b, *g_csgu_cw, *g_csgu_cb, *g_cg_w2, *g_cg_b2;
+  float* g_merge_p[8];             /* in the order of fwd->merge_p */
+  float *g_merge_w, *g_merge_b;
+  float *g_ff_w1, *g_ff_b1, *g_ff_w2, *g_ff_b2;
+  float* g_ln;                     /* [5][2][D] */
+  float* ws;
+  int64_t ws_floats;
+} tavsr_bf_layer_bwd_desc;
+int64_t tavsr_branchformer_layer_bwd_ws(const tavsr_bf_layer_bwd_desc* b);
+int tavsr_branchformer_layer_bwd(const tavsr_bf_layer_bwd_desc* b, tavsr_stream_t stream);
+
 /* Elementwise helpers: out = a*x + b*y (y may be NULL); strided 2-D form; dz = dh * act'(z). */
 int tavsr_axpby(const float* x, const float* y, float a, float b, float* out, int64_t n, tavsr_stream_t stream);
 int tavsr_axpby2d(const float* x, int64_t ldx, const float* y, int64_t ldy, float a, float b, float* out,

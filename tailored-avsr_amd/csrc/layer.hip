@@ -202,3 +202,319 @@ extern "C" int tavsr_branchformer_layer_fwd(const tavsr_bf_layer_desc* d, tavsr_
   }
   return sequence(d, (hipStream_t)stream, ws);
 }
+
+// ---------------------------------------------------------------------------------------------- backward
+// tavsr_branchformer_layer_bwd: what tavsr/functional.py:BranchformerLayerFn.backward enqueues (autograd of
+// MyBranchformerEncoderLayer.forward, src/encoder/branchformer/encoder_layer.py:153-321) as one C call over the same entry
+// points, in the same order, with the same grouping of the weight gradients (one grouped launch at the end) and of the five
+// d_model LayerNorms' (dgamma, dbeta) reductions - results are bit-identical to the Python sequencing.
+namespace {
+
+struct WItem { const float* dy; int64_t lddy; const float* x; int64_t ldx; int rows, N, K; float alpha; float *out, *gb; };
+
+struct WGroup {        // tavsr/ops.py:WgradGroup
+  WItem it[16];
+  int n = 0;
+  void add(const float* dy, int64_t lddy, const float* x, int64_t ldx, int rows, int N, int K, float alpha, float* out, float* gb) {
+    it[n++] = WItem{dy, lddy, x, ldx, rows, N, K, alpha, out, gb};
+  }
+  static tavsr_gemm_desc desc(const WItem& w) {
+    tavsr_gemm_desc g;
+    memset(&g, 0, sizeof g);
+    g.M = w.N; g.N = w.K; g.K = w.rows;
+    g.a_kmajor = g.b_kmajor = 1;
+    g.A = w.dy; g.lda = w.lddy; g.B = w.x; g.ldb = w.ldx; g.C = w.out; g.ldc = w.K;
+    g.nb1 = g.nb2 = 1;
+    g.alpha = w.alpha;
+    g.a_rowsum = w.gb;
+    return g;
+  }
+  static long tiles(const WItem& w) { return (long)cdiv(w.N, 64) * cdiv(w.K, 64); }
+  int flush(Bump& ws, hipStream_t s) {
+    bool keep[16];
+    for (int i = 0; i < n; ++i) keep[i] = true;
+    long total = 0;
+    for (int i = 0; i < n; ++i) total += tiles(it[i]);
+    int rc;
+    if (n <= 12 && total > 256 && total % 256) {      // shed the fewest small problems down to a multiple of 256 tiles
+      const long target = total / 256 * 256;
+      int order[16];
+      for (int i = 0; i < n; ++i) order[i] = i;
+      for (int i = 1; i < n; ++i)                       // stable, descending by tiles
+        for (int j = i; j > 0 && tiles(it[order[j]]) > tiles(it[order[j - 1]]); --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+      bool shed[16];
+      for (int i = 0; i < n; ++i) shed[i] = false;
+      long tot = total;
+      int nshed = 0;
+      for (int o = 0; o < n; ++o) {
+        const int i = order[o];
+        if (tiles(it[i]) <= tot - target) { tot -= tiles(it[i]); shed[i] = true; ++nshed; }
+      }
+      if (tot == target && nshed <= 2)
+        for (int i = 0; i < n; ++i)
+          if (shed[i]) {
+            keep[i] = false;
+            tavsr_gemm_desc g = desc(it[i]);
+            if ((rc = run_gemm(g, ws, s))) return rc;
+          }
+    }
+    tavsr_gemm_desc arr[12];
+    int m = 0;
+    for (int i = 0; i <= n; ++i) {
+      if (i < n && keep[i]) arr[m++] = desc(it[i]);
+      if (m == 12 || (i == n && m > 0)) {
+        if (!ws.dry) {
+          rc = m > 1 ? tavsr_gemm_grouped(arr, m, (tavsr_stream_t)s) : TAVSR_EUNSUPPORTED;
+          if (rc == TAVSR_EUNSUPPORTED) {
+            for (int j = 0; j < m; ++j)
+              if ((rc = run_gemm(arr[j], ws, s))) return rc;
+          } else if (rc) {
+            return rc;
+          }
+        } else {
+          for (int j = 0; j < m; ++j) { const int64_t need = tavsr_gemm_ws(&arr[j]); if (need > 0) ws.take(need); }
+        }
+        m = 0;
+      }
+    }
+    n = 0;
+    return TAVSR_OK;
+  }
+};
+
+struct LnGroup {       // tavsr/ops.py:LNGroup for the five d_model LayerNorms of a layer
+  float* slab = nullptr;
+  int64_t slab_ld = 0;
+  int nb = 0, k = 0, M = 0, D = 0;
+  float* out = nullptr;      // [5][2][D]
+  int bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_add, float* dx,
+          float* dx_drop, float p, const uint64_t* seed, uint64_t off, bool dry, hipStream_t s) {
+    float* part = dry ? nullptr : slab + (int64_t)k * 2 * D;
+    ++k;
+    if (dry) return TAVSR_OK;
+    if (dx_drop)
+      return tavsr_layernorm_bwd_partial_drop(dy, D, x, D, mean, rstd, gamma, dx_add, dx_add ? D : 0, dx, D, part, slab_ld, M, D, dx_drop, p,
+                                              seed, off, (tavsr_stream_t)s);
+    return tavsr_layernorm_bwd_partial(dy, D, x, D, mean, rstd, gamma, dx_add, dx_add ? D : 0, dx, D, part, slab_ld, M, D, (tavsr_stream_t)s);
+  }
+  int flush(bool dry, hipStream_t s) {
+    if (dry || !k) return TAVSR_OK;
+    return tavsr_sum_partials(slab, nb, slab_ld, out, k * 2 * D, 0, (tavsr_stream_t)s);
+  }
+};
+
+// backward of one feed-forward residual block (tavsr/functional.py:_FFN.bwd, streaming dgrad pair): dyd = dy under the block's outer
+// mask (== dy without dropout); returns dx (+ dx under `out_drop` when the next block wants it) through the LayerNorm group
+int ffn_bwd(const tavsr_bf_layer_desc* f, const float* dy, const float* dyd, const float* x, const float* mean, const float* rstd,
+            const float* n, const float* z, const float* h, const float* ln_w, const float* w1, const float* w2, uint64_t off_in,
+            float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* dx, float* dx_drop, uint64_t off_next, WGroup& grp, LnGroup& lng,
+            Bump& ws, hipStream_t s) {
+  const int M = f->B * f->T, D = f->D, N1 = f->ffn_units, Mp = (M + 127) / 128 * 128;
+  int rc;
+  grp.add(dyd, D, h, N1, M, D, N1, 0.5f, g_w2, g_b2);
+  float* dz = ws.take((int64_t)Mp * N1);
+  float* dn = ws.take((int64_t)M * D);
+  const int64_t nws = tavsr_ffn2_ws(M, D, N1);
+  float* fws = ws.take(nws);
+  TAVSR_REQUIRE(ws.dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_bwd: workspace too small");
+  if (!ws.dry && (rc = tavsr_ffn2_bwd_dx(dyd, D, 0.5f, w1, w2, z, f->ffn_act, M, D, N1, f->p_drop, f->p_drop > 0.f ? f->seed : nullptr, off_in, dz, dn,
+                                         fws, nws, (tavsr_stream_t)s)))
+    return rc;
+  grp.add(dz, N1, n, D, M, N1, D, 1.f, g_w1, g_b1);
+  return lng.bwd(dn, x, mean, rstd, ln_w, dy, dx, dx_drop, f->p_drop, f->seed, off_next, ws.dry, s);
+}
+
+int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
+  const tavsr_bf_layer_desc* d = b->fwd;
+  const int B = d->B, T = d->T, M = B * T, D = d->D, H = d->H, dk = D / H, C2 = d->cg_units, Cn = C2 / 2, W = 2 * T - 1, Wp = (W + 3) / 4 * 4;
+  const bool dry = ws.dry, drop = d->p_drop > 0.f;
+  hipStream_t s2 = (hipStream_t)d->stream2;
+  const uint64_t* seed = drop || d->p_att > 0.f ? d->seed : nullptr;
+  int rc;
+  auto mat = [&](int64_t n) { return ws.take(n); };
+  WGroup grp;
+  LnGroup lng;
+  lng.M = M; lng.D = D;
+  lng.nb = (int)(tavsr_layernorm_bwd_ws(M, D) / (2 * D));
+  lng.slab_ld = 8 * 2 * D;
+  lng.slab = mat((int64_t)lng.nb * lng.slab_ld);
+  lng.out = b->g_ln;
+  float* g_ln = b->g_ln;
+  // ---- norm_final; the feed-forward block (its outer mask rides in norm_final's backward, merge_proj's in its own LayerNorm's)
+  float* dx3 = mat((int64_t)M * D);
+  float* dyd = drop ? mat((int64_t)M * D) : nullptr;
+  float* dx2 = mat((int64_t)M * D);
+  float* dxd = drop ? mat((int64_t)M * D) : nullptr;
+  TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_bwd: workspace too small");
+  if ((rc = lng.bwd(b->dy, d->x3, d->fin_mean, d->fin_rstd, d->final_ln_w, nullptr, dx3, dyd, d->p_drop, seed, d->drop_off[8], dry, s))) return rc;
+  if ((rc = ffn_bwd(d, dx3, drop ? dyd : dx3, d->x2, d->ff_mean, d->ff_rstd, d->ff_n, d->ff_z, d->ff_h, d->ff_ln_w, d->ff_w1, d->ff_w2,
+                    d->drop_off[7], b->g_ff_w1, b->g_ff_b1, b->g_ff_w2, b->g_ff_b2, dx2, dxd, d->drop_off[6], grp, lng, ws, s)))
+    return rc;
+  // ---- merge_proj, learned-average merge (dxa / dxm come back under the branch outputs' masks)
+  const float* dmp = drop ? dxd : dx2;
+  grp.add(dmp, D, d->m, D, M, D, D, d->coeff, b->g_merge_w, b->g_merge_b);
+  float* dm = mat((int64_t)M * D);
+  float* dxa = mat((int64_t)M * D);
+  float* dxm = mat((int64_t)M * D);
+  {
+    tavsr_gemm_desc g = lin(M, D, D, dmp, D, d->merge_w, nullptr, dm, D);
+    g.b_kmajor = 1; g.ldb = D; g.alpha = d->coeff;
+    if ((rc = run_gemm(g, ws, s))) return rc;
+    const int64_t nws = tavsr_merge_rows_bwd_ws(B, T, D);
+    float* mws = mat(nws);
+    float* dparams[8] = {b->g_merge_p[0], b->g_merge_p[1], b->g_merge_p[4], b->g_merge_p[5],
+                         b->g_merge_p[2], b->g_merge_p[3], b->g_merge_p[6], b->g_merge_p[7]};
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_bwd: workspace too small");
+    if (!dry && (rc = tavsr_merge_rows_bwd(dm, d->xa, d->xm, d->lens, nullptr, d->merge_p, d->score, d->wts, d->pooled, dxa, dxm, dparams, 0, mws,
+                                           d->p_drop, d->drop_off[3], d->p_drop, d->drop_off[5], seed, B, T, D, (tavsr_stream_t)s)))
+      return rc;
+  }
+  // ---- attention branch on the second queue
+  float* dn_a = mat((int64_t)M * D);
+  {
+    if (!dry) {
+      TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_fork, s));
+      TAVSR_HIP_CHECK(hipStreamWaitEvent(s2, (hipEvent_t)d->ev_fork, 0));
+      if ((rc = probe_fork(s2, s, false))) return rc;
+    }
+    grp.add(dxa, D, d->cx, D, M, D, D, 1.f, b->g_wo, b->g_bo);
+    float* dcx = mat((int64_t)M * D);
+    tavsr_gemm_desc g = lin(M, D, D, dxa, D, d->wo, nullptr, dcx, D);
+    g.b_kmajor = 1; g.ldb = D;
+    if ((rc = run_gemm(g, ws, s2))) return rc;
+    float* dqkv = mat((int64_t)M * 3 * D);
+    float* dqu = mat((int64_t)M * D);
+    float* dqv = mat((int64_t)M * D);
+    float* sk = mat((int64_t)H * B * T * Wp);
+    float* qu = mat((int64_t)M * D);
+    float* qv = mat((int64_t)M * D);
+    float* dp = mat((int64_t)W * D);
+    float* csws = mat(2 * tavsr_colsum_ws(M, D));
+    float* wcat = mat((int64_t)3 * D * D);
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_bwd: workspace too small");
+    if (!dry) {
+      if ((rc = tavsr_fill(sk, 0.f, (int64_t)H * B * T * Wp, (tavsr_stream_t)s2))) return rc;      // the kernel writes the band of every row
+      tavsr_attn_desc a;
+      memset(&a, 0, sizeof a);
+      a.q = d->qkv; a.k = d->qkv + D; a.v = d->qkv + 2 * D;
+      a.ldq = a.ldk = a.ldv = 3 * D;
+      a.pos = d->pp; a.ldp = D; a.bias_u = d->pos_u; a.bias_v = d->pos_v; a.klens = d->lens;
+      a.B = B; a.H = H; a.T1 = a.T2 = T; a.dk = dk;
+      a.scale = 1.f / sqrtf((float)dk);
+      if (d->p_att > 0.f) { a.p_drop = d->p_att; a.seed_dev = d->seed; a.drop_offset = d->drop_off[2]; }
+      if ((rc = tavsr_attn_bwd(&a, dcx, d->cx, D, d->lse, dqu, dqv, D, dqkv + D, 3 * D, dqkv + 2 * D, 3 * D, sk, Wp, (tavsr_stream_t)s2))) return rc;
+      // dP[:, h] = sum_b ds_skew[h, b]^T (q + v)[b, :, h]: one K = B T contraction per head
+      if ((rc = tavsr_add_head_bias(d->qkv, 3 * D, d->pos_u, d->pos_v, qu, qv, M, D, (tavsr_stream_t)s2))) return rc;
+    }
+    {
+      tavsr_gemm_desc gp;
+      memset(&gp, 0, sizeof gp);
+      gp.M = W; gp.N = dk; gp.K = M;
+      gp.a_kmajor = gp.b_kmajor = 1;
+      gp.A = sk; gp.lda = Wp; gp.B = qv; gp.ldb = D; gp.C = dp; gp.ldc = D;
+      gp.nb1 = H; gp.nb2 = 1;
+      gp.sA1 = (int64_t)M * Wp; gp.sB1 = dk; gp.sC1 = dk;
+      gp.alpha = 1.f;
+      if ((rc = run_gemm(gp, ws, s2))) return rc;
+    }
+    if (!dry && (rc = tavsr_add2_colsum(dqu, D, dqv, D, dqkv, 3 * D, M, D, b->g_pos_u, b->g_pos_v, csws, (tavsr_stream_t)s2))) return rc;
+    {
+      tavsr_gemm_desc gw;       // linear_pos.weight: K = 2T - 1 is not a multiple of 32, it stays alone
+      memset(&gw, 0, sizeof gw);
+      gw.M = D; gw.N = D; gw.K = W;
+      gw.a_kmajor = gw.b_kmajor = 1;
+      gw.A = dp; gw.lda = D; gw.B = d->pos_emb; gw.ldb = D; gw.C = b->g_wpos; gw.ldc = D;
+      gw.nb1 = gw.nb2 = 1;
+      gw.alpha = 1.f;
+      if ((rc = run_gemm(gw, ws, s2))) return rc;
+    }
+    grp.add(dqkv, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wq, b->g_bq);
+    grp.add(dqkv + D, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wk, b->g_bk);
+    grp.add(dqkv + 2 * D, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wv, b->g_bv);
+    if (!dry) {
+      void* dst[3] = {wcat, wcat + (int64_t)D * D, wcat + (int64_t)2 * D * D};
+      const void* src[3] = {d->wq, d->wk, d->wv};
+      const int64_t nbytes[3] = {(int64_t)D * D * 4, (int64_t)D * D * 4, (int64_t)D * D * 4};
+      if ((rc = tavsr_multi_copy(dst, src, nbytes, 3, (tavsr_stream_t)s2))) return rc;
+    }
+    tavsr_gemm_desc gc = lin(M, D, 3 * D, dqkv, 3 * D, wcat, nullptr, dn_a, D);     // dn = dqkv [wq; wk; wv]: one K = 3 D GEMM
+    gc.b_kmajor = 1; gc.ldb = D;
+    if ((rc = run_gemm(gc, ws, s2))) return rc;
+  }
+  // ---- cgMLP branch on the calling queue
+  float* dx1 = mat((int64_t)M * D);
+  {
+    grp.add(dxm, D, d->u, Cn, M, D, Cn, 1.f, b->g_cg_w2, b->g_cg_b2);
+    float* du = mat((int64_t)M * Cn);
+    tavsr_gemm_desc g = lin(M, Cn, D, dxm, D, d->cg_w2, nullptr, du, Cn);
+    g.b_kmajor = 1; g.ldb = Cn;
+    if (drop) { g.drop_p = d->p_drop; g.drop_seed = d->seed; g.drop_offset = d->drop_off[4]; }
+    if ((rc = run_gemm(g, ws, s))) return rc;
+    float* dg = mat((int64_t)M * C2);
+    float* dgn = mat((int64_t)M * Cn);
+    float* cws = mat(tavsr_dwconv_gate_bwd_ws(B, T, Cn, d->cg_kernel));
+    float* lws = mat(tavsr_layernorm_bwd_ws(M, Cn));
+    float* dn = mat((int64_t)M * D);
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_bwd: workspace too small");
+    if (!dry) {
+      if ((rc = tavsr_dwconv_gate_bwd_act(du, d->gn, d->g, C2, d->conv, d->csgu_cw, dg, C2, dgn, b->g_csgu_cw, b->g_csgu_cb, 0, cws, B, T, Cn,
+                                          d->cg_kernel, d->g_z, C2, TAVSR_ACT_GELU, (tavsr_stream_t)s)))
+        return rc;
+      if ((rc = tavsr_layernorm_bwd_act(dgn, Cn, d->g + Cn, C2, d->g_mean, d->g_rstd, d->csgu_ln_w, dg + Cn, C2, b->g_csgu_ln_w, b->g_csgu_ln_b, 0,
+                                        lws, M, Cn, d->g_z + Cn, C2, TAVSR_ACT_GELU, (tavsr_stream_t)s)))
+        return rc;
+    }
+    grp.add(dg, C2, d->n_mlp, D, M, C2, D, 1.f, b->g_cg_w1, b->g_cg_b1);
+    tavsr_gemm_desc g1 = lin(M, D, C2, dg, C2, d->cg_w1, nullptr, dn, D);
+    g1.b_kmajor = 1; g1.ldb = D;
+    if ((rc = run_gemm(g1, ws, s))) return rc;
+    if ((rc = lng.bwd(dn, d->x1, d->br_mean, d->br_rstd, d->mlp_ln_w, dx2, dx1, nullptr, 0.f, nullptr, 0, dry, s))) return rc;
+  }
+  if (!dry) {
+    TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_join, s2));
+    TAVSR_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)d->ev_join, 0));
+    if ((rc = probe_fork(s2, s, true))) return rc;
+  }
+  // ---- norm_mha (same accumulation order into dx1 as a single queue: cgMLP branch first, then attention), macaron block
+  float* dx1b = mat((int64_t)M * D);
+  float* dyd2 = drop ? mat((int64_t)M * D) : nullptr;
+  TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_bwd: workspace too small");
+  if ((rc = lng.bwd(dn_a, d->x1, d->br_mean, d->br_rstd, d->mha_ln_w, dx1, dx1b, dyd2, d->p_drop, seed, d->drop_off[1], dry, s))) return rc;
+  if ((rc = ffn_bwd(d, dx1b, drop ? dyd2 : dx1b, d->x, d->ffm_mean, d->ffm_rstd, d->ffm_n, d->ffm_z, d->ffm_h, d->ffm_ln_w, d->ffm_w1, d->ffm_w2,
+                    d->drop_off[0], b->g_ffm_w1, b->g_ffm_b1, b->g_ffm_w2, b->g_ffm_b2, b->dx, nullptr, 0, grp, lng, ws, s)))
+    return rc;
+  if ((rc = grp.flush(ws, s))) return rc;
+  (void)g_ln;
+  return lng.flush(dry, s);
+}
+
+}  // namespace
+
+extern "C" int64_t tavsr_branchformer_layer_bwd_ws(const tavsr_bf_layer_bwd_desc* b) {
+  if (!b || !b->fwd || supported(b->fwd, "branchformer_layer_bwd_ws")) return 0;
+  Bump ws{nullptr, 0, 0, true, false};
+  if (sequence_bwd(b, nullptr, ws)) return 0;
+  return ws.used;
+}
+
+extern "C" int tavsr_branchformer_layer_bwd(const tavsr_bf_layer_bwd_desc* b, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(b && b->fwd, TAVSR_EINVAL, "branchformer_layer_bwd: null descriptor");
+  const tavsr_bf_layer_desc* d = b->fwd;
+  int rc = supported(d, "branchformer_layer_bwd");
+  if (rc) return rc;
+  TAVSR_REQUIRE(d->save, TAVSR_EINVAL, "branchformer_layer_bwd: the forward call must have kept its state (save = 1)");
+  TAVSR_REQUIRE(b->dy && b->dx && b->g_ln && b->ws && d->ev_fork && d->ev_join, TAVSR_EINVAL, "branchformer_layer_bwd: null buffer");
+  const float* const need[] = {b->g_ffm_w1, b->g_ffm_b1, b->g_ffm_w2, b->g_ffm_b2, b->g_wq, b->g_bq, b->g_wk, b->g_bk, b->g_wv, b->g_bv, b->g_wo, b->g_bo,
+                               b->g_wpos, b->g_pos_u, b->g_pos_v, b->g_cg_w1, b->g_cg_b1, b->g_csgu_ln_w, b->g_csgu_ln_b, b->g_csgu_cw, b->g_csgu_cb,
+                               b->g_cg_w2, b->g_cg_b2, b->g_merge_w, b->g_merge_b, b->g_ff_w1, b->g_ff_b1, b->g_ff_w2, b->g_ff_b2};
+  for (const float* g : need) TAVSR_REQUIRE(g, TAVSR_EINVAL, "branchformer_layer_bwd: null gradient buffer");
+  for (int i = 0; i < 8; ++i) TAVSR_REQUIRE(b->g_merge_p[i], TAVSR_EINVAL, "branchformer_layer_bwd: null merge gradient %d", i);
+  {
+    Bump dryrun{nullptr, 0, 0, true, false};
+    if ((rc = sequence_bwd(b, nullptr, dryrun))) return rc;
+    TAVSR_REQUIRE(dryrun.used <= b->ws_floats, TAVSR_EINVAL, "branchformer_layer_bwd: workspace too small (tavsr_branchformer_layer_bwd_ws)");
+  }
+  Bump ws{b->ws, b->ws_floats, 0, false, false};
+  return sequence_bwd(b, (hipStream_t)stream, ws);
+}
+

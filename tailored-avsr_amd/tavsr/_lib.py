@@ -88,6 +88,20 @@ class BfLayerDesc(C.Structure):
     )
 
 
+class BfLayerBwdDesc(C.Structure):
+    """tavsr_bf_layer_bwd_desc (include/tavsr.h)"""
+    _fields_ = (
+        [("fwd", C.POINTER(BfLayerDesc)), ("dy", C.c_void_p), ("dx", C.c_void_p)]
+        + [(n, C.c_void_p) for n in (
+            "g_ffm_w1", "g_ffm_b1", "g_ffm_w2", "g_ffm_b2",
+            "g_wq", "g_bq", "g_wk", "g_bk", "g_wv", "g_bv", "g_wo", "g_bo", "g_wpos", "g_pos_u", "g_pos_v",
+            "g_cg_w1", "g_cg_b1", "g_csgu_ln_w", "g_csgu_ln_b", "g_csgu_cw", "g_csgu_cb", "g_cg_w2", "g_cg_b2")]
+        + [("g_merge_p", C.c_void_p * 8)]
+        + [(n, C.c_void_p) for n in ("g_merge_w", "g_merge_b", "g_ff_w1", "g_ff_b1", "g_ff_w2", "g_ff_b2", "g_ln", "ws")]
+        + [("ws_floats", C.c_int64)]
+    )
+
+
 class FfnDesc(C.Structure):
     """tavsr_ffn_desc (include/tavsr.h)"""
     _fields_ = [

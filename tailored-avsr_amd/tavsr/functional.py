@@ -370,10 +370,72 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
           "x1": b["x1"], "xa": b["xa"], "xm": b["xm"]}
     ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = sv, cfg, P, lens, pos_emb
     ctx.shape = (B, T, D)
+    if need:
+        ctx.cdesc = d      # the descriptor (raw addresses of the parameters and of every kept buffer; ctx.sv / ctx.P hold the tensors)
     # (ws goes back to the allocator here: every launch that reads it is enqueued, the side queue has been joined into the calling
     # one inside the call, and the block can only be handed to later work of the calling queue)
     cfg["_last_w"] = b["wts"]
     return b["y"].view(B, T, D)
+
+
+# gradient slot of tavsr_bf_layer_bwd_desc -> parameter (BF_PARAM_NAMES); the five d_model LayerNorms come back in one buffer
+_BWD_FIELDS = (
+    ("g_ffm_w1", "feed_forward_macaron.w_1.weight"), ("g_ffm_b1", "feed_forward_macaron.w_1.bias"),
+    ("g_ffm_w2", "feed_forward_macaron.w_2.weight"), ("g_ffm_b2", "feed_forward_macaron.w_2.bias"),
+    ("g_wq", "attn.linear_q.weight"), ("g_bq", "attn.linear_q.bias"), ("g_wk", "attn.linear_k.weight"), ("g_bk", "attn.linear_k.bias"),
+    ("g_wv", "attn.linear_v.weight"), ("g_bv", "attn.linear_v.bias"), ("g_wo", "attn.linear_out.weight"), ("g_bo", "attn.linear_out.bias"),
+    ("g_wpos", "attn.linear_pos.weight"), ("g_pos_u", "attn.pos_bias_u"), ("g_pos_v", "attn.pos_bias_v"),
+    ("g_cg_w1", "cgmlp.channel_proj1.0.weight"), ("g_cg_b1", "cgmlp.channel_proj1.0.bias"),
+    ("g_csgu_ln_w", "cgmlp.csgu.norm.weight"), ("g_csgu_ln_b", "cgmlp.csgu.norm.bias"),
+    ("g_csgu_cw", "cgmlp.csgu.conv.weight"), ("g_csgu_cb", "cgmlp.csgu.conv.bias"),
+    ("g_cg_w2", "cgmlp.channel_proj2.weight"), ("g_cg_b2", "cgmlp.channel_proj2.bias"),
+    ("g_merge_w", "merge_proj.weight"), ("g_merge_b", "merge_proj.bias"),
+    ("g_ff_w1", "feed_forward.w_1.weight"), ("g_ff_b1", "feed_forward.w_1.bias"),
+    ("g_ff_w2", "feed_forward.w_2.weight"), ("g_ff_b2", "feed_forward.w_2.bias"))
+_BWD_MERGE = ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias", "pooling_proj2.bias",
+              "weight_proj1.weight", "weight_proj2.weight", "weight_proj1.bias", "weight_proj2.bias")
+_BWD_NORMS = ("norm_final", "norm_ff", "norm_mlp", "norm_mha", "norm_ff_macaron")
+
+
+def _layer_c_backward(ctx, dy):
+    """BranchformerLayerFn.backward as one C call (tavsr_branchformer_layer_bwd) on the state a C forward call left: allocates
+    the gradients, fills the descriptor; bit-identical to the Python sequencing below."""
+    from ._lib import BfLayerBwdDesc, check, lib
+    import ctypes as C
+    d, P = ctx.cdesc, ctx.P
+    B, T, D = ctx.shape
+    M = B * T
+    dy2 = dy.contiguous().view(M, D)
+    main = torch.cuda.current_stream()
+    side = ops.branch_stream(main) if ops.forks_enabled() else main
+    ev = ops.branch_events(main)
+    d.stream2, d.ev_fork, d.ev_join = side.cuda_stream, ev[0].cuda_event, ev[1].cuda_event
+    b = BfLayerBwdDesc()
+    b.fwd = C.pointer(d)
+    G: List[Optional[torch.Tensor]] = [None] * len(BF_PARAM_NAMES)
+    for f, n in _BWD_FIELDS:
+        G[_I[n]] = g = torch.empty_like(P[_I[n]], memory_format=torch.contiguous_format)
+        setattr(b, f, ops._addr(g))
+    for j, n in enumerate(_BWD_MERGE):
+        G[_I[n]] = g = torch.empty_like(P[_I[n]], memory_format=torch.contiguous_format)
+        b.g_merge_p[j] = ops._addr(g)
+    g_ln = ops.empty(len(_BWD_NORMS) * 2 * D, like=dy2)
+    for j, n in enumerate(_BWD_NORMS):
+        G[_I[n + ".weight"]] = g_ln[2 * j * D: (2 * j + 1) * D]
+        G[_I[n + ".bias"]] = g_ln[(2 * j + 1) * D: (2 * j + 2) * D]
+    dx = ops.empty(M, D, like=dy2)
+    b.dy, b.dx, b.g_ln = ops._addr(dy2), ops._addr(dx), ops._addr(g_ln)
+    key = ("bwd", B, T, D, d.H, d.ffn_units, d.cg_units, d.p_drop > 0.0)
+    nws = _LAYER_WS.get(key)
+    if nws is None:
+        fn = lib().tavsr_branchformer_layer_bwd_ws
+        fn.restype = C.c_int64
+        nws = _LAYER_WS[key] = int(fn(C.byref(b)))
+    ws = ops.empty(max(nws, 4), like=dy2)
+    b.ws, b.ws_floats = ops._addr(ws), nws
+    check(lib().tavsr_branchformer_layer_bwd(C.byref(b), C.c_void_p(main.cuda_stream)), "tavsr_branchformer_layer_bwd")
+    ctx.sv = ctx.cdesc = None
+    return (dx.view(B, T, D), None, None, None, *G)
 
 
 class BranchformerLayerFn(torch.autograd.Function):
@@ -512,6 +574,9 @@ class BranchformerLayerFn(torch.autograd.Function):
     @staticmethod
     @guarded
     def backward(ctx, dy):
+        if (getattr(ctx, "cdesc", None) is not None and ops.LAYER_C and ops.PROFILE is None and all(p is not None for p in ctx.P)
+                and not (ops.LAYER_C_EAGER_ONLY and torch.cuda.is_current_stream_capturing())):
+            return _layer_c_backward(ctx, dy)
         sv, cfg, P = ctx.sv, ctx.cfg, ctx.P
         B, T, D = ctx.shape
         M = B * T

@@ -1,6 +1,7 @@
-"""GPU: one Branchformer layer forward as ONE C call (tavsr_branchformer_layer_fwd, csrc/layer.hip) against the Python
-sequencing of the same launches (functional.BranchformerLayerFn) - outputs, everything the backward pass keeps (through the
-gradients the shared backward computes from it), with the recipe's dropout on (same tokens, same masks) and in eval."""
+"""GPU: one Branchformer layer forward AND backward as ONE C call each (tavsr_branchformer_layer_fwd / _bwd, csrc/layer.hip)
+against the Python sequencing of the same launches (functional.BranchformerLayerFn; autograd of
+src/encoder/branchformer/encoder_layer.py:153-321) - outputs and every gradient BIT-equal, with the recipe's dropout on (same
+tokens, same masks) and in eval, full and ragged lengths."""
 import pytest
 import torch
 
@@ -55,7 +56,7 @@ def test_layer_forward_in_c_equals_python_sequencing(B, T, train):
     assert torch.equal(y_c, y_p)                     # the same launches with the same arguments
     assert len(g_c) == len(g_p) and len(g_c) == (0 if not train else len(g_c))
     for a, b in zip(g_c, g_p):
-        _close(a, b, 1e-6)
+        assert torch.equal(a, b), float((a - b).abs().max())      # same launches, same grouping, same order
 
 
 def test_layer_in_c_is_used_and_refuses_foreign_shapes():
@@ -71,3 +72,9 @@ def test_layer_in_c_is_used_and_refuses_foreign_shapes():
     assert lib().tavsr_branchformer_layer_fwd(C.byref(d), None) != 0
     d.D, d.H = 256, 4
     assert fn(C.byref(d)) > 0
+    # the backward entry wants the state a save = 1 forward call kept
+    from tavsr._lib import BfLayerBwdDesc
+    b = BfLayerBwdDesc()
+    b.fwd = C.pointer(d)
+    assert lib().tavsr_branchformer_layer_bwd(C.byref(b), None) != 0
+    assert b"save" in lib().tavsr_last_error_string()
