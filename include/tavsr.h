@@ -416,6 +416,77 @@ int tavsr_dwconv_gate_bwd_act(const float* du, const float* gn, const float* r, 
                               tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Block-level entry points (csrc/blocks.hip): a whole module of the reference model as ONE call, sequenced in C over the
+ * primitive entry points above - same launches, order and results as a caller that issues them one by one.
+ *
+ * tavsr_cgmlp_fwd: espnet ConvolutionalGatingMLP with the dropout / residual the layers put around it
+ *   (src/encoder/branchformer/encoder_layer.py:213-226; src/encoder/audiovisual/tailored/encoder_layer.py:198-208,246-256):
+ *       g = gelu(x w1^T + b1);  u = dropout_p(g[:, :C] * dwconv_31(LayerNorm(g[:, C:])));  out = res + alpha * dropout_p_out(u w2^T + b2)
+ *   x: the block's (already normalised) input rows [B*T][D]; res may be NULL; units = 2C (C <= 1024, 2C % 128 == 0), kernel 31.
+ *   Kept for the backward pass (save = 1): g, g_z (pre-activations), gn, conv, g_mean / g_rstd, u.
+ * tavsr_cgmlp_bwd: dy = gradient w.r.t. out (the residual path's share is the caller's); writes dx (w.r.t. x) and the eight
+ *   parameter gradients (overwritten).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tavsr_cgmlp_desc {
+  int32_t B, T, D, units, kernel, save;
+  float p_drop, p_out, alpha;
+  const uint64_t* seed;            /* device; NULL without dropout */
+  uint64_t off_u, off_out;         /* dropout offsets of u [B*T][C] and of the output [B*T][D] (tavsr_dropout mapping) */
+  const float *x, *res;
+  const float *w1, *b1, *ln_w, *ln_b, *cw /* [C][31] */, *cb, *w2, *b2;
+  float *g /* [B*T][2C] */, *g_z, *gn, *g_mean, *g_rstd, *u, *conv, *out;
+  float* ws;
+  int64_t ws_floats;
+} tavsr_cgmlp_desc;
+int64_t tavsr_cgmlp_ws(const tavsr_cgmlp_desc* d);
+int tavsr_cgmlp_fwd(const tavsr_cgmlp_desc* d, tavsr_stream_t stream);
+typedef struct tavsr_cgmlp_bwd_desc {
+  const tavsr_cgmlp_desc* fwd;
+  const float* dy;
+  float* dx;
+  float *g_w1, *g_b1, *g_ln_w, *g_ln_b, *g_cw, *g_cb, *g_w2, *g_b2;
+  float* ws;
+  int64_t ws_floats;
+} tavsr_cgmlp_bwd_desc;
+int64_t tavsr_cgmlp_bwd_ws(const tavsr_cgmlp_bwd_desc* b);
+int tavsr_cgmlp_bwd(const tavsr_cgmlp_bwd_desc* b, tavsr_stream_t stream);
+
+/* tavsr_conv2d_subsample_fwd: espnet Conv2dSubsampling / Conv2dSubsamplingWOPosEnc (src/encoder/branchformer/encoder.py:364,
+ *   src/embedding_for_avsr/default.py:111-162): out = xscale * (Linear(flatten_{c,f}(relu(conv2(relu(conv1(x)))))) ), both
+ *   convolutions 3x3 / stride 2 / no padding, x [B][T][F] (one input channel), parameters in torch layouts (w1 [C][1][3][3],
+ *   w2 [C][C][3][3], wo [odim][C * F2]).  Channels-last inside: y1 [B][T1][F1][C], y2 [B*T2*F2][C] (kept for the backward pass
+ *   together with the re-indexed weights w2r [C][9C] and wor [odim][F2*C], which the call writes).  The second convolution runs as
+ *   an implicit GEMM (C % 64 == 0, B*T2*F2 % 32 == 0, else TAVSR_EUNSUPPORTED).  zero_page: 64 zero floats (device).
+ * tavsr_conv2d_subsample_bwd: dout [B*T2][odim] -> the six parameter gradients in torch layouts (the input gets none). */
+typedef struct tavsr_subsample_desc {
+  int32_t B, T, F, C, odim;
+  float xscale;
+  const float* x;
+  const float *w1, *b1, *w2, *b2, *wo, *bo;
+  const float* zero_page;
+  float *y1, *y2, *w2r, *wor, *out;
+  float* ws;
+  int64_t ws_floats;
+} tavsr_subsample_desc;
+int64_t tavsr_conv2d_subsample_ws(const tavsr_subsample_desc* d);
+int tavsr_conv2d_subsample_fwd(const tavsr_subsample_desc* d, tavsr_stream_t stream);
+typedef struct tavsr_subsample_bwd_desc {
+  const tavsr_subsample_desc* fwd;
+  const float* dout;
+  float *g_w1, *g_b1, *g_w2, *g_b2, *g_wo, *g_bo;
+  float* ws;
+  int64_t ws_floats;
+} tavsr_subsample_bwd_desc;
+int64_t tavsr_conv2d_subsample_bwd_ws(const tavsr_subsample_bwd_desc* b);
+int tavsr_conv2d_subsample_bwd(const tavsr_subsample_bwd_desc* b, tavsr_stream_t stream);
+
+/* Workspace of any descriptor-driven entry point in BYTES (the per-entry *_ws queries count floats): kind names the descriptor
+ * type behind `desc`.  -1: unknown kind; 0: nothing needed, or a descriptor the entry point would refuse. */
+enum { TAVSR_WS_GEMM = 0, TAVSR_WS_FFN2 = 1, TAVSR_WS_BF_LAYER_FWD = 2, TAVSR_WS_BF_LAYER_BWD = 3, TAVSR_WS_CGMLP_FWD = 4,
+       TAVSR_WS_CGMLP_BWD = 5, TAVSR_WS_SUBSAMPLE_FWD = 6, TAVSR_WS_SUBSAMPLE_BWD = 7 };
+int64_t tavsr_workspace_bytes(int32_t kind, const void* desc);
+
+/* ---------------------------------------------------------------------------------------------
  * learned_ave branch merge (encoder_layer.py:232-293) and the same pooling used by
  * AdaptiveAudioVisualFusion (adaptive_audiovisual_fusion.py:137-191).
  *   params (HOST array of 8 device pointers): pooling_proj{1,2}.weight[D], pooling_proj{1,2}.bias[1],

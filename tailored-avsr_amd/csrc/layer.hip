@@ -2,58 +2,13 @@
 // tavsr/functional.py:BranchformerLayerFn.forward enqueues through ~45 Python-level calls, as one C call over the same entry
 // points - for un-captured (ragged) training loops, whose step is host-bound on that sequencing.  Host code only.
 // Reference: src/encoder/branchformer/encoder_layer.py:153-321 (MyBranchformerEncoderLayer.forward).
-#include <cmath>
-#include <cstring>
-
-#include "common.h"
+#include "seq.h"
 
 using namespace tavsr;
 
-#define TAVSR_HIP_CHECK(call)                                                                    \
-  do {                                                                                            \
-    hipError_t e__ = (call);                                                                      \
-    if (e__ != hipSuccess) {                                                                      \
-      ::tavsr::set_error("%s:%d %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e__));     \
-      return (int)e__;                                                                            \
-    }                                                                                             \
-  } while (0)
-
 namespace {
 
-struct Bump {           // workspace carving (two queues run side by side: every launch gets its own region)
-  float* base;
-  int64_t cap, used;
-  bool dry;
-  bool overflow = false;
-  // dry run: sizes only, but a non-null sentinel so that descriptors which switch on "is this pointer given" (rowstat)
-  // plan the same launches as the real pass; real pass: never past the caller's capacity
-  float* take(int64_t n) {
-    n = (n + 63) / 64 * 64;
-    float* p = dry ? reinterpret_cast<float*>(uintptr_t(64)) : base + used;
-    if (!dry && used + n > cap) { overflow = true; p = nullptr; }
-    used += n;
-    return p;
-  }
-};
-
-tavsr_gemm_desc lin(int M, int N, int K, const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t ldo) {
-  tavsr_gemm_desc g;
-  memset(&g, 0, sizeof g);
-  g.M = M; g.N = N; g.K = K;
-  g.A = x; g.lda = ldx; g.B = w; g.ldb = K; g.C = out; g.ldc = ldo;
-  g.nb1 = g.nb2 = 1;
-  g.bias = b;
-  g.alpha = 1.f;
-  return g;
-}
-
-int run_gemm(tavsr_gemm_desc& g, Bump& ws, hipStream_t s) {
-  const int64_t need = tavsr_gemm_ws(&g);
-  if (need > 0) { g.ws = ws.take(need); g.ws_floats = need; }
-  if (ws.dry) return TAVSR_OK;
-  TAVSR_REQUIRE(!ws.overflow, TAVSR_EINVAL, "branchformer_layer_fwd: workspace too small for a GEMM's split-K slabs");
-  return tavsr_gemm(&g, (tavsr_stream_t)s);
-}
+using namespace tavsr::seq;
 
 tavsr_ffn_desc ffn(const tavsr_bf_layer_desc* d, const float* x, const float* ln_w, const float* ln_b, const float* w1,
                    const float* b1, const float* w2, const float* b2, float* y, float* n, float* mean, float* rstd, float* z,

@@ -102,6 +102,37 @@ class BfLayerBwdDesc(C.Structure):
     )
 
 
+class CgmlpDesc(C.Structure):
+    """tavsr_cgmlp_desc (include/tavsr.h)"""
+    _fields_ = ([(n, C.c_int32) for n in ("B", "T", "D", "units", "kernel", "save")]
+                + [(n, C.c_float) for n in ("p_drop", "p_out", "alpha")]
+                + [("seed", C.c_void_p), ("off_u", C.c_uint64), ("off_out", C.c_uint64)]
+                + [(n, C.c_void_p) for n in ("x", "res", "w1", "b1", "ln_w", "ln_b", "cw", "cb", "w2", "b2",
+                                             "g", "g_z", "gn", "g_mean", "g_rstd", "u", "conv", "out", "ws")]
+                + [("ws_floats", C.c_int64)])
+
+
+class CgmlpBwdDesc(C.Structure):
+    """tavsr_cgmlp_bwd_desc (include/tavsr.h)"""
+    _fields_ = ([("fwd", C.POINTER(CgmlpDesc)), ("dy", C.c_void_p), ("dx", C.c_void_p)]
+                + [(n, C.c_void_p) for n in ("g_w1", "g_b1", "g_ln_w", "g_ln_b", "g_cw", "g_cb", "g_w2", "g_b2", "ws")]
+                + [("ws_floats", C.c_int64)])
+
+
+class SubsampleDesc(C.Structure):
+    """tavsr_subsample_desc (include/tavsr.h)"""
+    _fields_ = ([(n, C.c_int32) for n in ("B", "T", "F", "C", "odim")] + [("xscale", C.c_float)]
+                + [(n, C.c_void_p) for n in ("x", "w1", "b1", "w2", "b2", "wo", "bo", "zero_page", "y1", "y2", "w2r", "wor", "out", "ws")]
+                + [("ws_floats", C.c_int64)])
+
+
+class SubsampleBwdDesc(C.Structure):
+    """tavsr_subsample_bwd_desc (include/tavsr.h)"""
+    _fields_ = ([("fwd", C.POINTER(SubsampleDesc)), ("dout", C.c_void_p)]
+                + [(n, C.c_void_p) for n in ("g_w1", "g_b1", "g_w2", "g_b2", "g_wo", "g_bo", "ws")]
+                + [("ws_floats", C.c_int64)])
+
+
 class FfnDesc(C.Structure):
     """tavsr_ffn_desc (include/tavsr.h)"""
     _fields_ = [

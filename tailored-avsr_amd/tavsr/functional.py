@@ -836,6 +836,13 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2, wo, bo, xscale):
         B, T, F = x.shape
         Cn = w1.shape[0]
+        if CONV2_IMPLICIT and ops.BLOCKS_C and ops.conv2d_subsample_ok(x, w1, wo):      # the whole module as one C call
+            out, T2, F2, kept, desc = ops.conv2d_subsample_fwd(x, w1.contiguous(), b1, w2.contiguous(), b2, wo.contiguous(), bo, xscale)
+            ctx.cdesc, ctx.ckept = desc, kept
+            ctx.save_for_backward()
+            ctx.dims = (B, T, F, Cn, T2, F2, xscale, w1.shape, w2.shape, wo.shape)
+            return out.view(B, T2, -1)
+        ctx.cdesc = None
         y1 = ops.conv1_fwd(x.contiguous(), w1.reshape(Cn, 9), b1)              # [B,T1,F1,C] NHWC, relu
         # torch (co, ci, kh, kw) -> (co, kh, kw, ci) to match the channels-last patch order
         w2r = ops.transpose_inner(w2, Cn, Cn, 9).view(Cn, 9 * Cn)
@@ -857,9 +864,13 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
     @staticmethod
     @guarded
     def backward(ctx, dout):
-        x, y1, col, y2, w2r, wor = ctx.saved_tensors
         B, T, F, Cn, T2, F2, xscale, w1s, w2s, wos = ctx.dims
         do = dout.contiguous().view(B * T2, -1)
+        if ctx.cdesc is not None:
+            gw1, gb1, gw2, gb2, gwo, gbo = ops.conv2d_subsample_bwd(ctx.cdesc, do, (w1s, w2s, wos))
+            ctx.cdesc = ctx.ckept = None
+            return None, gw1, gb1, gw2, gb2, gwo, gbo, None
+        x, y1, col, y2, w2r, wor = ctx.saved_tensors
         y2f = y2.view(B * T2, F2 * Cn)
         gwor, gbo = ops.linear_dw(do, y2f, alpha=xscale, bias_grad=True)        # [odim, F2*C], [odim]
         # dz2 = (do @ wor) * xscale * relu'(y2)

@@ -339,6 +339,12 @@ def _ts_branch_fwd(p, cfg, x1, n, mean, rstd, pos_emb, lens, B, T, need):
         return x2, (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_br)
     w1c = p["cgmlp.channel_proj1.0.weight"]
     cw = p["cgmlp.csgu.conv.weight"]
+    if ops.BLOCKS_C and ops.cgmlp_block_ok(n, w1c, cw) and x1.is_contiguous():      # the whole branch as one C call
+        x2, (g, z, gn, gmean, grstd, u, conv, t_u, t_br), _ = ops.cgmlp_fwd(
+            n, w1c, p["cgmlp.channel_proj1.0.bias"], p["cgmlp.csgu.norm.weight"], p["cgmlp.csgu.norm.bias"], cw,
+            p["cgmlp.csgu.conv.bias"], p["cgmlp.channel_proj2.weight"], p["cgmlp.channel_proj2.bias"], B, T, p=pd, p_out=pd, alpha=coeff,
+            res=x1, save=need)
+        return x2, (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_br)
     # channel_proj1's epilogue leaves the CSGU's LayerNorm statistics as per-tile row sums (no statistics launch)
     rst = (ops.empty(n.shape[0], w1c.shape[0] // 64, 2, like=n)
            if (ops.CSGU_FUSED and cw.shape[-1] == 31 and ops.csgu_rowstat_ok(n, w1c)) else None)

@@ -773,6 +773,7 @@ def ffn2_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
 
 # One Branchformer layer forward as ONE C call (csrc/layer.hip): the same launches, sequenced in C.  For un-captured loops
 # (the host is what limits an eager step); a captured step replays the same kernels either way.  TAVSR_LAYER_C=0: Python sequencing.
+BLOCKS_C = True      # block-level C entry points (tavsr_conv2d_subsample_*, tavsr_cgmlp_fwd) instead of launch-by-launch sequencing
 LAYER_C = os.environ.get("TAVSR_LAYER_C", "1") != "0"
 LAYER_C_EAGER_ONLY = os.environ.get("TAVSR_LAYER_C", "1") != "capture"     # TAVSR_LAYER_C=capture: also while a hipGraph is being captured
 _BR_EVENTS = {}
@@ -872,6 +873,110 @@ def csgu_fwd(g, ln_w, ln_b, eps, w, bias, B, T, p=0.0, save=True, rowstat=None):
 
 
 CGMLP_ACT_BWD_FUSED = True   # gelu' in the CSGU's two backward kernels
+
+
+def cgmlp_block_ok(x, w1, cw) -> bool:
+    """the shapes tavsr_cgmlp_fwd sequences (kernel 31, C <= 1024, one-pass CSGU with the statistics from channel_proj1's epilogue)"""
+    C2 = w1.shape[0]
+    return (PROFILE is None and CSGU_FUSED and CSGU_STATS_IN_GEMM and cw.shape[-1] == 31 and C2 % 128 == 0 and C2 // 2 <= 1024
+            and x.is_contiguous() and x.shape[1] % 32 == 0 and w1.is_contiguous() and cw.is_contiguous())
+
+
+def cgmlp_fwd(x, w1, b1, ln_w, ln_b, cw, cb, w2, b2, B, T, *, p=0.0, p_out=0.0, alpha=1.0, res=None, save=True):
+    """espnet ConvolutionalGatingMLP with the branch's dropout / residual around it as ONE C call (tavsr_cgmlp_fwd, csrc/blocks.hip):
+    -> (out, (g, z, gn, gmean, grstd, u, conv, t_u, t_out), desc); ``desc`` is what ``cgmlp_bwd`` wants back."""
+    M, D = x.shape
+    C2 = w1.shape[0]
+    Cn = C2 // 2
+    require_cuda(x, res, w1, b1, ln_w, ln_b, cw, cb, w2, b2)
+    d = L.CgmlpDesc()
+    d.B, d.T, d.D, d.units, d.kernel, d.save = B, T, D, C2, cw.shape[-1], int(save)
+    t_u = _new_token(p, M * Cn, x.device) if p and p > 0.0 else None
+    t_out = _new_token(p_out, M * D, x.device) if p_out and p_out > 0.0 else None
+    d.p_drop, d.p_out, d.alpha = (p if t_u else 0.0), (p_out if t_out else 0.0), alpha
+    seed = (t_u or t_out or (0.0, 0, None))[2]
+    d.seed, d.off_u, d.off_out = _addr(seed), (t_u[1] if t_u else 0), (t_out[1] if t_out else 0)
+    g, u, out = empty(M, C2, like=x), empty(M, Cn, like=x), empty(M, D, like=x)
+    gmean, grstd = empty(M, like=x), empty(M, like=x)
+    z = gn = conv = None
+    if save:
+        z, gn, conv = empty(M, C2, like=x), empty(M, Cn, like=x), empty(M, Cn, like=x)
+    for f, t in (("x", x), ("res", res), ("w1", w1), ("b1", b1), ("ln_w", ln_w), ("ln_b", ln_b), ("cw", cw), ("cb", cb), ("w2", w2),
+                 ("b2", b2), ("g", g), ("g_z", z), ("gn", gn), ("g_mean", gmean), ("g_rstd", grstd), ("u", u), ("conv", conv), ("out", out)):
+        setattr(d, f, _addr(t))
+    nws = lib_i64("tavsr_cgmlp_ws", C.byref(d))
+    ws = empty(max(nws, 4), like=x)
+    d.ws, d.ws_floats = _addr(ws), nws
+    check(lib().tavsr_cgmlp_fwd(C.byref(d), stream()), "tavsr_cgmlp_fwd")
+    return out, (g, z, gn, gmean, grstd, u, conv, t_u, t_out), d
+
+
+def cgmlp_bwd(desc, dy, params):
+    """backward of ``cgmlp_fwd`` (its descriptor; the caller keeps the forward's tensors alive): -> (dx, (g_w1, g_b1, g_ln_w, g_ln_b,
+    g_cw, g_cb, g_w2, g_b2)); ``params`` = the eight parameters in that order (shapes of the gradients)."""
+    M, D = dy.shape
+    require_cuda(dy)
+    b = L.CgmlpBwdDesc()
+    b.fwd = C.pointer(desc)
+    dx = empty(M, D, like=dy)
+    grads = [torch.empty_like(q, memory_format=torch.contiguous_format) for q in params]
+    b.dy, b.dx = _addr(dy), _addr(dx)
+    for f, t in zip(("g_w1", "g_b1", "g_ln_w", "g_ln_b", "g_cw", "g_cb", "g_w2", "g_b2"), grads):
+        setattr(b, f, _addr(t))
+    nws = lib_i64("tavsr_cgmlp_bwd_ws", C.byref(b))
+    ws = empty(max(nws, 4), like=dy)
+    b.ws, b.ws_floats = _addr(ws), nws
+    check(lib().tavsr_cgmlp_bwd(C.byref(b), stream()), "tavsr_cgmlp_bwd")
+    return dx, grads
+
+
+def conv2d_subsample_ok(x, w1, wo) -> bool:
+    B, T, F = x.shape
+    Cn = w1.shape[0]
+    T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    return PROFILE is None and T >= 7 and F >= 7 and Cn % 64 == 0 and (B * T2 * F2) % 32 == 0 and wo.shape[0] % 4 == 0
+
+
+def conv2d_subsample_fwd(x, w1, b1, w2, b2, wo, bo, xscale):
+    """espnet Conv2dSubsampling as ONE C call (tavsr_conv2d_subsample_fwd): -> (out [B*T2, odim], T2, F2, kept tensors, desc)"""
+    B, T, F = x.shape
+    Cn, odim = w1.shape[0], wo.shape[0]
+    T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    x = x.contiguous()
+    require_cuda(x, w1, b1, w2, b2, wo, bo)
+    assert all(t.is_contiguous() for t in (w1, w2, wo))
+    d = L.SubsampleDesc()
+    d.B, d.T, d.F, d.C, d.odim, d.xscale = B, T, F, Cn, odim, xscale
+    y1, y2 = empty(B, T1, F1, Cn, like=x), empty(B * T2 * F2, Cn, like=x)
+    w2r, wor, out = empty(Cn, 9 * Cn, like=x), empty(odim, F2 * Cn, like=x), empty(B * T2, odim, like=x)
+    for f, t in (("x", x), ("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2), ("wo", wo), ("bo", bo), ("zero_page", _zero_page(x.device)),
+                 ("y1", y1), ("y2", y2), ("w2r", w2r), ("wor", wor), ("out", out)):
+        setattr(d, f, _addr(t))
+    nws = lib_i64("tavsr_conv2d_subsample_ws", C.byref(d))
+    ws = empty(max(nws, 4), like=x)
+    d.ws, d.ws_floats = _addr(ws), nws
+    check(lib().tavsr_conv2d_subsample_fwd(C.byref(d), stream()), "tavsr_conv2d_subsample_fwd")
+    return out, T2, F2, (x, y1, y2, w2r, wor), d
+
+
+def conv2d_subsample_bwd(desc, dout, shapes):
+    """-> (g_w1, g_b1, g_w2, g_b2, g_wo, g_bo) in the torch layouts ``shapes`` = (w1, w2, wo shapes)"""
+    require_cuda(dout)
+    w1s, w2s, wos = shapes
+    b = L.SubsampleBwdDesc()
+    b.fwd = C.pointer(desc)
+    grads = [empty(*w1s, like=dout), empty(w1s[0], like=dout), empty(*w2s, like=dout), empty(w2s[0], like=dout),
+             empty(*wos, like=dout), empty(wos[0], like=dout)]
+    b.dout = _addr(dout)
+    for f, t in zip(("g_w1", "g_b1", "g_w2", "g_b2", "g_wo", "g_bo"), grads):
+        setattr(b, f, _addr(t))
+    nws = lib_i64("tavsr_conv2d_subsample_bwd_ws", C.byref(b))
+    ws = empty(max(nws, 4), like=dout)
+    b.ws, b.ws_floats = _addr(ws), nws
+    check(lib().tavsr_conv2d_subsample_bwd(C.byref(b), stream()), "tavsr_conv2d_subsample_bwd")
+    return grads
 
 
 def dwconv_gate_bwd(du, gn, r, conv, w, dr, B, T, zr=None, act="gelu"):
