@@ -416,6 +416,46 @@ int tavsr_dwconv_gate_bwd_act(const float* du, const float* gn, const float* r, 
                               tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The tailored audio-visual encoder layer (csrc/layer.hip): TailoredEncoderLayer.forward
+ * (src/encoder/audiovisual/tailored/encoder_layer.py:118-274).  Each modality stream runs  macaron FFN -> ONE branch (rel-pos
+ * attention or cgMLP, per layer and modality: encoder.py's acoustic_use_attn / visual_use_attn lists) with its residual -> FFN ->
+ * norm_final; the two FFNs and norm_ff_macaron / norm_ff / norm_final are shared modules, so both stream descriptors carry the same
+ * parameter pointers there.  tavsr_tailored_stream_fwd sequences ONE stream (9-10 launches); tavsr_tailored_layer_fwd runs the video
+ * stream on `stream2` beside the audio stream on the calling queue and joins them.  Fields as in tavsr_bf_layer_desc; br_ln_* is the
+ * branch's LayerNorm (norm_mha / norm_cgmlp), n_br its output; drop_off: 0 macaron inner, 1 macaron outer, 2 attention
+ * probabilities | cgMLP gate product, 3 branch output, 4 FFN inner, 5 FFN outer.  ws >= tavsr_tailored_stream_ws(d) floats each.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tavsr_tailored_stream_desc {
+  int32_t B, T, D, H, ffn_units, cg_units /* 2 C */, cg_kernel, ffn_act, save, use_attn;
+  float p_drop, p_att, coeff;
+  const float* x;                  /* [B*T][D] */
+  const float* pos_emb;            /* [2T-1][D] (attention streams) */
+  const int64_t* lens;             /* [B] */
+  const float *ffm_ln_w, *ffm_ln_b, *ffm_w1, *ffm_b1, *ffm_w2, *ffm_b2;
+  const float *br_ln_w, *br_ln_b;
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wpos, *pos_u, *pos_v, *wo, *bo;
+  const float *cg_w1, *cg_b1, *csgu_ln_w, *csgu_ln_b, *csgu_cw, *csgu_cb, *cg_w2, *cg_b2;
+  const float *ff_ln_w, *ff_ln_b, *ff_w1, *ff_b1, *ff_w2, *ff_b2, *final_ln_w, *final_ln_b;
+  const uint64_t* seed;
+  uint64_t drop_off[6];
+  float *x1, *ffm_n, *ffm_mean, *ffm_rstd, *ffm_z, *ffm_h;
+  float *n_br, *br_mean, *br_rstd;
+  float *qkv, *pp, *cx, *lse;
+  float *g, *g_z, *gn, *g_mean, *g_rstd, *u, *conv;
+  float *x2, *ff_n, *ff_mean, *ff_rstd, *ff_z, *ff_h, *x3, *y, *fin_mean, *fin_rstd;
+  float* ws;
+  int64_t ws_floats;
+} tavsr_tailored_stream_desc;
+int64_t tavsr_tailored_stream_ws(const tavsr_tailored_stream_desc* d);
+int tavsr_tailored_stream_fwd(const tavsr_tailored_stream_desc* d, tavsr_stream_t stream);
+typedef struct tavsr_tailored_layer_desc {
+  const tavsr_tailored_stream_desc *audio, *video;
+  tavsr_stream_t stream2;          /* the video stream's queue */
+  void *ev_fork, *ev_join;         /* hipEvent_t */
+} tavsr_tailored_layer_desc;
+int tavsr_tailored_layer_fwd(const tavsr_tailored_layer_desc* d, tavsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Block-level entry points (csrc/blocks.hip): a whole module of the reference model as ONE call, sequenced in C over the
  * primitive entry points above - same launches, order and results as a caller that issues them one by one.
  *

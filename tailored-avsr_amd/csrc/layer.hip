@@ -158,6 +158,163 @@ extern "C" int tavsr_branchformer_layer_fwd(const tavsr_bf_layer_desc* d, tavsr_
   return sequence(d, (hipStream_t)stream, ws);
 }
 
+// ---------------------------------------------------------------------------------------------- tailored AV layer
+// One modality stream of a TailoredEncoderLayer (src/encoder/audiovisual/tailored/encoder_layer.py:118-274): macaron FFN, the
+// stream's ONE branch (rel-pos attention or cgMLP, chosen per layer and modality) with its residual, FFN, norm_final - the launches
+// of tavsr/functional_av.py:TailoredStreamFn.forward; tavsr_tailored_layer_fwd runs the video stream on the second queue beside the
+// audio stream (the FFNs and three of the norms are shared modules: both descriptors point at the same parameters).
+namespace {
+
+int ts_ok(const tavsr_tailored_stream_desc* d, const char* who) {
+  TAVSR_REQUIRE(d, TAVSR_EINVAL, "%s: null descriptor", who);
+  TAVSR_REQUIRE(d->B > 0 && d->T > 0 && d->D == 256 && d->H > 0 && d->D % d->H == 0 && d->D / d->H == 64 && d->ffn_units >= 1024 &&
+                    d->ffn_units % 32 == 0 && (d->use_attn || (d->cg_units > 0 && d->cg_units % 128 == 0 && d->cg_units / 2 <= 1024 && d->cg_kernel == 31)),
+                TAVSR_EUNSUPPORTED, "%s: d_model 256, 64-wide heads, hidden >= 1024, cgMLP kernel 31 only", who);
+  return TAVSR_OK;
+}
+
+tavsr_ffn_desc ts_ffn(const tavsr_tailored_stream_desc* d, const float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1,
+                      const float* w2, const float* b2, float* y, float* n, float* mean, float* rstd, float* z, float* h, uint64_t off_in,
+                      uint64_t off_out) {
+  tavsr_ffn_desc f;
+  memset(&f, 0, sizeof f);
+  f.M = d->B * d->T; f.D = d->D; f.N1 = d->ffn_units; f.act = d->ffn_act;
+  f.scale = 0.5f; f.eps = 1e-12f;
+  f.x = x; f.ldx = d->D;
+  f.ln_w = ln_w; f.ln_b = ln_b; f.w1 = w1; f.b1 = b1; f.w2 = w2; f.b2 = b2;
+  f.y = y;
+  if (d->save) { f.n_out = n; f.mean = mean; f.rstd = rstd; f.z = z; f.h = h; }
+  f.p_drop = d->p_drop; f.seed = d->seed; f.offset_in = off_in; f.offset_out = off_out;
+  f.ln2_eps = 1e-12f;
+  return f;
+}
+
+// dropout offsets: 0 macaron inner, 1 macaron outer, then attention: 2 probabilities, 3 branch output | cgMLP: 2 gate product, 3 branch
+// output; 4 FFN inner, 5 FFN outer  (the order tavsr/functional_av.py draws its tokens in)
+int ts_sequence(const tavsr_tailored_stream_desc* d, hipStream_t s, Bump& ws) {
+  const int M = d->B * d->T, D = d->D, W = 2 * d->T - 1;
+  const bool dry = ws.dry;
+  int rc;
+  {
+    tavsr_ffn_desc f = ts_ffn(d, d->x, d->ffm_ln_w, d->ffm_ln_b, d->ffm_w1, d->ffm_b1, d->ffm_w2, d->ffm_b2, d->x1, d->ffm_n, d->ffm_mean, d->ffm_rstd,
+                              d->ffm_z, d->ffm_h, d->drop_off[0], d->drop_off[1]);
+    f.ln2_w[0] = d->br_ln_w; f.ln2_b[0] = d->br_ln_b; f.ln2_out[0] = d->n_br;
+    if (d->save) { f.ln2_mean = d->br_mean; f.ln2_rstd = d->br_rstd; }
+    f.ws_floats = tavsr_ffn2_ws(M, D, d->ffn_units);
+    f.ws = ws.take(f.ws_floats);
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "tailored_stream_fwd: workspace too small");
+    if (!dry && (rc = tavsr_ffn2_fwd(&f, (tavsr_stream_t)s))) return rc;
+  }
+  if (d->use_attn) {
+    if (!dry) {
+      tavsr_gemm_desc q3[3] = {lin(M, D, D, d->n_br, D, d->wq, d->bq, d->qkv, 3 * D), lin(M, D, D, d->n_br, D, d->wk, d->bk, d->qkv + D, 3 * D),
+                               lin(M, D, D, d->n_br, D, d->wv, d->bv, d->qkv + 2 * D, 3 * D)};
+      if ((rc = tavsr_gemm_grouped(q3, 3, (tavsr_stream_t)s))) return rc;
+    }
+    tavsr_gemm_desc gp = lin(W, D, D, d->pos_emb, D, d->wpos, nullptr, d->pp, D);
+    if ((rc = run_gemm(gp, ws, s))) return rc;
+    if (!dry) {
+      tavsr_attn_desc a;
+      memset(&a, 0, sizeof a);
+      a.q = d->qkv; a.k = d->qkv + D; a.v = d->qkv + 2 * D;
+      a.ldq = a.ldk = a.ldv = 3 * D;
+      a.pos = d->pp; a.ldp = D; a.bias_u = d->pos_u; a.bias_v = d->pos_v; a.klens = d->lens;
+      a.B = d->B; a.H = d->H; a.T1 = a.T2 = d->T; a.dk = D / d->H;
+      a.scale = 1.f / sqrtf((float)a.dk);
+      a.p_drop = d->p_att; a.seed_dev = d->seed; a.drop_offset = d->drop_off[2];
+      if ((rc = tavsr_attn_fwd(&a, d->cx, D, d->lse, (tavsr_stream_t)s))) return rc;
+    }
+    tavsr_gemm_desc go = lin(M, D, D, d->cx, D, d->wo, d->bo, d->x2, D);       // x2 = x1 + coeff dropout(linear_out(ctx))
+    go.alpha = d->coeff; go.R = d->x1; go.ldr = D;
+    go.drop_p = d->p_drop; go.drop_seed = d->seed; go.drop_offset = d->drop_off[3];
+    if ((rc = run_gemm(go, ws, s))) return rc;
+  } else {
+    const int C2 = d->cg_units, Cn = C2 / 2;
+    tavsr_gemm_desc g1 = lin(M, C2, D, d->n_br, D, d->cg_w1, d->cg_b1, d->g, C2);
+    g1.act = TAVSR_ACT_GELU;
+    if (d->save) g1.Z = d->g_z;
+    float* rowstat = ws.take((int64_t)M * (C2 / 64) * 2);
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "tailored_stream_fwd: workspace too small");
+    g1.rowstat = rowstat;
+    if ((rc = run_gemm(g1, ws, s))) return rc;
+    if (!dry && (rc = tavsr_csgu_fwd(d->g, C2, d->csgu_ln_w, d->csgu_ln_b, 1e-12f, d->csgu_cw, d->csgu_cb, d->u, d->save ? d->gn : nullptr,
+                                     d->save ? d->conv : nullptr, d->g_mean, d->g_rstd, d->p_drop, d->seed, d->drop_off[2], d->B, d->T, Cn,
+                                     d->cg_kernel, rowstat, (tavsr_stream_t)s)))
+      return rc;
+    tavsr_gemm_desc g2 = lin(M, D, Cn, d->u, Cn, d->cg_w2, d->cg_b2, d->x2, D);  // x2 = x1 + coeff dropout(cgmlp(.))
+    g2.alpha = d->coeff; g2.R = d->x1; g2.ldr = D;
+    g2.drop_p = d->p_drop; g2.drop_seed = d->seed; g2.drop_offset = d->drop_off[3];
+    if ((rc = run_gemm(g2, ws, s))) return rc;
+  }
+  {
+    tavsr_ffn_desc f = ts_ffn(d, d->x2, d->ff_ln_w, d->ff_ln_b, d->ff_w1, d->ff_b1, d->ff_w2, d->ff_b2, d->x3, d->ff_n, d->ff_mean, d->ff_rstd,
+                              d->ff_z, d->ff_h, d->drop_off[4], d->drop_off[5]);
+    f.ln2_w[0] = d->final_ln_w; f.ln2_b[0] = d->final_ln_b; f.ln2_out[0] = d->y;
+    if (d->save) { f.ln2_mean = d->fin_mean; f.ln2_rstd = d->fin_rstd; }
+    f.ws_floats = tavsr_ffn2_ws(M, D, d->ffn_units);
+    f.ws = ws.take(f.ws_floats);
+    TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "tailored_stream_fwd: workspace too small");
+    if (!dry && (rc = tavsr_ffn2_fwd(&f, (tavsr_stream_t)s))) return rc;
+  }
+  return TAVSR_OK;
+}
+
+int ts_check(const tavsr_tailored_stream_desc* d, const char* who) {
+  int rc = ts_ok(d, who);
+  if (rc) return rc;
+  TAVSR_REQUIRE(d->x && d->x1 && d->n_br && d->x2 && d->x3 && d->y && d->ws && d->ffm_ln_w && d->ffm_w1 && d->ffm_w2 && d->ff_ln_w && d->ff_w1 &&
+                    d->ff_w2 && d->br_ln_w && d->br_ln_b && d->final_ln_w && d->final_ln_b,
+                TAVSR_EINVAL, "%s: null buffer", who);
+  if (d->use_attn)
+    TAVSR_REQUIRE(d->pos_emb && d->wq && d->wk && d->wv && d->wo && d->wpos && d->pos_u && d->pos_v && d->qkv && d->pp && d->cx && d->lse, TAVSR_EINVAL,
+                  "%s: null attention buffer", who);
+  else
+    TAVSR_REQUIRE(d->cg_w1 && d->cg_b1 && d->csgu_ln_w && d->csgu_ln_b && d->csgu_cw && d->csgu_cb && d->cg_w2 && d->cg_b2 && d->g && d->u &&
+                      d->g_mean && d->g_rstd,
+                  TAVSR_EINVAL, "%s: null cgMLP buffer", who);
+  TAVSR_REQUIRE(!d->save || (d->ffm_n && d->ffm_mean && d->ffm_rstd && d->ffm_z && d->ffm_h && d->br_mean && d->br_rstd && d->ff_n && d->ff_mean &&
+                             d->ff_rstd && d->ff_z && d->ff_h && d->fin_mean && d->fin_rstd && (d->use_attn || (d->g_z && d->gn && d->conv))),
+                TAVSR_EINVAL, "%s: save = 1 needs every saved buffer", who);
+  TAVSR_REQUIRE((d->p_drop == 0.f && d->p_att == 0.f) || d->seed, TAVSR_EINVAL, "%s: dropout needs a device seed", who);
+  Bump dryrun{nullptr, 0, 0, true, false};
+  if ((rc = ts_sequence(d, nullptr, dryrun))) return rc;
+  TAVSR_REQUIRE(dryrun.used <= d->ws_floats, TAVSR_EINVAL, "%s: workspace too small (tavsr_tailored_stream_ws)", who);
+  return TAVSR_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t tavsr_tailored_stream_ws(const tavsr_tailored_stream_desc* d) {
+  if (ts_ok(d, "tailored_stream_ws")) return 0;
+  Bump ws{nullptr, 0, 0, true, false};
+  if (ts_sequence(d, nullptr, ws)) return 0;
+  return ws.used;
+}
+
+extern "C" int tavsr_tailored_stream_fwd(const tavsr_tailored_stream_desc* d, tavsr_stream_t stream) {
+  int rc = ts_check(d, "tailored_stream_fwd");
+  if (rc) return rc;
+  Bump ws{d->ws, d->ws_floats, 0, false, false};
+  return ts_sequence(d, (hipStream_t)stream, ws);
+}
+
+extern "C" int tavsr_tailored_layer_fwd(const tavsr_tailored_layer_desc* d, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(d && d->audio && d->video && d->ev_fork && d->ev_join, TAVSR_EINVAL, "tailored_layer_fwd: null descriptor / event");
+  int rc;
+  if ((rc = ts_check(d->audio, "tailored_layer_fwd (audio)")) || (rc = ts_check(d->video, "tailored_layer_fwd (video)"))) return rc;
+  hipStream_t s = (hipStream_t)stream, s2 = (hipStream_t)d->stream2;
+  TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_fork, s));
+  TAVSR_HIP_CHECK(hipStreamWaitEvent(s2, (hipEvent_t)d->ev_fork, 0));
+  if ((rc = probe_fork(s2, s, false))) return rc;
+  Bump wv{d->video->ws, d->video->ws_floats, 0, false, false};
+  if ((rc = ts_sequence(d->video, s2, wv))) return rc;
+  Bump wa{d->audio->ws, d->audio->ws_floats, 0, false, false};
+  if ((rc = ts_sequence(d->audio, s, wa))) return rc;
+  TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_join, s2));
+  TAVSR_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)d->ev_join, 0));
+  return probe_fork(s2, s, true);
+}
+
 // ---------------------------------------------------------------------------------------------- backward
 // tavsr_branchformer_layer_bwd: what tavsr/functional.py:BranchformerLayerFn.backward enqueues (autograd of
 // MyBranchformerEncoderLayer.forward, src/encoder/branchformer/encoder_layer.py:153-321) as one C call over the same entry

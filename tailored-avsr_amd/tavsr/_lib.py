@@ -102,6 +102,32 @@ class BfLayerBwdDesc(C.Structure):
     )
 
 
+class TailoredStreamDesc(C.Structure):
+    """tavsr_tailored_stream_desc (include/tavsr.h): field order is the header's"""
+    _fields_ = (
+        [(n, C.c_int32) for n in ("B", "T", "D", "H", "ffn_units", "cg_units", "cg_kernel", "ffn_act", "save", "use_attn")]
+        + [(n, C.c_float) for n in ("p_drop", "p_att", "coeff")]
+        + [(n, C.c_void_p) for n in (
+            "x", "pos_emb", "lens",
+            "ffm_ln_w", "ffm_ln_b", "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "br_ln_w", "br_ln_b",
+            "wq", "bq", "wk", "bk", "wv", "bv", "wpos", "pos_u", "pos_v", "wo", "bo",
+            "cg_w1", "cg_b1", "csgu_ln_w", "csgu_ln_b", "csgu_cw", "csgu_cb", "cg_w2", "cg_b2",
+            "ff_ln_w", "ff_ln_b", "ff_w1", "ff_b1", "ff_w2", "ff_b2", "final_ln_w", "final_ln_b", "seed")]
+        + [("drop_off", C.c_uint64 * 6)]
+        + [(n, C.c_void_p) for n in (
+            "x1", "ffm_n", "ffm_mean", "ffm_rstd", "ffm_z", "ffm_h", "n_br", "br_mean", "br_rstd",
+            "qkv", "pp", "cx", "lse", "g", "g_z", "gn", "g_mean", "g_rstd", "u", "conv",
+            "x2", "ff_n", "ff_mean", "ff_rstd", "ff_z", "ff_h", "x3", "y", "fin_mean", "fin_rstd", "ws")]
+        + [("ws_floats", C.c_int64)]
+    )
+
+
+class TailoredLayerDesc(C.Structure):
+    """tavsr_tailored_layer_desc (include/tavsr.h)"""
+    _fields_ = [("audio", C.POINTER(TailoredStreamDesc)), ("video", C.POINTER(TailoredStreamDesc)), ("stream2", C.c_void_p),
+                ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p)]
+
+
 class CgmlpDesc(C.Structure):
     """tavsr_cgmlp_desc (include/tavsr.h)"""
     _fields_ = ([(n, C.c_int32) for n in ("B", "T", "D", "units", "kernel", "save")]

@@ -488,6 +488,118 @@ class TailoredStreamFn(torch.autograd.Function):
 # the per-stream form keeps two launch queues whose kernels fill each other's prologue / finishing phases.  Removed in round 4.)
 
 
+_TS_WS = {}
+
+
+def _ts_c_ok(x, cfg, p) -> bool:
+    """the shapes csrc/layer.hip's tailored-stream sequencer takes (un-captured loops only unless TAVSR_LAYER_C=capture)"""
+    if not ops.LAYER_C or ops.PROFILE is not None or (ops.LAYER_C_EAGER_ONLY and torch.cuda.is_current_stream_capturing()):
+        return False
+    B, T, D = x.shape
+    w1, w1m = p["feed_forward.w_1.weight"], p["feed_forward_macaron.w_1.weight"]
+    if not (x.is_cuda and D == 256 and D // cfg["heads"] == 64 and w1.shape == w1m.shape and w1.shape[0] >= 1024 and w1.shape[0] % 32 == 0):
+        return False
+    if cfg["use_attn"]:
+        return True
+    cw, c1 = p["cgmlp.csgu.conv.weight"], p["cgmlp.channel_proj1.0.weight"]
+    return cw.shape[-1] == 31 and c1.shape[0] % 128 == 0 and c1.shape[0] // 2 <= 1024
+
+
+def _ts_c_desc(ns, x, pos_emb, lens, cfg, p, names, need):
+    """descriptor + buffers of one stream for tavsr_tailored_layer_fwd; leaves ``ns`` exactly as TailoredStreamFn.forward does
+    (the Python backward runs on it).  Draws the stream's dropout tokens in the order of the Python sequencing."""
+    from ._lib import TailoredStreamDesc, lib
+    import ctypes as C
+    B, T, D = x.shape
+    M, H = B * T, cfg["heads"]
+    N1 = p["feed_forward.w_1.weight"].shape[0]
+    ua = bool(cfg["use_attn"])
+    pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)
+    x2d = x.contiguous().view(M, D)
+    E = lambda *s: ops.empty(*s, like=x)
+    Mp = (M + 127) // 128 * 128
+    d = TailoredStreamDesc()
+    d.B, d.T, d.D, d.H, d.ffn_units, d.ffn_act, d.save, d.use_attn = B, T, D, H, N1, ops.ACT[cfg["ffn_act"]], int(need), int(ua)
+    d.p_drop, d.p_att, d.coeff = pd, pa, cfg.get("coeff", 1.0)
+    bn = "norm_mha" if ua else "norm_cgmlp"
+    fields = [("ffm_ln_w", "norm_ff_macaron.weight"), ("ffm_ln_b", "norm_ff_macaron.bias"), ("ffm_w1", "feed_forward_macaron.w_1.weight"),
+              ("ffm_b1", "feed_forward_macaron.w_1.bias"), ("ffm_w2", "feed_forward_macaron.w_2.weight"),
+              ("ffm_b2", "feed_forward_macaron.w_2.bias"), ("br_ln_w", bn + ".weight"), ("br_ln_b", bn + ".bias"),
+              ("ff_ln_w", "norm_ff.weight"), ("ff_ln_b", "norm_ff.bias"), ("ff_w1", "feed_forward.w_1.weight"), ("ff_b1", "feed_forward.w_1.bias"),
+              ("ff_w2", "feed_forward.w_2.weight"), ("ff_b2", "feed_forward.w_2.bias"), ("final_ln_w", "norm_final.weight"),
+              ("final_ln_b", "norm_final.bias")]
+    if ua:
+        fields += [("wq", "attn.linear_q.weight"), ("bq", "attn.linear_q.bias"), ("wk", "attn.linear_k.weight"), ("bk", "attn.linear_k.bias"),
+                   ("wv", "attn.linear_v.weight"), ("bv", "attn.linear_v.bias"), ("wpos", "attn.linear_pos.weight"), ("pos_u", "attn.pos_bias_u"),
+                   ("pos_v", "attn.pos_bias_v"), ("wo", "attn.linear_out.weight"), ("bo", "attn.linear_out.bias")]
+        sizes = (M * N1, M * D, B * H * T * ops.pad4(T), M * D, M * N1, M * D)
+        rates = (pd, pd, pa, pd, pd, pd)
+    else:
+        C2 = p["cgmlp.channel_proj1.0.weight"].shape[0]
+        Cn = C2 // 2
+        d.cg_units, d.cg_kernel = C2, p["cgmlp.csgu.conv.weight"].shape[-1]
+        fields += [("cg_w1", "cgmlp.channel_proj1.0.weight"), ("cg_b1", "cgmlp.channel_proj1.0.bias"), ("csgu_ln_w", "cgmlp.csgu.norm.weight"),
+                   ("csgu_ln_b", "cgmlp.csgu.norm.bias"), ("csgu_cw", "cgmlp.csgu.conv.weight"), ("csgu_cb", "cgmlp.csgu.conv.bias"),
+                   ("cg_w2", "cgmlp.channel_proj2.weight"), ("cg_b2", "cgmlp.channel_proj2.bias")]
+        sizes = (M * N1, M * D, M * Cn, M * D, M * N1, M * D)
+        rates = (pd,) * 6
+    for f, n in fields:
+        setattr(d, f, ops._addr(p[n]))
+    d.x, d.pos_emb, d.lens = ops._addr(x2d), ops._addr(pos_emb), ops._addr(lens)
+    toks = [ops._new_token(r, n, x.device) if r and r > 0.0 else None for r, n in zip(rates, sizes)]
+    for j, t in enumerate(toks):
+        if t is not None:
+            d.drop_off[j] = t[1]
+            d.seed = ops._addr(t[2])
+    b = {k: E(M, D) for k in ("x1", "n_br", "x2", "x3", "y")}
+    if ua:
+        b.update(qkv=E(M, 3 * D), pp=E(2 * T - 1, D), cx=E(M, D), lse=E(B * H, T))
+    else:
+        b.update(g=E(M, C2), u=E(M, Cn), g_mean=E(M), g_rstd=E(M))
+        if need:
+            b.update(g_z=E(M, C2), gn=E(M, Cn), conv=E(M, Cn))
+    if need:
+        b.update(ffm_n=E(M, D), ff_n=E(M, D), ffm_z=E(Mp, N1)[:M], ffm_h=E(Mp, N1)[:M], ff_z=E(Mp, N1)[:M], ff_h=E(Mp, N1)[:M])
+        b.update({k: E(M) for k in ("ffm_mean", "ffm_rstd", "br_mean", "br_rstd", "ff_mean", "ff_rstd", "fin_mean", "fin_rstd")})
+    for k, t in b.items():
+        setattr(d, k, ops._addr(t))
+    key = (B, T, D, H, N1, int(ua), d.cg_units, int(need))
+    nws = _TS_WS.get(key)
+    if nws is None:
+        fn = lib().tavsr_tailored_stream_ws
+        fn.restype = C.c_int64
+        nws = _TS_WS[key] = int(fn(C.byref(d)))
+    ws = ops.empty(max(nws, 4), like=x)
+    d.ws, d.ws_floats = ops._addr(ws), nws
+    g = b.get
+    if ua:
+        br = (g("br_mean"), g("br_rstd"), b["n_br"], b["qkv"], b["pp"], None, None, b["cx"], (b["lse"], toks[2]), None, toks[3])
+    else:
+        br = (g("br_mean"), g("br_rstd"), b["n_br"], b["g"], g("g_z"), g("gn"), b["g_mean"], b["g_rstd"], b["u"], g("conv"), toks[2], toks[3])
+    sv = {"ffm": (x2d, g("ffm_mean"), g("ffm_rstd"), g("ffm_n"), g("ffm_z"), g("ffm_h"), toks[0], toks[1]), "br": br,
+          "ff": (b["x2"], g("ff_mean"), g("ff_rstd"), g("ff_n"), g("ff_z"), g("ff_h"), toks[4], toks[5]),
+          "final": (b["x3"], g("fin_mean"), g("fin_rstd")), "x1": b["x1"]}
+    ns.sv, ns.cfg, ns.p, ns.names, ns.pos_emb, ns.shape, ns.lens = sv, cfg, p, names, pos_emb, (B, T, D), lens
+    return d, ws, b["y"].view(B, T, D)
+
+
+def _tailored_c_forward(ca, cv, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, pa, pv, names_a, names_v, need):
+    """TailoredLayerFn.forward as one C call (tavsr_tailored_layer_fwd): the video stream on the forked queue beside the audio
+    stream; every buffer comes from the calling stream's pool (the call joins the queues before it returns)."""
+    from ._lib import TailoredLayerDesc, check, lib
+    import ctypes as C
+    dv, wsv, yv = _ts_c_desc(cv, video, vpos, vlens, cfg_v, pv, names_v, need)      # (the Python sequencing draws the video stream's tokens first)
+    da, wsa, ya = _ts_c_desc(ca, audio, apos, alens, cfg_a, pa, names_a, need)
+    main = torch.cuda.current_stream()
+    side = ops.branch_stream(main) if ops.forks_enabled() else main
+    ev = ops.branch_events(main)
+    L = TailoredLayerDesc()
+    L.audio, L.video = C.pointer(da), C.pointer(dv)
+    L.stream2, L.ev_fork, L.ev_join = side.cuda_stream, ev[0].cuda_event, ev[1].cuda_event
+    check(lib().tavsr_tailored_layer_fwd(C.byref(L), C.c_void_p(main.cuda_stream)), "tavsr_tailored_layer_fwd")
+    return ya, yv
+
+
 class TailoredLayerFn(torch.autograd.Function):
     """Both modality streams of one TailoredEncoderLayer as ONE autograd node, so that the video stream can run on the
     forked stream beside the audio stream, forward and backward (two separate nodes would leave the stream hand-over
@@ -504,6 +616,11 @@ class TailoredLayerFn(torch.autograd.Function):
         ns = len(TS_SHARED)
         Pa, Pv = P[:na], P[:ns] + P[na: na + nv - ns]
         ca, cv = types.SimpleNamespace(), types.SimpleNamespace()
+        pa_, pv_ = dict(zip(names_a, Pa)), dict(zip(names_v, Pv))
+        if _ts_c_ok(audio, cfg_a, pa_) and _ts_c_ok(video, cfg_v, pv_):
+            ya, yv = _tailored_c_forward(ca, cv, audio, apos, alens, cfg_a, video, vpos, vlens, cfg_v, pa_, pv_, names_a, names_v, need)
+            ctx.ca, ctx.cv, ctx.n = ca, cv, (ns, na, nv)
+            return ya, yv
         br = ops.BranchScope(audio.is_cuda)
         with br:
             yv = TailoredStreamFn.forward(cv, video, vpos, vlens, cfg_v, *Pv)

@@ -78,3 +78,53 @@ def test_layer_in_c_is_used_and_refuses_foreign_shapes():
     b.fwd = C.pointer(d)
     assert lib().tavsr_branchformer_layer_bwd(C.byref(b), None) != 0
     assert b"save" in lib().tavsr_last_error_string()
+
+
+@pytest.mark.parametrize("ua,uv", [([True], [False]), ([False], [True]), ([True], [True]), ([False], [False])])
+@pytest.mark.parametrize("train", [False, True])
+def test_tailored_layer_forward_in_c_equals_python_sequencing(ua, uv, train):
+    """tavsr_tailored_layer_fwd (both modality streams of a TailoredEncoderLayer, the video stream on the second queue;
+    src/encoder/audiovisual/tailored/encoder_layer.py:118-274) against functional_av.TailoredLayerFn's Python sequencing: outputs
+    and - through the shared Python backward, which runs on the state the C call kept - every gradient bit-equal."""
+    from tavsr import ops
+    from tavsr.encoder.audiovisual.tailored.encoder import TailoredEncoder
+    from tavsr.layers import RelPositionalEncoding
+
+    def run(layer_c):
+        keep = ops.LAYER_C
+        ops.LAYER_C = layer_c
+        try:
+            torch.manual_seed(0)
+            B, T, D = 3, 50, 256
+            p = 0.1 if train else 0.0
+            enc = TailoredEncoder("rel_pos", "latest", num_blocks=1, dropout_rate=p, positional_dropout_rate=0.0, attention_dropout_rate=p,
+                                  acoustic_use_attn=ua, visual_use_attn=uv).cuda()
+            enc.train(train)
+            layer = enc.encoders[0]
+            g = torch.Generator(device="cuda").manual_seed(5)
+            a, v = torch.randn(B, T, D, device="cuda", generator=g), torch.randn(B, T, D, device="cuda", generator=g)
+            pe = RelPositionalEncoding(D, 0.0)
+            xa, pos = pe(a)
+            xv, _ = pe(v)
+            xa, xv = xa.detach().requires_grad_(train), xv.detach().requires_grad_(train)
+            alens, vlens = torch.tensor([T, 37, 20], device="cuda"), torch.tensor([T, T, 31], device="cuda")
+            ar = torch.arange(T, device="cuda")[None, :]
+            am, vm = (ar < alens[:, None])[:, None, :], (ar < vlens[:, None])[:, None, :]
+            ops.manual_seed(321)
+            ops.rng_step_begin(a.device)
+            with torch.set_grad_enabled(train):
+                (ya, _), _, (yv, _), _ = layer((xa, pos), am, (xv, pos), vm)
+            grads = []
+            if train:
+                ((ya * torch.randn(B, T, D, device="cuda", generator=g)).sum() + (yv * torch.randn(B, T, D, device="cuda", generator=g)).sum()).backward()
+                grads = [xa.grad, xv.grad] + [q.grad for _, q in sorted(layer.named_parameters()) if q.grad is not None]
+            return ya.detach(), yv.detach(), grads
+        finally:
+            ops.LAYER_C = keep
+
+    ya_c, yv_c, g_c = run(True)
+    ya_p, yv_p, g_p = run(False)
+    assert torch.equal(ya_c, ya_p) and torch.equal(yv_c, yv_p)
+    assert len(g_c) == len(g_p)
+    for x, y in zip(g_c, g_p):
+        assert torch.equal(x, y), float((x - y).abs().max())
