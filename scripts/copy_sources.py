@@ -17,13 +17,14 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="asr")
+    ap.add_argument("--no-opt", action="store_true", help="fwd+bwd only, as bench.py steps (gradients land through AccumulateGrad)")
     a = ap.parse_args()
     bench.WORKLOAD = a.workload
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = bench.build_product_model().to(dev).train()
     from tavsr.train import FusedAdam
-    opt = FusedAdam(model.parameters(), lr=1e-4)
+    opt = None if a.no_opt else FusedAdam(model.parameters(), lr=1e-4)
     params = [p for p in model.parameters() if p.requires_grad]
     batch = bench.make_batch(bench.B_PER_GPU, 1234, dev)
 

@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace tavsr {
@@ -647,14 +649,23 @@ __global__ __launch_bounds__(256) void ffn2_finish_kernel(const float* __restric
   const int rb = m / kRB, rr = m % kRB;       // row block, row inside it
   const float* p = slab + (((long)rb * wpb) * kRB + rr) * 256 + lane * 4;     // partial j of the block: + j * kRB * 256
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j0 = 0; j0 < wpb; j0 += 4) {         // four independent loads in flight, added in workgroup order
-    float4 t[4];
+  // every partial of the row (and the residual row) in flight before the first add: ONE exposed memory latency per row instead
+  // of one per group of four; added in workgroup order (the same sum as before)
+  float4 xres = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (res) xres = *reinterpret_cast<const float4*>(res + (long)m * ldr + lane * 4);
+  auto sum_parts = [&](auto np_tag) {
+    constexpr int NP = decltype(np_tag)::value;
+    for (int j0 = 0; j0 < wpb; j0 += NP) {
+      float4 t[NP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const float4*>(p + (long)min(j0 + j, wpb - 1) * (kRB * 256));
+      for (int j = 0; j < NP; ++j) t[j] = *reinterpret_cast<const float4*>(p + (long)min(j0 + j, wpb - 1) * (kRB * 256));
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j0 + j < wpb) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
-  }
+      for (int j = 0; j < NP; ++j)
+        if (j0 + j < wpb) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+    }
+  };
+  if (wpb <= 6) sum_parts(std::integral_constant<int, 6>{});      // (loads past wpb repeat the last partial: keep them few)
+  else sum_parts(std::integral_constant<int, 12>{});
   if (bias) {
     const float4 b = *reinterpret_cast<const float4*>(bias + lane * 4);
     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
@@ -669,10 +680,7 @@ __global__ __launch_bounds__(256) void ffn2_finish_kernel(const float* __restric
     v.w = r[3] >= thr ? v.w * inv_keep : 0.f;
   }
   v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-  if (res) {
-    const float4 x = *reinterpret_cast<const float4*>(res + (long)m * ldr + lane * 4);
-    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-  }
+  if (res) { v.x += xres.x; v.y += xres.y; v.z += xres.z; v.w += xres.w; }
   *reinterpret_cast<float4*>(y + (long)m * 256 + lane * 4) = v;
   if (o0) {
     const float mu = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
