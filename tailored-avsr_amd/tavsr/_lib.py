@@ -232,6 +232,7 @@ _FORKED = {}          # raw handle -> (torch.cuda.Stream forked, torch.cuda.Stre
 _CUR_FORK = None      # the forked stream launches currently go to (None: an owning / main stream), kept by the scopes below
 _CUR_SEEN = None      # addresses already recorded in the innermost scope (a scope re-reads its operands many times)
 SINGLE_STREAM = os.environ.get("TAVSR_SINGLE_STREAM", "0") == "1"      # every fork disabled: one queue, as the reference
+RULES_OFF = False     # (tests only: switch both rules off to show that the race amplifier then catches the missing dependencies)
 
 
 def register_fork(forked: "torch.cuda.Stream", owner: "torch.cuda.Stream") -> None:
@@ -240,7 +241,7 @@ def register_fork(forked: "torch.cuda.Stream", owner: "torch.cuda.Stream") -> No
 
 def _note(t) -> None:
     """rule 1 for one tensor (parameters and other step-persistent tensors are never freed inside a step: skipped)"""
-    if isinstance(t, torch.nn.Parameter):
+    if isinstance(t, torch.nn.Parameter) or RULES_OFF:
         return
     a = t.data_ptr()
     if _CUR_SEEN is not None:
@@ -274,7 +275,8 @@ def enter_node() -> tuple:
         if ent is None:
             _CUR_FORK = _CUR_SEEN = None
         elif _CUR_FORK is not ent[0]:
-            ent[0].wait_stream(ent[1])
+            if not RULES_OFF:
+                ent[0].wait_stream(ent[1])
             _CUR_FORK, _CUR_SEEN = ent[0], set()
     return prev
 
