@@ -52,9 +52,11 @@ def hbm_traffic(layout_key):
     """HBM bytes per launch of the dominant GEMM family, from the committed rocprofv3 PMC pass over this same step
     (scripts/gpu_pmc_hbm.sh -> profiles/summarize_pmc.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes).  PMC
     counters cannot be read from inside the process, so this is the profile's number, or None if it is absent."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_hbm_av.json" if WORKLOAD == "avsr" else "r03_pmc_hbm_asr.json")
-    if not os.path.exists(path):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_" + ("av" if WORKLOAD == "avsr" else "asr") + ".json")))
+    if not cands:
         return None
+    path = cands[-1]              # the latest round's pass
     ak, bkm = {"NT": ("false", "false"), "NN": ("false", "true"), "TN": ("true", "true"), "TT": ("true", "false")}[layout_key[-3:-1]]
     tot = calls = 0.0
     for name, v in json.load(open(path)).items():

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fwd-encoder --no-eager --sustain-s 0 "$@" > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout 420 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fwd-encoder --no-eager --no-asr --no-box --sustain-s 0 "$@" > $R/gpurun_out/pmc_$c.log 2>&1
   echo "$c rc=$?"; grep -v "^    @" $R/gpurun_out/pmc_$c.log | tail -2 | cut -c1-300
 done
 cd $R

@@ -8,7 +8,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_mfma -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fwd-encoder --no-eager --sustain-s 0 "$@" > $R/gpurun_out/pmc_mfma.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_mfma -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-fwd-encoder --no-eager --no-asr --no-box --sustain-s 0 "$@" > $R/gpurun_out/pmc_mfma.log 2>&1
 echo "rc=$?"; grep -v "^    @" $R/gpurun_out/pmc_mfma.log | tail -2 | cut -c1-300
 cd $R
 OUT=${OUT:-pmc_mfma}
