@@ -161,3 +161,30 @@ def test_stream_safety_rules_are_not_bypassed():
     assert not offenders, offenders
     assert not unguarded, unguarded
     assert not keeps, keeps
+
+
+def test_spanish_recipes_and_language_model_recipes():
+    """the Spanish recipes (configs/*spanish*.yaml: the reference's values, 37-character inventory of
+    src/tokenizers/char/spanish.txt) build with their own token list, and the LM recipes (configs/lm/*.yaml,
+    the reference's configs/LM/lm-{english,spanish}.yaml) build through ``LMTask`` with espnet2's ``lm.*`` key prefix."""
+    import copy
+
+    import yaml
+    from tavsr.tasks.asr import ASRTask
+    from tavsr.tasks.lm import LMTask
+    from tavsr.utils.tokens import CHAR_SPANISH, load_token_list
+    assert len(CHAR_SPANISH) == 37 and CHAR_SPANISH[:3] == ["<blank>", "<unk>", "<space>"] and CHAR_SPANISH[-1] == "<sos/eos>"
+    assert load_token_list("char/spanish") == CHAR_SPANISH and "Ñ" in CHAR_SPANISH and "'" not in CHAR_SPANISH
+    cfg = os.path.join(ROOT, "tailored-avsr_amd", "configs")
+    conf = yaml.safe_load(open(os.path.join(cfg, "asr_branchformer_transformer_ctc_spanish.yaml")))
+    assert conf["inference_conf"]["beam_size"] == 30 and conf["inference_conf"]["lm_weight"] == 0.4
+    model = ASRTask.build_model(argparse.Namespace(**copy.deepcopy(conf)))
+    assert model.ctc.ctc_lo.weight.shape[0] == 37 and model.decoder.output_layer.weight.shape[0] == 37
+    for lang, V in (("english", 41), ("spanish", 37)):
+        lc = yaml.safe_load(open(os.path.join(cfg, "lm", f"lm_{lang}.yaml")))
+        lm = LMTask.build_model(argparse.Namespace(**lc))
+        sd = lm.state_dict()
+        assert all(k.startswith("lm.") for k in sd) and sd["lm.embed.weight"].shape == (V, 128) and sd["lm.decoder.weight"].shape == (V, 512)
+        assert len(lm.lm.encoder.encoders) == 16
+    with pytest.raises(ValueError):
+        LMTask.build_model(argparse.Namespace(lm="rnn", lm_conf={}, token_list="char/english"))
