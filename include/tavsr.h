@@ -886,6 +886,13 @@ int tavsr_video_prep(const void* src, int32_t is_u8, int32_t Ts, int32_t H, int3
                      int32_t n_affine, const uint8_t* masked, float* mean_frame_ws, float* dst, int32_t Tpad, float pad,
                      tavsr_stream_t stream);
 int tavsr_add_noise(const float* audio, const float* noise, float* out, int64_t n, float inv_snr, tavsr_stream_t stream);
+/* Audio SpeedRate augmentation (src/transforms/audio_transforms.py:141-178: sox effects "speed f", "rate 16000" - the clip played
+ * f times faster, resampled back to the sample rate): y[n] = sum_k x[k] c sinc(c (n f - k)) Kaiser_beta((n f - k) / W) with
+ * c = rolloff * min(1, 1 / f) and W = zeros / c input samples; n_out = tavsr_resample_len(n_in, f) = round(n_in / f).  A windowed-sinc
+ * restatement of sox's band-limited rate conversion (sox itself is not reproduced bit for bit: its polyphase filter design is its own). */
+int64_t tavsr_resample_len(int64_t n_in, double factor);
+int tavsr_resample_sinc(const float* x, int64_t n_in, float* y, int64_t n_out, double factor, double rolloff, int32_t zeros, double beta,
+                        tavsr_stream_t stream);
 
 #ifdef __cplusplus
 }

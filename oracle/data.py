@@ -177,3 +177,25 @@ MEAN, STD, FPS = 0.421, 0.165, 25.0          # avsr_main.py:164-167 (lip-ROI sta
 def seed_all(seed):
     random.seed(seed)
     torch.manual_seed(seed)
+
+
+def resample_sinc(x, factor, rolloff=0.9475937167399596, zeros=64, beta=14.769656459379492):
+    """CPU restatement (numpy, fp64) of the band-limited resampling the SpeedRate augmentation stands for
+    (src/transforms/audio_transforms.py:141-178 calls sox "speed f" + "rate"; sox is absent from this image, so this follows the
+    textbook windowed-sinc interpolation with the Kaiser "best" constants - parity UNPINNED against sox itself):
+    y[n] = sum_k x[k] c sinc(c (n f - k)) w((n f - k) / W), c = rolloff min(1, 1 / f), W = zeros / c, n < round(len / f)."""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    n_out = int(round(len(x) / factor))
+    c = rolloff * min(1.0, 1.0 / factor)
+    W = zeros / c
+    y = np.zeros(n_out)
+    i0b = np.i0(beta)
+    for n in range(n_out):
+        t = n * factor
+        k0, k1 = max(0, int(np.ceil(t - W))), min(len(x) - 1, int(np.floor(t + W)))
+        k = np.arange(k0, k1 + 1)
+        u = t - k
+        w = np.i0(beta * np.sqrt(np.maximum(0.0, 1.0 - (u / W) ** 2))) / i0b
+        y[n] = np.sum(x[k] * c * np.sinc(c * u) * w)
+    return y

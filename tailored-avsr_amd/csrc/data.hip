@@ -110,6 +110,66 @@ extern "C" int tavsr_video_prep(const void* src, int32_t is_u8, int32_t Ts, int3
   return TAVSR_OK;
 }
 
+// Band-limited resampling of a mono waveform by a rational-free factor (the audio SpeedRate augmentation,
+// src/transforms/audio_transforms.py:141-178: sox "speed f" + "rate 16000" = play the clip f times faster and resample back):
+//   y[n] = sum_k x[k] c sinc(c (n f - k)) w((n f - k) / W),  c = rolloff min(1, 1 / f),  W = zeros / c,  w = Kaiser(beta)
+// One thread per output sample, taps k in [n f - W, n f + W] clipped to the clip; the window's I0 by its power series.
+__device__ __forceinline__ double bessel_i0(double x) {
+  double s = 1.0, t = 1.0;
+  const double q = 0.25 * x * x;
+  for (int k = 1; k < 64; ++k) {
+    t *= q / ((double)k * (double)k);
+    s += t;
+    if (t < 1e-17 * s) break;
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void resample_sinc_kernel(const float* __restrict__ x, int64_t n_in, float* __restrict__ y, int64_t n_out,
+                                                            double step, double cutoff, double halfw, double beta, double inv_i0b) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_out) return;
+  const double t = (double)n * step;
+  int64_t k0 = (int64_t)ceil(t - halfw), k1 = (int64_t)floor(t + halfw);
+  k0 = k0 < 0 ? 0 : k0;
+  k1 = k1 > n_in - 1 ? n_in - 1 : k1;
+  double acc = 0.0;
+  for (int64_t k = k0; k <= k1; ++k) {
+    const double u = t - (double)k, r = u / halfw;
+    const double a = cutoff * u;
+    const double sn = a == 0.0 ? 1.0 : sinpi(a) / (3.14159265358979323846 * a);
+    const double w = bessel_i0(beta * sqrt(fmax(0.0, 1.0 - r * r))) * inv_i0b;
+    acc += (double)x[k] * cutoff * sn * w;
+  }
+  y[n] = (float)acc;
+}
+
+static double host_i0(double x) {
+  double s = 1.0, t = 1.0;
+  const double q = 0.25 * x * x;
+  for (int k = 1; k < 64; ++k) {
+    t *= q / ((double)k * (double)k);
+    s += t;
+    if (t < 1e-17 * s) break;
+  }
+  return s;
+}
+
+extern "C" int64_t tavsr_resample_len(int64_t n_in, double factor) { return factor > 0.0 ? (int64_t)llround((double)n_in / factor) : 0; }
+
+extern "C" int tavsr_resample_sinc(const float* x, int64_t n_in, float* y, int64_t n_out, double factor, double rolloff, int32_t zeros,
+                                   double beta, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && y, TAVSR_EINVAL, "resample_sinc: null pointer");
+  TAVSR_REQUIRE(factor > 0.0 && rolloff > 0.0 && rolloff <= 1.0 && zeros > 0 && zeros <= 256 && beta >= 0.0, TAVSR_EINVAL,
+                "resample_sinc: factor > 0, rolloff in (0, 1], 1..256 zero crossings, beta >= 0");
+  if (n_in <= 0 || n_out <= 0) return TAVSR_OK;
+  const double cutoff = rolloff * (factor > 1.0 ? 1.0 / factor : 1.0);
+  hipLaunchKernelGGL(resample_sinc_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n_in, y, n_out, factor,
+                     cutoff, (double)zeros / cutoff, beta, 1.0 / host_i0(beta));
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
 extern "C" int tavsr_add_noise(const float* audio, const float* noise, float* out, int64_t n, float inv_snr, tavsr_stream_t stream) {
   TAVSR_REQUIRE(audio && noise && out, TAVSR_EINVAL, "add_noise: null pointer");
   if (n <= 0) return TAVSR_OK;

@@ -1590,6 +1590,23 @@ def add_noise(audio, noise, inv_snr):
 
 
 # ---------------------------------------------------------------------------------------------- error rates
+RESAMPLE_ROLLOFF, RESAMPLE_ZEROS, RESAMPLE_BETA = 0.9475937167399596, 64, 14.769656459379492      # "kaiser_best" filter constants
+
+
+def resample(audio, factor: float):
+    """band-limited resampling of a mono waveform [1, T] or [T] by ``factor`` (output length round(T / factor)): the clip played
+    ``factor`` times faster at the same sample rate (tavsr_resample_sinc)"""
+    require_cuda(audio)
+    x = audio.float().contiguous().view(-1)
+    fn = lib().tavsr_resample_len
+    fn.restype = C.c_int64
+    n_out = int(fn(C.c_int64(x.numel()), C.c_double(factor)))
+    y = empty(n_out, like=x)
+    check(lib().tavsr_resample_sinc(ptr(x), C.c_int64(x.numel()), ptr(y), C.c_int64(n_out), C.c_double(factor), C.c_double(RESAMPLE_ROLLOFF),
+                                    RESAMPLE_ZEROS, C.c_double(RESAMPLE_BETA), stream()), "tavsr_resample_sinc")
+    return y.view(*audio.shape[:-1], n_out)
+
+
 def edit_distance(ref, ref_off, hyp, hyp_off, n_pairs, max_len):
     """Levenshtein distance of n_pairs (reference, hypothesis) id sequences packed as (int32 ids, int64 offsets)."""
     require_cuda(ref, ref_off, hyp, hyp_off)

@@ -1,7 +1,9 @@
 """Audio augmentation on the MI355X: AddNoise of src/transforms/audio_transforms.py:74-139 (the evaluation
 pipeline of avsr_main.py:160-162), same constructor arguments and python ``random`` draws (offset, then SNR level).
 The noise recording is given as a tensor or as a PCM WAV file read with the standard library (the reference goes through
-sox; a file at another sample rate needs resampling first and is refused).  SpeedRate (sox "speed" effect) is not built."""
+sox; a file at another sample rate needs resampling first and is refused).  SpeedRate (src/transforms/audio_transforms.py:141-178:
+sox "speed" + "rate") is a windowed-sinc resampling launch - sox itself is absent here, so this one is a parity-unpinned restatement
+of its documented effect (band-limited rate conversion), with the reference's random draw."""
 from __future__ import annotations
 
 import os
@@ -56,3 +58,21 @@ class AddNoise:
             return audio_data
         snr = (10 ** (snr_db / 10.0)) ** 0.5
         return ops.add_noise(audio_data.float().contiguous(), noise.contiguous(), 1 / snr)
+
+
+class SpeedRate:
+    """Subsample / upsample the waveform: speed factor drawn from (0.9, 1.0, 1.1) as the reference does, then the clip is played
+    that many times faster and resampled back to ``sample_rate`` (sox effects "speed f", "rate sample_rate").  Same constructor,
+    same single ``random.choice`` draw, [1, T] in -> [1, round(T / f)] out on the device."""
+
+    FACTORS = [0.9, 1.0, 1.1]
+
+    def __init__(self, sample_rate: float = 16000):
+        self.sample_rate = sample_rate
+
+    def __call__(self, audio_data: torch.Tensor) -> torch.Tensor:
+        speed_factor = random.choice(self.FACTORS)
+        if speed_factor == 1.0:
+            return audio_data
+        ops.require_cuda(audio_data)
+        return ops.resample(audio_data, speed_factor)

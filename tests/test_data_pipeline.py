@@ -112,3 +112,45 @@ def test_asr_and_vsr_collate_and_float_clips():
     v8 = vsr_data_processing(samples, None, tr, D.CharTokenizer(), D.CharConverter(), CONFIG)
     vf = vsr_data_processing(fl, None, tr, D.CharTokenizer(), D.CharConverter(), CONFIG)
     assert torch.equal(v8["speech"], vf["speech"]) and v8["speech"].shape[2:] == (88, 88)
+
+
+def test_oracle_resampling_of_a_sine_keeps_amplitude_and_scales_frequency():
+    """SpeedRate's resampling (src/transforms/audio_transforms.py:141-178, sox "speed f" + "rate"): a 440 Hz tone played 1.1 times faster
+    is a 484 Hz tone of the same amplitude and round(T / 1.1) samples (the oracle's windowed-sinc restatement; sox itself is absent)."""
+    import numpy as np
+    from oracle.data import resample_sinc
+    fs, T = 16000, 4000
+    x = np.sin(2 * np.pi * 440.0 * np.arange(T) / fs)
+    for f in (0.9, 1.1):
+        y = resample_sinc(x, f)
+        assert len(y) == int(round(T / f))
+        n = np.arange(len(y))
+        want = np.sin(2 * np.pi * 440.0 * f * n / fs)
+        mid = slice(200, len(y) - 200)                    # away from the clip edges (the filter sees zeros beyond them)
+        assert np.abs(y[mid] - want[mid]).max() < 2e-3, (f, np.abs(y[mid] - want[mid]).max())
+
+
+@pytest.mark.gpu
+def test_speed_rate_transform_equals_the_oracle_resampling():
+    import random
+
+    import numpy as np
+    from oracle.data import resample_sinc
+    from tavsr.transforms.audio_transforms import SpeedRate
+    torch.manual_seed(3)
+    x = torch.randn(1, 6000, device="cuda")
+    tr = SpeedRate(16000)
+    seen = set()
+    for seed in range(12):
+        random.seed(seed)
+        f = random.choice([0.9, 1.0, 1.1])               # the draw the transform will make
+        random.seed(seed)
+        y = tr(x)
+        seen.add(f)
+        if f == 1.0:
+            assert y is x
+            continue
+        ref = resample_sinc(x.cpu().numpy(), f)
+        assert y.shape == (1, len(ref))
+        assert np.abs(y.cpu().numpy().reshape(-1) - ref).max() < 2e-5 * np.abs(ref).max() + 1e-6
+    assert seen == {0.9, 1.0, 1.1}
