@@ -125,8 +125,8 @@ def test_conv2d_subsample_block_vs_fp64_and_the_launches(B, T, Fq, Cn, odim):
     ref = 16.0 * F.linear(h.transpose(1, 2).contiguous().view(B, T2, Cn * F2), P[4], P[5])
     _close(y_c, ref, 2e-5)
     (ref * dout.double()).sum().backward()
-    for a, q in zip(g_c, P):
-        _close(a, q.grad, 3e-4)
+    for a, q in zip(g_c, P):      # (the weight gradients sum 60 k - 250 k positions per tap in fp32 at the encoder's batch: the full-size bar of DESIGN.md section 2, 5e-3)
+        _close(a, q.grad, 3e-4 if B * T < 2000 else 5e-3)
 
 
 def test_workspace_bytes_is_the_per_entry_query_times_four():
