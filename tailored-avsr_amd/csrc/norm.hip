@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     g[i] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int row0 = (blockIdx.x * 4 + w) * LN_RPW; row0 < M; row0 += gridDim.x * 4 * LN_RPW) {
-    float4 xv[LN_RPW][NV], dv[LN_RPW][NV], av[LN_RPW][NV];
+    float4 xv[LN_RPW][NV], dv[LN_RPW][NV], av[LN_RPW][NV];      // av: the dx_add rows, or (az given: never both) the pre-activations
     float mu[LN_RPW], rs[LN_RPW];
 #pragma unroll
     for (int q = 0; q < LN_RPW; ++q) {
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           xv[q][i] = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + c);
           dv[q][i] = *reinterpret_cast<const float4*>(dy + (int64_t)row * lddy + c);
           if (dx_add) av[q][i] = *reinterpret_cast<const float4*>(dx_add + (int64_t)row * ldadd + c);
+          else if (az) av[q][i] = *reinterpret_cast<const float4*>(az + (int64_t)row * ldaz + c);      // with the other loads, not behind the reductions
         }
       }
     }
@@ -134,12 +135,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int c = (i * 64 + lane) * 4;
         if (c < D) {
           float4 o;
-          o.x = rs[q] * (gd[i].x - s1 - xh[i].x * s2) + av[q][i].x;
-          o.y = rs[q] * (gd[i].y - s1 - xh[i].y * s2) + av[q][i].y;
-          o.z = rs[q] * (gd[i].z - s1 - xh[i].z * s2) + av[q][i].z;
-          o.w = rs[q] * (gd[i].w - s1 - xh[i].w * s2) + av[q][i].w;
-          if (az) {
-            const float4 zz = *reinterpret_cast<const float4*>(az + (int64_t)(row0 + q) * ldaz + c);
+          o.x = rs[q] * (gd[i].x - s1 - xh[i].x * s2);
+          o.y = rs[q] * (gd[i].y - s1 - xh[i].y * s2);
+          o.z = rs[q] * (gd[i].z - s1 - xh[i].z * s2);
+          o.w = rs[q] * (gd[i].w - s1 - xh[i].w * s2);
+          if (dx_add) {
+            o.x += av[q][i].x; o.y += av[q][i].y; o.z += av[q][i].z; o.w += av[q][i].w;
+          } else if (az) {
+            const float4 zz = av[q][i];
             o.x *= act_bwd(act, zz.x); o.y *= act_bwd(act, zz.y); o.z *= act_bwd(act, zz.z); o.w *= act_bwd(act, zz.w);
           }
           *reinterpret_cast<float4*>(or_ + c) = o;
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(256) void add2_colsum_part_kernel(const float* __re
     part[((int64_t)blockIdx.y * 2 + ry) * N + col] = (red[0][ry][cx] + red[1][ry][cx]) + (red[2][ry][cx] + red[3][ry][cx]);
 }
 
-static inline int ln_blocks(int M) { return min(cdiv(M, 4 * LN_RPW * 2), 512); }   // ~2 row pairs per wave
+static inline int ln_blocks(int M) { return min(cdiv(M, 4 * LN_RPW), 1024); }   // one row pair per wave up to 8192 rows: every row of the
+                                                                                  // encoder's shapes in flight at once (two passes measured 8 / 31 us at D = 256 / 1024)
 static inline int colsum_chunks(int M) { return min(cdiv(M, 64), 64); }
 
 }  // namespace tavsr
