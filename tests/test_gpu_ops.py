@@ -458,7 +458,8 @@ def test_lsm_loss_and_embed():
     ref = torch.zeros(V, D, dtype=torch.float64, device="cuda").index_add_(0, ids.view(-1), do.double() * 16)
     _close(dt, ref, 1e-5)
     # the decoder's size (32 x 41 tokens, 5000 rows), ids that repeat a lot, N not a multiple of the block; run-to-run equal
-    for n_tok, vocab in ((1312, 5000), (1000, 7), (1, 3)):
+    # (... and batches past the kernel's 15 000-token LDS list: chunks that accumulate, ADVICE round 3 - 128 x 120 tokens and more)
+    for n_tok, vocab in ((1312, 5000), (1000, 7), (1, 3), (15360, 41), (40000, 41)):
         ids = torch.randint(0, min(vocab, 50), (n_tok,), device="cuda")
         do = torch.randn(n_tok, D, device="cuda")
         dt = ops.embed_bwd(ids.view(1, -1), do, 16.0, vocab)
