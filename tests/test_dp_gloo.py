@@ -411,3 +411,52 @@ def test_two_graph_step_with_the_real_collective_between_the_replays_world1():
     finally:
         dp.shutdown()
     assert not dp.RCCL_ABI and not dp.FORCE_WORLD1
+
+
+def test_two_phase_backward_refuses_a_loss_that_bypasses_the_cut():
+    """with an intermediate-CTC tap below the cut the loss reaches the lower half of the graph without passing a
+    detached leaf; phase_a would walk (and free) it and phase_b run it again.  TwoPhaseBackward.phase_a refuses such a step;
+    the clean split still equals one backward pass."""
+    sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
+    from tavsr import dp
+    w1, w2 = torch.randn(4, 4, requires_grad=True), torch.randn(4, 4, requires_grad=True)
+    x = torch.randn(3, 4)
+
+    def net(bypass):
+        h = torch.tanh(x @ w1)
+        t = dp.cut(h)
+        y = torch.tanh(t @ w2).sum()
+        return y + (h * h).sum() if bypass else y
+
+    two = dp.TwoPhaseBackward()
+    with two.forward():
+        loss = net(True)
+    assert two.split and two.bypassed(loss)
+    with pytest.raises(RuntimeError, match="below dp.cut"):
+        two.phase_a(loss)
+    w1.grad = w2.grad = None
+    with two.forward():
+        loss = net(False)
+    assert two.split and not two.bypassed(loss)
+    assert [id(p) for p in two.late_params([w1, w2])] == [id(w1)]
+    two.phase_a(loss)
+    assert w1.grad is None and w2.grad is not None
+    two.phase_b()
+    g1, g2 = w1.grad.clone(), w2.grad.clone()
+    w1.grad = w2.grad = None
+    net(False).backward()
+    assert torch.equal(g1, w1.grad) and torch.equal(g2, w2.grad)
+
+
+def test_replan_drops_the_old_plans_staging_and_keeps_the_communication_stream():
+    sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
+    from tavsr import dp
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 7, 3, 9)]
+    gb = dp.GradBuckets(ps, bucket_bytes=32)
+    n0 = len(gb.buckets)
+    gb._hostbuf[0] = torch.zeros(3)
+    gb._comm = "stream"
+    n_early = gb.replan([ps[0]])
+    assert gb._hostbuf == {} and gb._comm == "stream"
+    assert 0 < n_early <= len(gb.buckets) and any(ps[0] is p for p in gb.buckets[-1])
+    assert sum(len(b) for b in gb.buckets) == 4 and n0 >= 1
