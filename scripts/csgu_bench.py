@@ -25,6 +25,11 @@ def main():
             return u, conv, F_._drop_(u, p)
         print(f"{mode:6s} LayerNorm + dwconv_gate (+ dropout) {timed(base):7.1f} us", flush=True)
         print(f"{mode:6s} tavsr_csgu_fwd                       {timed(lambda: ops.csgu_fwd(g, lw, lb, 1e-12, w, bias, B, T, p=p, save=save)):7.1f} us", flush=True)
+        # with the LayerNorm statistics from channel_proj1's epilogue (the layer's form: no statistics launch)
+        gg = g[:, Cn:].double().view(B * T, Cn // 64, 64)
+        rst = torch.zeros(B * T, 2 * Cn // 64, 2, device="cuda")
+        rst[:, Cn // 64:, 0], rst[:, Cn // 64:, 1] = gg.sum(-1).float(), (gg * gg).sum(-1).float()
+        print(f"{mode:6s} tavsr_csgu_fwd, statistics given     {timed(lambda: ops.csgu_fwd(g, lw, lb, 1e-12, w, bias, B, T, p=p, save=save, rowstat=rst)):7.1f} us", flush=True)
 
 
 if __name__ == "__main__":
