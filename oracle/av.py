@@ -280,20 +280,40 @@ class ConventionalEncoderOracle(nn.Module):
         assert self.acoustic_encoder.embed is None and self.visual_encoder.embed is None                  # :92-94
         self.interctc_layer_idx = list(interctc_layer_idx)
         self.interctc_use_conditioning = interctc_use_conditioning
+        self.audiovisual_interctc_conditioning = audiovisual_interctc_conditioning
         self.conditioning_layer = None
 
     def output_size(self):
         return self.acoustic_encoder.output_size()
 
     def forward(self, audio_pad, audio_masks, video_pad, video_masks, prev_states=None, ctc=None, audiovisual_fusion=None):
-        for la, lv in zip(self.acoustic_encoder.encoders, self.visual_encoder.encoders):           # :150-153 lock step
+        ae, ve = self.acoustic_encoder, self.visual_encoder
+        inter = []
+        for idx, (la, lv) in enumerate(zip(ae.encoders, ve.encoders)):           # :150-153 lock step
             audio_pad, audio_masks = la(audio_pad, audio_masks)
             video_pad, video_masks = lv(video_pad, video_masks)
+            if idx + 1 in self.interctc_layer_idx:                                   # :154-199
+                a_out, v_out = audio_pad[0], video_pad[0]
+                if ae.normalize_before:
+                    a_out = ae.after_norm(a_out)
+                if ve.normalize_before:
+                    v_out = ve.after_norm(v_out)
+                av_out, _ = audiovisual_fusion(a_out, audio_masks, v_out, video_masks)
+                inter.append((idx + 1, av_out))
+                if self.interctc_use_conditioning:
+                    if self.audiovisual_interctc_conditioning:
+                        ca = cv = ctc.softmax(av_out)
+                    else:
+                        ca, cv = ctc.softmax(a_out), ctc.softmax(v_out)
+                    audio_pad = (audio_pad[0] + self.conditioning_layer(ca), audio_pad[1])
+                    video_pad = (video_pad[0] + self.conditioning_layer(cv), video_pad[1])
         a, v = audio_pad[0], video_pad[0]
-        if self.acoustic_encoder.normalize_before:
-            a = self.acoustic_encoder.after_norm(a)
-        if self.visual_encoder.normalize_before:
-            v = self.visual_encoder.after_norm(v)
+        if ae.normalize_before:
+            a = ae.after_norm(a)
+        if ve.normalize_before:
+            v = ve.after_norm(v)
+        if inter:
+            return (a, inter), audio_masks, v, video_masks, None
         return a, audio_masks, v, video_masks, None
 
 

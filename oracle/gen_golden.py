@@ -433,8 +433,10 @@ def gen_interctc():
           gnorm_keys=np.array(list(gnorm.keys())), gnorm_vals=np.array(list(gnorm.values()), dtype=np.float64),
           keys=np.array(sorted(model.state_dict().keys())), **grads)
 
-    for tag, avcond in (("av", True), ("sep", False)):
-        conf = avsr_conf(AVSR_YAML, num_blocks=3, dec_blocks=1, interctc_layer_idx=[2], interctc_use_conditioning=True,
+    # (conv_*: the wrapper encoder's own intermediate-CTC block, conventional/encoder.py:154-199)
+    for tag, avcond, yml in (("av", True, AVSR_YAML), ("sep", False, AVSR_YAML), ("conv_av", True, AVSR_CONV_YAML),
+                             ("conv_sep", False, AVSR_CONV_YAML)):
+        conf = avsr_conf(yml, num_blocks=3, dec_blocks=1, interctc_layer_idx=[2], interctc_use_conditioning=True,
                          audiovisual_interctc_conditioning=avcond)
         conf["model_conf"]["interctc_weight"] = 0.25
         conf["token_list"] = TOKENS
@@ -451,7 +453,8 @@ def gen_interctc():
         loss_t.backward()
         params = dict(model.named_parameters())
         gnorm = {n: float(p.grad.norm()) for n, p in params.items() if p.grad is not None}
-        pick = ["encoder.conditioning_layer.weight", "ctc.ctc_lo.weight", "encoder.modality_encoding.weight",
+        pick = ["encoder.conditioning_layer.weight", "ctc.ctc_lo.weight",
+                "encoder.modality_encoding.weight" if yml == AVSR_YAML else "encoder.visual_encoder.after_norm.weight",
                 "audiovisual_fusion.audiovisual_layer.w_1.weight"]
         grads = {"g_" + n: compact(params[n].grad) for n in pick}
         _save(f"av_model_interctc_{tag}_3L", B=B, Ta=Ta, Tv=Tv, alens=_np(alens), vlens=_np(vlens), tlens=_np(tlens), text=_np(text),

@@ -60,6 +60,20 @@ def test_no_cpu_fallback_and_error_behaviour():
     layer = MyBranchformerEncoder(input_layer=None, num_blocks=1).encoders[0]
     with pytest.raises(NotImplementedError):       # encoder_layer.py:168-169
         layer((torch.zeros(1, 4, 256), torch.zeros(1, 7, 256)), None, cache=torch.zeros(1))
+    # the conventional wrapper: sub-encoder choice and its intermediate-CTC assertions (conventional/encoder.py:96-111, :211-217)
+    from tavsr.encoder.audiovisual.conventional.encoder import ConventionalEncoder
+    sub = dict(encoder_class_type="branchformer", pos_enc_layer_type="rel_pos", rel_pos_type="latest", num_blocks=2, input_layer=None)
+    ConventionalEncoder(256, dict(sub), dict(sub), interctc_layer_idx=[1], interctc_use_conditioning=True)
+    with pytest.raises(ValueError):
+        ConventionalEncoder(256, dict(sub, encoder_class_type="conformer"), dict(sub))
+    with pytest.raises(ValueError):
+        ConventionalEncoder(256, dict(sub, encoder_class_type="bogus"), dict(sub))
+    with pytest.raises(AssertionError):            # layer index outside 1 .. num_blocks - 1
+        ConventionalEncoder(256, dict(sub), dict(sub), interctc_layer_idx=[2])
+    with pytest.raises(AssertionError):            # audio-visual conditioning without conditioning
+        ConventionalEncoder(256, dict(sub), dict(sub), interctc_layer_idx=[1], audiovisual_interctc_conditioning=True)
+    with pytest.raises(AssertionError):            # intermediate CTC belongs to the wrapper, not to a wrapped encoder
+        ConventionalEncoder(256, dict(sub, interctc_layer_idx=[1]), dict(sub))
 
 
 def test_yaml_overrides_grammar(tmp_path):

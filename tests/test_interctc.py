@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import AVSR_YAML, TOKENS_EN, relu_gated_tol, asr_conf, avsr_conf, golden, grad_ok, max_rel, rel_err
+from helpers import AVSR_CONV_YAML, AVSR_YAML, TOKENS_EN, relu_gated_tol, asr_conf, avsr_conf, golden, grad_ok, max_rel, rel_err
 from oracle.av import build_avsr_oracle
 from oracle.model import build_asr_oracle, compact, fill_parameters_, synth
 
@@ -59,8 +59,8 @@ def test_oracle_asr_interctc_matches_reference():
     _check_asr(model, g, "cpu", 2e-4)
 
 
-def _av_conf(avcond):
-    conf = avsr_conf(AVSR_YAML, num_blocks=3, dec_blocks=1, interctc_layer_idx=[2], interctc_use_conditioning=True,
+def _av_conf(avcond, yml=AVSR_YAML):
+    conf = avsr_conf(yml, num_blocks=3, dec_blocks=1, interctc_layer_idx=[2], interctc_use_conditioning=True,
                      audiovisual_interctc_conditioning=avcond)
     conf["model_conf"]["interctc_weight"] = 0.25
     return conf
@@ -84,10 +84,14 @@ def _check_av(model, g, dev, tol_g):
         assert abs(float(params[str(n)].grad.norm()) - v) <= relu_gated_tol(str(n), tol_g) * max(v, 1e-6) + 1e-6, n
 
 
-@pytest.mark.parametrize("tag,avcond", [("av", True), ("sep", False)])
-def test_oracle_avsr_interctc_matches_reference(tag, avcond):
+# (conv_*: the conventional wrapper encoder's own intermediate-CTC block, conventional/encoder.py:154-199)
+AV_CASES = [("av", True, AVSR_YAML), ("sep", False, AVSR_YAML), ("conv_av", True, AVSR_CONV_YAML), ("conv_sep", False, AVSR_CONV_YAML)]
+
+
+@pytest.mark.parametrize("tag,avcond,yml", AV_CASES)
+def test_oracle_avsr_interctc_matches_reference(tag, avcond, yml):
     g = golden(f"av_model_interctc_{tag}_3L")
-    model = build_avsr_oracle(_av_conf(avcond), TOKENS_EN)
+    model = build_avsr_oracle(_av_conf(avcond, yml), TOKENS_EN)
     assert sorted(model.state_dict().keys()) == list(g["keys"])
     fill_parameters_(model, seed=311)
     _check_av(model, g, "cpu", 5e-4)
@@ -106,11 +110,11 @@ def test_hip_asr_interctc_matches_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,avcond", [("av", True), ("sep", False)])
-def test_hip_avsr_interctc_matches_reference(tag, avcond):
+@pytest.mark.parametrize("tag,avcond,yml", AV_CASES)
+def test_hip_avsr_interctc_matches_reference(tag, avcond, yml):
     from tavsr.tasks.avsr import AVSRTask
     g = golden(f"av_model_interctc_{tag}_3L")
-    conf = _av_conf(avcond)
+    conf = _av_conf(avcond, yml)
     conf["token_list"] = TOKENS_EN
     model = AVSRTask.build_model(argparse.Namespace(**conf))
     assert sorted(model.state_dict().keys()) == list(g["keys"])
