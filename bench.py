@@ -280,6 +280,16 @@ def box_calibration(dev):
 
     t_m = timed(mfma, 4)
     tf = blocks * 4 * iters * 4 * 4096.0 / t_m / 1e12
+    # the same instruction stream on random operands (a different A / B pair for every consecutive instruction): what the
+    # device's power management leaves of that rate once the multiplier inputs toggle the way activations do
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    operands = torch.randn(16, 256, generator=gen).to(dev)
+
+    def mfma_data():
+        check(lib().tavsr_mfma_peak_f32_data(iters, blocks, ptr(operands), ptr(sink), stream()), "tavsr_mfma_peak_f32_data")
+
+    t_d = timed(mfma_data, 4)
+    tf_d = blocks * 4 * iters * 4 * 4096.0 / t_d / 1e12
     n = 1 << 28
     x, y = torch.empty(n, device=dev), torch.empty(n, device=dev)
     ops.fill_(x, 1.0)
@@ -289,9 +299,11 @@ def box_calibration(dev):
     return {"device": torch.cuda.get_device_name(dev), "cus": cus,
             "fp32_mfma_tflops": round(tf, 1), "fp32_mfma_frac_of_nominal": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
             "mfma_ms_per_launch": round(1e3 * t_m, 2),
+            "fp32_mfma_tflops_data": round(tf_d, 1), "fp32_mfma_data_frac_of_nominal": round(tf_d / PEAK_FP32_MFMA_TFLOPS, 4),
             "hbm_copy_gb_per_s": round(2 * 4 * n / t_c / 1e9, 1),
             "note": "in-process calibration before the model is built: back-to-back v_mfma_f32_32x32x2_f32 on every CU "
-                    "(8 waves/CU, 4 independent accumulator tiles per wave, ~0.2 s) and a 1 GiB -> 1 GiB copy kernel"}
+                    "(8 waves/CU, 4 independent accumulator tiles per wave, ~0.2 s; `_data`: the same stream on random operands "
+                    "instead of constants) and a 1 GiB -> 1 GiB copy kernel"}
 
 
 def bench_asr_step(dev, steps=20, warmup=5):

@@ -44,6 +44,10 @@ int tavsr_race_probe(float us, int mode);
  * v_mfma_f32_32x32x2_f32 (4096 FLOP each) and nothing else - the fp32 matrix rate this device holds, against which a 5 %
  * difference between two boxes of a pool can be told from a regression.  `sink`: one device word (never written). */
 int tavsr_mfma_peak_f32(int32_t iters, int32_t blocks, float* sink, tavsr_stream_t stream);
+/* ... with operands from memory: `operands` = 16 x 256 floats (8 A / B pairs per lane, [2 j + {0, 1}][lane of the workgroup]), a
+ * different pair for every consecutive instruction; same FLOP count.  Random operands toggle the multiplier inputs the way
+ * activations do - the rate the device's power management leaves for real data (bench.py `box.fp32_mfma_tflops_data`). */
+int tavsr_mfma_peak_f32_data(int32_t iters, int32_t blocks, const float* operands, float* sink, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM (fp32 MFMA, v_mfma_f32_32x32x2_f32).  Replaces torch.nn.Linear / torch.matmul wherever the

@@ -41,11 +41,32 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Activations on the hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp each) instead of libm's expf / erff and an IEEE
+// division: Swish 6 instructions instead of ~35, GELU ~16 instead of ~50 (erff is two branches of ~45, both taken by a wave) -
+// in a K = 256 GEMM epilogue the libm GELU cost 40 % of the tile's MFMA time, in the LayerNorm backward of cgMLP's gate half it
+// was most of the launch.  erf: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute; everything here is ~1e-7 relative on the
+// activation's value, three orders inside the 1e-4 parity bar (espnet: torch.nn.GELU() = erf form, Swish = x * sigmoid(x)).
+__device__ __forceinline__ float sigmoid_fast(float z) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+// (E = exp(-x^2), shared by erf's tail and the normal density of the GELU derivative)
+__device__ __forceinline__ float erf_from_exp(float x, float E) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  return copysignf(fmaf(-p * t, E, 1.f), x);
+}
 __device__ __forceinline__ float act_fwd(int act, float z) {
   switch (act) {
     case TAVSR_ACT_RELU: return z > 0.f ? z : 0.f;
-    case TAVSR_ACT_SWISH: return z / (1.f + expf(-z));
-    case TAVSR_ACT_GELU: return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+    case TAVSR_ACT_SWISH: return z * sigmoid_fast(z);
+    case TAVSR_ACT_GELU: {
+      const float E = __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);      // exp(-z^2 / 2)
+      return 0.5f * z * (1.f + erf_from_exp(z * 0.70710678118654752440f, E));
+    }
     default: return z;
   }
 }
@@ -54,13 +75,13 @@ __device__ __forceinline__ float act_bwd(int act, float z) {
   switch (act) {
     case TAVSR_ACT_RELU: return z > 0.f ? 1.f : 0.f;
     case TAVSR_ACT_SWISH: {
-      float s = 1.f / (1.f + expf(-z));
+      const float s = sigmoid_fast(z);
       return s * (1.f + z * (1.f - s));
     }
     case TAVSR_ACT_GELU: {
-      float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
-      float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
-      return cdf + z * pdf;
+      const float E = __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);      // exp(-z^2 / 2)
+      const float cdf = 0.5f * (1.f + erf_from_exp(z * 0.70710678118654752440f, E));
+      return cdf + z * (0.39894228040143267794f * E);
     }
     default: return 1.f;
   }

@@ -62,7 +62,40 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) 
   const float s = a0[0] + a1[1] + a2[2] + a3[3];
   if (s == 12345.678f) sink[0] = s;      // (never true: keeps the loop alive)
 }
+
+// The same loop fed with DATA: 8 operand pairs per lane from memory (the caller's random numbers), a different pair for every
+// consecutive instruction - the constant operands above barely toggle the multiplier inputs, real activations do, and the
+// device's power management answers to that.
+__global__ __launch_bounds__(256) void mfma_peak_data_kernel(int iters, const float* __restrict__ ops, float* sink) {
+  f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+  float x[8], y[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    x[j] = ops[(j * 2) * 256 + threadIdx.x];
+    y[j] = ops[(j * 2 + 1) * 256 + threadIdx.x];
+  }
+  for (int i = 0; i < iters; i += 2) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[0], y[0], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[1], y[1], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[2], y[2], a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[3], y[3], a3, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[4], y[4], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[5], y[5], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[6], y[6], a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[7], y[7], a3, 0, 0, 0);
+  }
+  const float s = a0[0] + a1[1] + a2[2] + a3[3];
+  if (s == 12345.678f) sink[0] = s;
+}
 }  // namespace tavsr
+
+extern "C" int tavsr_mfma_peak_f32_data(int32_t iters, int32_t blocks, const float* operands, float* sink, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(iters > 0 && iters % 2 == 0 && blocks > 0 && blocks <= 65536 && operands && sink, TAVSR_EINVAL,
+                "mfma_peak_f32_data: an even iters > 0, blocks > 0, 4096 operand words and a sink word");
+  hipLaunchKernelGGL(tavsr::mfma_peak_data_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, operands, sink);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
 
 extern "C" int tavsr_mfma_peak_f32(int32_t iters, int32_t blocks, float* sink, tavsr_stream_t stream) {
   TAVSR_REQUIRE(iters > 0 && blocks > 0 && blocks <= 65536 && sink, TAVSR_EINVAL, "mfma_peak_f32: iters, blocks > 0 and a sink word");
