@@ -312,6 +312,12 @@ def addr(t, off: int = 0):
     return t.data_ptr() + 4 * off
 
 
+def param_ptrs(P):
+    """storage addresses of a parameter list (None -> 0), as one tuple: the signature a cached descriptor template is valid for
+    (a ``.to()`` or an optimizer that swaps ``.data`` changes it).  Parameters are not noted on a forked stream (``_note``)."""
+    return tuple(0 if p is None else p.data_ptr() for p in P)
+
+
 def cached_params(module, names):
     """[parameter or None for n in names] of ``module``, looked up once: the Parameter objects of a module never change
     identity (``.to()`` / ``load_state_dict`` / the fused optimizer swap ``.data``), while ``dict(named_parameters())`` per

@@ -283,68 +283,140 @@ def _layer_c_ok(x, cfg, P, pd, pos_emb=None) -> bool:
             and bool(ops.lib().tavsr_branchformer_layer_ok(B, T, D, cfg["heads"], w1.shape[0], 2 * cw.shape[0], cw.shape[-1])))
 
 
+_DESC_PARAMS = (("ffm_ln_w", "norm_ff_macaron.weight"), ("ffm_ln_b", "norm_ff_macaron.bias"),
+                ("ffm_w1", "feed_forward_macaron.w_1.weight"), ("ffm_b1", "feed_forward_macaron.w_1.bias"),
+                ("ffm_w2", "feed_forward_macaron.w_2.weight"), ("ffm_b2", "feed_forward_macaron.w_2.bias"),
+                ("mha_ln_w", "norm_mha.weight"), ("mha_ln_b", "norm_mha.bias"),
+                ("wq", "attn.linear_q.weight"), ("bq", "attn.linear_q.bias"), ("wk", "attn.linear_k.weight"),
+                ("bk", "attn.linear_k.bias"), ("wv", "attn.linear_v.weight"), ("bv", "attn.linear_v.bias"),
+                ("wpos", "attn.linear_pos.weight"), ("pos_u", "attn.pos_bias_u"), ("pos_v", "attn.pos_bias_v"),
+                ("wo", "attn.linear_out.weight"), ("bo", "attn.linear_out.bias"),
+                ("mlp_ln_w", "norm_mlp.weight"), ("mlp_ln_b", "norm_mlp.bias"),
+                ("cg_w1", "cgmlp.channel_proj1.0.weight"), ("cg_b1", "cgmlp.channel_proj1.0.bias"),
+                ("csgu_ln_w", "cgmlp.csgu.norm.weight"), ("csgu_ln_b", "cgmlp.csgu.norm.bias"),
+                ("csgu_cw", "cgmlp.csgu.conv.weight"), ("csgu_cb", "cgmlp.csgu.conv.bias"),
+                ("cg_w2", "cgmlp.channel_proj2.weight"), ("cg_b2", "cgmlp.channel_proj2.bias"),
+                ("merge_w", "merge_proj.weight"), ("merge_b", "merge_proj.bias"),
+                ("ff_ln_w", "norm_ff.weight"), ("ff_ln_b", "norm_ff.bias"),
+                ("ff_w1", "feed_forward.w_1.weight"), ("ff_b1", "feed_forward.w_1.bias"),
+                ("ff_w2", "feed_forward.w_2.weight"), ("ff_b2", "feed_forward.w_2.bias"),
+                ("final_ln_w", "norm_final.weight"), ("final_ln_b", "norm_final.bias"))
+_DESC_MERGE = ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias", "pooling_proj2.bias",
+               "weight_proj1.weight", "weight_proj2.weight", "weight_proj1.bias", "weight_proj2.bias")
+_DESC_TMPL = {}       # id(parameter list of a layer) -> (storage addresses, descriptor bytes with the parameter fields filled)
+_LAYER_LAYOUT = {}    # shape key -> ({buffer: (offset, shape)}, floats): the kept state of one layer as ONE allocation
+
+
+def _layer_layout(B, T, D, H, N1, C2, need):
+    """Every buffer a C-side layer forward writes besides its output, as offsets (256-byte aligned) into one allocation:
+    fifty allocator calls and tensor objects per layer were a third of an un-captured step's host time."""
+    key = (B, T, D, H, N1, C2, need)
+    lay = _LAYER_LAYOUT.get(key)
+    if lay is None:
+        M, W, Cn = B * T, 2 * T - 1, C2 // 2
+        Mp = (M + 127) // 128 * 128
+        items = [(k, (M, D)) for k in ("x1", "n_mha", "n_mlp", "cx", "xa", "xm", "m", "x2", "x3")]
+        items += [("qkv", (M, 3 * D)), ("pp", (W, D)), ("lse", (B * H, T)), ("g", (M, C2)), ("u", (M, Cn)), ("g_mean", (M,)),
+                  ("g_rstd", (M,)), ("score", (2, B, T)), ("pooled", (4, M)), ("wts", (B, 2))]
+        rows = {}
+        if need:
+            items += [("ffm_n", (M, D)), ("ff_n", (M, D))]
+            items += [(k, (Mp, N1)) for k in ("ffm_z", "ffm_h", "ff_z", "ff_h")]      # (the streaming kernel writes whole row blocks)
+            rows = {k: M for k in ("ffm_z", "ffm_h", "ff_z", "ff_h")}
+            items += [("g_z", (M, C2)), ("gn", (M, Cn)), ("conv", (M, Cn))]
+            items += [(k, (M,)) for k in ("ffm_mean", "ffm_rstd", "br_mean", "br_rstd", "ff_mean", "ff_rstd", "fin_mean", "fin_rstd")]
+        off, o = {}, 0
+        for k, shp in items:
+            n = 1
+            for v in shp:
+                n *= v
+            off[k] = (o, (rows[k],) + tuple(shp[1:]) if k in rows else tuple(shp))
+            o += (n + 63) // 64 * 64
+        lay = _LAYER_LAYOUT[key] = (off, o)
+    return lay
+
+
+def _layer_sv(flat, off, x2d, toks):
+    """the kept state as the tensors the Python sequencing keeps (views of the one allocation)"""
+    def g(k):
+        e = off.get(k)
+        if e is None:
+            return None
+        o, shp = e
+        n = 1
+        for v in shp:
+            n *= v
+        return flat[o: o + n].view(shp)
+    return {"ffm": (x2d, g("ffm_mean"), g("ffm_rstd"), g("ffm_n"), g("ffm_z"), g("ffm_h"), toks[0], toks[1]),
+            "attn": (g("br_mean"), g("br_rstd"), g("n_mha"), g("qkv"), g("pp"), None, None, g("cx"), (g("lse"), toks[2]), None, toks[3]),
+            "mlp": (g("br_mean"), g("br_rstd"), g("n_mlp"), g("g"), g("g_z"), g("gn"), g("g_mean"), g("g_rstd"), g("u"), g("conv"),
+                    toks[4], toks[5]),
+            "merge": (g("score"), g("pooled"), g("wts"), g("m")),
+            "drop": (None, toks[6]),
+            "ff": (g("x2"), g("ff_mean"), g("ff_rstd"), g("ff_n"), g("ff_z"), g("ff_h"), toks[7], toks[8]),
+            "final": (g("x3"), g("fin_mean"), g("fin_rstd")),
+            "x1": g("x1"), "xa": g("xa"), "xm": g("xm")}
+
+
+class _LazySV:
+    """``ctx.sv`` of a C-side forward: the tensors of the Python backward are only built if that path runs"""
+    __slots__ = ("flat", "off", "x2d", "toks", "_sv")
+
+    def __init__(self, flat, off, x2d, toks):
+        self.flat, self.off, self.x2d, self.toks, self._sv = flat, off, x2d, toks, None
+
+    def __getitem__(self, k):
+        if self._sv is None:
+            self._sv = _layer_sv(self.flat, self.off, self.x2d, self.toks)
+        return self._sv[k]
+
+
 def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
-    """BranchformerLayerFn.forward as one C call (tavsr_branchformer_layer_fwd): allocates what the backward pass reads,
-    fills the descriptor, leaves ``ctx`` exactly as the Python sequencing does."""
-    from ._lib import BfLayerDesc, check, lib
+    """BranchformerLayerFn.forward as one C call (tavsr_branchformer_layer_fwd).  Host side of an un-captured step: the
+    parameter fields of the descriptor come from a per-layer template (rebuilt when a parameter's storage moves), everything the
+    call writes besides its output is ONE allocation (``_layer_layout``), and the tensors the Python backward would read are
+    views built only if that path runs (``_LazySV``)."""
+    from ._lib import BfLayerDesc, check, lib, param_ptrs
     import ctypes as C
     B, T, D = x.shape
     M, H = B * T, cfg["heads"]
-    W = 2 * T - 1
-    p = lambda n: P[_I[n]]
-    N1 = p("feed_forward.w_1.weight").shape[0]
-    C2 = p("cgmlp.channel_proj1.0.weight").shape[0]
+    N1 = P[_I["feed_forward.w_1.weight"]].shape[0]
+    C2 = P[_I["cgmlp.channel_proj1.0.weight"]].shape[0]
     Cn = C2 // 2
     pd, pa = cfg.get("p", 0.0), cfg.get("p_att", 0.0)
-    E = lambda *s: ops.empty(*s, like=x)
-    Mp = (M + 127) // 128 * 128
     x2d = x.view(M, D)
-    d = BfLayerDesc()
+    sig = param_ptrs(P)
+    tm = _DESC_TMPL.get(id(P))
+    if tm is None or tm[0] != sig:
+        t = BfLayerDesc()
+        for f, n in _DESC_PARAMS:
+            setattr(t, f, sig[_I[n]])
+        for j, n in enumerate(_DESC_MERGE):
+            t.merge_p[j] = sig[_I[n]]
+        tm = _DESC_TMPL[id(P)] = (sig, bytes(t))
+    d = BfLayerDesc.from_buffer_copy(tm[1])
     d.B, d.T, d.D, d.H, d.ffn_units, d.cg_units, d.cg_kernel = B, T, D, H, N1, C2, 31
     d.ffn_act, d.save = ops.ACT[cfg["ffn_act"]], int(need)
     d.p_drop, d.p_att, d.coeff = pd, pa, cfg.get("coeff", 1.0)
     d.x, d.pos_emb, d.lens = ops._addr(x2d), ops._addr(pos_emb), ops._addr(lens)
-    for f, n in (("ffm_ln_w", "norm_ff_macaron.weight"), ("ffm_ln_b", "norm_ff_macaron.bias"),
-                 ("ffm_w1", "feed_forward_macaron.w_1.weight"), ("ffm_b1", "feed_forward_macaron.w_1.bias"),
-                 ("ffm_w2", "feed_forward_macaron.w_2.weight"), ("ffm_b2", "feed_forward_macaron.w_2.bias"),
-                 ("mha_ln_w", "norm_mha.weight"), ("mha_ln_b", "norm_mha.bias"),
-                 ("wq", "attn.linear_q.weight"), ("bq", "attn.linear_q.bias"), ("wk", "attn.linear_k.weight"),
-                 ("bk", "attn.linear_k.bias"), ("wv", "attn.linear_v.weight"), ("bv", "attn.linear_v.bias"),
-                 ("wpos", "attn.linear_pos.weight"), ("pos_u", "attn.pos_bias_u"), ("pos_v", "attn.pos_bias_v"),
-                 ("wo", "attn.linear_out.weight"), ("bo", "attn.linear_out.bias"),
-                 ("mlp_ln_w", "norm_mlp.weight"), ("mlp_ln_b", "norm_mlp.bias"),
-                 ("cg_w1", "cgmlp.channel_proj1.0.weight"), ("cg_b1", "cgmlp.channel_proj1.0.bias"),
-                 ("csgu_ln_w", "cgmlp.csgu.norm.weight"), ("csgu_ln_b", "cgmlp.csgu.norm.bias"),
-                 ("csgu_cw", "cgmlp.csgu.conv.weight"), ("csgu_cb", "cgmlp.csgu.conv.bias"),
-                 ("cg_w2", "cgmlp.channel_proj2.weight"), ("cg_b2", "cgmlp.channel_proj2.bias"),
-                 ("merge_w", "merge_proj.weight"), ("merge_b", "merge_proj.bias"),
-                 ("ff_ln_w", "norm_ff.weight"), ("ff_ln_b", "norm_ff.bias"),
-                 ("ff_w1", "feed_forward.w_1.weight"), ("ff_b1", "feed_forward.w_1.bias"),
-                 ("ff_w2", "feed_forward.w_2.weight"), ("ff_b2", "feed_forward.w_2.bias"),
-                 ("final_ln_w", "norm_final.weight"), ("final_ln_b", "norm_final.bias")):
-        setattr(d, f, ops._addr(p(n)))
-    for j, n in enumerate(("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias", "pooling_proj2.bias",
-                           "weight_proj1.weight", "weight_proj2.weight", "weight_proj1.bias", "weight_proj2.bias")):
-        d.merge_p[j] = ops._addr(p(n))
     # dropout tokens in the order the Python sequencing draws them (same masks either way)
-    T4 = ops.pad4(T)
-    sizes = (M * N1, M * D, B * H * T * T4, M * D, M * Cn, M * D, M * D, M * N1, M * D)
-    rates = (pd, pd, pa, pd, pd, pd, pd, pd, pd)
-    toks = [ops._new_token(r, n, x.device) if r and r > 0.0 else None for r, n in zip(rates, sizes)]
-    for j, t in enumerate(toks):
-        if t is not None:
-            d.drop_off[j] = t[1]
-            d.seed = ops._addr(t[2])
-    # buffers
-    b = {k: E(M, D) for k in ("x1", "n_mha", "n_mlp", "cx", "xa", "xm", "m", "x2", "x3", "y")}
-    b.update(qkv=E(M, 3 * D), pp=E(W, D), lse=E(B * H, T), g=E(M, C2), u=E(M, Cn), g_mean=E(M), g_rstd=E(M),
-             score=E(2, B, T), pooled=E(4, M), wts=E(B, 2))
-    if need:
-        b.update(ffm_n=E(M, D), ff_n=E(M, D), ffm_z=E(Mp, N1)[:M], ffm_h=E(Mp, N1)[:M], ff_z=E(Mp, N1)[:M], ff_h=E(Mp, N1)[:M],
-                 g_z=E(M, C2), gn=E(M, Cn), conv=E(M, Cn))
-        b.update({k: E(M) for k in ("ffm_mean", "ffm_rstd", "br_mean", "br_rstd", "ff_mean", "ff_rstd", "fin_mean", "fin_rstd")})
-    for k, t in b.items():
-        setattr(d, k, ops._addr(t))
+    toks = [None] * 9
+    if pd > 0.0 or pa > 0.0:
+        T4 = ops.pad4(T)
+        sizes = (M * N1, M * D, B * H * T * T4, M * D, M * Cn, M * D, M * D, M * N1, M * D)
+        rates = (pd, pd, pa, pd, pd, pd, pd, pd, pd)
+        toks = [ops._new_token(r, n, x.device) if r and r > 0.0 else None for r, n in zip(rates, sizes)]
+        for j, t in enumerate(toks):
+            if t is not None:
+                d.drop_off[j] = t[1]
+                d.seed = ops._addr(t[2])
+    off, nfl = _layer_layout(B, T, D, H, N1, C2, bool(need))
+    flat = ops.empty(nfl, like=x)
+    y = ops.empty(M, D, like=x)
+    base = ops._addr(flat)
+    for k, (o, _) in off.items():
+        setattr(d, k, base + 4 * o)
+    d.y = ops._addr(y)
     main = torch.cuda.current_stream()
     side = ops.branch_stream(main) if ops.forks_enabled() else main      # (one queue: the fork / join events order nothing new)
     ev = ops.branch_events(main)
@@ -358,24 +430,15 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
     ws = ops.empty(max(nws, 4), like=x)
     d.ws, d.ws_floats = ops._addr(ws), nws
     check(lib().tavsr_branchformer_layer_fwd(C.byref(d), C.c_void_p(main.cuda_stream)), "tavsr_branchformer_layer_fwd")
-    g = b.get
-    sv = {"ffm": (x2d, g("ffm_mean"), g("ffm_rstd"), g("ffm_n"), g("ffm_z"), g("ffm_h"), toks[0], toks[1]),
-          "attn": (g("br_mean"), g("br_rstd"), b["n_mha"], b["qkv"], b["pp"], None, None, b["cx"], (b["lse"], toks[2]), None, toks[3]),
-          "mlp": (g("br_mean"), g("br_rstd"), b["n_mlp"], b["g"], g("g_z"), g("gn"), b["g_mean"], b["g_rstd"], b["u"], g("conv"),
-                  toks[4], toks[5]),
-          "merge": (b["score"], b["pooled"], b["wts"], b["m"]),
-          "drop": (None, toks[6]),
-          "ff": (b["x2"], g("ff_mean"), g("ff_rstd"), g("ff_n"), g("ff_z"), g("ff_h"), toks[7], toks[8]),
-          "final": (b["x3"], g("fin_mean"), g("fin_rstd")),
-          "x1": b["x1"], "xa": b["xa"], "xm": b["xm"]}
-    ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = sv, cfg, P, lens, pos_emb
+    ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = _LazySV(flat, off, x2d, toks), cfg, P, lens, pos_emb
     ctx.shape = (B, T, D)
     if need:
         ctx.cdesc = d      # the descriptor (raw addresses of the parameters and of every kept buffer; ctx.sv / ctx.P hold the tensors)
     # (ws goes back to the allocator here: every launch that reads it is enqueued, the side queue has been joined into the calling
     # one inside the call, and the block can only be handed to later work of the calling queue)
-    cfg["_last_w"] = b["wts"]
-    return b["y"].view(B, T, D)
+    o, shp = off["wts"]
+    cfg["_last_w"] = flat[o: o + shp[0] * shp[1]].view(shp)
+    return y.view(B, T, D)
 
 
 # gradient slot of tavsr_bf_layer_bwd_desc -> parameter (BF_PARAM_NAMES); the five d_model LayerNorms come back in one buffer
@@ -397,9 +460,42 @@ _BWD_MERGE = ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bia
 _BWD_NORMS = ("norm_final", "norm_ff", "norm_mlp", "norm_mha", "norm_ff_macaron")
 
 
+_GRAD_LAYOUT = {}     # id(parameter list) -> (shapes, [(slot, field or merge index, offset, numel, shape)], floats)
+
+
+def _grad_layout(P, D):
+    """the layer's parameter gradients as views of ONE allocation (256-byte aligned offsets); the five d_model LayerNorms'
+    (dgamma, dbeta) pairs are one contiguous run, as tavsr_branchformer_layer_bwd writes them"""
+    shapes = tuple(None if p is None else tuple(p.shape) for p in P)
+    lay = _GRAD_LAYOUT.get(id(P))
+    if lay is None or lay[0] != shapes:
+        ent, o = [], 0
+        for f, n in _BWD_FIELDS:
+            shp = shapes[_I[n]]
+            k = 1
+            for v in shp:
+                k *= v
+            ent.append((_I[n], f, o, k, shp))
+            o += (k + 63) // 64 * 64
+        for j, n in enumerate(_BWD_MERGE):
+            shp = shapes[_I[n]]
+            k = 1
+            for v in shp:
+                k *= v
+            ent.append((_I[n], j, o, k, shp))
+            o += (k + 63) // 64 * 64
+        ln0 = o
+        for j, n in enumerate(_BWD_NORMS):
+            ent.append((_I[n + ".weight"], None, o, D, (D,)))
+            ent.append((_I[n + ".bias"], None, o + D, D, (D,)))
+            o += 2 * D
+        lay = _GRAD_LAYOUT[id(P)] = (shapes, ent, ln0, o)
+    return lay
+
+
 def _layer_c_backward(ctx, dy):
     """BranchformerLayerFn.backward as one C call (tavsr_branchformer_layer_bwd) on the state a C forward call left: allocates
-    the gradients, fills the descriptor; bit-identical to the Python sequencing below."""
+    the gradients (one block, handed out as views), fills the descriptor; bit-identical to the Python sequencing below."""
     from ._lib import BfLayerBwdDesc, check, lib
     import ctypes as C
     d, P = ctx.cdesc, ctx.P
@@ -412,19 +508,20 @@ def _layer_c_backward(ctx, dy):
     d.stream2, d.ev_fork, d.ev_join = side.cuda_stream, ev[0].cuda_event, ev[1].cuda_event
     b = BfLayerBwdDesc()
     b.fwd = C.pointer(d)
+    _, ent, ln0, nfl = _grad_layout(P, D)
+    gflat = ops.empty(nfl, like=dy2)
+    base = ops._addr(gflat)
     G: List[Optional[torch.Tensor]] = [None] * len(BF_PARAM_NAMES)
-    for f, n in _BWD_FIELDS:
-        G[_I[n]] = g = torch.empty_like(P[_I[n]], memory_format=torch.contiguous_format)
-        setattr(b, f, ops._addr(g))
-    for j, n in enumerate(_BWD_MERGE):
-        G[_I[n]] = g = torch.empty_like(P[_I[n]], memory_format=torch.contiguous_format)
-        b.g_merge_p[j] = ops._addr(g)
-    g_ln = ops.empty(len(_BWD_NORMS) * 2 * D, like=dy2)
-    for j, n in enumerate(_BWD_NORMS):
-        G[_I[n + ".weight"]] = g_ln[2 * j * D: (2 * j + 1) * D]
-        G[_I[n + ".bias"]] = g_ln[(2 * j + 1) * D: (2 * j + 2) * D]
+    for slot, f, o, k, shp in ent:
+        G[slot] = gflat[o: o + k].view(shp)
+        if f is None:
+            continue
+        if isinstance(f, int):
+            b.g_merge_p[f] = base + 4 * o
+        else:
+            setattr(b, f, base + 4 * o)
     dx = ops.empty(M, D, like=dy2)
-    b.dy, b.dx, b.g_ln = ops._addr(dy2), ops._addr(dx), ops._addr(g_ln)
+    b.dy, b.dx, b.g_ln = ops._addr(dy2), ops._addr(dx), base + 4 * ln0
     key = ("bwd", B, T, D, d.H, d.ffn_units, d.cg_units, d.p_drop > 0.0)
     nws = _LAYER_WS.get(key)
     if nws is None:

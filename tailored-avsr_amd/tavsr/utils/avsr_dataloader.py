@@ -26,6 +26,15 @@ def _pad_stack(seqs, pad_value, dtype, device):
     return out
 
 
+def _lengths(values):
+    """int64 lengths in HBM with their maximum attached as a host value: the model's "cut to the longest" (espnet_model.py:372)
+    then needs no device read (tavsr.models.espnet_model.host_max)."""
+    values = [int(v) for v in values]
+    t = torch.tensor(values, dtype=torch.int64).to(DEVICE)
+    t._tavsr_max = max(values) if values else 0
+    return t
+
+
 def _audio(sample, audio_transforms):
     audio = sample["audio"].to(DEVICE)
     audio = audio_transforms(audio) if audio_transforms else audio
@@ -46,14 +55,14 @@ def _videos(data, video_transforms, pad_value):
     out = torch.empty((len(clips), tmax, h, w), dtype=torch.float32, device=DEVICE)
     for b, c in enumerate(clips):
         c.render(out[b], pad_value)
-    return out, torch.tensor([c.shape[0] for c in clips], dtype=torch.int64, device=DEVICE)
+    return out, _lengths(c.shape[0] for c in clips)
 
 
 def _texts(data, tokenizer, converter, pad_value):
     ids = [list(converter.tokens2ids(tokenizer.text2tokens(s["transcription"]))) for s in data]
     tmax = max(len(t) for t in ids)
     text = torch.tensor([t + [pad_value] * (tmax - len(t)) for t in ids], dtype=torch.int64).to(DEVICE)
-    return text, torch.tensor([len(t) for t in ids], dtype=torch.int64).to(DEVICE)
+    return text, _lengths(len(t) for t in ids)
 
 
 def asr_data_processing(data, audio_transforms, video_transforms, tokenizer, converter, config):
@@ -62,7 +71,7 @@ def asr_data_processing(data, audio_transforms, video_transforms, tokenizer, con
     text, text_lengths = _texts(data, tokenizer, converter, pad)
     return {"sample_id": [s["sample_id"] for s in data],
             "speech": _pad_stack(speech, pad, torch.float32, DEVICE),
-            "speech_lengths": torch.tensor([a.shape[0] for a in speech], dtype=torch.int64, device=DEVICE),
+            "speech_lengths": _lengths(a.shape[0] for a in speech),
             "text": text, "text_lengths": text_lengths, "refs": [s["transcription"] for s in data]}
 
 
@@ -87,6 +96,6 @@ def avsr_data_processing(data, audio_transforms, video_transforms, tokenizer, co
     text, text_lengths = _texts(data, tokenizer, converter, pad)
     return {"sample_id": [s["sample_id"] for s in data],
             "audio": _pad_stack(audio, pad, torch.float32, DEVICE),
-            "audio_lengths": torch.tensor([a.shape[0] for a in audio], dtype=torch.int64, device=DEVICE),
+            "audio_lengths": _lengths(a.shape[0] for a in audio),
             "video": video, "video_lengths": video_lengths,
             "text": text, "text_lengths": text_lengths, "refs": [s["transcription"] for s in data]}

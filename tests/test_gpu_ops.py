@@ -595,3 +595,26 @@ def test_unpadded_strided_3x3_implicit_conv(B, H, W, C):
             dz.double().view(B, Ho, Wo, C).permute(0, 3, 1, 2))
         _close(gw.view(C, 3, 3, C), wr.grad.permute(0, 2, 3, 1), 1e-5)
         _close(gb, br.grad, 1e-5)
+
+
+@pytest.mark.gpu
+def test_cut_to_longest_reads_the_maximum_without_a_stale_answer():
+    """models/espnet_model.py:host_max - the collate functions' host value, else one device read per tensor object and
+    version (espnet_model.py:372 cuts by ``lengths.max()`` every step)."""
+    from tavsr.models import espnet_model as EM
+    x = torch.arange(4 * 10, dtype=torch.float32, device="cuda").view(4, 10)
+    lens = torch.tensor([3, 7, 5, 2], device="cuda")
+    assert EM.cut_to_longest(x, lens).shape == (4, 7)
+    assert EM._MAX_SEEN[id(lens)][2] == 7
+    assert EM.cut_to_longest(x, lens).shape == (4, 7)                 # same object, same version: from the cache
+    lens[1] = 4                                                        # in-place change: the version counter moves
+    assert EM.cut_to_longest(x, lens).shape == (4, 5)
+    key = id(lens)
+    del lens
+    assert key not in EM._MAX_SEEN                                     # the entry dies with the tensor
+    lens2 = torch.tensor([10, 1, 1, 1], device="cuda")
+    assert EM.cut_to_longest(x, lens2) is x
+    hinted = torch.tensor([2, 2, 2, 2], device="cuda")
+    hinted._tavsr_max = 6                                              # what utils/avsr_dataloader.py attaches
+    assert EM.cut_to_longest(x, hinted).shape == (4, 6)
+    assert EM.cut_to_longest(x.cpu(), torch.tensor([1, 9, 2, 2])).shape == (4, 9)
