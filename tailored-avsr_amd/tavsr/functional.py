@@ -317,7 +317,7 @@ def _layer_layout(B, T, D, H, N1, C2, need):
         Mp = (M + 127) // 128 * 128
         items = [(k, (M, D)) for k in ("x1", "n_mha", "n_mlp", "cx", "xa", "xm", "m", "x2", "x3")]
         items += [("qkv", (M, 3 * D)), ("pp", (W, D)), ("lse", (B * H, T)), ("g", (M, C2)), ("u", (M, Cn)), ("g_mean", (M,)),
-                  ("g_rstd", (M,)), ("score", (2, B, T)), ("pooled", (4, M)), ("wts", (B, 2))]
+                  ("g_rstd", (M,)), ("score", (2, B, T)), ("pooled", (4, M))]
         rows = {}
         if need:
             items += [("ffm_n", (M, D)), ("ff_n", (M, D))]
@@ -336,7 +336,7 @@ def _layer_layout(B, T, D, H, N1, C2, need):
     return lay
 
 
-def _layer_sv(flat, off, x2d, toks):
+def _layer_sv(flat, off, x2d, toks, wts):
     """the kept state as the tensors the Python sequencing keeps (views of the one allocation)"""
     def g(k):
         e = off.get(k)
@@ -351,7 +351,7 @@ def _layer_sv(flat, off, x2d, toks):
             "attn": (g("br_mean"), g("br_rstd"), g("n_mha"), g("qkv"), g("pp"), None, None, g("cx"), (g("lse"), toks[2]), None, toks[3]),
             "mlp": (g("br_mean"), g("br_rstd"), g("n_mlp"), g("g"), g("g_z"), g("gn"), g("g_mean"), g("g_rstd"), g("u"), g("conv"),
                     toks[4], toks[5]),
-            "merge": (g("score"), g("pooled"), g("wts"), g("m")),
+            "merge": (g("score"), g("pooled"), wts, g("m")),
             "drop": (None, toks[6]),
             "ff": (g("x2"), g("ff_mean"), g("ff_rstd"), g("ff_n"), g("ff_z"), g("ff_h"), toks[7], toks[8]),
             "final": (g("x3"), g("fin_mean"), g("fin_rstd")),
@@ -360,14 +360,14 @@ def _layer_sv(flat, off, x2d, toks):
 
 class _LazySV:
     """``ctx.sv`` of a C-side forward: the tensors of the Python backward are only built if that path runs"""
-    __slots__ = ("flat", "off", "x2d", "toks", "_sv")
+    __slots__ = ("flat", "off", "x2d", "toks", "wts", "_sv")
 
-    def __init__(self, flat, off, x2d, toks):
-        self.flat, self.off, self.x2d, self.toks, self._sv = flat, off, x2d, toks, None
+    def __init__(self, flat, off, x2d, toks, wts):
+        self.flat, self.off, self.x2d, self.toks, self.wts, self._sv = flat, off, x2d, toks, wts, None
 
     def __getitem__(self, k):
         if self._sv is None:
-            self._sv = _layer_sv(self.flat, self.off, self.x2d, self.toks)
+            self._sv = _layer_sv(self.flat, self.off, self.x2d, self.toks, self.wts)
         return self._sv[k]
 
 
@@ -413,10 +413,11 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
     off, nfl = _layer_layout(B, T, D, H, N1, C2, bool(need))
     flat = ops.empty(nfl, like=x)
     y = ops.empty(M, D, like=x)
+    wts = ops.empty(B, 2, like=x)      # (its own block: the module keeps it as weight_global / weight_local beyond the step)
     base = ops._addr(flat)
     for k, (o, _) in off.items():
         setattr(d, k, base + 4 * o)
-    d.y = ops._addr(y)
+    d.y, d.wts = ops._addr(y), ops._addr(wts)
     main = torch.cuda.current_stream()
     side = ops.branch_stream(main) if ops.forks_enabled() else main      # (one queue: the fork / join events order nothing new)
     ev = ops.branch_events(main)
@@ -430,14 +431,13 @@ def _layer_c_forward(ctx, x, pos_emb, lens, cfg, P, need):
     ws = ops.empty(max(nws, 4), like=x)
     d.ws, d.ws_floats = ops._addr(ws), nws
     check(lib().tavsr_branchformer_layer_fwd(C.byref(d), C.c_void_p(main.cuda_stream)), "tavsr_branchformer_layer_fwd")
-    ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = _LazySV(flat, off, x2d, toks), cfg, P, lens, pos_emb
+    ctx.sv, ctx.cfg, ctx.P, ctx.lens, ctx.pos_emb = _LazySV(flat, off, x2d, toks, wts), cfg, P, lens, pos_emb
     ctx.shape = (B, T, D)
     if need:
         ctx.cdesc = d      # the descriptor (raw addresses of the parameters and of every kept buffer; ctx.sv / ctx.P hold the tensors)
     # (ws goes back to the allocator here: every launch that reads it is enqueued, the side queue has been joined into the calling
     # one inside the call, and the block can only be handed to later work of the calling queue)
-    o, shp = off["wts"]
-    cfg["_last_w"] = flat[o: o + shp[0] * shp[1]].view(shp)
+    cfg["_last_w"] = wts
     return y.view(B, T, D)
 
 
