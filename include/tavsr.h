@@ -754,6 +754,8 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
 int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, const float* gamma, const float* beta, float eps,
                  const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr, float* out,
                  int64_t ldo, int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
+/* tuning aid (scripts/rowlin_bench.py): 1 = half the waves per block, twice the k range per wave; 0 = the library's plan */
+int tavsr_rowlin_tune(int32_t cfg);
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                          const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N, int32_t H,
                          int32_t dk, float scale, const int32_t* step_dev, const float* k_new, const float* v_new,

@@ -476,9 +476,20 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
   }
 }
 
+static int g_rowlin_cfg = 0;      // tavsr_rowlin_tune: 0 = the plan below; 1 = half the waves, twice the k per wave (tuning runs)
+
 template <int R>
 static bool rowlin_launch(const RowLinArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)((a.Nout + R - 1) / R));
+  if (g_rowlin_cfg == 1) {
+    switch (a.K) {
+      case 256: hipLaunchKernelGGL((rowlin_kernel<R, 2, 128>), grid, dim3(128), 0, st, a); return true;
+      case 512: hipLaunchKernelGGL((rowlin_kernel<R, 4, 128>), grid, dim3(256), 0, st, a); return true;
+      case 1024: hipLaunchKernelGGL((rowlin_kernel<R, 8, 128>), grid, dim3(512), 0, st, a); return true;
+      case 2048: hipLaunchKernelGGL((rowlin_kernel<R, 8, 256>), grid, dim3(512), 0, st, a); return true;
+      default: break;
+    }
+  }
   switch (a.K) {
     case 64: hipLaunchKernelGGL((rowlin_kernel<R, 1, 64>), grid, dim3(64), 0, st, a); return true;
     case 128: hipLaunchKernelGGL((rowlin_kernel<R, 2, 64>), grid, dim3(128), 0, st, a); return true;
@@ -526,6 +537,12 @@ extern "C" int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, 
   if (N <= 16) rowlin_launch<16>(a, (hipStream_t)stream);
   else rowlin_launch<32>(a, (hipStream_t)stream);
   TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_rowlin_tune(int32_t cfg) {      // tuning aid (scripts/rowlin_bench.py), not part of the product ABI
+  TAVSR_REQUIRE(cfg >= 0 && cfg <= 1, TAVSR_EINVAL, "rowlin_tune: 0 or 1");
+  g_rowlin_cfg = cfg;
   return TAVSR_OK;
 }
 

@@ -102,6 +102,13 @@ class _DecoderStep:
         self.emb = self.dec.embed[0].weight
         self.xscale = math.sqrt(D)
 
+    def refill(self, enc):
+        """a new batch of the same shape into the buffers a captured step reads (the source-attention keys / values)"""
+        U, T, D = enc.shape
+        mem2 = enc.reshape(U * T, D)
+        for L, kv in zip(self.layers, self.memkv):
+            ops.linear(mem2, L["wkv2"], L["bkv2"], out=kv, ldc=kv.stride(0))
+
     def step(self, i, tok, anc, dyn=None, **score):
         """tok [N] last tokens, anc int32 [N, >= i+1] (column i already points at this step's rows) -> logp [N, V].
         ``dyn`` = (step_dev, pe_row): the step index and its positional row come from device buffers (``i`` is then the
@@ -203,6 +210,7 @@ class BatchBeamSearch:
         # avsr_inference.py:298: pre_beam_score_key = None when ctc_weight == 1 -> the CTC prefix scorer sees every token
         self.C = self.V if ctc_weight == 1.0 else min(int(1.5 * beam_size), self.V)
         self._pinned = None
+        self._captured = None      # the captured step of the last batch shape (buffers + hipGraph), re-used while the shape repeats
         self.dec_step = _DecoderStep(model.decoder)
         self.lm_step = _LMStep(lm) if (lm is not None and lm_weight != 0.0) else None
 
@@ -229,22 +237,37 @@ class BatchBeamSearch:
                              "the CTC prefix scorer cannot score a prefix longer than its input")
         steps = max(maxl_h)
         ctc = self.model.ctc
-        logp_ctc = ops.log_softmax_rows(ops.linear(enc.reshape(U * T, D), ctc.ctc_lo.weight, ctc.ctc_lo.bias)).view(U, T, V)
-        self.dec_step.start(enc, enc_lens, N, K, steps)
-        if self.lm_step is not None:
-            self.lm_step.start(enc, N, steps, K)
-        # running state
-        tok = torch.full((N,), self.sos, dtype=torch.int64, device=dev)
-        yseq = torch.full((N, steps + 2), self.eos, dtype=torch.int64, device=dev)
-        yseq[:, 0] = self.sos
-        score = torch.full((U, K), -float("inf"), device=dev)
-        score[:, 0] = 0.0                                          # one <sos> hypothesis per utterance
-        score = score.view(N)
-        anc = torch.zeros(N, steps, dtype=torch.int32, device=dev)
-        slot_ids = torch.arange(N, dtype=torch.int32, device=dev)
-        r_prev = torch.zeros(N, T, 2, device=dev)
-        s_prev = torch.zeros(N, device=dev)
-        utt_base = (torch.arange(U, device=dev) * K).view(U, 1)
+        # A captured step is tied to its buffers, not to a batch: while the shape (utterances, frames, token budget) repeats -
+        # a stream of 4 s clips - the buffers are refilled in place and the hipGraph of the previous call is replayed; capture
+        # and warm-up were 8-10 ms of a 95 ms batch-1 search.
+        key = (U, T, D, steps, str(dev), self.lm_step is not None)
+        cap = self._captured if (GRAPH_STEP and self._captured is not None and self._captured["key"] == key) else None
+        if cap is not None:
+            logp_ctc, lens_buf = cap["logp_ctc"], cap["enc_lens"]
+            lens_buf.copy_(enc_lens)
+            enc_lens = lens_buf
+            ops.log_softmax_rows(ops.linear(enc.reshape(U * T, D), ctc.ctc_lo.weight, ctc.ctc_lo.bias), out=logp_ctc.view(U * T, V))
+            self.dec_step.refill(enc)
+            tok, yseq, score, anc, slot_ids, r_prev, s_prev, utt_base = cap["bufs"]
+        else:
+            self._captured = None
+            enc_lens = enc_lens.clone()
+            logp_ctc = ops.log_softmax_rows(ops.linear(enc.reshape(U * T, D), ctc.ctc_lo.weight, ctc.ctc_lo.bias)).view(U, T, V)
+            self.dec_step.start(enc, enc_lens, N, K, steps)
+            if self.lm_step is not None:
+                self.lm_step.start(enc, N, steps, K)
+            # running state
+            tok = torch.full((N,), self.sos, dtype=torch.int64, device=dev)
+            yseq = torch.full((N, steps + 2), self.eos, dtype=torch.int64, device=dev)
+            yseq[:, 0] = self.sos
+            score = torch.full((U, K), -float("inf"), device=dev)
+            score[:, 0] = 0.0                                          # one <sos> hypothesis per utterance
+            score = score.view(N)
+            anc = torch.zeros(N, steps, dtype=torch.int32, device=dev)
+            slot_ids = torch.arange(N, dtype=torch.int32, device=dev)
+            r_prev = torch.zeros(N, T, 2, device=dev)
+            s_prev = torch.zeros(N, device=dev)
+            utt_base = (torch.arange(U, device=dev) * K).view(U, 1)
         # host-side bookkeeping, vectorised over utterances ([U] / [N]-sized CPU tensors)
         lens_c = torch.tensor(maxl_h)                               # per-utterance maxlen: the last iteration closes every hypothesis
         active = torch.ones(U, dtype=torch.bool)
@@ -323,7 +346,12 @@ class BatchBeamSearch:
             s_prev.zero_()
 
         graph = dyn = None
-        if GRAPH_STEP:
+        if cap is not None:
+            graph, dyn = cap["graph"], cap["dyn"]
+            reset_state()
+            dyn["ctr"].copy_(torch.tensor([0, 1], dtype=torch.int64))
+            dyn["maxl"].copy_(torch.tensor(maxl_h, dtype=torch.int32))
+        elif GRAPH_STEP:
             # One token costs ~300 scorer launches plus ~90 small ones for the beam update, all on [N, d]-sized operands.
             # The whole device side of a step is captured once per decode() - the step index, the positional row, tokens,
             # ancestor lists, CTC state and scores live in fixed device buffers updated in place - and replayed per token;
@@ -349,6 +377,8 @@ class BatchBeamSearch:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 device_step(steps, dyn)
+            self._captured = dict(key=key, graph=graph, dyn=dyn, logp_ctc=logp_ctc, enc_lens=enc_lens,
+                                  bufs=(tok, yseq, score, anc, slot_ids, r_prev, s_prev, utt_base))
         ended = [[] for _ in range(U)]
 
         def host_step(i, tok_h, score_h, rows_of):

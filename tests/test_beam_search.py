@@ -100,6 +100,38 @@ def test_hip_beam_search_matches_oracle(beam, ctc_w, lm_w, pen):
 
 
 @pytest.mark.gpu
+def test_captured_step_is_reused_for_the_next_batch_of_the_same_shape():
+    """a stream of equally long clips: the second ``decode`` refills the first one's buffers and replays its hipGraph - same
+    hypotheses and scores as a search object that has never seen another batch; a different shape captures anew"""
+    from tavsr.inference.beam_search import BatchBeamSearch
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.asr import ASRTask
+    conf = asr_conf(num_blocks=2, dec_blocks=2)
+    conf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**conf)).eval()
+    fill_parameters_(pm, seed=5)
+    plm = TransformerLM(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(plm, seed=6)
+    pm, plm = pm.cuda(), plm.cuda()
+    with torch.no_grad():
+        batches = []
+        for seed, lens in ((7, [160, 120]), (8, [160, 97]), (9, [160, 160]), (10, [120, 120])):
+            x = synth((2, max(lens), 80), seed=seed).cuda()
+            batches.append(pm.encode(x, torch.tensor(lens).cuda()))
+        search = BatchBeamSearch(pm, plm, 10, 0.1, 0.6, 0.5)
+        graphs = []
+        for enc, olens in batches:
+            got = search.decode(enc, olens)
+            graphs.append(search._captured["graph"])
+            want = BatchBeamSearch(pm, plm, 10, 0.1, 0.6, 0.5).decode(enc, olens)
+            for u in range(2):
+                assert [h[0] for h in got[u]] == [h[0] for h in want[u]], u
+                assert [h[1] for h in got[u]] == [h[1] for h in want[u]], u
+    assert graphs[0] is graphs[1] is graphs[2], "same shape: the captured step must be re-used"
+    assert graphs[3] is not graphs[2], "another shape: a new capture"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ratio", [0.25, -9, 0.8])
 def test_hip_beam_search_length_ratio_matches_oracle(ratio):
     """maxlenratio != 0 (espnet BeamSearch.forward: max(1, int(ratio * T)) tokens, or -ratio tokens, no end detection; the
