@@ -754,6 +754,16 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
 int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, const float* gamma, const float* beta, float eps,
                  const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr, float* out,
                  int64_t ldo, int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
+/* The same launch with rows held as a SUM of tensors: x = sum_{p < x_parts} x[p * x_pstride + ...] (added while the operand is
+ * loaded, in that order; the LayerNorm sees the sum), res likewise; ksplit > 1: K is dealt to ksplit blocks per column tile and block y
+ * writes partial tensor y of the output at out + y * out_pstride (bias and residual ride in partial 0; no LayerNorm, no activation) -
+ * the next launch of the chain reads the partials as its x_parts / res_parts.  The 2048 -> d projection that closes a feed-forward
+ * block is otherwise 32 blocks of 16 waves, each alone with 128 KB of weights and all of x (8.3 us against 4.9 for its K = 512
+ * neighbours); no reduction launch, no atomics, no fences: the kernel boundary publishes the partials. */
+int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, int64_t x_pstride, const float* gamma, const float* beta,
+                       float eps, const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr,
+                       int32_t res_parts, int64_t res_pstride, float* out, int64_t ldo, int32_t ksplit, int64_t out_pstride,
+                       int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
 /* tuning aid (scripts/rowlin_bench.py): 1 = half the waves per block, twice the k range per wave; 0 = the library's plan */
 int tavsr_rowlin_tune(int32_t cfg);
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,

@@ -26,6 +26,7 @@ def counting_replay(self):
 torch.cuda.CUDAGraph.replay = counting_replay
 
 def timed(tag):
+    search._captured = None          # (a captured step is re-used while the shape repeats: every variant captures its own)
     for _ in range(2):
         steps_seen.append(0)
         search.decode(enc, olens, nbest=1)
@@ -39,6 +40,10 @@ def timed(tag):
     print(f"{tag:46s} {1e6 * min(ts):8.1f} us per token ({steps_seen[-1]} tokens)", flush=True)
 
 timed("both scorers, two queues")
+from tavsr import ops as _ops
+for ff in (8, 1, 4):
+    _ops.ROWLIN_KSPLIT = ff
+    timed(f"both scorers, feed-forward closing projection in {ff} K slice(s)")
 dec_step, lm_step = search.dec_step.step, search.lm_step.step
 N, V = search.K, search.V
 const = torch.full((N, V), -3.7, device=dev)

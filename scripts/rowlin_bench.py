@@ -42,4 +42,8 @@ for rnd in range(2):
             us = chain_us(lambda: ops.rowlin(x, w, b, ln=(gam, bet, 1e-12) if ln else None, act=act, res=res, out=out))
             row.append(us)
         lib().tavsr_rowlin_tune(0)
+        if K == 2048:
+            for ks in (2, 4, 8):
+                row.append(chain_us(lambda: ops.rowlin(x, w, b, res=res, ksplit=ks)))
+            print(f"round {rnd} {name:22s} K dealt to 2 / 4 / 8 blocks (partial tensors out): {row[2]:6.2f} / {row[3]:6.2f} / {row[4]:6.2f} us", flush=True)
         print(f"round {rnd} {name:22s} K {K:5d} -> {Nout:5d}: plan {row[0]:6.2f} us   half-waves {row[1]:6.2f} us", flush=True)

@@ -376,6 +376,9 @@ struct RowLinArgs {
   const float* W; int64_t ldw; const float* bias;
   const float* res; int64_t ldr; float* out; int64_t ldo;
   int N, K, Nout, act;
+  // rows held as a SUM of tensors (tavsr_rowlin_parts): x = sum_p x[p * xps ..], res likewise; gridDim.y > 1: block y owns a K
+  // slice and writes partial tensor y of the output (stride ops) - the next launch of the chain adds them while it loads
+  int xparts; int64_t xps; int rparts; int64_t rps; int64_t ops;
 };
 
 template <int R, int WPB, int KW>
@@ -390,7 +393,8 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
   const int r = lane & (R - 1), g = lane / R;
   const int col0 = blockIdx.x * R;
   const int row = min(r, a.N - 1), col = min(col0 + r, a.Nout - 1);     // surplus lanes repeat the last row / column
-  const int kb = wave * KW + 4 * g;
+  // (K dealt to gridDim.y blocks: block y owns k in [y WPB KW, (y + 1) WPB KW); no LayerNorm then - it needs whole rows)
+  const int kb = blockIdx.y * (WPB * KW) + wave * KW + 4 * g;
   const float* xr = a.x + (a.gather ? a.gather[row] : (int64_t)row) * a.ldx + kb;
   const float* wr = a.W + (int64_t)col * a.ldw + kb;
   float4 av[NJ], bv[NJ];
@@ -398,6 +402,13 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
   for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(wr + 4 * G * j);
 #pragma unroll
   for (int j = 0; j < NJ; ++j) av[j] = *reinterpret_cast<const float4*>(xr + 4 * G * j);
+  for (int p = 1; p < a.xparts; ++p) {      // the rows arrive as a sum of partial tensors (same order every time)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + p * a.xps + 4 * G * j);
+      av[j].x += t.x; av[j].y += t.y; av[j].z += t.z; av[j].w += t.w;
+    }
+  }
   if (a.gamma) {
     float4 gv[NJ], ev[NJ];
 #pragma unroll
@@ -468,10 +479,13 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
 #pragma unroll
     for (int w = 0; w < WPB; ++w) v += s_acc[w][q][l];
     if (rw < a.N && c < a.Nout) {
-      if (a.bias) v += a.bias[c];
-      v = act_fwd(a.act, v);
-      if (a.res) v += a.res[(int64_t)rw * a.ldr + c];
-      a.out[(int64_t)rw * a.ldo + c] = v;
+      if (blockIdx.y == 0) {          // (a K slice other than the first carries neither bias nor residual; no activation when split)
+        if (a.bias) v += a.bias[c];
+        v = act_fwd(a.act, v);
+        if (a.res)
+          for (int p = 0; p < a.rparts; ++p) v += a.res[p * a.rps + (int64_t)rw * a.ldr + c];
+      }
+      a.out[blockIdx.y * a.ops + (int64_t)rw * a.ldo + c] = v;
     }
   }
 }
@@ -479,8 +493,16 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
 static int g_rowlin_cfg = 0;      // tavsr_rowlin_tune: 0 = the plan below; 1 = half the waves, twice the k per wave (tuning runs)
 
 template <int R>
-static bool rowlin_launch(const RowLinArgs& a, hipStream_t st) {
-  const dim3 grid((unsigned)((a.Nout + R - 1) / R));
+static bool rowlin_launch(const RowLinArgs& a, hipStream_t st, int ksplit = 1) {
+  const dim3 grid((unsigned)((a.Nout + R - 1) / R), (unsigned)ksplit);
+  if (ksplit > 1) {
+    switch (a.K / ksplit) {      // K of one slice
+      case 256: hipLaunchKernelGGL((rowlin_kernel<R, 4, 64>), grid, dim3(256), 0, st, a); return true;
+      case 512: hipLaunchKernelGGL((rowlin_kernel<R, 8, 64>), grid, dim3(512), 0, st, a); return true;
+      case 1024: hipLaunchKernelGGL((rowlin_kernel<R, 16, 64>), grid, dim3(1024), 0, st, a); return true;
+      default: return false;
+    }
+  }
   if (g_rowlin_cfg == 1) {
     switch (a.K) {
       case 256: hipLaunchKernelGGL((rowlin_kernel<R, 2, 128>), grid, dim3(128), 0, st, a); return true;
@@ -533,9 +555,44 @@ extern "C" int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, 
                 TAVSR_EALIGN, "rowlin: rows of x / W (and gamma / beta) must be 16-byte aligned");
   TAVSR_REQUIRE(out != x, TAVSR_EINVAL, "rowlin: out must not alias x");
   if (N <= 0 || Nout <= 0) return TAVSR_OK;
-  RowLinArgs a{x, ldx, gather, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act};
+  RowLinArgs a{x, ldx, gather, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act, 1, 0, 1, 0, 0};
   if (N <= 16) rowlin_launch<16>(a, (hipStream_t)stream);
   else rowlin_launch<32>(a, (hipStream_t)stream);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, int64_t x_pstride, const float* gamma,
+                                  const float* beta, float eps, const float* W, int64_t ldw, const float* bias, int32_t act,
+                                  const float* res, int64_t ldr, int32_t res_parts, int64_t res_pstride, float* out, int64_t ldo,
+                                  int32_t ksplit, int64_t out_pstride, int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(x && W && out, TAVSR_EINVAL, "rowlin_parts: null pointer");
+  TAVSR_REQUIRE((gamma == nullptr) == (beta == nullptr), TAVSR_EINVAL, "rowlin_parts: gamma and beta go together");
+  TAVSR_REQUIRE(N >= 0 && N <= 32, TAVSR_EUNSUPPORTED, "rowlin_parts: up to 32 rows (got %d)", N);
+  TAVSR_REQUIRE(x_parts >= 1 && x_parts <= 16 && res_parts >= 1 && res_parts <= 16 && ksplit >= 1 && ksplit <= 16, TAVSR_EINVAL,
+                "rowlin_parts: 1..16 partial tensors / K slices");
+  TAVSR_REQUIRE(x_pstride % 4 == 0 && (x_parts == 1 || x_pstride >= (int64_t)N * ldx) && (res_parts == 1 || !res || res_pstride > 0),
+                TAVSR_EINVAL, "rowlin_parts: partial tensors must be whole [N][ld] slabs, 16-byte aligned");
+  if (ksplit > 1) {
+    TAVSR_REQUIRE(!gamma && act == TAVSR_ACT_NONE, TAVSR_EUNSUPPORTED,
+                  "rowlin_parts: a K split carries neither LayerNorm (whole rows) nor an activation (it is not additive)");
+    TAVSR_REQUIRE(K % ksplit == 0 && (K / ksplit == 256 || K / ksplit == 512 || K / ksplit == 1024), TAVSR_EUNSUPPORTED,
+                  "rowlin_parts: slices of 256, 512 or 1024 (got K = %d, %d slices)", K, ksplit);
+    TAVSR_REQUIRE(out_pstride >= (int64_t)N * ldo, TAVSR_EINVAL, "rowlin_parts: output partial tensors overlap");
+  } else {
+    TAVSR_REQUIRE(K == 64 || K == 128 || K == 256 || K == 512 || K == 1024 || K == 2048, TAVSR_EUNSUPPORTED,
+                  "rowlin_parts: K in {64, 128, 256, 512, 1024, 2048} (got %d)", K);
+  }
+  TAVSR_REQUIRE(!gamma || K <= 1024, TAVSR_EUNSUPPORTED, "rowlin_parts: LayerNorm prologue up to K = 1024");
+  TAVSR_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)x | (uintptr_t)W) & 15) == 0 &&
+                    (!gamma || (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
+                TAVSR_EALIGN, "rowlin_parts: rows of x / W (and gamma / beta) must be 16-byte aligned");
+  TAVSR_REQUIRE(out != x, TAVSR_EINVAL, "rowlin_parts: out must not alias x");
+  if (N <= 0 || Nout <= 0) return TAVSR_OK;
+  RowLinArgs a{x, ldx, nullptr, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act,
+               x_parts, x_pstride, res_parts, res_pstride, out_pstride};
+  const bool ok = N <= 16 ? rowlin_launch<16>(a, (hipStream_t)stream, ksplit) : rowlin_launch<32>(a, (hipStream_t)stream, ksplit);
+  TAVSR_REQUIRE(ok, TAVSR_EUNSUPPORTED, "rowlin_parts: no kernel for K = %d in %d slices", K, ksplit);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -52,18 +52,22 @@ def _ln_linear(x, norm, w, b, act=None):
     return ops.linear(n, w, b, act=act)
 
 
-def _linear_res(x, w, b, res):
-    """res + W x + b."""
+def _linear_res(x, w, b, res, ksplit=1):
+    """res + W x + b (``ksplit`` > 1, up to 16 rows: K dealt to that many blocks per column tile, the result an ``ops.RowParts``)."""
     if ops.rowlin_ok(x, w):
+        if ksplit > 1 and x.shape[0] <= 16 and x.shape[1] % ksplit == 0 and x.shape[1] // ksplit in (256, 512, 1024):
+            return ops.rowlin(x, w, b, res=res, ksplit=ksplit)
         return ops.rowlin(x, w, b, res=res)
     return ops.linear(x, w, b, res=res)
 
 
 def _ffn_step(x, norm, L):
-    """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows."""
+    """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows.  Up to 16 rows, hidden size 2048:
+    the closing projection deals its K to ops.ROWLIN_KSPLIT blocks per column tile and the result stays a sum of that many tensors
+    (``ops.RowParts``) until the next launches of the chain add them while they load their operands."""
     if ops.rowlin_ok(x, L["w1"]):
         t = ops.rowlin(x, L["w1"], L["b1"], ln=(norm[0], norm[1], EPS), act="relu")
-        return _linear_res(t, L["w2"], L["b2"], x)
+        return _linear_res(t, L["w2"], L["b2"], x, ops.ROWLIN_KSPLIT if t.shape[1] == 2048 else 1)
     n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
     t = ops.linear(n, L["w1"], L["b1"], act="relu")
     return ops.linear(t, L["w2"], L["b2"], res=x)

@@ -1634,15 +1634,53 @@ ROWLIN = True
 
 def rowlin_ok(x, w, n_rows=None) -> bool:
     """the one-launch small-step Linear (tavsr_rowlin) takes up to 32 rows and K in {64 .. 2048} powers of two."""
+    if isinstance(x, RowParts):
+        x = x.t[0]
     K = x.shape[1]
     N = x.shape[0] if n_rows is None else n_rows
     return (ROWLIN and N <= 32 and K in (64, 128, 256, 512, 1024, 2048) and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
             and x.stride(1) == 1 and w.stride(1) == 1 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
-def rowlin(x, w, b=None, *, ln=None, act=None, res=None, out=None, gather=None):
+class RowParts:
+    """rows held as a SUM of tensors: ``t`` [P, N, D] contiguous - what a K-split ``rowlin`` leaves and the next launches of the
+    chain add while they load (tavsr_rowlin_parts)"""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        assert t.dim() == 3 and t.is_contiguous()
+        self.t = t
+
+    @property
+    def shape(self):
+        return self.t.shape[1:]
+
+    def sum(self):
+        return self.t.sum(0)
+
+
+ROWLIN_KSPLIT = 4      # K slices of the 2048 -> d projection of a one-token feed-forward block (<= 16 rows); 0: one block per tile
+
+
+def rowlin(x, w, b=None, *, ln=None, act=None, res=None, out=None, gather=None, ksplit=1):
     """out = res + act(LN(x[gather]) @ w.T + b) in one launch (csrc/decode.hip:rowlin_kernel) - the Linear layers of a
-    one-token scorer step.  ln = (gamma, beta, eps) or None; gather: int64 row indices into x (embedding lookup)."""
+    one-token scorer step.  ln = (gamma, beta, eps) or None; gather: int64 row indices into x (embedding lookup).
+    ``x`` / ``res`` may be ``RowParts``; ``ksplit`` > 1 deals K to that many blocks per column tile and returns ``RowParts``."""
+    if isinstance(x, RowParts) or isinstance(res, RowParts) or ksplit > 1:
+        assert gather is None
+        xt, xp = (x.t[0], x.t.shape[0]) if isinstance(x, RowParts) else (x, 1)
+        rt, rp = (res.t[0], res.t.shape[0]) if isinstance(res, RowParts) else (res, 1)
+        N, K, Nout = xt.shape[0], xt.shape[1], w.shape[0]
+        require_cuda(xt, w)
+        assert w.shape[1] == K and out is None
+        g, be, eps = ln if ln is not None else (None, None, 0.0)
+        o = empty(ksplit, N, Nout, like=xt) if ksplit > 1 else empty(N, Nout, like=xt)
+        check(lib().tavsr_rowlin_parts(ptr(xt), C.c_int64(xt.stride(0)), xp, C.c_int64(x.t.stride(0) if xp > 1 else 0), ptr(g),
+                                       ptr(be), C.c_float(eps), ptr(w), C.c_int64(w.stride(0)), ptr(b), ACT[act], ptr(rt),
+                                       C.c_int64(0 if rt is None else rt.stride(0)), rp, C.c_int64(res.t.stride(0) if rp > 1 else 0),
+                                       ptr(o), C.c_int64(Nout), ksplit, C.c_int64(N * Nout if ksplit > 1 else 0), N, K, Nout,
+                                       stream()), "tavsr_rowlin_parts")
+        return RowParts(o) if ksplit > 1 else o
     N = x.shape[0] if gather is None else gather.numel()
     K, Nout = x.shape[1], w.shape[0]
     require_cuda(x, w)

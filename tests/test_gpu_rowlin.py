@@ -68,6 +68,33 @@ def test_rowlin_gathers_embedding_rows_and_may_write_over_its_residual():
     assert float((out.double() - ref).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("N,D,ks", [(10, 512, 4), (10, 256, 4), (16, 512, 2), (3, 256, 8)])
+def test_rowlin_k_split_leaves_partial_tensors_the_next_launches_add_while_loading(N, D, ks):
+    """tavsr_rowlin_parts: the closing projection of a feed-forward block (2048 -> D) as ``ks`` K slices, then the two consumers of
+    its result in a scorer step - LayerNorm + Linear on the rows, and a Linear that takes them as its residual - against fp64"""
+    from tavsr import ops
+    g = torch.Generator(device="cuda").manual_seed(N + D + ks)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    t, w2, b2, x = r(N, 2048).relu(), r(D, 2048) / 45, r(D), r(N, D)
+    parts = ops.rowlin(t, w2, b2, res=x, ksplit=ks)
+    assert isinstance(parts, ops.RowParts) and parts.t.shape == (ks, N, D)
+    ref = _ref(t, w2, b2, None, None, x)
+    assert float((parts.t.double().sum(0) - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert float((ops.rowlin(t, w2, b2, res=x).double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    # consumer 1: LayerNorm + Linear of the summed rows
+    w, b, lnp = r(3 * D, D) / D ** 0.5, r(3 * D), (r(D).abs() + 0.5, r(D), 1e-12)
+    y = ops.rowlin(parts, w, b, ln=lnp)
+    ref1 = _ref(ref.float(), w, b, lnp, None, None)
+    assert float((y.double() - ref1).abs().max() / ref1.abs().max()) < 5e-6
+    # consumer 2: the summed rows as the residual of another Linear
+    a, wo, bo = r(N, D), r(D, D) / D ** 0.5, r(D)
+    y2 = ops.rowlin(a, wo, bo, res=parts)
+    ref2 = _ref(a, wo, bo, None, None, None) + ref
+    assert float((y2.double() - ref2).abs().max() / ref2.abs().max()) < 2e-6
+    with pytest.raises(RuntimeError):       # an activation is not additive over K slices
+        ops.rowlin(t, w2, b2, act="relu", ksplit=ks)
+
+
 def test_rowlin_rejects_what_it_cannot_do():
     from tavsr import ops
     w = torch.randn(8, 96, device="cuda")
