@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
                                                              const float* __restrict__ k_new, const float* __restrict__ v_new,
                                                              float* __restrict__ kpool_w, float* __restrict__ vpool_w, int group) {
   constexpr int KG = 64 / DL;
+  constexpr int VP = 16;                                    // value rows per lane fetched ahead of the softmax: VP * KG keys
   __shared__ float s_p[4][kTreeMaxKeys];
   __shared__ int32_t s_a[4][kTreeMaxKeys];
   if (step_dev) nkeys = min(*step_dev + 1, nkeys);        // replayed graphs: the step counter lives in device memory
@@ -43,7 +44,25 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
   const int32_t* a = anc + (int64_t)n * ld_anc;
   for (int d = lane; d < dk; d += 64) s_q[wave][d] = qv[d] * scale;
   for (int j = lane; j < nkeys; j += 64) s_a[wave][j] = a[j];
-  __syncthreads();
+  // every wave works on its own slices of the LDS arrays: the order of one wave's LDS operations is all that is needed
+  // (no workgroup barrier: a wave does not wait for its three neighbours' loads)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int dl = lane & (DL - 1), kg = lane / DL;
+  const bool dok = dl * 4 < dk;
+  const int doff = h * dk + (dok ? dl * 4 : 0);
+  const float* vb = vpool + doff;
+  const float* vlast = v_new ? v_new + (int64_t)n * ldq + doff : nullptr;       // key nkeys - 1 of this hypothesis
+  auto vrow = [&](int j) { return (vlast && j == nkeys - 1) ? vlast : vb + (int64_t)s_a[wave][j] * ldkv; };
+  // the value rows depend on the ancestor list only, not on the scores: the first VP * KG keys' rows are requested now, with
+  // the key rows - one memory round trip for both instead of one after the other (a search step is a chain of such trips)
+  float4 vpre[VP];
+#pragma unroll
+  for (int u = 0; u < VP; ++u) {
+    const int j = kg + u * KG;
+    vpre[u] = j < nkeys ? *reinterpret_cast<const float4*>(vrow(j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float mx = -INFINITY;
   for (int j = lane; j < nkeys; j += 64) {
     const float* kr = (k_new && j == nkeys - 1) ? k_new + (int64_t)n * ldq + h * dk : kpool + (int64_t)s_a[wave][j] * ldkv + h * dk;
@@ -63,16 +82,20 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
     sum += e;
   }
   sum = wave_sum(sum);
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const float inv = 1.f / sum;
-  const int dl = lane & (DL - 1), kg = lane / DL;
-  const bool dok = dl * 4 < dk;
-  const int doff = h * dk + (dok ? dl * 4 : 0);
-  const float* vb = vpool + doff;
-  const float* vlast = v_new ? v_new + (int64_t)n * ldq + doff : nullptr;       // key nkeys - 1 of this hypothesis
-  auto vrow = [&](int j) { return (vlast && j == nkeys - 1) ? vlast : vb + (int64_t)s_a[wave][j] * ldkv; };
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int j = kg;
+#pragma unroll
+  for (int u = 0; u < VP; ++u) {
+    const int j = kg + u * KG;
+    if (j < nkeys) {
+      const float pj = s_p[wave][j];
+      acc.x += pj * vpre[u].x; acc.y += pj * vpre[u].y; acc.z += pj * vpre[u].z; acc.w += pj * vpre[u].w;
+    }
+  }
+  int j = kg + VP * KG;
   for (; j + 7 * KG < nkeys; j += 8 * KG) {
     float4 v[8];
 #pragma unroll
