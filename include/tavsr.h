@@ -796,6 +796,13 @@ int tavsr_log_softmax_rows(const float* x, int64_t ldx, float* y, int64_t ldy, i
 int tavsr_beam_combine(const float* full, const int64_t* cand, const float* psi, float* psi_abs, const float* eos_s,
                        const float* eos_abs, const float* s_prev, const float* score, float* weighted, int32_t N, int32_t V,
                        int32_t C, int32_t eos, float w_ctc, tavsr_stream_t stream);
+/* tavsr_beam_combine and the top-k over (beam slot, token) of every utterance in ONE launch (one workgroup per utterance): top_s /
+ * top_i [N / K][K], descending, top_i = slot * V + token (int64, what tavsr_beam_reorder takes); among equal scores the lower index
+ * first.  weighted (nullable): also stores the [N][V] weighted scores.  K * V <= 8192, else TAVSR_EUNSUPPORTED. */
+int tavsr_beam_combine_topk(const float* full, const int64_t* cand, const float* psi, float* psi_abs, const float* eos_s,
+                            const float* eos_abs, const float* s_prev, const float* score, float* weighted, float* top_s,
+                            int64_t* top_i, int32_t N, int32_t K, int32_t V, int32_t C, int32_t eos, float w_ctc,
+                            tavsr_stream_t stream);
 int tavsr_beam_reorder(const int64_t* top_i, const float* top_s, const int64_t* cand, const float* r_new, const float* psi_abs,
                        const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out, int64_t* yseq_out, int32_t* anc_out,
                        int64_t* tok_out, float* score_out, int32_t N, int32_t K, int32_t V, int32_t C, int32_t T, int32_t ld_y,

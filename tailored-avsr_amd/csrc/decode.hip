@@ -331,6 +331,70 @@ __global__ __launch_bounds__(256) void beam_combine_kernel(const float* __restri
     if ((int)cand[(int64_t)n * C + c] == eos) psi_abs[(int64_t)n * C + c] = eos_abs[n];
 }
 
+// beam_combine and the top-k behind it in one launch, one workgroup per utterance: the K x V weighted scores of its beam slots
+// go to LDS (and to `weighted` when given), then K rounds of a workgroup arg-max pick the K best (slot * V + token) in descending
+// order - among equal scores the lower index first.  Replaces torch.topk's two launches (gather + sort, 25 us of a 130 us tail).
+constexpr int kTopkMax = 8192;
+__global__ __launch_bounds__(256) void beam_combine_topk_kernel(const float* __restrict__ full, const int64_t* __restrict__ cand,
+                                                                const float* __restrict__ psi, float* __restrict__ psi_abs,
+                                                                const float* __restrict__ eos_s, const float* __restrict__ eos_abs,
+                                                                const float* __restrict__ s_prev, const float* __restrict__ score,
+                                                                float* __restrict__ weighted, float* __restrict__ top_s,
+                                                                int64_t* __restrict__ top_i, int K, int V, int C, int eos,
+                                                                float w_ctc) {
+  __shared__ float s_w[kTopkMax];
+  __shared__ float s_bv[4];
+  __shared__ int s_bi[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int u = blockIdx.x;
+  for (int k = wave; k < K; k += 4) {
+    const int n = u * K + k;
+    const float base = -10000000000.0f - s_prev[n], es = eos_s[n], sc = score[n];
+    for (int v = lane; v < V; v += 64) {
+      float cf = v == eos ? es : base;
+      for (int c = 0; c < C; ++c)
+        if ((int)cand[(int64_t)n * C + c] == v) cf = v == eos ? es : psi[(int64_t)n * C + c];
+      {
+#pragma clang fp contract(off)
+        const float prod = w_ctc * cf;
+        const float sum = full[(int64_t)n * V + v] + prod;
+        const float wv = sum + sc;
+        s_w[k * V + v] = wv;
+        if (weighted) weighted[(int64_t)n * V + v] = wv;
+      }
+    }
+    for (int c = lane; c < C; c += 64)
+      if ((int)cand[(int64_t)n * C + c] == eos) psi_abs[(int64_t)n * C + c] = eos_abs[n];
+  }
+  __syncthreads();
+  const int KV = K * V;
+  for (int r = 0; r < K; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < KV; i += 256) {
+      const float x = s_w[i];
+      if (x != x) continue;                           // taken in an earlier round
+      if (bi == 0x7fffffff || x > bv || (x == bv && i < bi)) { bv = x; bi = i; }      // (-inf entries stay eligible)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
+      top_s[(int64_t)u * K + r] = bv;
+      top_i[(int64_t)u * K + r] = bi;
+      s_w[bi] = __builtin_nanf("");                 // taken: a NaN compares false against everything
+    }
+    __syncthreads();
+  }
+}
+
 // After the top-k over (beam slot, token) of every utterance (top_i [U][K] = slot * V + token): hypothesis n extends slot
 // prev = top_i / V + u * K with token top_i % V.  Gathers the running state of `prev` into the *_out buffers (the state
 // arrays are re-ordered, so they cannot be updated in place): CTC forward variables r_new[prev][:, :, cidx] (cidx = the
@@ -716,6 +780,22 @@ extern "C" int tavsr_beam_combine(const float* full, const int64_t* cand, const 
   if (N <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(beam_combine_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, full, cand, psi, psi_abs,
                      eos_s, eos_abs, s_prev, score, weighted, N, V, C, eos, w_ctc);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_beam_combine_topk(const float* full, const int64_t* cand, const float* psi, float* psi_abs, const float* eos_s,
+                                       const float* eos_abs, const float* s_prev, const float* score, float* weighted, float* top_s,
+                                       int64_t* top_i, int32_t N, int32_t K, int32_t V, int32_t C, int32_t eos, float w_ctc,
+                                       tavsr_stream_t stream) {
+  TAVSR_REQUIRE(full && cand && psi && psi_abs && eos_s && eos_abs && s_prev && score && top_s && top_i, TAVSR_EINVAL,
+                "beam_combine_topk: null pointer");
+  TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0 && V > 0 && K <= V, TAVSR_EINVAL, "beam_combine_topk: bad sizes");
+  TAVSR_REQUIRE((int64_t)K * V <= kTopkMax, TAVSR_EUNSUPPORTED,
+                "beam_combine_topk: beam x vocabulary up to %d (got %d x %d): use tavsr_beam_combine and a top-k of your own", kTopkMax,
+                K, V);
+  hipLaunchKernelGGL(beam_combine_topk_kernel, dim3((unsigned)(N / K)), dim3(256), 0, (hipStream_t)stream, full, cand, psi, psi_abs,
+                     eos_s, eos_abs, s_prev, score, weighted, top_s, top_i, K, V, C, eos, w_ctc);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -315,8 +315,11 @@ class BatchBeamSearch:
             if dyn is not None:
                 # beam update in three launches: weighted scores, top-k, gather of the extended slots' state into the
                 # shadow buffers + one multi-buffer commit (+ the counters); same arithmetic as the torch ops below
-                weighted = ops.beam_combine(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, self.eos, self.w_ctc)
-                top_s, top_i = torch.topk(weighted.view(U, K * V), K, dim=-1)
+                if ops.beam_combine_topk_ok(K, V):
+                    top_s, top_i = ops.beam_combine_topk(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, self.eos, self.w_ctc, K)
+                else:
+                    weighted = ops.beam_combine(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, self.eos, self.w_ctc)
+                    top_s, top_i = torch.topk(weighted.view(U, K * V), K, dim=-1)
                 ops.beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, dyn["shadow"], K, V, dyn["step"], hist=dyn["hist"])
                 ops.multi_copy_([r_prev, s_prev, yseq, anc, tok, score], list(dyn["shadow"]))
                 dyn["ctr"].add_(1)                                  # step, step64, stepp1 are views of this one tensor

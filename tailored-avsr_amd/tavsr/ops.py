@@ -1786,6 +1786,24 @@ def beam_combine(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, eos, w
     return weighted
 
 
+def beam_combine_topk_ok(K, V) -> bool:
+    return K * V <= 8192
+
+
+def beam_combine_topk(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, eos, w_ctc, K, keep_weighted=False):
+    """``beam_combine`` and ``torch.topk(weighted.view(U, K * V), K)`` in one launch -> (top_s, top_i[, weighted])."""
+    N, V = full.shape
+    Cn = cand.shape[1]
+    require_cuda(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score)
+    top_s = empty(N // K, K, like=full)
+    top_i = torch.empty(N // K, K, dtype=torch.int64, device=full.device)
+    weighted = empty(N, V, like=full) if keep_weighted else None
+    check(lib().tavsr_beam_combine_topk(ptr(full), ptr(cand), ptr(psi), ptr(psi_abs), ptr(eos_s), ptr(eos_abs), ptr(s_prev), ptr(score),
+                                        ptr(weighted), ptr(top_s), ptr(top_i), N, K, V, Cn, int(eos), C.c_float(w_ctc), stream()),
+          "tavsr_beam_combine_topk")
+    return (top_s, top_i, weighted) if keep_weighted else (top_s, top_i)
+
+
 def beam_step_begin(score, tok, anc, maxlen, K, eos, step_dev):
     """head of a captured search step (tavsr.h): ended hypotheses leave the beam, anc[:, step] names this step's rows."""
     N = score.numel()

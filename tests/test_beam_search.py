@@ -284,8 +284,20 @@ def test_beam_update_kernels_equal_the_torch_expressions():
     pa = psi_abs.clone()
     got = ops.beam_combine(full, cand, psi, pa, eos_s, eos_abs, s_prev, score, eos, 0.2)
     assert torch.equal(got, want) and torch.equal(pa, psi_abs_t)
-    # re-ordering
+    # ... and the same with the top-k in the launch (distinct random scores: the order is unique)
+    pa2 = psi_abs.clone()
+    ts, ti, w2 = ops.beam_combine_topk(full, cand, psi, pa2, eos_s, eos_abs, s_prev, score, eos, 0.2, K, keep_weighted=True)
     top_s, top_i = torch.topk(want.view(U, K * V), K, dim=-1)
+    assert torch.equal(w2, want) and torch.equal(pa2, psi_abs_t) and torch.equal(ts, top_s) and torch.equal(ti, top_i)
+    tie = full.clone()
+    tie[0:K] = tie[0:1]                        # six identical rows ... with identical scores: equal candidates, lower index first
+    sc2 = score.clone(); sc2[0:K] = sc2[0]; sp2 = s_prev.clone(); sp2[0:K] = sp2[0]; es2 = eos_s.clone(); es2[0:K] = es2[0]
+    cd2 = cand.clone(); cd2[0:K] = cd2[0:1]; ps2 = psi.clone(); ps2[0:K] = ps2[0:1]
+    ts2, ti2, w3 = ops.beam_combine_topk(tie, cd2, ps2, psi_abs.clone(), es2, eos_abs, sp2, sc2, eos, 0.2, K, keep_weighted=True)
+    flat = w3.view(U, K * V)[0]
+    order = sorted(range(K * V), key=lambda i: (-float(flat[i]), i))[:K]
+    assert ti2[0].tolist() == order and torch.equal(ts2[0], flat[order])
+    # re-ordering
     r_new = torch.randn(N, T, 2, C).cuda()
     yseq = torch.randint(0, V, (N, steps + 2)).cuda()
     anc = torch.randint(0, 1000, (N, steps), dtype=torch.int32).cuda()
