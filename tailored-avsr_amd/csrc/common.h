@@ -41,6 +41,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Whole-wave max / min on the data-parallel-primitive lane network (quad permutes, row mirrors, row broadcasts; result read from
+// lane 63): ~6 x 8 cycles against 6 dependent ds_bpermute round trips (~120 cycles each) of the shuffle form above - for the
+// selection loops of the search step, whose rounds are nothing but such reductions one after the other.
+#define TAVSR_DPP_STEP_F(OP, CTRL, RMASK) v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RMASK, 0xf, false)))
+#define TAVSR_DPP_STEP_I(OP, CTRL, RMASK) v = OP(v, __builtin_amdgcn_update_dpp(v, v, CTRL, RMASK, 0xf, false))
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  TAVSR_DPP_STEP_F(fmaxf, 0xB1, 0xf);      // quad_perm [1, 0, 3, 2]
+  TAVSR_DPP_STEP_F(fmaxf, 0x4E, 0xf);      // quad_perm [2, 3, 0, 1]
+  TAVSR_DPP_STEP_F(fmaxf, 0x141, 0xf);     // row_half_mirror
+  TAVSR_DPP_STEP_F(fmaxf, 0x140, 0xf);     // row_mirror: every lane of a row of 16 holds the row's value
+  TAVSR_DPP_STEP_F(fmaxf, 0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+  TAVSR_DPP_STEP_F(fmaxf, 0x143, 0xc);     // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_dpp(int v) {
+  TAVSR_DPP_STEP_I(min, 0xB1, 0xf);
+  TAVSR_DPP_STEP_I(min, 0x4E, 0xf);
+  TAVSR_DPP_STEP_I(min, 0x141, 0xf);
+  TAVSR_DPP_STEP_I(min, 0x140, 0xf);
+  TAVSR_DPP_STEP_I(min, 0x142, 0xa);
+  TAVSR_DPP_STEP_I(min, 0x143, 0xc);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Activations on the hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp each) instead of libm's expf / erff and an IEEE
 // division: Swish 6 instructions instead of ~35, GELU ~16 instead of ~50 (erff is two branches of ~45, both taken by a wave) -
 // in a K = 256 GEMM epilogue the libm GELU cost 40 % of the tile's MFMA time, in the LayerNorm backward of cgMLP's gate half it

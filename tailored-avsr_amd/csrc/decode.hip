@@ -140,9 +140,11 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict_
   *reinterpret_cast<float4*>(vpool + dst) = *reinterpret_cast<const float4*>(v + (int64_t)n * ld_src + c);
 }
 
+// log(e^a + e^b) = max + log(1 + e^-|a - b|) on v_exp_f32 / v_log_f32 (1 ulp each): ~8 instructions instead of two expf and a
+// logf (~70) - the prefix recursion runs three of these per frame, one frame after the other
 __device__ __forceinline__ float logaddexp2(float a, float b) {
-  const float m = fmaxf(a, b);
-  return m + logf(expf(a - m) + expf(b - m));
+  const float m = fmaxf(a, b), d = -fabsf(a - b);
+  return m + 0.69314718055994530942f * __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(1.4426950408889634f * d));
 }
 
 // One (hypothesis n, candidate column c) of CTCPrefixScoreTH.__call__.  logp [U][T][V] (log-softmax of the CTC head),
@@ -179,18 +181,49 @@ __device__ __forceinline__ void ctc_prefix_one(const float* __restrict__ logp, c
   if (first) { for (int t = 0; t < start - 1; ++t) cum += lp[(int64_t)t * V + blank]; }
   // log_psi accumulates logsumexp over t in [start, L) of (phi[t-1] + x[t][tok]) and r[start-1, nb]
   float acc = rn_n;
-  for (int t = start; t < L; ++t) {
-    float pn, pb;
-    if (first) cum += lp[(int64_t)(t - 1) * V + blank];
-    prev(t - 1, pn, pb);
-    const float phi = same ? pb : logaddexp2(pn, pb);
-    const float xt = lp[(int64_t)t * V + tok], xb = lp[(int64_t)t * V + blank];
-    const float nn = logaddexp2(rn_n, phi) + xt;
-    const float nb = logaddexp2(rn_n, rn_b) + xb;
-    acc = logaddexp2(acc, phi + xt);
-    rn_n = nn; rn_b = nb;
-    rn[(int64_t)(t * 2) * C] = nn;
-    rn[(int64_t)(t * 2 + 1) * C] = nb;
+  if (first) {
+    for (int t = start; t < L; ++t) {
+      float pn, pb;
+      cum += lp[(int64_t)(t - 1) * V + blank];
+      prev(t - 1, pn, pb);
+      const float phi = same ? pb : logaddexp2(pn, pb);
+      const float xt = lp[(int64_t)t * V + tok], xb = lp[(int64_t)t * V + blank];
+      const float nn = logaddexp2(rn_n, phi) + xt;
+      const float nb = logaddexp2(rn_n, rn_b) + xb;
+      acc = logaddexp2(acc, phi + xt);
+      rn_n = nn; rn_b = nb;
+      rn[(int64_t)(t * 2) * C] = nn;
+      rn[(int64_t)(t * 2 + 1) * C] = nb;
+    }
+  } else {
+    // The recursion is sequential in t, its INPUTS are not: the four values a frame needs (two posteriors, the previous
+    // prefix's two forward variables) are fetched 16 frames at a time, all loads of a chunk in flight together - one memory round
+    // trip per chunk instead of one per frame (100 frames: 51 us of a 130 us tail behind the scorers were these round trips).
+    constexpr int CH = 16;
+    for (int t0 = start; t0 < L; t0 += CH) {
+      float xt[CH], xb[CH], pn[CH], pb[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int t = min(t0 + j, L - 1);
+        xt[j] = lp[(int64_t)t * V + tok];
+        xb[j] = lp[(int64_t)t * V + blank];
+        pn[j] = rp[(t - 1) * 2];
+        pb[j] = rp[(t - 1) * 2 + 1];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int t = t0 + j;
+        if (t < L) {
+          const float phi = same ? pb[j] : logaddexp2(pn[j], pb[j]);
+          const float nn = logaddexp2(rn_n, phi) + xt[j];
+          const float nb = logaddexp2(rn_n, rn_b) + xb[j];
+          acc = logaddexp2(acc, phi + xt[j]);
+          rn_n = nn; rn_b = nb;
+          rn[(int64_t)(t * 2) * C] = nn;
+          rn[(int64_t)(t * 2 + 1) * C] = nb;
+        }
+      }
+    }
   }
   for (int t = max(L, start); t < T; ++t) { rn[(int64_t)(t * 2) * C] = logzero; rn[(int64_t)(t * 2 + 1) * C] = logzero; }
   const float out_psi = tok == blank ? logzero : acc;
@@ -261,11 +294,9 @@ __global__ __launch_bounds__(256) void ctc_prefix_topk_kernel(const float* __res
         if (!((taken >> j) & 1) && (x > best || (x == best && v < bi))) { best = x; bi = v; }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    {     // the wave's best: highest score, the lower index among equal ones (lane network reductions, common.h)
+      const float m = wave_max_dpp(best);
+      bi = wave_min_dpp((bi != 0x7fffffff && best == m) ? bi : 0x7fffffff);
     }
     if (bi == 0x7fffffff) bi = 0;     // fewer than C finite-or-not elements cannot happen for C <= V; keeps indices valid
     if ((bi & 63) == lane) taken |= 1ull << (bi >> 6);
@@ -332,10 +363,10 @@ __global__ __launch_bounds__(256) void beam_combine_kernel(const float* __restri
 }
 
 // beam_combine and the top-k behind it in one launch, one workgroup per utterance: the K x V weighted scores of its beam slots
-// go to LDS (and to `weighted` when given), then K rounds of a workgroup arg-max pick the K best (slot * V + token) in descending
+// go to LDS (and to `weighted` when given), then K rounds of a wave arg-max pick the K best (slot * V + token) in descending
 // order - among equal scores the lower index first.  Replaces torch.topk's two launches (gather + sort, 25 us of a 130 us tail).
 constexpr int kTopkMax = 8192;
-__global__ __launch_bounds__(256) void beam_combine_topk_kernel(const float* __restrict__ full, const int64_t* __restrict__ cand,
+__global__ __launch_bounds__(1024) void beam_combine_topk_kernel(const float* __restrict__ full, const int64_t* __restrict__ cand,
                                                                 const float* __restrict__ psi, float* __restrict__ psi_abs,
                                                                 const float* __restrict__ eos_s, const float* __restrict__ eos_abs,
                                                                 const float* __restrict__ s_prev, const float* __restrict__ score,
@@ -343,11 +374,9 @@ __global__ __launch_bounds__(256) void beam_combine_topk_kernel(const float* __r
                                                                 int64_t* __restrict__ top_i, int K, int V, int C, int eos,
                                                                 float w_ctc) {
   __shared__ float s_w[kTopkMax];
-  __shared__ float s_bv[4];
-  __shared__ int s_bi[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int u = blockIdx.x;
-  for (int k = wave; k < K; k += 4) {
+  for (int k = wave; k < K; k += 16) {      // (16 waves: every beam slot of the usual widths has a wave of its own)
     const int n = u * K + k;
     const float base = -10000000000.0f - s_prev[n], es = eos_s[n], sc = score[n];
     for (int v = lane; v < V; v += 64) {
@@ -368,30 +397,45 @@ __global__ __launch_bounds__(256) void beam_combine_topk_kernel(const float* __r
   }
   __syncthreads();
   const int KV = K * V;
+  if (wave != 0) return;
+  // the selection is one wave's work: up to 16 scores per lane in registers (K V <= 1024; the rest stay in LDS), a round is an
+  // arg-max over the lane's own values and six shuffle steps - no workgroup barrier inside the K rounds
+  constexpr int RG = 16;
+  float xv[RG];
+#pragma unroll
+  for (int j = 0; j < RG; ++j) xv[j] = lane + 64 * j < KV ? s_w[lane + 64 * j] : __builtin_nanf("");
   for (int r = 0; r < K; ++r) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < KV; i += 256) {
-      const float x = s_w[i];
-      if (x != x) continue;                           // taken in an earlier round
-      if (bi == 0x7fffffff || x > bv || (x == bv && i < bi)) { bv = x; bi = i; }      // (-inf entries stay eligible)
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    for (int j = 0; j < RG; ++j) {
+      const float x = xv[j];
+      const int i = lane + 64 * j;
+      if (x == x && (bi == 0x7fffffff || x > bv || (x == bv && i < bi))) { bv = x; bi = i; }     // (NaN: taken / past the end)
     }
-    if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < 4; ++w)
-        if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
+    for (int i = lane + 64 * RG; i < KV; i += 64) {
+      const float x = s_w[i];
+      if (x == x && (bi == 0x7fffffff || x > bv || (x == bv && i < bi))) { bv = x; bi = i; }
+    }
+    {     // the wave's best: highest score, the lower index among equal ones (lane network reductions, common.h)
+      const float lv = bv;
+      const int li = bi;
+      bv = wave_max_dpp(li == 0x7fffffff ? -INFINITY : lv);
+      bi = wave_min_dpp((li != 0x7fffffff && lv == bv) ? li : 0x7fffffff);
+    }
+    if (lane == 0) {
       top_s[(int64_t)u * K + r] = bv;
       top_i[(int64_t)u * K + r] = bi;
-      s_w[bi] = __builtin_nanf("");                 // taken: a NaN compares false against everything
     }
-    __syncthreads();
+    if ((bi & 63) == lane) {            // the owner retires the element
+      if (bi < 64 * RG) {
+#pragma unroll
+        for (int j = 0; j < RG; ++j)
+          if (j == (bi >> 6)) xv[j] = __builtin_nanf("");
+      } else {
+        s_w[bi] = __builtin_nanf("");
+      }
+    }
   }
 }
 
@@ -794,7 +838,7 @@ extern "C" int tavsr_beam_combine_topk(const float* full, const int64_t* cand, c
   TAVSR_REQUIRE((int64_t)K * V <= kTopkMax, TAVSR_EUNSUPPORTED,
                 "beam_combine_topk: beam x vocabulary up to %d (got %d x %d): use tavsr_beam_combine and a top-k of your own", kTopkMax,
                 K, V);
-  hipLaunchKernelGGL(beam_combine_topk_kernel, dim3((unsigned)(N / K)), dim3(256), 0, (hipStream_t)stream, full, cand, psi, psi_abs,
+  hipLaunchKernelGGL(beam_combine_topk_kernel, dim3((unsigned)(N / K)), dim3(1024), 0, (hipStream_t)stream, full, cand, psi, psi_abs,
                      eos_s, eos_abs, s_prev, score, weighted, top_s, top_i, K, V, C, eos, w_ctc);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
