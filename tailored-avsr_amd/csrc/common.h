@@ -30,38 +30,40 @@ void set_error(const char* fmt, ...);
 
 constexpr int kWave = 64;
 
+// Whole-wave reductions on the data-parallel-primitive lane network (quad permutes, row mirrors, row broadcasts; the result is read
+// from lane 63 and is uniform): six steps of ~8 cycles against six dependent ds_bpermute round trips (~120 cycles each) of a
+// __shfl_xor butterfly.  LayerNorm rows, softmax rows and the selection loops of the search step are chains of such reductions.
+// All 64 lanes must be active (every caller reduces under wave-uniform control flow).  `IDENT`: what a lane that a step does
+// not write contributes (0 for sums; the lane's own value for max / min).
+#define TAVSR_DPP_F(V, CTRL, RMASK, OLD) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(OLD), __float_as_int(V), CTRL, RMASK, 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-// Whole-wave max / min on the data-parallel-primitive lane network (quad permutes, row mirrors, row broadcasts; result read from
-// lane 63): ~6 x 8 cycles against 6 dependent ds_bpermute round trips (~120 cycles each) of the shuffle form above - for the
-// selection loops of the search step, whose rounds are nothing but such reductions one after the other.
-#define TAVSR_DPP_STEP_F(OP, CTRL, RMASK) v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RMASK, 0xf, false)))
-#define TAVSR_DPP_STEP_I(OP, CTRL, RMASK) v = OP(v, __builtin_amdgcn_update_dpp(v, v, CTRL, RMASK, 0xf, false))
-__device__ __forceinline__ float wave_max_dpp(float v) {
-  TAVSR_DPP_STEP_F(fmaxf, 0xB1, 0xf);      // quad_perm [1, 0, 3, 2]
-  TAVSR_DPP_STEP_F(fmaxf, 0x4E, 0xf);      // quad_perm [2, 3, 0, 1]
-  TAVSR_DPP_STEP_F(fmaxf, 0x141, 0xf);     // row_half_mirror
-  TAVSR_DPP_STEP_F(fmaxf, 0x140, 0xf);     // row_mirror: every lane of a row of 16 holds the row's value
-  TAVSR_DPP_STEP_F(fmaxf, 0x142, 0xa);     // row_bcast:15 into rows 1 and 3
-  TAVSR_DPP_STEP_F(fmaxf, 0x143, 0xc);     // row_bcast:31 into rows 2 and 3
+  v += TAVSR_DPP_F(v, 0xB1, 0xf, 0.f);       // quad_perm [1, 0, 3, 2]
+  v += TAVSR_DPP_F(v, 0x4E, 0xf, 0.f);       // quad_perm [2, 3, 0, 1]
+  v += TAVSR_DPP_F(v, 0x141, 0xf, 0.f);      // row_half_mirror
+  v += TAVSR_DPP_F(v, 0x140, 0xf, 0.f);      // row_mirror: every lane of a row of 16 holds the row's sum
+  v += TAVSR_DPP_F(v, 0x142, 0xa, 0.f);      // row_bcast:15 into rows 1 and 3
+  v += TAVSR_DPP_F(v, 0x143, 0xc, 0.f);      // row_bcast:31 into rows 2 and 3
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, TAVSR_DPP_F(v, 0xB1, 0xf, v));
+  v = fmaxf(v, TAVSR_DPP_F(v, 0x4E, 0xf, v));
+  v = fmaxf(v, TAVSR_DPP_F(v, 0x141, 0xf, v));
+  v = fmaxf(v, TAVSR_DPP_F(v, 0x140, 0xf, v));
+  v = fmaxf(v, TAVSR_DPP_F(v, 0x142, 0xa, v));
+  v = fmaxf(v, TAVSR_DPP_F(v, 0x143, 0xc, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_max(v); }
 __device__ __forceinline__ int wave_min_dpp(int v) {
-  TAVSR_DPP_STEP_I(min, 0xB1, 0xf);
-  TAVSR_DPP_STEP_I(min, 0x4E, 0xf);
-  TAVSR_DPP_STEP_I(min, 0x141, 0xf);
-  TAVSR_DPP_STEP_I(min, 0x140, 0xf);
-  TAVSR_DPP_STEP_I(min, 0x142, 0xa);
-  TAVSR_DPP_STEP_I(min, 0x143, 0xc);
+#define TAVSR_DPP_I(CTRL, RMASK) v = min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, RMASK, 0xf, false))
+  TAVSR_DPP_I(0xB1, 0xf);
+  TAVSR_DPP_I(0x4E, 0xf);
+  TAVSR_DPP_I(0x141, 0xf);
+  TAVSR_DPP_I(0x140, 0xf);
+  TAVSR_DPP_I(0x142, 0xa);
+  TAVSR_DPP_I(0x143, 0xc);
+#undef TAVSR_DPP_I
   return __builtin_amdgcn_readlane(v, 63);
 }
 
