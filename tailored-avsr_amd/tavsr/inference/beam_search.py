@@ -167,19 +167,20 @@ class _LMStep:
 
     def start(self, like, N, max_steps, K=1):
         self.N, self.K = N, K
+        # the LM's input layer (embedding -> Linear -> LayerNorm -> ReLU; espnet TransformerLM with pos_enc: null) depends on the token
+        # alone: one [V, d] table per search instead of three launches per token
+        lm = self.lm
+        emb = lm.encoder.embed
+        t = ops.linear(lm.embed.weight.contiguous(), emb[0].weight, emb[0].bias)
+        t = ops.layernorm_fwd(t, emb[1].weight, emb[1].bias, EPS, save=False)[0]
+        self.in_table = ops.act_(t, "relu")
         self.kpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
         self.vpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
 
     def step(self, i, tok, anc, dyn=None, logits_only=False, **score):
         N, D, H, dk = self.N, self.D, self.H, self.dk
         lm = self.lm
-        emb = lm.encoder.embed
-        if ops.rowlin_ok(lm.embed.weight, emb[0].weight, n_rows=N):            # embedding row gather inside the Linear's launch
-            h = ops.rowlin(lm.embed.weight, emb[0].weight, emb[0].bias, gather=tok)
-        else:
-            h = ops.linear(lm.embed.weight[tok].contiguous(), emb[0].weight, emb[0].bias)
-        h = ops.layernorm_fwd(h, emb[1].weight, emb[1].bias, EPS, save=False)[0]
-        ops.act_(h, "relu")
+        h = self.in_table.index_select(0, tok)
         for li, L in enumerate(self.layers):
             qkv = _ln_linear(h, L["n1"], L["wqkv"], L["bqkv"])
             # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
