@@ -764,6 +764,8 @@ int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, int64_t x_p
                        float eps, const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr,
                        int32_t res_parts, int64_t res_pstride, float* out, int64_t ldo, int32_t ksplit, int64_t out_pstride,
                        int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
+/* tuning aid (scripts/tree_attn_bench.py): 1 = four (hypothesis, head) items per workgroup whatever the step's size */
+int tavsr_tree_attn_tune(int32_t wpb4);
 /* tuning aid (scripts/rowlin_bench.py): 1 = half the waves per block, twice the k range per wave; 0 = the library's plan */
 int tavsr_rowlin_tune(int32_t cfg);
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd")); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from rowlin_bench import chain_us
 from tavsr import ops
+from tavsr._lib import lib
 N, K = 10, 10
 gen = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *s: torch.randn(*s, device="cuda", generator=gen)
@@ -19,5 +20,8 @@ for name, H, dk in (("LM 8 x 64", 8, 64), ("decoder 4 x 64", 4, 64)):
         anc[:, max(0, nkeys - 4):] += torch.arange(N, device="cuda", dtype=torch.int32).view(N, 1)
         anc = anc.contiguous()
         out = torch.empty(N, D, device="cuda")
-        us = chain_us(lambda: ops.tree_attn_step(qkv[:, :D], kpool, vpool, anc, nkeys, H, dk, out=out, k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:], group=K))
-        print(f"{name:16s} keys {nkeys:4d}: {us:6.2f} us", flush=True)
+        row = []
+        for wpb4 in (1, 0):
+            lib().tavsr_tree_attn_tune(wpb4)
+            row.append(chain_us(lambda: ops.tree_attn_step(qkv[:, :D], kpool, vpool, anc, nkeys, H, dk, out=out, k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:], group=K)))
+        print(f"{name:16s} keys {nkeys:4d}: four items per workgroup {row[0]:6.2f} us   one {row[1]:6.2f} us", flush=True)

@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
   // (nkeys-1) * N + n): read from here instead of the pool, and appended to the pool by the same wave (no append launch).
   __shared__ float s_q[4][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool live = blockIdx.x * 4 + wave < N * H;       // surplus waves recompute the last item and store nothing
-  const int item = min(blockIdx.x * 4 + wave, N * H - 1);
+  const int wpb = blockDim.x >> 6;                       // waves (items) per workgroup: 4, or 1 for small steps (see the launch)
+  const bool live = blockIdx.x * wpb + wave < N * H;     // surplus waves recompute the last item and store nothing
+  const int item = min(blockIdx.x * wpb + wave, N * H - 1);
   // item order (utterance, head, beam slot): the waves of a block are hypotheses of ONE utterance on ONE head - their
   // ancestor lists share most rows (a beam is a tree), so the block's gathers hit the same lines in the CU's cache
   const int n = (item / (H * group)) * group + item % group, h = (item / group) % H;
@@ -728,6 +729,12 @@ extern "C" int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, 
   return TAVSR_OK;
 }
 
+static int g_tree_wpb4 = 0;
+extern "C" int tavsr_tree_attn_tune(int32_t wpb4) {      // tuning aid: 1 = always four items per workgroup
+  g_tree_wpb4 = wpb4 ? 1 : 0;
+  return TAVSR_OK;
+}
+
 extern "C" int tavsr_rowlin_tune(int32_t cfg) {      // tuning aid (scripts/rowlin_bench.py), not part of the product ABI
   TAVSR_REQUIRE(cfg >= 0 && cfg <= 1, TAVSR_EINVAL, "rowlin_tune: 0 or 1");
   g_rowlin_cfg = cfg;
@@ -748,12 +755,14 @@ extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kp
   TAVSR_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)q | (uintptr_t)out | (uintptr_t)vpool | (uintptr_t)k_new | (uintptr_t)v_new) & 15) == 0,
                 TAVSR_EALIGN, "tree_attn_step: q / out / k_new / v_new rows must be 16-byte aligned");
   if (group <= 0 || N % group != 0) group = 1;
-  const dim3 grid((unsigned)((N * H + 3) / 4));
+  // few items (a batch-1 step: 10 hypotheses x 8 heads): one wave per workgroup - 80 CUs bring the rows in instead of 20
+  const int wpb = (N * H <= 256 && !g_tree_wpb4) ? 1 : 4;
+  const dim3 grid((unsigned)((N * H + wpb - 1) / wpb)), block((unsigned)(64 * wpb));
   if (dk <= 64)
-    hipLaunchKernelGGL(tree_attn_step_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
+    hipLaunchKernelGGL(tree_attn_step_kernel<16>, grid, block, 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
                        nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool), group);
   else
-    hipLaunchKernelGGL(tree_attn_step_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
+    hipLaunchKernelGGL(tree_attn_step_kernel<32>, grid, block, 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
                        nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool), group);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
