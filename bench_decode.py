@@ -95,7 +95,7 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
 
     from tavsr import dp
-    from tavsr.inference.beam_search import BatchBeamSearch
+    from tavsr.inference.beam_search import BatchBeamSearch, CapturedEncode
     from tavsr.lm.transformer_lm import TransformerLM
     from tavsr.tasks.avsr import AVSRTask
 
@@ -110,6 +110,7 @@ def main():
     lm = TransformerLM(len(conf["token_list"]), **LM_CONF).eval()
     model, lm = model.to(dev), lm.to(dev)
     search = BatchBeamSearch(model, lm, **SEARCH)
+    encode = CapturedEncode(model)           # what tavsr.inference.Speech2Text does: one hipGraph per input shape
 
     mine = list(range(rank, args.utterances, world))
     batches = [mine[i:i + args.batch] for i in range(0, len(mine), args.batch)]
@@ -118,7 +119,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
-            enc, olens = model.encode(*batch)
+            enc, olens = encode(*batch)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             hyps = search.decode(enc, olens, nbest=1)

@@ -488,6 +488,41 @@ class BatchBeamSearch:
         return out
 
 
+class CapturedEncode:
+    """``model.encode`` of an eval-mode model as a replayed hipGraph while the input shapes repeat (a stream of equally long clips):
+    at batch 1 the encoder is ~600 launches of a few microseconds each, i.e. host-bound when enqueued one by one.  Inputs are
+    copied into the capture's buffers, outputs are the capture's buffers (valid until the next call).  Lengths are device data the
+    kernels read, so utterances of different lengths inside one padded shape replay the same graph; another shape captures anew.
+    (The reference encodes eagerly, avsr_inference.py:449-470; results are the same launches' results.)"""
+
+    def __init__(self, model, max_batch: int = 8):
+        self.model, self.max_batch = model, max_batch      # (larger batches keep the GPU busy without a graph)
+        self._cap = None
+
+    @torch.no_grad()
+    def __call__(self, *batch):
+        if self.model.training or batch[0].shape[0] > self.max_batch or not all(t.is_cuda for t in batch):
+            return self.model.encode(*batch)
+        key = tuple((tuple(t.shape), t.dtype) for t in batch)
+        cap = self._cap
+        if cap is None or cap["key"] != key:
+            static = [t.clone() for t in batch]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.model.encode(*static)                 # warm-up outside the capture (lazy buffers, allocator pools)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.model.encode(*static)
+            cap = self._cap = dict(key=key, static=static, graph=graph, out=out)
+        else:
+            for s_, t in zip(cap["static"], batch):
+                s_.copy_(t)
+        cap["graph"].replay()
+        return cap["out"]
+
+
 class Speech2Text:
     """src/inference/avsr_inference.py:Speech2Text for models that are already built: encode + beam search, results as
     the reference returns them (:492-518): (text, tokens, token ids without sos/eos/blank, (yseq, score))."""
@@ -498,11 +533,12 @@ class Speech2Text:
         self.lm = None if lm is None else lm.eval()
         self.nbest = nbest
         self.beam_search = BatchBeamSearch(asr_model, lm, beam_size, ctc_weight, lm_weight, penalty, maxlenratio, minlenratio)
+        self.encode = CapturedEncode(self.asr_model)
 
     @torch.no_grad()
     def __call__(self, *batch):
         """batch: the tensors of ``asr_model.encode`` (speech, lengths) or (audio, lengths, video, lengths)."""
-        enc, enc_lens = self.asr_model.encode(*batch)
+        enc, enc_lens = self.encode(*batch)
         if isinstance(enc, tuple):
             enc = enc[0]
         results = []

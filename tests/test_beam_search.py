@@ -132,6 +132,34 @@ def test_captured_step_is_reused_for_the_next_batch_of_the_same_shape():
 
 
 @pytest.mark.gpu
+def test_captured_encode_equals_the_eager_encode():
+    """inference.CapturedEncode: the replayed hipGraph of ``model.encode`` gives what the eager launches give (same kernels: 1e-6),
+    for a second batch of the same shape with other lengths, and after a change of shape"""
+    from tavsr.inference.beam_search import CapturedEncode
+    from tavsr.tasks.asr import ASRTask
+    conf = asr_conf(num_blocks=2, dec_blocks=1)
+    conf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**conf)).eval()
+    fill_parameters_(pm, seed=5)
+    pm = pm.cuda()
+    enc_g = CapturedEncode(pm)
+    graphs = []
+    with torch.no_grad():
+        for seed, T, lens in ((7, 160, [160, 120]), (8, 160, [160, 97]), (9, 120, [120, 64])):
+            x, l = synth((2, T, 80), seed=seed).cuda(), torch.tensor(lens).cuda()
+            got, gl = enc_g(x, l)
+            graphs.append(enc_g._cap["graph"])
+            want, wl = pm.encode(x, l)
+            assert torch.equal(gl, wl)
+            assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    assert graphs[0] is graphs[1] and graphs[2] is not graphs[1]
+    pm.train()
+    with torch.no_grad():
+        enc_g(x, l)                           # a model in training mode is encoded eagerly (dropout, batch statistics)
+    assert enc_g._cap["graph"] is graphs[2]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ratio", [0.25, -9, 0.8])
 def test_hip_beam_search_length_ratio_matches_oracle(ratio):
     """maxlenratio != 0 (espnet BeamSearch.forward: max(1, int(ratio * T)) tokens, or -ratio tokens, no end detection; the
