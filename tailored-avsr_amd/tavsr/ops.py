@@ -1655,9 +1655,6 @@ class RowParts:
     def shape(self):
         return self.t.shape[1:]
 
-    def sum(self):
-        return self.t.sum(0)
-
 
 ROWLIN_KSPLIT = 4      # K slices of the 2048 -> d projection of a one-token feed-forward block (<= 16 rows); 0: one block per tile
 
