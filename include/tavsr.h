@@ -766,8 +766,7 @@ int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, int64_t x_p
                        int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
 /* tuning aid (scripts/tree_attn_bench.py): 1 = four (hypothesis, head) items per workgroup whatever the step's size */
 int tavsr_tree_attn_tune(int32_t wpb4);
-/* tuning aid (scripts/rowlin_bench.py): bit 0 = half the waves per block, twice the k range per wave; bit 1 = full-width column tiles
- * at up to 16 rows (the library uses half-width tiles there: twice the workgroups); 0 = the library's plan */
+/* tuning aid (scripts/rowlin_bench.py): 1 = half the waves per block, twice the k range per wave; 0 = the library's plan */
 int tavsr_rowlin_tune(int32_t cfg);
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                          const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N, int32_t H,

@@ -511,7 +511,6 @@ struct RowLinArgs {
   // rows held as a SUM of tensors (tavsr_rowlin_parts): x = sum_p x[p * xps ..], res likewise; gridDim.y > 1: block y owns a K
   // slice and writes partial tensor y of the output (stride ops) - the next launch of the chain adds them while it loads
   int xparts; int64_t xps; int rparts; int64_t rps; int64_t ops;
-  int ct;      // output columns per workgroup: R, or R / 2 (the lanes of the upper half repeat the lower half's columns and write nothing)
 };
 
 template <int R, int WPB, int KW>
@@ -524,8 +523,8 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
   __shared__ float s_red[2][WPB][R];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & (R - 1), g = lane / R;
-  const int col0 = blockIdx.x * a.ct;
-  const int row = min(r, a.N - 1), col = min(col0 + (r & (a.ct - 1)), a.Nout - 1);     // surplus lanes repeat a row / column
+  const int col0 = blockIdx.x * R;
+  const int row = min(r, a.N - 1), col = min(col0 + r, a.Nout - 1);     // surplus lanes repeat the last row / column
   // (K dealt to gridDim.y blocks: block y owns k in [y WPB KW, (y + 1) WPB KW); no LayerNorm then - it needs whole rows)
   const int kb = blockIdx.y * (WPB * KW) + wave * KW + 4 * g;
   const float* xr = a.x + (a.gather ? a.gather[row] : (int64_t)row) * a.ldx + kb;
@@ -607,7 +606,7 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
   for (int o = threadIdx.x; o < R * R; o += WPB * 64) {
     const int q = o >> 6, l = o & 63;
     const int rw = R == 32 ? (q & 3) + 8 * (q >> 2) + 4 * (l >> 5) : 4 * (l >> 4) + q;
-    const int c = (l & (R - 1)) < a.ct ? col0 + (l & (R - 1)) : a.Nout;          // (upper half of a half-width tile: nothing to write)
+    const int c = col0 + (l & (R - 1));
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < WPB; ++w) v += s_acc[w][q][l];
@@ -626,12 +625,8 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
 static int g_rowlin_cfg = 0;      // tavsr_rowlin_tune: 0 = the plan below; 1 = half the waves, twice the k per wave (tuning runs)
 
 template <int R>
-static bool rowlin_launch(const RowLinArgs& a_, hipStream_t st, int ksplit = 1) {
-  RowLinArgs a = a_;
-  // up to 16 rows: the launch is paced by what one CU can have in flight, so half-width column tiles on twice the CUs
-  // (tavsr_rowlin_tune bit 1 switches it off for the A/B)
-  a.ct = (R == 16 && !(g_rowlin_cfg & 2) && (a.Nout + R - 1) / R * ksplit <= 256) ? R / 2 : R;
-  const dim3 grid((unsigned)((a.Nout + a.ct - 1) / a.ct), (unsigned)ksplit);
+static bool rowlin_launch(const RowLinArgs& a, hipStream_t st, int ksplit = 1) {
+  const dim3 grid((unsigned)((a.Nout + R - 1) / R), (unsigned)ksplit);
   if (ksplit > 1) {
     switch (a.K / ksplit) {      // K of one slice
       case 256: hipLaunchKernelGGL((rowlin_kernel<R, 4, 64>), grid, dim3(256), 0, st, a); return true;
@@ -640,7 +635,7 @@ static bool rowlin_launch(const RowLinArgs& a_, hipStream_t st, int ksplit = 1) 
       default: return false;
     }
   }
-  if (g_rowlin_cfg & 1) {
+  if (g_rowlin_cfg == 1) {
     switch (a.K) {
       case 256: hipLaunchKernelGGL((rowlin_kernel<R, 2, 128>), grid, dim3(128), 0, st, a); return true;
       case 512: hipLaunchKernelGGL((rowlin_kernel<R, 4, 128>), grid, dim3(256), 0, st, a); return true;
@@ -692,7 +687,7 @@ extern "C" int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, 
                 TAVSR_EALIGN, "rowlin: rows of x / W (and gamma / beta) must be 16-byte aligned");
   TAVSR_REQUIRE(out != x, TAVSR_EINVAL, "rowlin: out must not alias x");
   if (N <= 0 || Nout <= 0) return TAVSR_OK;
-  RowLinArgs a{x, ldx, gather, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act, 1, 0, 1, 0, 0, 0};
+  RowLinArgs a{x, ldx, gather, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act, 1, 0, 1, 0, 0};
   if (N <= 16) rowlin_launch<16>(a, (hipStream_t)stream);
   else rowlin_launch<32>(a, (hipStream_t)stream);
   TAVSR_LAUNCH_CHECK();
@@ -727,7 +722,7 @@ extern "C" int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, 
   TAVSR_REQUIRE(out != x, TAVSR_EINVAL, "rowlin_parts: out must not alias x");
   if (N <= 0 || Nout <= 0) return TAVSR_OK;
   RowLinArgs a{x, ldx, nullptr, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act,
-               x_parts, x_pstride, res_parts, res_pstride, out_pstride, 0};
+               x_parts, x_pstride, res_parts, res_pstride, out_pstride};
   const bool ok = N <= 16 ? rowlin_launch<16>(a, (hipStream_t)stream, ksplit) : rowlin_launch<32>(a, (hipStream_t)stream, ksplit);
   TAVSR_REQUIRE(ok, TAVSR_EUNSUPPORTED, "rowlin_parts: no kernel for K = %d in %d slices", K, ksplit);
   TAVSR_LAUNCH_CHECK();
@@ -741,7 +736,7 @@ extern "C" int tavsr_tree_attn_tune(int32_t wpb4) {      // tuning aid: 1 = alwa
 }
 
 extern "C" int tavsr_rowlin_tune(int32_t cfg) {      // tuning aid (scripts/rowlin_bench.py), not part of the product ABI
-  TAVSR_REQUIRE(cfg >= 0 && cfg <= 3, TAVSR_EINVAL, "rowlin_tune: bit 0 = half the waves per block, bit 1 = full-width column tiles");
+  TAVSR_REQUIRE(cfg >= 0 && cfg <= 1, TAVSR_EINVAL, "rowlin_tune: 0 or 1");
   g_rowlin_cfg = cfg;
   return TAVSR_OK;
 }
