@@ -809,6 +809,14 @@ int tavsr_beam_reorder(const int64_t* top_i, const float* top_s, const int64_t* 
                        const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out, int64_t* yseq_out, int32_t* anc_out,
                        int64_t* tok_out, float* score_out, int32_t N, int32_t K, int32_t V, int32_t C, int32_t T, int32_t ld_y,
                        int32_t ld_a, const int32_t* step_dev, int32_t* hist, int32_t hist_steps, tavsr_stream_t stream);
+/* ... with the head of the NEXT step in the same launch (maxlen [N / K] int32 given): score_out = -inf for a hypothesis that took
+ * <eos> or whose utterance has used its token budget (step + 1 >= maxlen[u]), anc_out[n][step + 1] = n + (step + 1) * N - what
+ * tavsr_beam_step_begin would do at the top of step + 1 (the records in `hist` keep the unmasked score). */
+int tavsr_beam_reorder_begin(const int64_t* top_i, const float* top_s, const int64_t* cand, const float* r_new, const float* psi_abs,
+                             const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out, int64_t* yseq_out, int32_t* anc_out,
+                             int64_t* tok_out, float* score_out, int32_t N, int32_t K, int32_t V, int32_t C, int32_t T, int32_t ld_y,
+                             int32_t ld_a, const int32_t* step_dev, int32_t* hist, int32_t hist_steps, const int32_t* maxlen,
+                             int32_t eos, tavsr_stream_t stream);
 /* head of a captured search step: score[n] = -inf for the hypotheses that ended with the previous token (tok[n] == eos, or
  * *step_dev >= maxlen[n / K]: the previous iteration was their utterance's last), anc[n][*step_dev] = n + *step_dev * N.
  * tavsr_beam_reorder's hist (nullable) [hist_steps][3][N] int32 receives the token's record (token, extended slot, score
@@ -861,6 +869,10 @@ int tavsr_dp_destroy(void);
 int tavsr_multi_add(float* const* dst, const float* const* src, const int64_t* n, int32_t ntensors, tavsr_stream_t stream);
 /* dst[t] <- src[t], nbytes[t] bytes each (any dtype), nbuffers <= 24, one launch; HOST tables as in tavsr_multi_add. */
 int tavsr_multi_copy(void* const* dst, const void* const* src, const int64_t* nbytes, int32_t nbuffers, tavsr_stream_t stream);
+/* ... and `ncounters` (<= 64) int64 words at `counters` incremented by one in the same launch (the step counters of a captured search
+ * step: nothing in this launch reads them). */
+int tavsr_multi_copy_inc(void* const* dst, const void* const* src, const int64_t* nbytes, int32_t nbuffers, int64_t* counters,
+                         int32_t ncounters, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Train-mode dropout (every torch Dropout / F.dropout site of the path).  y[i] = keep_i ? x[i] / (1 - p) : 0 where

@@ -452,7 +452,8 @@ __global__ __launch_bounds__(256) void beam_reorder_kernel(const int64_t* __rest
                                                            int32_t* __restrict__ anc_out, int64_t* __restrict__ tok_out,
                                                            float* __restrict__ score_out, int N, int K, int V, int C, int T,
                                                            int ld_y, int ld_a, const int32_t* __restrict__ step_dev,
-                                                           int32_t* __restrict__ hist, int hist_steps) {
+                                                           int32_t* __restrict__ hist, int hist_steps,
+                                                           const int32_t* __restrict__ maxlen, int eos) {
   const int n = blockIdx.x;
   const int u = n / K;
   const int64_t ti = top_i[n];
@@ -463,11 +464,14 @@ __global__ __launch_bounds__(256) void beam_reorder_kernel(const int64_t* __rest
   const int step = *step_dev;
   for (int e = threadIdx.x; e < T * 2; e += 256) r_out[(int64_t)n * T * 2 + e] = r_new[((int64_t)prev * T * 2 + e) * C + cidx];
   for (int e = threadIdx.x; e < ld_y; e += 256) yseq_out[(int64_t)n * ld_y + e] = e == step + 1 ? (int64_t)tk : yseq[(int64_t)prev * ld_y + e];
-  for (int e = threadIdx.x; e < ld_a; e += 256) anc_out[(int64_t)n * ld_a + e] = anc[(int64_t)prev * ld_a + e];
+  // maxlen given: the head of the NEXT step rides along (tavsr_beam_step_begin for step + 1: a hypothesis that just took <eos>, or whose
+  // utterance has used up its token budget, leaves the beam; column step + 1 of the ancestor list names the next step's own row)
+  for (int e = threadIdx.x; e < ld_a; e += 256)
+    anc_out[(int64_t)n * ld_a + e] = (maxlen && e == step + 1) ? n + (step + 1) * N : anc[(int64_t)prev * ld_a + e];
   if (threadIdx.x == 0) {
     s_out[n] = psi_abs[(int64_t)prev * C + cidx];
     tok_out[n] = tk;
-    score_out[n] = top_s[n];
+    score_out[n] = (maxlen && (tk == eos || step + 1 >= maxlen[u])) ? -INFINITY : top_s[n];
     if (hist && step < hist_steps) {          // back-pointer record of this token: (token, extended slot, score bits)
       int32_t* h = hist + (int64_t)step * 3 * N;
       h[n] = tk;
@@ -858,13 +862,23 @@ extern "C" int tavsr_beam_reorder(const int64_t* top_i, const float* top_s, cons
                                   int64_t* yseq_out, int32_t* anc_out, int64_t* tok_out, float* score_out, int32_t N, int32_t K,
                                   int32_t V, int32_t C, int32_t T, int32_t ld_y, int32_t ld_a, const int32_t* step_dev,
                                   int32_t* hist, int32_t hist_steps, tavsr_stream_t stream) {
+  return tavsr_beam_reorder_begin(top_i, top_s, cand, r_new, psi_abs, yseq, anc, r_out, s_out, yseq_out, anc_out, tok_out, score_out, N,
+                                  K, V, C, T, ld_y, ld_a, step_dev, hist, hist_steps, nullptr, 0, stream);
+}
+
+extern "C" int tavsr_beam_reorder_begin(const int64_t* top_i, const float* top_s, const int64_t* cand, const float* r_new,
+                                        const float* psi_abs, const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out,
+                                        int64_t* yseq_out, int32_t* anc_out, int64_t* tok_out, float* score_out, int32_t N, int32_t K,
+                                        int32_t V, int32_t C, int32_t T, int32_t ld_y, int32_t ld_a, const int32_t* step_dev,
+                                        int32_t* hist, int32_t hist_steps, const int32_t* maxlen, int32_t eos, tavsr_stream_t stream) {
   TAVSR_REQUIRE(top_i && top_s && cand && r_new && psi_abs && yseq && anc && r_out && s_out && yseq_out && anc_out && tok_out &&
                     score_out && step_dev, TAVSR_EINVAL, "beam_reorder: null pointer");
   TAVSR_REQUIRE(r_out != r_new && (const int64_t*)yseq_out != yseq && (const int32_t*)anc_out != anc, TAVSR_EINVAL,
                 "beam_reorder: the state is re-ordered, outputs must not alias the inputs");
   TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0, TAVSR_EINVAL, "beam_reorder: bad sizes");
   hipLaunchKernelGGL(beam_reorder_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, top_i, top_s, cand, r_new, psi_abs, yseq,
-                     anc, r_out, s_out, yseq_out, anc_out, tok_out, score_out, N, K, V, C, T, ld_y, ld_a, step_dev, hist, hist_steps);
+                     anc, r_out, s_out, yseq_out, anc_out, tok_out, score_out, N, K, V, C, T, ld_y, ld_a, step_dev, hist, hist_steps, maxlen,
+                     eos);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

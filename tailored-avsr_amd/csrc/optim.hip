@@ -89,6 +89,8 @@ struct MultiCopyArgs {
   void* dst[kMultiAddMax];
   const void* src[kMultiAddMax];
   int64_t n[kMultiAddMax];
+  int64_t* counters;      // (nullable) ncounters int64 words incremented by one by this launch: the step counter of a captured search step
+  int ncounters;
 };
 __global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyArgs a) {
   const int t = blockIdx.y;
@@ -100,14 +102,30 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyArgs a) 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
     reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
   for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+  if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < a.ncounters) a.counters[threadIdx.x] += 1;
 }
 
 }  // namespace tavsr
 
 using namespace tavsr;
 
+static int multi_copy_impl(void* const* dst, const void* const* src, const int64_t* nbytes, int32_t nbuffers, int64_t* counters,
+                           int32_t ncounters, tavsr_stream_t stream);
+
 extern "C" int tavsr_multi_copy(void* const* dst, const void* const* src, const int64_t* nbytes, int32_t nbuffers,
                                 tavsr_stream_t stream) {
+  return multi_copy_impl(dst, src, nbytes, nbuffers, nullptr, 0, stream);
+}
+
+extern "C" int tavsr_multi_copy_inc(void* const* dst, const void* const* src, const int64_t* nbytes, int32_t nbuffers,
+                                    int64_t* counters, int32_t ncounters, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(counters && ncounters > 0 && ncounters <= 64 && nbuffers > 0, TAVSR_EINVAL,
+                "multi_copy_inc: 1..64 counters and at least one buffer");
+  return multi_copy_impl(dst, src, nbytes, nbuffers, counters, ncounters, stream);
+}
+
+static int multi_copy_impl(void* const* dst, const void* const* src, const int64_t* nbytes, int32_t nbuffers, int64_t* counters,
+                           int32_t ncounters, tavsr_stream_t stream) {
   TAVSR_REQUIRE(nbuffers <= 0 || (dst && src && nbytes), TAVSR_EINVAL, "multi_copy: null table");
   TAVSR_REQUIRE(nbuffers <= kMultiAddMax, TAVSR_EUNSUPPORTED, "multi_copy: at most %d buffers per call", kMultiAddMax);
   if (nbuffers <= 0) return TAVSR_OK;
@@ -118,7 +136,9 @@ extern "C" int tavsr_multi_copy(void* const* dst, const void* const* src, const 
     a.dst[t] = dst[t]; a.src[t] = src[t]; a.n[t] = nbytes[t];
     mx = std::max(mx, nbytes[t]);
   }
-  if (mx <= 0) return TAVSR_OK;
+  a.counters = counters;
+  a.ncounters = ncounters;
+  if (mx <= 0 && !counters) return TAVSR_OK;
   const int64_t chunks = std::min<int64_t>(std::max<int64_t>(1, (mx / 16 + 255) / 256), 512);
   hipLaunchKernelGGL(tavsr::multi_copy_kernel, dim3((unsigned)chunks, (unsigned)nbuffers), dim3(256), 0, (hipStream_t)stream, a);
   TAVSR_LAUNCH_CHECK();

@@ -292,9 +292,9 @@ class BatchBeamSearch:
                 anc[:, i] = slot_ids + i * N
                 sdyn = None
             else:
-                # hypotheses that ended with the previous token (<eos>, or their utterance's last iteration) leave the beam
-                # and column `step` of the ancestor lists is filled: one launch, no host input
-                ops.beam_step_begin(score, tok, anc, dyn["maxl"], K, self.eos, dyn["step"])
+                # (hypotheses that ended with the previous token - <eos>, or their utterance's last iteration - have left the beam
+                # and column `step` of the ancestor lists is filled: the previous step's re-ordering launch did both, reset_state()
+                # for step 0)
                 sdyn = (dyn["step"], self.dec_step.pe.index_select(0, dyn["step64"]))
             # full = w_dec * decoder + w_lm * lm + w_len (LengthBonus: 1 per token), summed by the scorers' last launches
             # the two scorers are independent chains of small launches: the LM runs on the side stream next to the decoder
@@ -321,9 +321,10 @@ class BatchBeamSearch:
                 else:
                     weighted = ops.beam_combine(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, self.eos, self.w_ctc)
                     top_s, top_i = torch.topk(weighted.view(U, K * V), K, dim=-1)
-                ops.beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, dyn["shadow"], K, V, dyn["step"], hist=dyn["hist"])
-                ops.multi_copy_([r_prev, s_prev, yseq, anc, tok, score], list(dyn["shadow"]))
-                dyn["ctr"].add_(1)                                  # step, step64, stepp1 are views of this one tensor
+                ops.beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, dyn["shadow"], K, V, dyn["step"], hist=dyn["hist"],
+                                 maxlen=dyn["maxl"], eos=self.eos)
+                # commit + the step counters (step, step64, stepp1 are views of this one tensor) in one launch
+                ops.multi_copy_([r_prev, s_prev, yseq, anc, tok, score], list(dyn["shadow"]), inc=dyn["ctr"])
                 return anc, tok
             is_eos_c = cand == self.eos
             psi = torch.where(is_eos_c, eos_s.unsqueeze(1), psi)
@@ -350,6 +351,7 @@ class BatchBeamSearch:
             score.fill_(NEG_INF)
             score.view(U, K)[:, 0] = 0.0
             anc.zero_()
+            anc[:, 0] = slot_ids                                      # step 0's own key / value rows
             r_prev.zero_()
             s_prev.zero_()
 

@@ -1546,8 +1546,9 @@ def multi_add_(dst, src):
     return dst
 
 
-def multi_copy_(dst, src):
-    """dst[t].copy_(src[t]) for lists of contiguous same-shape/dtype tensors in ONE launch (<= 24 tensors)."""
+def multi_copy_(dst, src, inc=None):
+    """dst[t].copy_(src[t]) for lists of contiguous same-shape/dtype tensors in ONE launch (<= 24 tensors); ``inc`` (int64 tensor):
+    every element incremented by one in the same launch."""
     assert len(dst) == len(src)
     require_cuda(*dst, *src)
     n = len(dst)
@@ -1556,6 +1557,11 @@ def multi_copy_(dst, src):
     dp = (C.c_void_p * n)(*[_addr(t) for t in dst])
     sp = (C.c_void_p * n)(*[_addr(t) for t in src])
     cnt = (C.c_int64 * n)(*[t.numel() * t.element_size() for t in dst])
+    if inc is not None:
+        require_cuda(inc)
+        assert inc.dtype == torch.int64 and inc.is_contiguous()
+        check(lib().tavsr_multi_copy_inc(dp, sp, cnt, n, ptr(inc), inc.numel(), stream()), "tavsr_multi_copy_inc")
+        return dst
     check(lib().tavsr_multi_copy(dp, sp, cnt, n, stream()), "tavsr_multi_copy")
     return dst
 
@@ -1810,8 +1816,9 @@ def beam_step_begin(score, tok, anc, maxlen, K, eos, step_dev):
                                       stream()), "tavsr_beam_step_begin")
 
 
-def beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, outs, K, V, step_dev, hist=None):
-    """gathers the state of the extended slots into ``outs`` = (r, s, yseq, anc, tok, score) buffers (tavsr.h)."""
+def beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, outs, K, V, step_dev, hist=None, maxlen=None, eos=0):
+    """gathers the state of the extended slots into ``outs`` = (r, s, yseq, anc, tok, score) buffers (tavsr.h).  ``maxlen`` (int32
+    [N / K]): the head of the next step rides along (tavsr_beam_reorder_begin)."""
     N, Cn = cand.shape
     T = r_new.shape[1]
     r_out, s_out, y_out, a_out, t_out, sc_out = outs
@@ -1819,6 +1826,14 @@ def beam_reorder(top_i, top_s, cand, r_new, psi_abs, yseq, anc, outs, K, V, step
     assert hist is None or (hist.dtype == torch.int32 and hist.is_contiguous() and hist.shape[1:] == (3, N))
     assert top_i.is_contiguous() and top_s.is_contiguous() and top_i.numel() == N and yseq.dtype == torch.int64
     assert anc.dtype == torch.int32 and y_out.shape == yseq.shape and a_out.shape == anc.shape and r_out.shape == (N, T, 2)
+    if maxlen is not None:
+        require_cuda(maxlen)
+        assert maxlen.dtype == torch.int32 and maxlen.numel() == N // K
+        check(lib().tavsr_beam_reorder_begin(ptr(top_i), ptr(top_s), ptr(cand), ptr(r_new), ptr(psi_abs), ptr(yseq), ptr(anc), ptr(r_out),
+                                             ptr(s_out), ptr(y_out), ptr(a_out), ptr(t_out), ptr(sc_out), N, K, V, Cn, T, yseq.stride(0),
+                                             anc.stride(0), ptr(step_dev), ptr(hist), 0 if hist is None else hist.shape[0],
+                                             ptr(maxlen), int(eos), stream()), "tavsr_beam_reorder_begin")
+        return
     check(lib().tavsr_beam_reorder(ptr(top_i), ptr(top_s), ptr(cand), ptr(r_new), ptr(psi_abs), ptr(yseq), ptr(anc), ptr(r_out),
                                    ptr(s_out), ptr(y_out), ptr(a_out), ptr(t_out), ptr(sc_out), N, K, V, Cn, T, yseq.stride(0),
                                    anc.stride(0), ptr(step_dev), ptr(hist), 0 if hist is None else hist.shape[0], stream()),

@@ -344,6 +344,18 @@ def test_beam_update_kernels_equal_the_torch_expressions():
     dst = [torch.zeros_like(o) for o in outs]
     ops.multi_copy_(dst, list(outs))
     assert all(torch.equal(d, o) for d, o in zip(dst, outs))
+    # the same with the head of the next step in the launch, and the commit launch counting the step
+    outs2 = tuple(torch.empty_like(o) for o in outs)
+    maxl = torch.tensor([20, i + 1, 20, 20], dtype=torch.int32).cuda()          # utterance 1 has used its budget after this token
+    ops.beam_reorder(top_i, top_s, cand, r_new, pa, yseq, anc, outs2, K, V, ctr.view(torch.int32)[0:1], maxlen=maxl, eos=eos)
+    kill = (new_tok == eos) | (torch.arange(N).cuda() // K == 1)
+    a_want = anc[prev].clone()
+    a_want[:, i + 1] = torch.arange(N, dtype=torch.int32).cuda() + (i + 1) * N
+    s_want = torch.where(kill, torch.full_like(top_s.view(N), -float("inf")), top_s.view(N))
+    for g, w in zip(outs2, (r_new[prev, :, :, cidx], pa[prev, cidx], y_want, a_want, new_tok, s_want)):
+        assert torch.equal(g, w)
+    ops.multi_copy_(dst, list(outs2), inc=ctr)
+    assert all(torch.equal(d, o) for d, o in zip(dst, outs2)) and ctr.tolist() == [i + 1, i + 2]
 
 
 @pytest.mark.gpu
