@@ -126,8 +126,15 @@ def gen_encoders():
         "bf_encoder_6L_T49": dict(nb=6, B=1, Tin=201, lens=[201]),
         "bf_encoder_2L_ragged": dict(nb=2, B=3, Tin=100, lens=[100, 77, 31]),
         "bf_encoder_12L_T99": dict(nb=12, B=2, Tin=400, lens=[400, 344]),
+        # the reference's real length range (src/datasets/avsr_dataset.py:27: clips up to 20 s = 2000 mel frames, T = 499):
+        # multi-block attention, merge tail beyond one batch, long cgMLP convolutions - wiring pinned by the reference itself
+        "bf_encoder_2L_T299": dict(nb=2, B=2, Tin=1200, lens=[1200, 904]),
+        "bf_encoder_2L_T499": dict(nb=2, B=1, Tin=2000, lens=[2000]),
     }
+    only = os.environ.get("GEN_GOLDEN_ENCODERS")
     for name, c in cases.items():
+        if only and name not in only.split(","):
+            continue
         conf = asr_conf(num_blocks=c["nb"])["encoder_conf"]
         enc = MyBranchformerEncoder(input_size=80, **conf).eval()
         fill_parameters_(enc, seed=31)
@@ -495,6 +502,9 @@ def main():
         return
     if "--cfg1-only" in sys.argv:
         gen_cfg1_wav()
+        return
+    if "--encoders-only" in sys.argv:
+        gen_encoders()
         return
     if "--interctc-only" in sys.argv:
         gen_interctc()

@@ -1,0 +1,224 @@
+"""Parity over the reference's REAL sequence-length range.  The reference trains on clips of up to 500 video frames = 20 s
+(/root/reference/src/datasets/avsr_dataset.py:27, configs/AVSR/tailored_transformer+ctc_english.yaml:147): 2000 mel frames,
+encoder T = 499 / 500, transcripts of ~200 characters.  At these lengths the shape-selected routes run that the 4 s
+benchmark shapes never reach: the CTC lattice outside LDS (csrc/ctc.hip), attention over several key blocks inside the
+model, the merge tail beyond one utterance per batch of workgroups (csrc/mergeproj.hip), the chunked embedding backward, the
+long-T positional table, ``CapturedEncode`` and the search's token budget.  Same bars as the 4 s parity tests
+(tests/test_gpu_parity.py, test_gpu_av.py): loss 1e-4, encoder output 1e-4 (max-rel), every gradient 5e-3 (rel-L2), greedy
+ids bit-exact where the oracle's top-2 logit gap is binding.  The reference-generated long fixtures
+(``bf_encoder_2L_T299`` / ``_T499``) are run by tests/test_gpu_parity.py::test_encoder_vs_reference_golden."""
+import argparse
+
+import pytest
+import torch
+
+from helpers import AVSR_YAML, TOKENS_EN, asr_conf, avsr_conf, grad_ok, max_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = 1e-4
+
+
+def _long_asr_batch():
+    from oracle.model import synth
+    speech = synth((3, 2000, 80), seed=2001)
+    slens = torch.tensor([2000, 1332, 700])
+    text = synth((3, 200), seed=2002, kind="int", lo=1, hi=40)
+    tlens = torch.tensor([200, 120, 40])
+    for i, l in enumerate(tlens):
+        text[i, int(l):] = -1
+    return speech, slens, text, tlens
+
+
+def _greedy_binding(oracle, eo, model, eg, og):
+    logits = oracle.ctc.ctc_lo(eo)
+    top2 = logits.topk(2, -1).values
+    binding = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert binding.float().mean() > 0.98
+    ids, hyp, hl = model.ctc.greedy(eg, og)
+    assert torch.equal(ids.cpu()[binding], logits.argmax(-1)[binding])
+
+
+def test_asr_12L_20s_ragged_vs_oracle():
+    """audio-only 12-layer model, B = 3 ragged {2000, 1332, 700} mel frames (T = 499 / 332 / 174), transcripts of
+    {200, 120, 40} tokens, train mode without dropout: HIP vs the pinned oracle on the host."""
+    from oracle.model import build_asr_oracle, fill_parameters_
+    from tavsr.tasks.asr import ASRTask
+    conf = asr_conf(num_blocks=12, dec_blocks=6)
+    oracle = build_asr_oracle(conf, TOKENS_EN)
+    fill_parameters_(oracle, seed=2000)
+    model = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=12, dec_blocks=6)))
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    oracle.train()
+    speech, slens, text, tlens = _long_asr_batch()
+    lo, so, _ = oracle(speech, slens, text, tlens)
+    lo.backward()
+    lg, sg, _ = model(speech.cuda(), slens.cuda(), text.cuda(), tlens.cuda())
+    lg.backward()
+    assert rel_err(sg["loss_ctc"].cpu(), so["loss_ctc"]) < 1e-4
+    assert rel_err(sg["loss_att"].cpu(), so["loss_att"]) < 1e-4
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 1e-4
+    # the same oracle in double precision says how well fp32 arithmetic determines each gradient at all: at T = 499 the
+    # merge's branch-weight projections (weight_proj*.bias: ONE number, a sum over 1005 frames of terms that cancel) differ
+    # by 2.5e-3 between the fp32 and the fp64 oracle.  Bar per parameter, against the fp64 gradients: 5e-3, or three
+    # times the fp32 oracle's own distance from them where that is larger.
+    o64 = build_asr_oracle(asr_conf(num_blocks=12, dec_blocks=6), TOKENS_EN)
+    o64.load_state_dict(oracle.state_dict())
+    o64 = o64.double().train()
+    l64, _, _ = o64(speech.double(), slens, text, tlens)
+    l64.backward()
+    assert rel_err(lg.detach().cpu(), l64.detach()) < 1e-4
+    po, p64 = dict(oracle.named_parameters()), dict(o64.named_parameters())
+    worst = ("", 0.0, 0.0)
+    for n, p in model.named_parameters():
+        ref = p64[n].grad
+        if float(ref.abs().max()) < 1e-6:
+            assert grad_ok(p.grad.cpu(), ref, 5e-3), n
+            continue
+        e32, e = rel_err(po[n].grad, ref), rel_err(p.grad.cpu(), ref)
+        assert e < max(5e-3, 3 * e32), (n, e, e32)
+        worst = max(worst, (n, e, e32), key=lambda t: t[1])
+    print("worst gradient (name, HIP vs fp64 oracle, fp32 oracle vs fp64 oracle)", worst)
+    model.eval()
+    oracle.eval()
+    with torch.no_grad():
+        eo, oo = oracle.encode(speech, slens)
+        eg, og = model.encode(speech.cuda(), slens.cuda())
+    assert eg.shape[1] == 499 and torch.equal(og.cpu(), oo)
+    assert max_rel(eg.cpu(), eo) < ACT_TOL
+    _greedy_binding(oracle, eo, model, eg, og)
+
+
+def _long_av_batch():
+    from oracle.model import synth
+    audio, video = synth((2, 2000, 80), seed=2011), synth((2, 500, 88, 88), seed=2012)
+    alens, vlens = torch.tensor([2000, 1200]), torch.tensor([500, 300])
+    text = synth((2, 200), seed=2013, kind="int", lo=1, hi=40)
+    tlens = torch.tensor([200, 110])
+    text[1, 110:] = -1
+    return audio, alens, video, vlens, text, tlens
+
+
+def test_av_tailored_12L_20s_vs_oracle():
+    """tailored AV 12-layer model, B = 2: (2000 mel + 500 lip frames) and (1200 + 300), train mode without dropout: loss,
+    every gradient, BatchNorm running statistics, then the encoder output and greedy ids in eval mode."""
+    import psutil
+    if psutil.virtual_memory().available < 32 * 2**30:
+        pytest.skip("the CPU oracle keeps ~10 GB of activations for 800 lip frames in training mode")
+    from oracle.av import build_avsr_oracle
+    from oracle.model import fill_parameters_
+    from tavsr.tasks.avsr import AVSRTask
+    conf = avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)
+    oracle = build_avsr_oracle(conf, TOKENS_EN)
+    fill_parameters_(oracle, seed=2010)
+    model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(AVSR_YAML, num_blocks=12, dec_blocks=6)))
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    oracle.train()
+    batch = _long_av_batch()
+    lg, sg, _ = model(*[t.cuda() for t in batch])
+    lg.backward()
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
+    bufs = {n: b.detach().float().cpu() for n, b in model.named_buffers()}
+    lo, so, _ = oracle(*batch)
+    lo.backward()
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 1e-4
+    for n, p in oracle.named_parameters():
+        assert grad_ok(got[n], p.grad, 5e-3), (n, rel_err(got[n], p.grad))
+    for n, b in oracle.named_buffers():
+        assert rel_err(bufs[n], b.float()) < 1e-4, n
+    for p in oracle.parameters():
+        p.grad = None
+    model.eval()
+    oracle.eval()
+    audio, alens, video, vlens = batch[:4]
+    with torch.no_grad():
+        eo, oo = oracle.encode(audio, alens, video, vlens)
+        eg, og = model.encode(audio.cuda(), alens.cuda(), video.cuda(), vlens.cuda())
+    assert eg.shape[1] == 500 and torch.equal(og.cpu(), oo)
+    assert max_rel(eg.cpu(), eo) < ACT_TOL
+    _greedy_binding(oracle, eo, model, eg, og)
+
+
+def test_asr_20s_step_eager_c_sequenced_equals_graph_replay():
+    """the 20 s batch of the first test (dropout 0): the eager step - Branchformer layers as C-side sequencers - and the same
+    step captured into one hipGraph and replayed give bit-identical loss and gradients (the capture runs the Python
+    sequencing of the layers: two different launch orders over the same kernels and plans)."""
+    from oracle.model import fill_parameters_
+    from tavsr.tasks.asr import ASRTask
+    model = ASRTask.build_model(argparse.Namespace(**asr_conf(num_blocks=12, dec_blocks=6)))
+    fill_parameters_(model, seed=2000)
+    model = model.cuda().train()
+    batch = [t.cuda() for t in _long_asr_batch()]
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = model(*[t.clone() for t in batch])[0]
+        loss.backward()
+        return loss
+
+    eager_loss = step().detach().clone()
+    eager = [p.grad.detach().clone() for p in params]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = model(*batch)[0]
+        static_loss.backward()
+    for replay in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_loss.detach(), eager_loss), replay
+        bad = [n for (n, p), g in zip(model.named_parameters(), eager) if not torch.equal(p.grad, g)]
+        assert not bad, (replay, bad[:8])
+
+
+def test_beam10_lm_on_a_20s_utterance_matches_oracle():
+    """config 5's search (beam 10, ctc 0.1, 16-layer x 512 LM at 0.6, length bonus 0.5) on ONE 20 s utterance of the 12-layer
+    audio-only model (T = 499 frames for the CTC prefix scorer, the K/V pools and the source attention) against the
+    oracle's search on the oracle's encoder output: best hypothesis (466 tokens with these weights) and its score."""
+    from oracle import beam_search as BS
+    from oracle.model import build_asr_oracle, fill_parameters_, synth
+    from tavsr.inference.beam_search import BatchBeamSearch
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.asr import ASRTask
+    lm_kw = dict(pos_enc=None, embed_unit=128, att_unit=512, head=8, unit=2048, layer=16, dropout_rate=0.0)
+    m = build_asr_oracle(asr_conf(num_blocks=12, dec_blocks=6), TOKENS_EN).eval()
+    fill_parameters_(m, seed=77)
+    lm = BS.TransformerLMOracle(len(TOKENS_EN), **lm_kw).eval()
+    fill_parameters_(lm, seed=78)
+    pconf = asr_conf(num_blocks=12, dec_blocks=6)
+    pconf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**pconf)).eval()
+    pm.load_state_dict(m.state_dict())
+    plm = TransformerLM(len(TOKENS_EN), **lm_kw).eval()
+    plm.load_state_dict(lm.state_dict())
+    pm, plm = pm.cuda(), plm.cuda()
+    x, lens = synth((1, 2000, 80), seed=79), torch.tensor([2000])
+    with torch.no_grad():
+        enc, olens = m.encode(x, lens)
+        genc, golens = pm.encode(x.cuda(), lens.cuda())
+        assert torch.equal(golens.cpu(), olens) and int(olens[0]) == 499
+        assert max_rel(genc.cpu(), enc) < ACT_TOL
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(min(8, nthreads))     # ~470 one-token steps on [10, 512] rows: 128 threads only add wake-ups
+        try:
+            ref = BS.build_beam_search(m, lm, 10, 0.1, 0.6, 0.5).forward(enc[0, :499])
+        finally:
+            torch.set_num_threads(nthreads)
+        hip = BatchBeamSearch(pm, plm, 10, 0.1, 0.6, 0.5).decode(genc, golens)[0]
+    assert len(hip) > 0 and len(ref) > 0
+    assert hip[0][0] == ref[0].yseq.tolist(), (hip[0], ref[0].yseq.tolist())
+    assert abs(hip[0][1] - ref[0].score) < 5e-4 * abs(ref[0].score)
+    top_h = {tuple(h[0]) for h in hip[:5]}
+    top_r = {tuple(h.yseq.tolist()) for h in ref[:5]}
+    assert len(top_h & top_r) >= 3, (top_h, top_r)

@@ -57,7 +57,8 @@ def test_layer_vs_reference_golden(tag, kw):
         assert rel_err(layer.weight_global.cpu(), g["weight_global"]) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["bf_encoder_6L_T49", "bf_encoder_2L_ragged", "bf_encoder_12L_T99"])
+@pytest.mark.parametrize("name", ["bf_encoder_6L_T49", "bf_encoder_2L_ragged", "bf_encoder_12L_T99", "bf_encoder_2L_T299",
+                                  "bf_encoder_2L_T499"])
 def test_encoder_vs_reference_golden(name):
     from oracle.model import synth
     from tavsr.encoder.branchformer.encoder import MyBranchformerEncoder

@@ -58,7 +58,8 @@ def test_layer_matches_reference(tag, kw):
         assert rel_err(layer.weight_global, g["weight_global"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["bf_encoder_6L_T49", "bf_encoder_2L_ragged", "bf_encoder_12L_T99"])
+@pytest.mark.parametrize("name", ["bf_encoder_6L_T49", "bf_encoder_2L_ragged", "bf_encoder_12L_T99", "bf_encoder_2L_T299",
+                                  "bf_encoder_2L_T499"])
 def test_encoder_matches_reference(name):
     g = golden(name)
     conf = asr_conf(num_blocks=int(g["nb"]))["encoder_conf"]
