@@ -131,7 +131,7 @@ def host_cores():
     return phys or allowed, allowed
 
 
-def cpu_baseline(budget_s=30.0):
+def cpu_baseline(budget_s=30.0, workload=None, bs=None):
     """The oracle's fwd+bwd of the same model/workload on the host cores (bounded sample, SURVEY 8d / task section 4).
     Threads = the physical cores this process may use (lscpu cores, capped by the affinity mask).  Batch: the GPU
     run's batch of 32 costs the oracle ~80 s per AV step on this class of host, far beyond the bounded sample the default
@@ -140,14 +140,19 @@ def cpu_baseline(budget_s=30.0):
     from oracle.model import build_asr_oracle
     from tavsr.utils.tokens import CHAR_ENGLISH
 
+    global WORKLOAD
     phys, allowed = host_cores()
     threads = max(1, min(phys, allowed))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    build = build_avsr_oracle if WORKLOAD == "avsr" else build_asr_oracle
-    model = build(copy.deepcopy(make_conf()), CHAR_ENGLISH).train()
-    bs = 4 if WORKLOAD == "avsr" else 8
-    batch = make_batch(bs, 1234, "cpu")
+    saved, WORKLOAD = WORKLOAD, workload or WORKLOAD       # (the `asr` object's own CPU figure: configs[1] beside the headline)
+    try:
+        build = build_avsr_oracle if WORKLOAD == "avsr" else build_asr_oracle
+        model = build(copy.deepcopy(make_conf()), CHAR_ENGLISH).train()
+        bs = bs or (4 if WORKLOAD == "avsr" else 8)
+        batch = make_batch(bs, 1234, "cpu")
+    finally:
+        WORKLOAD = saved
 
     def step():
         for p in model.parameters():
@@ -389,6 +394,7 @@ def main():
     ap.add_argument("--no-fwd-encoder", action="store_true", help="skip the fwd_encoder object of the default run")
     ap.add_argument("--no-eager", action="store_true", help="skip the eager (no-graph) timing beside the graph number")
     ap.add_argument("--no-asr", action="store_true", help="skip the `asr` object (BASELINE configs[1] step) of the default AV run")
+    ap.add_argument("--no-decode", action="store_true", help="skip the `decode` object (BASELINE configs[4]: batch-1 p50 RTF, batch-64 utt/s)")
     ap.add_argument("--no-box", action="store_true", help="skip the `box` calibration object (fp32 MFMA microbench, HBM copy)")
     ap.add_argument("--workload", choices=("asr", "avsr"), default="avsr",
                     help="asr: BASELINE configs[1] (headline); avsr: configs[2] tailored AV-Branchformer incl. the visual frontend")
@@ -640,6 +646,8 @@ def main():
         "frac_of_fp32_mfma_peak_whole_step": round(value * GFLOP_PER_UTT_STEP[WORKLOAD] / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
         "gflop_per_utt_step": round(GFLOP_PER_UTT_STEP[WORKLOAD], 2),
     }
+    # what the exchange really ran on: ranks of the C ABI's RCCL communicator (0: none), ranks torch.distributed sees, peak HBM per rank
+    out.update(dp.world_report(torch.cuda.max_memory_allocated()))
     if sustained is not None:
         out["sustained"] = sustained
     if exposed_ms is not None:
@@ -683,10 +691,15 @@ def main():
         out["fwd_encoder"] = bench_fwd_encoder(dev)
         if WORKLOAD == "avsr" and not args.no_asr:
             out["asr"] = bench_asr_step(dev)
+    if rank == 0 and world == 1 and WORKLOAD == "avsr" and not args.no_decode and not args.no_fwd_encoder:
+        import bench_decode                 # BASELINE configs[4] on the driver's record (replicas only; nothing to scale here)
+        out["decode"] = bench_decode.driver_record(dev)
     if box is not None:
         out["box"] = box
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+        if "asr" in out:
+            out["asr"]["cpu_baseline"] = cpu_baseline(budget_s=8.0, workload="asr", bs=4)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

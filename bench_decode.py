@@ -72,12 +72,88 @@ def cpu_baseline(model_state, lm_state, n_utt=1):
             "sample": f"{n_utt} utterance(s) of 4 s, encoder + beam-{SEARCH['beam_size']} + LM on the CPU oracle, {el:.1f} s"}
 
 
+def build(dev):
+    """the config-5 stack: tailored AV model + 16 x 512 LM (random-init, seed 1), the batched search and the captured encoder"""
+    from tavsr.inference.beam_search import BatchBeamSearch, CapturedEncode
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.avsr import AVSRTask
+    conf = make_conf()
+    torch.manual_seed(1)                     # random-init weights (no checkpoints offline), the same on every rank
+    model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf))).eval()
+    lm = TransformerLM(len(conf["token_list"]), **LM_CONF).eval()
+    model, lm = model.to(dev), lm.to(dev)
+    search = BatchBeamSearch(model, lm, **SEARCH)
+    encode = CapturedEncode(model)           # what tavsr.inference.Speech2Text does: one hipGraph per input shape
+    return model, lm, search, encode
+
+
+def timed_decode(search, encode, dev, utterances, batch_size, rank=0, world=1, warm_full=True):
+    """decode ``utterances`` synthetic 4 s clips (this rank's share) in batches of ``batch_size``, inputs resident in HBM before the
+    clock starts; -> (per-utterance latencies [s], wall [s], encoder [s], search [s], tokens decoded).  The warm-up batch has the
+    timed batches' size (a serving process in steady state: the search's captured step exists when the clock starts);
+    ``warm_full=False`` is rounds 1-4's protocol - a warm-up of at most 8 utterances, so that the first timed batch of a larger
+    size pays the ~10 ms capture of its step graph (``--cold-capture``)."""
+    mine = list(range(rank, utterances, world))
+    batches = [mine[i:i + batch_size] for i in range(0, len(mine), batch_size)]
+
+    def run(batch):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            enc, olens = encode(*batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hyps = search.decode(enc, olens, nbest=1)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, hyps
+
+    run(make_utts(batch_size if warm_full else min(batch_size, 8), 7, dev))      # warm-up (allocator pools, lazy module state)
+    data = [make_utts(len(b), 1234 + rank * 1000 + bi, dev) for bi, b in enumerate(batches)]   # resident in HBM
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    T0 = time.perf_counter()
+    lat, enc_s, dec_s, ntok = [], 0.0, 0.0, 0
+    for b, batch in zip(batches, data):
+        e, d, hyps = run(batch)
+        enc_s += e
+        dec_s += d
+        lat += [e + d] * len(b)
+        ntok += sum(len(h[0][0]) - 2 for h in hyps if h)
+    torch.cuda.synchronize()
+    return lat, time.perf_counter() - T0, enc_s, dec_s, ntok
+
+
+def driver_record(dev, n_b1=8, n_b64=128):
+    """the ``decode`` object of bench.py's default line (BASELINE configs[4] on the driver's record): batch-1 p50 RTF over ``n_b1``
+    utterances of 4 s and batch-64 throughput over ``n_b64``, one model / LM / search object, same protocol as this file's main()."""
+    model, lm, search, encode = build(dev)
+    lat1, wall1, e1, d1, tok1 = timed_decode(search, encode, dev, n_b1, 1)
+    rtf1 = np.array(lat1) / DUR_S
+    lat64, wall64, e64, d64, tok64 = timed_decode(search, encode, dev, n_b64, 64)
+    out = {"workload": "BASELINE configs[4]: tailored AV-Branchformer 12L + 6L decoder, beam 10, ctc 0.1, Transformer LM 16x512 "
+                       "(lm 0.6), length bonus 0.5, synthetic 4 s utterances, random-init weights",
+           "batch1": {"rtf_p50": round(float(np.percentile(rtf1, 50)), 4), "rtf_p90": round(float(np.percentile(rtf1, 90)), 4),
+                      "unit": "RTF (latency / 4 s)", "utterances": len(lat1), "encoder_ms_per_utt": round(1e3 * e1 / len(lat1), 2),
+                      "search_ms_per_utt": round(1e3 * d1 / len(lat1), 2), "tokens_per_utt": round(tok1 / len(lat1), 1),
+                      "search_us_per_token": round(1e6 * d1 / max(tok1, 1), 1)},
+           "batch64": {"utterances_per_s": round(len(lat64) / wall64, 2), "utterances": len(lat64), "wall_s": round(wall64, 3),
+                       "rtf_p50": round(float(np.percentile(np.array(lat64) / DUR_S, 50)), 4),
+                       "encoder_s": round(e64, 3), "search_s": round(d64, 3), "tokens_decoded": int(tok64)},
+           "higher_is_better": False, "dtype": "f32", "data": "synthetic"}
+    del model, lm, search, encode
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--utterances", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cold-capture", action="store_true", help="warm up with at most 8 utterances (the protocol of rounds 1-4)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -95,53 +171,15 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
 
     from tavsr import dp
-    from tavsr.inference.beam_search import BatchBeamSearch, CapturedEncode
-    from tavsr.lm.transformer_lm import TransformerLM
-    from tavsr.tasks.avsr import AVSRTask
 
     rank, local, world = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    conf = make_conf()
-    torch.manual_seed(1)                     # random-init weights (no checkpoints offline), the same on every rank
-    model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf))).eval()
-    lm = TransformerLM(len(conf["token_list"]), **LM_CONF).eval()
-    model, lm = model.to(dev), lm.to(dev)
-    search = BatchBeamSearch(model, lm, **SEARCH)
-    encode = CapturedEncode(model)           # what tavsr.inference.Speech2Text does: one hipGraph per input shape
-
-    mine = list(range(rank, args.utterances, world))
-    batches = [mine[i:i + args.batch] for i in range(0, len(mine), args.batch)]
-
-    def run(batch):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            enc, olens = encode(*batch)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            hyps = search.decode(enc, olens, nbest=1)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        return t1 - t0, t2 - t1, hyps
-
-    run(make_utts(min(args.batch, 8), 7, dev))      # warm-up (allocator pools, lazy module state)
-    data = [make_utts(len(b), 1234 + rank * 1000 + bi, dev) for bi, b in enumerate(batches)]   # resident in HBM
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    T0 = time.perf_counter()
-    lat, enc_s, dec_s, ntok = [], 0.0, 0.0, 0
-    for b, batch in zip(batches, data):
-        e, d, hyps = run(batch)
-        enc_s += e
-        dec_s += d
-        lat += [e + d] * len(b)
-        ntok += sum(len(h[0][0]) - 2 for h in hyps if h)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - T0
+    model, lm, search, encode = build(dev)
+    lat, wall, enc_s, dec_s, ntok = timed_decode(search, encode, dev, args.utterances, args.batch, rank, world,
+                                                     warm_full=not args.cold_capture)
     stats = torch.tensor([wall, float(len(lat)), enc_s, dec_s, float(ntok)], dtype=torch.float64, device=dev)
     if world > 1:
         allw = [torch.zeros_like(stats) for _ in range(world)]
@@ -156,7 +194,7 @@ def main():
         out = {
             "metric": "decode_rtf_p50", "value": round(float(np.percentile(rtf, 50)), 4), "unit": "RTF (latency / 4 s)",
             "n_gpus": world, "higher_is_better": False, "scaling": "replicas", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "utterances": len(lat), "batch": args.batch,
+            "data": "synthetic", "utterances": len(lat), "batch": args.batch, "warm_up": "cold capture" if args.cold_capture else "full batch",
             "rtf_p90": round(float(np.percentile(rtf, 90)), 4),
             "throughput_rtf": round(wall / (len(lat) * DUR_S), 6),
             "utterances_per_s": round(len(lat) / wall, 2), "wall_s": round(wall, 3),

@@ -30,6 +30,19 @@ void set_error(const char* fmt, ...);
 
 constexpr int kWave = 64;
 
+// The lane-network reductions below use the row_bcast:15 / row_bcast:31 DPP controls, which exist on GFX9 / CDNA only, and this
+// library is written for one ISA.  A device pass for anything else stops here instead of assembling garbage.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libtavsr_hip kernels are written for gfx950 (CDNA4): build with --offload-arch=gfx950"
+#endif
+// Debug builds (-DTAVSR_DEBUG_WAVE) trap when a whole-wave reduction is entered with lanes switched off: the result is read from
+// lane 63 and the row broadcasts take their sources by lane number, so a partial wave would return a stale value silently.
+#ifdef TAVSR_DEBUG_WAVE
+#define TAVSR_ASSERT_FULL_WAVE() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define TAVSR_ASSERT_FULL_WAVE() do { } while (0)
+#endif
+
 // Whole-wave reductions on the data-parallel-primitive lane network (quad permutes, row mirrors, row broadcasts; the result is read
 // from lane 63 and is uniform): six steps of ~8 cycles against six dependent ds_bpermute round trips (~120 cycles each) of a
 // __shfl_xor butterfly.  LayerNorm rows, softmax rows and the selection loops of the search step are chains of such reductions.
@@ -37,6 +50,7 @@ constexpr int kWave = 64;
 // not write contributes (0 for sums; the lane's own value for max / min).
 #define TAVSR_DPP_F(V, CTRL, RMASK, OLD) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(OLD), __float_as_int(V), CTRL, RMASK, 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
+  TAVSR_ASSERT_FULL_WAVE();
   v += TAVSR_DPP_F(v, 0xB1, 0xf, 0.f);       // quad_perm [1, 0, 3, 2]
   v += TAVSR_DPP_F(v, 0x4E, 0xf, 0.f);       // quad_perm [2, 3, 0, 1]
   v += TAVSR_DPP_F(v, 0x141, 0xf, 0.f);      // row_half_mirror
@@ -46,6 +60,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
+  TAVSR_ASSERT_FULL_WAVE();
   v = fmaxf(v, TAVSR_DPP_F(v, 0xB1, 0xf, v));
   v = fmaxf(v, TAVSR_DPP_F(v, 0x4E, 0xf, v));
   v = fmaxf(v, TAVSR_DPP_F(v, 0x141, 0xf, v));
@@ -56,6 +71,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float wave_max_dpp(float v) { return wave_max(v); }
 __device__ __forceinline__ int wave_min_dpp(int v) {
+  TAVSR_ASSERT_FULL_WAVE();
 #define TAVSR_DPP_I(CTRL, RMASK) v = min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, RMASK, 0xf, false))
   TAVSR_DPP_I(0xB1, 0xf);
   TAVSR_DPP_I(0x4E, 0xf);

@@ -424,11 +424,15 @@ __global__ __launch_bounds__(1024) void beam_combine_topk_kernel(const float* __
       bv = wave_max_dpp(li == 0x7fffffff ? -INFINITY : lv);
       bi = wave_min_dpp((li != 0x7fffffff && lv == bv) ? li : 0x7fffffff);
     }
+    // fewer than K comparable scores (a diverged model: NaN rows): the round has nothing left to pick.  The indices feed
+    // beam_reorder's slot arithmetic, so they stay in range - slot 0, token 0 at -inf, a hypothesis that is dead on arrival
+    const bool exhausted = bi == 0x7fffffff;
+    if (exhausted) { bi = 0; bv = -INFINITY; }
     if (lane == 0) {
       top_s[(int64_t)u * K + r] = bv;
       top_i[(int64_t)u * K + r] = bi;
     }
-    if ((bi & 63) == lane) {            // the owner retires the element
+    if (!exhausted && (bi & 63) == lane) {            // the owner retires the element
       if (bi < 64 * RG) {
 #pragma unroll
         for (int j = 0; j < RG; ++j)

@@ -149,6 +149,23 @@ def _init_from_env(backend: str | None = None, seed: int | None = 0, force_rccl:
     return rank, local, world
 
 
+def world_report(peak_bytes: int = 0) -> dict:
+    """First-contact record of an N > 1 run for the bench line: how many ranks the C ABI's RCCL communicator really holds
+    (``tavsr_dp_world()``: 0 = no communicator, gradients went through torch.distributed or nowhere), how many ranks
+    ``torch.distributed`` sees, and every rank's peak device memory.  A collective on the host side (``all_gather_object``):
+    call it on every rank, outside the timed region."""
+    from ._lib import lib
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    peaks = [None] * world
+    if world > 1:
+        dist.all_gather_object(peaks, float(peak_bytes))
+    else:
+        peaks = [float(peak_bytes)]
+    return {"rccl_world": int(lib().tavsr_dp_world()), "dist_world": world,
+            "dist_backend": dist.get_backend() if dist.is_initialized() else None,
+            "hbm_peak_gb_per_rank": [round(p / 2**30, 2) for p in peaks]}
+
+
 def shutdown():
     """frees the C ABI's communicator and the process group."""
     global RCCL_ABI, FORCE_WORLD1
@@ -553,7 +570,16 @@ class TwoPhaseBackward:
         """does the graph under ``loss`` reach a node below the cut WITHOUT passing a detached leaf (an intermediate-CTC tap of
         a layer below the cut, a parameter-sharing path)?  Then ``phase_a`` would already walk - and free - part of the lower
         graph and ``phase_b`` would run those nodes a second time: such a step must not be split."""
-        below = {t.grad_fn for t, _ in self.pairs if t.grad_fn is not None}
+        # every node of the lower graph, not only the cut tensors' own: a tap may sit any number of layers below the cut (the
+        # cut follows the middle encoder layer, an intermediate-CTC tap may follow layer 3).  AccumulateGrad nodes are left out:
+        # a parameter used on both sides of the cut is legal (it counts as late).
+        below, stack = set(), [t.grad_fn for t, _ in self.pairs if t.grad_fn is not None]
+        while stack:
+            fn = stack.pop()
+            if fn in below or hasattr(fn, "variable"):
+                continue
+            below.add(fn)
+            stack.extend(n for n, _ in fn.next_functions if n is not None)
         seen, stack = set(), [loss.grad_fn] if loss.grad_fn is not None else []
         while stack:
             fn = stack.pop()

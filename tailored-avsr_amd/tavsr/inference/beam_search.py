@@ -36,6 +36,36 @@ def _cat(ws):
     return torch.cat([w.detach() for w in ws], dim=0).contiguous()
 
 
+class _DerivedWeights:
+    """The step objects keep a few DERIVED copies of parameters (q / k / v weights side by side for one launch, the LM's input
+    table).  Everything else is read through the parameters' own storage.  ``sync()`` re-derives the copies IN PLACE (captured
+    graphs keep reading the same buffers) when a source parameter's version counter has moved since they were made - an
+    optimizer step or ``load_state_dict`` between two decodes (validation while training)."""
+
+    def __init__(self):
+        self._derived = []          # (destination, source parameters)
+        self._seen = None
+
+    def cat(self, ws):
+        dst = _cat(ws)
+        self._derived.append((dst, list(ws)))
+        return dst
+
+    def _versions(self):
+        return tuple(w._version for _, ws in self._derived for w in ws)
+
+    def sync(self) -> bool:
+        now = self._versions()
+        if self._seen is None:
+            self._seen = now
+        if now == self._seen:
+            return False
+        for dst, ws in self._derived:
+            torch.cat([w.detach() for w in ws], dim=0, out=dst)
+        self._seen = now
+        return True
+
+
 # One-token scorer steps are chains of small launches: the fused feed-forward block (LayerNorm + both GEMMs, csrc/ffn.hip)
 # and the fused source attention cut the chain.  TAVSR_DECODE_FUSED=0 keeps the GEMM launches (A/B switch).
 FUSED_STEP = True
@@ -78,6 +108,8 @@ class _DecoderStep:
 
     def __init__(self, dec):
         self.dec = dec
+        self.weights = _DerivedWeights()
+        _cat = self.weights.cat
         self.D = dec.after_norm.weight.numel()
         self.H = dec.heads
         self.dk = self.D // self.H
@@ -153,6 +185,8 @@ class _LMStep:
 
     def __init__(self, lm):
         self.lm = lm
+        self.weights = _DerivedWeights()
+        _cat = self.weights.cat
         self.D, self.H = lm.att_unit, lm.heads
         self.dk = self.D // self.H
         self.layers = []
@@ -169,13 +203,30 @@ class _LMStep:
         self.N, self.K = N, K
         # the LM's input layer (embedding -> Linear -> LayerNorm -> ReLU; espnet TransformerLM with pos_enc: null) depends on the token
         # alone: one [V, d] table per search instead of three launches per token
+        self.in_table = self._input_table()
+        emb = self.lm.encoder.embed
+        self._table_ver = tuple(w._version for w in (self.lm.embed.weight, emb[0].weight, emb[0].bias, emb[1].weight, emb[1].bias))
+        self.kpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
+        self.vpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
+
+    def _input_table(self):
         lm = self.lm
         emb = lm.encoder.embed
         t = ops.linear(lm.embed.weight.contiguous(), emb[0].weight, emb[0].bias)
         t = ops.layernorm_fwd(t, emb[1].weight, emb[1].bias, EPS, save=False)[0]
-        self.in_table = ops.act_(t, "relu")
-        self.kpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
-        self.vpool = [ops.empty(max_steps * N, self.D, like=like) for _ in self.layers]
+        return ops.act_(t, "relu")
+
+    def sync_weights(self):
+        """derived copies after a change of the LM's parameters: the q / k / v concatenations and - into the buffer a captured step
+        gathers from - the input table (one small GEMM, a LayerNorm, a ReLU)"""
+        lm = self.lm
+        emb = lm.encoder.embed
+        src = (lm.embed.weight, emb[0].weight, emb[0].bias, emb[1].weight, emb[1].bias)
+        ver = tuple(w._version for w in src)
+        changed = self.weights.sync()
+        if getattr(self, "in_table", None) is not None and (changed or ver != self._table_ver):
+            self.in_table.copy_(self._input_table())
+        self._table_ver = ver
 
     def step(self, i, tok, anc, dyn=None, logits_only=False, **score):
         N, D, H, dk = self.N, self.D, self.H, self.dk
@@ -242,6 +293,10 @@ class BatchBeamSearch:
                              "the CTC prefix scorer cannot score a prefix longer than its input")
         steps = max(maxl_h)
         ctc = self.model.ctc
+        # derived weight copies follow the parameters (an optimizer step / load_state_dict since the last call): ADVICE round 4
+        self.dec_step.weights.sync()
+        if self.lm_step is not None:
+            self.lm_step.sync_weights()
         # A captured step is tied to its buffers, not to a batch: while the shape (utterances, frames, token budget) repeats -
         # a stream of 4 s clips - the buffers are refilled in place and the hipGraph of the previous call is replayed; capture
         # and warm-up were 8-10 ms of a 95 ms batch-1 search.

@@ -100,7 +100,13 @@ def host_max(lengths: torch.Tensor) -> int:
     answers from a cache; anything else costs the one sync the reference pays too (espnet_model.py:372)."""
     m = getattr(lengths, "_tavsr_max", None)
     if m is not None:
-        return int(m)
+        # (version counter at the time the maximum was attached, maximum): an in-place edit of the collated tensor (copy_, clamp_,
+        # sub_) bumps the version and the hint is dropped for the synced path below
+        if isinstance(m, tuple):
+            if m[0] == lengths._version:
+                return int(m[1])
+        else:
+            return int(m)
     if not lengths.is_cuda:
         return int(lengths.max())
     key = id(lengths)

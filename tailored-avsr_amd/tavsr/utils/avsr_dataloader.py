@@ -31,7 +31,7 @@ def _lengths(values):
     then needs no device read (tavsr.models.espnet_model.host_max)."""
     values = [int(v) for v in values]
     t = torch.tensor(values, dtype=torch.int64).to(DEVICE)
-    t._tavsr_max = max(values) if values else 0
+    t._tavsr_max = (t._version, max(values) if values else 0)      # espnet_model.host_max checks the version counter
     return t
 
 

@@ -132,6 +132,42 @@ def test_captured_step_is_reused_for_the_next_batch_of_the_same_shape():
 
 
 @pytest.mark.gpu
+def test_reused_captured_step_follows_a_change_of_the_weights():
+    """between two decodes of one shape the parameters change in place (an optimizer step, load_state_dict: periodic
+    validation while training).  The re-used captured step must score with the NEW weights - its derived copies (q / k / v weights
+    side by side, the LM's input table) are re-derived when a source parameter's version counter has moved - i.e. give what a search
+    object built after the change gives."""
+    from tavsr.inference.beam_search import BatchBeamSearch
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.asr import ASRTask
+    conf = asr_conf(num_blocks=2, dec_blocks=2)
+    conf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**conf)).eval()
+    fill_parameters_(pm, seed=5)
+    plm = TransformerLM(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(plm, seed=6)
+    pm, plm = pm.cuda(), plm.cuda()
+    with torch.no_grad():
+        x = synth((2, 160, 80), seed=7).cuda()
+        enc, olens = pm.encode(x, torch.tensor([160, 120]).cuda())
+        search = BatchBeamSearch(pm, plm, 10, 0.1, 0.6, 0.5)
+        before = search.decode(enc, olens)
+        graph = search._captured["graph"]
+        other = TransformerLM(len(TOKENS_EN), **LM_KW)
+        fill_parameters_(other, seed=66)
+        plm.load_state_dict(other.state_dict())                      # copy_ in place: same storages, new versions
+        for l in pm.decoder.decoders:
+            l.self_attn.linear_q.weight.mul_(0.5)
+        got = search.decode(enc, olens)
+        assert search._captured["graph"] is graph
+        want = BatchBeamSearch(pm, plm, 10, 0.1, 0.6, 0.5).decode(enc, olens)
+    assert [h[0] for h in got[0]] != [h[0] for h in before[0]] or [h[1] for h in got[0]] != [h[1] for h in before[0]]
+    for u in range(2):
+        assert [h[0] for h in got[u]] == [h[0] for h in want[u]], u
+        assert [h[1] for h in got[u]] == [h[1] for h in want[u]], u
+
+
+@pytest.mark.gpu
 def test_captured_encode_equals_the_eager_encode():
     """inference.CapturedEncode: the replayed hipGraph of ``model.encode`` gives what the eager launches give (same kernels: 1e-6),
     for a second batch of the same shape with other lengths, and after a change of shape"""
@@ -325,6 +361,14 @@ def test_beam_update_kernels_equal_the_torch_expressions():
     flat = w3.view(U, K * V)[0]
     order = sorted(range(K * V), key=lambda i: (-float(flat[i]), i))[:K]
     assert ti2[0].tolist() == order and torch.equal(ts2[0], flat[order])
+    # an utterance with fewer than K comparable scores (NaN rows of a diverged model) - the indices stay in range
+    bad = full.clone()
+    bad[0:K] = float("nan")
+    bad[0, 3] = -1.0                                                  # one finite score in utterance 0
+    ts3, ti3, _ = ops.beam_combine_topk(bad, cand, psi, psi_abs.clone(), eos_s, eos_abs, s_prev, score, eos, 0.2, K, keep_weighted=True)
+    assert int(ti3.min()) >= 0 and int(ti3.max()) < K * V
+    assert int(ti3[0, 0]) == 3 and bool(torch.isinf(ts3[0, 1:]).all()) and bool((ts3[0, 1:] < 0).all())
+    assert torch.equal(ti3[1:], ti[1:]) and torch.equal(ts3[1:], ts[1:])
     # re-ordering
     r_new = torch.randn(N, T, 2, C).cuda()
     yseq = torch.randint(0, V, (N, steps + 2)).cuda()

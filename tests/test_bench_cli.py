@@ -34,3 +34,29 @@ def test_plain_gpus_n_self_launches_its_ranks(script, monkeypatch):
     assert int(cmd[cmd.index("--master-port") + 1]) > 0
     assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == script + ".py" and cmd[-2:] == ["--gpus", "4"]
     assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+
+
+def _report_worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
+    from tavsr import dp
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dp.init_from_env("gloo")
+    ret[rank] = dp.world_report((rank + 1) * 2**30)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_line_reports_the_communicator_and_every_ranks_peak_memory():
+    """first-contact aids of the N > 1 run: bench.py's line carries ``rccl_world`` = tavsr_dp_world() (0 under
+    the gloo rig: no RCCL communicator exists, and the line says so) and ``hbm_peak_gb_per_rank`` for every rank."""
+    import torch.multiprocessing as mp
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "dp.world_report(" in src
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_report_worker, args=(2, 29757, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        rep = ret[r]
+        assert rep["rccl_world"] == 0 and rep["dist_world"] == 2 and rep["dist_backend"] == "gloo"
+        assert rep["hbm_peak_gb_per_rank"] == [1.0, 2.0]

@@ -419,28 +419,47 @@ def test_two_phase_backward_refuses_a_loss_that_bypasses_the_cut():
     the clean split still equals one backward pass."""
     sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
     from tavsr import dp
-    w1, w2 = torch.randn(4, 4, requires_grad=True), torch.randn(4, 4, requires_grad=True)
+    w0, w1, w2 = (torch.randn(4, 4, requires_grad=True) for _ in range(3))
     x = torch.randn(3, 4)
 
     def net(bypass):
-        h = torch.tanh(x @ w1)
+        h0 = torch.tanh(x @ w0)
+        h = torch.tanh(h0 @ w1)
         t = dp.cut(h)
         y = torch.tanh(t @ w2).sum()
-        return y + (h * h).sum() if bypass else y
+        if bypass == "at the cut":
+            return y + (h * h).sum()
+        if bypass == "one layer below":           # ADVICE round 4: a tap strictly below the cut (layer 3 of 12 under a cut at 6)
+            return y + (h0 * h0).sum()
+        if bypass == "shared parameter":          # legal: w2 used above the cut, w1 again above it - no NODE of the lower graph is shared
+            return y + torch.tanh(t @ w1).sum()
+        return y
 
     two = dp.TwoPhaseBackward()
+    for how in ("at the cut", "one layer below"):
+        with two.forward():
+            loss = net(how)
+        assert two.split and two.bypassed(loss), how
+        with pytest.raises(RuntimeError, match="below dp.cut"):
+            two.phase_a(loss)
+        w0.grad = w1.grad = w2.grad = None
     with two.forward():
-        loss = net(True)
-    assert two.split and two.bypassed(loss)
-    with pytest.raises(RuntimeError, match="below dp.cut"):
-        two.phase_a(loss)
+        loss = net("shared parameter")
+    assert two.split and not two.bypassed(loss)
+    two.phase_a(loss)
+    two.phase_b()
+    ga = [w.grad.clone() for w in (w0, w1, w2)]
+    w0.grad = w1.grad = w2.grad = None
+    net("shared parameter").backward()
+    assert all(torch.allclose(a, w.grad, atol=1e-6) for a, w in zip(ga, (w0, w1, w2)))
+    w0.grad = w1.grad = w2.grad = None
     w1.grad = w2.grad = None
     with two.forward():
         loss = net(False)
     assert two.split and not two.bypassed(loss)
-    assert [id(p) for p in two.late_params([w1, w2])] == [id(w1)]
+    assert [id(p) for p in two.late_params([w0, w1, w2])] == [id(w0), id(w1)]
     two.phase_a(loss)
-    assert w1.grad is None and w2.grad is not None
+    assert w0.grad is None and w1.grad is None and w2.grad is not None
     two.phase_b()
     g1, g2 = w1.grad.clone(), w2.grad.clone()
     w1.grad = w2.grad = None

@@ -615,6 +615,8 @@ def test_cut_to_longest_reads_the_maximum_without_a_stale_answer():
     lens2 = torch.tensor([10, 1, 1, 1], device="cuda")
     assert EM.cut_to_longest(x, lens2) is x
     hinted = torch.tensor([2, 2, 2, 2], device="cuda")
-    hinted._tavsr_max = 6                                              # what utils/avsr_dataloader.py attaches
+    hinted._tavsr_max = (hinted._version, 6)                           # what utils/avsr_dataloader.py attaches
     assert EM.cut_to_longest(x, hinted).shape == (4, 6)
+    hinted.clamp_(max=1)                                               # an in-place edit voids the hint
+    assert EM.cut_to_longest(x, hinted).shape == (4, 1)
     assert EM.cut_to_longest(x.cpu(), torch.tensor([1, 9, 2, 2])).shape == (4, 9)
