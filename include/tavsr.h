@@ -40,6 +40,9 @@ const char* tavsr_last_error_string(void);   /* host string, thread-local */
  * mode 0 = head of the forked section, 1 = behind the join on the calling queue, 2 = alternately per call; us = 0 disarms. */
 int tavsr_spin(float us, tavsr_stream_t stream);
 int tavsr_race_probe(float us, int mode);
+/* tuning aid (scripts/launch_floor.py): a launch of `grid` x `block` threads that does nothing (kind 0), one 16-byte read + write per
+ * thread (1), or that plus a barrier and a dependent second read (2) - the floor under a one-token step's dependent launches */
+int tavsr_probe_launch(int32_t kind, int32_t grid, int32_t block, float* buf, int64_t n, tavsr_stream_t stream);
 /* Box calibration for bench.py's `box` object: `blocks` workgroups of 4 waves, each wave issuing 4 * iters independent
  * v_mfma_f32_32x32x2_f32 (4096 FLOP each) and nothing else - the fp32 matrix rate this device holds, against which a 5 %
  * difference between two boxes of a pool can be told from a regression.  `sink`: one device word (never written). */
@@ -638,6 +641,10 @@ int tavsr_lsm_loss(const float* logits, int64_t ld, const int64_t* target, int32
                    tavsr_stream_t stream);
 int tavsr_embed_pe(const int64_t* ids, const float* table, const float* pe, float scale, float* out, int64_t N,
                    int32_t L, int32_t D, tavsr_stream_t stream);
+/* the one-token form of a replayed search step (espnet TransformerDecoder.forward_one_step embeds ONE position): every row gets
+ * positional row min(*step_dev, L - 1) of pe [L][D]; the step counter is device data, so the launch is captured once */
+int tavsr_embed_pe_step(const int64_t* ids, const float* table, const float* pe, float scale, float* out, int64_t N,
+                        int32_t L, int32_t D, const int32_t* step_dev, tavsr_stream_t stream);
 int tavsr_embed_bwd(const int64_t* ids, const float* dout, float scale, float* dtable, int64_t N, int32_t V,
                     int32_t D, int32_t accumulate, tavsr_stream_t stream);
 
@@ -748,12 +755,12 @@ int tavsr_specaug_mask(float* x, int32_t B, int32_t T, int32_t F, const int64_t*
  *   tavsr_rowlin         : out[n][c] = res[n][c] + act(LN(x[g(n)])[:K] . W[c][:K] + bias[c]), n < N, c < Nout - one Linear of
  *       forward_one_step / batch_score (espnet transformer decoder_layer.py / encoder_layer.py with cache) with the
  *       LayerNorm in front of it (gamma/beta nullable: none), bias, activation (TAVSR_ACT_*) and residual (nullable; may
- *       alias out) in ONE launch.  gather (nullable): g(n) = gather[n] (embedding rows), else g(n) = n.  K % 32 == 0,
- *       16-byte aligned rows; out must not alias x.
+ *       alias out) in ONE launch.  gather (nullable): g(n) = gather[n] (embedding rows), else g(n) = n; res_gather (nullable): the
+ *       residual row of n is res[res_gather[n]] (res must not alias out then).  K % 32 == 0, 16-byte aligned rows; out must not alias x.
  * ------------------------------------------------------------------------------------------- */
 int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, const float* gamma, const float* beta, float eps,
-                 const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr, float* out,
-                 int64_t ldo, int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
+                 const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr,
+                 const int64_t* res_gather, float* out, int64_t ldo, int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
 /* The same launch with rows held as a SUM of tensors: x = sum_{p < x_parts} x[p * x_pstride + ...] (added while the operand is
  * loaded, in that order; the LayerNorm sees the sum), res likewise; ksplit > 1: K is dealt to ksplit blocks per column tile and block y
  * writes partial tensor y of the output at out + y * out_pstride (bias and residual ride in partial 0; no LayerNorm, no activation) -
@@ -764,10 +771,15 @@ int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, int64_t x_p
                        float eps, const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr,
                        int32_t res_parts, int64_t res_pstride, float* out, int64_t ldo, int32_t ksplit, int64_t out_pstride,
                        int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream);
-/* tuning aid (scripts/tree_attn_bench.py): 1 = four (hypothesis, head) items per workgroup whatever the step's size */
-int tavsr_tree_attn_tune(int32_t wpb4);
-/* tuning aid (scripts/rowlin_bench.py): 1 = half the waves per block, twice the k range per wave; 0 = the library's plan */
-int tavsr_rowlin_tune(int32_t cfg);
+/* tuning / test aid (scripts/tree_attn_bench.py, tests/test_gpu_rowlin.py): how a small step (N * H <= 256 items) is launched -
+ * 3: the plan (0 for histories beyond ~80 keys - a captured step: half its pool capacity -, else 1); 0: a workgroup of four waves per
+ * item, the keys dealt to the waves; 1: one wave per item and workgroup; 2: one wave per item, four items per workgroup (what larger
+ * steps always run) */
+int tavsr_tree_attn_tune(int32_t mode);
+/* 1 when tavsr_rowlin (ksplit 1) / tavsr_rowlin_parts has a one-launch plan for N rows, this K, with / without the LayerNorm
+ * prologue, in `ksplit` K slices: N <= 32; K in {64 .. 512}; 1024 (with LayerNorm: up to 16 rows); 2048 without LayerNorm and up to 16
+ * rows (more rows: in slices); slices of 256 / 512 / 1024 without LayerNorm.  Every plan runs without register spills. */
+int tavsr_rowlin_ok(int32_t N, int32_t K, int32_t with_ln, int32_t ksplit);
 int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                          const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N, int32_t H,
                          int32_t dk, float scale, const int32_t* step_dev, const float* k_new, const float* v_new,
@@ -805,6 +817,17 @@ int tavsr_beam_combine_topk(const float* full, const int64_t* cand, const float*
                             const float* eos_abs, const float* s_prev, const float* score, float* weighted, float* top_s,
                             int64_t* top_i, int32_t N, int32_t K, int32_t V, int32_t C, int32_t eos, float w_ctc,
                             tavsr_stream_t stream);
+/* The beam update behind the scorers in one launch, for vocabularies of up to 64 tokens and beams of up to 16 (espnet
+ * BatchBeamSearch.search with the partial CTC scorer, avsr_inference.py:277-304): psi_all / psi_abs_all [N][V] are the CTC prefix scores
+ * of EVERY token (tavsr_ctc_prefix_step with the identity candidate list - it can run beside the scorers, off the step's critical
+ * path).  full = dec + w_lm * log_softmax(z_lm) + add (z_lm nullable: full = dec); pre-beam = the C best tokens of full; weighted as
+ * tavsr_beam_combine with those candidates; top_s / top_i as tavsr_beam_combine_topk.  psi_abs_all[n][eos] becomes eos_abs[n].
+ * full_out / weighted [N][V], cand_out [N][C] (int64, the pre-beam in descending order): nullable records of the intermediate values.
+ * Bit for bit what tavsr_log_softmax_rows (accumulate) + tavsr_ctc_prefix_step_topk + tavsr_beam_combine_topk give. */
+int tavsr_beam_select_topk(const float* dec, const float* z_lm, float w_lm, float add, const float* psi_all, float* psi_abs_all,
+                           const float* eos_s, const float* eos_abs, const float* s_prev, const float* score, float* full_out,
+                           float* weighted, int64_t* cand_out, float* top_s, int64_t* top_i, int32_t N, int32_t K, int32_t V,
+                           int32_t C, int32_t eos, float w_ctc, tavsr_stream_t stream);
 int tavsr_beam_reorder(const int64_t* top_i, const float* top_s, const int64_t* cand, const float* r_new, const float* psi_abs,
                        const int64_t* yseq, const int32_t* anc, float* r_out, float* s_out, int64_t* yseq_out, int32_t* anc_out,
                        int64_t* tok_out, float* score_out, int32_t N, int32_t K, int32_t V, int32_t C, int32_t T, int32_t ld_y,

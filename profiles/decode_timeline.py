@@ -9,7 +9,7 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 names = [re.sub(r"\(.*$", "", r[0]).replace("void ", "").replace("tavsr::", "") for r in rows]
-marks = [i for i, n in enumerate(names) if "beam_combine" in n]
+marks = [i for i, n in enumerate(names) if "beam_combine" in n or "beam_select" in n]
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (len(marks) // 2, len(marks) // 2 + 40)
 hi = min(hi, len(marks) - 1)
 spans, busys, overs, agg = [], [], [], {}

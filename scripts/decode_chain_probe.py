@@ -40,8 +40,16 @@ def timed(tag):
     print(f"{tag:46s} {1e6 * min(ts):8.1f} us per token ({steps_seen[-1]} tokens)", flush=True)
 
 timed("both scorers, two queues")
+B.CTC_BESIDE_SCORERS = not B.CTC_BESIDE_SCORERS
+timed(f"both scorers, CTC prefix scores beside the scorers = {B.CTC_BESIDE_SCORERS}")
+B.CTC_BESIDE_SCORERS = not B.CTC_BESIDE_SCORERS
+timed("both scorers, two queues (again)")
+from tavsr._lib import lib as _lib
+for mode, what in ((0, "four waves per item"), (1, "one wave per item"), (3, "the plan")):
+    _lib().tavsr_tree_attn_tune(mode)
+    timed(f"both scorers, tree attention: {what}")
 from tavsr import ops as _ops
-for ff in (8, 1, 4):
+for ff in (4,):
     _ops.ROWLIN_KSPLIT = ff
     timed(f"both scorers, feed-forward closing projection in {ff} K slice(s)")
 dec_step, lm_step = search.dec_step.step, search.lm_step.step

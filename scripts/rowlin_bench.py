@@ -1,5 +1,5 @@
 """one-token Linear launches of the search step (tavsr_rowlin) at their shapes, 10 hypothesis rows: us per call in a captured
-chain of 20 dependent calls, library plan vs the half-waves plan (tavsr_rowlin_tune)."""
+chain of 20 dependent calls."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tailored-avsr_amd"))
@@ -36,14 +36,9 @@ for rnd in range(2):
         gam, bet = 1 + 0.1 * r(K), 0.1 * r(K)
         res = None if ln else r(N, Nout)
         out = torch.empty(N, Nout, device="cuda")
-        row = []
-        for cfg in (0, 1):
-            lib().tavsr_rowlin_tune(cfg)
-            us = chain_us(lambda: ops.rowlin(x, w, b, ln=(gam, bet, 1e-12) if ln else None, act=act, res=res, out=out))
-            row.append(us)
-        lib().tavsr_rowlin_tune(0)
+        row = [chain_us(lambda: ops.rowlin(x, w, b, ln=(gam, bet, 1e-12) if ln else None, act=act, res=res, out=out))] * 2
         if K == 2048:
             for ks in (2, 4, 8):
                 row.append(chain_us(lambda: ops.rowlin(x, w, b, res=res, ksplit=ks)))
             print(f"round {rnd} {name:22s} K dealt to 2 / 4 / 8 blocks (partial tensors out): {row[2]:6.2f} / {row[3]:6.2f} / {row[4]:6.2f} us", flush=True)
-        print(f"round {rnd} {name:22s} K {K:5d} -> {Nout:5d}: plan {row[0]:6.2f} us   half-waves {row[1]:6.2f} us", flush=True)
+        print(f"round {rnd} {name:22s} K {K:5d} -> {Nout:5d}: {row[0]:6.2f} us", flush=True)

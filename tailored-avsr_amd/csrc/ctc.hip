@@ -313,15 +313,18 @@ __global__ __launch_bounds__(256) void lsm_loss_kernel(const float* __restrict__
 }
 
 // out[n,:] = table[ids[n],:] * scale + pe[n % L, :]      (decoder embed: Embedding + PositionalEncoding)
+// (step_dev: every row takes positional row min(*step_dev, L - 1) - the one-token step of a replayed search graph, whose step
+// counter lives in device memory: no index_select launch in front of the scorers)
 __global__ void embed_pe_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                 const float* __restrict__ pe, float scale, float* __restrict__ out, int64_t total4,
-                                int D4, int L) {
+                                int D4, int L, const int32_t* __restrict__ step_dev) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   int64_t n = i / D4;
   int c4 = (int)(i % D4);
+  const int64_t prow = step_dev ? (int64_t)min(max(*step_dev, 0), L - 1) : n % L;
   float4 e = reinterpret_cast<const float4*>(table)[ids[n] * D4 + c4];
-  float4 p = reinterpret_cast<const float4*>(pe)[(n % L) * D4 + c4];
+  float4 p = reinterpret_cast<const float4*>(pe)[prow * D4 + c4];
   reinterpret_cast<float4*>(out)[i] = make_float4(e.x * scale + p.x, e.y * scale + p.y, e.z * scale + p.z, e.w * scale + p.w);
 }
 
@@ -432,7 +435,19 @@ extern "C" int tavsr_embed_pe(const int64_t* ids, const float* table, const floa
   int64_t total4 = N * (D / 4);
   if (total4 <= 0) return TAVSR_OK;
   hipLaunchKernelGGL(embed_pe_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, ids, table, pe, scale,
-                     out, total4, D / 4, L);
+                     out, total4, D / 4, L, (const int32_t*)nullptr);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_embed_pe_step(const int64_t* ids, const float* table, const float* pe, float scale, float* out,
+                                   int64_t N, int32_t L, int32_t D, const int32_t* step_dev, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(ids && table && pe && out && step_dev, TAVSR_EINVAL, "embed_pe_step: null pointer");
+  TAVSR_REQUIRE(D % 4 == 0 && L > 0, TAVSR_EINVAL, "embed_pe_step: D %% 4 == 0 required");
+  int64_t total4 = N * (D / 4);
+  if (total4 <= 0) return TAVSR_OK;
+  hipLaunchKernelGGL(embed_pe_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, ids, table, pe, scale,
+                     out, total4, D / 4, L, step_dev);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -127,6 +127,111 @@ __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __rest
   }
 }
 
+// The same step for SMALL steps (N H <= 256 items: batch 1 - 3 x beam 10): one workgroup of four waves per (hypothesis, head), the keys
+// dealt to the waves in four contiguous runs.  A one-wave item walks its ~100 keys in two passes of dependent gathers (ancestor list ->
+// key rows -> value rows beyond the prefetched ones): 8 us of a 30 us LM layer.  Here a wave has at most 64 keys per round - ONE per
+// lane for up to 256 keys - so a round is two round trips to memory: the ancestor indices (with q), then every key AND value row of
+// the run at once (the value rows in the (float4 column, key group) lane layout, their row indices passed over the lane network).
+// Each wave keeps an online softmax (running max, sum, un-normalised context); the four partial results meet in LDS behind the one
+// workgroup barrier and wave 0 merges them.  Item -> (n, h) mapping, k_new / v_new append and step_dev as in the kernel above.
+template <int DL>
+__global__ __launch_bounds__(256) void tree_attn_split_kernel(const float* __restrict__ q, int64_t ldq,
+                                                              const float* __restrict__ kpool, const float* __restrict__ vpool,
+                                                              int64_t ldkv, const int32_t* __restrict__ anc, int64_t ld_anc,
+                                                              int nkeys, float* __restrict__ out, int64_t ldo, int N, int H,
+                                                              int dk, float scale, const int32_t* __restrict__ step_dev,
+                                                              const float* __restrict__ k_new, const float* __restrict__ v_new,
+                                                              float* __restrict__ kpool_w, float* __restrict__ vpool_w, int group) {
+  constexpr int KG = 64 / DL;             // key groups of a wave in the value phase
+  constexpr int NW = 4;                   // waves per item
+  constexpr int NQ = DL;                  // float4s of a head row (dk <= 4 DL)
+  __shared__ float s_m[NW], s_s[NW];
+  __shared__ float4 s_acc[NW][DL];
+  if (step_dev) nkeys = min(*step_dev + 1, nkeys);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x;
+  const int n = (item / (H * group)) * group + item % group, h = (item / group) % H;
+  const int nq = dk >> 2;                 // float4s actually present
+  const float* qv = q + (int64_t)n * ldq + h * dk;
+  const int32_t* a = anc + (int64_t)n * ld_anc;
+  const int per = (nkeys + NW - 1) / NW;
+  const int j0 = wave * per, j1 = min(nkeys, j0 + per);
+  const int dl = lane & (DL - 1), kg = lane / DL;
+  const bool dok = dl < nq;
+  const int doff = h * dk + (dok ? dl * 4 : 0);
+  const float* klast = k_new ? k_new + (int64_t)n * ldq + h * dk : nullptr;
+  const float* vlast = v_new ? v_new + (int64_t)n * ldq + doff : nullptr;
+  // round trip 1: the query (the same 16 / 32 float4s for every lane) and the first round's ancestor index of this lane's key
+  float4 qr[NQ];
+#pragma unroll
+  for (int d = 0; d < NQ; ++d) qr[d] = d < nq ? *reinterpret_cast<const float4*>(qv + 4 * d) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float m = -INFINITY, ssum = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = j0; base < j1; base += 64) {
+    const int j = base + lane;
+    const bool kvalid = j < j1;
+    const int aj = kvalid ? a[j] : 0;
+    // round trip 2: this lane's key row, and the value rows of keys base + kg + u KG in the (dl, kg) layout
+    const float* kr = (klast && j == nkeys - 1) ? klast : kpool + (int64_t)aj * ldkv + h * dk;
+    float4 kv[NQ];
+#pragma unroll
+    for (int d = 0; d < NQ; ++d) kv[d] = (kvalid && d < nq) ? *reinterpret_cast<const float4*>(kr + 4 * d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 vv[DL];
+#pragma unroll
+    for (int u = 0; u < DL; ++u) {
+      const int src = kg + u * KG;                       // lane that holds this key's ancestor index
+      const int jj = base + src;
+      const int av = __shfl(aj, src, 64);
+      const float* vr = (vlast && jj == nkeys - 1) ? vlast : vpool + (int64_t)av * ldkv + doff;
+      vv[u] = (jj < j1 && dok) ? *reinterpret_cast<const float4*>(vr) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < NQ; ++d) dot += (qr[d].x * kv[d].x + qr[d].y * kv[d].y) + (qr[d].z * kv[d].z + qr[d].w * kv[d].w);
+    dot = kvalid ? dot * scale : -INFINITY;
+    const float mr = wave_max(dot);
+    const float mn = fmaxf(m, mr);                        // (a round of a non-empty run always holds a valid key: mn is finite)
+    const float p = kvalid ? expf(dot - mn) : 0.f;
+    const float corr = m == -INFINITY ? 0.f : expf(m - mn);
+    ssum = ssum * corr + wave_sum(p);
+    acc.x *= corr; acc.y *= corr; acc.z *= corr; acc.w *= corr;
+#pragma unroll
+    for (int u = 0; u < DL; ++u) {
+      const float pj = __shfl(p, kg + u * KG, 64);
+      acc.x += pj * vv[u].x; acc.y += pj * vv[u].y; acc.z += pj * vv[u].z; acc.w += pj * vv[u].w;
+    }
+    m = mn;
+  }
+#pragma unroll
+  for (int o = DL; o < 64; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (lane == 0) { s_m[wave] = m; s_s[wave] = ssum; }
+  if (kg == 0) s_acc[wave][dl] = acc;
+  __syncthreads();
+  if (wave != 0 || kg != 0 || !dok) return;
+  float M = s_m[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w]);
+  float S = 0.f;
+  float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const float f = s_m[w] == -INFINITY ? 0.f : expf(s_m[w] - M);
+    const float4 t = s_acc[w][dl];
+    S += s_s[w] * f;
+    o4.x += t.x * f; o4.y += t.y * f; o4.z += t.z * f; o4.w += t.w * f;
+  }
+  const float inv = 1.f / S;
+  if (v_new) {
+    const int64_t rowp = (int64_t)(nkeys - 1) * N + n;
+    *reinterpret_cast<float4*>(vpool_w + rowp * ldkv + doff) = *reinterpret_cast<const float4*>(vlast);
+    *reinterpret_cast<float4*>(kpool_w + rowp * ldkv + doff) = *reinterpret_cast<const float4*>(k_new + (int64_t)n * ldq + doff);
+  }
+  *reinterpret_cast<float4*>(out + (int64_t)n * ldo + doff) = make_float4(o4.x * inv, o4.y * inv, o4.z * inv, o4.w * inv);
+}
+
 // kpool/vpool row (step * N + n) = this step's key / value of hypothesis n; step read from device memory so that one
 // captured graph serves every step of the search (steps past the pool are dropped)
 __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict__ k, const float* __restrict__ v, int64_t ld_src,
@@ -363,44 +468,11 @@ __global__ __launch_bounds__(256) void beam_combine_kernel(const float* __restri
     if ((int)cand[(int64_t)n * C + c] == eos) psi_abs[(int64_t)n * C + c] = eos_abs[n];
 }
 
-// beam_combine and the top-k behind it in one launch, one workgroup per utterance: the K x V weighted scores of its beam slots
-// go to LDS (and to `weighted` when given), then K rounds of a wave arg-max pick the K best (slot * V + token) in descending
-// order - among equal scores the lower index first.  Replaces torch.topk's two launches (gather + sort, 25 us of a 130 us tail).
-constexpr int kTopkMax = 8192;
-__global__ __launch_bounds__(1024) void beam_combine_topk_kernel(const float* __restrict__ full, const int64_t* __restrict__ cand,
-                                                                const float* __restrict__ psi, float* __restrict__ psi_abs,
-                                                                const float* __restrict__ eos_s, const float* __restrict__ eos_abs,
-                                                                const float* __restrict__ s_prev, const float* __restrict__ score,
-                                                                float* __restrict__ weighted, float* __restrict__ top_s,
-                                                                int64_t* __restrict__ top_i, int K, int V, int C, int eos,
-                                                                float w_ctc) {
-  __shared__ float s_w[kTopkMax];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int u = blockIdx.x;
-  for (int k = wave; k < K; k += 16) {      // (16 waves: every beam slot of the usual widths has a wave of its own)
-    const int n = u * K + k;
-    const float base = -10000000000.0f - s_prev[n], es = eos_s[n], sc = score[n];
-    for (int v = lane; v < V; v += 64) {
-      float cf = v == eos ? es : base;
-      for (int c = 0; c < C; ++c)
-        if ((int)cand[(int64_t)n * C + c] == v) cf = v == eos ? es : psi[(int64_t)n * C + c];
-      {
-#pragma clang fp contract(off)
-        const float prod = w_ctc * cf;
-        const float sum = full[(int64_t)n * V + v] + prod;
-        const float wv = sum + sc;
-        s_w[k * V + v] = wv;
-        if (weighted) weighted[(int64_t)n * V + v] = wv;
-      }
-    }
-    for (int c = lane; c < C; c += 64)
-      if ((int)cand[(int64_t)n * C + c] == eos) psi_abs[(int64_t)n * C + c] = eos_abs[n];
-  }
-  __syncthreads();
-  const int KV = K * V;
-  if (wave != 0) return;
-  // the selection is one wave's work: up to 16 scores per lane in registers (K V <= 1024; the rest stay in LDS), a round is an
-  // arg-max over the lane's own values and six shuffle steps - no workgroup barrier inside the K rounds
+// K rounds of a wave arg-max over the K V weighted scores of one utterance (in LDS): the K best (slot * V + token) in descending order,
+// among equal scores the lower index first.  One wave's work: up to 16 scores per lane in registers (K V <= 1024; the rest stay in
+// LDS), a round is an arg-max over the lane's own values and the lane-network reductions - no workgroup barrier inside the rounds.
+__device__ __forceinline__ void beam_topk_rounds(float* s_w, int KV, int K, int u, float* __restrict__ top_s,
+                                                 int64_t* __restrict__ top_i, int lane) {
   constexpr int RG = 16;
   float xv[RG];
 #pragma unroll
@@ -442,6 +514,111 @@ __global__ __launch_bounds__(1024) void beam_combine_topk_kernel(const float* __
       }
     }
   }
+}
+
+// beam_combine and the top-k behind it in one launch, one workgroup per utterance: the K x V weighted scores of its beam slots
+// go to LDS (and to `weighted` when given), then K rounds of a wave arg-max pick the K best (slot * V + token) in descending
+// order - among equal scores the lower index first.  Replaces torch.topk's two launches (gather + sort, 25 us of a 130 us tail).
+constexpr int kTopkMax = 8192;
+__global__ __launch_bounds__(1024) void beam_combine_topk_kernel(const float* __restrict__ full, const int64_t* __restrict__ cand,
+                                                                const float* __restrict__ psi, float* __restrict__ psi_abs,
+                                                                const float* __restrict__ eos_s, const float* __restrict__ eos_abs,
+                                                                const float* __restrict__ s_prev, const float* __restrict__ score,
+                                                                float* __restrict__ weighted, float* __restrict__ top_s,
+                                                                int64_t* __restrict__ top_i, int K, int V, int C, int eos,
+                                                                float w_ctc) {
+  __shared__ float s_w[kTopkMax];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int u = blockIdx.x;
+  for (int k = wave; k < K; k += 16) {      // (16 waves: every beam slot of the usual widths has a wave of its own)
+    const int n = u * K + k;
+    const float base = -10000000000.0f - s_prev[n], es = eos_s[n], sc = score[n];
+    for (int v = lane; v < V; v += 64) {
+      float cf = v == eos ? es : base;
+      for (int c = 0; c < C; ++c)
+        if ((int)cand[(int64_t)n * C + c] == v) cf = v == eos ? es : psi[(int64_t)n * C + c];
+      {
+#pragma clang fp contract(off)
+        const float prod = w_ctc * cf;
+        const float sum = full[(int64_t)n * V + v] + prod;
+        const float wv = sum + sc;
+        s_w[k * V + v] = wv;
+        if (weighted) weighted[(int64_t)n * V + v] = wv;
+      }
+    }
+    for (int c = lane; c < C; c += 64)
+      if ((int)cand[(int64_t)n * C + c] == eos) psi_abs[(int64_t)n * C + c] = eos_abs[n];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  beam_topk_rounds(s_w, K * V, K, u, top_s, top_i, lane);
+}
+
+// The whole beam update behind the scorers in ONE launch, for vocabularies of up to 64 tokens (character models) whose CTC prefix
+// scores were computed for EVERY token beside the scorers (tavsr_ctc_prefix_step with the identity candidate list, on its own
+// queue: the recursion over the frames - 20 us - leaves the step's critical path).  One workgroup per utterance, wave k = beam slot k,
+// lane v = token v:
+//   full = dec + w_lm log_softmax(z_lm) + add                                  (tavsr_log_softmax_rows' accumulate form, same arithmetic)
+//   pre-beam: the C best tokens of full (descending, lower index first)        (espnet pre_beam on the weighted full scores)
+//   weighted = full + w_ctc * (v == eos ? eos_s : in pre-beam ? psi_all[v] : -1e10 - s_prev) + score      (tavsr_beam_combine)
+//   top-K over the K x V weighted scores                                        (tavsr_beam_combine_topk)
+// Same values, bit for bit, as those launches in sequence; psi_abs_all[n][eos] = eos_abs[n] (the state stored for an <eos> extension).
+__global__ __launch_bounds__(1024) void beam_select_topk_kernel(const float* __restrict__ dec, const float* __restrict__ z_lm,
+                                                               float w_lm, float add, const float* __restrict__ psi_all,
+                                                               float* __restrict__ psi_abs_all, const float* __restrict__ eos_s,
+                                                               const float* __restrict__ eos_abs, const float* __restrict__ s_prev,
+                                                               const float* __restrict__ score, float* __restrict__ full_out,
+                                                               float* __restrict__ weighted, int64_t* __restrict__ cand_out,
+                                                               float* __restrict__ top_s, int64_t* __restrict__ top_i, int K, int V,
+                                                               int C, int eos, float w_ctc) {
+  __shared__ float s_w[16 * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int u = blockIdx.x;
+  if (wave < K) {
+    const int n = u * K + wave;
+    const bool in = lane < V;
+    float f = in ? dec[(int64_t)n * V + lane] : -INFINITY;
+    if (z_lm) {                    // log_softmax_rows_kernel with alpha = w_lm, accumulate, add - one element per lane
+      const float x = in ? z_lm[(int64_t)n * V + lane] : -INFINITY;
+      const float mx = wave_max(x);
+      const float sm = wave_sum(in ? expf(x - mx) : 0.f);
+      const float lse = mx + logf(sm);
+      if (in) {
+        float v = x - lse;
+        if (w_lm != 1.f) v *= w_lm;
+        v = f + v;
+        if (add != 0.f) v += add;
+        f = v;
+      }
+    }
+    if (full_out && in) full_out[(int64_t)n * V + lane] = f;
+    // pre-beam: C rounds of the wave's arg-max (ctc_prefix_topk_kernel's selection with the row in one register per lane)
+    bool taken = false;
+    for (int c = 0; c < C; ++c) {
+      const float mine = (in && !taken) ? f : -INFINITY;
+      const float m = wave_max_dpp(mine);
+      int bi = wave_min_dpp((in && !taken && mine == m) ? lane : 0x7fffffff);
+      if (bi == 0x7fffffff) bi = 0;
+      if (bi == lane) taken = true;
+      if (cand_out && lane == 0) cand_out[(int64_t)n * C + c] = bi;
+    }
+    if (in) {
+      const float base = -10000000000.0f - s_prev[n], es = eos_s[n], sc = score[n];
+      const float cf = lane == eos ? es : (taken ? psi_all[(int64_t)n * V + lane] : base);
+      {
+#pragma clang fp contract(off)
+        const float prod = w_ctc * cf;
+        const float sum = f + prod;
+        const float wv = sum + sc;
+        s_w[wave * V + lane] = wv;
+        if (weighted) weighted[(int64_t)n * V + lane] = wv;
+      }
+      if (lane == eos) psi_abs_all[(int64_t)n * V + lane] = eos_abs[n];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  beam_topk_rounds(s_w, K * V, K, u, top_s, top_i, lane);
 }
 
 // After the top-k over (beam slot, token) of every utterance (top_i [U][K] = slot * V + token): hypothesis n extends slot
@@ -516,12 +693,13 @@ struct RowLinArgs {
   const float* W; int64_t ldw; const float* bias;
   const float* res; int64_t ldr; float* out; int64_t ldo;
   int N, K, Nout, act;
+  const int64_t* rgather;       // residual rows by index (the LM's input-table rows as the residual of layer 0's output projection)
   // rows held as a SUM of tensors (tavsr_rowlin_parts): x = sum_p x[p * xps ..], res likewise; gridDim.y > 1: block y owns a K
   // slice and writes partial tensor y of the output (stride ops) - the next launch of the chain adds them while it loads
   int xparts; int64_t xps; int rparts; int64_t rps; int64_t ops;
 };
 
-template <int R, int WPB, int KW>
+template <int R, int WPB, int KW, bool LN>      // LN: LayerNorm prologue compiled in (its gamma / beta operands are 2 KW / G more registers)
 __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
   constexpr int G = 64 / R;                 // lane groups along k
   constexpr int NJ = KW / (4 * G);          // float4 loads per operand per lane
@@ -542,6 +720,25 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
   for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(wr + 4 * G * j);
 #pragma unroll
   for (int j = 0; j < NJ; ++j) av[j] = *reinterpret_cast<const float4*>(xr + 4 * G * j);
+  // the epilogue's operands (bias, up to four residual parts) of this thread's FIRST output element are requested now, with the
+  // tiles: they used to be a second, dependent round trip to memory behind the last barrier (~1 us of a ~5 us launch)
+  constexpr int PRE = 4;
+  float pre_b = 0.f, pre_r[PRE] = {0.f, 0.f, 0.f, 0.f};
+  bool pre_ok = false;
+  if (threadIdx.x < R * R && blockIdx.y == 0) {
+    const int q0 = threadIdx.x >> 6, l0 = threadIdx.x & 63;
+    const int rw0 = R == 32 ? (q0 & 3) + 8 * (q0 >> 2) + 4 * (l0 >> 5) : 4 * (l0 >> 4) + q0;
+    const int c0 = col0 + (l0 & (R - 1));
+    if (rw0 < a.N && c0 < a.Nout) {
+      pre_ok = true;
+      if (a.bias) pre_b = a.bias[c0];
+      if (a.res) {
+#pragma unroll
+        for (int p = 0; p < PRE; ++p)
+          if (p < a.rparts) pre_r[p] = a.res[p * a.rps + (a.rgather ? a.rgather[rw0] : (int64_t)rw0) * a.ldr + c0];
+      }
+    }
+  }
   for (int p = 1; p < a.xparts; ++p) {      // the rows arrive as a sum of partial tensors (same order every time)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -549,38 +746,49 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
       av[j].x += t.x; av[j].y += t.y; av[j].z += t.z; av[j].w += t.w;
     }
   }
-  if (a.gamma) {
+  if constexpr (LN) {
     float4 gv[NJ], ev[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       gv[j] = *reinterpret_cast<const float4*>(a.gamma + kb + 4 * G * j);
       ev[j] = *reinterpret_cast<const float4*>(a.beta + kb + 4 * G * j);
     }
+    // Row statistics with ONE workgroup barrier: every wave reduces its own K slice to (mean, sum of squared deviations from
+    // that mean) on the lane network, the WPB pairs meet in LDS and are merged by the equal-count form of Chan's update,
+    //   mean = avg_w mean_w,   K var = sum_w M2_w + KW sum_w (mean_w - mean)^2
+    // - the deviations are taken from a mean, never from raw second moments (no cancellation), and the second barrier + LDS round
+    // of a global two-pass form is gone (1.3 us of a 4.9 us launch went into the statistics).
     float sm = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) sm += (av[j].x + av[j].y) + (av[j].z + av[j].w);
 #pragma unroll
     for (int o = R; o < 64; o <<= 1) sm += __shfl_xor(sm, o, 64);
-    if (g == 0) s_red[0][wave][r] = sm;
+    const float mw = sm * (1.f / (float)KW);
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float dx = av[j].x - mw, dy = av[j].y - mw, dz = av[j].z - mw, dw = av[j].w - mw;
+      sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+#pragma unroll
+    for (int o = R; o < 64; o <<= 1) sq += __shfl_xor(sq, o, 64);
+    if (g == 0) { s_red[0][wave][r] = mw; s_red[1][wave][r] = sq; }
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
     for (int w = 0; w < WPB; ++w) mean += s_red[0][w][r];
-    mean /= (float)a.K;
-    float sq = 0.f;
+    mean *= 1.f / (float)WPB;
+    float var = 0.f, dm2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      av[j].x -= mean; av[j].y -= mean; av[j].z -= mean; av[j].w -= mean;
-      sq += (av[j].x * av[j].x + av[j].y * av[j].y) + (av[j].z * av[j].z + av[j].w * av[j].w);
+    for (int w = 0; w < WPB; ++w) {
+      const float d = s_red[0][w][r] - mean;
+      var += s_red[1][w][r];
+      dm2 += d * d;
     }
-#pragma unroll
-    for (int o = R; o < 64; o <<= 1) sq += __shfl_xor(sq, o, 64);
-    if (g == 0) s_red[1][wave][r] = sq;
-    __syncthreads();
-    float var = 0.f;
-#pragma unroll
-    for (int w = 0; w < WPB; ++w) var += s_red[1][w][r];
+    var += (float)KW * dm2;
     const float rstd = rsqrtf(var / (float)a.K + a.eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { av[j].x -= mean; av[j].y -= mean; av[j].z -= mean; av[j].w -= mean; }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       av[j].x = av[j].x * rstd * gv[j].x + ev[j].x;
@@ -620,48 +828,58 @@ __global__ __launch_bounds__(WPB * 64) void rowlin_kernel(RowLinArgs a) {
     for (int w = 0; w < WPB; ++w) v += s_acc[w][q][l];
     if (rw < a.N && c < a.Nout) {
       if (blockIdx.y == 0) {          // (a K slice other than the first carries neither bias nor residual; no activation when split)
-        if (a.bias) v += a.bias[c];
+        const bool pre = pre_ok && o == (int)threadIdx.x;      // the element whose operands came with the tiles
+        if (a.bias) v += pre ? pre_b : a.bias[c];
         v = act_fwd(a.act, v);
-        if (a.res)
-          for (int p = 0; p < a.rparts; ++p) v += a.res[p * a.rps + (int64_t)rw * a.ldr + c];
+        if (a.res) {
+          int p0 = 0;
+          if (pre) {                  // same order of additions as the loop below (parts 0, 1, 2, ...)
+#pragma unroll
+            for (int p = 0; p < PRE; ++p)
+              if (p < a.rparts) v += pre_r[p];
+            p0 = PRE;
+          }
+          for (int p = p0; p < a.rparts; ++p) v += a.res[p * a.rps + (a.rgather ? a.rgather[rw] : (int64_t)rw) * a.ldr + c];
+        }
       }
       a.out[blockIdx.y * a.ops + (int64_t)rw * a.ldo + c] = v;
     }
   }
 }
 
-static int g_rowlin_cfg = 0;      // tavsr_rowlin_tune: 0 = the plan below; 1 = half the waves, twice the k per wave (tuning runs)
-
+// Launch plan.  Every variant fits its registers (no scratch: a spilled operand is a second trip to memory in a kernel whose whole
+// point is ONE): blocks of at most 8 waves (two per SIMD: 256 VGPRs each), K = waves x KW.
+//   R = 16 rows: K 64 .. 512 as K / 64 waves of 64; 1024 as 8 x 128; 2048 as 8 x 256 (no LayerNorm there: its gamma / beta would
+//                be 128 registers more - K = 2048 is the projection that closes a feed-forward block);
+//   R = 32 rows: K 64 .. 512 as K / 64 waves of 64; 1024 as 8 x 128 without LayerNorm; 2048 only in K slices (tavsr_rowlin_parts);
+//   K slices of 256 / 512 / 1024: the plans above (a slice carries no LayerNorm).
+#define TAVSR_ROWLIN_GO(RR, W, KWW, LNN) \
+  do { hipLaunchKernelGGL((rowlin_kernel<RR, W, KWW, LNN>), grid, dim3(W * 64), 0, st, a); return true; } while (0)
 template <int R>
 static bool rowlin_launch(const RowLinArgs& a, hipStream_t st, int ksplit = 1) {
   const dim3 grid((unsigned)((a.Nout + R - 1) / R), (unsigned)ksplit);
-  if (ksplit > 1) {
-    switch (a.K / ksplit) {      // K of one slice
-      case 256: hipLaunchKernelGGL((rowlin_kernel<R, 4, 64>), grid, dim3(256), 0, st, a); return true;
-      case 512: hipLaunchKernelGGL((rowlin_kernel<R, 8, 64>), grid, dim3(512), 0, st, a); return true;
-      case 1024: hipLaunchKernelGGL((rowlin_kernel<R, 16, 64>), grid, dim3(1024), 0, st, a); return true;
+  const int Ks = a.K / ksplit;      // K of one block
+  if (a.gamma) {
+    switch (Ks) {
+      case 64: TAVSR_ROWLIN_GO(R, 1, 64, true);
+      case 128: TAVSR_ROWLIN_GO(R, 2, 64, true);
+      case 256: TAVSR_ROWLIN_GO(R, 4, 64, true);
+      case 512: TAVSR_ROWLIN_GO(R, 8, 64, true);
+      case 1024: if constexpr (R == 16) TAVSR_ROWLIN_GO(16, 8, 128, true); else return false;
       default: return false;
     }
   }
-  if (g_rowlin_cfg == 1) {
-    switch (a.K) {
-      case 256: hipLaunchKernelGGL((rowlin_kernel<R, 2, 128>), grid, dim3(128), 0, st, a); return true;
-      case 512: hipLaunchKernelGGL((rowlin_kernel<R, 4, 128>), grid, dim3(256), 0, st, a); return true;
-      case 1024: hipLaunchKernelGGL((rowlin_kernel<R, 8, 128>), grid, dim3(512), 0, st, a); return true;
-      case 2048: hipLaunchKernelGGL((rowlin_kernel<R, 8, 256>), grid, dim3(512), 0, st, a); return true;
-      default: break;
-    }
-  }
-  switch (a.K) {
-    case 64: hipLaunchKernelGGL((rowlin_kernel<R, 1, 64>), grid, dim3(64), 0, st, a); return true;
-    case 128: hipLaunchKernelGGL((rowlin_kernel<R, 2, 64>), grid, dim3(128), 0, st, a); return true;
-    case 256: hipLaunchKernelGGL((rowlin_kernel<R, 4, 64>), grid, dim3(256), 0, st, a); return true;
-    case 512: hipLaunchKernelGGL((rowlin_kernel<R, 8, 64>), grid, dim3(512), 0, st, a); return true;
-    case 1024: hipLaunchKernelGGL((rowlin_kernel<R, 16, 64>), grid, dim3(1024), 0, st, a); return true;
-    case 2048: hipLaunchKernelGGL((rowlin_kernel<R, 16, 128>), grid, dim3(1024), 0, st, a); return true;
+  switch (Ks) {
+    case 64: TAVSR_ROWLIN_GO(R, 1, 64, false);
+    case 128: TAVSR_ROWLIN_GO(R, 2, 64, false);
+    case 256: TAVSR_ROWLIN_GO(R, 4, 64, false);
+    case 512: TAVSR_ROWLIN_GO(R, 8, 64, false);
+    case 1024: TAVSR_ROWLIN_GO(R, 8, 128, false);
+    case 2048: if constexpr (R == 16) TAVSR_ROWLIN_GO(16, 8, 256, false); else return false;
     default: return false;
   }
 }
+#undef TAVSR_ROWLIN_GO
 
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -681,23 +899,36 @@ extern "C" int tavsr_act_fwd(const float* x, float* y, int64_t n, int32_t act, t
 }
 
 
+// which (rows, K, LayerNorm, K slices) combinations have a one-launch plan (rowlin_launch): the host asks before it routes a step here
+extern "C" int tavsr_rowlin_ok(int32_t N, int32_t K, int32_t with_ln, int32_t ksplit) {
+  if (N < 0 || N > 32 || ksplit < 1 || ksplit > 16 || K <= 0 || K % ksplit) return 0;
+  const int Ks = K / ksplit;
+  if (ksplit > 1) return !with_ln && (Ks == 256 || Ks == 512 || Ks == 1024);
+  if (with_ln) return Ks == 64 || Ks == 128 || Ks == 256 || Ks == 512 || (Ks == 1024 && N <= 16);
+  return Ks == 64 || Ks == 128 || Ks == 256 || Ks == 512 || Ks == 1024 || (Ks == 2048 && N <= 16);
+}
+
 extern "C" int tavsr_rowlin(const float* x, int64_t ldx, const int64_t* gather, const float* gamma, const float* beta, float eps,
                             const float* W, int64_t ldw, const float* bias, int32_t act, const float* res, int64_t ldr,
-                            float* out, int64_t ldo, int32_t N, int32_t K, int32_t Nout, tavsr_stream_t stream) {
+                            const int64_t* res_gather, float* out, int64_t ldo, int32_t N, int32_t K, int32_t Nout,
+                            tavsr_stream_t stream) {
   TAVSR_REQUIRE(x && W && out, TAVSR_EINVAL, "rowlin: null pointer");
   TAVSR_REQUIRE((gamma == nullptr) == (beta == nullptr), TAVSR_EINVAL, "rowlin: gamma and beta go together");
   TAVSR_REQUIRE(N <= 32, TAVSR_EUNSUPPORTED, "rowlin: at most 32 rows (got %d): larger steps go through tavsr_gemm", N);
   TAVSR_REQUIRE(K == 64 || K == 128 || K == 256 || K == 512 || K == 1024 || K == 2048, TAVSR_EUNSUPPORTED,
                 "rowlin: K in {64, 128, 256, 512, 1024, 2048} (got %d)", K);
-  TAVSR_REQUIRE(!gamma || K <= 1024, TAVSR_EUNSUPPORTED, "rowlin: LayerNorm prologue up to K = 1024");
+  TAVSR_REQUIRE(tavsr_rowlin_ok(N, K, gamma != nullptr, 1), TAVSR_EUNSUPPORTED,
+                "rowlin: no one-launch plan for %d rows, K = %d%s (tavsr_rowlin_ok; K = 2048 with more than 16 rows goes through "
+                "tavsr_rowlin_parts in K slices)", N, K, gamma ? " with LayerNorm" : "");
   TAVSR_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)x | (uintptr_t)W) & 15) == 0 &&
                     (!gamma || (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
                 TAVSR_EALIGN, "rowlin: rows of x / W (and gamma / beta) must be 16-byte aligned");
   TAVSR_REQUIRE(out != x, TAVSR_EINVAL, "rowlin: out must not alias x");
   if (N <= 0 || Nout <= 0) return TAVSR_OK;
-  RowLinArgs a{x, ldx, gather, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act, 1, 0, 1, 0, 0};
-  if (N <= 16) rowlin_launch<16>(a, (hipStream_t)stream);
-  else rowlin_launch<32>(a, (hipStream_t)stream);
+  TAVSR_REQUIRE(!res_gather || res != out, TAVSR_EINVAL, "rowlin: a gathered residual must not alias out");
+  RowLinArgs a{x, ldx, gather, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act, res_gather, 1, 0, 1, 0, 0};
+  const bool ok = N <= 16 ? rowlin_launch<16>(a, (hipStream_t)stream) : rowlin_launch<32>(a, (hipStream_t)stream);
+  TAVSR_REQUIRE(ok, TAVSR_EUNSUPPORTED, "rowlin: no kernel for K = %d, %d rows", K, N);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }
@@ -723,13 +954,15 @@ extern "C" int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, 
     TAVSR_REQUIRE(K == 64 || K == 128 || K == 256 || K == 512 || K == 1024 || K == 2048, TAVSR_EUNSUPPORTED,
                   "rowlin_parts: K in {64, 128, 256, 512, 1024, 2048} (got %d)", K);
   }
-  TAVSR_REQUIRE(!gamma || K <= 1024, TAVSR_EUNSUPPORTED, "rowlin_parts: LayerNorm prologue up to K = 1024");
+  TAVSR_REQUIRE(tavsr_rowlin_ok(N, K, gamma != nullptr, ksplit), TAVSR_EUNSUPPORTED,
+                "rowlin_parts: no one-launch plan for %d rows, K = %d in %d slice(s)%s (tavsr_rowlin_ok)", N, K, ksplit,
+                gamma ? " with LayerNorm" : "");
   TAVSR_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)x | (uintptr_t)W) & 15) == 0 &&
                     (!gamma || (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
                 TAVSR_EALIGN, "rowlin_parts: rows of x / W (and gamma / beta) must be 16-byte aligned");
   TAVSR_REQUIRE(out != x, TAVSR_EINVAL, "rowlin_parts: out must not alias x");
   if (N <= 0 || Nout <= 0) return TAVSR_OK;
-  RowLinArgs a{x, ldx, nullptr, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act,
+  RowLinArgs a{x, ldx, nullptr, gamma, beta, eps, W, ldw, bias, res, ldr, out, ldo, N, K, Nout, act, nullptr,
                x_parts, x_pstride, res_parts, res_pstride, out_pstride};
   const bool ok = N <= 16 ? rowlin_launch<16>(a, (hipStream_t)stream, ksplit) : rowlin_launch<32>(a, (hipStream_t)stream, ksplit);
   TAVSR_REQUIRE(ok, TAVSR_EUNSUPPORTED, "rowlin_parts: no kernel for K = %d in %d slices", K, ksplit);
@@ -737,17 +970,16 @@ extern "C" int tavsr_rowlin_parts(const float* x, int64_t ldx, int32_t x_parts, 
   return TAVSR_OK;
 }
 
-static int g_tree_wpb4 = 0;
-extern "C" int tavsr_tree_attn_tune(int32_t wpb4) {      // tuning aid: 1 = always four items per workgroup
-  g_tree_wpb4 = wpb4 ? 1 : 0;
+// tuning / test aid: how a SMALL step (N H <= 256 items) is launched - 3: the plan (by history length: 0 for long ones, else 1);
+// 0: four waves per item, keys dealt to the waves; 1: one wave per item, one item per workgroup; 2: one wave per item, four items per
+// workgroup (large steps' plan)
+static int g_tree_mode = 3;
+extern "C" int tavsr_tree_attn_tune(int32_t mode) {
+  TAVSR_REQUIRE(mode >= 0 && mode <= 3, TAVSR_EINVAL, "tree_attn_tune: 0 .. 3");
+  g_tree_mode = mode;
   return TAVSR_OK;
 }
 
-extern "C" int tavsr_rowlin_tune(int32_t cfg) {      // tuning aid (scripts/rowlin_bench.py), not part of the product ABI
-  TAVSR_REQUIRE(cfg >= 0 && cfg <= 1, TAVSR_EINVAL, "rowlin_tune: 0 or 1");
-  g_rowlin_cfg = cfg;
-  return TAVSR_OK;
-}
 
 extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kpool, const float* vpool, int64_t ldkv,
                                     const int32_t* anc, int64_t ld_anc, int32_t nkeys, float* out, int64_t ldo, int32_t N,
@@ -763,8 +995,22 @@ extern "C" int tavsr_tree_attn_step(const float* q, int64_t ldq, const float* kp
   TAVSR_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)q | (uintptr_t)out | (uintptr_t)vpool | (uintptr_t)k_new | (uintptr_t)v_new) & 15) == 0,
                 TAVSR_EALIGN, "tree_attn_step: q / out / k_new / v_new rows must be 16-byte aligned");
   if (group <= 0 || N % group != 0) group = 1;
+  // small steps with LONG histories: four waves per item, keys dealt to the waves (tree_attn_split_kernel).  Its time is flat in
+  // the keys (6.0 us at 1 key, 6.5 at 100, 10.1 at 300) where one wave per item grows (3.9 / 7.1 / 13.8): it pays from ~65 keys.  A
+  // captured step is launched with its pool capacity as `nkeys` and sees every length up to it, so the choice goes by half of that.
+  if (N * H <= 256 && (g_tree_mode == 0 || (g_tree_mode == 3 && (step_dev ? nkeys / 2 : nkeys) > 80))) {
+    const dim3 grid((unsigned)(N * H)), block(256);
+    if (dk <= 64)
+      hipLaunchKernelGGL(tree_attn_split_kernel<16>, grid, block, 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
+                         nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool), group);
+    else
+      hipLaunchKernelGGL(tree_attn_split_kernel<32>, grid, block, 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
+                         nkeys, out, ldo, N, H, dk, scale, step_dev, k_new, v_new, const_cast<float*>(kpool), const_cast<float*>(vpool), group);
+    TAVSR_LAUNCH_CHECK();
+    return TAVSR_OK;
+  }
   // few items (a batch-1 step: 10 hypotheses x 8 heads): one wave per workgroup - 80 CUs bring the rows in instead of 20
-  const int wpb = (N * H <= 256 && !g_tree_wpb4) ? 1 : 4;
+  const int wpb = (N * H <= 256 && g_tree_mode != 2) ? 1 : 4;      // (reached with mode 1, 2, or 3 and a short history)
   const dim3 grid((unsigned)((N * H + wpb - 1) / wpb)), block((unsigned)(64 * wpb));
   if (dk <= 64)
     hipLaunchKernelGGL(tree_attn_step_kernel<16>, grid, block, 0, (hipStream_t)stream, q, ldq, kpool, vpool, ldkv, anc, ld_anc,
@@ -857,6 +1103,23 @@ extern "C" int tavsr_beam_combine_topk(const float* full, const int64_t* cand, c
                 K, V);
   hipLaunchKernelGGL(beam_combine_topk_kernel, dim3((unsigned)(N / K)), dim3(1024), 0, (hipStream_t)stream, full, cand, psi, psi_abs,
                      eos_s, eos_abs, s_prev, score, weighted, top_s, top_i, K, V, C, eos, w_ctc);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+extern "C" int tavsr_beam_select_topk(const float* dec, const float* z_lm, float w_lm, float add, const float* psi_all, float* psi_abs_all,
+                                      const float* eos_s, const float* eos_abs, const float* s_prev, const float* score, float* full_out,
+                                      float* weighted, int64_t* cand_out, float* top_s, int64_t* top_i, int32_t N, int32_t K, int32_t V,
+                                      int32_t C, int32_t eos, float w_ctc, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(dec && psi_all && psi_abs_all && eos_s && eos_abs && s_prev && score && top_s && top_i, TAVSR_EINVAL,
+                "beam_select_topk: null pointer");
+  TAVSR_REQUIRE(N > 0 && K > 0 && N % K == 0 && V > 0 && K <= V && C > 0 && C <= V && eos >= 0 && eos < V, TAVSR_EINVAL,
+                "beam_select_topk: bad sizes");
+  TAVSR_REQUIRE(V <= 64 && K <= 16, TAVSR_EUNSUPPORTED,
+                "beam_select_topk: vocabularies of up to 64 tokens and beams of up to 16 (got %d, %d): tavsr_ctc_prefix_step_topk + "
+                "tavsr_beam_combine_topk take the rest", V, K);
+  hipLaunchKernelGGL(beam_select_topk_kernel, dim3((unsigned)(N / K)), dim3(1024), 0, (hipStream_t)stream, dec, z_lm, w_lm, add, psi_all,
+                     psi_abs_all, eos_s, eos_abs, s_prev, score, full_out, weighted, cand_out, top_s, top_i, K, V, C, eos, w_ctc);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

@@ -37,6 +37,35 @@ extern "C" int tavsr_spin(float us, tavsr_stream_t stream) {
   return TAVSR_OK;
 }
 
+// What does a dependent launch cost before it does anything?  kind 0: every thread returns; 1: every thread reads one float4 of
+// `buf` (element (block * threads + thread) % n4) and writes it back + 1 - one memory round trip and one store, the skeleton of
+// a one-token Linear; 2: the same with a workgroup barrier and a second dependent read (an epilogue operand).  Timed in a
+// captured chain by scripts/launch_floor.py at the grids of the search step.
+namespace tavsr {
+__global__ void probe_launch_kernel(int kind, float* buf, long long n4) {
+  if (kind == 0) return;
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) % n4;
+  float4 v = reinterpret_cast<const float4*>(buf)[i];
+  if (kind == 2) {
+    __syncthreads();
+    const long long j = (i + (long long)(v.x != 12345.f) * 977) % n4;
+    const float4 w = reinterpret_cast<const float4*>(buf)[j];
+    v.y += w.y;
+  }
+  v.x += 1.f;
+  reinterpret_cast<float4*>(buf)[i] = v;
+}
+}  // namespace tavsr
+
+extern "C" int tavsr_probe_launch(int32_t kind, int32_t grid, int32_t block, float* buf, int64_t n, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(kind >= 0 && kind <= 2 && grid > 0 && block > 0 && block <= 1024, TAVSR_EINVAL, "probe_launch: kind 0..2, block <= 1024");
+  TAVSR_REQUIRE(kind == 0 || (buf && n >= 4), TAVSR_EINVAL, "probe_launch: a buffer of at least 4 floats");
+  hipLaunchKernelGGL(tavsr::probe_launch_kernel, dim3((unsigned)grid), dim3((unsigned)block), 0, (hipStream_t)stream, kind, buf,
+                     (long long)(n / 4));
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
 extern "C" int tavsr_race_probe(float us, int mode) {
   TAVSR_REQUIRE(us >= 0.f && us <= 1e6f && mode >= 0 && mode <= 2, TAVSR_EINVAL, "race_probe: us in 0 .. 1e6, mode 0 / 1 / 2");
   tavsr::g_probe_us = us;

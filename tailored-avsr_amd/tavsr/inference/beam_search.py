@@ -72,32 +72,45 @@ FUSED_STEP = True
 SCORERS_PARALLEL = True   # decoder || LM on two streams (TAVSR_SINGLE_STREAM=1 disables every fork)
 TREE_GROUP = 1     # beams of an utterance side by side in the tree attention
 PREBEAM_FUSED = True   # pre-beam top-k inside the CTC prefix launch
+# Vocabularies of up to 64 tokens (character models): the CTC prefix scores of EVERY token are computed beside the LM's chain, in front
+# of the decoder's - the recursion over the frames (20 us) leaves the critical path of a captured step - and the whole beam update
+# behind the scorers (LM log-softmax, pre-beam, weighted scores, top-k) is one launch (tavsr_beam_select_topk).
+CTC_BESIDE_SCORERS = os.environ.get("TAVSR_DECODE_CTC_BESIDE", "1") != "0"
 
 
 def _ln_linear(x, norm, w, b, act=None):
     """act(W LN(x) + b): one launch (ops.rowlin) when the shapes allow, else LayerNorm + GEMM launches."""
-    if ops.rowlin_ok(x, w):
+    if ops.rowlin_ok(x, w, ln=True):
         return ops.rowlin(x, w, b, ln=(norm[0], norm[1], EPS), act=act)
+    if isinstance(x, ops.RowParts):
+        x = x.t.sum(0)
     n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
     return ops.linear(n, w, b, act=act)
 
 
 def _linear_res(x, w, b, res, ksplit=1):
-    """res + W x + b (``ksplit`` > 1, up to 16 rows: K dealt to that many blocks per column tile, the result an ``ops.RowParts``)."""
+    """res + W x + b (``ksplit`` > 1: K dealt to that many blocks per column tile, the result an ``ops.RowParts``; a K the one-launch
+    kernel only takes in slices - 2048 with more than 16 rows - is dealt to ``ops.ROWLIN_KSPLIT`` blocks whatever the caller asked)."""
+    if ksplit == 1 and not ops.rowlin_ok(x, w) and ops.rowlin_ok(x, w, ksplit=max(2, ops.ROWLIN_KSPLIT)):
+        ksplit = max(2, ops.ROWLIN_KSPLIT)
+    if ksplit > 1 and ops.rowlin_ok(x, w, ksplit=ksplit):
+        return ops.rowlin(x, w, b, res=res, ksplit=ksplit)
     if ops.rowlin_ok(x, w):
-        if ksplit > 1 and x.shape[0] <= 16 and x.shape[1] % ksplit == 0 and x.shape[1] // ksplit in (256, 512, 1024):
-            return ops.rowlin(x, w, b, res=res, ksplit=ksplit)
         return ops.rowlin(x, w, b, res=res)
+    if isinstance(res, ops.RowParts):
+        res = res.t.sum(0)
     return ops.linear(x, w, b, res=res)
 
 
 def _ffn_step(x, norm, L):
-    """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows.  Up to 16 rows, hidden size 2048:
-    the closing projection deals its K to ops.ROWLIN_KSPLIT blocks per column tile and the result stays a sum of that many tensors
+    """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows.  Hidden size 2048: the closing
+    projection deals its K to ops.ROWLIN_KSPLIT blocks per column tile and the result stays a sum of that many tensors
     (``ops.RowParts``) until the next launches of the chain add them while they load their operands."""
-    if ops.rowlin_ok(x, L["w1"]):
+    if ops.rowlin_ok(x, L["w1"], ln=True):
         t = ops.rowlin(x, L["w1"], L["b1"], ln=(norm[0], norm[1], EPS), act="relu")
         return _linear_res(t, L["w2"], L["b2"], x, ops.ROWLIN_KSPLIT if t.shape[1] == 2048 else 1)
+    if isinstance(x, ops.RowParts):
+        x = x.t.sum(0)
     n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
     t = ops.linear(n, L["w1"], L["b1"], act="relu")
     return ops.linear(t, L["w2"], L["b2"], res=x)
@@ -147,11 +160,13 @@ class _DecoderStep:
 
     def step(self, i, tok, anc, dyn=None, **score):
         """tok [N] last tokens, anc int32 [N, >= i+1] (column i already points at this step's rows) -> logp [N, V].
-        ``dyn`` = (step_dev, pe_row): the step index and its positional row come from device buffers (``i`` is then the
+        ``dyn`` = (step_dev,): the step index - and with it the positional row - is read from a device buffer (``i`` is then the
         pool capacity in steps), so the launches can be captured once and replayed for every step."""
         N, D, H, dk, U, T, K = self.N, self.D, self.H, self.dk, self.U, self.T, self.K
-        pe = self.pe[i:i + 1].contiguous() if dyn is None else dyn[1]
-        x = ops.embed_pe(tok.view(N, 1), self.emb, pe, self.xscale).view(N, D)
+        if dyn is None:
+            x = ops.embed_pe(tok.view(N, 1), self.emb, self.pe[i:i + 1].contiguous(), self.xscale).view(N, D)
+        else:      # the positional row of the device-side step counter: read by the embedding launch itself
+            x = ops.embed_pe(tok.view(N, 1), self.emb, self.pe, self.xscale, step_dev=dyn[0]).view(N, D)
         for li, L in enumerate(self.layers):
             qkv = _ln_linear(x, L["n1"], L["wqkv"], L["bqkv"])
             # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
@@ -231,14 +246,23 @@ class _LMStep:
     def step(self, i, tok, anc, dyn=None, logits_only=False, **score):
         N, D, H, dk = self.N, self.D, self.H, self.dk
         lm = self.lm
-        h = self.in_table.index_select(0, tok)
+        # the token's row of the input table is gathered by the first layer's launches themselves where the one-launch Linear
+        # runs (its ``gather`` / ``res_gather`` operands): no gather launch at the head of the LM's chain
+        fold = ops.rowlin_ok(self.in_table, self.layers[0]["wqkv"], n_rows=N, ln=True)
+        h = None if fold else self.in_table.index_select(0, tok)
         for li, L in enumerate(self.layers):
-            qkv = _ln_linear(h, L["n1"], L["wqkv"], L["bqkv"])
+            if li == 0 and fold:
+                qkv = ops.rowlin(self.in_table, L["wqkv"], L["bqkv"], ln=(L["n1"][0], L["n1"][1], EPS), gather=tok)
+            else:
+                qkv = _ln_linear(h, L["n1"], L["wqkv"], L["bqkv"])
             # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
             a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
                                    step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:],
                                    group=TREE_GROUP * self.K)
-            h = _linear_res(a, L["wo"], L["bo"], h)
+            if li == 0 and fold:
+                h = ops.rowlin(a, L["wo"], L["bo"], res=self.in_table, res_gather=tok)
+            else:
+                h = _linear_res(a, L["wo"], L["bo"], h)
             h = _ffn_step(h, L["n2"], L)
         z = _ln_linear(h, (lm.encoder.after_norm.weight, lm.encoder.after_norm.bias), lm.decoder.weight, lm.decoder.bias)
         return z if logits_only else ops.log_softmax_rows(z, **score)
@@ -350,16 +374,30 @@ class BatchBeamSearch:
                 # (hypotheses that ended with the previous token - <eos>, or their utterance's last iteration - have left the beam
                 # and column `step` of the ancestor lists is filled: the previous step's re-ordering launch did both, reset_state()
                 # for step 0)
-                sdyn = (dyn["step"], self.dec_step.pe.index_select(0, dyn["step64"]))
+                sdyn = (dyn["step"],)
             # full = w_dec * decoder + w_lm * lm + w_len (LengthBonus: 1 per token), summed by the scorers' last launches
             # the two scorers are independent chains of small launches: the LM runs on the side stream next to the decoder
             has_lm = self.lm_step is not None
+            spec = dyn is not None and CTC_BESIDE_SCORERS and ops.beam_select_topk_ok(K, V) and C <= V
             if has_lm:
                 with ops.BranchScope(enabled=SCORERS_PARALLEL) as br:
                     z_lm = self.lm_step.step(i, tok, anc, sdyn, logits_only=True)
+            if spec:
+                # on the decoder's queue, in front of its chain: the decoder has ~100 us of slack behind the LM (a third queue for it
+                # made the whole step 45 us SLOWER: profiles/r05_notes.md)
+                r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, dyn["cand_all"], K, i,
+                                                                          step_dev=dyn["step"])
             full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
             if has_lm:
                 br.join()
+            if spec:
+                top_s, top_i = ops.beam_select_topk(full, z_lm if has_lm else None, self.w_lm, self.w_len if has_lm else 0.0, psi, psi_abs,
+                                                    eos_s, eos_abs, s_prev, score, self.eos, self.w_ctc, K, C)
+                ops.beam_reorder(top_i, top_s, dyn["cand_all"], r_new, psi_abs, yseq, anc, dyn["shadow"], K, V, dyn["step"],
+                                 hist=dyn["hist"], maxlen=dyn["maxl"], eos=self.eos)
+                ops.multi_copy_([r_prev, s_prev, yseq, anc, tok, score], list(dyn["shadow"]), inc=dyn["ctr"])
+                return anc, tok
+            if has_lm:
                 ops.log_softmax_rows(z_lm, out=full, alpha=self.w_lm, add=self.w_len, accumulate=True)
             if PREBEAM_FUSED and C <= 64 and V <= 4096:            # pre-beam on the weighted full scores inside the CTC launch
                 cand, r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step_topk(
@@ -430,6 +468,7 @@ class BatchBeamSearch:
             dyn = dict(ctr=ctr, step64=ctr[0:1], stepp1=ctr[1:2], step=ctr.view(torch.int32)[0:1],     # (low word: little endian)
                        maxl=torch.tensor(maxl_h, dtype=torch.int32, device=dev),
                        hist=torch.zeros(steps, 3, N, dtype=torch.int32, device=dev),
+                       cand_all=torch.arange(V, dtype=torch.int64, device=dev).repeat(N, 1),      # every token a "candidate" of the CTC scorer
                        shadow=(torch.empty_like(r_prev), torch.empty_like(s_prev), torch.empty_like(yseq), torch.empty_like(anc),
                                torch.empty_like(tok), torch.empty_like(score)))
             side = torch.cuda.Stream()

@@ -244,10 +244,10 @@ def forks_enabled() -> bool:
     return not L.SINGLE_STREAM
 
 
-def branch_stream(main: torch.cuda.Stream) -> torch.cuda.Stream:
-    """the side stream that belongs to ``main`` (one per forking stream, so nested forks never share a stream with
-    their siblings)."""
-    key = (main.device.index, main.cuda_stream)
+def branch_stream(main: torch.cuda.Stream, slot: int = 0) -> torch.cuda.Stream:
+    """the side stream that belongs to ``main`` (one per forking stream and ``slot``, so nested forks never share a stream with
+    their siblings; ``slot`` > 0: a further side stream of the same owner, for a second section that runs beside the first)."""
+    key = (main.device.index, main.cuda_stream, slot)
     s = _BRANCH.get(key)
     if s is None:
         s = _BRANCH[key] = torch.cuda.Stream(device=main.device)
@@ -295,15 +295,16 @@ class BranchScope:
     to a later body, which starts with a wait on the main stream, so main-stream readers enqueued before that are always
     finished.  Capturable (fork/join inside one hipGraph capture)."""
 
-    def __init__(self, enabled=True):
+    def __init__(self, enabled=True, slot=0):
         self.enabled = enabled and forks_enabled()
+        self.slot = slot              # which of the owner's side streams (two scopes open at once take different slots)
         self.on = False               # (join() of a scope that was never entered is a no-op)
 
     def __enter__(self):
         self.main = torch.cuda.current_stream()
         self.on = self.enabled
         if self.on:
-            self.side = branch_stream(self.main)
+            self.side = branch_stream(self.main, self.slot)
             self.side.wait_stream(self.main)
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
@@ -1194,11 +1195,17 @@ def lsm_loss(logits2d, target, ignore, smoothing):
     return row_loss, grad, correct
 
 
-def embed_pe(ids, table, pe, scale):
+def embed_pe(ids, table, pe, scale, step_dev=None):
+    """table[ids] * scale + pe; ``step_dev`` (int32 device scalar): ids is [N, 1] and every row takes pe[step] (tavsr_embed_pe_step)"""
     B, Lq = ids.shape
     D = table.shape[1]
     require_cuda(ids, table, pe)
     out = empty(B, Lq, D, like=table)
+    if step_dev is not None:
+        assert Lq == 1 and step_dev.dtype == torch.int32 and pe.is_contiguous() and pe.shape[1] == D
+        check(lib().tavsr_embed_pe_step(ptr(ids), ptr(table), ptr(pe), C.c_float(scale), ptr(out), C.c_int64(B), pe.shape[0], D,
+                                        ptr(step_dev), stream()), "tavsr_embed_pe_step")
+        return out
     check(lib().tavsr_embed_pe(ptr(ids), ptr(table), ptr(pe), C.c_float(scale), ptr(out), C.c_int64(B * Lq), Lq, D,
                                stream()), "tavsr_embed_pe")
     return out
@@ -1638,14 +1645,17 @@ def bootstrap_rates(dist, reflen, iters, seed):
 ROWLIN = True
 
 
-def rowlin_ok(x, w, n_rows=None) -> bool:
-    """the one-launch small-step Linear (tavsr_rowlin) takes up to 32 rows and K in {64 .. 2048} powers of two."""
+def rowlin_ok(x, w, n_rows=None, ln=False, ksplit=1) -> bool:
+    """does the one-launch small-step Linear (tavsr_rowlin / tavsr_rowlin_parts) take this call?  Up to 32 rows, K a power of two
+    in 64 .. 2048; which (rows, K, LayerNorm prologue, K slices) combinations have a spill-free plan is the library's answer
+    (tavsr_rowlin_ok: e.g. K = 2048 with more than 16 rows only in slices, K = 1024 with LayerNorm only up to 16 rows)."""
     if isinstance(x, RowParts):
         x = x.t[0]
     K = x.shape[1]
     N = x.shape[0] if n_rows is None else n_rows
-    return (ROWLIN and N <= 32 and K in (64, 128, 256, 512, 1024, 2048) and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
-            and x.stride(1) == 1 and w.stride(1) == 1 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+    return bool(ROWLIN and N <= 32 and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
+                and x.stride(1) == 1 and w.stride(1) == 1 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+                and lib().tavsr_rowlin_ok(int(N), int(K), int(bool(ln)), int(ksplit)))
 
 
 class RowParts:
@@ -1662,15 +1672,15 @@ class RowParts:
         return self.t.shape[1:]
 
 
-ROWLIN_KSPLIT = 4      # K slices of the 2048 -> d projection of a one-token feed-forward block (<= 16 rows); 0: one block per tile
+ROWLIN_KSPLIT = 4      # K slices of the 2048 -> d projection of a one-token feed-forward block; 1: one block per tile (<= 16 rows only)
 
 
-def rowlin(x, w, b=None, *, ln=None, act=None, res=None, out=None, gather=None, ksplit=1):
+def rowlin(x, w, b=None, *, ln=None, act=None, res=None, out=None, gather=None, ksplit=1, res_gather=None):
     """out = res + act(LN(x[gather]) @ w.T + b) in one launch (csrc/decode.hip:rowlin_kernel) - the Linear layers of a
     one-token scorer step.  ln = (gamma, beta, eps) or None; gather: int64 row indices into x (embedding lookup).
     ``x`` / ``res`` may be ``RowParts``; ``ksplit`` > 1 deals K to that many blocks per column tile and returns ``RowParts``."""
     if isinstance(x, RowParts) or isinstance(res, RowParts) or ksplit > 1:
-        assert gather is None
+        assert gather is None and res_gather is None
         xt, xp = (x.t[0], x.t.shape[0]) if isinstance(x, RowParts) else (x, 1)
         rt, rp = (res.t[0], res.t.shape[0]) if isinstance(res, RowParts) else (res, 1)
         N, K, Nout = xt.shape[0], xt.shape[1], w.shape[0]
@@ -1687,14 +1697,14 @@ def rowlin(x, w, b=None, *, ln=None, act=None, res=None, out=None, gather=None, 
     N = x.shape[0] if gather is None else gather.numel()
     K, Nout = x.shape[1], w.shape[0]
     require_cuda(x, w)
-    assert w.shape[1] == K
+    assert w.shape[1] == K and (res_gather is None or (res is not None and res_gather.numel() == N and res_gather.dtype == torch.int64))
     if out is None:
         out = empty(N, Nout, like=x)
     assert out.data_ptr() != x.data_ptr()
     g, be, eps = ln if ln is not None else (None, None, 0.0)
     check(lib().tavsr_rowlin(ptr(x), C.c_int64(x.stride(0)), ptr(gather), ptr(g), ptr(be), C.c_float(eps), ptr(w),
                              C.c_int64(w.stride(0)), ptr(b), ACT[act], ptr(res), C.c_int64(0 if res is None else res.stride(0)),
-                             ptr(out), C.c_int64(out.stride(0)), N, K, Nout, stream()), "tavsr_rowlin")
+                             ptr(res_gather), ptr(out), C.c_int64(out.stride(0)), N, K, Nout, stream()), "tavsr_rowlin")
     return out
 
 
@@ -1805,6 +1815,27 @@ def beam_combine_topk(full, cand, psi, psi_abs, eos_s, eos_abs, s_prev, score, e
                                         ptr(weighted), ptr(top_s), ptr(top_i), N, K, V, Cn, int(eos), C.c_float(w_ctc), stream()),
           "tavsr_beam_combine_topk")
     return (top_s, top_i, weighted) if keep_weighted else (top_s, top_i)
+
+
+def beam_select_topk_ok(K, V) -> bool:
+    return V <= 64 and K <= 16 and K <= V
+
+
+def beam_select_topk(dec, z_lm, w_lm, add, psi_all, psi_abs_all, eos_s, eos_abs, s_prev, score, eos, w_ctc, K, Cn, keep=False):
+    """the beam update behind the scorers in one launch (tavsr_beam_select_topk; V <= 64): -> (top_s, top_i) or, with ``keep``,
+    (top_s, top_i, full, weighted, cand) - the intermediate values the separate launches would have produced"""
+    N, V = dec.shape
+    require_cuda(dec, z_lm, psi_all, psi_abs_all, eos_s, eos_abs, s_prev, score)
+    assert dec.is_contiguous() and psi_all.is_contiguous() and psi_abs_all.is_contiguous() and (z_lm is None or z_lm.is_contiguous())
+    top_s = empty(N // K, K, like=dec)
+    top_i = torch.empty(N // K, K, dtype=torch.int64, device=dec.device)
+    full = empty(N, V, like=dec) if keep else None
+    weighted = empty(N, V, like=dec) if keep else None
+    cand = torch.empty(N, Cn, dtype=torch.int64, device=dec.device) if keep else None
+    check(lib().tavsr_beam_select_topk(ptr(dec), ptr(z_lm), C.c_float(w_lm), C.c_float(add), ptr(psi_all), ptr(psi_abs_all), ptr(eos_s),
+                                       ptr(eos_abs), ptr(s_prev), ptr(score), ptr(full), ptr(weighted), ptr(cand), ptr(top_s), ptr(top_i),
+                                       N, K, V, int(Cn), int(eos), C.c_float(w_ctc), stream()), "tavsr_beam_select_topk")
+    return (top_s, top_i, full, weighted, cand) if keep else (top_s, top_i)
 
 
 def beam_step_begin(score, tok, anc, maxlen, K, eos, step_dev):

