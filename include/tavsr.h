@@ -130,6 +130,13 @@ int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);
  * problems (weight gradients, K = B*T) are split so the whole chip works; each slice stores an fp32 slab and a
  * second kernel sums the slabs in slice order (deterministic) and applies the epilogue. */
 int64_t tavsr_gemm_ws(const tavsr_gemm_desc* desc);
+/* tavsr_gemm of a plain unbatched Linear (bias / activation / alpha / residual; no dropout, Z, DZ, a_rowsum, rowstat, convolution)
+ * and the LayerNorm that follows it: ln_out[m][:N] = LN(C[m][:N]) * gamma + beta (row stride ld_ln; eps as torch).  Where the GEMM
+ * splits K, the slab sum, the epilogue and the LayerNorm are ONE launch (one wave per row) instead of an epilogue launch plus a
+ * LayerNorm launch - the x + f(x) -> norm(x) seams of a batched one-token decoder / LM step (espnet decoder_layer.py,
+ * encoder_layer.py: every sub-block starts with a LayerNorm of the residual stream).  N % 4 == 0, N <= 2048, 16-byte aligned rows. */
+int tavsr_gemm_ln(const tavsr_gemm_desc* desc, const float* gamma, const float* beta, float eps, float* ln_out, int64_t ld_ln,
+                  tavsr_stream_t stream);
 /* up to 12 independent, unbatched problems of ONE layout (a_kmajor, b_kmajor) in one launch, no K split: the weight
  * gradients of a layer (16-128 output tiles each) fill the chip together.  Every problem must satisfy the fast
  * kernel's conditions (16-byte aligned operands and leading dimensions, K %% 32 == 0, row-contiguous operands with a

@@ -1151,8 +1151,90 @@ static int launch_layout(const tavsr_gemm_desc& d, F&& f) {
   return f(std::true_type{}, std::false_type{});
 }
 
+// tavsr_gemm_ln: the LayerNorm that follows a Linear, taken where the result row is finished.  A one-token step of a batched search
+// (640 hypothesis rows) runs its N = 256 / 512 projections with K split over workgroups: the slabs are summed by an epilogue launch
+// and the next block's LayerNorm is another launch over the same rows - 38 + 38 launches of ~5 us per token at batch 64.  Here one
+// wave per row sums the slabs (fixed order), applies the same epilogue arithmetic as splitk_epilogue_kernel, stores C and, with the
+// row still in registers, its LayerNorm (two-pass statistics, as layernorm_fwd_kernel).  nsplit == 1: C is final; the wave reads it.
+struct LnTail {
+  const float* gamma; const float* beta; float eps; float* out; int64_t ld;
+};
+static const LnTail* g_ln_tail = nullptr;      // set by tavsr_gemm_ln around its run(): the library is not re-entrant
+
+constexpr int kLnTailMaxN = 2048;
+__global__ __launch_bounds__(256) void epilogue_ln_kernel(const GemmArgs args, const LnTail ln) {
+  const tavsr_gemm_desc& d = args.d;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= d.M) return;
+  constexpr int Q = kLnTailMaxN / 256;             // float4s per lane
+  const int n4 = d.N >> 2;
+  const int64_t mn = (int64_t)d.M * d.N;
+  float4 x[Q];
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int c4 = lane + 64 * q;
+    x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < n4) {
+      const int n = 4 * c4;
+      const int64_t o = (int64_t)m * d.ldc + n;
+      float4 v;
+      if (args.nsplit > 1) {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = d.ws + (int64_t)m * d.N + n;
+        for (int sidx = 0; sidx < args.nsplit; ++sidx) {
+          const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)sidx * mn);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float y = e[k];
+          if (d.bias) y += d.bias[n + k];
+          y = act_fwd(d.act, y);
+          y *= d.alpha;
+          if (d.R) y += d.R[(int64_t)m * d.ldr + n + k];
+          e[k] = y;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<float4*>(d.C + o) = v;
+      } else {
+        v = *reinterpret_cast<const float4*>(d.C + o);
+      }
+      x[q] = v;
+      sum += (v.x + v.y) + (v.z + v.w);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)d.N;
+  float sq = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (lane + 64 * q < n4) {
+      const float a = x[q].x - mean, b = x[q].y - mean, c = x[q].z - mean, e = x[q].w - mean;
+      sq += (a * a + b * b) + (c * c + e * e);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)d.N + ln.eps);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int c4 = lane + 64 * q;
+    if (c4 < n4) {
+      const float4 g = *reinterpret_cast<const float4*>(ln.gamma + 4 * c4), b = *reinterpret_cast<const float4*>(ln.beta + 4 * c4);
+      *reinterpret_cast<float4*>(ln.out + (int64_t)m * ln.ld + 4 * c4) =
+          make_float4((x[q].x - mean) * rstd * g.x + b.x, (x[q].y - mean) * rstd * g.y + b.y, (x[q].z - mean) * rstd * g.z + b.z,
+                      (x[q].w - mean) * rstd * g.w + b.w);
+    }
+  }
+}
+
 static int launch_epilogue(const GemmArgs& a, hipStream_t s) {
   const tavsr_gemm_desc& d = a.d;
+  if (g_ln_tail) {                 // tavsr_gemm_ln: slab sum + epilogue + the next LayerNorm, one wave per row
+    hipLaunchKernelGGL(epilogue_ln_kernel, dim3(cdiv(d.M, 4)), dim3(256), 0, s, a, *g_ln_tail);
+    TAVSR_LAUNCH_CHECK();
+    return TAVSR_OK;
+  }
   if (a.nsplit > 1) {
     const int64_t mn = (int64_t)d.M * d.N;
     if (d.N % 4 == 0)
@@ -1483,6 +1565,23 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
 
 extern "C" int tavsr_gemm(const tavsr_gemm_desc* dp, tavsr_stream_t stream) {
   return tavsr::run(dp, -1, 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tavsr_gemm_ln(const tavsr_gemm_desc* dp, const float* gamma, const float* beta, float eps, float* ln_out, int64_t ld_ln,
+                             tavsr_stream_t stream) {
+  using namespace tavsr;
+  TAVSR_REQUIRE(dp && gamma && beta && ln_out, TAVSR_EINVAL, "tavsr_gemm_ln: null pointer");
+  const tavsr_gemm_desc& d = *dp;
+  TAVSR_REQUIRE(d.nb1 * d.nb2 <= 1 && d.conv_mode == 0 && d.drop_p == 0.f && !d.Z && !d.DZ && !d.a_rowsum && !d.rowstat,
+                TAVSR_EUNSUPPORTED, "tavsr_gemm_ln: a plain unbatched Linear (bias / activation / alpha / residual) only");
+  TAVSR_REQUIRE(d.N % 4 == 0 && d.N <= kLnTailMaxN && d.ldc % 4 == 0 && ld_ln % 4 == 0 && (!d.R || d.ldr % 4 == 0) &&
+                    aligned16(d.C) && aligned16(ln_out) && aligned16(gamma) && aligned16(beta) && ln_out != d.C,
+                TAVSR_EALIGN, "tavsr_gemm_ln: N %% 4 == 0, N <= %d, 16-byte aligned rows of C / ln_out / gamma / beta", kLnTailMaxN);
+  const LnTail ln{gamma, beta, eps, ln_out, ld_ln};
+  g_ln_tail = &ln;
+  const int rc = run(dp, -1, 0, static_cast<hipStream_t>(stream));
+  g_ln_tail = nullptr;
+  return rc;
 }
 
 extern "C" int tavsr_gemm_grouped(const tavsr_gemm_desc* descs, int32_t n, tavsr_stream_t stream) {

@@ -75,45 +75,74 @@ PREBEAM_FUSED = True   # pre-beam top-k inside the CTC prefix launch
 # Vocabularies of up to 64 tokens (character models): the CTC prefix scores of EVERY token are computed beside the LM's chain, in front
 # of the decoder's - the recursion over the frames (20 us) leaves the critical path of a captured step - and the whole beam update
 # behind the scorers (LM log-softmax, pre-beam, weighted scores, top-k) is one launch (tavsr_beam_select_topk).
+LN_IN_EPILOGUE = os.environ.get("TAVSR_DECODE_LN_EPILOGUE", "1") != "0"     # batched steps: tavsr_gemm_ln at the x + f(x) -> norm(x) seams
 CTC_BESIDE_SCORERS = os.environ.get("TAVSR_DECODE_CTC_BESIDE", "1") != "0"
 
 
+class _Normed:
+    """rows of the residual stream together with their LayerNorm under one particular (gamma, beta): what the launch that finished
+    the rows leaves when it was told which norm follows (``_linear_res(..., ln_next=)``, GEMM path: tavsr_gemm_ln)"""
+    __slots__ = ("x", "n", "gamma")
+
+    def __init__(self, x, n, gamma):
+        self.x, self.n, self.gamma = x, n, gamma
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+
+def _rows(x):
+    """the plain [N, d] tensor of a residual stream held as ``ops.RowParts`` / ``_Normed``"""
+    if isinstance(x, _Normed):
+        return x.x
+    if isinstance(x, ops.RowParts):
+        return x.t.sum(0)
+    return x
+
+
 def _ln_linear(x, norm, w, b, act=None):
-    """act(W LN(x) + b): one launch (ops.rowlin) when the shapes allow, else LayerNorm + GEMM launches."""
+    """act(W LN(x) + b): one launch (ops.rowlin) when the shapes allow, else LayerNorm + GEMM launches (no LayerNorm launch when
+    the rows arrive with this norm already taken)."""
+    if isinstance(x, _Normed):
+        if x.gamma is norm[0]:
+            return ops.linear(x.n, w, b, act=act)
+        x = x.x
     if ops.rowlin_ok(x, w, ln=True):
         return ops.rowlin(x, w, b, ln=(norm[0], norm[1], EPS), act=act)
-    if isinstance(x, ops.RowParts):
-        x = x.t.sum(0)
-    n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
+    n = ops.layernorm_fwd(_rows(x), *norm, EPS, save=False)[0]
     return ops.linear(n, w, b, act=act)
 
 
-def _linear_res(x, w, b, res, ksplit=1):
+def _linear_res(x, w, b, res, ksplit=1, ln_next=None):
     """res + W x + b (``ksplit`` > 1: K dealt to that many blocks per column tile, the result an ``ops.RowParts``; a K the one-launch
-    kernel only takes in slices - 2048 with more than 16 rows - is dealt to ``ops.ROWLIN_KSPLIT`` blocks whatever the caller asked)."""
+    kernel only takes in slices - 2048 with more than 16 rows - is dealt to ``ops.ROWLIN_KSPLIT`` blocks whatever the caller asked).
+    ``ln_next`` = (gamma, beta) of the LayerNorm the result goes through next: on the GEMM path (more than 32 rows) the launch that
+    finishes the rows - the sum of the K-split slabs - also normalises them (``_Normed``)."""
+    if isinstance(res, _Normed):
+        res = res.x
     if ksplit == 1 and not ops.rowlin_ok(x, w) and ops.rowlin_ok(x, w, ksplit=max(2, ops.ROWLIN_KSPLIT)):
         ksplit = max(2, ops.ROWLIN_KSPLIT)
     if ksplit > 1 and ops.rowlin_ok(x, w, ksplit=ksplit):
         return ops.rowlin(x, w, b, res=res, ksplit=ksplit)
     if ops.rowlin_ok(x, w):
         return ops.rowlin(x, w, b, res=res)
-    if isinstance(res, ops.RowParts):
-        res = res.t.sum(0)
+    res = _rows(res)
+    if ln_next is not None and LN_IN_EPILOGUE and w.shape[0] % 4 == 0 and w.shape[0] <= 2048:
+        y, n = ops.linear(x, w, b, res=res, ln=(ln_next[0], ln_next[1], EPS))
+        return _Normed(y, n, ln_next[0])
     return ops.linear(x, w, b, res=res)
 
 
-def _ffn_step(x, norm, L):
+def _ffn_step(x, norm, L, ln_next=None):
     """x + W2 relu(W1 LN(x) + b1) + b2 of one decoder / LM layer for the current token rows.  Hidden size 2048: the closing
     projection deals its K to ops.ROWLIN_KSPLIT blocks per column tile and the result stays a sum of that many tensors
     (``ops.RowParts``) until the next launches of the chain add them while they load their operands."""
-    if ops.rowlin_ok(x, L["w1"], ln=True):
+    if not isinstance(x, _Normed) and ops.rowlin_ok(x, L["w1"], ln=True):
         t = ops.rowlin(x, L["w1"], L["b1"], ln=(norm[0], norm[1], EPS), act="relu")
         return _linear_res(t, L["w2"], L["b2"], x, ops.ROWLIN_KSPLIT if t.shape[1] == 2048 else 1)
-    if isinstance(x, ops.RowParts):
-        x = x.t.sum(0)
-    n = ops.layernorm_fwd(x, *norm, EPS, save=False)[0]
-    t = ops.linear(n, L["w1"], L["b1"], act="relu")
-    return ops.linear(t, L["w2"], L["b2"], res=x)
+    t = _ln_linear(x, norm, L["w1"], L["b1"], act="relu")
+    return _linear_res(t, L["w2"], L["b2"], x, ln_next=ln_next)
 
 
 class _DecoderStep:
@@ -167,13 +196,14 @@ class _DecoderStep:
             x = ops.embed_pe(tok.view(N, 1), self.emb, self.pe[i:i + 1].contiguous(), self.xscale).view(N, D)
         else:      # the positional row of the device-side step counter: read by the embedding launch itself
             x = ops.embed_pe(tok.view(N, 1), self.emb, self.pe, self.xscale, step_dev=dyn[0]).view(N, D)
+        after = (self.dec.after_norm.weight, self.dec.after_norm.bias)
         for li, L in enumerate(self.layers):
             qkv = _ln_linear(x, L["n1"], L["wqkv"], L["bqkv"])
             # this step's keys / values are the last key of every hypothesis: the attention launch appends them to the pools
             a = ops.tree_attn_step(qkv[:, :D], self.kpool[li], self.vpool[li], anc, i + 1 if dyn is None else i, H, dk,
                                    step_dev=None if dyn is None else dyn[0], k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:],
                                    group=TREE_GROUP * self.K)
-            x = _linear_res(a, L["wo"], L["bo"], x)
+            x = _linear_res(a, L["wo"], L["bo"], x, ln_next=L["n2"])
             q2 = _ln_linear(x, L["n2"], L["wq2"], L["bq2"])
             # source attention: the K slots of an utterance are K query rows against that utterance's memory
             kv = self.memkv[li]
@@ -188,10 +218,9 @@ class _DecoderStep:
                 c2 = ops.empty(N, D, like=x)
                 ops.gemm(K, dk, T, att, S, kv, 2 * D, c2, D, b_off=D, b_kmajor=True, nb1=U, nb2=H, sA=(K * S, U * K * S),
                          sB=(T * 2 * D, dk), sC=(K * D, dk))
-            x = _linear_res(c2, L["wo2"], L["bo2"], x)
-            x = _ffn_step(x, L["n3"], L)
-        z = _ln_linear(x, (self.dec.after_norm.weight, self.dec.after_norm.bias), self.dec.output_layer.weight,
-                       self.dec.output_layer.bias)
+            x = _linear_res(c2, L["wo2"], L["bo2"], x, ln_next=L["n3"])
+            x = _ffn_step(x, L["n3"], L, ln_next=self.layers[li + 1]["n1"] if li + 1 < len(self.layers) else after)
+        z = _ln_linear(x, after, self.dec.output_layer.weight, self.dec.output_layer.bias)
         return ops.log_softmax_rows(z, **score)
 
 
@@ -248,6 +277,7 @@ class _LMStep:
         lm = self.lm
         # the token's row of the input table is gathered by the first layer's launches themselves where the one-launch Linear
         # runs (its ``gather`` / ``res_gather`` operands): no gather launch at the head of the LM's chain
+        after = (lm.encoder.after_norm.weight, lm.encoder.after_norm.bias)
         fold = ops.rowlin_ok(self.in_table, self.layers[0]["wqkv"], n_rows=N, ln=True)
         h = None if fold else self.in_table.index_select(0, tok)
         for li, L in enumerate(self.layers):
@@ -262,9 +292,9 @@ class _LMStep:
             if li == 0 and fold:
                 h = ops.rowlin(a, L["wo"], L["bo"], res=self.in_table, res_gather=tok)
             else:
-                h = _linear_res(a, L["wo"], L["bo"], h)
-            h = _ffn_step(h, L["n2"], L)
-        z = _ln_linear(h, (lm.encoder.after_norm.weight, lm.encoder.after_norm.bias), lm.decoder.weight, lm.decoder.bias)
+                h = _linear_res(a, L["wo"], L["bo"], h, ln_next=L["n2"])
+            h = _ffn_step(h, L["n2"], L, ln_next=self.layers[li + 1]["n1"] if li + 1 < len(self.layers) else after)
+        z = _ln_linear(h, after, lm.decoder.weight, lm.decoder.bias)
         return z if logits_only else ops.log_softmax_rows(z, **score)
 
 
@@ -290,6 +320,7 @@ class BatchBeamSearch:
         # avsr_inference.py:298: pre_beam_score_key = None when ctc_weight == 1 -> the CTC prefix scorer sees every token
         self.C = self.V if ctc_weight == 1.0 else min(int(1.5 * beam_size), self.V)
         self._pinned = None
+        self._copy_q = None        # the queue the per-token records leave on (created with the first captured search)
         self._captured = None      # the captured step of the last batch shape (buffers + hipGraph), re-used while the shape repeats
         self.dec_step = _DecoderStep(model.decoder)
         self.lm_step = _LMStep(lm) if (lm is not None and lm_weight != 0.0) else None
@@ -541,12 +572,24 @@ class BatchBeamSearch:
             timing = os.environ.get("TAVSR_DECODE_TIMING") == "1"   # host-side cost of a token: replay call / record processing
             t_replay = t_host = t_wait = 0.0
             import time as _time
+            # the records travel on a queue of their own: the copy of token i's record waits for step i (an event), step i + 1 does
+            # not wait for the copy - the search queue holds nothing but the replays (a 120-byte copy between two replays cost the
+            # chain a launch of its own per token)
+            main_q = torch.cuda.current_stream()
+            if self._copy_q is None:
+                self._copy_q = torch.cuda.Stream()
+            copy_q = self._copy_q
+            copy_q.wait_stream(main_q)
             for i in range(steps):
                 t0 = _time.perf_counter()
                 graph.replay()
-                pin[i].copy_(hist[i], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
+                stepped = torch.cuda.Event()
+                stepped.record(main_q)
+                copy_q.wait_event(stepped)
+                with torch.cuda.stream(copy_q):
+                    pin[i].copy_(hist[i], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_q)
                 events.append(ev)
                 t1 = _time.perf_counter()
                 while done < i and bool(active.any()):              # the host works one token behind the device
@@ -567,7 +610,8 @@ class BatchBeamSearch:
                 events[done].synchronize()
                 host_step(done, pin[done, 0].to(torch.int64), pin[done, 2].view(torch.float32), rows_from_records(done))
                 done += 1
-            torch.cuda.current_stream().synchronize()               # a step the device ran ahead may still be in flight
+            main_q.wait_stream(copy_q)
+            main_q.synchronize()                                    # a step the device ran ahead may still be in flight
         else:
             for i in range(steps):
                 anc, tok = device_step(i, None)

@@ -66,9 +66,10 @@ def _zero_page(device) -> torch.Tensor:
 def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
          R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, conv=None, force=None, ws_cap=None,
-         drop=None, rowstat=None):
+         drop=None, rowstat=None, ln=None):
     """Raw descriptor call; offsets are in elements into the given tensors.  ``force=(cfg, nsplit)`` bypasses
-    the planner (tuning / tests); ``ws_cap`` caps the split-K workspace handed to the library (tests of its fallback)."""
+    the planner (tuning / tests); ``ws_cap`` caps the split-K workspace handed to the library (tests of its fallback).
+    ``ln`` = (gamma, beta, eps, out [M, N]): also the LayerNorm of the result rows (tavsr_gemm_ln)."""
     require_cuda(A, B, Cc, bias, Z, R, DZ, a_rowsum)
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -110,7 +111,12 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.ws, d.ws_floats = _addr(ws), need
 
     def call():
-        if force is None:
+        if ln is not None:
+            assert force is None
+            require_cuda(ln[0], ln[1], ln[3])
+            check(lib().tavsr_gemm_ln(C.byref(d), ptr(ln[0]), ptr(ln[1]), C.c_float(ln[2]), ptr(ln[3]), C.c_int64(ln[3].stride(0)),
+                                      stream()), "tavsr_gemm_ln")
+        elif force is None:
             check(lib().tavsr_gemm(C.byref(d), stream()), "tavsr_gemm")
         else:
             check(lib().tavsr_gemm_tune(C.byref(d), int(force[0]), int(force[1]), stream()), "tavsr_gemm_tune")
@@ -141,9 +147,10 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
 
 
 def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=None, out_off=0, ldc=None, force=None,
-           rowstat=None):
+           rowstat=None, ln=None):
     """y = res + alpha*act(x @ w.T + b); x [M,K] (row stride x.stride(0)), w [N,K] torch layout.  ``rowstat`` (tensor
-    [M, ceil(N / 64), 2]): receives the per-row (sum, sum of squares) of every 64-column tile of y (tavsr_gemm_desc.rowstat)."""
+    [M, ceil(N / 64), 2]): receives the per-row (sum, sum of squares) of every 64-column tile of y (tavsr_gemm_desc.rowstat).
+    ``ln`` = (gamma, beta, eps): also returns LayerNorm(y) - (y, normed) - from the launch that finishes the rows (tavsr_gemm_ln)."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
@@ -151,8 +158,13 @@ def linear(x, w, b=None, *, act=None, alpha=1.0, res=None, save_z=False, out=Non
         ldc = N
     z = empty(M, N, like=x) if save_z else None
     assert not save_z or (out_off == 0 and ldc == N)
+    normed = empty(M, N, like=x) if ln is not None else None
+    assert ln is None or (not save_z and rowstat is None and out_off == 0)
     gemm(M, N, K, x, x.stride(0), w, w.stride(0), out, ldc, c_off=out_off, bias=b, act=act, alpha=alpha, Z=z,
-         R=res, ldr=0 if res is None else res.stride(0), force=force, rowstat=rowstat)
+         R=res, ldr=0 if res is None else res.stride(0), force=force, rowstat=rowstat,
+         ln=None if ln is None else (ln[0], ln[1], ln[2], normed))
+    if ln is not None:
+        return out, normed
     return (out, z) if save_z else out
 
 

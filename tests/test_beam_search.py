@@ -100,6 +100,39 @@ def test_hip_beam_search_matches_oracle(beam, ctc_w, lm_w, pen):
 
 
 @pytest.mark.gpu
+def test_hip_beam_search_with_more_than_32_rows_matches_oracle(monkeypatch):
+    """7 utterances x beam 5 = 35 hypothesis rows: every Linear of the step runs on the GEMM kernels (the one-launch small-step
+    Linear takes up to 32 rows), the K-split ones finish their rows together with the LayerNorm that follows (tavsr_gemm_ln) - against
+    the oracle's one-by-one search, and with the LayerNorm launches kept separate (same best hypotheses, scores within 1e-5)."""
+    from tavsr.inference import beam_search as PBS
+    from tavsr.lm.transformer_lm import TransformerLM
+    from tavsr.tasks.asr import ASRTask
+    m, lm = _oracle_models()
+    conf = asr_conf(num_blocks=2, dec_blocks=2)
+    conf["token_list"] = TOKENS_EN
+    pm = ASRTask.build_model(argparse.Namespace(**conf)).eval()
+    fill_parameters_(pm, seed=5)
+    plm = TransformerLM(len(TOKENS_EN), **LM_KW).eval()
+    fill_parameters_(plm, seed=6)
+    pm, plm = pm.cuda(), plm.cuda()
+    U = 7
+    x = synth((U, 128, 80), seed=27)
+    lens = torch.tensor([128, 128, 120, 112, 96, 88, 64])
+    with torch.no_grad():
+        enc, olens = m.encode(x, lens)
+        ref = [BS.build_beam_search(m, lm, 5, 0.3, 0.6, 0.5).forward(enc[u, : int(olens[u])]) for u in range(U)]
+        outs = []
+        for flag in (True, False):
+            monkeypatch.setattr(PBS, "LN_IN_EPILOGUE", flag)
+            outs.append(PBS.BatchBeamSearch(pm, plm, 5, 0.3, 0.6, 0.5).decode(enc.cuda(), olens.cuda()))
+    for u in range(U):
+        for hip in outs:
+            assert hip[u][0][0] == ref[u][0].yseq.tolist(), (u, hip[u][0], ref[u][0].yseq.tolist())
+            assert abs(hip[u][0][1] - ref[u][0].score) < 2e-4 * abs(ref[u][0].score)
+        assert outs[0][u][0][0] == outs[1][u][0][0] and abs(outs[0][u][0][1] - outs[1][u][0][1]) < 1e-5 * abs(outs[1][u][0][1])
+
+
+@pytest.mark.gpu
 def test_captured_step_is_reused_for_the_next_batch_of_the_same_shape():
     """a stream of equally long clips: the second ``decode`` refills the first one's buffers and replays its hipGraph - same
     hypotheses and scores as a search object that has never seen another batch; a different shape captures anew"""

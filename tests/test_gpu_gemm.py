@@ -254,3 +254,31 @@ def test_gemm_epilogue_dropout_equals_the_standalone_mask(M, N, K, split):
     got = ops.linear_dx_drop(dy, w2, tok2, alpha=0.5, DZ=zz, dact="swish")
     ref = ops.dropout_act_bwd(ops.linear_dx(dy, w2, alpha=0.5), zz, "swish", tok2)
     assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(640, 512, 2048, None, True), (640, 256, 2048, None, True), (640, 512, 512, None, True),
+                                           (640, 256, 256, None, True), (77, 256, 2048, "relu", False), (640, 1024, 512, None, True),
+                                           (35, 128, 2048, None, True)])
+def test_gemm_ln_result_and_its_layernorm_from_the_launch_that_finishes_the_rows(M, N, K, act, res):
+    """tavsr_gemm_ln: y = res + act(x W^T + b) and LayerNorm(y) (eps 1e-12) - where K is split over workgroups the slab sum, the
+    epilogue and the LayerNorm are one launch, else the LayerNorm is taken by one launch behind the GEMM - against fp64, and y bit-equal
+    to the plain tavsr_gemm of the same problem (same split plan, same slab order, same epilogue arithmetic)."""
+    from tavsr import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x, w, b = r(M, K), r(N, K) / K ** 0.5, r(N)
+    rs = r(M, N) if res else None
+    gam, bet = r(N).abs() + 0.5, r(N)
+    y, n = ops.linear(x, w, b, act=act, res=rs, ln=(gam, bet, 1e-12))
+    y0 = ops.linear(x, w, b, act=act, res=rs)
+    assert torch.equal(y, y0)
+    ref = x.double() @ w.double().t() + b.double()
+    if act == "relu":
+        ref = ref.relu()
+    if res:
+        ref = ref + rs.double()
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    nref = torch.nn.functional.layer_norm(ref, (N,), gam.double(), bet.double(), 1e-12)
+    assert float((n.double() - nref).abs().max() / nref.abs().max()) < 5e-6
+    n0 = ops.layernorm_fwd(y0, gam, bet, 1e-12, save=False)[0]
+    assert float((n - n0).abs().max() / n0.abs().max()) < 2e-6
