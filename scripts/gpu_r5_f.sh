@@ -1,0 +1,7 @@
+mkdir -p gpurun_out
+export PYTHONFAULTHANDLER=1
+timeout 900 python -m pytest tests/test_gpu_rowlin.py -q -m gpu -x > gpurun_out/rowlin_tests.log 2>&1; echo "rowlin tests rc=$?"; tail -5 gpurun_out/rowlin_tests.log
+timeout 900 python -m pytest tests/test_beam_search.py -q -m gpu -x > gpurun_out/beam_tests.log 2>&1; echo "beam tests rc=$?"; tail -3 gpurun_out/beam_tests.log
+timeout 600 python bench_decode.py --utterances 256 --batch 64 --no-cpu-baseline > gpurun_out/decode_b64.json 2> gpurun_out/decode_b64.err; echo "decode64 rc=$?"; cut -c1-420 gpurun_out/decode_b64.json
+timeout 600 python bench_decode.py --utterances 512 --batch 256 --no-cpu-baseline > gpurun_out/decode_b256.json 2> gpurun_out/decode_b256.err; echo "decode256 rc=$?"; cut -c1-420 gpurun_out/decode_b256.json
+bash scripts/gpu_decode_prof.sh 64 | head -12

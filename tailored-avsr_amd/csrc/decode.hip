@@ -18,6 +18,12 @@ constexpr int kTreeMaxKeys = 1024;
 // one wave per (hypothesis n, head h).  Latency-bound at small N (a chain of dependent gathers): the ancestor list is
 // read once into LDS, the scores use one lane per key (16 float4 loads in flight per lane), the weighted value sum uses
 // 64 / DL key groups x DL lanes of float4 so that a wave has 8 independent row gathers in flight per lane.
+// Large steps (a batch of utterances x beam: 5120 items at 64 x 10 x 8 heads) are bound by the rate at which the L2s serve the row
+// gathers - 262 MB of requests per launch at 100 keys, 28 us, whatever the beams share (measured 1.2 - 1.4 distinct rows per step and
+// utterance).  Three forms that tried to use the sharing all lost (profiles/r05_tree_attn_large_step_variants.txt, r05_notes.md): a
+// whole beam per workgroup (same time: the vector cache does not merge the requests), one workgroup per (utterance, head) copying
+// the distinct rows into LDS once (1.5x slower: its phases are serial behind workgroup barriers, one workgroup per compute unit),
+// rows read 256 bytes at a time by 16 lanes with the scores summed on the lane network (1.3x slower).
 template <int DL>      // lanes along the head dimension (float4 each): 16 (dk <= 64) or 32 (dk <= 128)
 __global__ __launch_bounds__(256) void tree_attn_step_kernel(const float* __restrict__ q, int64_t ldq,
                                                              const float* __restrict__ kpool, const float* __restrict__ vpool,
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(256) void tree_attn_split_kernel(const float* __res
   const int n = (item / (H * group)) * group + item % group, h = (item / group) % H;
   const int nq = dk >> 2;                 // float4s actually present
   const float* qv = q + (int64_t)n * ldq + h * dk;
+  asm volatile("" : "+v"(qv));          // the query in vector registers (as 64 - 128 scalar ones it spilled them)
   const int32_t* a = anc + (int64_t)n * ld_anc;
   const int per = (nkeys + NW - 1) / NW;
   const int j0 = wave * per, j1 = min(nkeys, j0 + per);

@@ -75,6 +75,7 @@ PREBEAM_FUSED = True   # pre-beam top-k inside the CTC prefix launch
 # Vocabularies of up to 64 tokens (character models): the CTC prefix scores of EVERY token are computed beside the LM's chain, in front
 # of the decoder's - the recursion over the frames (20 us) leaves the critical path of a captured step - and the whole beam update
 # behind the scorers (LM log-softmax, pre-beam, weighted scores, top-k) is one launch (tavsr_beam_select_topk).
+RECORD_QUEUE = os.environ.get("TAVSR_DECODE_RECORD_QUEUE", "1") != "0"     # per-token records leave on a queue of their own
 LN_IN_EPILOGUE = os.environ.get("TAVSR_DECODE_LN_EPILOGUE", "1") != "0"     # batched steps: tavsr_gemm_ln at the x + f(x) -> norm(x) seams
 CTC_BESIDE_SCORERS = os.environ.get("TAVSR_DECODE_CTC_BESIDE", "1") != "0"
 
@@ -577,7 +578,7 @@ class BatchBeamSearch:
             # chain a launch of its own per token)
             main_q = torch.cuda.current_stream()
             if self._copy_q is None:
-                self._copy_q = torch.cuda.Stream()
+                self._copy_q = torch.cuda.Stream() if RECORD_QUEUE else main_q
             copy_q = self._copy_q
             copy_q.wait_stream(main_q)
             for i in range(steps):
@@ -679,6 +680,9 @@ class Speech2Text:
     def __call__(self, *batch):
         """batch: the tensors of ``asr_model.encode`` (speech, lengths) or (audio, lengths, video, lengths)."""
         enc, enc_lens = self.encode(*batch)
+        return self._results(enc, enc_lens)
+
+    def _results(self, enc, enc_lens):
         if isinstance(enc, tuple):
             enc = enc[0]
         results = []
