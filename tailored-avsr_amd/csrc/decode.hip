@@ -159,7 +159,6 @@ __global__ __launch_bounds__(256) void tree_attn_split_kernel(const float* __res
   const int n = (item / (H * group)) * group + item % group, h = (item / group) % H;
   const int nq = dk >> 2;                 // float4s actually present
   const float* qv = q + (int64_t)n * ldq + h * dk;
-  asm volatile("" : "+v"(qv));          // the query in vector registers (as 64 - 128 scalar ones it spilled them)
   const int32_t* a = anc + (int64_t)n * ld_anc;
   const int per = (nkeys + NW - 1) / NW;
   const int j0 = wave * per, j1 = min(nkeys, j0 + per);
