@@ -43,6 +43,12 @@ int tavsr_race_probe(float us, int mode);
 /* tuning aid (scripts/launch_floor.py): a launch of `grid` x `block` threads that does nothing (kind 0), one 16-byte read + write per
  * thread (1), or that plus a barrier and a dependent second read (2) - the floor under a one-token step's dependent launches */
 int tavsr_probe_launch(int32_t kind, int32_t grid, int32_t block, float* buf, int64_t n, tavsr_stream_t stream);
+/* tuning aid (scripts/seam_bench.py): `nphase` dependent phases (every workgroup writes per_wg floats, then reads what another workgroup
+ * wrote in the phase before) as nphase launches (kind 0) or as ONE launch with XCD-hierarchical grid barriers between the phases (kind 1;
+ * kind + 256 * (s + 1): a phase reads the slab of workgroup (g + s) % grid instead of (g + 97) % grid; ctl: 2304 zeroed bytes kept across calls, epoch0 = 0; grid <= 256: one workgroup per compute unit) - what a phase
+ * boundary inside a persistent layer kernel costs against the launch boundary it would replace */
+int tavsr_probe_seam(int32_t kind, int32_t grid, int64_t per_wg, int32_t nphase, float* buf, void* ctl, uint32_t epoch0,
+                     tavsr_stream_t stream);
 /* Box calibration for bench.py's `box` object: `blocks` workgroups of 4 waves, each wave issuing 4 * iters independent
  * v_mfma_f32_32x32x2_f32 (4096 FLOP each) and nothing else - the fp32 matrix rate this device holds, against which a 5 %
  * difference between two boxes of a pool can be told from a regression.  `sink`: one device word (never written). */

@@ -66,6 +66,95 @@ extern "C" int tavsr_probe_launch(int32_t kind, int32_t grid, int32_t block, flo
   return TAVSR_OK;
 }
 
+// What does a phase boundary INSIDE a launch cost against a launch boundary?  ("a persistent FFN -> tail -> FFN phase
+// pair with barrier-xcd-style seams: measure the seam against the finish + launch it replaces before building more".)  Two phases of the
+// same shape - every workgroup writes `per_wg` floats of its own slab, then reads the slab of workgroup (g + 97) % G written in the phase
+// before (the cross-workgroup dependency of a layer seam: partial outputs of other compute units) - either as two launches, or as one
+// launch with a grid-wide barrier between them: per-XCD arrival counters (workgroup b runs on XCD b % 8), the last arrival of an XCD
+// arrives at a top counter, the last XCD releases every XCD's generation word; lane 0 of each workgroup publishes with an agent-scope
+// release fence before it arrives and takes an agent-scope acquire after it saw its generation.  Grid <= one workgroup per compute unit.
+namespace tavsr {
+struct SeamCtl { unsigned xcd[8][32]; unsigned top[32]; unsigned gen[8][32]; unsigned base[32]; };      // every word on a 128-byte line of its own
+
+__device__ __forceinline__ void seam_phase(float* buf, long long per_wg, int phase, int G, int shift) {
+  if (shift & 0x10000) return;                                   // barriers only
+  const bool old = (shift & 0x20000) != 0;                       // read what was written a whole chain ago instead of a phase ago
+  shift &= 0xffff;
+  float* mine = buf + ((long long)phase * G + blockIdx.x) * per_wg;
+  const float4 seed = make_float4((float)phase, 1.f, 2.f, 3.f);
+  if (phase == 0) {
+    for (long long i = threadIdx.x * 4ll; i < per_wg; i += blockDim.x * 4ll) *reinterpret_cast<float4*>(mine + i) = seed;
+  } else {
+    const float* src = buf + ((long long)(old ? (phase + 1) % 9 : phase - 1) * G + (blockIdx.x + shift) % G) * per_wg;
+    for (long long i = threadIdx.x * 4ll; i < per_wg; i += blockDim.x * 4ll) {
+      float4 v = *reinterpret_cast<const float4*>(src + i);
+      v.x += 1.f;
+      *reinterpret_cast<float4*>(mine + i) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void seam_phase_kernel(float* buf, long long per_wg, int phase, int shift) { seam_phase(buf, per_wg, phase, gridDim.x, shift); }
+
+__global__ __launch_bounds__(256) void seam_fused_kernel(float* buf, long long per_wg, int nphase, SeamCtl* ctl, unsigned epoch0, int shift) {
+  const int G = gridDim.x, xcd = blockIdx.x & 7;
+  const unsigned per_xcd = (unsigned)((G - xcd + 7) / 8);
+  // barriers taken by earlier launches: device data, so that the launch can be captured and replayed (read before this launch's first
+  // barrier by every workgroup; workgroup 0 moves it on behind the last one, when every workgroup has read it)
+  __shared__ unsigned s_base;
+  if (threadIdx.x == 0) s_base = __hip_atomic_load(&ctl->base[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  epoch0 += s_base;
+  for (int ph = 0; ph < nphase; ++ph) {
+    seam_phase(buf, per_wg, ph, G, shift);
+    if (ph + 1 == nphase) break;
+    const unsigned epoch = epoch0 + (unsigned)ph + 1u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned a = __hip_atomic_fetch_add(&ctl->xcd[xcd][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      if (a == epoch * per_xcd) {
+        const unsigned t = __hip_atomic_fetch_add(&ctl->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (t == epoch * 8u)
+          for (int x = 0; x < 8; ++x) __hip_atomic_store(&ctl->gen[x][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      long long spins = 0;
+      while (__hip_atomic_load(&ctl->gen[xcd][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch && ++spins < (1ll << 24))
+        __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ph + 2 == nphase && blockIdx.x == 0)
+        __hip_atomic_store(&ctl->base[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+}
+}  // namespace tavsr
+
+// kind 0: `nphase` launches; kind 1: one launch with nphase - 1 grid barriers.  ctl: sizeof(SeamCtl) = 2304 zeroed bytes that persist
+// across calls (the barrier epochs only grow; the count of barriers taken so far lives in it, so the launch can be replayed from a graph;
+// epoch0: 0).  buf: nphase * grid * per_wg floats.
+extern "C" int tavsr_probe_seam(int32_t kind, int32_t grid, int64_t per_wg, int32_t nphase, float* buf, void* ctl, uint32_t epoch0,
+                                tavsr_stream_t stream) {
+  int shift = kind >> 8;          // (kind = form + 256 * (s + 1) + 0x1000000 * flags; shift 0: the default 97; flags 1: barriers only, 2: read old data)
+  const int flags = shift >> 16;
+  shift &= 0xffff;
+  kind &= 255;
+  TAVSR_REQUIRE(buf && (kind == 0 || ctl) && grid >= 8 && grid <= 256 && nphase >= 1 && per_wg >= 4 && per_wg % 4 == 0, TAVSR_EINVAL,
+                "probe_seam: 8 <= grid <= 256 (one workgroup per compute unit), per_wg %% 4 == 0");
+  if (kind == 0) {
+    for (int ph = 0; ph < nphase; ++ph)
+      hipLaunchKernelGGL(tavsr::seam_phase_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, buf, (long long)per_wg, ph,
+                         (shift ? shift - 1 : 97) | (flags << 16));
+  } else {
+    hipLaunchKernelGGL(tavsr::seam_fused_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, buf, (long long)per_wg, nphase,
+                       (tavsr::SeamCtl*)ctl, epoch0, (shift ? shift - 1 : 97) | (flags << 16));
+  }
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
 extern "C" int tavsr_race_probe(float us, int mode) {
   TAVSR_REQUIRE(us >= 0.f && us <= 1e6f && mode >= 0 && mode <= 2, TAVSR_EINVAL, "race_probe: us in 0 .. 1e6, mode 0 / 1 / 2");
   tavsr::g_probe_us = us;
