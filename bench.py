@@ -692,8 +692,20 @@ def main():
         if WORKLOAD == "avsr" and not args.no_asr:
             out["asr"] = bench_asr_step(dev)
     if rank == 0 and world == 1 and WORKLOAD == "avsr" and not args.no_decode and not args.no_fwd_encoder:
-        import bench_decode                 # BASELINE configs[4] on the driver's record (replicas only; nothing to scale here)
-        out["decode"] = bench_decode.driver_record(dev)
+        # BASELINE configs[4] on the driver's record (replicas only; nothing to scale here).  A process of its own: a batch-1 search is a
+        # chain of ~140 launches per token that the host must keep ahead of, and this process - its allocator pools, queues and heap after
+        # the training legs - runs the same search 14 % slower per token than a fresh one (731 vs 640 us on one box).  A child, started
+        # when this process has no GPU work in flight; never an exec.
+        import subprocess
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_decode.py"), "--driver-record"], capture_output=True, text=True,
+                               timeout=600, env=dict(os.environ))
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out["decode"] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:      # noqa: BLE001 - the headline line must still be printed
+            out["decode"] = {"error": repr(e)[:400]}
     if box is not None:
         out["box"] = box
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -108,7 +108,11 @@ def timed_decode(search, encode, dev, utterances, batch_size, rank=0, world=1, w
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1, hyps
 
-    run(make_utts(batch_size if warm_full else min(batch_size, 8), 7, dev))      # warm-up (allocator pools, lazy module state)
+    # warm-up: allocator pools, lazy module state, the captured step - and, for small batches, the chip's clocks: a batch-1 search keeps
+    # a few compute units busy, and the first utterances after an idle spell decode ~14 % slower per token than the following ones
+    # (p50 0.0157 with a p90 of 0.0182 over 16 utterances behind ONE warm-up utterance) - a serving process is past that
+    for _ in range(1 if not warm_full else max(1, 8 // batch_size)):
+        run(make_utts(batch_size if warm_full else min(batch_size, 8), 7, dev))
     data = [make_utts(len(b), 1234 + rank * 1000 + bi, dev) for bi, b in enumerate(batches)]   # resident in HBM
     if world > 1:
         torch.distributed.barrier()
@@ -154,7 +158,15 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cold-capture", action="store_true", help="warm up with at most 8 utterances (the protocol of rounds 1-4)")
+    ap.add_argument("--driver-record", action="store_true",
+                    help="print the `decode` object of bench.py's default line (batch-1 p50 RTF over 8 utterances, batch-64 utt/s over 128) and exit")
     args = ap.parse_args()
+
+    if args.driver_record:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        print(json.dumps(driver_record(dev)), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench_decode.py --gpus N`: start the N replicas as a child torch.distributed.run BEFORE this process

@@ -129,6 +129,13 @@ typedef struct tavsr_gemm_desc {
      channel_proj1's output, consumed by tavsr_csgu_fwd).  Unbatched problems on the 16-byte path, no K split; otherwise
      TAVSR_EUNSUPPORTED and nothing is launched. */
   float* rowstat;
+  /* with rowstat: per row and 64-column tile the two weighted sums (sum_n C[m][n] * rowdot_a[n], sum_n C[m][n] * rowdot_b[n]) instead of
+     (sum, sum of squares) - the learned-average merge's pooling / branch-weight projections of a branch output (encoder_layer.py:
+     246-280: pooling_proj_k, weight_proj_k are Linear(d, 1)) taken where the branch's last Linear stores its rows, so that
+     tavsr_merge_proj_fwd does not re-read both branch outputs of the whole utterance per workgroup.  [N] each, 16-byte aligned; both or
+     neither. */
+  const float* rowdot_a;
+  const float* rowdot_b;
 } tavsr_gemm_desc;
 
 int tavsr_gemm(const tavsr_gemm_desc* desc, tavsr_stream_t stream);
@@ -594,6 +601,14 @@ int tavsr_merge_proj_fwd(const float* x1, const float* x2, const int64_t* lens, 
                          const float* w, const float* bias, const float* res, float alpha, float p_drop, const uint64_t* seed_dev,
                          uint64_t drop_offset, float* dots, float* score, float* wout, float* mix, float* out, int32_t B, int32_t T,
                          int32_t D, tavsr_stream_t stream);
+/* ... with the row dots handed in: rowdots_k [B*T][4][2] = per row and 64-column tile of branch output x_k the two sums (<pooling_proj_k,
+ * x_k>, <weight_proj_k, x_k>) that the GEMM producing x_k left (tavsr_gemm_desc.rowstat with rowdot_a = pooling_proj_k.weight,
+ * rowdot_b = weight_proj_k.weight): the launch then reads 64 bytes per row and branch instead of both branch outputs of the whole
+ * utterance per workgroup.  Both NULL: tavsr_merge_proj_fwd. */
+int tavsr_merge_proj_fwd_dots(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2, const float* const* params,
+                              const float* w, const float* bias, const float* res, float alpha, float p_drop, const uint64_t* seed_dev,
+                              uint64_t drop_offset, const float* rowdots1, const float* rowdots2, float* dots, float* score, float* wout,
+                              float* mix, float* out, int32_t B, int32_t T, int32_t D, tavsr_stream_t stream);
 int64_t tavsr_merge_bwd_ws(int32_t B, int32_t D);
 int tavsr_merge_bwd(const float* dm, const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
                     const float* const* params, const float* score, const float* pooled, const float* w,

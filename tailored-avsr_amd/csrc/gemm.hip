@@ -509,8 +509,14 @@ __device__ __forceinline__ void finish_tile_vec(const tavsr_gemm_desc& d, int ns
     }
     *reinterpret_cast<float4*>(base + o) = v;
     }
-    if (rowstat) {       // the 16 lanes that share a row of a 64-wide tile: sum and sum of squares of what was stored
+    if (rowstat) {       // the 16 lanes that share a row of a 64-wide tile: sum and sum of squares of what was stored ...
       float s1 = ok ? (v.x + v.y) + (v.z + v.w) : 0.f, s2 = ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+      if (d.rowdot_a) {  // ... or its two weighted sums (tavsr_gemm_desc.rowdot_a / _b: the merge's pooling and branch-weight projections)
+        const float4 wa = ok ? *reinterpret_cast<const float4*>(d.rowdot_a + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 wb = ok ? *reinterpret_cast<const float4*>(d.rowdot_b + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s1 = (v.x * wa.x + v.y * wa.y) + (v.z * wa.z + v.w * wa.w);
+        s2 = (v.x * wb.x + v.y * wb.y) + (v.z * wb.z + v.w * wb.w);
+      }
 #pragma unroll
       for (int o2 = 8; o2 > 0; o2 >>= 1) { s1 += __shfl_xor(s1, o2, 64); s2 += __shfl_xor(s2, o2, 64); }
       if (c4 == 0 && m < d.M)
@@ -1533,9 +1539,12 @@ static int run(const tavsr_gemm_desc* dp, int force_cfg, int force_split, hipStr
     TAVSR_REQUIRE((fast || tail) && force_cfg < 0 && d.nb1 * d.nb2 == 1 && vec_epi_ok(d), TAVSR_EUNSUPPORTED,
                   "tavsr_gemm: epilogue dropout needs an unbatched problem on the 16-byte path");
   }
+  TAVSR_REQUIRE((d.rowdot_a == nullptr) == (d.rowdot_b == nullptr) && (!d.rowdot_a || d.rowstat), TAVSR_EINVAL,
+                "tavsr_gemm: rowdot_a and rowdot_b go together, with rowstat as their output");
   if (d.rowstat) {
-    TAVSR_REQUIRE(fast && force_cfg < 0 && d.nb1 * d.nb2 == 1 && vec_epi_ok(d) && aligned16(d.rowstat), TAVSR_EUNSUPPORTED,
-                  "tavsr_gemm: row statistics need an unbatched problem on the 16-byte path");
+    TAVSR_REQUIRE(fast && force_cfg < 0 && d.nb1 * d.nb2 == 1 && vec_epi_ok(d) && aligned16(d.rowstat) && aligned16(d.rowdot_a) &&
+                      aligned16(d.rowdot_b), TAVSR_EUNSUPPORTED,
+                  "tavsr_gemm: row statistics / row dots need an unbatched problem on the 16-byte path");
     return launch(8, d, vec, 1, d.K, s);             // 64-wide tiles, no K split: the statistics are taken where the tile is stored
   }
   Plan p = plan(d, can_split, fast || tail);

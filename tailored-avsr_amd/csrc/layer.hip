@@ -68,9 +68,15 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
     a.p_drop = d->p_att; a.seed_dev = d->seed; a.drop_offset = d->drop_off[2];
     if ((rc = tavsr_attn_fwd(&a, d->cx, D, d->lse, (tavsr_stream_t)s2))) return rc;
   }
+  // the merge's four row dots (pooling / branch-weight projections of both branch outputs) come out of the epilogues of the GEMMs that
+  // store those outputs (tavsr_gemm_desc.rowdot_*): [M][4 tiles][2] per branch, read by the tail launch instead of the rows themselves
+  float* rd1 = ws.take((int64_t)M * 8);
+  float* rd2 = ws.take((int64_t)M * 8);
+  TAVSR_REQUIRE(dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_fwd: workspace too small");
   {
     tavsr_gemm_desc go = lin(M, D, D, d->cx, D, d->wo, d->bo, d->xa, D);       // x_att = dropout(linear_out(ctx))
     go.drop_p = d->p_drop; go.drop_seed = d->seed; go.drop_offset = d->drop_off[3];
+    go.rowstat = rd1; go.rowdot_a = d->merge_p[0]; go.rowdot_b = d->merge_p[4];
     if ((rc = run_gemm(go, ws, s2))) return rc;
   }
   // ---- cgMLP branch on the calling queue
@@ -89,6 +95,7 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
       return rc;
     tavsr_gemm_desc g2 = lin(M, D, Cn, d->u, Cn, d->cg_w2, d->cg_b2, d->xm, D);
     g2.drop_p = d->p_drop; g2.drop_seed = d->seed; g2.drop_offset = d->drop_off[5];
+    g2.rowstat = rd2; g2.rowdot_a = d->merge_p[1]; g2.rowdot_b = d->merge_p[5];
     if ((rc = run_gemm(g2, ws, s))) return rc;
   }
   if (!dry) {
@@ -97,9 +104,9 @@ int sequence(const tavsr_bf_layer_desc* d, hipStream_t s, Bump& ws) {
     if ((rc = probe_fork(s2, s, true))) return rc;
     // ---- the tail behind the join as one launch: learned-average merge (d->pooled receives the row dots [4][B*T] its backward
     //      reads), x2 = x1 + coeff dropout(merge_proj(m))
-    if ((rc = tavsr_merge_proj_fwd(d->xa, d->xm, d->lens, nullptr, d->merge_p, d->merge_w, d->merge_b, d->x1, d->coeff, d->p_drop,
-                                   d->seed, d->drop_off[6], d->pooled, d->score, d->wts, d->save ? d->m : nullptr, d->x2, d->B, d->T,
-                                   D, (tavsr_stream_t)s)))
+    if ((rc = tavsr_merge_proj_fwd_dots(d->xa, d->xm, d->lens, nullptr, d->merge_p, d->merge_w, d->merge_b, d->x1, d->coeff, d->p_drop,
+                                        d->seed, d->drop_off[6], rd1, rd2, d->pooled, d->score, d->wts, d->save ? d->m : nullptr, d->x2,
+                                        d->B, d->T, D, (tavsr_stream_t)s)))
       return rc;
   }
   // ---- x3 = x2 + 0.5 dropout(ffn(norm_ff(x2))); y = norm_final(x3)

@@ -41,6 +41,7 @@ struct MpArgs {
   uint64_t offset4;
   float *dots, *score, *wout, *mix, *out;
   int B, T;
+  const float *rd1, *rd2;      // [B T][4][2]: per row and 64-column tile (<wp_k, x_k>, <ww_k, x_k>) from the producers' GEMM epilogues (or null)
 };
 
 __device__ __forceinline__ float dot4f(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
@@ -88,7 +89,20 @@ __global__ __launch_bounds__(256) void merge_proj_fwd_kernel(const MpArgs a) {
   }
 
   // ---- phase 0: dots of every frame of the utterance
-  {
+  if (a.rd1) {
+    // the branches' last Linear launches left them as four partial sums per row (tavsr_gemm_desc.rowdot_*): 64 bytes per row and
+    // branch instead of the 2 KB of the rows themselves (every workgroup of an utterance used to re-read all of them from L2)
+    for (int t = tid; t < T; t += 256) {
+      const float4* p1 = reinterpret_cast<const float4*>(a.rd1 + (r0 + t) * 8);
+      const float4* p2 = reinterpret_cast<const float4*>(a.rd2 + (r0 + t) * 8);
+      const float4 u0 = p1[0], u1 = p1[1], v0 = p2[0], v1 = p2[1];         // (tile 0: pool, weight | tile 1: pool, weight), (tiles 2, 3)
+      s_s[t] = (u0.x + u0.z) + (u1.x + u1.z);
+      s_q[t] = (u0.y + u0.w) + (u1.y + u1.w);
+      s_s[T + t] = (v0.x + v0.z) + (v1.x + v1.z);
+      s_q[T + t] = (v0.y + v0.w) + (v1.y + v1.w);
+    }
+  } else {
+
     float4 wp1[4], wp2[4], ww1[4], ww2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -247,6 +261,18 @@ extern "C" int tavsr_merge_proj_fwd(const float* x1, const float* x2, const int6
                                     const float* const* params, const float* w, const float* bias, const float* res, float alpha,
                                     float p_drop, const uint64_t* seed, uint64_t drop_offset, float* dots, float* score, float* wout,
                                     float* mix, float* out, int32_t B, int32_t T, int32_t D, tavsr_stream_t stream) {
+  return tavsr_merge_proj_fwd_dots(x1, x2, lens, lens2, params, w, bias, res, alpha, p_drop, seed, drop_offset, nullptr, nullptr, dots,
+                                   score, wout, mix, out, B, T, D, stream);
+}
+
+extern "C" int tavsr_merge_proj_fwd_dots(const float* x1, const float* x2, const int64_t* lens, const int64_t* lens2,
+                                         const float* const* params, const float* w, const float* bias, const float* res, float alpha,
+                                         float p_drop, const uint64_t* seed, uint64_t drop_offset, const float* rowdots1,
+                                         const float* rowdots2, float* dots, float* score, float* wout, float* mix, float* out,
+                                         int32_t B, int32_t T, int32_t D, tavsr_stream_t stream) {
+  TAVSR_REQUIRE((rowdots1 == nullptr) == (rowdots2 == nullptr), TAVSR_EINVAL, "merge_proj_fwd: the row dots of both branches or of neither");
+  TAVSR_REQUIRE(((reinterpret_cast<uintptr_t>(rowdots1) | reinterpret_cast<uintptr_t>(rowdots2)) & 15) == 0, TAVSR_EALIGN,
+                "merge_proj_fwd: row dots must be 16-byte aligned");
   TAVSR_REQUIRE(x1 && x2 && params && w && bias && dots && score && wout && out, TAVSR_EINVAL, "merge_proj_fwd: null pointer");
   for (int i = 0; i < 8; ++i) TAVSR_REQUIRE(params[i], TAVSR_EINVAL, "merge_proj_fwd: null parameter %d", i);
   TAVSR_REQUIRE(tavsr_merge_proj_ok(T, D), TAVSR_EUNSUPPORTED, "merge_proj_fwd: D == 256 and T <= 2048 required (T=%d D=%d)", T, D);
@@ -265,6 +291,7 @@ extern "C" int tavsr_merge_proj_fwd(const float* x1, const float* x2, const int6
   a.seed = seed; a.offset4 = drop_offset >> 2;
   a.dots = dots; a.score = score; a.wout = wout; a.mix = mix; a.out = out;
   a.B = B; a.T = T;
+  a.rd1 = rowdots1; a.rd2 = rowdots2;
   const size_t lds = (size_t)(((4 * T + 3) & ~3) + 2 * MP_R * MP_LD) * sizeof(float);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_proj_fwd_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);     // T = 2048: 66 KB

@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
         ("conv_mode", C.c_int32), ("conv_H", C.c_int32), ("conv_W", C.c_int32), ("conv_C", C.c_int32),
         ("conv_zero", C.c_void_p), ("conv_stride", C.c_int32), ("conv_taps", C.c_int32),
         ("drop_p", C.c_float), ("drop_seed", C.c_void_p), ("drop_offset", C.c_uint64),
-        ("rowstat", C.c_void_p),
+        ("rowstat", C.c_void_p), ("rowdot_a", C.c_void_p), ("rowdot_b", C.c_void_p),
     ]
 
 

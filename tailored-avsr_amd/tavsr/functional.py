@@ -567,6 +567,16 @@ class BranchformerLayerFn(torch.autograd.Function):
         two = has_attn and has_mlp
         cat = ops.empty(M, 2 * D, like=x) if merge == "concat" else None
         xa = xm = None
+        mp = rd = None
+        use_rd = False
+        if two and merge == "learned_ave":
+            mp = [p(k) for k in ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias",
+                                 "pooling_proj2.bias", "weight_proj1.weight", "weight_proj2.weight",
+                                 "weight_proj1.bias", "weight_proj2.bias")]
+            rd = [None, None]
+            # the fused tail takes the merge's row dots from the epilogues of the launches that store the branch outputs
+            use_rd = (ops.MERGE_ROWDOT and not cfg["merge_identity"] and ops.MERGE_PROJ and ops.MERGE_ROWS
+                      and bool(ops.lib().tavsr_merge_proj_ok(T, D)))
         br = ops.BranchScope(two)     # attention branch beside the cgMLP branch (joined before the merge)
         with br:
             if has_attn:
@@ -590,7 +600,11 @@ class BranchformerLayerFn(torch.autograd.Function):
                     ops.linear(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), out=cat, out_off=0, ldc=2 * D)
                     xa = cat[:, :D]
                 else:
-                    xa, t_xa = ops.linear_drop(cx, p("attn.linear_out.weight"), p("attn.linear_out.bias"), pd)   # x1 = dropout(x_att)  (encoder_layer.py:212)
+                    wo_ = p("attn.linear_out.weight")
+                    if use_rd and ops.rowdot_ok(cx, wo_):     # ... and the merge's row dots of x1 from the same launch's epilogue
+                        xa, t_xa, rd[0] = ops.linear_drop(cx, wo_, p("attn.linear_out.bias"), pd, rowdot=(mp[0], mp[4]))
+                    else:
+                        xa, t_xa = ops.linear_drop(cx, wo_, p("attn.linear_out.bias"), pd)   # x1 = dropout(x_att)  (encoder_layer.py:212)
                 sv["attn"] = (mean, rstd, n, qkv, pp, qu, qv, cx, attn, t_att, t_xa)
         if has_mlp:
             n, mean, rstd = nbr[-1], bmean, brstd
@@ -619,20 +633,22 @@ class BranchformerLayerFn(torch.autograd.Function):
                            ldc=2 * D)
                 xm = cat[:, D:]
             else:
-                xm, t_xm = ops.linear_drop(u, p("cgmlp.channel_proj2.weight"), p("cgmlp.channel_proj2.bias"), pd)   # x2 = dropout(x2)  (encoder_layer.py:224)
+                w2_ = p("cgmlp.channel_proj2.weight")
+                if use_rd and ops.rowdot_ok(u, w2_):
+                    xm, t_xm, rd[1] = ops.linear_drop(u, w2_, p("cgmlp.channel_proj2.bias"), pd, rowdot=(mp[1], mp[5]))
+                else:
+                    xm, t_xm = ops.linear_drop(u, w2_, p("cgmlp.channel_proj2.bias"), pd)   # x2 = dropout(x2)  (encoder_layer.py:224)
             sv["mlp"] = (mean, rstd, n, g, z, gn, gmean, grstd, u, conv, t_u, t_xm)
         br.join()
         t_cat = _drop_(cat, pd) if (merge == "concat" and cat is not None) else None   # both halves in one call (iid)
         wts = None
         x2 = None
         if two and merge == "learned_ave":
-            mp = [p(k) for k in ("pooling_proj1.weight", "pooling_proj2.weight", "pooling_proj1.bias",
-                                 "pooling_proj2.bias", "weight_proj1.weight", "weight_proj2.weight",
-                                 "weight_proj1.bias", "weight_proj2.bias")]
             if not cfg["merge_identity"] and ops.merge_proj_ok(xa, xm, p("merge_proj.weight"), T, D, res=x1):
                 # merge + merge_proj + dropout + residual: the whole tail behind the join as ONE launch
                 score, pooled, wts, m, x2, t_m = ops.merge_proj_fwd(xa, xm, lens, mp, p("merge_proj.weight"), p("merge_proj.bias"),
-                                                                    x1, coeff, pd, B, T, save=need)
+                                                                    x1, coeff, pd, B, T, save=need,
+                                                                    rowdots=(rd[0], rd[1]) if rd[0] is not None and rd[1] is not None else None)
             else:
                 score, pooled, wts, m = ops.merge_fwd(xa, xm, lens, mp, B, T)       # pooling + weighted sum: one launch for T <= 128
             sv["merge"] = (score, pooled, wts, m)

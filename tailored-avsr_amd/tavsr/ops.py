@@ -66,7 +66,7 @@ def _zero_page(device) -> torch.Tensor:
 def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False,
          nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=None, alpha=1.0, Z=None,
          R=None, r_off=0, ldr=0, sR=(0, 0), DZ=None, dact=None, a_rowsum=None, conv=None, force=None, ws_cap=None,
-         drop=None, rowstat=None, ln=None):
+         drop=None, rowstat=None, ln=None, rowdot=None):
     """Raw descriptor call; offsets are in elements into the given tensors.  ``force=(cfg, nsplit)`` bypasses
     the planner (tuning / tests); ``ws_cap`` caps the split-K workspace handed to the library (tests of its fallback).
     ``ln`` = (gamma, beta, eps, out [M, N]): also the LayerNorm of the result rows (tavsr_gemm_ln)."""
@@ -95,6 +95,9 @@ def gemm(M, N, K, A, lda, B, ldb, Cc, ldc, *, a_off=0, b_off=0, c_off=0, a_kmajo
         d.drop_p, d.drop_offset, d.drop_seed = drop[0], drop[1], _addr(drop[2])
     if rowstat is not None:     # [M, ceil(N / 64), 2]: per-row (sum, sum of squares) of every 64-column tile of the result
         d.rowstat = _addr(rowstat)
+        if rowdot is not None:  # ... or the two weighted sums (<rowdot[0], row>, <rowdot[1], row>) per tile (tavsr_gemm_desc.rowdot_*)
+            require_cuda(rowdot[0], rowdot[1])
+            d.rowdot_a, d.rowdot_b = _addr(rowdot[0]), _addr(rowdot[1])
     if conv is not None:       # (mode, H, W, C[, stride, taps]): implicit convolution operand (include/tavsr.h)
         d.conv_mode, d.conv_H, d.conv_W, d.conv_C = conv[:4]
         if len(conv) > 4:
@@ -187,11 +190,26 @@ def _drop_fusable(x, N, K) -> bool:
     return N % 4 == 0 and K % 32 == 0 and K >= 32 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
 
 
-def linear_drop(x, w, b, p, *, act=None, alpha=1.0, res=None, save_z=False):
+def rowdot_ok(x, w) -> bool:
+    """can the Linear x @ w.T leave weighted row sums of its result (tavsr_gemm_desc.rowstat + rowdot_*: the fast kernel, no K split)?"""
+    K, N = x.shape[1], w.shape[0]
+    return (N % 64 == 0 and K % 32 == 0 and K <= 1024 and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0)
+
+
+def linear_drop(x, w, b, p, *, act=None, alpha=1.0, res=None, save_z=False, rowdot=None):
     """out = res + alpha * dropout(act(x @ w.T + b), p) -> (out[, z], token); one launch when the GEMM's 16-byte epilogue
-    can carry the mask (else GEMM + dropout / dropout_add launches with the same mask and token)."""
+    can carry the mask (else GEMM + dropout / dropout_add launches with the same mask and token).  ``rowdot`` = (a [N], b [N]) with
+    ``rowdot_ok(x, w)``: also returns rd [M, N / 64, 2] = per row and 64-column tile (<a, out row>, <b, out row>) as the LAST element."""
     M, K = x.shape
     N = w.shape[0]
+    if rowdot is not None:
+        assert not save_z and res is None and act is None and rowdot_ok(x, w)
+        rd = empty(M, N // 64, 2, like=x)
+        out = empty(M, N, like=x)
+        tok = _new_token(p, M * N, x.device) if p and p > 0.0 else None
+        gemm(M, N, K, x, x.stride(0), w, w.stride(0), out, N, bias=b, alpha=alpha, drop=tok, rowstat=rd, rowdot=rowdot)
+        return out, tok, rd
     if not p or p <= 0.0:
         r = linear(x, w, b, act=act, alpha=alpha, res=res, save_z=save_z)
         return (r[0], r[1], None) if save_z else (r, None)
@@ -1051,6 +1069,7 @@ def merge_fwd(x1, x2, lens, params, B, T, lens2=None):
 
 
 MERGE_PROJ = os.environ.get("TAVSR_MERGE_PROJ", "1") == "1"      # A/B switch: merge + merge_proj + residual as one launch
+MERGE_ROWDOT = os.environ.get("TAVSR_MERGE_ROWDOT", "1") != "0"      # the fused tail reads the merge's row dots from the producers' GEMM epilogues (flipped in tests/test_gpu_switches.py)
 
 
 def merge_proj_ok(x1, x2, w, T, D, res=None) -> bool:
@@ -1058,7 +1077,7 @@ def merge_proj_ok(x1, x2, w, T, D, res=None) -> bool:
             and (res is None or res.is_contiguous()) and bool(lib().tavsr_merge_proj_ok(T, D)))
 
 
-def merge_proj_fwd(x1, x2, lens, params, w, b, res, alpha, p, B, T, lens2=None, save=True):
+def merge_proj_fwd(x1, x2, lens, params, w, b, res, alpha, p, B, T, lens2=None, save=True, rowdots=None):
     """the layer's tail behind the branch join in one launch (csrc/mergeproj.hip): learned_ave merge of x1 / x2 and
     ``res + alpha * dropout(merge_proj(mix), p)`` -> (score, dots, wts, mix | None, out, token).  ``dots`` / ``score`` / ``wts`` are
     what ``merge_bwd`` wants back (the row-parallel route's saved tensors), ``mix`` merge_proj's saved input (``save``)."""
@@ -1069,10 +1088,12 @@ def merge_proj_fwd(x1, x2, lens, params, w, b, res, alpha, p, B, T, lens2=None, 
     mix = torch.empty_like(x1) if save else None
     out = torch.empty_like(x1)
     tok = _new_token(p, M * D, x1.device) if p and p > 0.0 else None
-    check(lib().tavsr_merge_proj_fwd(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(w), ptr(b), ptr(res),
-                                     C.c_float(alpha), C.c_float(p if tok is not None else 0.0), ptr(None if tok is None else tok[2]),
-                                     C.c_uint64(0 if tok is None else tok[1]), ptr(dots), ptr(score), ptr(wts), ptr(mix), ptr(out),
-                                     B, T, D, stream()), "tavsr_merge_proj_fwd")
+    rd1, rd2 = rowdots if rowdots is not None else (None, None)      # the producers' GEMM epilogues left the row dots (linear_drop(rowdot=))
+    assert rd1 is None or (rd1.shape == (M, 4, 2) and rd2.shape == (M, 4, 2) and rd1.is_contiguous() and rd2.is_contiguous())
+    check(lib().tavsr_merge_proj_fwd_dots(ptr(x1), ptr(x2), ptr(lens), ptr(lens2), _ptr_array(params), ptr(w), ptr(b), ptr(res),
+                                          C.c_float(alpha), C.c_float(p if tok is not None else 0.0), ptr(None if tok is None else tok[2]),
+                                          C.c_uint64(0 if tok is None else tok[1]), ptr(rd1), ptr(rd2), ptr(dots), ptr(score), ptr(wts),
+                                          ptr(mix), ptr(out), B, T, D, stream()), "tavsr_merge_proj_fwd_dots")
     return score, dots, wts, mix, out, tok
 
 

@@ -339,6 +339,34 @@ def test_merge_proj_fused_tail_matches_fp64_and_the_launches_it_replaces(B, T, p
     ops.rng_step_begin(x1.device)
     _, _, _, none_mix, out2, _ = ops.merge_proj_fwd(x1, x2, lens, prm, W, bias, res, coeff, p, B, T, save=False)
     assert none_mix is None and torch.equal(out2, out)
+    # the row dots handed in by the launches that produce the branch outputs (tavsr_gemm_desc.rowdot_*): x_k = dropout(Linear(c_k)), the
+    # merge's pooling / branch-weight projections of x_k per 64-column tile from that launch's epilogue - same tail, no re-read of the rows
+    c1, c2 = torch.randn(B * T, 256, device="cuda"), torch.randn(B * T, 1024, device="cuda")
+    w1, b1, w2, b2 = torch.randn(D, 256, device="cuda") / 16, torch.randn(D, device="cuda"), torch.randn(D, 1024, device="cuda") / 32, torch.randn(D, device="cuda")
+    assert ops.rowdot_ok(c1, w1) and ops.rowdot_ok(c2, w2)
+    ops.manual_seed(78)
+    ops.rng_step_begin(x1.device)
+    y1, t1, rd1 = ops.linear_drop(c1, w1, b1, p, rowdot=(prm[0], prm[4]))
+    y2, t2, rd2 = ops.linear_drop(c2, w2, b2, p, rowdot=(prm[1], prm[5]))
+    ops.manual_seed(78)
+    ops.rng_step_begin(x1.device)
+    z1, u1 = ops.linear_drop(c1, w1, b1, p)
+    z2, u2 = ops.linear_drop(c2, w2, b2, p)
+    assert (t1 is None) == (u1 is None)
+    _close(y1, z1, 2e-6)              # (the row-dot form runs without a K split: equal up to the order of the K = 1024 sum)
+    _close(y2, z2, 2e-6)
+    for y, rdk, k in ((y1, rd1, 0), (y2, rd2, 1)):
+        want = torch.stack([(y.double().view(-1, 4, 64) * prm[k].double().view(1, 4, 64)).sum(-1),
+                            (y.double().view(-1, 4, 64) * prm[4 + k].double().view(1, 4, 64)).sum(-1)], -1)
+        _close(rdk, want, 2e-5)
+    ops.manual_seed(79)
+    ops.rng_step_begin(x1.device)
+    sc_a, dots_a, wts_a, mix_a, out_a, _ = ops.merge_proj_fwd(y1, y2, lens, prm, W, bias, res, coeff, p, B, T)
+    ops.manual_seed(79)
+    ops.rng_step_begin(x1.device)
+    sc_b, dots_b, wts_b, mix_b, out_b, _ = ops.merge_proj_fwd(y1, y2, lens, prm, W, bias, res, coeff, p, B, T, rowdots=(rd1, rd2))
+    for a_, b_ in ((sc_a, sc_b), (dots_a, dots_b), (wts_a, wts_b), (mix_a, mix_b), (out_a, out_b)):
+        _close(b_, a_, 2e-5)
     # the saved tensors drive the existing backward
     dm = torch.randn(B * T, D, device="cuda")
     a = ops.merge_bwd(dm, x1, x2, lens, prm, score, dots, wts, B, T)

@@ -19,7 +19,7 @@ from helpers import AVSR_YAML, asr_conf, avsr_conf, grad_ok
 pytestmark = pytest.mark.gpu
 
 ASR_SWITCHES = [("tavsr.ops", "FFN2", False), ("tavsr.ops", "FFN2_BWD", False), ("tavsr.ops", "MERGE_ROWS", False),
-                ("tavsr.ops", "MERGE_PROJ", False), ("tavsr.ops", "LN_BWD_DROP", False), ("tavsr.ops", "LAYER_C", False),
+                ("tavsr.ops", "MERGE_PROJ", False), ("tavsr.ops", "MERGE_ROWDOT", False), ("tavsr.ops", "LN_BWD_DROP", False), ("tavsr.ops", "LAYER_C", False),
                 ("tavsr.ops", "ATTN_FUSED", False), ("tavsr.ops", "CSGU_FUSED", False), ("tavsr.ops", "CSGU_STATS_IN_GEMM", False),
                 ("tavsr.ops", "CGMLP_ACT_BWD_FUSED", False), ("tavsr.functional", "CONV2_IMPLICIT", False),
                 ("tavsr.models.espnet_model", "LOSS_BRANCH", False), ("tavsr._lib", "SINGLE_STREAM", True)]
@@ -83,7 +83,7 @@ def test_every_route_selector_of_the_audio_only_step():
 
 def test_the_mask_preserving_routes_agree_under_dropout():
     """the fused launches draw the masks of the launches they replace (same Philox counters): also equal with dropout on"""
-    _flip_and_compare("asr", [s for s in ASR_SWITCHES if s[1] in ("FFN2", "FFN2_BWD", "MERGE_PROJ", "LN_BWD_DROP", "LAYER_C",
+    _flip_and_compare("asr", [s for s in ASR_SWITCHES if s[1] in ("FFN2", "FFN2_BWD", "MERGE_PROJ", "MERGE_ROWDOT", "LN_BWD_DROP", "LAYER_C",
                                                                    "CSGU_FUSED", "LOSS_BRANCH", "SINGLE_STREAM")], 0.1)
 
 
