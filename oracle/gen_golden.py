@@ -312,6 +312,19 @@ def gen_tailored():
         _save(f"av_tailored_layer_{tag}", B=B, T=T, D=D, alens=_np(alens), vlens=_np(vlens), ya=_np(ya), yv=_np(yv),
               grad_a=_np(a.grad), grad_v=_np(v.grad), keys=np.array(sorted(layer.state_dict().keys())), **grads)
 
+    _gen_tailored_encoder("av_tailored_encoder_4L_fusion", B, T, alens, vlens, 1)
+    # the reference's real length range (500 lip frames = 20 s, src/datasets/avsr_dataset.py:27): every 7th output row is stored
+    _gen_tailored_encoder("av_tailored_encoder_4L_fusion_T500", 2, 500, torch.tensor([500, 300]), torch.tensor([500, 304]), 7)
+
+
+def _gen_tailored_encoder(name, B, T, alens, vlens, row_step):
+    from espnet.nets.pytorch_backend.transformer.embedding import RelPositionalEncoding
+    from src.audiovisual_fusion.adaptive_audiovisual_fusion import AdaptiveAudioVisualFusion
+    from src.encoder.audiovisual.tailored.encoder import TailoredEncoder
+    D = 256
+    am = (torch.arange(T)[None, :] < alens[:, None])[:, None, :]
+    vm = (torch.arange(T)[None, :] < vlens[:, None])[:, None, :]
+    pe = RelPositionalEncoding(D, 0.0)
     conf = avsr_conf(num_blocks=4)["encoder_conf"]
     enc = TailoredEncoder("rel_pos", "latest", **conf).train()
     fusion = AdaptiveAudioVisualFusion(input_size=256, **avsr_conf()["audiovisual_fusion_conf"]).train()
@@ -330,8 +343,10 @@ def gen_tailored():
              ["modality_encoding.weight", "encoders.0.feed_forward.w_1.weight", "encoders.3.norm_final.bias",
               "after_norm.weight", "encoders.1.acoustic_attn.linear_q.weight", "encoders.0.acoustic_cgmlp.csgu.conv.bias"]}
     grads.update({"g_fus." + n: compact(p.grad) for n, p in pf.items()})
-    _save("av_tailored_encoder_4L_fusion", B=B, T=T, D=D, alens=_np(alens), vlens=_np(vlens), ya=_np(ya), yv=_np(yv),
-          yf=_np(yf), olens=_np(olens), grad_a=_np(a.grad), grad_v=_np(v.grad),
+    rows = slice(None, None, row_step)
+    extra = {} if row_step == 1 else {"row_step": row_step}
+    _save(name, B=B, T=T, D=D, **extra, alens=_np(alens), vlens=_np(vlens), ya=_np(ya[:, rows]), yv=_np(yv[:, rows]),
+          yf=_np(yf[:, rows]), olens=_np(olens), grad_a=_np(a.grad[:, rows]), grad_v=_np(v.grad[:, rows]),
           acoustic_weight=_np(fusion.acoustic_weight), visual_weight=_np(fusion.visual_weight),
           enc_keys=np.array(sorted(enc.state_dict().keys())), fus_keys=np.array(sorted(fusion.state_dict().keys())), **grads)
 
@@ -505,6 +520,9 @@ def main():
         return
     if "--encoders-only" in sys.argv:
         gen_encoders()
+        return
+    if "--tailored-only" in sys.argv:
+        gen_tailored()
         return
     if "--interctc-only" in sys.argv:
         gen_interctc()

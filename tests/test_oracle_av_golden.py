@@ -88,9 +88,11 @@ def test_tailored_layer_matches_reference(tag, ua, uv):
             assert rel_err(compact(p.grad), g["g_" + n]) < 1e-4, n
 
 
-def test_tailored_encoder_and_fusion_match_reference():
-    g = golden("av_tailored_encoder_4L_fusion")
+@pytest.mark.parametrize("name", ["av_tailored_encoder_4L_fusion", "av_tailored_encoder_4L_fusion_T500"])
+def test_tailored_encoder_and_fusion_match_reference(name):
+    g = golden(name)
     B, T, D = int(g["B"]), int(g["T"]), int(g["D"])
+    rows = slice(None, None, int(g["row_step"]) if "row_step" in g.files else 1)      # (the 20 s fixture keeps every 7th output row)
     enc = TailoredEncoderOracle("rel_pos", "latest", **avsr_conf(num_blocks=4)["encoder_conf"]).train()
     fusion = AdaptiveFusionOracle(input_size=256, **avsr_conf()["audiovisual_fusion_conf"]).train()
     assert sorted(enc.state_dict().keys()) == list(g["enc_keys"])
@@ -106,10 +108,10 @@ def test_tailored_encoder_and_fusion_match_reference():
     ya, oam, yv, ovm, _ = enc((xa, pos), am, (xv, pos), vm)
     yf, olens = fusion(ya, oam, yv, ovm)
     (yf * synth((B, T, D), seed=85)).sum().backward()
-    assert max_rel(ya, g["ya"]) < TOL and max_rel(yv, g["yv"]) < TOL and max_rel(yf, g["yf"]) < TOL
+    assert max_rel(ya[:, rows], g["ya"]) < TOL and max_rel(yv[:, rows], g["yv"]) < TOL and max_rel(yf[:, rows], g["yf"]) < TOL
     assert np.array_equal(olens.numpy(), g["olens"])
     assert rel_err(fusion.acoustic_weight, g["acoustic_weight"]) < 1e-5
-    assert rel_err(a.grad, g["grad_a"]) < 2e-4 and rel_err(v.grad, g["grad_v"]) < 2e-4
+    assert rel_err(a.grad[:, rows], g["grad_a"]) < 2e-4 and rel_err(v.grad[:, rows], g["grad_v"]) < 2e-4
     pe_, pf = dict(enc.named_parameters()), dict(fusion.named_parameters())
     for k in g.files:
         if k.startswith("g_enc."):
