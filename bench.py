@@ -12,7 +12,12 @@ its own batch of 32; ranks exchange gradients once per step (RCCL all-reduce, ta
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   box          - in-process calibration of THIS device before the model is built (fp32 MFMA microbench, HBM copy);
-  asr          - BASELINE configs[1] (the audio-only step) under the same protocol, so the driver's record holds it too;
+  asr          - BASELINE configs[1] (the audio-only step) under the same protocol, so the driver's record holds it too (with its own
+                 CPU figure);
+  decode       - BASELINE configs[4] (beam 10 + 16 x 512 LM on the AV model): batch-1 p50 RTF over 8 utterances of 4 s and batch-64
+                 utterances/s over 128, taken by a child `bench_decode.py --driver-record` when this process has no GPU work in flight;
+  rccl_world, dist_world, dist_backend, hbm_peak_gb_per_rank - which exchange really ran (ranks of the C ABI's RCCL communicator,
+                 0 = none) and every rank's peak device memory: the first things to read on an N > 1 line;
   fwd_encoder  - north_star's forward target (12-layer Branchformer forward, batch 32);
   roofline     - the dominant kernel (fp32 MFMA GEMM instantiation with the largest total time): algorithmic
                  FLOPs / HIP-event launch durations, measured in a separate instrumented replay of the same step;
