@@ -466,7 +466,12 @@ def test_config5_full_av_model_beam10_lm16x512_matches_oracle():
         genc, golens = pm.encode(audio.cuda(), alens.cuda(), video.cuda(), vlens.cuda())
         assert torch.equal(golens.cpu(), olens)
         assert float((genc.cpu() - enc).abs().max() / enc.abs().max()) < 1e-4
-        ref = [BS.build_beam_search(m, lm, 10, 0.1, 0.6, 0.5).forward(enc[u, : int(olens[u])]) for u in range(2)]
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(min(16, nthreads))     # one-token steps on [10, 512] rows: 128 host threads only add wake-ups
+        try:
+            ref = [BS.build_beam_search(m, lm, 10, 0.1, 0.6, 0.5).forward(enc[u, : int(olens[u])]) for u in range(2)]
+        finally:
+            torch.set_num_threads(nthreads)
         hip = BatchBeamSearch(pm, plm, 10, 0.1, 0.6, 0.5).decode(genc, golens)
     for u in range(2):
         assert len(hip[u]) > 0 and len(ref[u]) > 0
