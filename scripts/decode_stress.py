@@ -8,6 +8,9 @@ from tavsr.inference import beam_search as B
 from tavsr.lm.transformer_lm import TransformerLM
 from tavsr.tasks.avsr import AVSRTask
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for flag in sys.argv[2:]:              # e.g. CTC_BESIDE_SCORERS=0 RECORD_QUEUE=0: module constants of the search, flipped for this run
+    k, v = flag.split("=")
+    setattr(B, k, v not in ("0", "False"))
 dev = torch.device("cuda:0")
 conf = BD.make_conf()
 torch.manual_seed(1)

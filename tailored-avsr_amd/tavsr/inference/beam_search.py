@@ -75,9 +75,10 @@ PREBEAM_FUSED = True   # pre-beam top-k inside the CTC prefix launch
 # Vocabularies of up to 64 tokens (character models): the CTC prefix scores of EVERY token are computed beside the LM's chain, in front
 # of the decoder's - the recursion over the frames (20 us) leaves the critical path of a captured step - and the whole beam update
 # behind the scorers (LM log-softmax, pre-beam, weighted scores, top-k) is one launch (tavsr_beam_select_topk).
-RECORD_QUEUE = os.environ.get("TAVSR_DECODE_RECORD_QUEUE", "1") != "0"     # per-token records leave on a queue of their own
-LN_IN_EPILOGUE = os.environ.get("TAVSR_DECODE_LN_EPILOGUE", "1") != "0"     # batched steps: tavsr_gemm_ln at the x + f(x) -> norm(x) seams
-CTC_BESIDE_SCORERS = os.environ.get("TAVSR_DECODE_CTC_BESIDE", "1") != "0"
+# (module constants, flipped in-process by tests/test_beam_search.py and scripts/decode_chain_probe.py - not environment switches)
+RECORD_QUEUE = True        # per-token records leave on a queue of their own
+LN_IN_EPILOGUE = True      # batched steps: tavsr_gemm_ln at the x + f(x) -> norm(x) seams
+CTC_BESIDE_SCORERS = True
 
 
 class _Normed:

@@ -1069,7 +1069,7 @@ def merge_fwd(x1, x2, lens, params, B, T, lens2=None):
 
 
 MERGE_PROJ = os.environ.get("TAVSR_MERGE_PROJ", "1") == "1"      # A/B switch: merge + merge_proj + residual as one launch
-MERGE_ROWDOT = os.environ.get("TAVSR_MERGE_ROWDOT", "1") != "0"      # the fused tail reads the merge's row dots from the producers' GEMM epilogues (flipped in tests/test_gpu_switches.py)
+MERGE_ROWDOT = True      # the fused tail reads the merge's row dots from the producers' GEMM epilogues (flipped in tests/test_gpu_switches.py)
 
 
 def merge_proj_ok(x1, x2, w, T, D, res=None) -> bool:
