@@ -61,15 +61,23 @@ def cpu_baseline(model_state, lm_state, n_utt=1):
     lm = BS.TransformerLMOracle(len(conf["token_list"]), **LM_CONF).eval()
     lm.load_state_dict(lm_state)
     batch = make_utts(n_utt, 99, "cpu")
+    threads = torch.get_num_threads()
     t0 = time.perf_counter()
     with torch.no_grad():
         enc, olens = model.encode(*batch)
-        for u in range(n_utt):
-            BS.build_beam_search(model, lm, SEARCH["beam_size"], SEARCH["ctc_weight"], SEARCH["lm_weight"],
-                                 SEARCH["penalty"]).forward(enc[u, : int(olens[u])])
+        # the search is ~100 one-token steps on [10, 512] rows per utterance: more than ~16 host threads only add wake-ups (it ran
+        # 2 - 3x slower on all 128); the encoder above uses every core
+        torch.set_num_threads(min(16, threads))
+        try:
+            for u in range(n_utt):
+                BS.build_beam_search(model, lm, SEARCH["beam_size"], SEARCH["ctc_weight"], SEARCH["lm_weight"],
+                                     SEARCH["penalty"]).forward(enc[u, : int(olens[u])])
+        finally:
+            torch.set_num_threads(threads)
     el = time.perf_counter() - t0
-    return {"value": round(el / (n_utt * DUR_S), 4), "unit": "RTF", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_utt} utterance(s) of 4 s, encoder + beam-{SEARCH['beam_size']} + LM on the CPU oracle, {el:.1f} s"}
+    return {"value": round(el / (n_utt * DUR_S), 4), "unit": "RTF", "cores": threads, "kind": "port",
+            "sample": f"{n_utt} utterance(s) of 4 s, encoder ({threads} threads) + beam-{SEARCH['beam_size']} + LM (min(16, {threads}) threads) on "
+                      f"the CPU oracle, {el:.1f} s"}
 
 
 def build(dev):
@@ -129,7 +137,7 @@ def timed_decode(search, encode, dev, utterances, batch_size, rank=0, world=1, w
     return lat, time.perf_counter() - T0, enc_s, dec_s, ntok
 
 
-def driver_record(dev, n_b1=8, n_b64=128):
+def driver_record(dev, n_b1=8, n_b64=128, cpu=True):
     """the ``decode`` object of bench.py's default line (BASELINE configs[4] on the driver's record): batch-1 p50 RTF over ``n_b1``
     utterances of 4 s and batch-64 throughput over ``n_b64``, one model / LM / search object, same protocol as this file's main()."""
     model, lm, search, encode = build(dev)
@@ -146,6 +154,8 @@ def driver_record(dev, n_b1=8, n_b64=128):
                        "rtf_p50": round(float(np.percentile(np.array(lat64) / DUR_S, 50)), 4),
                        "encoder_s": round(e64, 3), "search_s": round(d64, 3), "tokens_decoded": int(tok64)},
            "higher_is_better": False, "dtype": "f32", "data": "synthetic"}
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in model.state_dict().items()}, {k: v.cpu() for k, v in lm.state_dict().items()})
     del model, lm, search, encode
     torch.cuda.empty_cache()
     return out
