@@ -165,7 +165,21 @@ def cpu_baseline(budget_s=30.0, workload=None, bs=None):
         loss, _, _ = model(*batch)
         loss.backward()
 
+    torch.set_num_threads(min(16, threads))
     step()  # warm-up (allocator, oneDNN primitives)
+    # how many threads?  The lscpu core count is the HOST's; a pool box hands a job a share of it (16 CPUs for one GPU), and the oracle on
+    # 128 threads over that share ran 6 - 10x SLOWER than on 16 (audio-only batch 4: 0.85 vs 8.8 utt/s; AV: 0.40 vs 2.4): one probe step
+    # per candidate count, the fastest is the baseline's thread count (reported as `threads`; `cores` stays the host's physical cores)
+    best = (float("inf"), threads)
+    for th in sorted({t for t in (8, 16, 32, 64, threads) if t <= threads}):
+        torch.set_num_threads(th)
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        if dt < best[0]:
+            best = (dt, th)
+    threads = best[1]
+    torch.set_num_threads(threads)
     times = []
     t_all = time.perf_counter()
     while len(times) < 3 or (time.perf_counter() - t_all < budget_s and len(times) < 10):
@@ -176,8 +190,8 @@ def cpu_baseline(budget_s=30.0, workload=None, bs=None):
     return {"value": round(bs / med, 3), "unit": "utterances/s", "cores": phys, "threads": threads, "kind": "port",
             "sample": f"median of {len(times)} timed fwd+bwd steps (1 warm-up) of batch {bs} x 4 s clips (same model/config, "
                       f"same dropout rates; batch 32 would take ~{32 / (bs / med):.0f} s per step), eager torch fp32 oracle, "
-                      f"{threads} threads on {phys} physical cores ({allowed} hardware threads allowed), "
-                      f"{sum(times):.1f} s timed"}
+                      f"{threads} threads (the fastest of 8 / 16 / 32 / 64 / all on a probe step) on a host of {phys} physical cores "
+                      f"({allowed} hardware threads allowed), {sum(times):.1f} s timed"}
 
 
 def bench_fwd_encoder(dev, steps=20, warmup=5):

@@ -12,6 +12,11 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle the parity tests compare against runs on the host: torch sizes its thread pool by the HOST's cores, a pool box
+    # gives a job a share of them (16 CPUs for one GPU), and the oracle on 128 threads over that share is 6 - 10x slower than on 16
+    # (scripts/cpu_threads_probe.py).  A cap, not a setting: fewer cores stay as they are.
+    import torch
+    torch.set_num_threads(min(16, torch.get_num_threads()))
 
 
 @pytest.fixture(scope="session")
