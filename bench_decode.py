@@ -61,23 +61,23 @@ def cpu_baseline(model_state, lm_state, n_utt=1):
     lm = BS.TransformerLMOracle(len(conf["token_list"]), **LM_CONF).eval()
     lm.load_state_dict(lm_state)
     batch = make_utts(n_utt, 99, "cpu")
-    threads = torch.get_num_threads()
+    host = torch.get_num_threads()
+    # torch sizes its pool by the HOST's cores; a pool box hands a job a share of them (16 CPUs for one GPU) and 128 threads over that
+    # share run the oracle 6 - 10x slower (scripts/cpu_threads_probe.py; the search alone - ~100 one-token steps on [10, 512] rows - 2 - 3x)
+    threads = min(16, host)
+    torch.set_num_threads(threads)
     t0 = time.perf_counter()
-    with torch.no_grad():
-        enc, olens = model.encode(*batch)
-        # the search is ~100 one-token steps on [10, 512] rows per utterance: more than ~16 host threads only add wake-ups (it ran
-        # 2 - 3x slower on all 128); the encoder above uses every core
-        torch.set_num_threads(min(16, threads))
-        try:
+    try:
+        with torch.no_grad():
+            enc, olens = model.encode(*batch)
             for u in range(n_utt):
                 BS.build_beam_search(model, lm, SEARCH["beam_size"], SEARCH["ctc_weight"], SEARCH["lm_weight"],
                                      SEARCH["penalty"]).forward(enc[u, : int(olens[u])])
-        finally:
-            torch.set_num_threads(threads)
+    finally:
+        torch.set_num_threads(host)
     el = time.perf_counter() - t0
     return {"value": round(el / (n_utt * DUR_S), 4), "unit": "RTF", "cores": threads, "kind": "port",
-            "sample": f"{n_utt} utterance(s) of 4 s, encoder ({threads} threads) + beam-{SEARCH['beam_size']} + LM (min(16, {threads}) threads) on "
-                      f"the CPU oracle, {el:.1f} s"}
+            "sample": f"{n_utt} utterance(s) of 4 s, encoder + beam-{SEARCH['beam_size']} + LM on the CPU oracle, {threads} threads, {el:.1f} s"}
 
 
 def build(dev):
