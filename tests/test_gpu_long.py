@@ -12,7 +12,7 @@ import argparse
 import pytest
 import torch
 
-from helpers import AVSR_YAML, TOKENS_EN, asr_conf, avsr_conf, grad_ok, max_rel, rel_err
+from helpers import AVSR_CONV_YAML, AVSR_YAML, TOKENS_EN, asr_conf, avsr_conf, grad_ok, max_rel, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -148,6 +148,50 @@ def test_av_tailored_12L_20s_vs_oracle():
         eo, oo = oracle.encode(audio, alens, video, vlens)
         eg, og = model.encode(audio.cuda(), alens.cuda(), video.cuda(), vlens.cuda())
     assert eg.shape[1] == 500 and torch.equal(og.cpu(), oo)
+    assert max_rel(eg.cpu(), eo) < ACT_TOL
+    _greedy_binding(oracle, eo, model, eg, og)
+
+
+def test_av_conventional_4L_15s_vs_oracle():
+    """the CONVENTIONAL audio-visual encoder (two Branchformer encoders - Conv2dSubsampling for the audio, the lip front-end + Linear for
+    the video - and the adaptive fusion, src/encoder/audiovisual/conventional/encoder.py) at 1500 mel + 375 lip frames (T = 374 / 375),
+    4 layers per modality, one ragged pair: loss, every gradient, BatchNorm statistics, encoder output and greedy ids against the oracle."""
+    from oracle.av import build_avsr_oracle
+    from oracle.model import fill_parameters_, synth
+    from tavsr.tasks.avsr import AVSRTask
+    conf = avsr_conf(AVSR_CONV_YAML, num_blocks=4, dec_blocks=2)
+    oracle = build_avsr_oracle(conf, TOKENS_EN)
+    fill_parameters_(oracle, seed=2020)
+    model = AVSRTask.build_model(argparse.Namespace(**avsr_conf(AVSR_CONV_YAML, num_blocks=4, dec_blocks=2)))
+    model.load_state_dict(oracle.state_dict())
+    model = model.cuda().train()
+    oracle.train()
+    audio, video = synth((2, 1500, 80), seed=2021), synth((2, 375, 88, 88), seed=2022)
+    alens, vlens = torch.tensor([1500, 1000]), torch.tensor([375, 250])
+    text = synth((2, 150), seed=2023, kind="int", lo=1, hi=40)
+    tlens = torch.tensor([150, 90])
+    text[1, 90:] = -1
+    batch = (audio, alens, video, vlens, text, tlens)
+    lg, _, _ = model(*[t.cuda() for t in batch])
+    lg.backward()
+    lo, _, _ = oracle(*batch)
+    lo.backward()
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 1e-4
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
+    for n, p in oracle.named_parameters():
+        if p.numel() == 1 and float(p.grad.abs()) > 1e-6:        # (one-element gradients: see test_asr_12L_20s_ragged_vs_oracle)
+            assert abs(float(got[n]) - float(p.grad)) < 2e-2 * abs(float(p.grad)) + 1e-5, (n, float(got[n]), float(p.grad))
+        else:
+            assert grad_ok(got[n], p.grad, 5e-3), (n, rel_err(got[n], p.grad))
+    bufs = {n: b.detach().float().cpu() for n, b in model.named_buffers()}
+    for n, b in oracle.named_buffers():
+        assert rel_err(bufs[n], b.float()) < 1e-4, n
+    model.eval()
+    oracle.eval()
+    with torch.no_grad():
+        eo, oo = oracle.encode(audio, alens, video, vlens)
+        eg, og = model.encode(audio.cuda(), alens.cuda(), video.cuda(), vlens.cuda())
+    assert torch.equal(og.cpu(), oo) and eg.shape[1] >= 374
     assert max_rel(eg.cpu(), eo) < ACT_TOL
     _greedy_binding(oracle, eo, model, eg, og)
 
