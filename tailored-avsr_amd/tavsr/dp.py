@@ -362,6 +362,7 @@ class GradBuckets:
         for h, st in self._hook_streams.items():
             if h != cur.cuda_stream:
                 cur.wait_stream(st)
+        ops.wgrad_fence()          # ... and behind the weight-gradient launches a layer left open on its side queue
         ops.bucket_copy(ptrs, offs, sizes, len(bucket), flat, 1.0, True, mx)
         self._issue_flat(i, flat)
 
@@ -485,7 +486,12 @@ class GradBuckets:
 
         for b in self.buckets:
             for p in b:
+                if getattr(p, "_post_accumulate_grad_hooks", None):
+                    foreign = True       # somebody else's hook reads the gradient where it is accumulated: no deferred weight gradients
+                else:
+                    foreign = False
                 p.register_post_accumulate_grad_hook(hook)
+                p._tavsr_hooks_fence = not foreign      # (ops.wgrad_may_go_beside: this package's hooks fence in _launch_bucket)
 
 
 

@@ -826,8 +826,11 @@ class BranchformerLayerFn(torch.autograd.Function):
         for i, prm in enumerate(P):
             if prm is None:
                 G[i] = None
-        grp.flush()
-        lng.flush()
+        if ops.wgrad_may_go_beside(P):       # no reader before the end of the pass: beside the next layer's chain
+            ops.wgrad_beside(lambda: (grp.flush(), lng.flush()))
+        else:
+            grp.flush()
+            lng.flush()
         ctx.sv = None
         return (dx.view(B, T, D), None, None, None, *G)
 
@@ -1131,6 +1134,9 @@ class TransformerDecoderFn(torch.autograd.Function):
         dx, G[an_i], G[an_i + 1], *dyd = lng.bwd(dxn, x, mf, rf, an_w, drop=ctx.saved[nb - 1]["ff"][-1])
         dmem = None
         mem2 = ctx.mem2
+        # the weight gradients of ALL layers in a few grouped launches at the end: a layer's own group is 384 tiles of K = 1312 (1.5 per compute
+        # unit, 42 TFLOP/s, 95 us of the 280 a layer's backward takes); 2304 tiles together run at the rate of the encoder's groups
+        grp = ops.WgradGroup()
         for li in reversed(range(nb)):
             base = 1 + li * _NL
             p = lambda n, base=base: P[base + _DI[n]]
@@ -1139,7 +1145,6 @@ class TransformerDecoderFn(torch.autograd.Function):
                 G[base + _DI[n]] = g
 
             s = ctx.saved[li]
-            grp = ops.WgradGroup()
             dx2, gs, *dt2 = _FFN.bwd(dx, s["ff"], p("norm3.weight"), p("feed_forward.w_1.weight"), p("feed_forward.w_2.weight"),
                                      "relu", 1.0, grp=grp, lng=lng, dyd=dyd[0] if dyd else None, out_drop=s["src"][-1])
             for n_, g in zip(("norm3.weight", "norm3.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
@@ -1187,7 +1192,7 @@ class TransformerDecoderFn(torch.autograd.Function):
             dx, g1, g2, *dyd = lng.bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1,
                                        drop=ctx.saved[li - 1]["ff"][-1] if li else None)
             put("norm1.weight", g1); put("norm1.bias", g2)
-            grp.flush()
+        grp.flush()
         lng.flush()
         _drop_bwd_(dx, ctx.t_pos)
         G[0] = ops.embed_bwd(ctx.ys_in.contiguous(), dx, math.sqrt(D), P[0].shape[0])

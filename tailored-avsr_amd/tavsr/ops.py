@@ -356,6 +356,66 @@ class BranchScope:
             _probe("join", self._tick)
 
 
+# Weight gradients beside the backward chain.  A layer's weight gradients (one grouped launch of ~180 us at 12.4 rows per compute unit, the
+# (dgamma, dbeta) partial sums behind it) have no consumer inside the backward pass; on the chain's own queue they sit between two layers
+# whose first 150 us are one streaming FFN launch and eight latency-bound ones.  ``wgrad_beside(fn)`` enqueues them on the owner's side queue
+# instead and does NOT join: the side queue is in-order, so the next layer's forked branch (and its join) comes behind them, and the end of the
+# autograd pass joins what is still open (``Variable._execution_engine.queue_callback``).  Only taken when nobody reads the gradients before
+# that: every parameter's ``.grad`` is None (AccumulateGrad then keeps the tensor, it does not add into one) and carries no hook other than
+# this package's own bucket hooks, which fence themselves (``wgrad_fence``).
+WGRAD_BESIDE = os.environ.get("TAVSR_WGRAD_BESIDE", "1") != "0"
+WGRAD_SLOT = int(os.environ.get("TAVSR_WGRAD_SLOT", "0"))
+_WGRAD_OPEN = {}        # raw handle of the owning stream -> (owner, side) with weight-gradient launches nobody has joined yet
+_WGRAD_CB = [False]
+
+
+def wgrad_fence() -> None:
+    """orders the CURRENT stream behind every weight-gradient launch that ``wgrad_beside`` left open (a no-op when there is none)"""
+    if not _WGRAD_OPEN:
+        return
+    cur = torch.cuda.current_stream()
+    for owner, side in list(_WGRAD_OPEN.values()):
+        cur.wait_stream(side)
+        if owner.cuda_stream != cur.cuda_stream:       # (the owner itself must be behind them too before a capture ends)
+            owner.wait_stream(side)
+    _WGRAD_OPEN.clear()
+
+
+def _wgrad_end_of_pass() -> None:
+    _WGRAD_CB[0] = False
+    wgrad_fence()
+
+
+def wgrad_may_go_beside(params) -> bool:
+    if not (WGRAD_BESIDE and forks_enabled()):
+        return False
+    for p_ in params:
+        if p_ is None:
+            continue
+        if p_.grad is not None or p_._backward_hooks:
+            return False
+        if getattr(p_, "_post_accumulate_grad_hooks", None) and not getattr(p_, "_tavsr_hooks_fence", False):
+            return False
+    return True
+
+
+def wgrad_beside(fn) -> None:
+    """``fn()`` (launches only) on the side queue of the current stream, left open until the next ``wgrad_fence`` / the end of the pass"""
+    from torch.autograd import Variable
+    if not _WGRAD_CB[0]:
+        try:
+            Variable._execution_engine.queue_callback(_wgrad_end_of_pass)
+            _WGRAD_CB[0] = True
+        except RuntimeError:          # not inside an autograd pass (a test driving a backward by hand): nothing would join it
+            fn()
+            return
+    sc = BranchScope(True, slot=WGRAD_SLOT)
+    with sc:
+        fn()
+    if sc.on:
+        _WGRAD_OPEN[sc.main.cuda_stream] = (sc.main, sc.side)
+
+
 def linear_dw(dy, x, *, alpha=1.0, out=None, bias_grad=False, force=None):
     """dW = alpha * dy.T @ x;  dy [M,N], x [M,K] -> [N,K] (torch weight layout).  With ``bias_grad`` also returns
     db = alpha * dy.sum(0), computed by the same launch from the A fragments (tavsr_gemm a_rowsum)."""
@@ -428,8 +488,19 @@ class WgradGroup:
                          a_kmajor=True, b_kmajor=True, alpha=alpha, a_rowsum=gb)
                 keep = set(id(it) for it in rest)
                 items = [it for it in items if id(it) in keep]
-        for i in range(0, len(items), self.MAX):
-            chunk = items[i: i + self.MAX]
+        chunks = [items[i: i + self.MAX] for i in range(0, len(items), self.MAX)]
+        if len(items) > self.MAX:
+            # many layers' problems at once (the decoder): problems of one reduction length together (a launch lasts as long as its longest
+            # tile), at most 5 x 256 tiles per launch (what is resident at once)
+            chunks, cur, cur_t = [], [], 0
+            for it in sorted(items, key=lambda it: (-it[0].shape[0], -self._tiles(it))):
+                if cur and (len(cur) == self.MAX or cur_t + self._tiles(it) > 1280 or it[0].shape[0] != cur[0][0].shape[0]):
+                    chunks.append(cur)
+                    cur, cur_t = [], 0
+                cur.append(it)
+                cur_t += self._tiles(it)
+            chunks.append(cur)
+        for chunk in chunks:
             arr = (GemmDesc * len(chunk))()
             for d, it in zip(arr, chunk):
                 self._desc(d, *it)
