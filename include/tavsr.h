@@ -395,6 +395,10 @@ typedef struct tavsr_bf_layer_bwd_desc {
   float* g_ln;                     /* [5][2][D] */
   float* ws;
   int64_t ws_floats;
+  int32_t wgrad_beside;            /* 1: the weight-gradient launches at the end of the call (one grouped launch, the problems it sheds, the
+                                      (dgamma, dbeta) reduction) are enqueued on fwd->stream2 behind what `stream` holds at that point and are
+                                      NOT joined: the caller orders every reader of the g_* buffers, and the next user of ws / dy / the kept
+                                      forward state, behind stream2.  Same results.  0 (or stream2 == stream): on `stream`, as before. */
 } tavsr_bf_layer_bwd_desc;
 int64_t tavsr_branchformer_layer_bwd_ws(const tavsr_bf_layer_bwd_desc* b);
 int tavsr_branchformer_layer_bwd(const tavsr_bf_layer_bwd_desc* b, tavsr_stream_t stream);

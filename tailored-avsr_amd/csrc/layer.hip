@@ -602,9 +602,15 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
   if ((rc = ffn_bwd(d, dx1b, drop ? dyd2 : dx1b, d->x, d->ffm_mean, d->ffm_rstd, d->ffm_n, d->ffm_z, d->ffm_h, d->ffm_ln_w, d->ffm_w1, d->ffm_w2,
                     d->drop_off[0], b->g_ffm_w1, b->g_ffm_b1, b->g_ffm_w2, b->g_ffm_b2, b->dx, nullptr, 0, grp, lng, ws, s)))
     return rc;
-  if ((rc = grp.flush(ws, s))) return rc;
+  hipStream_t sw = s;
+  if (!dry && b->wgrad_beside && s2 != s) {     // nobody inside the backward pass reads a weight gradient: beside the next layer's chain
+    TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_fork, s));
+    TAVSR_HIP_CHECK(hipStreamWaitEvent(s2, (hipEvent_t)d->ev_fork, 0));
+    sw = s2;
+  }
+  if ((rc = grp.flush(ws, sw))) return rc;
   (void)g_ln;
-  return lng.flush(dry, s);
+  return lng.flush(dry, sw);
 }
 
 }  // namespace

@@ -98,7 +98,7 @@ class BfLayerBwdDesc(C.Structure):
             "g_cg_w1", "g_cg_b1", "g_csgu_ln_w", "g_csgu_ln_b", "g_csgu_cw", "g_csgu_cb", "g_cg_w2", "g_cg_b2")]
         + [("g_merge_p", C.c_void_p * 8)]
         + [(n, C.c_void_p) for n in ("g_merge_w", "g_merge_b", "g_ff_w1", "g_ff_b1", "g_ff_w2", "g_ff_b2", "g_ln", "ws")]
-        + [("ws_floats", C.c_int64)]
+        + [("ws_floats", C.c_int64), ("wgrad_beside", C.c_int32)]
     )
 
 

@@ -530,7 +530,14 @@ def _layer_c_backward(ctx, dy):
         nws = _LAYER_WS[key] = int(fn(C.byref(b)))
     ws = ops.empty(max(nws, 4), like=dy2)
     b.ws, b.ws_floats = ops._addr(ws), nws
+    beside = side is not main and ops.WGRAD_SLOT == 0 and ops.wgrad_may_go_beside(P) and ops.wgrad_open(main, side)
+    b.wgrad_beside = 1 if beside else 0
     check(lib().tavsr_branchformer_layer_bwd(C.byref(b), C.c_void_p(main.cuda_stream)), "tavsr_branchformer_layer_bwd")
+    if beside:      # what those launches read and write is freed on THIS stream (rule 1 of _lib.py, by hand: the addresses were taken here)
+        sv = ctx.sv
+        for t in (ws, gflat, dy2, sv.flat, sv.x2d, sv.wts, ctx.pos_emb):
+            if torch.is_tensor(t) and not isinstance(t, torch.nn.Parameter):
+                t.record_stream(side)
     ctx.sv = ctx.cdesc = None
     return (dx.view(B, T, D), None, None, None, *G)
 
@@ -720,6 +727,7 @@ class BranchformerLayerFn(torch.autograd.Function):
         for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                           "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
             put(n_, g)
+        ops.wgrad_launch_carried("ffn")
         # merge projection: x2 = x1 + coeff * (m Wm^T + bm)
         m = sv["merge"][-1]
         t_cat = sv["drop"][0]
@@ -814,6 +822,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             dx1, g1, g2, *dyd = lng.bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1, drop=None if has_attn else t_ffm)
             put("norm_mlp.weight", g1); put("norm_mlp.bias", g2)
         br.join()
+        ops.wgrad_launch_carried("join")
         if has_attn:     # same accumulation order into dx1 as a single stream: cgMLP branch first, then attention
             dx1, g1, g2, *dyd = lng.bwd(dn_a, x1, a_mean, a_rstd, p("norm_mha.weight"), dx_add=dx1, drop=t_ffm)
             put("norm_mha.weight", g1); put("norm_mha.bias", g2)
@@ -827,7 +836,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             if prm is None:
                 G[i] = None
         if ops.wgrad_may_go_beside(P):       # no reader before the end of the pass: beside the next layer's chain
-            ops.wgrad_beside(lambda: (grp.flush(), lng.flush()))
+            ops.wgrad_defer(lambda: (grp.flush(), lng.flush()))
         else:
             grp.flush()
             lng.flush()
@@ -1072,6 +1081,14 @@ class TransformerDecoderFn(torch.autograd.Function):
         x = ops.embed_pe(ys_in.contiguous(), emb_w, pe, math.sqrt(D)).view(M, D)
         t_pos = _drop_(x, ppos)                              # PositionalEncoding dropout
         saved = []
+        # the key / value projections of the encoder memory do not depend on the decoder's state: all layers' in grouped launches up front
+        # (2400 tiles of M = B T rows) instead of one 200-tile launch inside every layer's chain; layer li reads its window of kv_all
+        ldkv = nb * 2 * D
+        kv_all = ops.empty(B * T, ldkv, like=memory)
+        kvp = [(P[1 + li * _NL + _DI[f"src_attn.linear_{c}.weight"]], P[1 + li * _NL + _DI[f"src_attn.linear_{c}.bias"]], (2 * li + j) * D)
+               for li in range(nb) for j, c in enumerate("kv")]
+        for i in range(0, len(kvp), 12):
+            ops.linear_group(mem2, kvp[i: i + 12], kv_all)
         for li in range(nb):
             p = lambda n, li=li: P[1 + li * _NL + _DI[n]]
             s = {}
@@ -1092,17 +1109,15 @@ class TransformerDecoderFn(torch.autograd.Function):
             # --- source attention over the encoder memory
             n2, m2, r2 = ops.layernorm_fwd(x1, p("norm2.weight"), p("norm2.bias"), EPS_ESPNET)
             q2 = ops.linear(n2, p("src_attn.linear_q.weight"), p("src_attn.linear_q.bias"))
-            kv = ops.empty(B * T, 2 * D, like=x)
-            ops.linear_group(mem2, [(p(f"src_attn.linear_{c}.weight"), p(f"src_attn.linear_{c}.bias"), j * D)
-                                    for j, c in enumerate("kv")], kv)
+            ko = 2 * li * D
             if fused:
                 tk_a2 = "fused"
-                cx2, attn2 = _AttnFused.fwd(q2, 0, kv, 0, kv, D, B, L, T, H, dk, hlens, False, p_att=psrc)
+                cx2, attn2 = _AttnFused.fwd(q2, 0, kv_all, ko, kv_all, ko + D, B, L, T, H, dk, hlens, False, p_att=psrc)
             else:
-                cx2, attn2, tk_a2 = _SelfAttnCore.fwd(q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, B, L, T, H, dk, hlens, False,
+                cx2, attn2, tk_a2 = _SelfAttnCore.fwd(q2, D, 0, kv_all, ldkv, ko, kv_all, ldkv, ko + D, B, L, T, H, dk, hlens, False,
                                                       p_att=psrc)
             x2, tk_r2 = ops.linear_drop(cx2, p("src_attn.linear_out.weight"), p("src_attn.linear_out.bias"), pd, res=x1)   # x + dropout(src_attn(...))
-            s["src"] = (x1, m2, r2, n2, q2, kv, cx2, attn2, tk_a2, tk_r2)
+            s["src"] = (x1, m2, r2, n2, q2, ko, cx2, attn2, tk_a2, tk_r2)
             # --- position-wise FFN (ReLU, scale 1)
             x, s["ff"] = _FFN.fwd(x2, p("norm3.weight"), p("norm3.bias"), p("feed_forward.w_1.weight"),
                                   p("feed_forward.w_1.bias"), p("feed_forward.w_2.weight"), p("feed_forward.w_2.bias"),
@@ -1113,7 +1128,7 @@ class TransformerDecoderFn(torch.autograd.Function):
         logits = ops.linear(xn, out_w, out_b)
         ctx.saved, ctx.final, ctx.t_pos = saved, (x, mf, rf, xn), t_pos
         ctx.P, ctx.cfg, ctx.dims = P, cfg, (B, T, L, D, H, dk, nb)
-        ctx.mem2, ctx.ys_in, ctx.hlens, ctx.ys_lens = mem2, ys_in, hlens, ys_lens
+        ctx.mem2, ctx.ys_in, ctx.hlens, ctx.ys_lens, ctx.kv_all = mem2, ys_in, hlens, ys_lens, kv_all
         return logits.view(B, L, -1)
 
     @staticmethod
@@ -1132,11 +1147,13 @@ class TransformerDecoderFn(torch.autograd.Function):
         lng = ops.LNGroup(cap=3 * nb + 1)     # all LayerNorms of the decoder: one (dgamma, dbeta) reduction at the end
         # (every LayerNorm backward also writes its dx under the mask of the residual block below it: no dropout launches)
         dx, G[an_i], G[an_i + 1], *dyd = lng.bwd(dxn, x, mf, rf, an_w, drop=ctx.saved[nb - 1]["ff"][-1])
-        dmem = None
-        mem2 = ctx.mem2
+        mem2, kv_all = ctx.mem2, ctx.kv_all
+        ldkv = nb * 2 * D
+        dkv_all = torch.empty_like(kv_all)      # every layer's (dK | dV) side by side: the memory's gradient is ONE K = 2 D nb GEMM at the end
         # the weight gradients of ALL layers in a few grouped launches at the end: a layer's own group is 384 tiles of K = 1312 (1.5 per compute
         # unit, 42 TFLOP/s, 95 us of the 280 a layer's backward takes); 2304 tiles together run at the rate of the encoder's groups
         grp = ops.WgradGroup()
+        beside = ops.wgrad_may_go_beside(P)
         for li in reversed(range(nb)):
             base = 1 + li * _NL
             p = lambda n, base=base: P[base + _DI[n]]
@@ -1151,24 +1168,23 @@ class TransformerDecoderFn(torch.autograd.Function):
                               "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
                 put(n_, g)
             # --- source attention
-            x1, m2, r2, n2, q2, kv, cx2, attn2, tk_a2, tk_r2 = s["src"]
+            x1, m2, r2, n2, q2, ko, cx2, attn2, tk_a2, tk_r2 = s["src"]
             dt2 = dt2[0] if dt2 else _drop_bwd(dx2, tk_r2)
             gw_, gb_ = grp.add(dt2, cx2, bias_grad=True)
             put("src_attn.linear_out.weight", gw_); put("src_attn.linear_out.bias", gb_)
             dcx2 = ops.linear_dx(dt2, p("src_attn.linear_out.weight"))
             dq2 = ops.empty(M, D, like=dl)
-            dkv = torch.empty_like(kv)
             if tk_a2 == "fused":
-                _AttnFused.bwd(dcx2, cx2, attn2, q2, 0, kv, 0, kv, D, dq2, 0, dkv, 0, dkv, D, B, L, T, H, dk, ctx.hlens, False)
+                _AttnFused.bwd(dcx2, cx2, attn2, q2, 0, kv_all, ko, kv_all, ko + D, dq2, 0, dkv_all, ko, dkv_all, ko + D, B, L, T, H, dk,
+                               ctx.hlens, False)
             else:
-                _SelfAttnCore.bwd(dcx2, attn2, q2, D, 0, kv, 2 * D, 0, kv, 2 * D, D, dq2, D, 0, dkv, 2 * D, 0, dkv, 2 * D, D,
-                                  B, L, T, H, dk, tok=tk_a2)
+                _SelfAttnCore.bwd(dcx2, attn2, q2, D, 0, kv_all, ldkv, ko, kv_all, ldkv, ko + D, dq2, D, 0, dkv_all, ldkv, ko,
+                                  dkv_all, ldkv, ko + D, B, L, T, H, dk, tok=tk_a2)
             gw_, gb_ = grp.add(dq2, n2, bias_grad=True)
             put("src_attn.linear_q.weight", gw_); put("src_attn.linear_q.bias", gb_)
             for j, nm in enumerate(("k", "v")):
-                gw_, gb_ = grp.add(dkv[:, j * D:(j + 1) * D], mem2, bias_grad=True)
+                gw_, gb_ = grp.add(dkv_all[:, ko + j * D: ko + (j + 1) * D], mem2, bias_grad=True)
                 put(f"src_attn.linear_{nm}.weight", gw_); put(f"src_attn.linear_{nm}.bias", gb_)
-            dmem = ops.linear_dx_cat(dkv, [p("src_attn.linear_k.weight"), p("src_attn.linear_v.weight")], res=dmem, out=dmem)
             dn2 = ops.linear_dx(dq2, p("src_attn.linear_q.weight"))
             dx1, g1, g2, *dt1 = lng.bwd(dn2, x1, m2, r2, p("norm2.weight"), dx_add=dx2, drop=s["self"][-1])
             put("norm2.weight", g1); put("norm2.bias", g2)
@@ -1192,12 +1208,20 @@ class TransformerDecoderFn(torch.autograd.Function):
             dx, g1, g2, *dyd = lng.bwd(dn1, x0, m1, r1, p("norm1.weight"), dx_add=dx1,
                                        drop=ctx.saved[li - 1]["ff"][-1] if li else None)
             put("norm1.weight", g1); put("norm1.bias", g2)
+            if beside and li and (nb - li) % _DEC_WGRAD == 0:
+                ops.wgrad_beside(grp.flush)
+        # (in the layers' chain it was an accumulating K = 2 D launch over B T rows per layer - the only launches of the chain over the memory's
+        # rows rather than the 1312 token rows)
+        dmem = ops.linear_dx_cat(dkv_all, [P[1 + li * _NL + _DI[f"src_attn.linear_{c}.weight"]] for li in range(nb) for c in "kv"])
         grp.flush()
         lng.flush()
         _drop_bwd_(dx, ctx.t_pos)
         G[0] = ops.embed_bwd(ctx.ys_in.contiguous(), dx, math.sqrt(D), P[0].shape[0])
-        ctx.saved = None
+        ctx.saved = ctx.kv_all = None
         return (dmem.view(B, T, D), None, None, None, None, None, *G)
+
+
+_DEC_WGRAD = int(os.environ.get("TAVSR_DEC_WGRAD", "3"))
 
 
 class LabelSmoothingLossFn(torch.autograd.Function):

@@ -257,7 +257,8 @@ def linear_dx_cat(dy_cat, ws, *, res=None, out=None):
     assert dy_cat.shape[1] == sum(rows) and all(w.shape[1] == K and w.is_contiguous() for w in ws)
     wcat = empty(sum(rows), K, like=dy_cat)
     offs = [sum(rows[:j]) for j in range(len(ws))]
-    multi_copy_([wcat[o: o + r] for o, r in zip(offs, rows)], list(ws))
+    for i in range(0, len(ws), 24):
+        multi_copy_([wcat[o: o + r] for o, r in zip(offs[i: i + 24], rows[i: i + 24])], list(ws[i: i + 24]))
     return linear_dx(dy_cat, wcat, res=res, out=out)
 
 
@@ -383,7 +384,40 @@ def wgrad_fence() -> None:
 
 def _wgrad_end_of_pass() -> None:
     _WGRAD_CB[0] = False
+    while _WGRAD_CARRY:          # nobody offered a launch point any more: on the calling stream
+        _WGRAD_CARRY.pop(0)()
     wgrad_fence()
+
+
+WGRAD_AT = os.environ.get("TAVSR_WGRAD_AT", "end")     # where a layer's weight gradients are enqueued: "end" of its own backward, or carried
+_WGRAD_CARRY = []                                      # to the NEXT layer's backward: behind its first "ffn" block / behind its branch "join"
+
+
+def _wgrad_callback() -> bool:
+    from torch.autograd import Variable
+    if not _WGRAD_CB[0]:
+        try:
+            Variable._execution_engine.queue_callback(_wgrad_end_of_pass)
+            _WGRAD_CB[0] = True
+        except RuntimeError:          # not inside an autograd pass (a test driving a backward by hand): nothing would join it
+            return False
+    return True
+
+
+def wgrad_defer(fn) -> None:
+    """the end of a layer's backward: ``fn`` computes its weight gradients (launches only)"""
+    if WGRAD_AT == "end":
+        return wgrad_beside(fn)
+    if not _wgrad_callback():
+        return fn()
+    wgrad_launch_carried()
+    _WGRAD_CARRY.append(fn)
+
+
+def wgrad_launch_carried(at=None) -> None:
+    if _WGRAD_CARRY and (at is None or at == WGRAD_AT):
+        while _WGRAD_CARRY:
+            wgrad_beside(_WGRAD_CARRY.pop(0))
 
 
 def wgrad_may_go_beside(params) -> bool:
@@ -399,16 +433,18 @@ def wgrad_may_go_beside(params) -> bool:
     return True
 
 
+def wgrad_open(main, side) -> bool:
+    """(the C-side sequencer enqueues its weight gradients on ``side`` itself) notes them as open; False: not inside an autograd pass"""
+    if not _wgrad_callback():
+        return False
+    _WGRAD_OPEN[main.cuda_stream] = (main, side)
+    return True
+
+
 def wgrad_beside(fn) -> None:
     """``fn()`` (launches only) on the side queue of the current stream, left open until the next ``wgrad_fence`` / the end of the pass"""
-    from torch.autograd import Variable
-    if not _WGRAD_CB[0]:
-        try:
-            Variable._execution_engine.queue_callback(_wgrad_end_of_pass)
-            _WGRAD_CB[0] = True
-        except RuntimeError:          # not inside an autograd pass (a test driving a backward by hand): nothing would join it
-            fn()
-            return
+    if not _wgrad_callback():
+        return fn()
     sc = BranchScope(True, slot=WGRAD_SLOT)
     with sc:
         fn()
