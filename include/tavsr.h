@@ -329,6 +329,16 @@ int tavsr_ffn2_fwd(const tavsr_ffn_desc* d, tavsr_stream_t stream);
 int tavsr_ffn2_bwd_dx(const float* dy, int64_t lddy, float alpha, const float* w1, const float* w2, const float* z, int32_t act,
                       int32_t M, int32_t D, int32_t N1, float p_drop, const uint64_t* seed_dev, uint64_t offset_in, float* dz,
                       float* dn, float* ws, int64_t ws_floats, tavsr_stream_t stream);
+/* dn == NULL: the finishing launch that sums dn's partials is left out; they stay in ws in the layout tavsr_ffn2_slab_layout reports
+ * (row m = sum over j < wpb of ws[((m / rb_rows) * wpb + j) * rb_rows + m % rb_rows][256], j ascending) for the LayerNorm backward that
+ * consumes dn to sum them where it reads the row: tavsr_layernorm_bwd_partial_slab = tavsr_layernorm_bwd_partial (dx_drop NULL) /
+ * tavsr_layernorm_bwd_partial_drop on those slabs - same bits, one launch less per feed-forward block
+ * (src/encoder/branchformer/encoder_layer.py:191-194, 310-314: the block's LayerNorm is the first thing its input gradient meets). */
+int tavsr_ffn2_slab_layout(int32_t M, int32_t N1, int32_t* wpb, int32_t* rb_rows);
+int tavsr_layernorm_bwd_partial_slab(const float* slab, int32_t wpb, int32_t rb_rows, const float* x, int64_t ldx, const float* mean,
+                                     const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd, float* dx, int64_t lddx,
+                                     float* ws, int64_t ws_ld, int32_t M, int32_t D, float* dx_drop, float p_drop,
+                                     const uint64_t* seed_dev, uint64_t offset, tavsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One Branchformer encoder layer forward as ONE call (csrc/layer.hip): MyBranchformerEncoderLayer.forward

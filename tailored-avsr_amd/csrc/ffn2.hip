@@ -802,7 +802,7 @@ extern "C" int tavsr_ffn2_bwd_dx(const float* dy, int64_t lddy, float alpha, con
   TAVSR_REQUIRE(M > 0 && D == 256 && N1 >= 1024 && N1 % 32 == 0, TAVSR_EUNSUPPORTED,
                 "ffn2_bwd_dx: d_model 256 and a hidden size >= 1024 that is a multiple of 32 (got %d, %d)", D, N1);
   TAVSR_REQUIRE(act == TAVSR_ACT_RELU || act == TAVSR_ACT_SWISH, TAVSR_EUNSUPPORTED, "ffn2_bwd_dx: ReLU or Swish only");
-  TAVSR_REQUIRE(dy && w1 && w2 && z && dz && dn && ws, TAVSR_EINVAL, "ffn2_bwd_dx: null operand");
+  TAVSR_REQUIRE(dy && w1 && w2 && z && dz && ws, TAVSR_EINVAL, "ffn2_bwd_dx: null operand");
   TAVSR_REQUIRE(al16(dy) && al16(w1) && al16(w2) && al16(z) && al16(dz) && al16(dn) && al16(ws) && lddy % 4 == 0, TAVSR_EINVAL,
                 "ffn2_bwd_dx: operands must be 16-byte aligned");
   TAVSR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_dev) && offset_in % 4 == 0, TAVSR_EINVAL,
@@ -827,9 +827,19 @@ extern "C" int tavsr_ffn2_bwd_dx(const float* dy, int64_t lddy, float alpha, con
     else hipLaunchKernelGGL((ffn2_bwd_kernel<false, TAVSR_ACT_SWISH>), grid, dim3(256), 0, s, a);
   }
   TAVSR_LAUNCH_CHECK();
+  if (!dn) return TAVSR_OK;      // the caller's LayerNorm backward sums the partials itself (tavsr_layernorm_bwd_partial_slab)
   hipLaunchKernelGGL(ffn2_finish_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, ws, p.wpb, (const float*)nullptr, (const float*)nullptr,
                      0L, dn, M, 1.f, 0u, 1.f, (const uint64_t*)nullptr, (uint64_t)0, (const float*)nullptr, (const float*)nullptr,
                      (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// where tavsr_ffn2_bwd_dx(dn = NULL) leaves the partials of dn: row m = sum over j < *wpb of ws[((m / *rb_rows) * *wpb + j) * *rb_rows + m % *rb_rows][256]
+extern "C" int tavsr_ffn2_slab_layout(int32_t M, int32_t N1, int32_t* wpb, int32_t* rb_rows) {
+  TAVSR_REQUIRE(M > 0 && N1 >= 1024 && N1 % 32 == 0 && wpb && rb_rows, TAVSR_EINVAL, "ffn2_slab_layout: bad argument");
+  const Plan p = ffn2_plan(M, N1);
+  *wpb = p.wpb;
+  *rb_rows = kRB;
   return TAVSR_OK;
 }

@@ -416,6 +416,15 @@ struct LnGroup {       // tavsr/ops.py:LNGroup for the five d_model LayerNorms o
                                               seed, off, (tavsr_stream_t)s);
     return tavsr_layernorm_bwd_partial(dy, D, x, D, mean, rstd, gamma, dx_add, dx_add ? D : 0, dx, D, part, slab_ld, M, D, (tavsr_stream_t)s);
   }
+  // dy as the unsummed partials of tavsr_ffn2_bwd_dx(dn = NULL) (tavsr/ops.py: LNGroup.bwd on ops.DnSlabs)
+  int bwd_slab(const float* slabs, int wpb, int rbr, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_add,
+               float* dx, float* dx_drop, float p, const uint64_t* seed, uint64_t off, bool dry, hipStream_t s) {
+    float* part = dry ? nullptr : slab + (int64_t)k * 2 * D;
+    ++k;
+    if (dry) return TAVSR_OK;
+    return tavsr_layernorm_bwd_partial_slab(slabs, wpb, rbr, x, D, mean, rstd, gamma, dx_add, dx_add ? D : 0, dx, D, part, slab_ld, M, D, dx_drop, p,
+                                            seed, off, (tavsr_stream_t)s);
+  }
   int flush(bool dry, hipStream_t s) {
     if (dry || !k) return TAVSR_OK;
     return tavsr_sum_partials(slab, nb, slab_ld, out, k * 2 * D, 0, (tavsr_stream_t)s);
@@ -432,15 +441,17 @@ int ffn_bwd(const tavsr_bf_layer_desc* f, const float* dy, const float* dyd, con
   int rc;
   grp.add(dyd, D, h, N1, M, D, N1, 0.5f, g_w2, g_b2);
   float* dz = ws.take((int64_t)Mp * N1);
-  float* dn = ws.take((int64_t)M * D);
   const int64_t nws = tavsr_ffn2_ws(M, D, N1);
   float* fws = ws.take(nws);
   TAVSR_REQUIRE(ws.dry || !ws.overflow, TAVSR_EINVAL, "branchformer_layer_bwd: workspace too small");
-  if (!ws.dry && (rc = tavsr_ffn2_bwd_dx(dyd, D, 0.5f, w1, w2, z, f->ffn_act, M, D, N1, f->p_drop, f->p_drop > 0.f ? f->seed : nullptr, off_in, dz, dn,
+  // dn stays in the launch's partial slabs: the block's LayerNorm backward, its only reader, sums them (no finishing launch)
+  if (!ws.dry && (rc = tavsr_ffn2_bwd_dx(dyd, D, 0.5f, w1, w2, z, f->ffn_act, M, D, N1, f->p_drop, f->p_drop > 0.f ? f->seed : nullptr, off_in, dz, nullptr,
                                          fws, nws, (tavsr_stream_t)s)))
     return rc;
   grp.add(dz, N1, n, D, M, N1, D, 1.f, g_w1, g_b1);
-  return lng.bwd(dn, x, mean, rstd, ln_w, dy, dx, dx_drop, f->p_drop, f->seed, off_next, ws.dry, s);
+  int wpb = 0, rbr = 0;
+  if ((rc = tavsr_ffn2_slab_layout(M, N1, &wpb, &rbr))) return rc;
+  return lng.bwd_slab(fws, wpb, rbr, x, mean, rstd, ln_w, dy, dx, dx_drop, f->p_drop, f->seed, off_next, ws.dry, s);
 }
 
 int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {

@@ -65,7 +65,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // One wave per row, LN_RPW rows per wave with the loads of both rows issued together (the kernel is pure
 // latency otherwise: 3168 rows x 1 KB); NV = D / 256 float4 chunks per lane.
 constexpr int LN_RPW = 2;
-template <int NV>
+// SLAB (NV == 1, D == 256): dy is not a tensor but the UNSUMMED partial slabs a streaming feed-forward backward left in its workspace
+// (tavsr_ffn2_bwd_dx with dn == NULL): row m = the sum over j < lddy of dy[((m / ldaz) * lddy + j) * ldaz + m % ldaz][256], added in
+// that order - exactly the sum the block's finishing launch forms, which this mode replaces (lddy = partials per row block, ldaz = rows
+// per row block; az itself is not used).
+template <int NV, bool SLAB = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ mean,
@@ -104,14 +108,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         xv[q][i] = dv[q][i] = av[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < D) {
           xv[q][i] = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + c);
-          dv[q][i] = *reinterpret_cast<const float4*>(dy + (int64_t)row * lddy + c);
+          if constexpr (!SLAB) dv[q][i] = *reinterpret_cast<const float4*>(dy + (int64_t)row * lddy + c);
           if (dx_add) av[q][i] = *reinterpret_cast<const float4*>(dx_add + (int64_t)row * ldadd + c);
-          else if (az) av[q][i] = *reinterpret_cast<const float4*>(az + (int64_t)row * ldaz + c);      // with the other loads, not behind the reductions
+          else if (!SLAB && az) av[q][i] = *reinterpret_cast<const float4*>(az + (int64_t)row * ldaz + c);      // with the other loads, not behind the reductions
         }
+      }
+    }
+    if constexpr (SLAB) {
+      static_assert(!SLAB || NV == 1, "slab mode: D == 256");
+      const int wpb = (int)lddy, rbr = (int)ldaz;
+      const float* p[LN_RPW];
+#pragma unroll
+      for (int q = 0; q < LN_RPW; ++q) {
+        const int row = min(row0 + q, M - 1);
+        p[q] = dy + (((int64_t)(row / rbr) * wpb) * rbr + row % rbr) * 256 + lane * 4;
+      }
+      constexpr int NP = 6;      // partials of both rows in flight per round (the finishing launch's order: j ascending)
+      for (int j0 = 0; j0 < wpb; j0 += NP) {
+        float4 t[LN_RPW][NP];
+#pragma unroll
+        for (int q = 0; q < LN_RPW; ++q)
+#pragma unroll
+          for (int j = 0; j < NP; ++j) t[q][j] = *reinterpret_cast<const float4*>(p[q] + (int64_t)min(j0 + j, wpb - 1) * rbr * 256);
+#pragma unroll
+        for (int q = 0; q < LN_RPW; ++q)
+#pragma unroll
+          for (int j = 0; j < NP; ++j)
+            if (j0 + j < wpb) { dv[q][0].x += t[q][j].x; dv[q][0].y += t[q][j].y; dv[q][0].z += t[q][j].z; dv[q][0].w += t[q][j].w; }
       }
     }
 #pragma unroll
     for (int q = 0; q < LN_RPW; ++q) {
+#pragma clang fp contract(off)      // the SLAB instantiation must round like the plain one: no per-instantiation choice of fused multiply-adds
       if (row0 + q >= M) break;
       float4 xh[NV], gd[NV];
       float s1 = 0.f, s2 = 0.f;
@@ -141,7 +169,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.w = rs[q] * (gd[i].w - s1 - xh[i].w * s2);
           if (dx_add) {
             o.x += av[q][i].x; o.y += av[q][i].y; o.z += av[q][i].z; o.w += av[q][i].w;
-          } else if (az) {
+          } else if (!SLAB && az) {
             const float4 zz = av[q][i];
             o.x *= act_bwd(act, zz.x); o.y *= act_bwd(act, zz.y); o.z *= act_bwd(act, zz.z); o.w *= act_bwd(act, zz.w);
           }
@@ -342,6 +370,30 @@ extern "C" int tavsr_layernorm_bwd_partial_drop(const float* dy, int64_t lddy, c
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dx_add, ldadd, dx,
                        lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4, (const float*)nullptr, (int64_t)0, 0);
+  TAVSR_LAUNCH_CHECK();
+  return TAVSR_OK;
+}
+
+// tavsr_layernorm_bwd_partial[_drop] on the unsummed partial slabs of tavsr_ffn2_bwd_dx(dn = NULL): the sum over the partials is formed
+// where the row is read (same order as the finishing launch: same bits) - one launch less per feed-forward block of a backward pass
+extern "C" int tavsr_layernorm_bwd_partial_slab(const float* slab, int32_t wpb, int32_t rb_rows, const float* x, int64_t ldx, const float* mean,
+                                                const float* rstd, const float* gamma, const float* dx_add, int64_t ldadd, float* dx,
+                                                int64_t lddx, float* ws, int64_t ws_ld, int32_t M, int32_t D, float* dx_drop, float p_drop,
+                                                const uint64_t* seed_dev, uint64_t offset, tavsr_stream_t stream) {
+  TAVSR_REQUIRE(slab && x && mean && rstd && gamma && dx && ws, TAVSR_EINVAL, "layernorm_bwd_partial_slab: null pointer");
+  TAVSR_REQUIRE(D == 256 && wpb >= 1 && rb_rows >= 1, TAVSR_EUNSUPPORTED, "layernorm_bwd_partial_slab: D = 256 only (got %d), wpb / rows per block >= 1", D);
+  TAVSR_REQUIRE(ws_ld >= 2 * (int64_t)D, TAVSR_EINVAL, "layernorm_bwd_partial_slab: partial slab rows too short");
+  TAVSR_REQUIRE(!dx_drop || (p_drop > 0.f && p_drop < 1.f && seed_dev && offset % 4 == 0 && lddx == D), TAVSR_EINVAL,
+                "layernorm_bwd_partial_slab: the masked copy needs p in (0, 1), a device seed, an offset %% 4 == 0 and contiguous dx");
+  TAVSR_REQUIRE(ldx % 4 == 0 && lddx % 4 == 0 && ldadd % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)slab % 16 == 0) &&
+                    ((uintptr_t)dx % 16 == 0) && ((uintptr_t)dx_add % 16 == 0) && ((uintptr_t)dx_drop % 16 == 0),
+                TAVSR_EALIGN, "layernorm_bwd_partial_slab: rows must be 16-byte aligned");
+  if (M <= 0) return TAVSR_OK;
+  const uint32_t thr = dx_drop ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  const float ik = dx_drop ? 1.f / (1.f - p_drop) : 1.f;
+  hipLaunchKernelGGL((layernorm_bwd_kernel<1, true>), dim3(ln_blocks(M)), dim3(256), 0, (hipStream_t)stream, slab, (int64_t)wpb, x, ldx, mean, rstd,
+                     gamma, dx_add, ldadd, dx, lddx, ws, ws_ld, M, D, dx_drop, thr, ik, seed_dev, offset / 4, (const float*)nullptr,
+                     (int64_t)rb_rows, 0);
   TAVSR_LAUNCH_CHECK();
   return TAVSR_OK;
 }

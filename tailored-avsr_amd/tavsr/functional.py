@@ -117,7 +117,10 @@ class _FFN:
         gw2, gb2 = wgrad(dyd, h, alpha=scale, bias_grad=True)
         stream2 = chain and ops.FFN2_BWD and ops.ffn2_shape_ok(dyd, w1, act) and z.is_contiguous()
         if stream2:
-            dz, dn = ops.ffn2_bwd_dx(dyd, scale, w1, w2, z, act, t_in)
+            # the block's own LayerNorm backward is dn's only reader: it sums the launch's partials itself (no finishing launch)
+            slab_ok = (ops.FFN2_BWD_LN and lng is not None and lng.takes(*x.shape) and (out_drop is None or ops.LN_BWD_DROP)
+                       and x.is_contiguous())
+            dz, dn = ops.ffn2_bwd_dx(dyd, scale, w1, w2, z, act, t_in, sum_dn=not slab_ok)
         else:
             dz = ops.linear_dx_drop(dyd, w2, t_in, alpha=scale, DZ=z, dact=act)    # inner mask and act'(z) in the epilogue
         gw1, gb1 = wgrad(dz, n, bias_grad=True)

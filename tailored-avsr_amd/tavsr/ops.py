@@ -667,10 +667,16 @@ class LNGroup:
         self.CAP = cap
         self.key, self.slab, self.out, self.k = None, None, None, 0
 
+    def takes(self, M, D) -> bool:
+        """the next ``bwd`` of this shape goes through the group's own launch (D = 256: also in the slab form)"""
+        return D == 256 and (self.key is None or ((M, D) == self.key and self.k < self.CAP))
+
     def bwd(self, dy, x, mean, rstd, gamma, *, dx_add=None, dx=None, drop=None):
         """``drop`` (a dropout token): also returns dx * mask / keep as a fourth result (the masked gradient the next residual
         block's branch starts from) - from the same launch when the group takes the call, else from a dropout launch."""
         M, D = x.shape
+        if isinstance(dy, DnSlabs):       # (callers ask ``takes`` first: the group's own launch is the only one that reads slabs)
+            assert self.takes(M, D) and (drop is None or LN_BWD_DROP)
         if drop is not None and not LN_BWD_DROP:
             r = self.bwd(dy, x, mean, rstd, gamma, dx_add=dx_add, dx=dx)
             return r + (dropout(r[0], drop[0], token=drop)[0],)
@@ -682,10 +688,26 @@ class LNGroup:
         if (M, D) != self.key or self.k >= self.CAP:
             r = layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=dx_add, dx=dx)
             return r if drop is None else r + (dropout(r[0], drop[0], token=drop)[0],)
-        require_cuda(dy, x, mean, rstd, gamma, dx_add)
+        slabs = dy if isinstance(dy, DnSlabs) else None
+        require_cuda(slabs.ws if slabs else dy, x, mean, rstd, gamma, dx_add)
         if dx is None:
             dx = empty(M, D, like=x)
         off = self.k * 2 * D
+        if slabs is not None:
+            dxd = empty(M, D, like=x) if drop is not None else None
+            assert dx.is_contiguous()
+            check(lib().tavsr_layernorm_bwd_partial_slab(ptr(slabs.ws), slabs.wpb, slabs.rb, ptr(x), C.c_int64(x.stride(0)), ptr(mean),
+                                                         ptr(rstd), ptr(gamma), ptr(dx_add),
+                                                         C.c_int64(0 if dx_add is None else dx_add.stride(0)), ptr(dx),
+                                                         C.c_int64(dx.stride(0)), C.c_void_p(_addr(self.slab) + 4 * off),
+                                                         C.c_int64(self.slab.stride(0)), M, D, ptr(dxd),
+                                                         C.c_float(drop[0] if drop is not None else 0.0),
+                                                         ptr(drop[2] if drop is not None else None),
+                                                         C.c_uint64(drop[1] if drop is not None else 0), stream()),
+                  "tavsr_layernorm_bwd_partial_slab")
+            self.k += 1
+            r = (dx, self.out[off: off + D], self.out[off + D: off + 2 * D])
+            return r if drop is None else r + (dxd,)
         if drop is not None:
             assert dx.is_contiguous()
             dxd = empty(M, D, like=x)
@@ -892,21 +914,44 @@ def ffn2_fwd(x, ln_w, ln_b, eps, w1, b1, w2, b2, act, scale, p=0.0, save=True, l
     return y, (n, mean, rstd, z, h, tok_in, tok_out), outs, (m2, r2)
 
 
-def ffn2_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in):
+FFN2_BWD_LN = os.environ.get("TAVSR_FFN2_BWD_LN", "1") != "0"      # the block's LayerNorm backward sums dn's partials itself (no finishing launch); flipped in tests/test_gpu_switches.py
+
+
+class DnSlabs:
+    """dn of ``ffn2_bwd_dx(..., sum_dn=False)``: the unsummed partials in the launch's workspace (tavsr_ffn2_slab_layout)"""
+    __slots__ = ("ws", "wpb", "rb", "shape")
+
+    def __init__(self, ws, wpb, rb, shape):
+        self.ws, self.wpb, self.rb, self.shape = ws, wpb, rb, shape
+
+
+def ffn2_bwd_dx(dyd, alpha, w1, w2, z, act, tok_in, sum_dn=True):
     """(dz [M, N1], dn [M, 256]) of the block: dz = ((alpha * dyd) w2) * mask / keep * act'(z), dn = dz w1 - the streaming
-    counterpart of linear_dx_drop + linear_dx (weights untransposed)."""
+    counterpart of linear_dx_drop + linear_dx (weights untransposed).  ``sum_dn`` False: dn comes back as ``DnSlabs`` for
+    ``LNGroup.bwd``, which sums the partials where it reads the rows."""
     M, D = dyd.shape
     N1 = w1.shape[0]
     require_cuda(dyd, w1, w2, z)
     assert w1.is_contiguous() and w2.is_contiguous() and z.is_contiguous() and z.shape == (M, N1)
-    dz, dn = empty((M + 127) // 128 * 128, N1, like=dyd)[:M], empty(M, D, like=dyd)
+    dz = empty((M + 127) // 128 * 128, N1, like=dyd)[:M]
+    dn = empty(M, D, like=dyd) if sum_dn else None
     nws = lib_i64("tavsr_ffn2_ws", M, D, N1)
     ws = empty(nws, like=dyd)
     check(lib().tavsr_ffn2_bwd_dx(ptr(dyd), C.c_int64(dyd.stride(0)), C.c_float(alpha), ptr(w1), ptr(w2), ptr(z), ACT[act], M, D,
                                   N1, C.c_float(tok_in[0] if tok_in else 0.0), ptr(tok_in[2] if tok_in else None),
                                   C.c_uint64(tok_in[1] if tok_in else 0), ptr(dz), ptr(dn), ptr(ws), C.c_int64(nws), stream()),
           "tavsr_ffn2_bwd_dx")
-    return dz, dn
+    if sum_dn:
+        return dz, dn
+    lay = _SLAB_LAYOUT.get((M, N1))
+    if lay is None:
+        wpb, rb = C.c_int32(0), C.c_int32(0)
+        check(lib().tavsr_ffn2_slab_layout(M, N1, C.byref(wpb), C.byref(rb)), "tavsr_ffn2_slab_layout")
+        lay = _SLAB_LAYOUT[(M, N1)] = (wpb.value, rb.value)
+    return dz, DnSlabs(ws, lay[0], lay[1], (M, D))
+
+
+_SLAB_LAYOUT = {}
 
 
 # One Branchformer layer forward as ONE C call (csrc/layer.hip): the same launches, sequenced in C.  For un-captured loops

@@ -160,6 +160,33 @@ def test_ffn2_backward_dx_matches_fp64(M, N1, act, p, cfg):
     assert torch.equal(dz, dz2) and torch.equal(dn, dn2)
 
 
+@pytest.mark.parametrize("M,N1,p_out", [(3168, 2048, 0.0), (3168, 2048, 0.1), (1312, 2048, 0.1), (100, 2048, 0.0), (1, 2048, 0.1), (300, 1056, 0.0)])
+def test_layernorm_backward_on_the_unsummed_partials_equals_finish_then_layernorm(M, N1, p_out):
+    """tavsr_layernorm_bwd_partial_slab (ops.LNGroup.bwd on ops.DnSlabs): the feed-forward block's LayerNorm backward reads dn as the
+    partial slabs of tavsr_ffn2_bwd_dx(dn = NULL) and sums them in the finishing launch's order - dx, the masked copy and (dgamma, dbeta)
+    bit-equal to the finishing launch + tavsr_layernorm_bwd_partial[_drop] it replaces, at every row-block count (wpb = 3 ... 23)."""
+    from tavsr import ops
+    D = 256
+    ln_w, _, w1, _, w2, _ = _params(D, N1, seed=M + 7)
+    z = torch.randn(M, N1, device="cuda") * 1.5
+    dyd, x, dy = (torch.randn(M, D, device="cuda") for _ in range(3))
+    mean, rstd = x.mean(1), torch.rsqrt(x.var(1, unbiased=False) + 1e-5)
+    ops.manual_seed(9)
+    tok = ops._new_token(p_out, M * D, z.device) if p_out else None
+    res = []
+    for sum_dn in (True, False):
+        dz, dn = ops.ffn2_bwd_dx(dyd, 0.5, w1, w2, z, "swish", None, sum_dn=sum_dn)
+        assert sum_dn or isinstance(dn, ops.DnSlabs)
+        lng = ops.LNGroup()
+        assert lng.takes(M, D)
+        out = lng.bwd(dn, x, mean, rstd, ln_w, dx_add=dy, drop=tok)
+        lng.flush()
+        res.append((dz,) + tuple(t.clone() for t in out))
+    assert len(res[0]) == (5 if p_out else 4)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_ffn_block_function_streaming_equals_gemm_launches():
     """functional._FFN forward + backward with the streaming forward against the LayerNorm + GEMM + GEMM launches, with the
     recipe's dropout on: same masks, so outputs and every gradient agree."""
