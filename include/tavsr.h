@@ -40,6 +40,11 @@ const char* tavsr_last_error_string(void);   /* host string, thread-local */
  * mode 0 = head of the forked section, 1 = behind the join on the calling queue, 2 = alternately per call; us = 0 disarms. */
 int tavsr_spin(float us, tavsr_stream_t stream);
 int tavsr_race_probe(float us, int mode);
+/* a queue of the host side's own (hipStreamCreateWithFlags, non-blocking) for the side of a fork.  torch hands its streams out of a pool
+ * of 32 per device, round-robin: the 33rd `torch.cuda.Stream()` of a process IS the first one again, so a side stream taken from the pool can
+ * turn up later as somebody's capturing stream - and the host's fork registry, keyed by the raw handle, would then order a capture behind a
+ * stream outside it.  The handle lives as long as the process. */
+int tavsr_stream_create(tavsr_stream_t* out);
 /* tuning aid (scripts/launch_floor.py): a launch of `grid` x `block` threads that does nothing (kind 0), one 16-byte read + write per
  * thread (1), or that plus a barrier and a dependent second read (2) - the floor under a one-token step's dependent launches */
 int tavsr_probe_launch(int32_t kind, int32_t grid, int32_t block, float* buf, int64_t n, tavsr_stream_t stream);

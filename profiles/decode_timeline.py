@@ -1,6 +1,7 @@
 """Per-token timeline of the beam search from a rocprofv3 kernel trace (rocpd sqlite) of bench_decode.py: a step is the
 span between two beam_combine launches.  Prints the median step span, the time with at least one kernel running, and
-per-kernel calls / time per step.   usage: python profiles/decode_timeline.py <results.db> [first_step last_step]"""
+per-kernel calls / time per step.   usage: python profiles/decode_timeline.py <results.db> [first_step last_step] [--sequence]
+--sequence: one step in the middle, launch by launch (start offset, duration, hardware queue, kernels already running at its start)."""
 import re
 import sqlite3
 import statistics
@@ -10,7 +11,16 @@ db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 names = [re.sub(r"\(.*$", "", r[0]).replace("void ", "").replace("tavsr::", "") for r in rows]
 marks = [i for i, n in enumerate(names) if "beam_combine" in n or "beam_select" in n]
-lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (len(marks) // 2, len(marks) // 2 + 40)
+if "--sequence" in sys.argv:
+    q = db.execute("select queue_id from kernels order by start").fetchall()
+    si = len(marks) // 2
+    t0, ends = rows[marks[si]][1], []
+    for i in range(marks[si], marks[si + 1] + 1):
+        ends = [e for e in ends if e > rows[i][1]]
+        print(f"{(rows[i][1] - t0) / 1e3:9.2f} us  {(rows[i][2] - rows[i][1]) / 1e3:7.2f} us  q{q[i][0]}  beside {len(ends)}  {names[i][:100]}")
+        ends.append(rows[i][2])
+    sys.exit(0)
+lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 and sys.argv[2].isdigit() else (len(marks) // 2, len(marks) // 2 + 40)
 hi = min(hi, len(marks) - 1)
 spans, busys, overs, agg = [], [], [], {}
 for si in range(lo, hi):

@@ -9,13 +9,17 @@ from tavsr.inference import beam_search as B
 from tavsr.lm.transformer_lm import TransformerLM
 from tavsr.tasks.avsr import AVSRTask
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--short", action="store_true", help="only: both / LM only / decoder only / neither / one queue")
+args = ap.parse_args()
 dev = torch.device("cuda:0")
 conf = BD.make_conf()
 torch.manual_seed(1)
 model = AVSRTask.build_model(argparse.Namespace(**copy.deepcopy(conf))).eval().to(dev)
 lm = TransformerLM(len(conf["token_list"]), **BD.LM_CONF).eval().to(dev)
 search = B.BatchBeamSearch(model, lm, **BD.SEARCH)
-batch = BD.make_utts(1, 1234, dev)
+batch = BD.make_utts(args.batch, 1234, dev)
 with torch.no_grad():
     enc, olens = model.encode(*batch)
 steps_seen = []
@@ -40,20 +44,27 @@ def timed(tag):
     print(f"{tag:46s} {1e6 * min(ts):8.1f} us per token ({steps_seen[-1]} tokens)", flush=True)
 
 timed("both scorers, two queues")
-B.CTC_BESIDE_SCORERS = not B.CTC_BESIDE_SCORERS
-timed(f"both scorers, CTC prefix scores beside the scorers = {B.CTC_BESIDE_SCORERS}")
-B.CTC_BESIDE_SCORERS = not B.CTC_BESIDE_SCORERS
+B.RECORD_QUEUE = not B.RECORD_QUEUE
+search._copy_q = None
+timed(f"both scorers, records on a queue of their own = {B.RECORD_QUEUE}")
+B.RECORD_QUEUE = not B.RECORD_QUEUE
+search._copy_q = None
 timed("both scorers, two queues (again)")
-from tavsr._lib import lib as _lib
-for mode, what in ((0, "four waves per item"), (1, "one wave per item"), (3, "the plan")):
+if not args.short:
+  B.CTC_BESIDE_SCORERS = not B.CTC_BESIDE_SCORERS
+  timed(f"both scorers, CTC prefix scores beside the scorers = {B.CTC_BESIDE_SCORERS}")
+  B.CTC_BESIDE_SCORERS = not B.CTC_BESIDE_SCORERS
+  timed("both scorers, two queues (again)")
+  from tavsr._lib import lib as _lib
+  for mode, what in ((0, "four waves per item"), (1, "one wave per item"), (3, "the plan")):
     _lib().tavsr_tree_attn_tune(mode)
     timed(f"both scorers, tree attention: {what}")
-from tavsr import ops as _ops
-for ff in (4,):
+  from tavsr import ops as _ops
+  for ff in (4,):
     _ops.ROWLIN_KSPLIT = ff
     timed(f"both scorers, feed-forward closing projection in {ff} K slice(s)")
 dec_step, lm_step = search.dec_step.step, search.lm_step.step
-N, V = search.K, search.V
+N, V = search.K * args.batch, search.V
 const = torch.full((N, V), -3.7, device=dev)
 def fake_dec(i, tok, anc, dyn=None, **score):
     out = torch.empty(N, V, device=dev)

@@ -155,6 +155,15 @@ extern "C" int tavsr_probe_seam(int32_t kind, int32_t grid, int64_t per_wg, int3
   return TAVSR_OK;
 }
 
+extern "C" int tavsr_stream_create(tavsr_stream_t* out) {
+  TAVSR_REQUIRE(out, TAVSR_EINVAL, "stream_create: null pointer");
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  TAVSR_REQUIRE(e == hipSuccess, TAVSR_EINVAL, "stream_create: %s", hipGetErrorString(e));
+  *out = (tavsr_stream_t)s;
+  return TAVSR_OK;
+}
+
 extern "C" int tavsr_race_probe(float us, int mode) {
   TAVSR_REQUIRE(us >= 0.f && us <= 1e6f && mode >= 0 && mode <= 2, TAVSR_EINVAL, "race_probe: us in 0 .. 1e6, mode 0 / 1 / 2");
   tavsr::g_probe_us = us;

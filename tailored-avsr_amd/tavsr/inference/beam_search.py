@@ -76,9 +76,14 @@ PREBEAM_FUSED = True   # pre-beam top-k inside the CTC prefix launch
 # of the decoder's - the recursion over the frames (20 us) leaves the critical path of a captured step - and the whole beam update
 # behind the scorers (LM log-softmax, pre-beam, weighted scores, top-k) is one launch (tavsr_beam_select_topk).
 # (module constants, flipped in-process by tests/test_beam_search.py and scripts/decode_chain_probe.py - not environment switches)
-RECORD_QUEUE = True        # per-token records leave on a queue of their own
+# per-token records on a queue of their own (TAVSR_RECORD_QUEUE=1) or on the search queue between two replays (default).  A queue of their
+# own needs an event behind every replay that ANOTHER queue waits on - and that wait costs the NEXT replay ~1.5 us per launch it holds
+# (scripts/graph_pair_probe.py: 60 launches +90 us, 190 launches +275 us; an event record alone, an eager launch or the 128-byte copy on
+# the replaying queue itself: +5 us).  In the search: 633 -> 563 us per token at batch 1, 2359 -> 2188 at batch 64 (same process, alternating).
+RECORD_QUEUE = os.environ.get("TAVSR_RECORD_QUEUE", "0") == "1"
 LN_IN_EPILOGUE = True      # batched steps: tavsr_gemm_ln at the x + f(x) -> norm(x) seams
 CTC_BESIDE_SCORERS = True
+_DEC_FIRST = os.environ.get("TAVSR_DEC_FIRST", "0") == "1"      # (experiment: which chain is captured first)
 
 
 class _Normed:
@@ -412,16 +417,24 @@ class BatchBeamSearch:
             # the two scorers are independent chains of small launches: the LM runs on the side stream next to the decoder
             has_lm = self.lm_step is not None
             spec = dyn is not None and CTC_BESIDE_SCORERS and ops.beam_select_topk_ok(K, V) and C <= V
-            if has_lm:
+            if has_lm and spec and _DEC_FIRST:
+                with ops.BranchScope(enabled=SCORERS_PARALLEL) as br:
+                    r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, dyn["cand_all"], K, i,
+                                                                              step_dev=dyn["step"])
+                    full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
+                z_lm = self.lm_step.step(i, tok, anc, sdyn, logits_only=True)
+                br.join()
+            else:
+              if has_lm:
                 with ops.BranchScope(enabled=SCORERS_PARALLEL) as br:
                     z_lm = self.lm_step.step(i, tok, anc, sdyn, logits_only=True)
-            if spec:
+              if spec:
                 # on the decoder's queue, in front of its chain: the decoder has ~100 us of slack behind the LM (a third queue for it
                 # made the whole step 45 us SLOWER: profiles/r05_notes.md)
                 r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, dyn["cand_all"], K, i,
                                                                           step_dev=dyn["step"])
-            full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
-            if has_lm:
+              full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
+              if has_lm:
                 br.join()
             if spec:
                 top_s, top_i = ops.beam_select_topk(full, z_lm if has_lm else None, self.w_lm, self.w_len if has_lm else 0.0, psi, psi_abs,
@@ -574,9 +587,8 @@ class BatchBeamSearch:
             timing = os.environ.get("TAVSR_DECODE_TIMING") == "1"   # host-side cost of a token: replay call / record processing
             t_replay = t_host = t_wait = 0.0
             import time as _time
-            # the records travel on a queue of their own: the copy of token i's record waits for step i (an event), step i + 1 does
-            # not wait for the copy - the search queue holds nothing but the replays (a 120-byte copy between two replays cost the
-            # chain a launch of its own per token)
+            # the record of token i leaves behind step i on the search queue itself (see RECORD_QUEUE for the queue of their own the
+            # records had, and what the event it needs costs the next replay)
             main_q = torch.cuda.current_stream()
             if self._copy_q is None:
                 self._copy_q = torch.cuda.Stream() if RECORD_QUEUE else main_q
@@ -585,9 +597,10 @@ class BatchBeamSearch:
             for i in range(steps):
                 t0 = _time.perf_counter()
                 graph.replay()
-                stepped = torch.cuda.Event()
-                stepped.record(main_q)
-                copy_q.wait_event(stepped)
+                if copy_q is not main_q:
+                    stepped = torch.cuda.Event()
+                    stepped.record(main_q)
+                    copy_q.wait_event(stepped)
                 with torch.cuda.stream(copy_q):
                     pin[i].copy_(hist[i], non_blocking=True)
                     ev = torch.cuda.Event()

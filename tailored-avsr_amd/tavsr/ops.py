@@ -281,9 +281,19 @@ def branch_stream(main: torch.cuda.Stream, slot: int = 0) -> torch.cuda.Stream:
     key = (main.device.index, main.cuda_stream, slot)
     s = _BRANCH.get(key)
     if s is None:
-        s = _BRANCH[key] = torch.cuda.Stream(device=main.device)
+        s = _BRANCH[key] = own_stream(main.device)
         L.register_fork(s, main)
     return s
+
+
+def own_stream(device) -> torch.cuda.Stream:
+    """a queue that is nobody else's (tavsr_stream_create): ``torch.cuda.Stream()`` comes out of a round-robin pool of 32 per device, and a
+    side stream that later re-appears as some capture's stream would make the fork registry (keyed by raw handles) order that capture
+    behind a stream outside it."""
+    h = C.c_void_p(0)
+    with torch.cuda.device(device):
+        check(lib().tavsr_stream_create(C.byref(h)), "tavsr_stream_create")
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 # Race amplifier (tests only): TAVSR_RACE_PROBE=<microseconds> enqueues a spin kernel at the head of every forked body

@@ -234,3 +234,18 @@ def test_the_amplifier_catches_the_races_the_rules_prevent(_streams_restored):
     assert counts[False] == 0, counts
     if counts[True] == 0:      # (a race is a matter of timing: not provoking one on some box says nothing about the product)
         pytest.skip("the amplifier provoked no race with the rules off on this box")
+
+
+def test_the_side_of_a_fork_is_never_a_stream_of_torchs_pool():
+    """torch hands ``torch.cuda.Stream()`` out of a round-robin pool of 32 per device: a side stream taken from it re-appears, 32 streams
+    later, as somebody's main or capturing stream - and the fork registry (``_lib._FORKED``, keyed by raw handles) then made a hipGraph
+    capture wait for a stream outside it (a segfault in the first replay, in whatever test happened to draw the alias).  Side streams are
+    the package's own (tavsr_stream_create): none of them is ever handed out by the pool."""
+    from tavsr import _lib, ops
+    pool = {torch.cuda.Stream().cuda_stream for _ in range(70)}      # both priorities' pools wrap around well before 70
+    assert len(pool) <= 64
+    mains = [torch.cuda.Stream() for _ in range(3)] + [torch.cuda.current_stream()]
+    sides = [ops.branch_stream(m, slot) for m in mains for slot in (0, 1)]
+    assert len({s.cuda_stream for s in sides}) >= 7                 # (the three pool streams may alias each other; their sides do not)
+    assert not {s.cuda_stream for s in sides} & pool
+    assert not set(_lib._FORKED) & pool
