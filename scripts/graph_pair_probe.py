@@ -146,6 +146,22 @@ for n, us in ((60, 3.0), (190, 3.0), (190, 12.0)):
                 gs[0].replay()
                 pdst.copy_(dsrc, non_blocking=True)
 
+    try:
+        e_ext = torch.cuda.Event(external=True)
+        g_ext = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_ext, stream=main):
+            chain(n, us)
+            e_ext.record(torch.cuda.current_stream())
+
+        def with_external_event(reps=40):       # the event is a node of the graph; another stream waits for it after every replay
+            with torch.cuda.stream(main):
+                for _ in range(reps):
+                    g_ext.replay()
+                    sa.wait_event(e_ext)
+        t_ext = f"{timed(with_external_event, 5) / 40:8.1f} us"
+    except Exception as exc:      # (no external events in this torch / HIP)
+        t_ext = f"n/a ({type(exc).__name__})"
+    print(f"   an event recorded INSIDE the captured graph (external) that another stream waits for after every replay {t_ext}", flush=True)
     print(f"   between two replays: an event record only {timed(with_record_only, 5) / 40:8.1f} us   an eager launch {timed(with_eager_launch, 5) / 40:8.1f} us   "
           f"a 128-byte copy to pinned memory on the same stream {timed(with_copy_on_main, 5) / 40:8.1f} us", flush=True)
     print(f"chain of {n} launches of {us:4.1f} us, 40 replays back to back, per replay: the same executable graph {timed(same, 5) / 40:8.1f} us   "
