@@ -730,7 +730,6 @@ class BranchformerLayerFn(torch.autograd.Function):
         for n_, g in zip(("norm_ff.weight", "norm_ff.bias", "feed_forward.w_1.weight", "feed_forward.w_1.bias",
                           "feed_forward.w_2.weight", "feed_forward.w_2.bias"), gs):
             put(n_, g)
-        ops.wgrad_launch_carried("ffn")
         # merge projection: x2 = x1 + coeff * (m Wm^T + bm)
         m = sv["merge"][-1]
         t_cat = sv["drop"][0]
@@ -825,7 +824,6 @@ class BranchformerLayerFn(torch.autograd.Function):
             dx1, g1, g2, *dyd = lng.bwd(dn, x1, mean, rstd, p("norm_mlp.weight"), dx_add=dx1, drop=None if has_attn else t_ffm)
             put("norm_mlp.weight", g1); put("norm_mlp.bias", g2)
         br.join()
-        ops.wgrad_launch_carried("join")
         if has_attn:     # same accumulation order into dx1 as a single stream: cgMLP branch first, then attention
             dx1, g1, g2, *dyd = lng.bwd(dn_a, x1, a_mean, a_rstd, p("norm_mha.weight"), dx_add=dx1, drop=t_ffm)
             put("norm_mha.weight", g1); put("norm_mha.bias", g2)
@@ -839,7 +837,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             if prm is None:
                 G[i] = None
         if ops.wgrad_may_go_beside(P):       # no reader before the end of the pass: beside the next layer's chain
-            ops.wgrad_defer(lambda: (grp.flush(), lng.flush()))
+            ops.wgrad_beside(lambda: (grp.flush(), lng.flush()))
         else:
             grp.flush()
             lng.flush()

@@ -83,7 +83,6 @@ PREBEAM_FUSED = True   # pre-beam top-k inside the CTC prefix launch
 RECORD_QUEUE = os.environ.get("TAVSR_RECORD_QUEUE", "0") == "1"
 LN_IN_EPILOGUE = True      # batched steps: tavsr_gemm_ln at the x + f(x) -> norm(x) seams
 CTC_BESIDE_SCORERS = True
-_DEC_FIRST = os.environ.get("TAVSR_DEC_FIRST", "0") == "1"      # (experiment: which chain is captured first)
 
 
 class _Normed:
@@ -417,24 +416,16 @@ class BatchBeamSearch:
             # the two scorers are independent chains of small launches: the LM runs on the side stream next to the decoder
             has_lm = self.lm_step is not None
             spec = dyn is not None and CTC_BESIDE_SCORERS and ops.beam_select_topk_ok(K, V) and C <= V
-            if has_lm and spec and _DEC_FIRST:
-                with ops.BranchScope(enabled=SCORERS_PARALLEL) as br:
-                    r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, dyn["cand_all"], K, i,
-                                                                              step_dev=dyn["step"])
-                    full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
-                z_lm = self.lm_step.step(i, tok, anc, sdyn, logits_only=True)
-                br.join()
-            else:
-              if has_lm:
+            if has_lm:
                 with ops.BranchScope(enabled=SCORERS_PARALLEL) as br:
                     z_lm = self.lm_step.step(i, tok, anc, sdyn, logits_only=True)
-              if spec:
+            if spec:
                 # on the decoder's queue, in front of its chain: the decoder has ~100 us of slack behind the LM (a third queue for it
                 # made the whole step 45 us SLOWER: profiles/r05_notes.md)
                 r_new, psi, psi_abs, eos_s, eos_abs = ops.ctc_prefix_step(logp_ctc, enc_lens, r_prev, s_prev, tok, dyn["cand_all"], K, i,
                                                                           step_dev=dyn["step"])
-              full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
-              if has_lm:
+            full = self.dec_step.step(i, tok, anc, sdyn, alpha=self.w_dec, add=0.0 if has_lm else self.w_len)
+            if has_lm:
                 br.join()
             if spec:
                 top_s, top_i = ops.beam_select_topk(full, z_lm if has_lm else None, self.w_lm, self.w_len if has_lm else 0.0, psi, psi_abs,

@@ -377,7 +377,6 @@ class BranchScope:
 WGRAD_BESIDE = os.environ.get("TAVSR_WGRAD_BESIDE", "1") != "0"
 WGRAD_SLOT = int(os.environ.get("TAVSR_WGRAD_SLOT", "0"))
 _WGRAD_OPEN = {}        # raw handle of the owning stream -> (owner, side) with weight-gradient launches nobody has joined yet
-_WGRAD_CB = [False]
 
 
 def wgrad_fence() -> None:
@@ -385,7 +384,12 @@ def wgrad_fence() -> None:
     if not _WGRAD_OPEN:
         return
     cur = torch.cuda.current_stream()
+    capturing = torch.cuda.is_current_stream_capturing()
     for owner, side in list(_WGRAD_OPEN.values()):
+        if capturing:
+            with torch.cuda.stream(side):
+                if not torch.cuda.is_current_stream_capturing():
+                    continue       # left open by a pass that died before this capture began: not this graph's work (a capture cannot wait for it)
         cur.wait_stream(side)
         if owner.cuda_stream != cur.cuda_stream:       # (the owner itself must be behind them too before a capture ends)
             owner.wait_stream(side)
@@ -393,41 +397,19 @@ def wgrad_fence() -> None:
 
 
 def _wgrad_end_of_pass() -> None:
-    _WGRAD_CB[0] = False
-    while _WGRAD_CARRY:          # nobody offered a launch point any more: on the calling stream
-        _WGRAD_CARRY.pop(0)()
     wgrad_fence()
 
 
-WGRAD_AT = os.environ.get("TAVSR_WGRAD_AT", "end")     # where a layer's weight gradients are enqueued: "end" of its own backward, or carried
-_WGRAD_CARRY = []                                      # to the NEXT layer's backward: behind its first "ffn" block / behind its branch "join"
-
-
 def _wgrad_callback() -> bool:
+    """queues the end-of-pass join with the autograd pass that is running.  One per caller, not one per pass behind a flag: a pass that dies
+    half-way (an out-of-memory error the training loop survives) never runs its callbacks, and a flag it had set would leave every later pass
+    un-joined; a second ... twelfth callback of one pass finds nothing open and returns."""
     from torch.autograd import Variable
-    if not _WGRAD_CB[0]:
-        try:
-            Variable._execution_engine.queue_callback(_wgrad_end_of_pass)
-            _WGRAD_CB[0] = True
-        except RuntimeError:          # not inside an autograd pass (a test driving a backward by hand): nothing would join it
-            return False
+    try:
+        Variable._execution_engine.queue_callback(_wgrad_end_of_pass)
+    except RuntimeError:              # not inside an autograd pass (a test driving a backward by hand): nothing would join it
+        return False
     return True
-
-
-def wgrad_defer(fn) -> None:
-    """the end of a layer's backward: ``fn`` computes its weight gradients (launches only)"""
-    if WGRAD_AT == "end":
-        return wgrad_beside(fn)
-    if not _wgrad_callback():
-        return fn()
-    wgrad_launch_carried()
-    _WGRAD_CARRY.append(fn)
-
-
-def wgrad_launch_carried(at=None) -> None:
-    if _WGRAD_CARRY and (at is None or at == WGRAD_AT):
-        while _WGRAD_CARRY:
-            wgrad_beside(_WGRAD_CARRY.pop(0))
 
 
 def wgrad_may_go_beside(params) -> bool:

@@ -226,3 +226,34 @@ def test_no_one_token_linear_variant_spills_registers():
     assert len(names) == len(scratch) and any("rowlin_kernel" in n for n in names)
     bad = [(n, s) for n, s in zip(names, scratch) if "rowlin_kernel" in n and s > 0]
     assert not bad, bad
+
+
+def test_weight_gradients_only_go_beside_the_chain_when_nobody_reads_them_inside_the_pass():
+    """``ops.wgrad_may_go_beside``: a layer leaves its weight gradients in flight on the side queue (joined at the end of the autograd
+    pass) only if AccumulateGrad will KEEP the tensors - no parameter has a ``.grad`` to add into - and nobody's hook reads them where
+    they are accumulated; this package's own bucket hooks (``dp.GradBuckets.attach_overlap_hooks``) fence themselves and are let through;
+    one queue (``TAVSR_SINGLE_STREAM``) and ``WGRAD_BESIDE = False`` switch it off."""
+    import torch
+    from tavsr import _lib, ops
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(3)]
+    assert ops.wgrad_may_go_beside(ps + [None])
+    ps[1].grad = torch.zeros(3)                       # a second micro-batch: AccumulateGrad adds in place, on arrival
+    assert not ops.wgrad_may_go_beside(ps)
+    ps[1].grad = None
+    h = ps[2].register_hook(lambda g: g)              # a tensor hook sees the gradient inside the pass
+    assert not ops.wgrad_may_go_beside(ps)
+    h.remove()
+    assert ops.wgrad_may_go_beside(ps)
+    h = ps[0].register_post_accumulate_grad_hook(lambda p: None)      # somebody else's hook
+    assert not ops.wgrad_may_go_beside(ps)
+    ps[0]._tavsr_hooks_fence = True                   # ... this package's own (dp marks its parameters)
+    assert ops.wgrad_may_go_beside(ps)
+    keep = (ops.WGRAD_BESIDE, _lib.SINGLE_STREAM)
+    try:
+        ops.WGRAD_BESIDE = False
+        assert not ops.wgrad_may_go_beside(ps)
+        ops.WGRAD_BESIDE, _lib.SINGLE_STREAM = True, True
+        assert not ops.wgrad_may_go_beside(ps)
+    finally:
+        ops.WGRAD_BESIDE, _lib.SINGLE_STREAM = keep
+    ops.wgrad_fence()                                 # nothing open: a no-op, also without a GPU
