@@ -477,8 +477,8 @@ class TailoredStreamFn(torch.autograd.Function):
         dx, gs = _FFN.bwd(dx1, sv["ffm"], p["norm_ff_macaron.weight"], p["feed_forward_macaron.w_1.weight"],
                           p["feed_forward_macaron.w_2.weight"], act, 0.5, grp=grp, lng=lng, chain=False, dyd=dyd)
         G.update(zip(_FFM, gs))
-        grp.flush()
-        lng.flush()
+        grp.flush()        # (on the side queue, un-joined, as the Branchformer layer does: 380 -> 375 utt/s on the AV step - the two modality
+        lng.flush()        # streams already share the chip, and the second stream's side queue is a third queue)
         ctx.sv = None
         return (dx.view(B, T, D), None, None, None, *[G[n] for n in ctx.names])
 

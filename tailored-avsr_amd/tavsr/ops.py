@@ -390,10 +390,8 @@ def wgrad_fence() -> None:
             with torch.cuda.stream(side):
                 if not torch.cuda.is_current_stream_capturing():
                     continue       # left open by a pass that died before this capture began: not this graph's work (a capture cannot wait for it)
-        cur.wait_stream(side)
-        if owner.cuda_stream != cur.cuda_stream:       # (the owner itself must be behind them too before a capture ends)
-            owner.wait_stream(side)
-    _WGRAD_OPEN.clear()
+        cur.wait_stream(side)      # (only the calling stream: an owner that is itself a forked stream has been joined already - a wait enqueued
+    _WGRAD_OPEN.clear()            # on it now would be work no capture ever joins)
 
 
 def _wgrad_end_of_pass() -> None:
