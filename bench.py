@@ -15,7 +15,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   asr          - BASELINE configs[1] (the audio-only step) under the same protocol, so the driver's record holds it too (with its own
                  CPU figure);
   decode       - BASELINE configs[4] (beam 10 + 16 x 512 LM on the AV model): batch-1 p50 RTF over 8 utterances of 4 s and batch-64
-                 utterances/s over 128, taken by a child `bench_decode.py --driver-record` when this process has no GPU work in flight;
+                 utterances/s over 128, taken by a child `bench_decode.py --driver-record` BEFORE this process touches the GPU (a second HIP
+                 context on the device, even an idle one, costs a batch-1 search 11 - 19 % per token);
   rccl_world, dist_world, dist_backend, hbm_peak_gb_per_rank - which exchange really ran (ranks of the C ABI's RCCL communicator,
                  0 = none) and every rank's peak device memory: the first things to read on an N > 1 line;
   fwd_encoder  - north_star's forward target (12-layer Branchformer forward, batch 32);
@@ -440,6 +441,23 @@ def main():
                "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    decode_obj = None
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and WORKLOAD == "avsr" and args.mode == "step" and not args.no_decode
+            and not args.no_fwd_encoder):
+        # BASELINE configs[4] on the driver's record (replicas only; nothing to scale here), taken by a CHILD process BEFORE this process
+        # touches the GPU.  A batch-1 search is a chain of ~140 dependent launches per token; it runs 11 - 19 % slower per token when a second
+        # process holds a HIP context on the same GPU, idle or not (scripts/decode_after_load_probe.sh: 632 us per token alone, 693 beside an
+        # idle process with 8 streams; behind this file's training legs as a child of this process: 749) - and 14 % slower inside a process
+        # that has run the training legs.  Heat is not it: right behind 30 s of training steps a fresh process decodes at 629.  Never an exec.
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_decode.py"), "--driver-record"], capture_output=True, text=True,
+                               timeout=600, env=dict(os.environ))
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            decode_obj = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:      # noqa: BLE001 - the headline line must still be printed
+            decode_obj = {"error": repr(e)[:400]}
+
     from tavsr import dp, ops
 
     rank, local, world = dp.init_from_env(force_rccl=args.force_rccl)
@@ -710,21 +728,8 @@ def main():
         out["fwd_encoder"] = bench_fwd_encoder(dev)
         if WORKLOAD == "avsr" and not args.no_asr:
             out["asr"] = bench_asr_step(dev)
-    if rank == 0 and world == 1 and WORKLOAD == "avsr" and not args.no_decode and not args.no_fwd_encoder:
-        # BASELINE configs[4] on the driver's record (replicas only; nothing to scale here).  A process of its own: a batch-1 search is a
-        # chain of ~140 launches per token that the host must keep ahead of, and this process - its allocator pools, queues and heap after
-        # the training legs - runs the same search 14 % slower per token than a fresh one (731 vs 640 us on one box).  A child, started
-        # when this process has no GPU work in flight; never an exec.
-        import subprocess
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_decode.py"), "--driver-record"], capture_output=True, text=True,
-                               timeout=600, env=dict(os.environ))
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            out["decode"] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-400:]}
-        except Exception as e:      # noqa: BLE001 - the headline line must still be printed
-            out["decode"] = {"error": repr(e)[:400]}
+    if decode_obj is not None and rank == 0:
+        out["decode"] = decode_obj
     if box is not None:
         out["box"] = box
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
