@@ -1,18 +1,9 @@
-# how the number of hardware queues the HIP runtime spreads its streams over (GPU_MAX_HW_QUEUES, default 4) moves the search:
-# batch 64 (utt/s) and batch 1 (p50 RTF)
+# how the number of hardware queues the HIP runtime spreads its streams over (GPU_MAX_HW_QUEUES, default 4) moves the search
+# (driver-record protocol: batch-1 p50 RTF over 8 utterances, batch-64 utt/s over 128), alternating inside one call
 mkdir -p gpurun_out
-for q in "" 1 2 3 6 8; do
+DR='import bench_decode as B, torch, json; d = B.driver_record(torch.device("cuda:0"), cpu=False); print(json.dumps({"b1_p50": d["batch1"]["rtf_p50"], "us_per_token": d["batch1"]["search_us_per_token"], "b64": d["batch64"]["utterances_per_s"]}))'
+for rep in 1 2; do
+for q in "" 2 3 8; do
   if [ -n "$q" ]; then export GPU_MAX_HW_QUEUES=$q; else unset GPU_MAX_HW_QUEUES; fi
-  timeout 600 python bench_decode.py --utterances 128 --batch 64 --no-cpu-baseline > gpurun_out/hwq.json 2> gpurun_out/hwq.err || tail -3 gpurun_out/hwq.err
-  python - "${q:-default}" 64 <<'PY'
-import json, sys
-d = json.loads(open("gpurun_out/hwq.json").read().strip().splitlines()[-1])
-print(f"GPU_MAX_HW_QUEUES={sys.argv[1]:8s} batch {sys.argv[2]}: {d.get('value')} {d.get('unit')}  p50 RTF {d.get('rtf_p50')}", flush=True)
-PY
-  timeout 600 python bench_decode.py --utterances 12 --batch 1 --no-cpu-baseline > gpurun_out/hwq.json 2> gpurun_out/hwq.err || tail -3 gpurun_out/hwq.err
-  python - "${q:-default}" 1 <<'PY'
-import json, sys
-d = json.loads(open("gpurun_out/hwq.json").read().strip().splitlines()[-1])
-print(f"GPU_MAX_HW_QUEUES={sys.argv[1]:8s} batch {sys.argv[2]}: {d.get('value')} {d.get('unit')}  p50 RTF {d.get('rtf_p50')}", flush=True)
-PY
-done
+  echo "GPU_MAX_HW_QUEUES=${q:-default(4)}: $(timeout 300 python -c "$DR" 2>/dev/null | tail -1)"
+done; done
