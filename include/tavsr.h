@@ -562,6 +562,12 @@ typedef struct tavsr_subsample_bwd_desc {
   float *g_w1, *g_b1, *g_w2, *g_b2, *g_wo, *g_bo;
   float* ws;
   int64_t ws_floats;
+  int32_t wgrad_beside;            /* 1 (with stream2 and ev_fork): the weight gradients of the second convolution and of the output Linear, and their
+                                      re-layouts, are enqueued on stream2 behind the launch that produces dz2 and are NOT joined (as
+                                      tavsr_bf_layer_bwd_desc.wgrad_beside): the caller orders the readers of g_w2 / g_b2 / g_wo / g_bo and the next
+                                      user of ws / dout behind stream2.  Same results. */
+  tavsr_stream_t stream2;
+  void* ev_fork;                   /* a hipEvent_t of the caller's */
 } tavsr_subsample_bwd_desc;
 int64_t tavsr_conv2d_subsample_bwd_ws(const tavsr_subsample_bwd_desc* b);
 int tavsr_conv2d_subsample_bwd(const tavsr_subsample_bwd_desc* b, tavsr_stream_t stream);

@@ -154,8 +154,11 @@ int sub_bwd_seq(const tavsr_subsample_bwd_desc* b, hipStream_t s, Bump& ws) {
   const int64_t M2 = (int64_t)B * q.T2, K2 = (int64_t)q.F2 * C, Mo = M2 * q.F2;
   const bool dry = ws.dry;
   int rc;
+  // wgrad_beside: the two weight-gradient GEMMs (0.09 + 0.67 ms at batch 32) and their re-layouts have no reader inside the backward pass;
+  // on stream2 they run beside the dgrad GEMM, col2im and the first convolution's backward instead of in front of them.  NOT joined here.
+  hipStream_t sw = s;
+  if (!dry && b->wgrad_beside && b->stream2 && (hipStream_t)b->stream2 != s) sw = (hipStream_t)b->stream2;
   float* gwor = ws.take((int64_t)odim * K2);
-  if ((rc = wgrad(b->dout, odim, d->y2, K2, (int)M2, odim, (int)K2, d->xscale, gwor, b->g_bo, ws, s))) return rc;
   // dz2 = (dout wor) * xscale * relu'(y2)
   float* dz2 = ws.take(Mo * C);
   {
@@ -163,6 +166,11 @@ int sub_bwd_seq(const tavsr_subsample_bwd_desc* b, hipStream_t s, Bump& ws) {
     g.b_kmajor = 1; g.ldb = K2; g.alpha = d->xscale; g.DZ = d->y2; g.dact = TAVSR_ACT_RELU;
     if ((rc = run_gemm(g, ws, s))) return rc;
   }
+  if (sw != s) {
+    TAVSR_HIP_CHECK(hipEventRecord((hipEvent_t)b->ev_fork, s));
+    TAVSR_HIP_CHECK(hipStreamWaitEvent(sw, (hipEvent_t)b->ev_fork, 0));
+  }
+  if ((rc = wgrad(b->dout, odim, d->y2, K2, (int)M2, odim, (int)K2, d->xscale, gwor, b->g_bo, ws, sw))) return rc;
   float* gw2r = ws.take((int64_t)C * 9 * C);
   {
     tavsr_gemm_desc g;
@@ -175,7 +183,11 @@ int sub_bwd_seq(const tavsr_subsample_bwd_desc* b, hipStream_t s, Bump& ws) {
     g.a_rowsum = b->g_b2;
     g.conv_mode = 2; g.conv_H = q.T1; g.conv_W = q.F1; g.conv_C = C; g.conv_stride = 2; g.conv_taps = 90;
     g.conv_zero = d->zero_page;
-    if ((rc = run_gemm(g, ws, s))) return rc;
+    if ((rc = run_gemm(g, ws, sw))) return rc;
+  }
+  if (!dry) {
+    if ((rc = tavsr_transpose_inner(gwor, b->g_wo, odim, q.F2, C, 0, (tavsr_stream_t)sw))) return rc;
+    if ((rc = tavsr_transpose_inner(gw2r, b->g_w2, C, 9, C, 0, (tavsr_stream_t)sw))) return rc;
   }
   float* dcol = ws.take(Mo * 9 * C);
   {
@@ -189,8 +201,6 @@ int sub_bwd_seq(const tavsr_subsample_bwd_desc* b, hipStream_t s, Bump& ws) {
   if (!dry) {
     if ((rc = tavsr_col2im3x3s2_relu(dcol, d->y1, dz1, B, q.T1, q.F1, C, (tavsr_stream_t)s))) return rc;
     if ((rc = tavsr_conv1_bwd(dz1, d->x, b->g_w1, b->g_b1, 0, cws, B, d->T, d->F, C, (tavsr_stream_t)s))) return rc;
-    if ((rc = tavsr_transpose_inner(gwor, b->g_wo, odim, q.F2, C, 0, (tavsr_stream_t)s))) return rc;
-    if ((rc = tavsr_transpose_inner(gw2r, b->g_w2, C, 9, C, 0, (tavsr_stream_t)s))) return rc;
   }
   return TAVSR_OK;
 }

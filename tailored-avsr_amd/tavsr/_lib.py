@@ -156,7 +156,7 @@ class SubsampleBwdDesc(C.Structure):
     """tavsr_subsample_bwd_desc (include/tavsr.h)"""
     _fields_ = ([("fwd", C.POINTER(SubsampleDesc)), ("dout", C.c_void_p)]
                 + [(n, C.c_void_p) for n in ("g_w1", "g_b1", "g_w2", "g_b2", "g_wo", "g_bo", "ws")]
-                + [("ws_floats", C.c_int64)])
+                + [("ws_floats", C.c_int64), ("wgrad_beside", C.c_int32), ("stream2", C.c_void_p), ("ev_fork", C.c_void_p)])
 
 
 class FfnDesc(C.Structure):

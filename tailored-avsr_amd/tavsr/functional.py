@@ -964,11 +964,11 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         Cn = w1.shape[0]
         if CONV2_IMPLICIT and ops.BLOCKS_C and ops.conv2d_subsample_ok(x, w1, wo):      # the whole module as one C call
             out, T2, F2, kept, desc = ops.conv2d_subsample_fwd(x, w1.contiguous(), b1, w2.contiguous(), b2, wo.contiguous(), bo, xscale)
-            ctx.cdesc, ctx.ckept = desc, kept
+            ctx.cdesc, ctx.ckept, ctx.cparams = desc, kept, (w1, b1, w2, b2, wo, bo)
             ctx.save_for_backward()
             ctx.dims = (B, T, F, Cn, T2, F2, xscale, w1.shape, w2.shape, wo.shape)
             return out.view(B, T2, -1)
-        ctx.cdesc = None
+        ctx.cdesc, ctx.cparams = None, (w1, b1, w2, b2, wo, bo)
         y1 = ops.conv1_fwd(x.contiguous(), w1.reshape(Cn, 9), b1)              # [B,T1,F1,C] NHWC, relu
         # torch (co, ci, kh, kw) -> (co, kh, kw, ci) to match the channels-last patch order
         w2r = ops.transpose_inner(w2, Cn, Cn, 9).view(Cn, 9 * Cn)
@@ -993,24 +993,29 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         B, T, F, Cn, T2, F2, xscale, w1s, w2s, wos = ctx.dims
         do = dout.contiguous().view(B * T2, -1)
         if ctx.cdesc is not None:
-            gw1, gb1, gw2, gb2, gwo, gbo = ops.conv2d_subsample_bwd(ctx.cdesc, do, (w1s, w2s, wos))
-            ctx.cdesc = ctx.ckept = None
+            gw1, gb1, gw2, gb2, gwo, gbo = ops.conv2d_subsample_bwd(ctx.cdesc, do, (w1s, w2s, wos), params=ctx.cparams, kept=ctx.ckept)
+            ctx.cdesc = ctx.ckept = ctx.cparams = None
             return None, gw1, gb1, gw2, gb2, gwo, gbo, None
         x, y1, col, y2, w2r, wor = ctx.saved_tensors
         y2f = y2.view(B * T2, F2 * Cn)
-        gwor, gbo = ops.linear_dw(do, y2f, alpha=xscale, bias_grad=True)        # [odim, F2*C], [odim]
         # dz2 = (do @ wor) * xscale * relu'(y2)
         dz2 = ops.linear_dx(do, wor, alpha=xscale, DZ=y2f, dact="relu").view(B * T2 * F2, Cn)
-        if col is None:
-            gw2r, gb2 = ops.conv3x3_dw(dz2, y1.view(-1, Cn), y1.shape[1], y1.shape[2], stride=2, pad0=True, bias_grad=True)
-        else:
-            gw2r, gb2 = ops.linear_dw(dz2, col, bias_grad=True)                 # [C, 9C], [C]
+        res = {}
+
+        def wgrads():
+            gwor, res["gbo"] = ops.linear_dw(do, y2f, alpha=xscale, bias_grad=True)        # [odim, F2*C], [odim]
+            if col is None:
+                gw2r, res["gb2"] = ops.conv3x3_dw(dz2, y1.view(-1, Cn), y1.shape[1], y1.shape[2], stride=2, pad0=True, bias_grad=True)
+            else:
+                gw2r, res["gb2"] = ops.linear_dw(dz2, col, bias_grad=True)                 # [C, 9C], [C]
+            res["gwo"] = ops.transpose_inner(gwor, wos[0], F2, Cn).view(wos)
+            res["gw2"] = ops.transpose_inner(gw2r, Cn, 9, Cn).view(w2s)
+
+        ops.wgrad_beside(wgrads) if ops.wgrad_may_go_beside(ctx.cparams) else wgrads()      # (as the C-side block: beside the dgrad chain)
         dcol = ops.linear_dx(dz2, w2r)                                          # [B*T2*F2, 9C]
         dz1 = ops.col2im3x3s2_relu(dcol, y1)
         gw1, gb1 = ops.conv1_bwd(dz1, x.contiguous(), Cn)
-        gwo = ops.transpose_inner(gwor, wos[0], F2, Cn).view(wos)
-        gw2 = ops.transpose_inner(gw2r, Cn, 9, Cn).view(w2s)
-        return None, gw1.view(w1s), gb1, gw2, gb2, gwo, gbo, None
+        return None, gw1.view(w1s), gb1, res["gw2"], res["gb2"], res["gwo"], res["gbo"], None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -946,7 +946,7 @@ _SLAB_LAYOUT = {}
 
 # One Branchformer layer forward as ONE C call (csrc/layer.hip): the same launches, sequenced in C.  For un-captured loops
 # (the host is what limits an eager step); a captured step replays the same kernels either way.  TAVSR_LAYER_C=0: Python sequencing.
-BLOCKS_C = True      # block-level C entry points (tavsr_conv2d_subsample_*, tavsr_cgmlp_fwd) instead of launch-by-launch sequencing
+BLOCKS_C = os.environ.get("TAVSR_BLOCKS_C", "1") != "0"      # block-level C entry points (tavsr_conv2d_subsample_*, tavsr_cgmlp_fwd) instead of launch-by-launch sequencing
 LAYER_C = os.environ.get("TAVSR_LAYER_C", "1") != "0"
 LAYER_C_EAGER_ONLY = os.environ.get("TAVSR_LAYER_C", "1") != "capture"     # TAVSR_LAYER_C=capture: also while a hipGraph is being captured
 _BR_EVENTS = {}
@@ -1134,8 +1134,9 @@ def conv2d_subsample_fwd(x, w1, b1, w2, b2, wo, bo, xscale):
     return out, T2, F2, (x, y1, y2, w2r, wor), d
 
 
-def conv2d_subsample_bwd(desc, dout, shapes):
-    """-> (g_w1, g_b1, g_w2, g_b2, g_wo, g_bo) in the torch layouts ``shapes`` = (w1, w2, wo shapes)"""
+def conv2d_subsample_bwd(desc, dout, shapes, params=None, kept=()):
+    """-> (g_w1, g_b1, g_w2, g_b2, g_wo, g_bo) in the torch layouts ``shapes`` = (w1, w2, wo shapes).  ``params`` (the module's six
+    parameters) + ``kept`` (the forward's buffers): the weight gradients may run on the side queue, un-joined (``wgrad_may_go_beside``)."""
     require_cuda(dout)
     w1s, w2s, wos = shapes
     b = L.SubsampleBwdDesc()
@@ -1148,7 +1149,16 @@ def conv2d_subsample_bwd(desc, dout, shapes):
     nws = lib_i64("tavsr_conv2d_subsample_bwd_ws", C.byref(b))
     ws = empty(max(nws, 4), like=dout)
     b.ws, b.ws_floats = _addr(ws), nws
+    main = torch.cuda.current_stream()
+    side = branch_stream(main) if (params is not None and forks_enabled() and WGRAD_SLOT == 0) else None
+    beside = side is not None and wgrad_may_go_beside(params) and wgrad_open(main, side)
+    if beside:
+        b.wgrad_beside, b.stream2, b.ev_fork = 1, side.cuda_stream, branch_events(main)[0].cuda_event
     check(lib().tavsr_conv2d_subsample_bwd(C.byref(b), stream()), "tavsr_conv2d_subsample_bwd")
+    if beside:      # what the side queue's launches read and write is freed on THIS stream (rule 1 of _lib.py, by hand)
+        for t in (ws, dout, *grads, *kept):
+            if torch.is_tensor(t) and not isinstance(t, torch.nn.Parameter):
+                t.record_stream(side)
     return grads
 
 
