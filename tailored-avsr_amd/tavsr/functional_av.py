@@ -91,6 +91,9 @@ def _bn_eval_bwd(dy, z, mean, rstd, gamma, beta, res, act):
     raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference's path (validation is no_grad)")
 
 
+_FRONT_WGRAD_BESIDE = os.environ.get("TAVSR_FRONT_WGRAD_BESIDE", "1") != "0"
+
+
 class VisualFrontendFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cfg, *P):
@@ -169,6 +172,16 @@ class VisualFrontendFn(torch.autograd.Function):
         B, T, N, Hc, Wc, cl = ctx.dims
         G = {}
         d = ops.avgpool_bwd(dfeat.contiguous().view(N, cl), N, Hc * Wc, cl)
+        # The chain of this backward is BatchNorm backward (two passes over the maps: HBM-bound) -> dgrad convolution (MFMA-bound) -> BatchNorm
+        # backward -> ...; the weight-gradient convolutions (12.7 ms of the step at batch 32) hang off it with no reader inside the pass.  On the
+        # side queue, un-joined (ops.wgrad_beside), they run under the BatchNorm passes instead of between them.
+        beside = _FRONT_WGRAD_BESIDE and ops.wgrad_may_go_beside(list(p.values()))
+
+        def wgrad(name, fn):
+            if beside:
+                ops.wgrad_beside(lambda: G.__setitem__(name, fn()))
+            else:
+                G[name] = fn()
 
         def self_ds_bwd(ds, dres, pre, Xin, N, Hin, Win, cin, stride):
             """backward of the 1x1 downsample convolution + its BatchNorm: parameter gradients into G, returns the data
@@ -176,26 +189,25 @@ class VisualFrontendFn(torch.autograd.Function):
             zd, md, rd, wd = ds
             _, dzd, G[pre + "downsample.1.weight"], G[pre + "downsample.1.bias"] = ops.bn_bwd(
                 dres, zd, md, rd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"], None, None, need_dz=False)
-            G[pre + "downsample.0.weight"] = _w2d_grad(_conv3x3_dw(dzd, Xin, N, Hin, Win, cin, stride, taps=1),
-                                                       p[pre + "downsample.0.weight"].shape)
+            wgrad(pre + "downsample.0.weight", lambda: _w2d_grad(_conv3x3_dw(dzd, Xin, N, Hin, Win, cin, stride, taps=1),
+                                                                 p[pre + "downsample.0.weight"].shape))
             return ops.linear_dx(dzd, wd)
 
         for (pre, stride, cin, planes, Hin, Win, Ho, Wo, Xin, z1, m1, r1, w1, z2, m2, r2, w2, res, ds, y1) in reversed(ctx.blocks):
             # out = swish(bn2(z2) + res)
             dres, dz2, G[pre + "bn2.weight"], G[pre + "bn2.bias"] = ops.bn_bwd(
                 d, z2, m2, r2, p[pre + "bn2.weight"], p[pre + "bn2.bias"], res, "swish")
-            G[pre + "conv2.weight"] = _w2d_grad(_conv3x3_dw(dz2, y1, N, Ho, Wo, planes), p[pre + "conv2.weight"].shape)
-            del y1
+            wgrad(pre + "conv2.weight", lambda: _w2d_grad(_conv3x3_dw(dz2, y1, N, Ho, Wo, planes), p[pre + "conv2.weight"].shape))
             dy1 = ops.conv3x3_dx(dz2, ops.conv_wflip(w2, planes, planes), Ho, Wo)
             _, dz1, G[pre + "bn1.weight"], G[pre + "bn1.bias"] = ops.bn_bwd(
                 dy1, z1, m1, r1, p[pre + "bn1.weight"], p[pre + "bn1.bias"], None, "swish", need_dz=False)
             fused_ds = False
             if stride == 1:
-                G[pre + "conv1.weight"] = _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin), p[pre + "conv1.weight"].shape)
+                wgrad(pre + "conv1.weight", lambda: _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin), p[pre + "conv1.weight"].shape))
                 # identity skip: its gradient joins in the GEMM epilogue (no separate add over the 0.4 GB maps)
                 dX = ops.conv3x3_dx(dz1, ops.conv_wflip(w1, planes, cin), Hin, Win, res=None if ds is not None else dres)
             else:
-                G[pre + "conv1.weight"] = _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin, stride), p[pre + "conv1.weight"].shape)
+                wgrad(pre + "conv1.weight", lambda: _w2d_grad(_conv3x3_dw(dz1, Xin, N, Hin, Win, cin, stride), p[pre + "conv1.weight"].shape))
                 dcol1 = ops.linear_dx(dz1, w1)
                 dcold = None
                 if ds is not None:   # the downsample path's data gradient joins inside the col2im pass (same stride, same input)
