@@ -411,7 +411,9 @@ def _wgrad_callback() -> bool:
 
 
 def wgrad_may_go_beside(params) -> bool:
-    if not (WGRAD_BESIDE and forks_enabled()):
+    # (not in an instrumented pass: ``PROFILE`` brackets every GEMM launch with events to time the KERNEL - beside the chain a launch shares the
+    # chip with whatever runs there, and bench.py's roofline would read 0.47 of peak for a kernel that does 0.63 alone)
+    if not (WGRAD_BESIDE and forks_enabled()) or PROFILE is not None:
         return False
     for p_ in params:
         if p_ is None:
