@@ -26,7 +26,8 @@ ASR_SWITCHES = [("tavsr.ops", "FFN2", False), ("tavsr.ops", "FFN2_BWD", False), 
                 ("tavsr.models.espnet_model", "LOSS_BRANCH", False), ("tavsr._lib", "SINGLE_STREAM", True)]
 AV_SWITCHES = [("tavsr.functional_av", "FRONT_PAIR", False), ("tavsr.functional_av", "STEM_POOL_FUSED", False),
                ("tavsr.ops", "STEM_PAD16", False), ("tavsr.ops", "STEM_IMPLICIT", False), ("tavsr.ops", "FFN2", False),
-               ("tavsr.ops", "MERGE_ROWS", False), ("tavsr.ops", "ATTN_FUSED", False), ("tavsr.ops", "CSGU_FUSED", False)]
+               ("tavsr.ops", "MERGE_ROWS", False), ("tavsr.ops", "ATTN_FUSED", False), ("tavsr.ops", "CSGU_FUSED", False),
+               ("tavsr.ops", "WGRAD_BESIDE", False), ("tavsr.functional_av", "_FRONT_WGRAD_BESIDE", False)]
 
 
 def _model(workload, dropout):
@@ -113,3 +114,22 @@ def test_launch_scheduling_switches_do_not_change_a_bit(dropout):
 
 def test_every_route_selector_of_the_audio_visual_step():
     _flip_and_compare("avsr", AV_SWITCHES, 0.0)
+
+
+def test_weight_gradients_beside_the_chain_do_not_change_a_bit_of_the_audio_visual_step():
+    """``WGRAD_BESIDE`` on the AV model: the lip front-end's 17 weight-gradient convolutions, Conv2dSubsampling's two and the decoder's first
+    flush run on side queues, joined at the end of the autograd pass - same kernels, same plans, another queue: every gradient bit-equal."""
+    from tavsr import ops
+    model, batch, params = _model("avsr", 0.0)
+    names = [n for n, _ in model.named_parameters()]
+    keep = ops.WGRAD_BESIDE
+    try:
+        ops.WGRAD_BESIDE = True
+        ref = _step(model, batch, params)
+        ops.WGRAD_BESIDE = False
+        got = _step(model, batch, params)
+    finally:
+        ops.WGRAD_BESIDE = keep
+    assert got[0] == ref[0]
+    bad = [n for n, a, b in zip(names, got[1], ref[1]) if not torch.equal(a, b)]
+    assert not bad, bad[:6]
