@@ -2,6 +2,8 @@
 // tavsr/functional.py:BranchformerLayerFn.forward enqueues through ~45 Python-level calls, as one C call over the same entry
 // points - for un-captured (ragged) training loops, whose step is host-bound on that sequencing.  Host code only.
 // Reference: src/encoder/branchformer/encoder_layer.py:153-321 (MyBranchformerEncoderLayer.forward).
+#include <functional>
+
 #include "seq.h"
 
 using namespace tavsr;
@@ -464,6 +466,8 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
   auto mat = [&](int64_t n) { return ws.take(n); };
   WGroup grp;
   LnGroup lng;
+  std::function<int(hipStream_t)> pos_chain;        // (set by the attention branch)
+  const bool pos_late = b->wgrad_beside != 0;      // (not a function of `dry`: the workspace is taken in the same order either way)
   lng.M = M; lng.D = D;
   lng.nb = (int)(tavsr_layernorm_bwd_ws(M, D) / (2 * D));
   lng.slab_ld = 8 * 2 * D;
@@ -533,10 +537,14 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
       a.scale = 1.f / sqrtf((float)dk);
       if (d->p_att > 0.f) { a.p_drop = d->p_att; a.seed_dev = d->seed; a.drop_offset = d->drop_off[2]; }
       if ((rc = tavsr_attn_bwd(&a, dcx, d->cx, D, d->lse, dqu, dqv, D, dqkv + D, 3 * D, dqkv + 2 * D, 3 * D, sk, Wp, (tavsr_stream_t)s2))) return rc;
-      // dP[:, h] = sum_b ds_skew[h, b]^T (q + v)[b, :, h]: one K = B T contraction per head
-      if ((rc = tavsr_add_head_bias(d->qkv, 3 * D, d->pos_u, d->pos_v, qu, qv, M, D, (tavsr_stream_t)s2))) return rc;
     }
-    {
+    // The gradient of the projected positional rows and linear_pos's weight gradient (add_head_bias + two GEMMs, ~55 us at batch 32) have ONE
+    // reader: the parameter's gradient.  With wgrad_beside they leave the attention branch - the longer one - and run with the other weight
+    // gradients at the end of the call (tavsr/functional.py: pos_dw; audio-only step 1902 -> 1954 utt/s).
+    pos_chain = [=, &ws](hipStream_t st) -> int {
+      int rc2;
+      // dP[:, h] = sum_b ds_skew[h, b]^T (q + v)[b, :, h]: one K = B T contraction per head
+      if (!ws.dry && (rc2 = tavsr_add_head_bias(d->qkv, 3 * D, d->pos_u, d->pos_v, qu, qv, M, D, (tavsr_stream_t)st))) return rc2;
       tavsr_gemm_desc gp;
       memset(&gp, 0, sizeof gp);
       gp.M = W; gp.N = dk; gp.K = M;
@@ -545,10 +553,7 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
       gp.nb1 = H; gp.nb2 = 1;
       gp.sA1 = (int64_t)M * Wp; gp.sB1 = dk; gp.sC1 = dk;
       gp.alpha = 1.f;
-      if ((rc = run_gemm(gp, ws, s2))) return rc;
-    }
-    if (!dry && (rc = tavsr_add2_colsum(dqu, D, dqv, D, dqkv, 3 * D, M, D, b->g_pos_u, b->g_pos_v, csws, (tavsr_stream_t)s2))) return rc;
-    {
+      if ((rc2 = run_gemm(gp, ws, st))) return rc2;
       tavsr_gemm_desc gw;       // linear_pos.weight: K = 2T - 1 is not a multiple of 32, it stays alone
       memset(&gw, 0, sizeof gw);
       gw.M = D; gw.N = D; gw.K = W;
@@ -556,8 +561,10 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
       gw.A = dp; gw.lda = D; gw.B = d->pos_emb; gw.ldb = D; gw.C = b->g_wpos; gw.ldc = D;
       gw.nb1 = gw.nb2 = 1;
       gw.alpha = 1.f;
-      if ((rc = run_gemm(gw, ws, s2))) return rc;
-    }
+      return run_gemm(gw, ws, st);
+    };
+    if (!pos_late && (rc = pos_chain(s2))) return rc;
+    if (!dry && (rc = tavsr_add2_colsum(dqu, D, dqv, D, dqkv, 3 * D, M, D, b->g_pos_u, b->g_pos_v, csws, (tavsr_stream_t)s2))) return rc;
     grp.add(dqkv, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wq, b->g_bq);
     grp.add(dqkv + D, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wk, b->g_bk);
     grp.add(dqkv + 2 * D, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wv, b->g_bv);
@@ -619,6 +626,7 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
     TAVSR_HIP_CHECK(hipStreamWaitEvent(s2, (hipEvent_t)d->ev_fork, 0));
     sw = s2;
   }
+  if (pos_late && pos_chain && (rc = pos_chain(sw))) return rc;
   if ((rc = grp.flush(ws, sw))) return rc;
   (void)g_ln;
   return lng.flush(dry, sw);

@@ -134,6 +134,9 @@ class _FFN:
         return dx, (gln_w, gln_b, gw1, gb1, gw2, gb2)
 
 
+_POS_DW_BESIDE = os.environ.get("TAVSR_POS_DW_BESIDE", "1") != "0"
+
+
 class _AttnFused:
     """Attention core on the fused kernels (ops.attn_fwd / attn_bwd): scores, rel_shift, mask, softmax, dropout and the
     context product in one launch; only the per-row log-sum-exp is kept for the backward, which recomputes the
@@ -148,9 +151,10 @@ class _AttnFused:
 
     @staticmethod
     def bwd(dctx, ctx, saved, q, q_off, kbuf, k_off, vbuf, v_off, dq, dq_off, dk_buf, dk_off, dv_buf, dv_off, B, T1, T2, H,
-            dk, klens, causal, pos=None, bias_u=None, bias_v=None):
+            dk, klens, causal, pos=None, bias_u=None, bias_v=None, lazy_dp=False):
         """writes d/d(q+u) into dq, dK, dV into their windows; rel-pos: returns (dqv, dp) with dp the gradient of the
-        projected positional rows [2*T1-1, H*dk]."""
+        projected positional rows [2*T1-1, H*dk].  ``lazy_dp``: dp comes back as a function that computes it (two launches whose only
+        reader is linear_pos's weight gradient: the caller may run them with its other weight gradients, off the backward chain)."""
         lse, tok = saved
         dqv, sk = ops.attn_bwd(dctx, ctx, lse, tok, q, q_off, kbuf, k_off, vbuf, v_off, B, T1, T2, H, dk, dq, dq_off,
                                dk_buf, dk_off, dv_buf, dv_off, klens=klens, causal=causal, pos=pos, bias_u=bias_u,
@@ -159,12 +163,15 @@ class _AttnFused:
             return None, None
         D = H * dk
         W, Wp = 2 * T1 - 1, sk.shape[-1]
-        # dP[:,h] = sum_b ds_skew[h,b]^T (q + v)[b,:,h]  == one K = B*T1 GEMM per head
-        _, qv = ops.add_head_bias(q[:, q_off: q_off + D], bias_u, bias_v)
-        dp = ops.empty(W, D, like=dctx)
-        ops.gemm(W, dk, B * T1, sk, Wp, qv, D, dp, D, a_kmajor=True, b_kmajor=True, nb1=H, sA=(B * T1 * Wp, 0),
-                 sB=(dk, 0), sC=(dk, 0))
-        return dqv, dp
+
+        def make_dp():
+            # dP[:,h] = sum_b ds_skew[h,b]^T (q + v)[b,:,h]  == one K = B*T1 GEMM per head
+            _, qv = ops.add_head_bias(q[:, q_off: q_off + D], bias_u, bias_v)
+            dp = ops.empty(W, D, like=dctx)
+            ops.gemm(W, dk, B * T1, sk, Wp, qv, D, dp, D, a_kmajor=True, b_kmajor=True, nb1=H, sA=(B * T1 * Wp, 0),
+                     sB=(dk, 0), sC=(dk, 0))
+            return dp
+        return dqv, (make_dp if lazy_dp else make_dp())
 
 
 class _SelfAttnCore:
@@ -715,6 +722,8 @@ class BranchformerLayerFn(torch.autograd.Function):
         def put(name, g, like=None):
             G[_I[name]] = g if like is None else g.view_as(like)
 
+        beside = ops.wgrad_may_go_beside(P)
+        pos_dw = None
         grp = ops.WgradGroup()     # every weight gradient of the layer in one grouped launch (flushed at the end)
         lng = ops.LNGroup()        # ... and the five d=256 LayerNorms' (dgamma, dbeta) partials in one reduction
         dy2 = dy.contiguous().view(M, D)
@@ -783,7 +792,7 @@ class BranchformerLayerFn(torch.autograd.Function):
                 if qu is None:       # fused attention core
                     dqv, dp = _AttnFused.bwd(dcx, cx, attn, qkv, 0, qkv, D, qkv, 2 * D, dqu, 0, dqkv, D, dqkv, 2 * D, B, T, T,
                                              H, dk, ctx.lens, False, pos=pp, bias_u=p("attn.pos_bias_u").reshape(-1),
-                                             bias_v=p("attn.pos_bias_v").reshape(-1))
+                                             bias_v=p("attn.pos_bias_v").reshape(-1), lazy_dp=beside and _POS_DW_BESIDE)
                 else:
                     dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
                                                 dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
@@ -791,7 +800,10 @@ class BranchformerLayerFn(torch.autograd.Function):
                 put("attn.pos_bias_u", gu_, like=p("attn.pos_bias_u"))
                 put("attn.pos_bias_v", gv_, like=p("attn.pos_bias_v"))
                 pe2d = ctx.pos_emb.reshape(-1, D)
-                put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))   # K = 2T-1: not a multiple of 32, stays alone
+                if callable(dp):      # the positional rows' gradient and linear_pos's weight gradient (4 launches, ~55 us of the attention
+                    pos_dw = lambda dp=dp: put("attn.linear_pos.weight", ops.linear_dw(dp(), pe2d))      # branch): with the others, beside
+                else:
+                    put("attn.linear_pos.weight", ops.linear_dw(dp, pe2d))   # K = 2T-1: not a multiple of 32, stays alone
                 for j, nm in enumerate(("q", "k", "v")):   # three problems with their own outputs (no sliced gradients)
                     gw_, gb_ = grp.add(dqkv[:, j * D:(j + 1) * D], n, bias_grad=True)
                     put(f"attn.linear_{nm}.weight", gw_); put(f"attn.linear_{nm}.bias", gb_)
@@ -836,8 +848,8 @@ class BranchformerLayerFn(torch.autograd.Function):
         for i, prm in enumerate(P):
             if prm is None:
                 G[i] = None
-        if ops.wgrad_may_go_beside(P):       # no reader before the end of the pass: beside the next layer's chain
-            ops.wgrad_beside(lambda: (grp.flush(), lng.flush()))
+        if beside:       # no reader before the end of the pass: beside the next layer's chain
+            ops.wgrad_beside(lambda: (pos_dw() if pos_dw else None, grp.flush(), lng.flush()))
         else:
             grp.flush()
             lng.flush()
