@@ -204,6 +204,8 @@ int64_t tavsr_colsum_ws(int32_t M, int32_t N);
  * gradients of RelPositionMultiHeadedAttention); ws >= 2 * tavsr_colsum_ws(M, N) floats */
 int tavsr_add2_colsum(const float* x, int64_t ldx, const float* y, int64_t ldy, float* out, int64_t ldo, int32_t M, int32_t N,
                       float* sum_x, float* sum_y, float* ws, tavsr_stream_t stream);
+/* (sum_x == sum_y == NULL: the reduction launch is left out; the column sums stay as tavsr_colsum_ws(M, N) / N partial rows of 2 N floats in ws
+ * for a later tavsr_sum_partials2(ws, rows, 2 N, sum_x, N, sum_y, N, 0, stream) - bias gradients have no reader inside a backward pass) */
 int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, float scale, float* out,
                  int32_t accumulate, float* ws, tavsr_stream_t stream);
 /* out[i] (+)= sum_{p < nparts} part[p*stride + i], i < n */

@@ -466,7 +466,7 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
   auto mat = [&](int64_t n) { return ws.take(n); };
   WGroup grp;
   LnGroup lng;
-  std::function<int(hipStream_t)> pos_chain;        // (set by the attention branch)
+  std::function<int(hipStream_t)> pos_chain, pos_sums;        // (set by the attention branch)
   const bool pos_late = b->wgrad_beside != 0;      // (not a function of `dry`: the workspace is taken in the same order either way)
   lng.M = M; lng.D = D;
   lng.nb = (int)(tavsr_layernorm_bwd_ws(M, D) / (2 * D));
@@ -564,7 +564,12 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
       return run_gemm(gw, ws, st);
     };
     if (!pos_late && (rc = pos_chain(s2))) return rc;
-    if (!dry && (rc = tavsr_add2_colsum(dqu, D, dqv, D, dqkv, 3 * D, M, D, b->g_pos_u, b->g_pos_v, csws, (tavsr_stream_t)s2))) return rc;
+    if (!dry && (rc = tavsr_add2_colsum(dqu, D, dqv, D, dqkv, 3 * D, M, D, pos_late ? nullptr : b->g_pos_u, pos_late ? nullptr : b->g_pos_v, csws,
+                                        (tavsr_stream_t)s2)))
+      return rc;
+    if (pos_late) pos_sums = [=](hipStream_t st) -> int {      // the two bias gradients: reduced with the other weight gradients at the end
+      return tavsr_sum_partials2(csws, (int32_t)(tavsr_colsum_ws(M, D) / D), 2 * (int64_t)D, b->g_pos_u, D, b->g_pos_v, D, 0, (tavsr_stream_t)st);
+    };
     grp.add(dqkv, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wq, b->g_bq);
     grp.add(dqkv + D, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wk, b->g_bk);
     grp.add(dqkv + 2 * D, 3 * D, d->n_mha, D, M, D, D, 1.f, b->g_wv, b->g_bv);
@@ -626,6 +631,7 @@ int sequence_bwd(const tavsr_bf_layer_bwd_desc* b, hipStream_t s, Bump& ws) {
     TAVSR_HIP_CHECK(hipStreamWaitEvent(s2, (hipEvent_t)d->ev_fork, 0));
     sw = s2;
   }
+  if (!dry && pos_sums && (rc = pos_sums(sw))) return rc;
   if (pos_late && pos_chain && (rc = pos_chain(sw))) return rc;
   if ((rc = grp.flush(ws, sw))) return rc;
   (void)g_ln;

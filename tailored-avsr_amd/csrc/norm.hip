@@ -447,13 +447,16 @@ extern "C" int tavsr_colsum(const float* x, int64_t ldx, int32_t M, int32_t N, f
 
 extern "C" int tavsr_add2_colsum(const float* x, int64_t ldx, const float* y, int64_t ldy, float* out, int64_t ldo, int32_t M,
                                  int32_t N, float* sum_x, float* sum_y, float* ws, tavsr_stream_t stream) {
-  TAVSR_REQUIRE(x && y && out && sum_x && sum_y && ws, TAVSR_EINVAL, "add2_colsum: null pointer");
+  TAVSR_REQUIRE(x && y && out && ws && ((sum_x != nullptr) == (sum_y != nullptr)), TAVSR_EINVAL, "add2_colsum: null pointer");
   if (N <= 0 || M <= 0) return TAVSR_OK;
   hipStream_t s = (hipStream_t)stream;
   const int chunks = colsum_chunks(M);
   const int rpc = cdiv(M, chunks);
   hipLaunchKernelGGL(add2_colsum_part_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, s, x, ldx, y, ldy, out, ldo, M, N, rpc, ws);
   TAVSR_LAUNCH_CHECK();
+  // sum_x == sum_y == NULL: the column sums stay as tavsr_colsum_ws(M, N) / N partial rows of 2 N in ws; the caller reduces them when it
+  // likes (tavsr_sum_partials2(ws, chunks, 2 N, sum_x, N, sum_y, N, 0, stream)) - the sums are bias gradients nobody reads inside a backward pass
+  if (!sum_x) return TAVSR_OK;
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * N, 64)), dim3(kSumWaves * 64), 0, s, ws, chunks, (int64_t)2 * N, sum_x, sum_y, N,
                      2 * N, 0, 1.f);
   TAVSR_LAUNCH_CHECK();

@@ -723,7 +723,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             G[_I[name]] = g if like is None else g.view_as(like)
 
         beside = ops.wgrad_may_go_beside(P)
-        pos_dw = None
+        pos_dw = pos_sums = None
         grp = ops.WgradGroup()     # every weight gradient of the layer in one grouped launch (flushed at the end)
         lng = ops.LNGroup()        # ... and the five d=256 LayerNorms' (dgamma, dbeta) partials in one reduction
         dy2 = dy.contiguous().view(M, D)
@@ -796,7 +796,8 @@ class BranchformerLayerFn(torch.autograd.Function):
                 else:
                     dqv, dp = _SelfAttnCore.bwd(dcx, attn, qu, D, 0, qkv, 3 * D, D, qkv, 3 * D, 2 * D, dqu, D, 0, dqkv, 3 * D, D,
                                                 dqkv, 3 * D, 2 * D, B, T, T, H, dk, qv=qv, p=pp, tok=t_att)
-                gu_, gv_ = ops.add2_colsum(dqu, dqv, dqkv[:, :D])      # dQ = dQu + dQv and both bias gradients, one pass
+                gu_, gv_, *late = ops.add2_colsum(dqu, dqv, dqkv[:, :D], lazy_sums=beside and _POS_DW_BESIDE)      # dQ = dQu + dQv and both bias gradients, one pass
+                pos_sums = late[0] if late else None
                 put("attn.pos_bias_u", gu_, like=p("attn.pos_bias_u"))
                 put("attn.pos_bias_v", gv_, like=p("attn.pos_bias_v"))
                 pe2d = ctx.pos_emb.reshape(-1, D)
@@ -849,7 +850,7 @@ class BranchformerLayerFn(torch.autograd.Function):
             if prm is None:
                 G[i] = None
         if beside:       # no reader before the end of the pass: beside the next layer's chain
-            ops.wgrad_beside(lambda: (pos_dw() if pos_dw else None, grp.flush(), lng.flush()))
+            ops.wgrad_beside(lambda: (pos_sums() if pos_sums else None, pos_dw() if pos_dw else None, grp.flush(), lng.flush()))
         else:
             grp.flush()
             lng.flush()

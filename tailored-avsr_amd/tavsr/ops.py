@@ -587,15 +587,23 @@ def colsum(x, *, scale=1.0, out=None, accumulate=False):
     return out
 
 
-def add2_colsum(x, y, out):
-    """out = x + y (row-strided 2-D views); returns (column sums of x, column sums of y)."""
+def add2_colsum(x, y, out, lazy_sums=False):
+    """out = x + y (row-strided 2-D views); returns (column sums of x, column sums of y).  ``lazy_sums``: a third result, a function that
+    reduces the launch's partial rows into the two sums - they are bias gradients; the caller runs it with its other weight gradients."""
     M, N = x.shape
     require_cuda(x, y, out)
     sx, sy = empty(N, like=x), empty(N, like=x)
-    ws = empty(2 * lib_i64("tavsr_colsum_ws", M, N), like=x)
+    nws = lib_i64("tavsr_colsum_ws", M, N)
+    ws = empty(2 * nws, like=x)
     check(lib().tavsr_add2_colsum(ptr(x), C.c_int64(x.stride(0)), ptr(y), C.c_int64(y.stride(0)), ptr(out),
-                                  C.c_int64(out.stride(0)), M, N, ptr(sx), ptr(sy), ptr(ws), stream()), "tavsr_add2_colsum")
-    return sx, sy
+                                  C.c_int64(out.stride(0)), M, N, ptr(None if lazy_sums else sx), ptr(None if lazy_sums else sy), ptr(ws),
+                                  stream()), "tavsr_add2_colsum")
+    if not lazy_sums:
+        return sx, sy
+
+    def reduce():
+        check(lib().tavsr_sum_partials2(ptr(ws), nws // N, C.c_int64(2 * N), ptr(sx), N, ptr(sy), N, 0, stream()), "tavsr_sum_partials2")
+    return sx, sy, reduce
 
 
 def lib_i64(name, *args) -> int:
