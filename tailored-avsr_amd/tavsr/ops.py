@@ -495,6 +495,22 @@ class WgradGroup:
         dy, x = it[0], it[1]
         return -(-dy.shape[1] // 64) * -(-x.shape[1] // 64)
 
+    @classmethod
+    def _chunks(cls, items):
+        """the grouped launches of ``items``: up to MAX problems each; more than MAX problems (many layers at once: the decoder): problems of
+        one reduction length together (a launch lasts as long as its longest tile), at most 5 x 256 tiles per launch (what is resident at once)"""
+        if len(items) <= cls.MAX:
+            return [items] if items else []
+        chunks, cur, cur_t = [], [], 0
+        for it in sorted(items, key=lambda it: (-it[0].shape[0], -cls._tiles(it))):
+            if cur and (len(cur) == cls.MAX or cur_t + cls._tiles(it) > 1280 or it[0].shape[0] != cur[0][0].shape[0]):
+                chunks.append(cur)
+                cur, cur_t = [], 0
+            cur.append(it)
+            cur_t += cls._tiles(it)
+        chunks.append(cur)
+        return chunks
+
     def flush(self):
         items, self.items = self.items, []
         # All tiles of a group are resident at once (5 block slots x 256 CUs) and equally long (same K), so the launch
@@ -516,19 +532,7 @@ class WgradGroup:
                          a_kmajor=True, b_kmajor=True, alpha=alpha, a_rowsum=gb)
                 keep = set(id(it) for it in rest)
                 items = [it for it in items if id(it) in keep]
-        chunks = [items[i: i + self.MAX] for i in range(0, len(items), self.MAX)]
-        if len(items) > self.MAX:
-            # many layers' problems at once (the decoder): problems of one reduction length together (a launch lasts as long as its longest
-            # tile), at most 5 x 256 tiles per launch (what is resident at once)
-            chunks, cur, cur_t = [], [], 0
-            for it in sorted(items, key=lambda it: (-it[0].shape[0], -self._tiles(it))):
-                if cur and (len(cur) == self.MAX or cur_t + self._tiles(it) > 1280 or it[0].shape[0] != cur[0][0].shape[0]):
-                    chunks.append(cur)
-                    cur, cur_t = [], 0
-                cur.append(it)
-                cur_t += self._tiles(it)
-            chunks.append(cur)
-        for chunk in chunks:
+        for chunk in self._chunks(items):
             arr = (GemmDesc * len(chunk))()
             for d, it in zip(arr, chunk):
                 self._desc(d, *it)

@@ -257,3 +257,26 @@ def test_weight_gradients_only_go_beside_the_chain_when_nobody_reads_them_inside
     finally:
         ops.WGRAD_BESIDE, _lib.SINGLE_STREAM = keep
     ops.wgrad_fence()                                 # nothing open: a no-op, also without a GPU
+
+
+def test_weight_gradient_group_deals_many_layers_problems_into_launches_of_one_reduction_length():
+    """``ops.WgradGroup._chunks`` (the decoder hands it the weight gradients of all its layers at once): every problem in exactly one grouped
+    launch, at most 12 problems and 5 x 256 tiles of 64 x 64 per launch, one reduction length (rows of dy) per launch - a launch lasts as long as
+    its longest tile -; up to 12 problems stay one launch in the order they were added (the encoder layer's group, which the C-side
+    sequencer mirrors)."""
+    import torch
+    from tavsr.ops import WgradGroup
+    def prob(rows, n, k):
+        return (torch.empty(rows, n), torch.empty(rows, k), 1.0, None, None)
+    layer = [prob(1312, 2048, 256), prob(1312, 256, 2048)] + [prob(1312, 256, 256)] * 6 + [prob(3168, 256, 256)] * 2     # a decoder layer
+    items = [p for _ in range(6) for p in layer]
+    chunks = WgradGroup._chunks(items)
+    assert sum(len(c) for c in chunks) == len(items) and sorted(map(id, (p for c in chunks for p in c))) == sorted(map(id, items))
+    for c in chunks:
+        assert 1 <= len(c) <= WgradGroup.MAX
+        assert len({p[0].shape[0] for p in c}) == 1
+        tiles = sum(WgradGroup._tiles(p) for p in c)
+        assert tiles <= 1280 or len(c) == 1
+    assert [p[0].shape[0] for c in chunks for p in c] == sorted((p[0].shape[0] for p in items), reverse=True)     # longest reductions first
+    small = layer[:10]
+    assert WgradGroup._chunks(small) == [small] and WgradGroup._chunks([]) == []
