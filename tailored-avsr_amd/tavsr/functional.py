@@ -1240,7 +1240,7 @@ class TransformerDecoderFn(torch.autograd.Function):
         return (dmem.view(B, T, D), None, None, None, None, None, *G)
 
 
-_DEC_WGRAD = int(os.environ.get("TAVSR_DEC_WGRAD", "3"))
+_DEC_WGRAD = int(os.environ.get("TAVSR_DEC_WGRAD", "5"))     # layers between two flushes of the decoder's weight gradients (6: one flush at the end)
 
 
 class LabelSmoothingLossFn(torch.autograd.Function):
