@@ -129,7 +129,14 @@ def _hook_order_worker(rank, world, port, ret):
     params = [p for l in layers for p in l.parameters()]       # it would silently sum the wrong tensors
     buckets = dp.GradBuckets(params, bucket_bytes=16 * 16 * 4)
     assert len(buckets.buckets) == 4
+    foreign = params[-1].register_post_accumulate_grad_hook(lambda p: None)      # somebody else's hook, there before this package's
     buckets.attach_overlap_hooks()
+    # (ops.wgrad_may_go_beside: a layer may leave its weight gradients in flight on a side queue only if every hook on its parameters is this
+    # package's own - those fence before they pack; a parameter that already carried a hook keeps the layer's gradients in place)
+    from tavsr import ops
+    assert all(getattr(p, "_tavsr_hooks_fence", False) for p in params[:-1]) and not params[-1]._tavsr_hooks_fence
+    assert ops.wgrad_may_go_beside(params[:-1]) and not ops.wgrad_may_go_beside(params)
+    foreign.remove()
     issued = []
     launch = buckets._launch_bucket_cpu
     buckets._launch_bucket_cpu = lambda i: (issued.append(i), launch(i))[1]
