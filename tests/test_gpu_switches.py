@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 ASR_SWITCHES = [("tavsr.ops", "FFN2", False), ("tavsr.ops", "FFN2_BWD", False), ("tavsr.ops", "MERGE_ROWS", False),
                 ("tavsr.ops", "MERGE_PROJ", False), ("tavsr.ops", "MERGE_ROWDOT", False), ("tavsr.ops", "LN_BWD_DROP", False), ("tavsr.ops", "LAYER_C", False),
-                ("tavsr.ops", "FFN2_BWD_LN", False), ("tavsr.ops", "WGRAD_BESIDE", False),
+                ("tavsr.ops", "FFN2_BWD_LN", False), ("tavsr.ops", "WGRAD_BESIDE", False), ("tavsr.functional", "_POS_DW_BESIDE", False),
                 ("tavsr.ops", "ATTN_FUSED", False), ("tavsr.ops", "CSGU_FUSED", False), ("tavsr.ops", "CSGU_STATS_IN_GEMM", False),
                 ("tavsr.ops", "CGMLP_ACT_BWD_FUSED", False), ("tavsr.functional", "CONV2_IMPLICIT", False),
                 ("tavsr.models.espnet_model", "LOSS_BRANCH", False), ("tavsr._lib", "SINGLE_STREAM", True)]
@@ -86,30 +86,32 @@ def test_every_route_selector_of_the_audio_only_step():
 def test_the_mask_preserving_routes_agree_under_dropout():
     """the fused launches draw the masks of the launches they replace (same Philox counters): also equal with dropout on"""
     _flip_and_compare("asr", [s for s in ASR_SWITCHES if s[1] in ("FFN2", "FFN2_BWD", "MERGE_PROJ", "MERGE_ROWDOT", "LN_BWD_DROP", "LAYER_C",
-                                                                   "FFN2_BWD_LN", "WGRAD_BESIDE", "CSGU_FUSED", "LOSS_BRANCH", "SINGLE_STREAM")], 0.1)
+                                                                   "FFN2_BWD_LN", "WGRAD_BESIDE", "_POS_DW_BESIDE", "CSGU_FUSED", "LOSS_BRANCH", "SINGLE_STREAM")], 0.1)
 
 
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_launch_scheduling_switches_do_not_change_a_bit(dropout):
-    """Two round-5 switches re-arrange launches without touching arithmetic: ``FFN2_BWD_LN`` (the feed-forward block's LayerNorm backward
+    """Round-5 switches that re-arrange launches without touching arithmetic: ``functional._POS_DW_BESIDE`` (the positional rows' gradient, ``linear_pos``'s
+    weight gradient and the two positional bias sums with the layer's other weight gradients), ``FFN2_BWD_LN`` (the feed-forward block's LayerNorm backward
     sums dn's partials in the order of the finishing launch it replaces) and ``WGRAD_BESIDE`` (the layers' weight gradients on the side
     queue, joined at the end of the autograd pass) - under the Python sequencing and the C-side sequencer alike: every gradient bit-equal."""
     from tavsr import ops
     model, batch, params = _model("asr", dropout)
     names = [n for n, _ in model.named_parameters()]
-    keep = (ops.LAYER_C, ops.FFN2_BWD_LN, ops.WGRAD_BESIDE)
+    from tavsr import functional as F_
+    keep = (ops.LAYER_C, ops.FFN2_BWD_LN, ops.WGRAD_BESIDE, F_._POS_DW_BESIDE)
     try:
         for layer_c in (False, True):
-            ops.LAYER_C, ops.FFN2_BWD_LN, ops.WGRAD_BESIDE = layer_c, True, True
+            ops.LAYER_C, ops.FFN2_BWD_LN, ops.WGRAD_BESIDE, F_._POS_DW_BESIDE = layer_c, True, True, True
             ref = _step(model, batch, params)
-            for ln, beside in ((False, True), (True, False), (False, False)):
-                ops.FFN2_BWD_LN, ops.WGRAD_BESIDE = ln, beside
+            for ln, beside, pos in ((False, True, True), (True, False, True), (False, False, True), (True, True, False)):
+                ops.FFN2_BWD_LN, ops.WGRAD_BESIDE, F_._POS_DW_BESIDE = ln, beside, pos      # (pos: the positional chain with the weight gradients)
                 got = _step(model, batch, params)
                 assert got[0] == ref[0]
                 bad = [n for n, a, b in zip(names, got[1], ref[1]) if not torch.equal(a, b)]
-                assert not bad, (layer_c, ln, beside, bad[:6])
+                assert not bad, (layer_c, ln, beside, pos, bad[:6])
     finally:
-        ops.LAYER_C, ops.FFN2_BWD_LN, ops.WGRAD_BESIDE = keep
+        ops.LAYER_C, ops.FFN2_BWD_LN, ops.WGRAD_BESIDE, F_._POS_DW_BESIDE = keep
 
 
 def test_every_route_selector_of_the_audio_visual_step():
